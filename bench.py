@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py - vectors scanned / second for the sqlite-vector hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c2|c3]
+
+Workload (BASELINE.json): configs[1] = 10M x 384 f32, L2, top-20, single query, corpus resident in HBM.
+A "step" is ONE complete query: upload the query, scan the whole shard, reduce to k candidates, bring the k keys
+back and decode them - i.e. what vector_full_scan's xFilter costs once the corpus is staged.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds its own row-range shard of the same
+size (weak scaling), each step = local scan -> all_gather of the per-shard candidate keys over RCCL/xGMI ->
+rank 0 merges.  value = rows scanned by ALL ranks / max-over-ranks time.
+
+The JSON line also carries
+  roofline     achieved HBM GB/s of the scan kernel = algorithmic bytes per launch (N*D*elem_size) /
+               mean kernel duration from HIP events recorded around the kernel on its own stream inside the
+               timed region (vg_set_profiling ring), against the 8 TB/s HBM3E peak.
+  cpu_baseline the reference's own kernel + top-k loop (oracle/_ref/libref_avx2.so, built from /root/reference by
+               oracle/Makefile) on ONE host core - the reference is single-threaded - over a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # name: (type enum, numpy dtype, dim, metric enum, description)
+    "c2": (1, np.float32, 384, 1, "10Mx384 f32 L2 top-20 single-query"),
+    "c3": (4, np.uint8, 768, 3, "10Mx768 u8 quantized cosine top-20 single-query"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU shard")
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    return ap.parse_args()
+
+
+def make_shard(pkg, torch, vt, dim, n_rows, seed, device):
+    """synthetic shard generated on the device in blocks and handed to the C-ABI as a raw device pointer"""
+    corpus = pkg.Corpus(vt, dim, device=device, capacity=n_rows)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    block = 1_000_000
+    es = pkg.TYPE_SIZE[vt]
+    for r0 in range(0, n_rows, block):
+        nr = min(block, n_rows - r0)
+        if vt == pkg.F32:
+            t = torch.randn((nr, dim), generator=gen, device="cuda", dtype=torch.float32)
+        else:
+            t = torch.randint(0, 256, (nr, dim), generator=gen, device="cuda", dtype=torch.uint8)
+        torch.cuda.synchronize()
+        corpus.append_device(t.data_ptr(), nr, dim * es)
+        del t
+    torch.cuda.empty_cache()
+    return corpus
+
+
+def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows):
+    """reference kernel + reference top-k loop, one core, bounded sample (about 10-30 s of CPU work)."""
+    from oracle import orc
+    rng = np.random.default_rng(42)
+    if vt == 1:
+        rows = rng.standard_normal((sample_rows, dim), dtype=np.float32)
+        q = rng.standard_normal(dim, dtype=np.float32)
+    else:
+        rows = rng.integers(0, 256, (sample_rows, dim), dtype=np.uint8)
+        q = rng.integers(0, 256, dim, dtype=np.uint8)
+    kind, runner = "port", None
+    if orc.have_ref():
+        ref = orc.RefKernels("avx2")
+        kind = "reference"
+        runner = lambda: ref.scan_topk(metric, vt, q, rows, k)           # noqa: E731
+        label = "oracle/_ref/libref_avx2.so (reference distance-avx2.c kernel via dispatch table, backend %s)" % ref.backend_name
+    else:
+        runner = lambda: orc.scan_topk_reference(orc.AVX2, metric, vt, q, rows, None, k)   # noqa: E731
+        label = "oracle/liboracle.so (C restatement, AVX2 order, scalar)"
+    runner()                                     # warm (page in)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        runner()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= 40:
+            break
+    return {"value": sample_rows * reps / el, "unit": "vectors/s", "cores": 1, "kind": kind,
+            "sample": "%d queries over a %dx%d %s sample, top-%d, %s; host has %d logical cores" %
+                      (reps, sample_rows, dim, np.dtype(np_dtype).name, k, label, os.cpu_count())}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    n_gpus = world if world > 1 else 1
+    if args.gpus != n_gpus and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
+
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    vt, np_dtype, dim, metric, desc = WORKLOADS[args.workload]
+    es = pkg.TYPE_SIZE[vt]
+    k = args.k
+    n_rows = args.rows
+
+    corpus = make_shard(pkg, torch, vt, dim, n_rows, 42 + rank, local_rank)
+    corpus.set_rowid_base(1 + rank * n_rows)
+    corpus.set_profiling(True)
+
+    # queries: a different one every step, pre-generated on the host
+    rng = np.random.default_rng(43)
+    nq = args.steps + args.warmup
+    if vt == pkg.F32:
+        queries = rng.standard_normal((nq, dim), dtype=np.float32)
+    else:
+        queries = rng.integers(0, 256, (nq, dim), dtype=np.uint8)
+
+    stream = torch.cuda.current_stream()
+    qpad = ((dim * es + 15) // 16) * 16
+    d_query = torch.zeros(qpad, dtype=torch.uint8, device="cuda")
+    h_query = torch.zeros(qpad, dtype=torch.uint8).pin_memory()
+    d_keys = torch.empty(64, dtype=torch.int64, device="cuda")
+    h_keys = torch.empty((n_gpus, 64), dtype=torch.int64).pin_memory()
+    d_all = torch.empty((n_gpus, 64), dtype=torch.int64, device="cuda") if world > 1 else None
+    offsets = [i * n_rows for i in range(n_gpus)]
+    last = {}
+
+    def step(i):
+        # query upload -> scan + candidate reduction on this shard -> (RCCL gather) -> k keys to the host -> merge
+        h_query[: dim * es] = torch.from_numpy(queries[i].view(np.uint8))
+        d_query.copy_(h_query, non_blocking=True)
+        corpus.scan_topk_device(metric, d_query.data_ptr(), k, d_keys.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_keys)
+            if rank == 0:
+                h_keys.copy_(d_all, non_blocking=True)
+        else:
+            h_keys[0].copy_(d_keys, non_blocking=True)
+        if rank == 0:
+            stream.synchronize()
+            pos, dd = pkg.merge_keys(h_keys.numpy().view(np.uint64), offsets, k)
+            last["pos"], last["dist"] = pos, dd
+
+    for i in range(args.warmup):
+        step(i)
+    corpus.set_profiling(True)                    # reset the event ring: only timed steps are averaged
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ts = time.perf_counter()
+        step(args.warmup + i)
+        lat.append(time.perf_counter() - ts)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_launch, scan_ms, merge_ms = corpus.profile_mean_ms()
+    if rank == 0:
+        total_rows = n_rows * n_gpus
+        algo_bytes = n_rows * dim * es                         # per launch (one shard), SURVEY 8d
+        achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+        out = {
+            "metric": "vectors scanned/sec, L2 top-20 over Nx384 f32" if args.workload == "c2" else
+                      "vectors scanned/sec, quantized cosine top-20 over Nx768 u8",
+            "value": total_rows * args.steps / elapsed,
+            "unit": "vectors/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "p50_query_latency_ms": float(np.median(lat) * 1e3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if vt == pkg.F32 else "u8", "data": "synthetic",
+            "config": {"workload": desc, "rows_per_gpu": n_rows, "dim": dim, "k": k,
+                       "sharding": "row-range shard per GPU, RCCL all_gather of 64 candidate keys per rank" if n_gpus > 1 else "single shard",
+                       "backend": pkg.backend_name()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": corpus.kernel_name(metric), "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms,
+                         "launches_timed": n_launch, "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(vt, np_dtype, dim, metric, k, args.cpu_sample_rows)
+            except Exception as e:                                        # the checker is optional on a bare box
+                out["cpu_baseline"] = {"value": None, "unit": "vectors/s", "cores": 0, "kind": "port",
+                                       "sample": "unavailable: %r" % (e,)}
+        print(json.dumps(out))
+    corpus.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,129 @@
+/*
+ * vectorgpu.h - C-ABI of the MI355X (gfx950) brute-force distance-scan + top-k engine.
+ *
+ * This is the drop-in boundary for sqlite-vector's hot path.  The SQLite extension host
+ * (sqlite-vector_amd/ext/vector_ext.c, plain C) keeps the reference's SQL surface and calls only the
+ * functions below; everything behind them is HIP.  Plain pointers and sizes, opaque handles, int return
+ * codes (0 = VG_OK); no C++/torch/SQLite types.  Citations are file:line under /root/reference/src/.
+ *
+ * What each entry point replaces in the reference:
+ *   vg_backend_name         distance_backend_name               distance-cpu.c:20, vector_backend() sqlite-vector.c:2549
+ *   vg_corpus_*             the per-query "SELECT pk, col FROM tbl" row stream      sqlite-vector.c:2077-2096
+ *                           and t_ctx->preloaded / precounter (quantized preload)   sqlite-vector.c:138-139, 1338-1404
+ *   vg_scan_topk            vcursor_run_callback + vcursor_sort_callback            sqlite-vector.c:183-184
+ *                           = vFullScanRun / vQuantRunMemory + vFullScanSortSlots   sqlite-vector.c:2071-2157, 2051-2069
+ *                           incl. dispatch_distance_table[metric][type]             distance-cpu.c:21, distance-cpu.h:60
+ *                           and the nearly_zero_float32 clamp                       sqlite-vector.c:994-996, 2099
+ *   vg_scan_distances       the per-row body of the *_stream cursors                sqlite-vector.c:1901-1998
+ *   vg_scan_topk_batch      (no reference entry point: Q independent vector_full_scan calls)
+ *   vg_quantize_query       quantize_float32/16/b16/u8/i8 on the query              sqlite-vector.c:2166-2177, 495-757
+ *
+ * Result contract (differs from the reference only where the reference is history-dependent):
+ *   - distances are the reference's float values (int8/uint8: bit-exact with distance-avx2.c; f32: <= 1e-5 rel);
+ *   - order is ascending (distance, scan position); NaN and +Inf distances never enter (strict '<' vs INFINITY
+ *     slots, sqlite-vector.c:1809,2102); fewer than k rows come back when fewer qualify (:1816-1817).
+ */
+#ifndef VECTORGPU_H
+#define VECTORGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* same numbering as the reference's enums, distance-cpu.h:36-58 */
+enum { VG_TYPE_F32 = 1, VG_TYPE_F16 = 2, VG_TYPE_BF16 = 3, VG_TYPE_U8 = 4, VG_TYPE_I8 = 5 };
+enum { VG_DIST_L2 = 1, VG_DIST_SQUARED_L2 = 2, VG_DIST_COSINE = 3, VG_DIST_DOT = 4, VG_DIST_L1 = 5 };
+enum { VG_QUANT_AUTO = 0, VG_QUANT_U8 = 1, VG_QUANT_S8 = 2 };
+
+enum {
+    VG_OK = 0,
+    VG_ERR_INVALID = 1,      /* bad argument */
+    VG_ERR_NO_DEVICE = 2,    /* no usable gfx950 device / HIP runtime failure at init */
+    VG_ERR_NOMEM = 3,        /* device or host allocation failed */
+    VG_ERR_HIP = 4,          /* any other HIP runtime error (see vg_last_error) */
+    VG_ERR_UNSUPPORTED = 5   /* valid request the engine does not implement (see vg_last_error) */
+};
+
+typedef struct vg_corpus vg_corpus;    /* one HBM-resident N x D matrix + host rowid map, on one device */
+
+/* ---- process / device ---- */
+int         vg_device_count(void);                 /* number of visible HIP devices (0 if none) */
+const char *vg_backend_name(void);                 /* "HIP gfx950" style string, static storage */
+const char *vg_last_error(void);                   /* thread-local message of the last failing call */
+
+/* ---- corpus staging ("stage once into HBM") ----
+ * Rows are stored row-major with a 16-byte-multiple stride (zero padded), base 256-byte aligned, in scan order.
+ * rowids == NULL means rowid = 1-based scan position (+ vg_corpus_set_rowid_base). */
+int     vg_corpus_create(int device, int vtype, int dim, int64_t capacity_rows_hint, vg_corpus **out);
+void    vg_corpus_destroy(vg_corpus *c);
+int     vg_corpus_clear(vg_corpus *c);
+int64_t vg_corpus_rows(const vg_corpus *c);
+int     vg_corpus_dim(const vg_corpus *c);
+int     vg_corpus_type(const vg_corpus *c);
+int     vg_corpus_device(const vg_corpus *c);
+int64_t vg_corpus_hbm_bytes(const vg_corpus *c);   /* bytes of HBM held by the row matrix */
+int     vg_corpus_set_rowid_base(vg_corpus *c, int64_t base);   /* implicit rowid = base + position (default 1) */
+
+/* host rows, any byte stride >= dim*elem_size (NULL rows in the SQL table are simply not appended, :2093) */
+int vg_corpus_append(vg_corpus *c, const void *host_rows, int64_t n_rows, int64_t row_stride_bytes,
+                     const int64_t *rowids);
+/* the reference's persisted/preloaded quantized format: n records of [int64 LE rowid][dim bytes], stride 8+dim
+ * (sqlite-vector.c:1296-1309, 2127-2147).  Corpus type must be U8 or I8.  De-interleaved on the GPU. */
+int vg_corpus_append_records(vg_corpus *c, const void *host_records, int64_t n_records);
+/* rows already in device memory (same device), e.g. produced by another kernel / a torch tensor */
+int vg_corpus_append_device(vg_corpus *c, const void *dev_rows, int64_t n_rows, int64_t row_stride_bytes,
+                            const int64_t *host_rowids);
+
+/* ---- the hot path ---- */
+/* One query (dim elements of the corpus type, host memory) -> the k best rows.
+ * out_rowids[k], out_dist[k] (float values widened to double, like vFullScanCursor.distance), *out_count <= k. */
+int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k,
+                 int64_t *out_rowids, double *out_dist, int *out_count);
+
+/* Same scan, but the k candidates stay on the device as packed 64-bit keys
+ * (hi 32 = order-preserving image of the float distance, lo 32 = scan position), ascending, padded with
+ * VG_KEY_EMPTY.  dev_query / dev_out_keys are device pointers; stream is a hipStream_t (NULL = corpus stream).
+ * No host synchronisation: this is what one rank of a row-sharded multi-GPU scan runs before the candidate
+ * gather (RCCL) and what bench.py times. */
+int vg_scan_topk_device(vg_corpus *c, int metric, const void *dev_query, int k,
+                        uint64_t *dev_out_keys, void *stream);
+#define VG_KEY_EMPTY 0xFFFFFFFFFFFFFFFFull
+/* decode / merge helpers for gathered keys (host side, tiny): */
+float   vg_key_distance(uint64_t key);
+uint32_t vg_key_position(uint64_t key);
+/* k-way merge of n_lists key lists (each list_len long, ascending, VG_KEY_EMPTY padded), list i's positions are
+ * offset by pos_offsets[i] (NULL = 0) to form global scan positions; ties broken by (list index, position) which
+ * equals global scan position order for row-range shards.  Returns count written (<= k). */
+int vg_merge_keys(const uint64_t *keys, int n_lists, int list_len, const int64_t *pos_offsets, int k,
+                  int64_t *out_global_pos, double *out_dist);
+
+/* All N distances in scan order (clamp applied), for the *_stream table-valued functions. */
+int vg_scan_distances(vg_corpus *c, int metric, const void *query, float *out_dist_host);
+int vg_scan_distances_device(vg_corpus *c, int metric, const void *dev_query, float *dev_out_dist, void *stream);
+/* rowid of a scan position (host map) */
+int64_t vg_corpus_rowid_at(const vg_corpus *c, int64_t position);
+
+/* nq queries at once (row-major nq x dim, host).  out_rowids / out_dist are nq x k, out_counts nq. */
+int vg_scan_topk_batch(vg_corpus *c, int metric, const void *queries, int nq, int k,
+                       int64_t *out_rowids, double *out_dist, int *out_counts);
+
+/* ---- query-side quantizer (host, bit-exact with sqlite-vector.c:495-757) ---- */
+int vg_quantize_query(int src_type, const void *src, int dim, float scale, float offset, int qtype, void *dst);
+
+/* ---- instrumentation ---- */
+/* When enabled, every scan records HIP events around its kernels on the stream they run on (a ring of 1024
+ * launches, no host synchronisation at launch time).  Enabling resets the launch counter. */
+int vg_set_profiling(vg_corpus *c, int enabled);
+/* milliseconds of the last scan's kernels: scan (dominant, HBM-bound) and merge (candidate reduction). */
+int vg_last_kernel_ms(vg_corpus *c, float *scan_ms, float *merge_ms);
+/* mean kernel milliseconds over the launches recorded since profiling was enabled (at most the last 1024) */
+int vg_profile_mean_ms(vg_corpus *c, int *n_launches, float *scan_ms, float *merge_ms);
+/* name of the scan kernel variant chosen for (metric) on this corpus, e.g. "scan_f32_l2_u6_lpr16" */
+const char *vg_scan_kernel_name(vg_corpus *c, int metric);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -764,6 +764,26 @@ int orc_scan_topk_reference(int backend, int metric, int type, const void *query
     return k - sort_slots(out_dist, out_rowids, k);
 }
 
+int orc_scan_topk_with_fn(orc_distance_fn fn, const void *query, const void *rows, int64_t n_rows,
+                          int64_t row_stride_bytes, int dim, const int64_t *rowids, int k,
+                          int64_t *out_rowids, double *out_dist) {
+    if (k <= 0) return 0;
+    const uint8_t *p = (const uint8_t *)rows;
+    for (int i = 0; i < k; ++i) { out_rowids[i] = 0; out_dist[i] = INFINITY; }
+    int worst = 0;
+    double cur = out_dist[worst];
+    for (int64_t r = 0; r < n_rows; ++r) {
+        float d = orc_clamp(fn(query, p + r * row_stride_bytes, dim));
+        if (d < cur) {
+            out_dist[worst] = d;
+            out_rowids[worst] = rowids ? rowids[r] : (r + 1);
+            worst = first_max(out_dist, k);
+            cur = out_dist[worst];
+        }
+    }
+    return k - sort_slots(out_dist, out_rowids, k);
+}
+
 /* ------------------------------------------------------------------ quantizer */
 
 /* (int)float as x86 cvttss2si does it: out-of-range / NaN -> INT_MIN (the f32 path at

@@ -51,6 +51,9 @@ def _lib():
     lib.orc_scan_topk_reference.restype = C.c_int
     lib.orc_scan_topk_reference.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.orc_scan_topk_with_fn.restype = C.c_int
+    lib.orc_scan_topk_with_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                                          C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.orc_quantize.restype = None
     lib.orc_quantize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int]
     lib.orc_quant_params.restype = None
@@ -196,6 +199,17 @@ class RefKernels:
         a = np.ascontiguousarray(a)
         b = np.ascontiguousarray(b)
         return float(self.table[metric][vtype](_ptr(a), _ptr(b), a.shape[0]))
+
+    def scan_topk(self, metric, vtype, query, rows, k):
+        """the reference's kernel (function pointer out of its dispatch table) inside the reference's top-k loop"""
+        rows = np.ascontiguousarray(rows)
+        query = np.ascontiguousarray(query)
+        fnptr = C.cast(self.table[metric][vtype], C.c_void_p)
+        out_ids = np.zeros(max(k, 1), dtype=np.int64)
+        out_d = np.zeros(max(k, 1), dtype=np.float64)
+        cnt = lib().orc_scan_topk_with_fn(fnptr, _ptr(query), _ptr(rows), rows.shape[0], rows.strides[0],
+                                          rows.shape[1], None, k, _ptr(out_ids), _ptr(out_d))
+        return out_ids[:cnt], out_d[:cnt]
 
     def scan(self, metric, vtype, query, rows):
         rows = np.ascontiguousarray(rows)

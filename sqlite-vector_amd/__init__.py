@@ -1,0 +1,205 @@
+"""sqlite-vector_amd: MI355X-native brute-force distance scan + top-k behind sqlite-vector's SQL surface.
+
+This Python module is plumbing only: it builds and loads the two native artefacts and exposes a thin ctypes
+view of the C-ABI (include/vectorgpu.h) for tests and bench.py.  The product is
+
+    libvectorgpu.so   HIP kernels + C-ABI                     (csrc/*.hip, hipcc --offload-arch=gfx950)
+    vector.so         the SQLite loadable extension, plain C  (ext/vector_ext.c; exports sqlite3_vector_init)
+
+Nothing here computes a distance: without the HIP library / a GPU every call raises.  The package never imports
+anything from oracle/ (that is test infrastructure).
+
+The directory name contains a '-', so load it with importlib (see __graft_entry__.load_package) or put the repo
+root on sys.path and use importlib.import_module("sqlite-vector_amd").
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvectorgpu.so")
+EXT_PATH = os.path.join(HERE, "vector.so")         # must be named vector.* (entry point sqlite3_vector_init)
+
+# enums (same numbering as the reference, distance-cpu.h:36-58)
+F32, F16, BF16, U8, I8 = 1, 2, 3, 4, 5
+L2, SQUARED_L2, COSINE, DOT, L1 = 1, 2, 3, 4, 5
+QUANT_U8, QUANT_S8 = 1, 2
+KEY_EMPTY = 0xFFFFFFFFFFFFFFFF
+TYPE_SIZE = {F32: 4, F16: 2, BF16: 2, U8: 1, I8: 1}
+
+
+class VectorGpuError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libvectorgpu.so (fails loudly if it has not been built: there is no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VectorGpuError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    sig = {
+        "vg_device_count": (i32, []),
+        "vg_backend_name": (C.c_char_p, []),
+        "vg_last_error": (C.c_char_p, []),
+        "vg_corpus_create": (i32, [i32, i32, i32, i64, C.POINTER(vp)]),
+        "vg_corpus_destroy": (None, [vp]),
+        "vg_corpus_clear": (i32, [vp]),
+        "vg_corpus_rows": (i64, [vp]),
+        "vg_corpus_dim": (i32, [vp]),
+        "vg_corpus_type": (i32, [vp]),
+        "vg_corpus_device": (i32, [vp]),
+        "vg_corpus_hbm_bytes": (i64, [vp]),
+        "vg_corpus_set_rowid_base": (i32, [vp, i64]),
+        "vg_corpus_append": (i32, [vp, vp, i64, i64, vp]),
+        "vg_corpus_append_records": (i32, [vp, vp, i64]),
+        "vg_corpus_append_device": (i32, [vp, vp, i64, i64, vp]),
+        "vg_scan_topk": (i32, [vp, i32, vp, i32, vp, vp, C.POINTER(i32)]),
+        "vg_scan_topk_device": (i32, [vp, i32, vp, i32, vp, vp]),
+        "vg_key_distance": (C.c_float, [C.c_uint64]),
+        "vg_key_position": (C.c_uint32, [C.c_uint64]),
+        "vg_merge_keys": (i32, [vp, i32, i32, vp, i32, vp, vp]),
+        "vg_scan_distances": (i32, [vp, i32, vp, vp]),
+        "vg_scan_distances_device": (i32, [vp, i32, vp, vp, vp]),
+        "vg_corpus_rowid_at": (i64, [vp, i64]),
+        "vg_scan_topk_batch": (i32, [vp, i32, vp, i32, i32, vp, vp, vp]),
+        "vg_quantize_query": (i32, [i32, vp, i32, C.c_float, C.c_float, i32, vp]),
+        "vg_set_profiling": (i32, [vp, i32]),
+        "vg_last_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "vg_profile_mean_ms": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "vg_scan_kernel_name": (C.c_char_p, [vp, i32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    L._sig = sig
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise VectorGpuError("vectorgpu error %d: %s" % (rc, lib().vg_last_error().decode()))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return lib().vg_device_count()
+
+
+def backend_name():
+    return lib().vg_backend_name().decode()
+
+
+class Corpus:
+    """One HBM-resident corpus shard (opaque vg_corpus handle)."""
+
+    def __init__(self, vtype, dim, device=0, capacity=0):
+        self.h = C.c_void_p()
+        self.vtype, self.dim = vtype, dim
+        _check(lib().vg_corpus_create(device, vtype, dim, capacity, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().vg_corpus_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    @property
+    def rows(self):
+        return lib().vg_corpus_rows(self.h)
+
+    def append(self, rows, rowids=None):
+        rows = np.ascontiguousarray(rows)
+        assert rows.ndim == 2 and rows.shape[1] * rows.itemsize >= self.dim * TYPE_SIZE[self.vtype]
+        ids = None if rowids is None else np.ascontiguousarray(rowids, dtype=np.int64)
+        _check(lib().vg_corpus_append(self.h, _ptr(rows), rows.shape[0], rows.strides[0], _ptr(ids)))
+
+    def append_strided(self, buf, n_rows, stride, rowids=None):
+        buf = np.ascontiguousarray(buf)
+        ids = None if rowids is None else np.ascontiguousarray(rowids, dtype=np.int64)
+        _check(lib().vg_corpus_append(self.h, _ptr(buf), n_rows, stride, _ptr(ids)))
+
+    def append_records(self, records, n):
+        records = np.ascontiguousarray(records)
+        _check(lib().vg_corpus_append_records(self.h, _ptr(records), n))
+
+    def append_device(self, dev_ptr, n_rows, stride, rowids=None):
+        ids = None if rowids is None else np.ascontiguousarray(rowids, dtype=np.int64)
+        _check(lib().vg_corpus_append_device(self.h, C.c_void_p(dev_ptr), n_rows, stride, _ptr(ids)))
+
+    def set_rowid_base(self, base):
+        _check(lib().vg_corpus_set_rowid_base(self.h, base))
+
+    def scan_topk(self, metric, query, k):
+        query = np.ascontiguousarray(query)
+        ids = np.zeros(max(k, 1), dtype=np.int64)
+        dist = np.zeros(max(k, 1), dtype=np.float64)
+        cnt = C.c_int(0)
+        _check(lib().vg_scan_topk(self.h, metric, _ptr(query), k, _ptr(ids), _ptr(dist), C.byref(cnt)))
+        return ids[:cnt.value], dist[:cnt.value]
+
+    def scan_topk_device(self, metric, dev_query_ptr, k, dev_keys_ptr, stream=None):
+        _check(lib().vg_scan_topk_device(self.h, metric, C.c_void_p(dev_query_ptr), k, C.c_void_p(dev_keys_ptr),
+                                         C.c_void_p(stream) if stream else None))
+
+    def scan_distances(self, metric, query):
+        query = np.ascontiguousarray(query)
+        out = np.empty(self.rows, dtype=np.float32)
+        _check(lib().vg_scan_distances(self.h, metric, _ptr(query), _ptr(out)))
+        return out
+
+    def scan_topk_batch(self, metric, queries, k):
+        queries = np.ascontiguousarray(queries)
+        nq = queries.shape[0]
+        ids = np.zeros((nq, max(k, 1)), dtype=np.int64)
+        dist = np.zeros((nq, max(k, 1)), dtype=np.float64)
+        cnt = np.zeros(nq, dtype=np.int32)
+        _check(lib().vg_scan_topk_batch(self.h, metric, _ptr(queries), nq, k, _ptr(ids), _ptr(dist), _ptr(cnt)))
+        return ids, dist, cnt
+
+    def set_profiling(self, on=True):
+        _check(lib().vg_set_profiling(self.h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        _check(lib().vg_last_kernel_ms(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def profile_mean_ms(self):
+        n, a, b = C.c_int(0), C.c_float(0), C.c_float(0)
+        _check(lib().vg_profile_mean_ms(self.h, C.byref(n), C.byref(a), C.byref(b)))
+        return n.value, a.value, b.value
+
+    def kernel_name(self, metric):
+        return lib().vg_scan_kernel_name(self.h, metric).decode()
+
+
+def quantize_query(src_type, src, scale, offset, qtype):
+    src = np.ascontiguousarray(src)
+    dst = np.empty(src.shape[0], dtype=np.uint8 if qtype == QUANT_U8 else np.int8)
+    _check(lib().vg_quantize_query(src_type, _ptr(src), src.shape[0], scale, offset, qtype, _ptr(dst)))
+    return dst
+
+
+def merge_keys(keys, pos_offsets, k):
+    """keys: (n_lists, list_len) uint64 array of per-shard candidate lists -> (global positions, distances)."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    n_lists, list_len = keys.shape
+    off = None if pos_offsets is None else np.ascontiguousarray(pos_offsets, dtype=np.int64)
+    pos = np.zeros(max(k, 1), dtype=np.int64)
+    dist = np.zeros(max(k, 1), dtype=np.float64)
+    cnt = lib().vg_merge_keys(_ptr(keys), n_lists, list_len, _ptr(off), k, _ptr(pos), _ptr(dist))
+    return pos[:cnt], dist[:cnt]

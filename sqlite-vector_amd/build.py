@@ -1,0 +1,87 @@
+"""In-tree native build for the MI355X scan path.
+
+    libvectorgpu.so : hipcc --offload-arch=gfx950 over csrc/*.hip     (HIP kernels + C-ABI)
+    vector.so       : gcc over ext/vector_ext.c                       (SQLite loadable extension, plain C)
+
+hipcc cross-compiles without a GPU.  The extension needs SQLite's public headers (sqlite3ext.h): they are taken
+from a system include dir or from the reference tree's vendored, unmodified copy (/root/reference/libs) at build
+time only - never copied into this repository.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+EXT = os.path.join(HERE, "ext")
+LIB = os.path.join(HERE, "libvectorgpu.so")
+VEC = os.path.join(HERE, "vector.so")
+
+HIP_SOURCES = ["vg_api.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm to build the gfx950 kernels)")
+
+
+def build_gpu_library(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(ROOT, "include", "vectorgpu.h")]
+    if not force and not _newer(LIB, deps):
+        return LIB
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+def sqlite_include_dir():
+    for d in ("/usr/include", "/usr/local/include", "/root/reference/libs"):
+        if os.path.exists(os.path.join(d, "sqlite3ext.h")) and os.path.exists(os.path.join(d, "sqlite3.h")):
+            return d
+    return None
+
+
+def build_extension(force=False, verbose=False):
+    src = os.path.join(EXT, "vector_ext.c")
+    if not os.path.exists(src):
+        return None
+    deps = [src, os.path.join(ROOT, "include", "vectorgpu.h")]
+    if not force and not _newer(VEC, deps):
+        return VEC
+    inc = sqlite_include_dir()
+    if inc is None:
+        if os.path.exists(VEC):
+            return VEC            # prebuilt artefact travelled here (GPU box): keep it
+        raise RuntimeError("sqlite3ext.h not found: cannot build the SQLite extension host")
+    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-parameter",
+           "-I" + inc, "-I" + os.path.join(ROOT, "include"), "-o", VEC, src, "-ldl", "-lm"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return VEC
+
+
+def build_all(force=False, verbose=False):
+    build_gpu_library(force, verbose)
+    build_extension(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,747 @@
+// vg_api.hip - implementation of the C-ABI in include/vectorgpu.h on top of the gfx950 kernels.
+//
+// Host-side responsibilities only: device memory for the staged corpus, query upload, kernel selection and
+// launch, decoding the k winning keys into (rowid, distance).  No distance is ever computed on the host: if
+// the HIP runtime / a gfx950 device is missing every entry point fails with VG_ERR_NO_DEVICE.
+#include "../../include/vectorgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vg_scan.h"
+
+#define VG_PROF_RING 1024
+
+// ------------------------------------------------------------------------------------------------ errors
+
+static thread_local std::string g_err;
+
+static int vg_fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess)                                                                            \
+            return vg_fail(e__ == hipErrorOutOfMemory ? VG_ERR_NOMEM : VG_ERR_HIP, "%s failed: %s (%s:%d)", \
+                           #expr, hipGetErrorString(e__), __FILE__, __LINE__);                            \
+    } while (0)
+
+extern "C" const char *vg_last_error(void) { return g_err.c_str(); }
+
+extern "C" int vg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *vg_backend_name(void) {
+    static char name[128] = {0};
+    if (name[0]) return name;
+    int n = vg_device_count();
+    if (n <= 0) {
+        snprintf(name, sizeof(name), "HIP (no device)");
+        return name;
+    }
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, 0) == hipSuccess) {
+        char arch[64];
+        snprintf(arch, sizeof(arch), "%s", p.gcnArchName);
+        char *colon = strchr(arch, ':');
+        if (colon) *colon = 0;
+        snprintf(name, sizeof(name), "HIP %s x%d", arch, n);
+    } else {
+        snprintf(name, sizeof(name), "HIP");
+    }
+    return name;
+}
+
+// ------------------------------------------------------------------------------------------------ corpus
+
+static int elem_size(int vtype) {
+    switch (vtype) {
+        case VG_TYPE_F32: return 4;
+        case VG_TYPE_F16: case VG_TYPE_BF16: return 2;
+        case VG_TYPE_U8: case VG_TYPE_I8: return 1;
+    }
+    return 0;
+}
+
+struct vg_corpus {
+    int device = 0;
+    int vtype = 0;
+    int dim = 0;
+    int es = 0;
+    int nch = 0;               // 16-byte chunks per stored row
+    int64_t stride = 0;        // bytes per stored row (nch * 16)
+    int64_t n_rows = 0;
+    int64_t cap_rows = 0;
+    uint8_t *d_rows = nullptr;
+    std::vector<int64_t> rowids;   // empty => implicit rowid_base + position
+    int64_t rowid_base = 1;
+
+    hipStream_t stream = nullptr;
+    uint8_t *d_query = nullptr;    // nch*16 bytes
+    uint8_t *h_query = nullptr;    // pinned
+    uint64_t *d_cand = nullptr;    // max_blocks * 64 keys
+    uint64_t *d_keys = nullptr;    // 64 keys
+    uint64_t *h_keys = nullptr;    // pinned, 64 keys
+    float *d_dist = nullptr;       // lazily sized to n_rows (stream scans / large k)
+    int64_t d_dist_cap = 0;
+    int max_blocks = 0;
+    int cu_count = 0;
+
+    // instrumentation: a ring of event triples (before scan | after scan | after merge), recorded on the stream
+    // each launch runs on, read back only when asked - no host synchronisation inside a timed region
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;            // 3 * VG_PROF_RING events, created on first enable
+    std::vector<uint8_t> ev_had_merge;
+    long long prof_launches = 0;           // launches recorded since profiling was (re)enabled
+    float last_scan_ms = 0.f, last_merge_ms = 0.f;
+    char kernel_name[64] = {0};
+};
+
+static int env_int(const char *name, int dflt) {
+    const char *s = getenv(name);
+    if (!s || !*s) return dflt;
+    return atoi(s);
+}
+
+extern "C" int vg_corpus_create(int device, int vtype, int dim, int64_t capacity_rows_hint, vg_corpus **out) {
+    if (!out) return vg_fail(VG_ERR_INVALID, "vg_corpus_create: out is NULL");
+    *out = nullptr;
+    int es = elem_size(vtype);
+    if (es == 0) return vg_fail(VG_ERR_INVALID, "vg_corpus_create: unknown vector type %d", vtype);
+    if (dim <= 0) return vg_fail(VG_ERR_INVALID, "vg_corpus_create: dimension must be positive (got %d)", dim);
+    int ndev = vg_device_count();
+    if (ndev <= 0) return vg_fail(VG_ERR_NO_DEVICE, "no HIP device available (the scan path is GPU-only)");
+    if (device < 0 || device >= ndev) return vg_fail(VG_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+    int64_t row_bytes = (int64_t)dim * es;
+    if (row_bytes > 64 * 1024) return vg_fail(VG_ERR_UNSUPPORTED, "rows larger than 64 KiB are not supported (dim=%d)", dim);
+    HIP_TRY(hipSetDevice(device));
+    vg_corpus *c = new vg_corpus();
+    c->device = device;
+    c->vtype = vtype;
+    c->dim = dim;
+    c->es = es;
+    c->nch = (int)((row_bytes + 15) / 16);
+    c->stride = (int64_t)c->nch * 16;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) { delete c; return vg_fail(VG_ERR_HIP, "hipGetDeviceProperties failed"); }
+    c->cu_count = p.multiProcessorCount;
+    c->max_blocks = c->cu_count * 8;
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc(&c->d_query, (size_t)c->stride)) != hipSuccess ||
+        (e = hipHostMalloc(&c->h_query, (size_t)c->stride)) != hipSuccess ||
+        (e = hipMalloc(&c->d_cand, (size_t)c->max_blocks * VG_WAVE * sizeof(uint64_t))) != hipSuccess ||
+        (e = hipMalloc(&c->d_keys, VG_WAVE * sizeof(uint64_t))) != hipSuccess ||
+        (e = hipHostMalloc(&c->h_keys, VG_WAVE * sizeof(uint64_t))) != hipSuccess) {
+        vg_corpus_destroy(c);
+        return vg_fail(VG_ERR_HIP, "vg_corpus_create: device setup failed: %s", hipGetErrorString(e));
+    }
+    if (capacity_rows_hint > 0) {
+        e = hipMalloc(&c->d_rows, (size_t)(capacity_rows_hint * c->stride));
+        if (e != hipSuccess) {
+            vg_corpus_destroy(c);
+            return vg_fail(VG_ERR_NOMEM, "vg_corpus_create: cannot allocate %lld bytes of HBM: %s",
+                           (long long)(capacity_rows_hint * c->stride), hipGetErrorString(e));
+        }
+        c->cap_rows = capacity_rows_hint;
+    }
+    *out = c;
+    return VG_OK;
+}
+
+extern "C" void vg_corpus_destroy(vg_corpus *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->d_rows) hipFree(c->d_rows);
+    if (c->d_query) hipFree(c->d_query);
+    if (c->h_query) hipHostFree(c->h_query);
+    if (c->d_cand) hipFree(c->d_cand);
+    if (c->d_keys) hipFree(c->d_keys);
+    if (c->h_keys) hipHostFree(c->h_keys);
+    if (c->d_dist) hipFree(c->d_dist);
+    for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int vg_corpus_clear(vg_corpus *c) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    c->n_rows = 0;
+    c->rowids.clear();
+    return VG_OK;
+}
+
+extern "C" int64_t vg_corpus_rows(const vg_corpus *c) { return c ? c->n_rows : 0; }
+extern "C" int vg_corpus_dim(const vg_corpus *c) { return c ? c->dim : 0; }
+extern "C" int vg_corpus_type(const vg_corpus *c) { return c ? c->vtype : 0; }
+extern "C" int vg_corpus_device(const vg_corpus *c) { return c ? c->device : -1; }
+extern "C" int64_t vg_corpus_hbm_bytes(const vg_corpus *c) { return c ? c->cap_rows * c->stride : 0; }
+extern "C" int vg_corpus_set_rowid_base(vg_corpus *c, int64_t base) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    c->rowid_base = base;
+    return VG_OK;
+}
+extern "C" int64_t vg_corpus_rowid_at(const vg_corpus *c, int64_t position) {
+    if (!c || position < 0 || position >= c->n_rows) return 0;
+    return c->rowids.empty() ? c->rowid_base + position : c->rowids[(size_t)position];
+}
+
+static int corpus_reserve(vg_corpus *c, int64_t need_rows) {
+    if (need_rows <= c->cap_rows) return VG_OK;
+    if (need_rows >= (1ll << 32)) return vg_fail(VG_ERR_UNSUPPORTED, "a corpus shard holds at most 2^32-1 rows");
+    int64_t new_cap = std::max<int64_t>(need_rows, c->cap_rows + c->cap_rows / 2);
+    new_cap = std::max<int64_t>(new_cap, 1024);
+    uint8_t *nb = nullptr;
+    HIP_TRY(hipMalloc(&nb, (size_t)(new_cap * c->stride)));
+    if (c->n_rows > 0) {
+        hipError_t e = hipMemcpyAsync(nb, c->d_rows, (size_t)(c->n_rows * c->stride), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(nb); return vg_fail(VG_ERR_HIP, "corpus grow copy failed: %s", hipGetErrorString(e)); }
+    }
+    if (c->d_rows) hipFree(c->d_rows);
+    c->d_rows = nb;
+    c->cap_rows = new_cap;
+    return VG_OK;
+}
+
+static void note_rowids(vg_corpus *c, const int64_t *rowids, int64_t n) {
+    if (rowids) {
+        if (c->rowids.empty() && c->n_rows > 0) {
+            c->rowids.resize((size_t)c->n_rows);
+            for (int64_t i = 0; i < c->n_rows; ++i) c->rowids[(size_t)i] = c->rowid_base + i;
+        }
+        c->rowids.insert(c->rowids.end(), rowids, rowids + n);
+    } else if (!c->rowids.empty()) {
+        for (int64_t i = 0; i < n; ++i) c->rowids.push_back(c->rowid_base + c->n_rows + i);
+    }
+}
+
+// De-interleave / pad: src rows (byte stride src_stride, payload at src_off, row_bytes long) -> 16-byte-multiple
+// rows.  One thread per destination 16-byte chunk; byte gathers because the source is arbitrarily aligned
+// (the reference's quantized records have a stride of 8+dim).
+__global__ void vg_repack_kernel(const uint8_t *src, long long src_stride, int src_off, int row_bytes,
+                                 uint8_t *dst, long long dst_stride, int nch, long long n_rows) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = n_rows * nch;
+    if (t >= total) return;
+    long long r = t / nch;
+    int ch = (int)(t - r * nch);
+    const uint8_t *s = src + r * src_stride + src_off + (long long)ch * 16;
+    int remain = row_bytes - ch * 16;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (remain >= 16 && ((reinterpret_cast<uintptr_t>(s) & 3) == 0)) {
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(s);
+        w[0] = s4[0]; w[1] = s4[1]; w[2] = s4[2]; w[3] = s4[3];
+    } else {
+        int nb = remain < 16 ? remain : 16;
+        for (int j = 0; j < nb; ++j) w[j >> 2] |= (uint32_t)s[j] << ((j & 3) * 8);
+    }
+    *reinterpret_cast<uint4 *>(dst + r * dst_stride + (long long)ch * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// copies [n_rows x src_stride] host or device bytes into the padded matrix at the current end of the corpus
+static int append_impl(vg_corpus *c, const void *src, bool src_on_device, int64_t n_rows, int64_t src_stride,
+                       int src_off) {
+    const int64_t row_bytes = (int64_t)c->dim * c->es;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = corpus_reserve(c, c->n_rows + n_rows);
+    if (rc != VG_OK) return rc;
+    uint8_t *dst = c->d_rows + c->n_rows * c->stride;
+    if (src_off == 0 && src_stride == c->stride) {
+        HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(n_rows * c->stride),
+                               src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return VG_OK;
+    }
+    // staged path: bounded pieces through a device staging buffer, then the repack kernel
+    const int64_t piece_rows = std::max<int64_t>(1, (256ll << 20) / src_stride);
+    uint8_t *stage = nullptr;
+    if (!src_on_device) HIP_TRY(hipMalloc(&stage, (size_t)(std::min(piece_rows, n_rows) * src_stride)));
+    for (int64_t r0 = 0; r0 < n_rows; r0 += piece_rows) {
+        int64_t nr = std::min(piece_rows, n_rows - r0);
+        const uint8_t *s = (const uint8_t *)src + r0 * src_stride;
+        const uint8_t *dsrc = s;
+        if (!src_on_device) {
+            // the last row may be shorter than the stride in the caller's buffer: copy only what is addressable
+            size_t bytes = (size_t)((nr - 1) * src_stride + src_off + row_bytes);
+            hipError_t e = hipMemcpyAsync(stage, s, bytes, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) { hipFree(stage); return vg_fail(VG_ERR_HIP, "H2D staging copy failed: %s", hipGetErrorString(e)); }
+            dsrc = stage;
+        }
+        long long total = nr * c->nch;
+        int threads = 256;
+        long long blocks = (total + threads - 1) / threads;
+        hipLaunchKernelGGL(vg_repack_kernel, dim3((unsigned)blocks), dim3(threads), 0, c->stream, dsrc, (long long)src_stride,
+                           src_off, (int)row_bytes, dst + r0 * c->stride, (long long)c->stride, c->nch, (long long)nr);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { if (stage) hipFree(stage); return vg_fail(VG_ERR_HIP, "repack failed: %s", hipGetErrorString(e)); }
+    }
+    if (stage) hipFree(stage);
+    return VG_OK;
+}
+
+extern "C" int vg_corpus_append(vg_corpus *c, const void *host_rows, int64_t n_rows, int64_t row_stride_bytes,
+                                const int64_t *rowids) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    if (n_rows == 0) return VG_OK;
+    if (!host_rows || n_rows < 0) return vg_fail(VG_ERR_INVALID, "vg_corpus_append: bad rows pointer / count");
+    if (row_stride_bytes < (int64_t)c->dim * c->es) return vg_fail(VG_ERR_INVALID, "vg_corpus_append: stride %lld smaller than a row (%lld bytes)", (long long)row_stride_bytes, (long long)c->dim * c->es);
+    int rc = append_impl(c, host_rows, false, n_rows, row_stride_bytes, 0);
+    if (rc != VG_OK) return rc;
+    note_rowids(c, rowids, n_rows);
+    c->n_rows += n_rows;
+    return VG_OK;
+}
+
+extern "C" int vg_corpus_append_device(vg_corpus *c, const void *dev_rows, int64_t n_rows, int64_t row_stride_bytes,
+                                       const int64_t *host_rowids) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    if (n_rows == 0) return VG_OK;
+    if (!dev_rows || n_rows < 0) return vg_fail(VG_ERR_INVALID, "vg_corpus_append_device: bad rows pointer / count");
+    if (row_stride_bytes < (int64_t)c->dim * c->es) return vg_fail(VG_ERR_INVALID, "vg_corpus_append_device: stride smaller than a row");
+    int rc = append_impl(c, dev_rows, true, n_rows, row_stride_bytes, 0);
+    if (rc != VG_OK) return rc;
+    note_rowids(c, host_rowids, n_rows);
+    c->n_rows += n_rows;
+    return VG_OK;
+}
+
+extern "C" int vg_corpus_append_records(vg_corpus *c, const void *host_records, int64_t n_records) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    if (c->vtype != VG_TYPE_U8 && c->vtype != VG_TYPE_I8) return vg_fail(VG_ERR_INVALID, "vg_corpus_append_records: corpus must be UINT8 or INT8");
+    if (n_records == 0) return VG_OK;
+    if (!host_records || n_records < 0) return vg_fail(VG_ERR_INVALID, "vg_corpus_append_records: bad pointer / count");
+    const int64_t rec = 8 + (int64_t)c->dim;
+    int rc = append_impl(c, host_records, false, n_records, rec, 8);
+    if (rc != VG_OK) return rc;
+    // rowids: little-endian int64 in front of every record (sqlite-vector.c:86-94, INT64_FROM_INT8PTR)
+    std::vector<int64_t> ids((size_t)n_records);
+    const uint8_t *p = (const uint8_t *)host_records;
+    for (int64_t i = 0; i < n_records; ++i) {
+        const uint8_t *q = p + i * rec;
+        uint64_t v = 0;
+        for (int b = 0; b < 8; ++b) v |= (uint64_t)q[b] << (8 * b);
+        ids[(size_t)i] = (int64_t)v;
+    }
+    note_rowids(c, ids.data(), n_records);
+    c->n_rows += n_records;
+    return VG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ kernel selection
+
+typedef void (*scan_fn_t)(ScanArgs);
+
+struct Shape { int lpr_log2; int U; };
+
+static const int kAllowedU[] = {1, 2, 3, 4, 6, 8};
+
+// Pick (lanes per row, chunks per lane): cover nch chunks with lpr*U slots, wasting as few lane slots as
+// possible; prefer >= 128 contiguous bytes per row per load instruction, then U = 6/4/3 (bytes in flight per lane).
+static bool choose_shape(int nch, Shape *out) {
+    static const int pref[9] = {0, 1, 2, 4, 5, 0, 6, 0, 3};   // preference rank by U (higher is better)
+    double best_eff = -1.0; int best_flag = -1, best_pref = -1; Shape best = {0, 0};
+    for (int l2 = 0; l2 <= 6; ++l2) {
+        int lpr = 1 << l2;
+        int need = (nch + lpr - 1) / lpr;
+        int U = 0;
+        for (int a : kAllowedU) if (a >= need) { U = a; break; }
+        if (!U) continue;
+        double eff = (double)nch / ((double)lpr * U);
+        int flag = (lpr >= 8 || lpr >= nch) ? 1 : 0;
+        bool better = eff > best_eff + 1e-9 ||
+                      (fabs(eff - best_eff) <= 1e-9 && (flag > best_flag || (flag == best_flag && pref[U] > best_pref)));
+        if (better) { best_eff = eff; best_flag = flag; best_pref = pref[U]; best.lpr_log2 = l2; best.U = U; }
+    }
+    if (best.U == 0) return false;
+    int fl = env_int("VG_LPR_LOG2", -1), fu = env_int("VG_U", -1);   // experiment overrides
+    if (fl >= 0 && fu > 0 && (nch + (1 << fl) - 1) / (1 << fl) <= fu) { best.lpr_log2 = fl; best.U = fu; }
+    *out = best;
+    return true;
+}
+
+template <int VT, int ACC>
+static scan_fn_t pick_u(int U) {
+    switch (U) {
+        case 1: return vg_scan_kernel<VT, ACC, 1>;
+        case 2: return vg_scan_kernel<VT, ACC, 2>;
+        case 3: return vg_scan_kernel<VT, ACC, 3>;
+        case 4: return vg_scan_kernel<VT, ACC, 4>;
+        case 6: return vg_scan_kernel<VT, ACC, 6>;
+        case 8: return vg_scan_kernel<VT, ACC, 8>;
+    }
+    return nullptr;
+}
+
+template <int VT>
+static scan_fn_t pick_acc(int acc, int U) {
+    switch (acc) {
+        case A_L2: return pick_u<VT, A_L2>(U);
+        case A_COS: return pick_u<VT, A_COS>(U);
+        case A_DOT: return pick_u<VT, A_DOT>(U);
+        case A_L1: return pick_u<VT, A_L1>(U);
+    }
+    return nullptr;
+}
+
+static scan_fn_t pick_kernel(int vtype, int acc, int U) {
+    switch (vtype) {
+        case VG_TYPE_F32: return pick_acc<T_F32>(acc, U);
+        case VG_TYPE_U8: return pick_acc<T_U8>(acc, U);
+        case VG_TYPE_I8: return pick_acc<T_I8>(acc, U);
+#ifdef VG_HAVE_HALF_TYPES
+        case VG_TYPE_F16: return pick_acc<T_F16>(acc, U);
+        case VG_TYPE_BF16: return pick_acc<T_BF16>(acc, U);
+#endif
+    }
+    return nullptr;
+}
+
+static int metric_to_acc(int metric) {
+    switch (metric) {
+        case VG_DIST_L2: case VG_DIST_SQUARED_L2: return A_L2;
+        case VG_DIST_COSINE: return A_COS;
+        case VG_DIST_DOT: return A_DOT;
+        case VG_DIST_L1: return A_L1;
+    }
+    return -1;
+}
+
+static const char *type_tag(int t) {
+    switch (t) { case VG_TYPE_F32: return "f32"; case VG_TYPE_F16: return "f16"; case VG_TYPE_BF16: return "bf16";
+                 case VG_TYPE_U8: return "u8"; case VG_TYPE_I8: return "i8"; }
+    return "?";
+}
+static const char *acc_tag(int a) {
+    switch (a) { case A_L2: return "l2"; case A_COS: return "cos"; case A_DOT: return "dot"; case A_L1: return "l1"; }
+    return "?";
+}
+
+extern "C" const char *vg_scan_kernel_name(vg_corpus *c, int metric) {
+    if (!c) return "";
+    Shape s;
+    int acc = metric_to_acc(metric);
+    if (acc < 0 || !choose_shape(c->nch, &s)) return "";
+    snprintf(c->kernel_name, sizeof(c->kernel_name), "scan_%s_%s_u%d_lpr%d", type_tag(c->vtype), acc_tag(acc), s.U, 1 << s.lpr_log2);
+    return c->kernel_name;
+}
+
+// Launch the scan (+ merge in top-k mode) on `stream`.  dev_query holds nch*16 zero-padded bytes.
+static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys,
+                       float *dev_out_dist, hipStream_t stream) {
+    int acc = metric_to_acc(metric);
+    if (acc < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
+    Shape s;
+    if (!choose_shape(c->nch, &s)) return vg_fail(VG_ERR_UNSUPPORTED, "row of %d bytes needs the long-row path (not implemented)", (int)c->stride);
+    scan_fn_t fn = pick_kernel(c->vtype, acc, s.U);
+    if (!fn) return vg_fail(VG_ERR_UNSUPPORTED, "no scan kernel for type %s", type_tag(c->vtype));
+
+    const int rpb = VG_WAVE >> s.lpr_log2;
+    const long long nbatch = (c->n_rows + rpb - 1) / rpb;
+    const int bpc = std::max(1, std::min(8, env_int("VG_BLOCKS_PER_CU", 4)));
+    long long blocks = (nbatch + VG_WAVES_PER_BLOCK - 1) / VG_WAVES_PER_BLOCK;
+    blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count * bpc));
+
+    ScanArgs a;
+    a.rows = c->d_rows;
+    a.query = dev_query;
+    a.cand = c->d_cand;
+    a.out_dist = dev_out_dist;
+    a.n_rows = c->n_rows;
+    a.stride = c->stride;
+    a.nch = c->nch;
+    a.lpr_log2 = s.lpr_log2;
+    a.k = k;
+    a.root = (metric == VG_DIST_L2) ? 1 : 0;
+    a.dim = c->dim;
+    size_t smem = std::max<size_t>((size_t)c->nch * 16, (size_t)VG_WAVES_PER_BLOCK * VG_WAVE * sizeof(uint64_t));
+
+    hipEvent_t *evs = nullptr;
+    if (c->profiling) {
+        int slot = (int)(c->prof_launches % VG_PROF_RING);
+        evs = &c->ev[(size_t)slot * 3];
+        c->ev_had_merge[(size_t)slot] = (dev_out_dist == nullptr);
+        ++c->prof_launches;
+        hipEventRecord(evs[0], stream);
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
+    if (evs) hipEventRecord(evs[1], stream);
+    if (!dev_out_dist) {
+        hipLaunchKernelGGL(vg_merge_kernel, dim3(1), dim3(VG_MERGE_WAVES * VG_WAVE), 0, stream,
+                           (const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys);
+    }
+    if (evs) hipEventRecord(evs[2], stream);
+    HIP_TRY(hipGetLastError());
+    return VG_OK;
+}
+
+static void stage_query(vg_corpus *c, const void *query) {
+    memset(c->h_query, 0, (size_t)c->stride);
+    memcpy(c->h_query, query, (size_t)c->dim * c->es);
+}
+
+// kernel times of ring slot `slot` (waits for that launch to finish)
+static void slot_times(vg_corpus *c, int slot, float *scan_ms, float *merge_ms) {
+    hipEvent_t *evs = &c->ev[(size_t)slot * 3];
+    hipEventSynchronize(evs[2]);
+    *scan_ms = 0.f; *merge_ms = 0.f;
+    hipEventElapsedTime(scan_ms, evs[0], evs[1]);
+    if (c->ev_had_merge[(size_t)slot]) hipEventElapsedTime(merge_ms, evs[1], evs[2]);
+}
+
+static void collect_timing(vg_corpus *c) {
+    if (!c->profiling || c->prof_launches == 0) return;
+    slot_times(c, (int)((c->prof_launches - 1) % VG_PROF_RING), &c->last_scan_ms, &c->last_merge_ms);
+}
+
+extern "C" float vg_key_distance(uint64_t key) { return vg_sortable_f32((uint32_t)(key >> 32)); }
+extern "C" uint32_t vg_key_position(uint64_t key) { return (uint32_t)(key & 0xFFFFFFFFull); }
+
+extern "C" int vg_scan_topk_device(vg_corpus *c, int metric, const void *dev_query, int k, uint64_t *dev_out_keys,
+                                   void *stream) {
+    if (!c || !dev_query || !dev_out_keys) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_device: NULL argument");
+    if (k < 1 || k > VG_MAX_FUSED_K) return vg_fail(VG_ERR_UNSUPPORTED, "vg_scan_topk_device: k must be in 1..%d", VG_MAX_FUSED_K);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (c->n_rows == 0) {
+        HIP_TRY(hipMemsetAsync(dev_out_keys, 0xFF, VG_WAVE * sizeof(uint64_t), st));
+        return VG_OK;
+    }
+    return launch_scan(c, metric, (const uint8_t *)dev_query, k, dev_out_keys, nullptr, st);
+}
+
+extern "C" int vg_scan_distances_device(vg_corpus *c, int metric, const void *dev_query, float *dev_out_dist, void *stream) {
+    if (!c || !dev_query || !dev_out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_distances_device: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->n_rows == 0) return VG_OK;
+    return launch_scan(c, metric, (const uint8_t *)dev_query, 0, nullptr, dev_out_dist, stream ? (hipStream_t)stream : c->stream);
+}
+
+static int ensure_dist_buffer(vg_corpus *c) {
+    if (c->d_dist_cap >= c->n_rows) return VG_OK;
+    if (c->d_dist) { hipFree(c->d_dist); c->d_dist = nullptr; c->d_dist_cap = 0; }
+    HIP_TRY(hipMalloc(&c->d_dist, (size_t)c->n_rows * sizeof(float)));
+    c->d_dist_cap = c->n_rows;
+    return VG_OK;
+}
+
+extern "C" int vg_scan_distances(vg_corpus *c, int metric, const void *query, float *out_dist_host) {
+    if (!c || !query || !out_dist_host) return vg_fail(VG_ERR_INVALID, "vg_scan_distances: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->n_rows == 0) return VG_OK;
+    int rc = ensure_dist_buffer(c);
+    if (rc != VG_OK) return rc;
+    stage_query(c, query);
+    HIP_TRY(hipMemcpyAsync(c->d_query, c->h_query, (size_t)c->stride, hipMemcpyHostToDevice, c->stream));
+    rc = launch_scan(c, metric, c->d_query, 0, nullptr, c->d_dist, c->stream);
+    if (rc != VG_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(out_dist_host, c->d_dist, (size_t)c->n_rows * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    collect_timing(c);
+    return VG_OK;
+}
+
+// k > 64: all N distances are produced by the same scan kernel (store mode) and the selection runs over the
+// N packed keys on the host side of the boundary.  Distances are GPU-computed; only the ordering of an
+// already-computed float array happens here.  (A device-side radix select replaces this in a later round.)
+static int scan_topk_large_k(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids,
+                             double *out_dist, int *out_count) {
+    std::vector<float> d((size_t)c->n_rows);
+    int rc = vg_scan_distances(c, metric, query, d.data());
+    if (rc != VG_OK) return rc;
+    std::vector<uint64_t> keys;
+    keys.reserve((size_t)c->n_rows);
+    for (int64_t i = 0; i < c->n_rows; ++i)
+        if (d[(size_t)i] < INFINITY) keys.push_back(vg_make_key(d[(size_t)i], (uint32_t)i));
+    size_t cnt = std::min<size_t>((size_t)k, keys.size());
+    std::partial_sort(keys.begin(), keys.begin() + cnt, keys.end());
+    for (size_t i = 0; i < cnt; ++i) {
+        out_dist[i] = (double)vg_key_distance(keys[i]);
+        out_rowids[i] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(keys[i]));
+    }
+    *out_count = (int)cnt;
+    return VG_OK;
+}
+
+extern "C" int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist,
+                            int *out_count) {
+    if (!c || !query || !out_count) return vg_fail(VG_ERR_INVALID, "vg_scan_topk: NULL argument");
+    *out_count = 0;
+    if (k <= 0 || c->n_rows == 0) return VG_OK;
+    if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk: NULL output");
+    if (metric_to_acc(metric) < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
+    HIP_TRY(hipSetDevice(c->device));
+    if (k > VG_MAX_FUSED_K) return scan_topk_large_k(c, metric, query, k, out_rowids, out_dist, out_count);
+    stage_query(c, query);
+    HIP_TRY(hipMemcpyAsync(c->d_query, c->h_query, (size_t)c->stride, hipMemcpyHostToDevice, c->stream));
+    int rc = launch_scan(c, metric, c->d_query, k, c->d_keys, nullptr, c->stream);
+    if (rc != VG_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_keys, c->d_keys, VG_WAVE * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    collect_timing(c);
+    int cnt = 0;
+    for (int i = 0; i < k; ++i) {
+        uint64_t key = c->h_keys[i];
+        if (key == VG_EMPTY_KEY) break;
+        out_dist[cnt] = (double)vg_key_distance(key);
+        out_rowids[cnt] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(key));
+        ++cnt;
+    }
+    *out_count = cnt;
+    return VG_OK;
+}
+
+extern "C" int vg_scan_topk_batch(vg_corpus *c, int metric, const void *queries, int nq, int k, int64_t *out_rowids,
+                                  double *out_dist, int *out_counts) {
+    if (!c || !queries || !out_counts) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch: NULL argument");
+    // round 1: the batched path is nq passes of the single-query kernel (the MFMA Q x C^T kernel is the next row)
+    const uint8_t *q = (const uint8_t *)queries;
+    for (int i = 0; i < nq; ++i) {
+        int rc = vg_scan_topk(c, metric, q + (size_t)i * c->dim * c->es, k, out_rowids + (size_t)i * k,
+                              out_dist + (size_t)i * k, out_counts + i);
+        if (rc != VG_OK) return rc;
+    }
+    return VG_OK;
+}
+
+extern "C" int vg_merge_keys(const uint64_t *keys, int n_lists, int list_len, const int64_t *pos_offsets, int k,
+                             int64_t *out_global_pos, double *out_dist) {
+    if (!keys || n_lists <= 0 || list_len <= 0 || k <= 0) return 0;
+    // heads-of-lists merge; lists are ascending.  Tie on distance -> lower list index first, then lower position:
+    // for contiguous row-range shards that IS global scan order.
+    std::vector<int> head((size_t)n_lists, 0);
+    int cnt = 0;
+    while (cnt < k) {
+        int best = -1;
+        uint64_t bk = VG_EMPTY_KEY;
+        for (int l = 0; l < n_lists; ++l) {
+            if (head[(size_t)l] >= list_len) continue;
+            uint64_t key = keys[(size_t)l * list_len + head[(size_t)l]];
+            if (key == VG_EMPTY_KEY) continue;
+            // compare by distance image only across lists (positions are list-local)
+            if (best < 0 || (key >> 32) < (bk >> 32)) { best = l; bk = key; }
+        }
+        if (best < 0) break;
+        out_dist[cnt] = (double)vg_key_distance(bk);
+        out_global_pos[cnt] = (pos_offsets ? pos_offsets[best] : 0) + (int64_t)vg_key_position(bk);
+        ++cnt;
+        ++head[(size_t)best];
+    }
+    return cnt;
+}
+
+// ------------------------------------------------------------------------------------------------ query quantizer
+// Host C, once per query.  Same arithmetic as the reference (sqlite-vector.c:495-757): s = (v - offset) * scale,
+// round half away from zero, clamp; f32 sources use the unguarded int conversion (:524-538), the other source
+// types go through the NaN/Inf-aware rounding (:495-515).
+
+static inline float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu, out;
+    if (exp == 0x1F) out = sign | 0x7F800000u | (man << 13);
+    else if (exp) out = sign | ((exp + 112u) << 23) | (man << 13);
+    else if (!man) out = sign;
+    else { float v = (float)man * 0x1.0p-24f; memcpy(&out, &v, 4); out |= sign; }
+    float f; memcpy(&f, &out, 4); return f;
+}
+static inline float bf16_to_float(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+static inline int cvt_trunc_x86(float r) {          // cvttss2si: NaN / out of range -> INT_MIN
+    if (!(r >= -2147483648.0f && r < 2147483648.0f)) return (int)0x80000000u;
+    return (int)r;
+}
+
+extern "C" int vg_quantize_query(int src_type, const void *src, int dim, float scale, float offset, int qtype, void *dst) {
+    if (!src || !dst || dim <= 0) return vg_fail(VG_ERR_INVALID, "vg_quantize_query: bad argument");
+    if (qtype != VG_QUANT_U8 && qtype != VG_QUANT_S8) return vg_fail(VG_ERR_INVALID, "vg_quantize_query: qtype must be UINT8 or INT8");
+    if (!elem_size(src_type)) return vg_fail(VG_ERR_INVALID, "vg_quantize_query: unknown source type");
+    for (int i = 0; i < dim; ++i) {
+        float v;
+        switch (src_type) {
+            case VG_TYPE_F32: v = ((const float *)src)[i]; break;
+            case VG_TYPE_F16: v = half_to_float(((const uint16_t *)src)[i]); break;
+            case VG_TYPE_BF16: v = bf16_to_float(((const uint16_t *)src)[i]); break;
+            case VG_TYPE_U8: v = (float)((const uint8_t *)src)[i]; break;
+            default: v = (float)((const int8_t *)src)[i]; break;
+        }
+        float s = (v - offset) * scale;
+        float r = s + 0.5f * (1.0f - 2.0f * (s < 0.0f));
+        if (src_type == VG_TYPE_F32) {
+            int ir = cvt_trunc_x86(r);
+            if (qtype == VG_QUANT_U8) ((uint8_t *)dst)[i] = (uint8_t)(ir > 255 ? 255 : (ir < 0 ? 0 : ir));
+            else ((int8_t *)dst)[i] = (int8_t)(ir > 127 ? 127 : (ir < -128 ? -128 : ir));
+        } else if (qtype == VG_QUANT_U8) {
+            uint8_t o;
+            if (!std::isfinite(s)) o = (s > 0.0f) ? 255u : 0u;
+            else if (r >= 255.0f) o = 255u;
+            else if (r <= 0.0f) o = 0u;
+            else o = (uint8_t)(int)r;
+            ((uint8_t *)dst)[i] = o;
+        } else {
+            int8_t o;
+            if (!std::isfinite(s)) o = (s > 0.0f) ? 127 : (s < 0.0f ? -128 : 0);
+            else if (r >= 127.0f) o = 127;
+            else if (r <= -128.0f) o = -128;
+            else o = (int8_t)(int)r;
+            ((int8_t *)dst)[i] = o;
+        }
+    }
+    return VG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ instrumentation
+
+extern "C" int vg_set_profiling(vg_corpus *c, int enabled) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    if (enabled && c->ev.empty()) {
+        c->ev.assign((size_t)VG_PROF_RING * 3, nullptr);
+        c->ev_had_merge.assign((size_t)VG_PROF_RING, 0);
+        for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+    }
+    c->profiling = enabled != 0;
+    c->prof_launches = 0;
+    return VG_OK;
+}
+
+extern "C" int vg_profile_mean_ms(vg_corpus *c, int *n_launches, float *scan_ms, float *merge_ms) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    long long n = std::min<long long>(c->prof_launches, VG_PROF_RING);
+    double s = 0.0, m = 0.0;
+    for (long long i = 0; i < n; ++i) {
+        float a = 0.f, b = 0.f;
+        slot_times(c, (int)((c->prof_launches - 1 - i) % VG_PROF_RING), &a, &b);
+        s += a; m += b;
+    }
+    if (n_launches) *n_launches = (int)n;
+    if (scan_ms) *scan_ms = n ? (float)(s / n) : 0.f;
+    if (merge_ms) *merge_ms = n ? (float)(m / n) : 0.f;
+    return VG_OK;
+}
+
+extern "C" int vg_last_kernel_ms(vg_corpus *c, float *scan_ms, float *merge_ms) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    collect_timing(c);      // waits for the recorded events of the last (possibly still running) scan
+    if (scan_ms) *scan_ms = c->last_scan_ms;
+    if (merge_ms) *merge_ms = c->last_merge_ms;
+    return VG_OK;
+}

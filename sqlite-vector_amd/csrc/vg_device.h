@@ -1,0 +1,126 @@
+// vg_device.h - device-side building blocks of the gfx950 scan: packed (distance, position) keys,
+// wavefront-wide sorted candidate list, per-(type, metric) accumulators and epilogues.
+//
+// CDNA4 only: 64-lane wavefronts are assumed everywhere (ballots are 64-bit, lists are one slot per lane).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VG_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+#define VG_WAVE 64
+#define VG_BLOCK 256                 // 4 wavefronts per workgroup
+#define VG_WAVES_PER_BLOCK (VG_BLOCK / VG_WAVE)
+#define VG_MAX_FUSED_K 64            // one list slot per lane
+
+// element types / metrics: numbering of the reference (distance-cpu.h:36-58)
+enum { T_F32 = 1, T_F16 = 2, T_BF16 = 3, T_U8 = 4, T_I8 = 5 };
+enum { M_L2 = 1, M_SQL2 = 2, M_COS = 3, M_DOT = 4, M_L1 = 5 };
+// accumulation kinds (L2 and squared-L2 share one; the root is an epilogue flag)
+enum { A_L2 = 0, A_COS = 1, A_DOT = 2, A_L1 = 3 };
+
+struct ScanArgs {
+    const uint8_t *rows;       // N x stride bytes, 16-byte-multiple stride, zero padded
+    const uint8_t *query;      // nch * 16 bytes, zero padded (device)
+    uint64_t *cand;            // [gridDim.x][64] block candidate lists (top-k mode)
+    float *out_dist;           // [n_rows] all distances (store mode) or nullptr
+    long long n_rows;
+    long long stride;          // bytes between rows
+    int nch;                   // 16-byte chunks per row
+    int lpr_log2;              // log2(lanes cooperating on one row)
+    int k;                     // <= 64 in top-k mode
+    int root;                  // 1: L2 (sqrt), 0: squared L2
+    int dim;                   // elements per row (for the special-value slow paths)
+};
+
+// ------------------------------------------------------------------------------------------ keys
+
+// order-preserving map float -> uint32 (ascending floats -> ascending unsigned)
+__host__ __device__ inline uint32_t vg_f32_sortable(float d) {
+    uint32_t b;
+#if defined(__HIP_DEVICE_COMPILE__)
+    b = __float_as_uint(d);
+#else
+    __builtin_memcpy(&b, &d, 4);
+#endif
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__host__ __device__ inline float vg_sortable_f32(uint32_t s) {
+    uint32_t b = s ^ ((s >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(b);
+#else
+    float f; __builtin_memcpy(&f, &b, 4); return f;
+#endif
+}
+__host__ __device__ inline uint64_t vg_make_key(float d, uint32_t pos) {
+    return ((uint64_t)vg_f32_sortable(d) << 32) | (uint64_t)pos;
+}
+
+// ------------------------------------------------------------------------------------------ wave helpers
+
+__device__ inline uint64_t vg_readlane64(uint64_t v, int lane_uniform) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane_uniform);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane_uniform);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Sorted candidate list spread over the wavefront: lane i holds the i-th smallest key, `thr` (wave-uniform)
+// is the key in slot k-1, i.e. the current k-th best.  Insert = one shift-up + selects (no loop, no LDS).
+__device__ inline void vg_list_insert(uint64_t &mine, uint64_t &thr, uint64_t c, int lane, int k) {
+    uint64_t prev = __shfl_up(mine, 1);
+    bool gt = mine > c;
+    bool pgt = (lane > 0) && (prev > c);
+    mine = gt ? (pgt ? prev : c) : mine;
+    thr = vg_readlane64(mine, k - 1);
+}
+
+// Offer one candidate per lane (valid lanes only).  Expected cost ~0 once thr has tightened.
+__device__ inline void vg_list_offer(uint64_t key, bool valid, uint64_t &mine, uint64_t &thr, int lane, int k) {
+    unsigned long long m = __ballot(valid && key < thr);
+    while (m) {
+        int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        uint64_t c = vg_readlane64(key, src);
+        if (c < thr) vg_list_insert(mine, thr, c, lane, k);
+    }
+}
+
+// butterfly sum over the 2^lpr_log2 lanes that share a row; every lane of the group ends with the total
+template <typename T>
+__device__ inline T vg_group_sum(T v, int lpr_log2) {
+    if (lpr_log2 > 0) v += __shfl_xor(v, 1);
+    if (lpr_log2 > 1) v += __shfl_xor(v, 2);
+    if (lpr_log2 > 2) v += __shfl_xor(v, 4);
+    if (lpr_log2 > 3) v += __shfl_xor(v, 8);
+    if (lpr_log2 > 4) v += __shfl_xor(v, 16);
+    if (lpr_log2 > 5) v += __shfl_xor(v, 32);
+    return v;
+}
+template <typename T>
+__device__ inline T vg_group_or(T v, int lpr_log2) {
+    if (lpr_log2 > 0) v |= __shfl_xor(v, 1);
+    if (lpr_log2 > 1) v |= __shfl_xor(v, 2);
+    if (lpr_log2 > 2) v |= __shfl_xor(v, 4);
+    if (lpr_log2 > 3) v |= __shfl_xor(v, 8);
+    if (lpr_log2 > 4) v |= __shfl_xor(v, 16);
+    if (lpr_log2 > 5) v |= __shfl_xor(v, 32);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------ epilogue math
+// Each operation below must round exactly once, like the reference's scalar epilogues: correctly rounded
+// sqrt / divide, no contraction of a*b+c.
+
+#pragma clang fp contract(off)
+
+// nearly_zero_float32 clamp, sqlite-vector.c:994-996 applied at :2099 / :2141
+__device__ inline float vg_clamp(float d) { return (fabsf(d) <= 8.0f * 1.1920928955078125e-7f) ? 0.0f : d; }
+
+// 1 - dot / (na * nb) with the zero-norm rule (distance-avx2.c:153-162, :744-753, :941-950; distance-cpu.c:103-109)
+__device__ inline float vg_cosine_from_norms(float dot, float na, float nb) {
+    if (na == 0.0f || nb == 0.0f) return 1.0f;
+    float den = na * nb;
+    float cs = __fdiv_rn(dot, den);
+    return 1.0f - cs;
+}

@@ -1,0 +1,129 @@
+// vg_scan.h - the brute-force scan kernel (single query): HBM-bound streaming read of the N x D corpus with a
+// fused wavefront-level top-k.  One template, instantiated per (element type, accumulation kind, U).
+//
+// Work decomposition (CDNA4):
+//   * a row is `nch` 16-byte chunks; LPR = 2^lpr_log2 lanes share a row, lane `sub` owns chunks sub + u*LPR
+//     (u < U), so one wave-wide global_load_dwordx4 reads 64/LPR rows x (LPR*16 B) contiguous bytes per row:
+//     full 128-byte lines, every byte of the corpus fetched exactly once;
+//   * a wavefront processes "batches" of 64/LPR rows in a grid-stride loop and keeps the next batch's U loads in
+//     flight while it reduces the current one (loads straight to VGPRs, no LDS round trip: nothing is reused);
+//   * the query lives in VGPRs (U x uint4 per lane), staged through LDS once per workgroup;
+//   * per batch: U chunk folds -> butterfly over the lane group -> scalar epilogue -> clamp -> 64-bit key ->
+//     ballot against the wave's current k-th best; only the rare survivors touch the sorted list;
+//   * at the end the 4 wave lists of a workgroup merge through LDS and ONE list per workgroup goes to HBM
+//     (grid x 64 keys); vg_merge_kernel reduces those to the final k.
+#pragma once
+
+#include "vg_accum.h"
+
+template <int U>
+__device__ inline void vg_load_batch(uint4 (&dst)[U], const uint8_t *rows, long long row, long long n_rows,
+                                     long long stride, int sub, int lpr, int nch) {
+    const uint8_t *p = rows + row * stride + (long long)sub * 16;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = sub + u * lpr;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row < n_rows && c < nch) v = *reinterpret_cast<const uint4 *>(p + (long long)u * lpr * 16);
+        dst[u] = v;
+    }
+}
+
+template <int VT, int ACC, int U>
+__global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & (VG_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int lpr_log2 = a.lpr_log2;
+    const int lpr = 1 << lpr_log2;
+    const int rpb = VG_WAVE >> lpr_log2;          // rows per batch
+    const int sub = lane & (lpr - 1);
+    const int rib = lane >> lpr_log2;             // row in batch
+
+    // ---- query: global -> LDS (once per workgroup) -> VGPRs
+    uint4 *qs = reinterpret_cast<uint4 *>(smem);
+    for (int c = threadIdx.x; c < a.nch; c += VG_BLOCK) qs[c] = reinterpret_cast<const uint4 *>(a.query)[c];
+    __syncthreads();
+    uint4 q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = sub + u * lpr;
+        q[u] = (c < a.nch) ? qs[c] : make_uint4(0u, 0u, 0u, 0u);
+    }
+    const typename Accum<VT, ACC>::QStat qstat = Accum<VT, ACC>::template query_stat<U>(q, lpr_log2);
+
+    // ---- candidate list (top-k mode)
+    uint64_t mine = VG_EMPTY_KEY, thr = VG_EMPTY_KEY;
+    const int k = a.k;
+    const bool store_mode = (a.out_dist != nullptr);
+
+    // ---- grid-stride loop over row batches, one batch prefetched
+    const long long nbatch = (a.n_rows + rpb - 1) / rpb;
+    const long long wstride = (long long)gridDim.x * VG_WAVES_PER_BLOCK;
+    long long b = (long long)blockIdx.x * VG_WAVES_PER_BLOCK + wave;
+
+    uint4 cur[U], nxt[U];
+    vg_load_batch<U>(cur, a.rows, b * rpb + rib, (b < nbatch) ? a.n_rows : 0, a.stride, sub, lpr, a.nch);
+    while (b < nbatch) {
+        const long long bn = b + wstride;
+        vg_load_batch<U>(nxt, a.rows, bn * rpb + rib, (bn < nbatch) ? a.n_rows : 0, a.stride, sub, lpr, a.nch);
+
+        Accum<VT, ACC> acc;
+        acc.init();
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc.chunk(q[u], cur[u]);
+        const long long row = b * rpb + rib;
+        float d = vg_clamp(acc.finish(qstat, lpr_log2, a.root));
+        const bool owner = (sub == 0) && (row < a.n_rows);
+        if (store_mode) {
+            if (owner) a.out_dist[row] = d;
+        } else {
+            // NaN and +Inf never enter (strict '<' against INFINITY-initialised slots, sqlite-vector.c:1809,2102)
+            vg_list_offer(vg_make_key(d, (uint32_t)row), owner && (d < INFINITY), mine, thr, lane, k);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        b = bn;
+    }
+    if (store_mode) return;
+
+    // ---- merge the workgroup's 4 lists through LDS; wave 0 publishes one list
+    __syncthreads();                                   // everyone is done with the query staging area
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);
+    if (wave > 0) lists[wave * VG_WAVE + lane] = mine;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll 1
+        for (int w = 1; w < VG_WAVES_PER_BLOCK; ++w) {
+            const uint64_t c = lists[w * VG_WAVE + lane];
+            vg_list_offer(c, (lane < k) && (c != VG_EMPTY_KEY), mine, thr, lane, k);
+        }
+        a.cand[(long long)blockIdx.x * VG_WAVE + lane] = (lane < k) ? mine : VG_EMPTY_KEY;
+    }
+}
+
+// Final reduction of `nlists` sorted 64-slot lists to the k best.  One workgroup of 16 wavefronts: each wave
+// folds every 16th list into its own sorted list, then wave 0 folds the 16 wave lists and writes k keys
+// (ascending, VG_EMPTY_KEY padded to 64).
+#define VG_MERGE_WAVES 16
+__global__ __launch_bounds__(VG_MERGE_WAVES * VG_WAVE) void vg_merge_kernel(const uint64_t *cand, int nlists, int k,
+                                                                            uint64_t *out_keys) {
+    __shared__ uint64_t lists[VG_MERGE_WAVES * VG_WAVE];
+    const int lane = threadIdx.x & (VG_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    uint64_t mine = VG_EMPTY_KEY, thr = VG_EMPTY_KEY;
+    for (int l = wave; l < nlists; l += VG_MERGE_WAVES) {
+        const uint64_t c = cand[(long long)l * VG_WAVE + lane];
+        vg_list_offer(c, (lane < k) && (c != VG_EMPTY_KEY), mine, thr, lane, k);
+    }
+    lists[wave * VG_WAVE + lane] = mine;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll 1
+        for (int w = 1; w < VG_MERGE_WAVES; ++w) {
+            const uint64_t c = lists[w * VG_WAVE + lane];
+            vg_list_offer(c, (lane < k) && (c != VG_EMPTY_KEY), mine, thr, lane, k);
+        }
+        out_keys[lane] = (lane < k) ? mine : VG_EMPTY_KEY;
+    }
+}

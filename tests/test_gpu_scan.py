@@ -1,0 +1,246 @@
+"""GPU parity tests proper: the HIP scan, called through the C-ABI (libvectorgpu.so), against the pinned CPU
+oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star):
+  * int8 / uint8: distances BIT-EXACT with the reference's distance-avx2.c path, identical rowid order
+    (ties resolved by scan position, the GPU contract - see DESIGN.md);
+  * f32: distances within 1e-5 relative of the reference arithmetic (plus an absolute term for the metrics that
+    cancel: dot / cosine), top-k identical to the (distance, position) order of the GPU's own distances.
+"""
+import numpy as np
+import pytest
+
+import datagen as dg
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as g
+    p = g.load_package()
+    if p.device_count() < 1:
+        pytest.fail("GPU tests need a HIP device (the product has no CPU fallback)")
+    return p
+
+
+def _abs_scale(vt, metric, q, rows):
+    """magnitude of the terms being summed - the natural absolute error scale for cancelling metrics"""
+    qf = dg.storage_to_f64(vt, q)
+    rf = dg.storage_to_f64(vt, rows)
+    if metric == dg.DOT:
+        return np.abs(rf * qf).sum(axis=1)
+    return np.ones(rows.shape[0])          # cosine is O(1)
+
+
+def _check_float_distances(got, want, vt, metric, q, rows):
+    got = got.astype(np.float64)
+    want = want.astype(np.float64)
+    both_nan = np.isnan(got) & np.isnan(want)
+    same_inf = np.isinf(want) & (got == want)
+    fin = ~(both_nan | same_inf)
+    assert not np.isnan(got[fin]).any() and not np.isinf(got[fin]).any(), "NaN/Inf mismatch"
+    err = np.abs(got[fin] - want[fin])
+    tol = REL_TOL * np.abs(want[fin])
+    if metric in (dg.DOT, dg.COSINE):
+        tol = tol + REL_TOL * _abs_scale(vt, metric, q, rows)[fin] * (1.0 if metric == dg.DOT else 1.0)
+    # values both sides clamp to exactly 0 (|d| <= 8 eps) may straddle the clamp
+    tol = np.maximum(tol, 8 * np.finfo(np.float32).eps * 1.01)
+    bad = err > tol
+    assert not bad.any(), (np.nonzero(bad)[0][:5], got[fin][bad][:5], want[fin][bad][:5])
+
+
+DIMS_F32 = (1, 3, 4, 5, 16, 35, 100, 128, 384, 768, 1000, 1024, 1536)
+DIMS_INT = (1, 3, 15, 16, 17, 35, 100, 384, 768, 1000, 1536, 2048)
+
+
+@pytest.mark.parametrize("dim", DIMS_F32)
+def test_f32_all_metrics_vs_oracle(pkg, orc, dim):
+    n = 2500
+    rows = dg.corpus(dg.F32, n, dim, 300 + dim)
+    q = dg.query(dg.F32, dim, 301 + dim)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    for metric in dg.ALL_METRICS:
+        want = orc.scan_distances(orc.AVX2, metric, dg.F32, q, rows)
+        got = c.scan_distances(metric, q)
+        _check_float_distances(got, want, dg.F32, metric, q, rows)
+        for k in (1, 20, 64):
+            ids, dist = c.scan_topk(metric, q, k)
+            oids, odist, _ = orc.topk_ordered(got, None, k)        # selection must be exact on the GPU's own floats
+            assert ids.tolist() == oids.tolist(), (dim, metric, k)
+            assert np.array_equal(dist, odist)
+    c.close()
+
+
+@pytest.mark.parametrize("vt", [dg.U8, dg.I8])
+@pytest.mark.parametrize("dim", DIMS_INT)
+def test_int8_bit_exact_vs_oracle(pkg, orc, vt, dim):
+    n = 2500
+    for low in (False, True):                      # low entropy -> many exact ties
+        rows = dg.corpus(vt, n, dim, 400 + dim, low_entropy=low)
+        q = dg.query(vt, dim, 401 + dim, low_entropy=low)
+        c = pkg.Corpus(vt, dim)
+        c.append(rows)
+        for metric in dg.ALL_METRICS:
+            want = orc.scan_distances(orc.AVX2, metric, vt, q, rows)
+            got = c.scan_distances(metric, q)
+            assert dg.same_float_bits(got, want), (dg.TYPE_NAMES[vt], dg.METRIC_NAMES[metric], dim, low,
+                                                   np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0][:5])
+            for k in (1, 20, 64):
+                ids, dist = c.scan_topk(metric, q, k)
+                oids, odist, _ = orc.topk_ordered(want, None, k)
+                assert ids.tolist() == oids.tolist(), (dim, metric, k, low)
+                assert np.array_equal(dist, odist)
+                # the reference's own (history dependent) slot algorithm returns the same distance sequence
+                rids, rdist = orc.topk_reference(want, None, k)
+                assert np.array_equal(rdist, odist)
+        c.close()
+
+
+def test_int8_extreme_values_bit_exact(pkg, orc):
+    """all-255 / all-(-128) rows: the largest integer sums (768*255^2 > 2^24: one rounding at the end only)."""
+    for vt in (dg.U8, dg.I8):
+        dim = 768
+        q, rows = dg.edge_rows(vt, dim, 77)
+        c = pkg.Corpus(vt, dim)
+        c.append(rows)
+        for metric in dg.ALL_METRICS:
+            for qq in dg.edge_queries(vt, dim, 78):
+                want = orc.scan_distances(orc.AVX2, metric, vt, qq, rows)
+                got = c.scan_distances(metric, qq)
+                assert dg.same_float_bits(got, want), (vt, metric)
+        c.close()
+
+
+def test_f32_nan_inf_rows_never_enter_topk(pkg, orc):
+    dim = 35
+    q, rows = dg.edge_rows(dg.F32, dim, 90)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    for metric in dg.ALL_METRICS:
+        got = c.scan_distances(metric, q)
+        want = orc.scan_distances(orc.AVX2, metric, dg.F32, q, rows)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), metric
+        assert np.array_equal(np.isposinf(got), np.isposinf(want)), metric
+        ids, dist = c.scan_topk(metric, q, 64)
+        oids, odist, _ = orc.topk_ordered(got, None, 64)
+        assert ids.tolist() == oids.tolist()
+        assert len(ids) == int(np.sum(got < np.inf))          # NaN and +Inf rows are absent, -Inf/finite present
+    # exact copy of the query: L2 distance clamps to exactly +0.0 and wins
+    ids, dist = c.scan_topk(dg.L2, q, 1)
+    assert ids.tolist() == [1] and dist[0] == 0.0
+    c.close()
+
+
+def test_short_table_empty_table_and_k_edge_cases(pkg, orc):
+    dim = 8
+    rows = dg.corpus(dg.F32, 5, dim, 1)
+    q = dg.query(dg.F32, dim, 2)
+    c = pkg.Corpus(pkg.F32, dim)
+    ids, dist = c.scan_topk(dg.L2, q, 10)
+    assert len(ids) == 0                                       # empty corpus
+    c.append(rows)
+    ids, dist = c.scan_topk(dg.L2, q, 10)                      # fewer rows than k (sqlite-vector.c:1816-1817)
+    d = orc.scan_distances(orc.AVX2, dg.L2, dg.F32, q, rows)
+    oids, odist, _ = orc.topk_ordered(d, None, 10)
+    assert ids.tolist() == oids.tolist() and len(ids) == 5
+    ids, dist = c.scan_topk(dg.L2, q, 0)                       # k == 0 -> nothing (:1796)
+    assert len(ids) == 0
+    c.close()
+
+
+def test_large_k_path(pkg, orc):
+    dim, n = 48, 3000
+    rows = dg.corpus(dg.I8, n, dim, 5, low_entropy=True)
+    q = dg.query(dg.I8, dim, 6, low_entropy=True)
+    c = pkg.Corpus(pkg.I8, dim)
+    c.append(rows)
+    want = orc.scan_distances(orc.AVX2, dg.L1, dg.I8, q, rows)
+    for k in (65, 500, n, n + 10):
+        ids, dist = c.scan_topk(dg.L1, q, k)
+        oids, odist, _ = orc.topk_ordered(want, None, k)
+        assert ids.tolist() == oids.tolist() and np.array_equal(dist, odist)
+    c.close()
+
+
+def test_rowids_strides_and_reference_record_format(pkg, orc):
+    """explicit rowids, a padded host stride, incremental appends, and the reference's [int64 rowid | dim bytes]
+    preload records (stride 8+dim, unaligned vectors) all stage to the same corpus."""
+    dim, n = 100, 1200
+    rows = dg.corpus(dg.U8, n, dim, 9)
+    q = dg.query(dg.U8, dim, 10)
+    rowids = (np.arange(n, dtype=np.int64) * 7 + 3) * np.where(np.arange(n) % 2 == 0, 1, -1)
+    want = orc.scan_distances(orc.AVX2, dg.COSINE, dg.U8, q, rows)
+    oids, odist, _ = orc.topk_ordered(want, rowids, 20)
+
+    c1 = pkg.Corpus(pkg.U8, dim)
+    c1.append(rows[:500], rowids[:500])
+    c1.append(rows[500:], rowids[500:])
+    ids, dist = c1.scan_topk(dg.COSINE, q, 20)
+    assert ids.tolist() == oids.tolist() and np.array_equal(dist, odist)
+    c1.close()
+
+    padded = np.zeros((n, 128), dtype=np.uint8)
+    padded[:, :dim] = rows
+    padded[:, dim:] = 0xAB                                     # garbage in the stride gap must be ignored
+    c2 = pkg.Corpus(pkg.U8, dim)
+    c2.append_strided(padded, n, 128, rowids)
+    ids, dist = c2.scan_topk(dg.COSINE, q, 20)
+    assert ids.tolist() == oids.tolist() and np.array_equal(dist, odist)
+    c2.close()
+
+    rec = np.zeros((n, 8 + dim), dtype=np.uint8)
+    rec[:, :8] = rowids.astype("<i8").view(np.uint8).reshape(n, 8)
+    rec[:, 8:] = rows
+    c3 = pkg.Corpus(pkg.U8, dim)
+    c3.append_records(rec, n)
+    ids, dist = c3.scan_topk(dg.COSINE, q, 20)
+    assert ids.tolist() == oids.tolist() and np.array_equal(dist, odist)
+    got = c3.scan_distances(dg.COSINE, q)
+    assert dg.same_float_bits(got, want)
+    c3.close()
+
+
+def test_logical_shards_merge_equals_single_shard(pkg, orc):
+    """row-range sharding (the 8-GPU layout) on one device: per-shard device keys + vg_merge_keys == 1 shard."""
+    import torch
+    dim, n, k, G = 64, 5000, 20, 4
+    rows = dg.corpus(dg.I8, n, dim, 21, low_entropy=True)      # heavy ties across shard borders
+    q = dg.query(dg.I8, dim, 22, low_entropy=True)
+    whole = pkg.Corpus(pkg.I8, dim)
+    whole.append(rows)
+    ids1, dist1 = whole.scan_topk(dg.SQUARED_L2, q, k)
+    whole.close()
+    bounds = [0, 1300, 2600, 2601, n]
+    qd = torch.zeros(((dim + 15) // 16) * 16, dtype=torch.uint8, device="cuda")
+    qd[:dim] = torch.from_numpy(q.view(np.uint8)).cuda()
+    keys = torch.empty((G, 64), dtype=torch.int64, device="cuda")
+    shards = []
+    for g in range(G):
+        s = pkg.Corpus(pkg.I8, dim)
+        s.append(rows[bounds[g]:bounds[g + 1]])
+        s.scan_topk_device(dg.SQUARED_L2, qd.data_ptr(), k, keys[g].data_ptr(),
+                           torch.cuda.current_stream().cuda_stream)
+        shards.append(s)
+    torch.cuda.synchronize()
+    pos, dist = pkg.merge_keys(keys.cpu().numpy().view(np.uint64), bounds[:G], k)
+    assert (pos + 1).tolist() == ids1.tolist()
+    assert np.array_equal(dist, dist1)
+    for s in shards:
+        s.close()
+
+
+def test_batch_entry_point(pkg, orc):
+    dim, n, nq, k = 96, 2000, 7, 10
+    rows = dg.corpus(dg.F32, n, dim, 31)
+    qs = dg.corpus(dg.F32, nq, dim, 32)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    ids, dist, cnt = c.scan_topk_batch(dg.DOT, qs, k)
+    for i in range(nq):
+        one_ids, one_dist = c.scan_topk(dg.DOT, qs[i], k)
+        assert cnt[i] == k and ids[i].tolist() == one_ids.tolist() and np.array_equal(dist[i], one_dist)
+    c.close()
