@@ -137,7 +137,9 @@ def main():
     else:
         queries = rng.integers(0, 256, (nq, dim), dtype=np.uint8)
 
-    stream = torch.cuda.current_stream()
+    # a real (non-null) stream: handle 0 would mean "use the corpus' own stream" to the C-ABI
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     qpad = ((dim * es + 15) // 16) * 16
     d_query = torch.zeros(qpad, dtype=torch.uint8, device="cuda")
     h_query = torch.zeros(qpad, dtype=torch.uint8).pin_memory()

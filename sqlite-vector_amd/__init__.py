@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvectorgpu.so")
+LIB_PATH = os.environ.get("VG_LIB_PATH") or os.path.join(HERE, "libvectorgpu.so")   # override: A/B kernel builds
 EXT_PATH = os.path.join(HERE, "vector.so")         # must be named vector.* (entry point sqlite3_vector_init)
 
 # enums (same numbering as the reference, distance-cpu.h:36-58)

