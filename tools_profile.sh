@@ -10,9 +10,9 @@ OUT="$REPO/gpurun_out/prof_$tag"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp
 # pass 1: per-kernel time
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o run -- python "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline "$@" > "$OUT/bench_stats.log" 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o run -- python "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu-baseline "$@" > "$OUT/bench_stats.log" 2>&1
 # pass 2: HBM bytes actually fetched (own run: --pmc never together with the trace domains gpurun refuses)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc" -o run -- python "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline "$@" > "$OUT/bench_pmc.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d "$OUT/pmc" -o run -- python "$REPO/bench.py" --steps 5 --warmup 1 --no-cpu-baseline "$@" > "$OUT/bench_pmc.log" 2>&1
 cd "$REPO"
 python - "$OUT" <<'EOF' > "$OUT/summary.txt" 2>&1
 import csv, glob, os, sys, json
