@@ -70,7 +70,7 @@ def build_extension(force=False, verbose=False):
         if os.path.exists(VEC):
             return VEC            # prebuilt artefact travelled here (GPU box): keep it
         raise RuntimeError("sqlite3ext.h not found: cannot build the SQLite extension host")
-    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-parameter",
+    cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-missing-field-initializers",
            "-I" + inc, "-I" + os.path.join(ROOT, "include"), "-o", VEC, src, "-ldl", "-lm"]
     if verbose:
         print(" ".join(cmd))
