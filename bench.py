@@ -120,6 +120,10 @@ def main():
 
     import __graft_entry__ as g
     pkg = g.load_package()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vg_shard", os.path.join(ROOT, "sqlite-vector_amd", "shard.py"))
+    shard = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard)
     vt, np_dtype, dim, metric, desc = WORKLOADS[args.workload]
     es = pkg.TYPE_SIZE[vt]
     k = args.k
@@ -155,15 +159,15 @@ def main():
         d_query.copy_(h_query, non_blocking=True)
         corpus.scan_topk_device(metric, d_query.data_ptr(), k, d_keys.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_keys)
-            if rank == 0:
-                h_keys.copy_(d_all, non_blocking=True)
+            # the path's only exchange: 64 keys per rank, one RCCL all_gather, rank 0 merges (shard.py)
+            res = shard.gather_and_merge(pkg, dist, d_keys, d_all, offsets, k, dst=0, host_buf=h_keys,
+                                         sync=stream.synchronize)
+            if res is not None:
+                last["pos"], last["dist"] = res
         else:
             h_keys[0].copy_(d_keys, non_blocking=True)
-        if rank == 0:
             stream.synchronize()
-            pos, dd = pkg.merge_keys(h_keys.numpy().view(np.uint64), offsets, k)
-            last["pos"], last["dist"] = pos, dd
+            last["pos"], last["dist"] = pkg.merge_keys(h_keys.numpy().view(np.uint64), offsets, k)
 
     for i in range(args.warmup):
         step(i)
@@ -209,6 +213,14 @@ def main():
                          "kernel": corpus.kernel_name(metric), "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms,
                          "launches_timed": n_launch, "algorithmic_bytes_per_launch": algo_bytes},
         }
+        try:        # HBM bytes per launch measured by the PMC pass committed under profiles/ (same kernel, same N)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                ent = json.load(f).get("%s@%d" % (corpus.kernel_name(metric), n_rows))
+            if ent:
+                out["roofline"]["traffic"] = ent["bytes_per_launch"]
+                out["roofline"]["traffic_source"] = ent["source"]
+        except Exception:
+            pass
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(vt, np_dtype, dim, metric, k, args.cpu_sample_rows)
