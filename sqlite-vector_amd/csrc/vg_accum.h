@@ -11,6 +11,7 @@
 #pragma once
 
 #include "vg_device.h"
+#include "vg_half.h"
 
 template <int VT, int ACC> struct Accum;
 
@@ -52,7 +53,7 @@ template <int ACC> struct Accum<T_F32, ACC> {
         return s;
     }
 
-    __device__ inline bool special() const { return false; }
+    __device__ inline bool special(const QStat &, int) const { return false; }
 
     __device__ inline float finish(const QStat &qs, int lpr_log2, int root) {
         float a = vg_group_sum((a0 + a1) + (a2 + a3), lpr_log2);
@@ -108,7 +109,7 @@ template <int VT, int ACC> struct AccumInt {
         return s;
     }
 
-    __device__ inline bool special() const { return false; }
+    __device__ inline bool special(const QStat &, int) const { return false; }
 
     // int -> float the way the reference's totals convert: u8 totals are uint32_t everywhere, i8 L2 totals are
     // uint32_t (distance-avx2.c:816) while i8 dot / L1 totals are int32_t (:871, :925)
@@ -136,3 +137,7 @@ template <int VT, int ACC> struct AccumInt {
 
 template <int ACC> struct Accum<T_U8, ACC> : AccumInt<T_U8, ACC> {};
 template <int ACC> struct Accum<T_I8, ACC> : AccumInt<T_I8, ACC> {};
+
+// ============================================================================================ f16 / bf16 (vg_half.h)
+template <int ACC> struct Accum<T_F16, ACC> : AccumHalf<T_F16, ACC> {};
+template <int ACC> struct Accum<T_BF16, ACC> : AccumHalf<T_BF16, ACC> {};

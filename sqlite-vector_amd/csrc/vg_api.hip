@@ -410,10 +410,8 @@ static scan_fn_t pick_type(int vtype, int acc, int U) {
         case VG_TYPE_F32: return pick_acc<T_F32, NT>(acc, U);
         case VG_TYPE_U8: return pick_acc<T_U8, NT>(acc, U);
         case VG_TYPE_I8: return pick_acc<T_I8, NT>(acc, U);
-#ifdef VG_HAVE_HALF_TYPES
         case VG_TYPE_F16: return pick_acc<T_F16, NT>(acc, U);
         case VG_TYPE_BF16: return pick_acc<T_BF16, NT>(acc, U);
-#endif
     }
     return nullptr;
 }

@@ -1,0 +1,254 @@
+// vg_half.h - f16 / bf16 support for the scan kernel.
+//
+// Fast path (Accum<T_F16|T_BF16, ACC>): rows made of finite values.  Arithmetic follows distance-avx2.c:
+//   f16  : f32 difference / f32 product (exact for halves), widened to f64, f64 accumulation   (:166-340)
+//   bf16 : f64 difference; f32 product widened to f64; f64 accumulation                          (:368-569)
+// Only the f64 summation ORDER differs from the 2 x 4-lane AVX2 accumulators, which is invisible after the final
+// rounding to float except in the last ulp.
+//
+// Any Inf/NaN element (exponent field all ones) in the row - or in the query - sends that row to the SLOW path:
+// the owning lane replays the reference's algorithm element by element, including its block(8)/tail split and
+// its quirks, so special-value results are bit-identical to distance-avx2.c:
+//   * Inf mismatch -> +Inf (L2/L1); NaN lanes contribute 0; same-signed Inf pair: 0 in a block, NaN in the tail;
+//   * dot: the first Inf-involving lane (in element order) that is not Inf*0 decides +-Inf; bf16 blocks test Inf
+//     BEFORE NaN and let Inf*0 poison the sum with NaN (distance-avx2.c:502-531), tails ignore such lanes;
+//   * cosine: f16 any Inf -> 1.0; non-finite dot / non-positive norms -> 1.0; clamp to [-1, 1].
+#pragma once
+
+#include "vg_device.h"
+
+typedef _Float16 vg_half2 __attribute__((ext_vector_type(2)));
+
+__device__ inline float vg_h2f(uint32_t h16) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h16); }
+__device__ inline float vg_b2f(uint32_t b16) { return __uint_as_float(b16 << 16); }
+
+template <int VT> __device__ inline float vg_elem_f32(uint32_t bits16) { return VT == T_F16 ? vg_h2f(bits16) : vg_b2f(bits16); }
+template <int VT> __device__ inline bool vg_is_inf16(uint32_t h) { return VT == T_F16 ? (h & 0x7FFFu) == 0x7C00u : (h & 0x7FFFu) == 0x7F80u; }
+template <int VT> __device__ inline bool vg_is_nan16(uint32_t h) {
+    return VT == T_F16 ? ((h & 0x7C00u) == 0x7C00u && (h & 0x03FFu)) : ((h & 0x7F80u) == 0x7F80u && (h & 0x007Fu));
+}
+__device__ inline bool vg_is_zero16(uint32_t h) { return (h & 0x7FFFu) == 0; }
+__device__ inline uint32_t vg_sign16(uint32_t h) { return (h >> 15) & 1u; }
+
+// nonzero iff either 16-bit half of w has an all-ones exponent (Inf or NaN)
+template <int VT> __device__ inline uint32_t vg_special_pair(uint32_t w) {
+    if (VT == T_F16) return ((w & 0x7C007C00u) + 0x04000400u) & 0x80008000u;
+    return ((w & 0x7F807F80u) + 0x00800080u) & 0x80008000u;
+}
+
+// two packed 16-bit elements -> two floats
+template <int VT> __device__ inline void vg_unpack2(uint32_t w, float &lo, float &hi) {
+    if (VT == T_F16) {
+        vg_half2 h = __builtin_bit_cast(vg_half2, w);
+        lo = (float)h.x; hi = (float)h.y;
+    } else {
+        lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xFFFF0000u);
+    }
+}
+
+// ============================================================================================ fast path
+
+template <int VT, int ACC> struct AccumHalf {
+    double a;               // L2: sum d^2 | L1: sum |d| | DOT/COS: sum q*x
+    double n;               // COS: sum x*x
+    uint32_t flag;          // nonzero once an Inf/NaN element was seen in this lane's part of the row
+    struct QStat { double qq; uint32_t qspecial; };
+
+    __device__ inline void init() { a = 0.0; n = 0.0; flag = 0; }
+
+    __device__ inline void pair(uint32_t qw, uint32_t xw) {
+        flag |= vg_special_pair<VT>(xw);
+        float q0, q1, x0, x1;
+        vg_unpack2<VT>(qw, q0, q1);
+        vg_unpack2<VT>(xw, x0, x1);
+        if (ACC == A_L2) {
+            if (VT == T_F16) {              // f32 subtract, square in f64 (distance-avx2.c:186-205)
+                const double d0 = (double)(q0 - x0), d1 = (double)(q1 - x1);
+                a = fma(d0, d0, a); a = fma(d1, d1, a);
+            } else {                         // f64 subtract (distance-avx2.c:383-409)
+                const double d0 = (double)q0 - (double)x0, d1 = (double)q1 - (double)x1;
+                a = fma(d0, d0, a); a = fma(d1, d1, a);
+            }
+        } else if (ACC == A_L1) {
+            if (VT == T_F16) { a += (double)fabsf(q0 - x0); a += (double)fabsf(q1 - x1); }
+            else { a += fabs((double)q0 - (double)x0); a += fabs((double)q1 - (double)x1); }
+        } else {                             // f32 product (exact for finite halves / bf16 unless it over/underflows)
+            a += (double)(q0 * x0); a += (double)(q1 * x1);
+            if (ACC == A_COS) { n += (double)(x0 * x0); n += (double)(x1 * x1); }
+        }
+    }
+    __device__ inline void chunk(const uint4 &qv, const uint4 &xv) {
+        pair(qv.x, xv.x); pair(qv.y, xv.y); pair(qv.z, xv.z); pair(qv.w, xv.w);
+    }
+
+    template <int U>
+    __device__ static inline QStat query_stat(const uint4 (&q)[U], int lpr_log2) {
+        QStat s; s.qq = 0.0;
+        uint32_t sp = 0;
+        double t = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sp |= vg_special_pair<VT>(w[j]);
+                float lo, hi;
+                vg_unpack2<VT>(w[j], lo, hi);
+                t += (double)(lo * lo); t += (double)(hi * hi);
+            }
+        }
+        s.qspecial = vg_group_or(sp, lpr_log2);
+        if (ACC == A_COS) s.qq = vg_group_sum(t, lpr_log2);
+        return s;
+    }
+
+    // true for every lane of the group if any lane saw a special element (or the query has one)
+    __device__ inline bool special(const QStat &qs, int lpr_log2) const { return (vg_group_or(flag, lpr_log2) | qs.qspecial) != 0; }
+
+    __device__ inline float finish(const QStat &qs, int lpr_log2, int root) {
+        const double s = vg_group_sum(a, lpr_log2);
+        if (ACC == A_L2) return root ? (float)sqrt(s) : (float)s;                 // distance-avx2.c:217, :421
+        if (ACC == A_L1) return (float)s;
+        if (ACC == A_DOT) return (float)(-s);
+        const double nn = vg_group_sum(n, lpr_log2);
+        // distance-avx2.c:343-364 / :571-582: float epilogue on the three rounded dot products
+        const float dot = (float)s;
+        const float na = sqrtf((float)qs.qq), nb = sqrtf((float)nn);
+        if (!(na > 0.0f) || !(nb > 0.0f) || !isfinite(na) || !isfinite(nb) || !isfinite(dot)) return 1.0f;
+        float cs = __fdiv_rn(dot, na * nb);
+        if (cs > 1.0f) cs = 1.0f;
+        if (cs < -1.0f) cs = -1.0f;
+        return 1.0f - cs;
+    }
+};
+
+// ============================================================================================ slow path (one lane, exact)
+
+__device__ inline double vg_hsum4(const double v[4]) { return (v[0] + v[2]) + (v[1] + v[3]); }   // hsum256d, :25-32
+
+template <int VT> __device__ inline bool vg_inf_mismatch(uint32_t x, uint32_t y) {
+    const bool xi = vg_is_inf16<VT>(x), yi = vg_is_inf16<VT>(y);
+    return (xi || yi) && !(xi && yi && vg_sign16(x) == vg_sign16(y));
+}
+
+// L2 / L1 for f16 (distance-avx2.c:166-279) and bf16 (:368-489)
+template <int VT, bool IS_L1>
+__device__ inline float vg_slow_l2_l1(const uint16_t *a, const uint16_t *b, int n, int root) {
+    double acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        for (int k = 0; k < 8; ++k) if (vg_inf_mismatch<VT>(a[i + k], b[i + k])) return INFINITY;
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t x = a[i + k], y = b[i + k];
+            double d;
+            if (VT == T_F16) {
+                if (vg_is_nan16<VT>(x) || vg_is_nan16<VT>(y)) d = 0.0;
+                else {
+                    float df = vg_h2f(x) - vg_h2f(y);
+                    if (IS_L1) df = fabsf(df);
+                    d = (df != df) ? 0.0 : (double)df;
+                }
+            } else {
+                d = (double)vg_b2f(x) - (double)vg_b2f(y);
+                if (IS_L1) d = fabs(d);
+                if (d != d) d = 0.0;
+            }
+            // lanes 0-3 -> first accumulator, lanes 4-7 -> second (L1 uses ONE accumulator: lane k then lane k+4)
+            if (IS_L1) { acc0[k & 3] = acc0[k & 3] + d; }
+            else if (k < 4) acc0[k] = acc0[k] + d * d;
+            else acc1[k - 4] = acc1[k - 4] + d * d;
+        }
+    }
+    double sum = IS_L1 ? vg_hsum4(acc0) : (vg_hsum4(acc0) + vg_hsum4(acc1));
+    for (; i < n; ++i) {
+        const uint32_t x = a[i], y = b[i];
+        if (vg_inf_mismatch<VT>(x, y)) return INFINITY;
+        if (vg_is_nan16<VT>(x) || vg_is_nan16<VT>(y)) continue;
+        const double d = (double)vg_elem_f32<VT>(x) - (double)vg_elem_f32<VT>(y);
+        if (IS_L1) sum += fabs(d); else sum = fma(d, d, sum);
+    }
+    if (IS_L1) return (float)sum;
+    return root ? (float)sqrt(sum) : (float)sum;
+}
+
+// returns -dot like the reference (distance-avx2.c:281-340 f16, :491-569 bf16)
+template <int VT>
+__device__ inline float vg_slow_dot(const uint16_t *a, const uint16_t *b, int n) {
+    double acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        float pf[8];
+        if (VT == T_F16) {
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t x = a[i + k], y = b[i + k];
+                if (vg_is_nan16<VT>(x) || vg_is_nan16<VT>(y)) { pf[k] = 0.0f; continue; }
+                const bool xi = vg_is_inf16<VT>(x), yi = vg_is_inf16<VT>(y);
+                if (xi || yi) {
+                    if ((xi && vg_is_zero16(y)) || (yi && vg_is_zero16(x))) pf[k] = 0.0f;
+                    else return (vg_sign16(x) ^ vg_sign16(y)) ? INFINITY : -INFINITY;
+                } else {
+                    const float p = vg_h2f(x) * vg_h2f(y);
+                    if (isinf(p)) return (p > 0) ? -INFINITY : INFINITY;
+                    pf[k] = (p != p) ? 0.0f : p;
+                }
+            }
+        } else {
+            for (int k = 0; k < 8; ++k) {                       // Inf test first; Inf*0 is only exempted from the return
+                const uint32_t x = a[i + k], y = b[i + k];
+                const bool xi = vg_is_inf16<VT>(x), yi = vg_is_inf16<VT>(y);
+                if (xi || yi) {
+                    if ((xi && vg_is_zero16(y)) || (yi && vg_is_zero16(x))) continue;
+                    return (vg_sign16(x) ^ vg_sign16(y)) ? INFINITY : -INFINITY;
+                }
+            }
+            for (int k = 0; k < 8; ++k) {
+                float x = vg_b2f(a[i + k]), y = vg_b2f(b[i + k]);
+                if (x != x) x = 0.0f;
+                if (y != y) y = 0.0f;
+                pf[k] = x * y;                                   // Inf * 0 -> NaN stays in the sum
+            }
+        }
+        for (int k = 0; k < 4; ++k) { acc0[k] = acc0[k] + (double)pf[k]; acc1[k] = acc1[k] + (double)pf[k + 4]; }
+    }
+    double dot = vg_hsum4(acc0);
+    dot += vg_hsum4(acc1);
+    for (; i < n; ++i) {
+        const uint32_t x = a[i], y = b[i];
+        if (vg_is_nan16<VT>(x) || vg_is_nan16<VT>(y)) continue;
+        const bool xi = vg_is_inf16<VT>(x), yi = vg_is_inf16<VT>(y);
+        if (xi || yi) {
+            if ((xi && vg_is_zero16(y)) || (yi && vg_is_zero16(x))) continue;
+            return (vg_sign16(x) ^ vg_sign16(y)) ? INFINITY : -INFINITY;
+        }
+        const double p = (double)vg_elem_f32<VT>(x) * (double)vg_elem_f32<VT>(y);
+        if (VT == T_F16) {
+            if (isinf(p)) return (p > 0) ? -INFINITY : INFINITY;
+            if (p == p) dot += p;
+        } else {
+            dot += p;
+        }
+    }
+    return (float)(-dot);
+}
+
+template <int VT>
+__device__ inline float vg_slow_cos(const uint16_t *a, const uint16_t *b, int n) {
+    if (VT == T_F16)                                             // distance-avx2.c:347-350
+        for (int i = 0; i < n; ++i) if (vg_is_inf16<VT>(a[i]) || vg_is_inf16<VT>(b[i])) return 1.0f;
+    const float dot = -vg_slow_dot<VT>(a, b, n);
+    const float na = sqrtf(-vg_slow_dot<VT>(a, a, n));
+    const float nb = sqrtf(-vg_slow_dot<VT>(b, b, n));
+    if (!(na > 0.0f) || !(nb > 0.0f) || !isfinite(na) || !isfinite(nb) || !isfinite(dot)) return 1.0f;
+    float cs = __fdiv_rn(dot, na * nb);
+    if (cs > 1.0f) cs = 1.0f;
+    if (cs < -1.0f) cs = -1.0f;
+    return 1.0f - cs;
+}
+
+template <int VT, int ACC>
+__device__ inline float vg_slow_distance(const uint16_t *query, const uint16_t *row, int dim, int root) {
+    if (ACC == A_L2) return vg_slow_l2_l1<VT, false>(query, row, dim, root);
+    if (ACC == A_L1) return vg_slow_l2_l1<VT, true>(query, row, dim, 0);
+    if (ACC == A_DOT) return vg_slow_dot<VT>(query, row, dim);
+    return vg_slow_cos<VT>(query, row, dim);
+}

@@ -87,8 +87,15 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) acc.chunk(q[u], cur[u]);
         const long long row = b * rpb + rib;
-        float d = vg_clamp(acc.finish(qstat, lpr_log2, a.root));
         const bool owner = (sub == 0) && (row < a.n_rows);
+        float d = acc.finish(qstat, lpr_log2, a.root);
+        if constexpr (VT == T_F16 || VT == T_BF16) {
+            // rows (or a query) holding Inf/NaN: the owning lane replays the reference algorithm exactly (vg_half.h)
+            if (acc.special(qstat, lpr_log2) && owner)
+                d = vg_slow_distance<VT, ACC>(reinterpret_cast<const uint16_t *>(qs),
+                                              reinterpret_cast<const uint16_t *>(a.rows + row * a.stride), a.dim, a.root);
+        }
+        d = vg_clamp(d);
         if (store_mode) {
             if (owner) a.out_dist[row] = d;
         } else {

@@ -252,3 +252,53 @@ def test_batch_entry_point(pkg, orc):
         one_ids, one_dist = c.scan_topk(dg.DOT, qs[i], k)
         assert cnt[i] == k and ids[i].tolist() == one_ids.tolist() and np.array_equal(dist[i], one_dist)
     c.close()
+
+
+# ------------------------------------------------------------------------------------------------- f16 / bf16
+
+@pytest.mark.parametrize("vt", [dg.F16, dg.BF16])
+@pytest.mark.parametrize("dim", (1, 5, 8, 13, 64, 100, 384, 768, 1024, 2048))
+def test_half_types_finite_rows_vs_oracle(pkg, orc, vt, dim):
+    """finite data: f64 accumulation like distance-avx2.c, only the summation order differs -> <= 1e-5 relative
+    (in practice the float results are bit-identical except for rare last-ulp roundings)."""
+    n = 2000
+    rows = dg.corpus(vt, n, dim, 500 + dim)
+    q = dg.query(vt, dim, 501 + dim)
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    for metric in dg.ALL_METRICS:
+        want = orc.scan_distances(orc.AVX2, metric, vt, q, rows)
+        got = c.scan_distances(metric, q)
+        _check_float_distances(got, want, vt, metric, q, rows)
+        ulp_off = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+        assert ulp_off.max() <= (2 if metric in (dg.L2, dg.SQUARED_L2, dg.L1) else 1 << 30)
+        ids, dist = c.scan_topk(metric, q, 20)
+        oids, odist, _ = orc.topk_ordered(got, None, 20)
+        assert ids.tolist() == oids.tolist() and np.array_equal(dist, odist)
+    c.close()
+
+
+@pytest.mark.parametrize("vt", [dg.F16, dg.BF16])
+@pytest.mark.parametrize("dim", (5, 8, 13, 16, 35, 384))
+def test_half_types_special_values_bit_exact(pkg, orc, vt, dim):
+    """rows / queries holding Inf, NaN, max-magnitude and subnormal lanes (block and tail positions) take the exact
+    slow path: bit-identical to the reference's distance-avx2.c results, quirks included."""
+    _, rows = dg.edge_rows(vt, dim, 1000 + dim)
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    special = np.zeros(rows.shape[0], dtype=bool)
+    expo = 0x7C00 if vt == dg.F16 else 0x7F80
+    special |= ((rows & expo) == expo).any(axis=1)
+    for qi, q in enumerate(dg.edge_queries(vt, dim, 2000 + dim)):
+        qspecial = bool(((q & expo) == expo).any())
+        for metric in dg.ALL_METRICS:
+            want = orc.scan_distances(orc.AVX2, metric, vt, q, rows)
+            got = c.scan_distances(metric, q)
+            sel = np.ones_like(special) if qspecial else special
+            assert dg.same_float_bits(got[sel], want[sel]), (dg.TYPE_NAMES[vt], dg.METRIC_NAMES[metric], dim, qi,
+                                                             got[sel], want[sel])
+            _check_float_distances(got[~sel], want[~sel], vt, metric, q, rows[~sel])
+            ids, dist = c.scan_topk(metric, q, 64)
+            oids, odist, _ = orc.topk_ordered(got, None, 64)
+            assert ids.tolist() == oids.tolist()
+    c.close()
