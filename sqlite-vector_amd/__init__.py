@@ -26,6 +26,7 @@ F32, F16, BF16, U8, I8 = 1, 2, 3, 4, 5
 L2, SQUARED_L2, COSINE, DOT, L1 = 1, 2, 3, 4, 5
 QUANT_U8, QUANT_S8 = 1, 2
 KEY_EMPTY = 0xFFFFFFFFFFFFFFFF
+HALF_TYPES = True            # f16 / bf16 scan kernels are built in
 TYPE_SIZE = {F32: 4, F16: 2, BF16: 2, U8: 1, I8: 1}
 
 

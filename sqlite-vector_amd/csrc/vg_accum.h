@@ -54,6 +54,7 @@ template <int ACC> struct Accum<T_F32, ACC> {
     }
 
     __device__ inline bool special(const QStat &, int) const { return false; }
+    __device__ static inline void merge_qstat(QStat &into, const QStat &part) { into.qq += part.qq; }
 
     __device__ inline float finish(const QStat &qs, int lpr_log2, int root) {
         float a = vg_group_sum((a0 + a1) + (a2 + a3), lpr_log2);
@@ -110,6 +111,7 @@ template <int VT, int ACC> struct AccumInt {
     }
 
     __device__ inline bool special(const QStat &, int) const { return false; }
+    __device__ static inline void merge_qstat(QStat &into, const QStat &part) { into.qq += part.qq; }
 
     // int -> float the way the reference's totals convert: u8 totals are uint32_t everywhere, i8 L2 totals are
     // uint32_t (distance-avx2.c:816) while i8 dot / L1 totals are int32_t (:871, :925)

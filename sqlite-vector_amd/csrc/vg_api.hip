@@ -132,7 +132,7 @@ extern "C" int vg_corpus_create(int device, int vtype, int dim, int64_t capacity
     if (ndev <= 0) return vg_fail(VG_ERR_NO_DEVICE, "no HIP device available (the scan path is GPU-only)");
     if (device < 0 || device >= ndev) return vg_fail(VG_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
     int64_t row_bytes = (int64_t)dim * es;
-    if (row_bytes > 64 * 1024) return vg_fail(VG_ERR_UNSUPPORTED, "rows larger than 64 KiB are not supported (dim=%d)", dim);
+    if (row_bytes > 128 * 1024) return vg_fail(VG_ERR_UNSUPPORTED, "rows larger than 128 KiB are not supported (dim=%d): the query must fit the CU's 160 KiB LDS", dim);
     HIP_TRY(hipSetDevice(device));
     vg_corpus *c = new vg_corpus();
     c->device = device;
@@ -352,20 +352,24 @@ extern "C" int vg_corpus_append_records(vg_corpus *c, const void *host_records, 
 
 typedef void (*scan_fn_t)(ScanArgs);
 
-struct Shape { int lpr_log2; int U; };
+struct Shape { int lpr_log2; int U; bool long_rows; };
 
 static const int kAllowedU[] = {1, 2, 3, 4, 6, 8};
 
 // Pick (lanes per row, chunks per lane): cover nch chunks with lpr*U slots, wasting as few lane slots as
 // possible; prefer >= 128 contiguous bytes per row per load instruction, then U = 6/4/3 (bytes in flight per lane).
-static bool choose_shape(int nch, Shape *out) {
+// 2-byte types cap U at 3: their f64 arithmetic (query pre-widened to f64 in VGPRs + 8 f64 accumulators) does not
+// fit the 128-VGPR budget of a 16-wave workgroup beyond that (U=6 spilled 200 B/lane and ran at 2.3 TB/s).
+// Rows that no (lpr <= 64, U <= cap) shape covers take the long-row kernel (query in LDS, one row per wavefront).
+static bool choose_shape(int nch, int elem_bytes, Shape *out) {
     static const int pref[9] = {0, 1, 2, 4, 5, 0, 6, 0, 3};   // preference rank by U (higher is better)
-    double best_eff = -1.0; int best_flag = -1, best_pref = -1; Shape best = {0, 0};
+    const int max_u = (elem_bytes == 2) ? 3 : 8;
+    double best_eff = -1.0; int best_flag = -1, best_pref = -1; Shape best = {0, 0, false};
     for (int l2 = 0; l2 <= 6; ++l2) {
         int lpr = 1 << l2;
         int need = (nch + lpr - 1) / lpr;
         int U = 0;
-        for (int a : kAllowedU) if (a >= need) { U = a; break; }
+        for (int a : kAllowedU) if (a >= need && a <= max_u) { U = a; break; }
         if (!U) continue;
         double eff = (double)nch / ((double)lpr * U);
         int flag = (lpr >= 8 || lpr >= nch) ? 1 : 0;
@@ -373,9 +377,9 @@ static bool choose_shape(int nch, Shape *out) {
                       (fabs(eff - best_eff) <= 1e-9 && (flag > best_flag || (flag == best_flag && pref[U] > best_pref)));
         if (better) { best_eff = eff; best_flag = flag; best_pref = pref[U]; best.lpr_log2 = l2; best.U = U; }
     }
-    if (best.U == 0) return false;
+    if (best.U == 0 || env_int("VG_FORCE_LONG", 0)) { best.lpr_log2 = 6; best.U = VG_LONG_U; best.long_rows = true; }
     int fl = env_int("VG_LPR_LOG2", -1), fu = env_int("VG_U", -1);   // experiment overrides
-    if (fl >= 0 && fu > 0 && (nch + (1 << fl) - 1) / (1 << fl) <= fu) { best.lpr_log2 = fl; best.U = fu; }
+    if (!best.long_rows && fl >= 0 && fu > 0 && (nch + (1 << fl) - 1) / (1 << fl) <= fu) { best.lpr_log2 = fl; best.U = fu; }
     *out = best;
     return true;
 }
@@ -416,8 +420,32 @@ static scan_fn_t pick_type(int vtype, int acc, int U) {
     return nullptr;
 }
 
-static scan_fn_t pick_kernel(int vtype, int acc, int U, bool nt) {
-    return nt ? pick_type<true>(vtype, acc, U) : pick_type<false>(vtype, acc, U);
+template <int VT, bool NT>
+static scan_fn_t pick_long_acc(int acc) {
+    switch (acc) {
+        case A_L2: return vg_scan_long_kernel<VT, A_L2, NT>;
+        case A_COS: return vg_scan_long_kernel<VT, A_COS, NT>;
+        case A_DOT: return vg_scan_long_kernel<VT, A_DOT, NT>;
+        case A_L1: return vg_scan_long_kernel<VT, A_L1, NT>;
+    }
+    return nullptr;
+}
+
+template <bool NT>
+static scan_fn_t pick_long_type(int vtype, int acc) {
+    switch (vtype) {
+        case VG_TYPE_F32: return pick_long_acc<T_F32, NT>(acc);
+        case VG_TYPE_U8: return pick_long_acc<T_U8, NT>(acc);
+        case VG_TYPE_I8: return pick_long_acc<T_I8, NT>(acc);
+        case VG_TYPE_F16: return pick_long_acc<T_F16, NT>(acc);
+        case VG_TYPE_BF16: return pick_long_acc<T_BF16, NT>(acc);
+    }
+    return nullptr;
+}
+
+static scan_fn_t pick_kernel(int vtype, int acc, const Shape &s, bool nt) {
+    if (s.long_rows) return nt ? pick_long_type<true>(vtype, acc) : pick_long_type<false>(vtype, acc);
+    return nt ? pick_type<true>(vtype, acc, s.U) : pick_type<false>(vtype, acc, s.U);
 }
 
 // stream with non-temporal loads once the corpus cannot live in the 256 MiB Infinity Cache anyway
@@ -451,9 +479,9 @@ extern "C" const char *vg_scan_kernel_name(vg_corpus *c, int metric) {
     if (!c) return "";
     Shape s;
     int acc = metric_to_acc(metric);
-    if (acc < 0 || !choose_shape(c->nch, &s)) return "";
-    snprintf(c->kernel_name, sizeof(c->kernel_name), "scan_%s_%s_u%d_lpr%d%s", type_tag(c->vtype), acc_tag(acc), s.U,
-             1 << s.lpr_log2, use_nt_loads(c) ? "_nt" : "");
+    if (acc < 0 || !choose_shape(c->nch, c->es, &s)) return "";
+    snprintf(c->kernel_name, sizeof(c->kernel_name), "scan%s_%s_%s_u%d_lpr%d%s", s.long_rows ? "_long" : "",
+             type_tag(c->vtype), acc_tag(acc), s.U, 1 << s.lpr_log2, use_nt_loads(c) ? "_nt" : "");
     return c->kernel_name;
 }
 
@@ -463,13 +491,14 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     int acc = metric_to_acc(metric);
     if (acc < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
     Shape s;
-    if (!choose_shape(c->nch, &s)) return vg_fail(VG_ERR_UNSUPPORTED, "row of %d bytes needs the long-row path (not implemented)", (int)c->stride);
-    scan_fn_t fn = pick_kernel(c->vtype, acc, s.U, use_nt_loads(c));
+    choose_shape(c->nch, c->es, &s);
+    scan_fn_t fn = pick_kernel(c->vtype, acc, s, use_nt_loads(c));
     if (!fn) return vg_fail(VG_ERR_UNSUPPORTED, "no scan kernel for type %s", type_tag(c->vtype));
 
     const int rpb = VG_WAVE >> s.lpr_log2;
     const long long nbatch = (c->n_rows + rpb - 1) / rpb;
-    const int bpc = std::max(1, std::min(8, env_int("VG_BLOCKS_PER_CU", 4)));
+    // 16-wave workgroups: one per CU is what ~96 VGPRs admit (5 waves/SIMD); a second one only queues behind it
+    const int bpc = std::max(1, std::min(8, env_int("VG_BLOCKS_PER_CU", 1)));
     long long blocks = (nbatch + VG_WAVES_PER_BLOCK - 1) / VG_WAVES_PER_BLOCK;
     blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count * bpc));
 
@@ -485,7 +514,12 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     a.k = k;
     a.root = (metric == VG_DIST_L2) ? 1 : 0;
     a.dim = c->dim;
-    size_t smem = std::max<size_t>((size_t)c->nch * 16, (size_t)VG_WAVES_PER_BLOCK * VG_WAVE * sizeof(uint64_t));
+    size_t qbytes = (size_t)c->nch * 16;
+    if (s.long_rows) {
+        const size_t slice = (size_t)VG_WAVE * VG_LONG_U;               // the long kernel pads the query to whole slices
+        qbytes = ((c->nch + slice - 1) / slice) * slice * 16;
+    }
+    size_t smem = std::max<size_t>(qbytes, (size_t)VG_WAVES_PER_BLOCK * VG_WAVE * sizeof(uint64_t));
 
     hipEvent_t *evs = nullptr;
     if (c->profiling) {
@@ -495,6 +529,8 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
         ++c->prof_launches;
         hipEventRecord(evs[0], stream);
     }
+    if (smem > 64 * 1024)          // very long rows: the query alone needs more than the default dynamic-LDS window
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
     if (evs) hipEventRecord(evs[1], stream);
     if (!dev_out_dist) {

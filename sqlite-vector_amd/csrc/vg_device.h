@@ -9,7 +9,8 @@
 
 #define VG_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 #define VG_WAVE 64
-#define VG_BLOCK 256                 // 4 wavefronts per workgroup
+#define VG_BLOCK 1024                // 16 wavefronts per workgroup = one workgroup per CU at ~96 VGPRs; the 16 wave
+                                     // lists merge in LDS, so only ONE candidate list per CU reaches HBM
 #define VG_WAVES_PER_BLOCK (VG_BLOCK / VG_WAVE)
 #define VG_MAX_FUSED_K 64            // one list slot per lane
 
@@ -67,10 +68,18 @@ __device__ inline uint64_t vg_readlane64(uint64_t v, int lane_uniform) {
 
 // Sorted candidate list spread over the wavefront: lane i holds the i-th smallest key, `thr` (wave-uniform)
 // is the key in slot k-1, i.e. the current k-th best.  Insert = one shift-up + selects (no loop, no LDS).
+// whole-wavefront shift by one lane (lane i <- lane i-1, lane 0 <- 0) as two DPP moves (v_mov_b32_dpp wave_shr:1):
+// no LDS crossbar round trip, unlike __shfl_up (ds_bpermute_b32)
+__device__ inline uint64_t vg_wave_shr1(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ inline void vg_list_insert(uint64_t &mine, uint64_t &thr, uint64_t c, int lane, int k) {
-    uint64_t prev = __shfl_up(mine, 1);
-    bool gt = mine > c;
-    bool pgt = (lane > 0) && (prev > c);
+    const uint64_t prev = vg_wave_shr1(mine);        // lane 0 sees 0, which is never > c
+    const bool gt = mine > c;
+    const bool pgt = prev > c;
     mine = gt ? (pgt ? prev : c) : mine;
     thr = vg_readlane64(mine, k - 1);
 }

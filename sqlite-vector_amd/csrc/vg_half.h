@@ -49,14 +49,16 @@ template <int VT> __device__ inline void vg_unpack2(uint32_t w, float &lo, float
 // ============================================================================================ fast path
 
 template <int VT, int ACC> struct AccumHalf {
-    double a;               // L2: sum d^2 | L1: sum |d| | DOT/COS: sum q*x
-    double n;               // COS: sum x*x
+    // four independent f64 accumulators per lane: a single chain of dependent v_fma_f64 / v_add_f64 (8 per chunk)
+    // left the kernel latency-bound at ~5 TB/s
+    double a0, a1, a2, a3;  // L2: sum d^2 | L1: sum |d| | DOT/COS: sum q*x
+    double n0, n1, n2, n3;  // COS: sum x*x
     uint32_t flag;          // nonzero once an Inf/NaN element was seen in this lane's part of the row
     struct QStat { double qq; uint32_t qspecial; };
 
-    __device__ inline void init() { a = 0.0; n = 0.0; flag = 0; }
+    __device__ inline void init() { a0 = a1 = a2 = a3 = 0.0; n0 = n1 = n2 = n3 = 0.0; flag = 0; }
 
-    __device__ inline void pair(uint32_t qw, uint32_t xw) {
+    __device__ inline void pair(uint32_t qw, uint32_t xw, double &s0, double &s1, double &m0, double &m1) {
         flag |= vg_special_pair<VT>(xw);
         float q0, q1, x0, x1;
         vg_unpack2<VT>(qw, q0, q1);
@@ -64,21 +66,22 @@ template <int VT, int ACC> struct AccumHalf {
         if (ACC == A_L2) {
             if (VT == T_F16) {              // f32 subtract, square in f64 (distance-avx2.c:186-205)
                 const double d0 = (double)(q0 - x0), d1 = (double)(q1 - x1);
-                a = fma(d0, d0, a); a = fma(d1, d1, a);
+                s0 = fma(d0, d0, s0); s1 = fma(d1, d1, s1);
             } else {                         // f64 subtract (distance-avx2.c:383-409)
                 const double d0 = (double)q0 - (double)x0, d1 = (double)q1 - (double)x1;
-                a = fma(d0, d0, a); a = fma(d1, d1, a);
+                s0 = fma(d0, d0, s0); s1 = fma(d1, d1, s1);
             }
         } else if (ACC == A_L1) {
-            if (VT == T_F16) { a += (double)fabsf(q0 - x0); a += (double)fabsf(q1 - x1); }
-            else { a += fabs((double)q0 - (double)x0); a += fabs((double)q1 - (double)x1); }
+            if (VT == T_F16) { s0 += (double)fabsf(q0 - x0); s1 += (double)fabsf(q1 - x1); }
+            else { s0 += fabs((double)q0 - (double)x0); s1 += fabs((double)q1 - (double)x1); }
         } else {                             // f32 product (exact for finite halves / bf16 unless it over/underflows)
-            a += (double)(q0 * x0); a += (double)(q1 * x1);
-            if (ACC == A_COS) { n += (double)(x0 * x0); n += (double)(x1 * x1); }
+            s0 += (double)(q0 * x0); s1 += (double)(q1 * x1);
+            if (ACC == A_COS) { m0 += (double)(x0 * x0); m1 += (double)(x1 * x1); }
         }
     }
     __device__ inline void chunk(const uint4 &qv, const uint4 &xv) {
-        pair(qv.x, xv.x); pair(qv.y, xv.y); pair(qv.z, xv.z); pair(qv.w, xv.w);
+        pair(qv.x, xv.x, a0, a1, n0, n1); pair(qv.y, xv.y, a2, a3, n2, n3);
+        pair(qv.z, xv.z, a0, a1, n0, n1); pair(qv.w, xv.w, a2, a3, n2, n3);
     }
 
     template <int U>
@@ -102,15 +105,17 @@ template <int VT, int ACC> struct AccumHalf {
         return s;
     }
 
+    __device__ static inline void merge_qstat(QStat &into, const QStat &part) { into.qq += part.qq; into.qspecial |= part.qspecial; }
+
     // true for every lane of the group if any lane saw a special element (or the query has one)
     __device__ inline bool special(const QStat &qs, int lpr_log2) const { return (vg_group_or(flag, lpr_log2) | qs.qspecial) != 0; }
 
     __device__ inline float finish(const QStat &qs, int lpr_log2, int root) {
-        const double s = vg_group_sum(a, lpr_log2);
+        const double s = vg_group_sum((a0 + a1) + (a2 + a3), lpr_log2);
         if (ACC == A_L2) return root ? (float)sqrt(s) : (float)s;                 // distance-avx2.c:217, :421
         if (ACC == A_L1) return (float)s;
         if (ACC == A_DOT) return (float)(-s);
-        const double nn = vg_group_sum(n, lpr_log2);
+        const double nn = vg_group_sum((n0 + n1) + (n2 + n3), lpr_log2);
         // distance-avx2.c:343-364 / :571-582: float epilogue on the three rounded dot products
         const float dot = (float)s;
         const float na = sqrtf((float)qs.qq), nb = sqrtf((float)nn);

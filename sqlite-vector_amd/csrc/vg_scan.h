@@ -10,8 +10,8 @@
 //   * the query lives in VGPRs (U x uint4 per lane), staged through LDS once per workgroup;
 //   * per batch: U chunk folds -> butterfly over the lane group -> scalar epilogue -> clamp -> 64-bit key ->
 //     ballot against the wave's current k-th best; only the rare survivors touch the sorted list;
-//   * at the end the 4 wave lists of a workgroup merge through LDS and ONE list per workgroup goes to HBM
-//     (grid x 64 keys); vg_merge_kernel reduces those to the final k.
+//   * at the end the 16 wave lists of a workgroup merge through LDS (binary tree) and ONE list per workgroup -
+//     i.e. per CU - goes to HBM (grid x 64 keys); vg_merge_kernel reduces those to the final k.
 #pragma once
 
 #include "vg_accum.h"
@@ -108,19 +108,118 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
     }
     if (store_mode) return;
 
-    // ---- merge the workgroup's 4 lists through LDS; wave 0 publishes one list
+    // ---- merge the workgroup's 16 wave lists through LDS as a binary tree (4 levels); wave 0 publishes one list
     __syncthreads();                                   // everyone is done with the query staging area
     uint64_t *lists = reinterpret_cast<uint64_t *>(smem);
-    if (wave > 0) lists[wave * VG_WAVE + lane] = mine;
-    __syncthreads();
-    if (wave == 0) {
 #pragma unroll 1
-        for (int w = 1; w < VG_WAVES_PER_BLOCK; ++w) {
-            const uint64_t c = lists[w * VG_WAVE + lane];
+    for (int s = VG_WAVES_PER_BLOCK / 2; s >= 1; s >>= 1) {
+        if (wave >= s && wave < 2 * s) lists[wave * VG_WAVE + lane] = mine;
+        __syncthreads();
+        if (wave < s) {
+            const uint64_t c = lists[(wave + s) * VG_WAVE + lane];
             vg_list_offer(c, (lane < k) && (c != VG_EMPTY_KEY), mine, thr, lane, k);
         }
-        a.cand[(long long)blockIdx.x * VG_WAVE + lane] = (lane < k) ? mine : VG_EMPTY_KEY;
     }
+    if (wave == 0) a.cand[(long long)blockIdx.x * VG_WAVE + lane] = (lane < k) ? mine : VG_EMPTY_KEY;
+}
+
+// Long rows (more 16-byte chunks than 64 lanes x the largest register-resident U): one row per wavefront per step,
+// the row is consumed in `S` slices of 64 x VG_LONG_U chunks with the accumulator carried across slices and the
+// query slice read from LDS (ds_read_b128) instead of living in VGPRs.  Same epilogue / top-k tail as above.
+#define VG_LONG_U 2
+template <int VT, int ACC, bool NT>
+__global__ __launch_bounds__(VG_BLOCK) void vg_scan_long_kernel(ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & (VG_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    constexpr int U = VG_LONG_U;
+    const int slice = VG_WAVE * U;                                  // chunks per slice
+    const int S = (a.nch + slice - 1) / slice;
+    const int nch_pad = S * slice;
+
+    // ---- query: global -> LDS, zero padded to whole slices; the candidate lists reuse the space at the end
+    uint4 *qs = reinterpret_cast<uint4 *>(smem);
+    for (int c = threadIdx.x; c < nch_pad; c += VG_BLOCK)
+        qs[c] = (c < a.nch) ? reinterpret_cast<const uint4 *>(a.query)[c] : make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    // query statistics over the whole query (norm / special flags), folded slice by slice
+    typename Accum<VT, ACC>::QStat qstat;
+    {
+        uint4 q0[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) q0[u] = qs[u * VG_WAVE + lane];
+        qstat = Accum<VT, ACC>::template query_stat<U>(q0, 6);
+        for (int s = 1; s < S; ++s) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) q0[u] = qs[s * slice + u * VG_WAVE + lane];
+            Accum<VT, ACC>::merge_qstat(qstat, Accum<VT, ACC>::template query_stat<U>(q0, 6));
+        }
+    }
+
+    uint64_t mine = VG_EMPTY_KEY, thr = VG_EMPTY_KEY;
+    const int k = a.k;
+    const bool store_mode = (a.out_dist != nullptr);
+    const long long wstride = (long long)gridDim.x * VG_WAVES_PER_BLOCK;
+    const long long gw = (long long)blockIdx.x * VG_WAVES_PER_BLOCK + wave;
+
+    // flattened (row, slice) stream per wavefront, one slice prefetched
+    auto load_slice = [&](uint4 (&dst)[U], long long row, int s) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = s * slice + u * VG_WAVE + lane;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (row < a.n_rows && c < a.nch) v = vg_load16<NT>(a.rows + row * a.stride + (long long)c * 16);
+            dst[u] = v;
+        }
+    };
+    uint4 cur[U], nxt[U];
+    long long row = gw;
+    load_slice(cur, row, 0);
+    Accum<VT, ACC> acc;
+    acc.init();
+    int s = 0;
+    while (row < a.n_rows) {
+        long long nrow = row;
+        int ns = s + 1;
+        if (ns == S) { ns = 0; nrow = row + wstride; }
+        load_slice(nxt, nrow, ns);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc.chunk(qs[s * slice + u * VG_WAVE + lane], cur[u]);
+        if (ns == 0) {                                              // row complete
+            float d = acc.finish(qstat, 6, a.root);
+            if constexpr (VT == T_F16 || VT == T_BF16) {
+                if (acc.special(qstat, 6) && lane == 0)
+                    d = vg_slow_distance<VT, ACC>(reinterpret_cast<const uint16_t *>(qs),
+                                                  reinterpret_cast<const uint16_t *>(a.rows + row * a.stride), a.dim, a.root);
+            }
+            d = vg_clamp(d);
+            if (store_mode) {
+                if (lane == 0) a.out_dist[row] = d;
+            } else {
+                vg_list_offer(vg_make_key(d, (uint32_t)row), (lane == 0) && (d < INFINITY), mine, thr, lane, k);
+            }
+            acc.init();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        row = nrow;
+        s = ns;
+    }
+    if (store_mode) return;
+
+    __syncthreads();
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);
+#pragma unroll 1
+    for (int t = VG_WAVES_PER_BLOCK / 2; t >= 1; t >>= 1) {
+        if (wave >= t && wave < 2 * t) lists[wave * VG_WAVE + lane] = mine;
+        __syncthreads();
+        if (wave < t) {
+            const uint64_t c = lists[(wave + t) * VG_WAVE + lane];
+            vg_list_offer(c, (lane < k) && (c != VG_EMPTY_KEY), mine, thr, lane, k);
+        }
+    }
+    if (wave == 0) a.cand[(long long)blockIdx.x * VG_WAVE + lane] = (lane < k) ? mine : VG_EMPTY_KEY;
 }
 
 // Final reduction of `nlists` sorted 64-slot lists to the k best.  One workgroup of 16 wavefronts: each wave
@@ -147,14 +246,14 @@ __global__ __launch_bounds__(VG_MERGE_WAVES * VG_WAVE) void vg_merge_kernel(cons
         for (int j = 0; j < VG_MERGE_DEPTH; ++j)
             vg_list_offer(c[j], (lane < k) && (c[j] != VG_EMPTY_KEY), mine, thr, lane, k);
     }
-    lists[wave * VG_WAVE + lane] = mine;
-    __syncthreads();
-    if (wave == 0) {
 #pragma unroll 1
-        for (int w = 1; w < VG_MERGE_WAVES; ++w) {
-            const uint64_t c = lists[w * VG_WAVE + lane];
+    for (int s = VG_MERGE_WAVES / 2; s >= 1; s >>= 1) {
+        if (wave >= s && wave < 2 * s) lists[wave * VG_WAVE + lane] = mine;
+        __syncthreads();
+        if (wave < s) {
+            const uint64_t c = lists[(wave + s) * VG_WAVE + lane];
             vg_list_offer(c, (lane < k) && (c != VG_EMPTY_KEY), mine, thr, lane, k);
         }
-        out_keys[lane] = (lane < k) ? mine : VG_EMPTY_KEY;
     }
+    if (wave == 0) out_keys[lane] = (lane < k) ? mine : VG_EMPTY_KEY;
 }

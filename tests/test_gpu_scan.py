@@ -302,3 +302,53 @@ def test_half_types_special_values_bit_exact(pkg, orc, vt, dim):
             oids, odist, _ = orc.topk_ordered(got, None, 64)
             assert ids.tolist() == oids.tolist()
     c.close()
+
+
+# ------------------------------------------------------------------------------------------------- long rows
+
+@pytest.mark.parametrize("vt,dim", [(dg.F32, 2304), (dg.F32, 5000), (dg.U8, 10000), (dg.I8, 8200), (dg.F16, 2048),
+                                    (dg.BF16, 4100), (dg.F16, 1600), (dg.F32, 20000)])
+def test_long_row_kernel_vs_oracle(pkg, orc, vt, dim):
+    """rows with more 16-byte chunks than a register-resident shape covers go through vg_scan_long_kernel
+    (query in LDS, one row per wavefront, sliced)."""
+    n = 300
+    rows = dg.corpus(vt, n, dim, 700 + dim)
+    q = dg.query(vt, dim, 701 + dim)
+    if vt in (dg.F16, dg.BF16):                       # a few special rows through the slow path as well
+        rows[5, dim - 1] = dg.F16_INF if vt == dg.F16 else dg.BF_INF
+        rows[9, 3] = dg.F16_NAN if vt == dg.F16 else dg.BF_NAN
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    assert "long" in c.kernel_name(dg.L2)
+    for metric in dg.ALL_METRICS:
+        want = orc.scan_distances(orc.AVX2, metric, vt, q, rows)
+        got = c.scan_distances(metric, q)
+        if vt in (dg.U8, dg.I8):
+            assert dg.same_float_bits(got, want), (vt, metric, dim)
+        else:
+            sp = np.zeros(n, dtype=bool)
+            if vt in (dg.F16, dg.BF16):
+                sp[[5, 9]] = True
+                assert dg.same_float_bits(got[sp], want[sp]), (vt, metric, got[sp], want[sp])
+            _check_float_distances(got[~sp], want[~sp], vt, metric, q, rows[~sp])
+        ids, dist = c.scan_topk(metric, q, 20)
+        oids, odist, _ = orc.topk_ordered(got, None, 20)
+        assert ids.tolist() == oids.tolist() and np.array_equal(dist, odist)
+    c.close()
+
+
+def test_long_row_kernel_forced_on_ordinary_rows(pkg, orc, monkeypatch):
+    """the long-row kernel must agree with the register-resident kernel on rows both can handle"""
+    dim, n = 384, 3000
+    rows = dg.corpus(dg.I8, n, dim, 41)
+    q = dg.query(dg.I8, dim, 42)
+    c = pkg.Corpus(pkg.I8, dim)
+    c.append(rows)
+    a = c.scan_distances(dg.COSINE, q)
+    ida, da = c.scan_topk(dg.COSINE, q, 33)
+    monkeypatch.setenv("VG_FORCE_LONG", "1")
+    assert "long" in c.kernel_name(dg.COSINE)
+    b = c.scan_distances(dg.COSINE, q)
+    idb, db = c.scan_topk(dg.COSINE, q, 33)
+    assert dg.same_float_bits(a, b) and ida.tolist() == idb.tolist() and np.array_equal(da, db)
+    c.close()
