@@ -19,9 +19,8 @@ EXT = os.path.join(HERE, "ext")
 LIB = os.path.join(HERE, "libvectorgpu.so")
 VEC = os.path.join(HERE, "vector.so")
 
-HIP_SOURCES = ["vg_api.hip"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wno-unused-value", "-Wno-unused-result"]
+HIP_SOURCES = ["vg_api.hip", "vg_select.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 
 def _newer(target, sources):
@@ -44,7 +43,21 @@ def build_gpu_library(force=False, verbose=False):
         [os.path.join(ROOT, "include", "vectorgpu.h")]
     if not force and not _newer(LIB, deps):
         return LIB
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB] + srcs
+    # one object per translation unit (compiled concurrently), then one link
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    objs, procs = [], []
+    for src in srcs:
+        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _newer(obj, [src] + deps):
+            cmd = [_hipcc()] + HIPCC_FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)

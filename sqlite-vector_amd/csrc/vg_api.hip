@@ -103,6 +103,10 @@ struct vg_corpus {
     uint64_t *h_keys = nullptr;    // pinned, 64 keys
     float *d_dist = nullptr;       // lazily sized to n_rows (stream scans / large k)
     int64_t d_dist_cap = 0;
+    uint64_t *d_sel_keys = nullptr, *d_sel_sorted = nullptr;   // k > 64 path: N keys, unsorted / sorted
+    void *d_sel_temp = nullptr;
+    size_t sel_temp_bytes = 0;
+    int64_t sel_cap = 0;
     int max_blocks = 0;
     int cu_count = 0;
 
@@ -179,6 +183,9 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_keys) hipFree(c->d_keys);
     if (c->h_keys) hipHostFree(c->h_keys);
     if (c->d_dist) hipFree(c->d_dist);
+    if (c->d_sel_keys) hipFree(c->d_sel_keys);
+    if (c->d_sel_sorted) hipFree(c->d_sel_sorted);
+    if (c->d_sel_temp) hipFree(c->d_sel_temp);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -608,25 +615,46 @@ extern "C" int vg_scan_distances(vg_corpus *c, int metric, const void *query, fl
     return VG_OK;
 }
 
-// k > 64: all N distances are produced by the same scan kernel (store mode) and the selection runs over the
-// N packed keys on the host side of the boundary.  Distances are GPU-computed; only the ordering of an
-// already-computed float array happens here.  (A device-side radix select replaces this in a later round.)
+// k > 64 (beyond the fused one-slot-per-lane list): store-mode scan -> key build -> device radix sort
+// (vg_select.hip).  Nothing is computed or ordered on the host; k keys come back and are decoded.
+extern "C" int vg_select_temp_bytes(long long n, size_t *bytes);
+extern "C" int vg_select_sorted_keys(const float *dist, long long n, uint64_t *keys_tmp, uint64_t *keys_sorted,
+                                     void *temp, size_t temp_bytes, hipStream_t stream);
+
 static int scan_topk_large_k(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids,
                              double *out_dist, int *out_count) {
-    std::vector<float> d((size_t)c->n_rows);
-    int rc = vg_scan_distances(c, metric, query, d.data());
+    int rc = ensure_dist_buffer(c);
     if (rc != VG_OK) return rc;
-    std::vector<uint64_t> keys;
-    keys.reserve((size_t)c->n_rows);
-    for (int64_t i = 0; i < c->n_rows; ++i)
-        if (d[(size_t)i] < INFINITY) keys.push_back(vg_make_key(d[(size_t)i], (uint32_t)i));
-    size_t cnt = std::min<size_t>((size_t)k, keys.size());
-    std::partial_sort(keys.begin(), keys.begin() + cnt, keys.end());
-    for (size_t i = 0; i < cnt; ++i) {
-        out_dist[i] = (double)vg_key_distance(keys[i]);
-        out_rowids[i] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(keys[i]));
+    if (c->sel_cap < c->n_rows) {
+        if (c->d_sel_keys) hipFree(c->d_sel_keys);
+        if (c->d_sel_sorted) hipFree(c->d_sel_sorted);
+        if (c->d_sel_temp) hipFree(c->d_sel_temp);
+        c->d_sel_keys = c->d_sel_sorted = nullptr; c->d_sel_temp = nullptr; c->sel_cap = 0;
+        if (vg_select_temp_bytes(c->n_rows, &c->sel_temp_bytes) != 0) return vg_fail(VG_ERR_HIP, "radix sort temp-size query failed");
+        HIP_TRY(hipMalloc(&c->d_sel_keys, (size_t)c->n_rows * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&c->d_sel_sorted, (size_t)c->n_rows * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&c->d_sel_temp, c->sel_temp_bytes ? c->sel_temp_bytes : 16));
+        c->sel_cap = c->n_rows;
     }
-    *out_count = (int)cnt;
+    stage_query(c, query);
+    HIP_TRY(hipMemcpyAsync(c->d_query, c->h_query, (size_t)c->stride, hipMemcpyHostToDevice, c->stream));
+    rc = launch_scan(c, metric, c->d_query, 0, nullptr, c->d_dist, c->stream);
+    if (rc != VG_OK) return rc;
+    if (vg_select_sorted_keys(c->d_dist, c->n_rows, c->d_sel_keys, c->d_sel_sorted, c->d_sel_temp, c->sel_temp_bytes, c->stream) != 0)
+        return vg_fail(VG_ERR_HIP, "device key sort failed: %s", hipGetErrorString(hipGetLastError()));
+    const size_t take = (size_t)std::min<int64_t>((int64_t)k, c->n_rows);
+    std::vector<uint64_t> keys(take);
+    HIP_TRY(hipMemcpyAsync(keys.data(), c->d_sel_sorted, take * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    collect_timing(c);
+    int cnt = 0;
+    for (size_t i = 0; i < take; ++i) {
+        if (keys[i] == VG_EMPTY_KEY) break;                   // NaN / +Inf rows sort last and are not results
+        out_dist[cnt] = (double)vg_key_distance(keys[i]);
+        out_rowids[cnt] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(keys[i]));
+        ++cnt;
+    }
+    *out_count = cnt;
     return VG_OK;
 }
 

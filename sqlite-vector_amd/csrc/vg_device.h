@@ -95,26 +95,44 @@ __device__ inline void vg_list_offer(uint64_t key, bool valid, uint64_t &mine, u
     }
 }
 
-// butterfly sum over the 2^lpr_log2 lanes that share a row; every lane of the group ends with the total
+// Butterfly sum over the 2^lpr_log2 lanes that share a row; every lane of the group ends with the (bitwise
+// identical) total.  Steps 1/2/4/8 stay inside a 16-lane DPP row and are single DPP moves feeding the add
+// (quad_perm, quad_perm, row_half_mirror, row_mirror) - no ds_bpermute round trip through the LDS crossbar, whose
+// ~100-cycle dependent latency per step made the 2-byte types latency-bound; only the 32- and 64-lane steps
+// (rows of >= 512 bytes per load) use the crossbar.
+#define VG_DPP_QUAD_PERM(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+#define VG_DPP_ROW_MIRROR 0x140
+#define VG_DPP_ROW_HALF_MIRROR 0x141
+
+template <int CTRL> __device__ inline uint32_t vg_dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ inline float vg_dpp(float v) { return __uint_as_float(vg_dpp_u32<CTRL>(__float_as_uint(v))); }
+template <int CTRL> __device__ inline uint32_t vg_dpp(uint32_t v) { return vg_dpp_u32<CTRL>(v); }
+template <int CTRL> __device__ inline double vg_dpp(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint64_t r = ((uint64_t)vg_dpp_u32<CTRL>((uint32_t)(b >> 32)) << 32) | vg_dpp_u32<CTRL>((uint32_t)b);
+    return __longlong_as_double((long long)r);
+}
+
 template <typename T>
 __device__ inline T vg_group_sum(T v, int lpr_log2) {
-    if (lpr_log2 > 0) v += __shfl_xor(v, 1);
-    if (lpr_log2 > 1) v += __shfl_xor(v, 2);
-    if (lpr_log2 > 2) v += __shfl_xor(v, 4);
-    if (lpr_log2 > 3) v += __shfl_xor(v, 8);
+    if (lpr_log2 > 0) v += vg_dpp<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(v);
+    if (lpr_log2 > 1) v += vg_dpp<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(v);
+    if (lpr_log2 > 2) v += vg_dpp<VG_DPP_ROW_HALF_MIRROR>(v);
+    if (lpr_log2 > 3) v += vg_dpp<VG_DPP_ROW_MIRROR>(v);
     if (lpr_log2 > 4) v += __shfl_xor(v, 16);
     if (lpr_log2 > 5) v += __shfl_xor(v, 32);
     return v;
 }
-template <typename T>
-__device__ inline T vg_group_or(T v, int lpr_log2) {
-    if (lpr_log2 > 0) v |= __shfl_xor(v, 1);
-    if (lpr_log2 > 1) v |= __shfl_xor(v, 2);
-    if (lpr_log2 > 2) v |= __shfl_xor(v, 4);
-    if (lpr_log2 > 3) v |= __shfl_xor(v, 8);
-    if (lpr_log2 > 4) v |= __shfl_xor(v, 16);
-    if (lpr_log2 > 5) v |= __shfl_xor(v, 32);
-    return v;
+
+// "does any lane of my group have flag != 0": one ballot + a per-lane shift/mask instead of a shuffle butterfly
+__device__ inline uint32_t vg_group_or(uint32_t flag, int lpr_log2) {
+    const unsigned long long m = __ballot(flag != 0);
+    const int lane = (int)(threadIdx.x & (VG_WAVE - 1));
+    const int base = lane & ~((1 << lpr_log2) - 1);
+    const unsigned long long gm = (lpr_log2 >= 6) ? ~0ull : ((1ull << (1 << lpr_log2)) - 1ull);
+    return ((m >> base) & gm) != 0ull ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------ epilogue math

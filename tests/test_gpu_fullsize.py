@@ -1,0 +1,143 @@
+"""Parity at BASELINE.json's full sizes (configs C2 and C3), where the CPU oracle cannot enumerate every row in a
+test's time budget.  Size-independent properties + independent device-side references:
+
+  C2 10M x 384 f32 L2 k=20   every one of the 10M distances vs an f64 torch reference (<= 1e-5 rel), top-20 vs
+                             torch.topk on the GPU's own distances, the 20 winners re-checked by the CPU oracle,
+                             idempotence (bit-identical reruns), sortedness, 3-shard == 1-shard.
+  C3 10M x 768 u8 cosine     EXACT: integer dot / norms computed independently (torch f64 matmul is exact for these
+                             magnitudes), float epilogue replayed with numpy float32 following distance-avx2.c:744-753
+                             -> all 10M distances must be bit-identical; top-20 identical; winners re-checked by the
+                             oracle; k=1000 goes through the on-device radix-sort path.
+"""
+import numpy as np
+import pytest
+
+import datagen as dg
+
+pytestmark = pytest.mark.gpu
+
+N = 10_000_000
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    torch.cuda.init()
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    if pkg.device_count() < 1:
+        pytest.fail("needs a GPU")
+    return pkg, torch
+
+
+def _build(pkg, torch, vt, dim, seed, keep_blocks=False):
+    c = pkg.Corpus(vt, dim, capacity=N)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    blocks = []
+    for r0 in range(0, N, 1_000_000):
+        if vt == pkg.F32:
+            t = torch.randn((1_000_000, dim), generator=gen, device="cuda", dtype=torch.float32)
+        else:
+            t = torch.randint(0, 256, (1_000_000, dim), generator=gen, device="cuda", dtype=torch.uint8)
+        torch.cuda.synchronize()
+        c.append_device(t.data_ptr(), 1_000_000, dim * pkg.TYPE_SIZE[vt])
+        blocks.append(t)
+    return c, blocks
+
+
+def test_c2_f32_l2_10m(env, orc):
+    pkg, torch = env
+    dim, k = 384, 20
+    c, blocks = _build(pkg, torch, pkg.F32, dim, 42)
+    assert c.rows == N and "_nt" in c.kernel_name(dg.L2)
+    q = np.random.default_rng(43).standard_normal(dim, dtype=np.float32)
+    qd = torch.from_numpy(q).cuda()
+
+    ids, dist = c.scan_topk(dg.L2, q, k)
+    assert len(ids) == k and np.all(np.diff(dist) >= 0)                       # sorted ascending
+    ids2, dist2 = c.scan_topk(dg.L2, q, k)
+    assert ids.tolist() == ids2.tolist() and np.array_equal(dist, dist2)     # idempotent, bit for bit
+
+    # all 10M distances on the device (store mode) vs an f64 reference of the same op
+    out = torch.empty(N, dtype=torch.float32, device="cuda")
+    st = torch.cuda.Stream()
+    qpad = torch.zeros(dim * 4, dtype=torch.uint8, device="cuda")
+    qpad.copy_(qd.view(torch.uint8))
+    torch.cuda.synchronize()
+    pkg._check(pkg.lib().vg_scan_distances_device(c.h, dg.L2, qpad.data_ptr(), out.data_ptr(), st.cuda_stream))
+    st.synchronize()
+    worst = 0.0
+    for b, t in enumerate(blocks):
+        ref = (t.double() - qd.double()).pow(2).sum(1).sqrt()
+        got = out[b * 1_000_000:(b + 1) * 1_000_000].double()
+        worst = max(worst, float(((got - ref).abs() / ref).max()))
+    assert worst <= 1e-5, worst
+    # selection is exact on the GPU's own floats: (distance, position) order == torch.topk + stable tie order
+    vals, idx = torch.topk(out, k, largest=False, sorted=True)
+    assert np.array_equal(vals.cpu().numpy().astype(np.float64), dist)
+    order = sorted(zip(vals.cpu().tolist(), idx.cpu().tolist()))
+    assert [i + 1 for _, i in order] == ids.tolist()
+    # the winners, recomputed by the pinned CPU oracle (reference arithmetic)
+    rows = np.stack([blocks[(i - 1) // 1_000_000][(i - 1) % 1_000_000].cpu().numpy() for i in ids.tolist()])
+    want = orc.scan_distances(orc.AVX2, dg.L2, dg.F32, q, rows).astype(np.float64)
+    assert np.allclose(dist, want, rtol=1e-5, atol=0)
+
+    # 3 row-range shards (ragged) == 1 shard
+    bounds = [0, 3_000_000, 7_000_000, N]
+    keys = torch.empty((3, 64), dtype=torch.int64, device="cuda")
+    shards = []
+    for g in range(3):
+        s = pkg.Corpus(pkg.F32, dim, capacity=bounds[g + 1] - bounds[g])
+        for b in range(bounds[g] // 1_000_000, bounds[g + 1] // 1_000_000):
+            s.append_device(blocks[b].data_ptr(), 1_000_000, dim * 4)
+        s.scan_topk_device(dg.L2, qpad.data_ptr(), k, keys[g].data_ptr(), st.cuda_stream)
+        shards.append(s)
+    st.synchronize()
+    pos, d3 = pkg.merge_keys(keys.cpu().numpy().view(np.uint64), bounds[:3], k)
+    assert (pos + 1).tolist() == ids.tolist() and np.array_equal(d3, dist)
+    for s in shards:
+        s.close()
+    c.close()
+
+
+def test_c3_u8_cosine_10m_bit_exact(env, orc):
+    pkg, torch = env
+    dim, k = 768, 20
+    c, blocks = _build(pkg, torch, pkg.U8, dim, 44)
+    q = np.random.default_rng(45).integers(0, 256, dim).astype(np.uint8)
+    qd64 = torch.from_numpy(q.astype(np.float64)).cuda()
+
+    # independent exact integer sums (f64 matmul is exact here: 768 * 255^2 < 2^53)
+    dot = np.empty(N, dtype=np.int64)
+    xx = np.empty(N, dtype=np.int64)
+    for b, t in enumerate(blocks):
+        for r0 in range(0, 1_000_000, 250_000):
+            x = t[r0:r0 + 250_000].double()
+            sl = slice(b * 1_000_000 + r0, b * 1_000_000 + r0 + 250_000)
+            dot[sl] = (x @ qd64).cpu().numpy().astype(np.int64)
+            xx[sl] = (x * x).sum(1).cpu().numpy().astype(np.int64)
+    qq = int((q.astype(np.int64) ** 2).sum())
+    # float epilogue of distance-avx2.c:744-753, one rounding per operation, in numpy float32
+    dot_f = dot.astype(np.uint32).astype(np.float32)
+    na = np.sqrt(np.float32(qq))
+    nb = np.sqrt(xx.astype(np.uint32).astype(np.float32))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = (np.float32(1.0) - dot_f / (na * nb)).astype(np.float32)
+    want[(xx == 0) | (qq == 0)] = 1.0
+    want[np.abs(want) <= 8 * np.finfo(np.float32).eps] = 0.0                  # the clamp, sqlite-vector.c:994-996
+
+    got = c.scan_distances(dg.COSINE, q)
+    assert dg.same_float_bits(got, want), np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0][:5]
+
+    ids, dist = c.scan_topk(dg.COSINE, q, k)
+    oids, odist, _ = orc.topk_ordered(want, None, k)
+    assert ids.tolist() == oids.tolist() and np.array_equal(dist, odist)
+    rows = np.stack([blocks[(i - 1) // 1_000_000][(i - 1) % 1_000_000].cpu().numpy() for i in ids.tolist()])
+    assert np.array_equal(orc.scan_distances(orc.AVX2, dg.COSINE, dg.U8, q, rows).astype(np.float64), dist)
+
+    # k > 64: on-device key sort path, at full size
+    ids_big, dist_big = c.scan_topk(dg.COSINE, q, 1000)
+    oids_big, odist_big, _ = orc.topk_ordered(want, None, 1000)
+    assert ids_big.tolist() == oids_big.tolist() and np.array_equal(dist_big, odist_big)
+    c.close()
