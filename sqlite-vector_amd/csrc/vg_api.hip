@@ -508,6 +508,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     const int bpc = std::max(1, std::min(8, env_int("VG_BLOCKS_PER_CU", 1)));
     long long blocks = (nbatch + VG_WAVES_PER_BLOCK - 1) / VG_WAVES_PER_BLOCK;
     blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count * bpc));
+    blocks = std::min<long long>(blocks, VG_SEL_MAX_HEADS);          // the final rank-select handles <= 256 lists
 
     ScanArgs a;
     a.rows = c->d_rows;
@@ -526,7 +527,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
         const size_t slice = (size_t)VG_WAVE * VG_LONG_U;               // the long kernel pads the query to whole slices
         qbytes = ((c->nch + slice - 1) / slice) * slice * 16;
     }
-    size_t smem = std::max<size_t>(qbytes, (size_t)VG_WAVES_PER_BLOCK * VG_WAVE * sizeof(uint64_t));
+    size_t smem = std::max<size_t>(qbytes, (size_t)VG_PUBLISH_LDS_BYTES);
 
     hipEvent_t *evs = nullptr;
     if (c->profiling) {
@@ -541,7 +542,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
     if (evs) hipEventRecord(evs[1], stream);
     if (!dev_out_dist) {
-        hipLaunchKernelGGL(vg_merge_kernel, dim3(1), dim3(VG_MERGE_WAVES * VG_WAVE), 0, stream,
+        hipLaunchKernelGGL(vg_merge_kernel, dim3(1), dim3(VG_MERGE_THREADS), 0, stream,
                            (const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys);
     }
     if (evs) hipEventRecord(evs[2], stream);

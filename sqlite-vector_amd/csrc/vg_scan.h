@@ -15,6 +15,20 @@
 #pragma once
 
 #include "vg_accum.h"
+#include "vg_lists.h"
+
+// LDS needed at the end of a scan workgroup: 16 wave lists + the selection scratch
+#define VG_PUBLISH_LDS_BYTES (VG_WAVES_PER_BLOCK * VG_WAVE * 8 + VG_SEL_SCRATCH_BYTES)
+
+// every wavefront deposits its sorted list in LDS, then the whole workgroup selects the k best into `dst` (global)
+__device__ inline void vg_block_publish(uint8_t *smem, uint64_t mine, int k, uint64_t *dst) {
+    const int lane = threadIdx.x & (VG_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);
+    lists[wave * VG_WAVE + lane] = (lane < k) ? mine : VG_EMPTY_KEY;
+    __syncthreads();
+    vg_select_lists(lists, VG_WAVES_PER_BLOCK, k, dst, smem + VG_WAVES_PER_BLOCK * VG_WAVE * 8);
+}
 
 typedef uint32_t vg_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -108,19 +122,9 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
     }
     if (store_mode) return;
 
-    // ---- merge the workgroup's 16 wave lists through LDS as a binary tree (4 levels); wave 0 publishes one list
+    // ---- the workgroup's 16 wave lists -> ONE list per CU in HBM (parallel rank-select, vg_lists.h)
     __syncthreads();                                   // everyone is done with the query staging area
-    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);
-#pragma unroll 1
-    for (int s = VG_WAVES_PER_BLOCK / 2; s >= 1; s >>= 1) {
-        if (wave >= s && wave < 2 * s) lists[wave * VG_WAVE + lane] = mine;
-        __syncthreads();
-        if (wave < s) {
-            const uint64_t c = lists[(wave + s) * VG_WAVE + lane];
-            vg_list_offer(c, (lane < k) && (c != VG_EMPTY_KEY), mine, thr, lane, k);
-        }
-    }
-    if (wave == 0) a.cand[(long long)blockIdx.x * VG_WAVE + lane] = (lane < k) ? mine : VG_EMPTY_KEY;
+    vg_block_publish(smem, mine, k, a.cand + (long long)blockIdx.x * VG_WAVE);
 }
 
 // Long rows (more 16-byte chunks than 64 lanes x the largest register-resident U): one row per wavefront per step,
@@ -208,52 +212,15 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_long_kernel(ScanArgs a) {
     }
     if (store_mode) return;
 
-    __syncthreads();
-    uint64_t *lists = reinterpret_cast<uint64_t *>(smem);
-#pragma unroll 1
-    for (int t = VG_WAVES_PER_BLOCK / 2; t >= 1; t >>= 1) {
-        if (wave >= t && wave < 2 * t) lists[wave * VG_WAVE + lane] = mine;
-        __syncthreads();
-        if (wave < t) {
-            const uint64_t c = lists[(wave + t) * VG_WAVE + lane];
-            vg_list_offer(c, (lane < k) && (c != VG_EMPTY_KEY), mine, thr, lane, k);
-        }
-    }
-    if (wave == 0) a.cand[(long long)blockIdx.x * VG_WAVE + lane] = (lane < k) ? mine : VG_EMPTY_KEY;
+    __syncthreads();                                   // everyone is done with the query staging area
+    vg_block_publish(smem, mine, k, a.cand + (long long)blockIdx.x * VG_WAVE);
 }
 
-// Final reduction of `nlists` sorted 64-slot lists to the k best.  One workgroup of 16 wavefronts: each wave
-// folds every 16th list into its own sorted list, then wave 0 folds the 16 wave lists and writes k keys
-// (ascending, VG_EMPTY_KEY padded to 64).
-#define VG_MERGE_WAVES 16
-#define VG_MERGE_DEPTH 16
-__global__ __launch_bounds__(VG_MERGE_WAVES * VG_WAVE) void vg_merge_kernel(const uint64_t *cand, int nlists, int k,
-                                                                            uint64_t *out_keys) {
-    __shared__ uint64_t lists[VG_MERGE_WAVES * VG_WAVE];
-    const int lane = threadIdx.x & (VG_WAVE - 1);
-    const int wave = threadIdx.x >> 6;
-    uint64_t mine = VG_EMPTY_KEY, thr = VG_EMPTY_KEY;
-    // the lists are independent: fetch VG_MERGE_DEPTH of them per round so the HBM/L2 latency is paid once per
-    // round instead of once per list (a dependent chain of 64 loads made this kernel 60 us)
-    for (int l0 = wave; l0 < nlists; l0 += VG_MERGE_WAVES * VG_MERGE_DEPTH) {
-        uint64_t c[VG_MERGE_DEPTH];
-#pragma unroll
-        for (int j = 0; j < VG_MERGE_DEPTH; ++j) {
-            const int l = l0 + j * VG_MERGE_WAVES;
-            c[j] = (l < nlists) ? cand[(long long)l * VG_WAVE + lane] : VG_EMPTY_KEY;
-        }
-#pragma unroll
-        for (int j = 0; j < VG_MERGE_DEPTH; ++j)
-            vg_list_offer(c[j], (lane < k) && (c[j] != VG_EMPTY_KEY), mine, thr, lane, k);
-    }
-#pragma unroll 1
-    for (int s = VG_MERGE_WAVES / 2; s >= 1; s >>= 1) {
-        if (wave >= s && wave < 2 * s) lists[wave * VG_WAVE + lane] = mine;
-        __syncthreads();
-        if (wave < s) {
-            const uint64_t c = lists[(wave + s) * VG_WAVE + lane];
-            vg_list_offer(c, (lane < k) && (c != VG_EMPTY_KEY), mine, thr, lane, k);
-        }
-    }
-    if (wave == 0) out_keys[lane] = (lane < k) ? mine : VG_EMPTY_KEY;
+// Final reduction of the per-CU lists (nlists <= 256) to the k best: one workgroup, parallel rank-select
+// (vg_lists.h).  out_keys receives k keys ascending, VG_EMPTY_KEY padded to 64.
+#define VG_MERGE_THREADS 1024
+__global__ __launch_bounds__(VG_MERGE_THREADS) void vg_merge_kernel(const uint64_t *cand, int nlists, int k,
+                                                                    uint64_t *out_keys) {
+    __shared__ __attribute__((aligned(16))) uint8_t scratch[VG_SEL_SCRATCH_BYTES];
+    vg_select_lists(cand, nlists, k, out_keys, scratch);
 }
