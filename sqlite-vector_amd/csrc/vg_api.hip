@@ -107,6 +107,9 @@ struct vg_corpus {
     void *d_sel_temp = nullptr;
     size_t sel_temp_bytes = 0;
     int64_t sel_cap = 0;
+    void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
+    uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;
+    size_t bq_bytes = 0, bcand_bytes = 0, bkeys_bytes = 0;
     int max_blocks = 0;
     int cu_count = 0;
 
@@ -186,6 +189,9 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_sel_keys) hipFree(c->d_sel_keys);
     if (c->d_sel_sorted) hipFree(c->d_sel_sorted);
     if (c->d_sel_temp) hipFree(c->d_sel_temp);
+    if (c->d_bq) hipFree(c->d_bq);
+    if (c->d_bcand) hipFree(c->d_bcand);
+    if (c->d_bkeys) hipFree(c->d_bkeys);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -687,10 +693,92 @@ extern "C" int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k, 
     return VG_OK;
 }
 
+// ---- batched queries: the MFMA path (vg_batch.hip) when the shape allows it, otherwise nq single-query scans
+extern "C" size_t vg_batch_lds_bytes(long long stride_bytes, int k);
+extern "C" int vg_batch_launch(const float *dev_rows, long long n_rows, long long stride_bytes,
+                               const float *dev_queries, int nq_pad, int k, int cosine, uint64_t *dev_cand,
+                               int npart, int tiles_per_part, uint64_t *dev_out_keys, hipStream_t stream);
+
+static bool batch_mfma_eligible(const vg_corpus *c, int metric, int k) {
+    if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
+    if (c->vtype != VG_TYPE_F32) return false;
+    if (metric != VG_DIST_DOT && metric != VG_DIST_COSINE) return false;
+    return vg_batch_lds_bytes(c->stride, k) != 0;
+}
+
+static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, int nq, int k, int64_t *out_rowids,
+                                double *out_dist, int *out_counts) {
+    const int QPB = 128;
+    const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
+    const int G = nq_pad / QPB;
+    // partitions: enough workgroups to cover the chip (G * npart ~ CUs), a multiple of 8 (one per XCD), <= 256
+    int npart = std::max(1, c->cu_count / G);
+    if (npart >= 8) npart = (npart / 8) * 8;
+    npart = std::min(npart, 256);
+    const long long ntiles = (c->n_rows + 31) / 32;
+    npart = (int)std::min<long long>(npart, ntiles);
+    const int tiles_per_part = (int)((ntiles + npart - 1) / npart);
+
+    const size_t qbytes = (size_t)nq_pad * c->stride, candbytes = (size_t)nq_pad * npart * 64 * sizeof(uint64_t);
+    const size_t keybytes = (size_t)nq_pad * 64 * sizeof(uint64_t);
+    if (c->bq_bytes < qbytes) { if (c->d_bq) hipFree(c->d_bq); c->d_bq = nullptr; c->bq_bytes = 0;
+                                HIP_TRY(hipMalloc(&c->d_bq, qbytes)); c->bq_bytes = qbytes; }
+    if (c->bcand_bytes < candbytes) { if (c->d_bcand) hipFree(c->d_bcand); c->d_bcand = nullptr; c->bcand_bytes = 0;
+                                      HIP_TRY(hipMalloc(&c->d_bcand, candbytes)); c->bcand_bytes = candbytes; }
+    if (c->bkeys_bytes < keybytes) { if (c->d_bkeys) hipFree(c->d_bkeys); c->d_bkeys = nullptr; c->bkeys_bytes = 0;
+                                     HIP_TRY(hipMalloc(&c->d_bkeys, keybytes)); c->bkeys_bytes = keybytes; }
+    // queries: zero-padded rows of the corpus stride, zero rows up to nq_pad
+    std::vector<uint8_t> hq(qbytes, 0);
+    const size_t row_bytes = (size_t)c->dim * c->es;
+    for (int i = 0; i < nq; ++i) memcpy(hq.data() + (size_t)i * c->stride, (const uint8_t *)queries + (size_t)i * row_bytes, row_bytes);
+    HIP_TRY(hipMemcpyAsync(c->d_bq, hq.data(), qbytes, hipMemcpyHostToDevice, c->stream));
+
+    hipEvent_t *evs = nullptr;
+    if (c->profiling) {
+        int slot = (int)(c->prof_launches % VG_PROF_RING);
+        evs = &c->ev[(size_t)slot * 3];
+        c->ev_had_merge[(size_t)slot] = 0;
+        ++c->prof_launches;
+        hipEventRecord(evs[0], c->stream);
+    }
+    int rc = vg_batch_launch((const float *)c->d_rows, c->n_rows, c->stride, (const float *)c->d_bq, nq_pad, k,
+                             metric == VG_DIST_COSINE ? 1 : 0, c->d_bcand, npart, tiles_per_part, c->d_bkeys, c->stream);
+    if (evs) { hipEventRecord(evs[1], c->stream); hipEventRecord(evs[2], c->stream); }
+    if (rc == -1) return -1;
+    if (rc != 0) return vg_fail(VG_ERR_HIP, "batched scan launch failed: %s", hipGetErrorString((hipError_t)rc));
+    std::vector<uint64_t> keys((size_t)nq * 64);
+    HIP_TRY(hipMemcpyAsync(keys.data(), c->d_bkeys, (size_t)nq * 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    collect_timing(c);
+    for (int i = 0; i < nq; ++i) {
+        int cnt = 0;
+        for (int j = 0; j < k; ++j) {
+            uint64_t key = keys[(size_t)i * 64 + j];
+            if (key == VG_EMPTY_KEY) break;
+            out_dist[(size_t)i * k + cnt] = (double)vg_key_distance(key);
+            out_rowids[(size_t)i * k + cnt] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(key));
+            ++cnt;
+        }
+        out_counts[i] = cnt;
+    }
+    return VG_OK;
+}
+
 extern "C" int vg_scan_topk_batch(vg_corpus *c, int metric, const void *queries, int nq, int k, int64_t *out_rowids,
                                   double *out_dist, int *out_counts) {
     if (!c || !queries || !out_counts) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch: NULL argument");
-    // round 1: the batched path is nq passes of the single-query kernel (the MFMA Q x C^T kernel is the next row)
+    if (nq <= 0) return VG_OK;
+    if (metric_to_acc(metric) < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
+    for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+    if (k <= 0 || c->n_rows == 0) return VG_OK;
+    if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch: NULL output");
+    HIP_TRY(hipSetDevice(c->device));
+    if (batch_mfma_eligible(c, metric, k)) {
+        int rc = scan_topk_batch_mfma(c, metric, queries, nq, k, out_rowids, out_dist, out_counts);
+        if (rc != -1) return rc;
+    }
+    // shapes the matrix-core kernel does not serve (other types / metrics, k > 32, rows > 512 floats):
+    // nq passes of the single-query kernel, still entirely on the GPU
     const uint8_t *q = (const uint8_t *)queries;
     for (int i = 0; i < nq; ++i) {
         int rc = vg_scan_topk(c, metric, q + (size_t)i * c->dim * c->es, k, out_rowids + (size_t)i * k,

@@ -1,0 +1,254 @@
+// vg_batch.hip - batched queries: Q x Corpus^T as a dense f32 GEMM on the matrix cores with a fused per-query
+// top-k (BASELINE config C5: 1024 queries x 10M x 384 f32, dot, top-20).
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate = a k-ordered fmaf chain, exact f32 semantics, 157 TF
+// peak).  The 1024 x 10M score matrix (41 GB) is never materialised: each 32x32 tile goes straight from the
+// accumulator registers into per-query candidate lists.
+//
+// Decomposition (one workgroup = 4 wavefronts = one CU, one wavefront per SIMD with the whole register file):
+//   * a workgroup owns 128 queries (32 per wavefront) x one contiguous partition of the corpus;
+//   * A (queries) is STATIONARY IN REGISTERS: lane (x = lane&31, h = lane>>5) keeps Q[x][8t + 4h + e] in
+//     a[4t + e], t < NT = ceil(D/8): 4*NT VGPRs (192 for D = 384).  No LDS traffic for A at all;
+//   * B (corpus) streams through LDS in tiles of 32 rows x D (49 KB at D = 384, double buffered) by LDS-DMA
+//     (global_load_lds_dwordx4: no staging VGPRs, asynchronous): the DMA of tile t+1 is issued before tile t's MFMAs
+//     and is complete at the single barrier per tile.  All 4 wavefronts consume the same tile against their own
+//     queries; one ds_read_b128 feeds 4 MFMAs (a lane's 4 consecutive k's pair with a[4t..4t+3]); row pitch D+4
+//     floats keeps the b128 reads bank-conflict free;
+//   * epilogue per tile: D[i][j] for query i = (r&3)+8(r>>2)+4h and row j = lane&31 sits in acc[r]; distance ->
+//     clamp -> compare with the query's current k-th best distance (32 floats per wavefront in LDS) -> only survivors
+//     take the slow path into the query's sorted list in LDS (each list is owned by exactly one wavefront: no locks);
+//   * one list per (query, partition) goes to HBM; vg_batch_merge_kernel rank-selects the final k per query.
+//
+// HBM traffic = corpus x (Q / 128) (each query group re-reads the corpus; the groups sharing a partition are placed
+// on one XCD so the re-reads hit its L2); at ~100+ TF the kernel is MFMA-bound, not bandwidth-bound.
+//
+// Metrics: DOT and COSINE (row norms accumulated from the same LDS reads).  L2/L1 and the other element types are
+// served by the single-query scan path (exact reference arithmetic) - see vg_api.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vg_lists.h"
+
+typedef float vgb_f32x16 __attribute__((ext_vector_type(16)));
+
+#define VGB_THREADS 256
+#define VGB_WAVES 4
+#define VGB_QPW 32                      // queries per wavefront
+#define VGB_QPB (VGB_WAVES * VGB_QPW)   // queries per workgroup
+#define VGB_TILE 32                     // corpus rows per tile
+#define VGB_MAX_K 32
+
+struct BatchArgs {
+    const float *rows;        // N x stride_f floats
+    const float *queries;     // nq_pad x stride_f floats (zero padded to a multiple of 128 queries)
+    uint64_t *cand;           // [nq_pad][npart][64] keys
+    long long n_rows;
+    long long stride_f;       // floats between rows (multiple of 4)
+    int nq_pad;
+    int npart;
+    int k;
+    int cosine;               // 0: dot, 1: cosine
+    int tiles_per_part;
+};
+
+template <int NT>
+__global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int PITCH = NT * 8 + 4;                         // floats per LDS tile row (16-byte pad: conflict-free b128)
+    constexpr int TILE_FLOATS = VGB_TILE * PITCH;
+    constexpr int PIECES = (NT * 2 + 63) / 64;                // 1-KiB DMA pieces per row
+    float *tile0 = reinterpret_cast<float *>(smem);
+    float *tile1 = tile0 + TILE_FLOATS;
+    float *thr_lds = tile1 + TILE_FLOATS;                     // [4][32] current k-th best distance per query
+    float *qn_lds = thr_lds + VGB_WAVES * VGB_QPW;            // [4][32] ||q|| (cosine)
+    uint64_t *lists = reinterpret_cast<uint64_t *>(qn_lds + VGB_WAVES * VGB_QPW);   // [4][32][k]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = lane & 31, h = lane >> 5;
+    const int k = a.k;
+
+    // block -> (query group, partition); the groups that share a partition sit on one XCD (block b runs on XCD b % 8)
+    const int G = a.nq_pad / VGB_QPB;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int g = idx % G;
+    const int part = (idx / G) * 8 + xcd;
+    if (part >= a.npart) return;
+    const int q0 = g * VGB_QPB + wave * VGB_QPW;              // this wavefront's first query
+
+    // ---- A operand: this lane's slice of query (q0 + x), kept in registers for the whole kernel
+    float areg[NT * 4];
+    float qq_part = 0.0f;
+    {
+        const float *qrow = a.queries + (long long)(q0 + x) * a.stride_f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int kk = 8 * t + 4 * h;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < a.stride_f) v = *reinterpret_cast<const float4 *>(qrow + kk);
+            areg[4 * t + 0] = v.x; areg[4 * t + 1] = v.y; areg[4 * t + 2] = v.z; areg[4 * t + 3] = v.w;
+            qq_part = fmaf(v.x, v.x, qq_part); qq_part = fmaf(v.y, v.y, qq_part);
+            qq_part = fmaf(v.z, v.z, qq_part); qq_part = fmaf(v.w, v.w, qq_part);
+        }
+    }
+    float *thr_w = thr_lds + wave * VGB_QPW;
+    float *qn_w = qn_lds + wave * VGB_QPW;
+    uint64_t *wave_lists = lists + (size_t)wave * VGB_QPW * k;
+    {
+        // ||q|| of query (q0+x): the two halves of the k range live in lanes x and x+32
+        const float qq_x = qq_part + __shfl_xor(qq_part, 32);
+        if (h == 0) { qn_w[x] = sqrtf(qq_x); thr_w[x] = INFINITY; }
+        for (int s = lane; s < VGB_QPW * k; s += 64) wave_lists[s] = VG_EMPTY_KEY;
+    }
+    // zero both tile buffers once: the k-padding columns [stride_f, NT*8) are never touched by the DMA
+    for (int s = tid; s < 2 * TILE_FLOATS; s += VGB_THREADS) tile0[s] = 0.0f;
+    __syncthreads();
+
+    // ---- tile streaming by LDS-DMA: wavefront w moves rows w, w+4, ... of the tile, one 1-KiB piece per instruction
+    const int chunks_per_row = (int)(a.stride_f / 4);
+    const long long tile_first = (long long)part * a.tiles_per_part;
+    const long long tile_last = min(tile_first + a.tiles_per_part, (a.n_rows + VGB_TILE - 1) / VGB_TILE);
+    auto dma_tile = [&](long long tile, float *dst_tile) {
+        const long long row0 = tile * VGB_TILE;
+#pragma unroll
+        for (int i = 0; i < VGB_TILE / VGB_WAVES; ++i) {
+            const int rr = wave + i * VGB_WAVES;
+            const long long grow = min(row0 + rr, a.n_rows - 1);            // rows past the end are masked later
+            const float *src_row = a.rows + grow * a.stride_f;
+#pragma unroll
+            for (int p = 0; p < PIECES; ++p) {
+                const int c = p * 64 + lane;
+                if (c < chunks_per_row)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_row + c * 4),
+                                                     (__attribute__((address_space(3))) void *)(dst_tile + rr * PITCH + p * 256),
+                                                     16, 0, 0);
+            }
+        }
+    };
+
+    if (tile_first < tile_last) dma_tile(tile_first, tile0);
+    __syncthreads();                                          // includes the vmcnt(0) that lands the DMA
+
+    for (long long tile = tile_first; tile < tile_last; ++tile) {
+        const float *cur = ((tile - tile_first) & 1) ? tile1 : tile0;
+        float *nxt = ((tile - tile_first) & 1) ? tile0 : tile1;
+        if (tile + 1 < tile_last) dma_tile(tile + 1, nxt);
+
+        // 32 queries x 32 rows x D on the matrix core
+        vgb_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        float xx_part = 0.0f;
+        const float *brow = cur + x * PITCH + 4 * h;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 b = *reinterpret_cast<const float4 *>(brow + 8 * t);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 0], b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 1], b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 2], b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 3], b.w, acc, 0, 0, 0);
+            if (a.cosine) {
+                xx_part = fmaf(b.x, b.x, xx_part); xx_part = fmaf(b.y, b.y, xx_part);
+                xx_part = fmaf(b.z, b.z, xx_part); xx_part = fmaf(b.w, b.w, xx_part);
+            }
+        }
+
+        // epilogue: acc[r] = <query i(r,h), row x of the tile>
+        const long long row = tile * VGB_TILE + x;
+        const bool row_ok = row < a.n_rows;
+        float xnorm = 0.0f;
+        if (a.cosine) xnorm = sqrtf(xx_part + __shfl_xor(xx_part, 32));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q_lo = (r & 3) + 8 * (r >> 2);
+            const int qi = q_lo + 4 * h;
+            float d;
+            if (a.cosine) d = vg_cosine_from_norms(acc[r], qn_w[qi], xnorm);
+            else d = -acc[r];
+            d = vg_clamp(d);
+            const bool pass = row_ok && (d <= thr_w[qi]) && (d < INFINITY);
+            unsigned long long m = __ballot(pass);
+            if (m) {                                          // rare once the lists have warmed up
+                const uint64_t key = vg_make_key(d, (uint32_t)row);
+                while (m) {
+                    const int src = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int q = q_lo + 4 * (src >> 5);
+                    uint64_t *list = wave_lists + q * k;
+                    const uint64_t c = vg_readlane64(key, src);
+                    if (c < list[k - 1]) {
+                        uint64_t mine = (lane < k) ? list[lane] : 0ull;
+                        const uint64_t prev = vg_wave_shr1(mine);
+                        mine = (mine > c) ? ((prev > c) ? prev : c) : mine;
+                        if (lane < k) list[lane] = mine;
+                        const uint64_t kth = vg_readlane64(mine, k - 1);
+                        if (lane == 0) thr_w[q] = vg_sortable_f32((uint32_t)(kth >> 32));
+                    }
+                }
+            }
+        }
+        __syncthreads();                                      // tile t consumed by all, tile t+1 landed
+    }
+
+    // ---- publish: [query][part][64] (a query's npart lists are contiguous for the merge)
+    for (int s = lane; s < VGB_QPW * 64; s += 64) {
+        const int qi = s >> 6, slot = s & 63;
+        a.cand[((long long)(q0 + qi) * a.npart + part) * 64 + slot] = (slot < k) ? wave_lists[qi * k + slot] : VG_EMPTY_KEY;
+    }
+}
+
+// per query: its npart sorted lists (contiguous in `cand`) -> final k (ascending, EMPTY padded to 64).
+// One workgroup per query, same parallel rank-select as the single-query path.
+__global__ __launch_bounds__(256) void vg_batch_merge_kernel(const uint64_t *cand, int nq_pad, int npart, int k,
+                                                             uint64_t *out_keys) {
+    __shared__ __attribute__((aligned(16))) uint8_t scratch[VG_SEL_SCRATCH_BYTES];
+    const int q = blockIdx.x;
+    vg_select_lists(cand + (long long)q * npart * 64, npart, k, out_keys + (long long)q * 64, scratch);
+}
+
+template <int NT>
+static int launch_nt(const BatchArgs &a, int blocks, size_t smem, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_kernel<NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(vg_batch_kernel<NT>, dim3((unsigned)blocks), dim3(VGB_THREADS), smem, stream, a);
+    return (int)hipGetLastError();
+}
+
+// LDS bytes of the batch kernel for a row of `stride_bytes` and k; 0 if the shape is not served
+extern "C" size_t vg_batch_lds_bytes(long long stride_bytes, int k) {
+    const int nt = (int)((stride_bytes / 4 + 7) / 8);
+    int NT;
+    if (nt <= 16) NT = 16; else if (nt <= 32) NT = 32; else if (nt <= 48) NT = 48; else if (nt <= 64) NT = 64;
+    else return 0;
+    if (k < 1 || k > VGB_MAX_K) return 0;
+    const size_t b = (size_t)2 * VGB_TILE * (NT * 8 + 4) * 4 + (size_t)2 * VGB_WAVES * VGB_QPW * 4 +
+                     (size_t)VGB_WAVES * VGB_QPW * k * 8;
+    return b <= 160 * 1024 ? b : 0;
+}
+
+// Host launcher.  Returns 0 on success, -1 if the shape is not served by this kernel (caller falls back to the
+// single-query path), a hipError_t otherwise.  dev_cand: nq_pad x npart x 64 keys; dev_out_keys: nq_pad x 64 keys.
+// A lives in 4*NT VGPRs per lane, so rows up to 512 floats are served; longer rows use the single-query path.
+extern "C" int vg_batch_launch(const float *dev_rows, long long n_rows, long long stride_bytes,
+                               const float *dev_queries, int nq_pad, int k, int cosine, uint64_t *dev_cand,
+                               int npart, int tiles_per_part, uint64_t *dev_out_keys, hipStream_t stream) {
+    const size_t smem = vg_batch_lds_bytes(stride_bytes, k);
+    if (!smem || nq_pad % VGB_QPB != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
+    BatchArgs a;
+    a.rows = dev_rows; a.queries = dev_queries; a.cand = dev_cand; a.n_rows = n_rows;
+    a.stride_f = stride_bytes / 4; a.nq_pad = nq_pad; a.npart = npart; a.k = k; a.cosine = cosine;
+    a.tiles_per_part = tiles_per_part;
+    const int nt = (int)((a.stride_f + 7) / 8);
+    const int G = nq_pad / VGB_QPB;
+    const int blocks = G * ((npart + 7) / 8) * 8;
+    int rc;
+    if (nt <= 16) rc = launch_nt<16>(a, blocks, smem, stream);
+    else if (nt <= 32) rc = launch_nt<32>(a, blocks, smem, stream);
+    else if (nt <= 48) rc = launch_nt<48>(a, blocks, smem, stream);
+    else rc = launch_nt<64>(a, blocks, smem, stream);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(vg_batch_merge_kernel, dim3((unsigned)nq_pad), dim3(256), 0, stream, (const uint64_t *)dev_cand,
+                       nq_pad, npart, k, dev_out_keys);
+    return (int)hipGetLastError();
+}

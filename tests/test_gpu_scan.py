@@ -241,17 +241,77 @@ def test_logical_shards_merge_equals_single_shard(pkg, orc):
         s.close()
 
 
-def test_batch_entry_point(pkg, orc):
-    dim, n, nq, k = 96, 2000, 7, 10
-    rows = dg.corpus(dg.F32, n, dim, 31)
-    qs = dg.corpus(dg.F32, nq, dim, 32)
+def _assert_topk_close(ids, dist, all_dist, k, tol):
+    """top-k validity under a floating-point tolerance: returned rows carry (within tol) their oracle distance, come
+    back ascending, and no unreturned row is better than the k-th returned one by more than tol."""
+    want_k = min(k, int(np.sum(all_dist < np.inf)))
+    assert len(ids) == want_k
+    assert np.all(np.diff(dist) >= 0)
+    pos = np.asarray(ids) - 1
+    assert len(set(pos.tolist())) == len(pos)
+    assert np.all(np.abs(dist - all_dist[pos].astype(np.float64)) <= tol[pos])
+    if want_k:
+        rest = np.ones(all_dist.shape[0], dtype=bool)
+        rest[pos] = False
+        rest &= all_dist < np.inf
+        assert np.all(all_dist[rest].astype(np.float64) >= dist[-1] - tol[rest])
+
+
+@pytest.mark.parametrize("dim", (16, 100, 128, 384, 500, 512))
+@pytest.mark.parametrize("metric", (dg.DOT, dg.COSINE))
+def test_batch_mfma_path_vs_oracle(pkg, orc, dim, metric):
+    """vg_scan_topk_batch on f32 dot / cosine runs Q x C^T on the matrix cores (v_mfma_f32_32x32x2_f32) with the
+    fused per-query top-k; every query is checked against the reference arithmetic (<= 1e-5 relative to the
+    magnitude of the summed terms)."""
+    n = 4133                                      # not a multiple of the 32-row tile
+    rows = dg.corpus(dg.F32, n, dim, 900 + dim)
+    rows[17] = 0.0                                # a zero-norm row (cosine -> 1.0)
     c = pkg.Corpus(pkg.F32, dim)
     c.append(rows)
-    ids, dist, cnt = c.scan_topk_batch(dg.DOT, qs, k)
-    for i in range(nq):
-        one_ids, one_dist = c.scan_topk(dg.DOT, qs[i], k)
-        assert cnt[i] == k and ids[i].tolist() == one_ids.tolist() and np.array_equal(dist[i], one_dist)
+    for nq, k in ((1, 20), (7, 1), (130, 20), (200, 32)):
+        qs = dg.corpus(dg.F32, nq, dim, 901 + dim + nq)
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        for i in range(nq):
+            want = orc.scan_distances(orc.AVX2, metric, dg.F32, qs[i], rows)
+            scale = np.abs(rows.astype(np.float64) * qs[i].astype(np.float64)).sum(axis=1) if metric == dg.DOT else np.ones(n)
+            tol = REL_TOL * (np.abs(want.astype(np.float64)) + scale) + 1e-6
+            _assert_topk_close(ids[i][:cnt[i]], dist[i][:cnt[i]], want, k, tol)
     c.close()
+
+
+def test_batch_small_corpus_and_fallback_shapes(pkg, orc):
+    dim = 96
+    rows = dg.corpus(dg.F32, 10, dim, 31)          # fewer rows than one tile, fewer than k
+    qs = dg.corpus(dg.F32, 3, dim, 32)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    ids, dist, cnt = c.scan_topk_batch(dg.DOT, qs, 20)
+    for i in range(3):
+        want = orc.scan_distances(orc.AVX2, dg.DOT, dg.F32, qs[i], rows)
+        assert cnt[i] == 10
+        assert sorted(ids[i][:10].tolist()) == list(range(1, 11))
+        assert np.allclose(dist[i][:10], np.sort(want), rtol=1e-5, atol=1e-5)
+    c.close()
+    # shapes the matrix-core kernel does not serve fall back to per-query scans with identical results
+    rows = dg.corpus(dg.F32, 2000, dim, 33)
+    qs = dg.corpus(dg.F32, 5, dim, 34)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    for metric, k in ((dg.L2, 10), (dg.L1, 10), (dg.DOT, 40)):
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        for i in range(5):
+            one_ids, one_dist = c.scan_topk(metric, qs[i], k)
+            assert cnt[i] == k and ids[i].tolist() == one_ids.tolist() and np.array_equal(dist[i], one_dist)
+    c.close()
+    r8 = dg.corpus(dg.I8, 1500, 64, 35)
+    q8 = dg.corpus(dg.I8, 4, 64, 36)
+    c8 = pkg.Corpus(pkg.I8, 64)
+    c8.append(r8)
+    ids, dist, cnt = c8.scan_topk_batch(dg.DOT, q8, 10)
+    for i in range(4):
+        one_ids, one_dist = c8.scan_topk(dg.DOT, q8[i], 10)
+        assert ids[i].tolist() == one_ids.tolist() and np.array_equal(dist[i], one_dist)
+    c8.close()
 
 
 # ------------------------------------------------------------------------------------------------- f16 / bf16
