@@ -17,6 +17,8 @@
 //   * epilogue per tile: D[i][j] for query i = (r&3)+8(r>>2)+4h and row j = lane&31 sits in acc[r]; distance ->
 //     clamp -> compare with the query's current k-th best distance (32 floats per wavefront in LDS) -> only survivors
 //     take the slow path into the query's sorted list in LDS (each list is owned by exactly one wavefront: no locks);
+//     the epilogue of tile t-1 and the DMA issue of tile t+1 are interleaved INTO tile t's MFMA loop (one register /
+//     one piece every few MFMAs) so that the matrix core never waits for them;
 //   * one list per (query, partition) goes to HBM; vg_batch_merge_kernel rank-selects the final k per query.
 //
 // HBM traffic = corpus x (Q / 128) (each query group re-reads the corpus; the groups sharing a partition are placed
@@ -26,6 +28,8 @@
 // served by the single-query scan path (exact reference arithmetic) - see vg_api.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "vg_lists.h"
 
@@ -50,6 +54,14 @@ struct BatchArgs {
     int cosine;               // 0: dot, 1: cosine
     int tiles_per_part;
 };
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void vgb_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        vgb_static_for<I + 1, N>(f);
+    }
+}
 
 template <int NT>
 __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
@@ -81,15 +93,15 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     float qq_part = 0.0f;
     {
         const float *qrow = a.queries + (long long)(q0 + x) * a.stride_f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        vgb_static_for<0, NT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
             const int kk = 8 * t + 4 * h;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kk < a.stride_f) v = *reinterpret_cast<const float4 *>(qrow + kk);
             areg[4 * t + 0] = v.x; areg[4 * t + 1] = v.y; areg[4 * t + 2] = v.z; areg[4 * t + 3] = v.w;
             qq_part = fmaf(v.x, v.x, qq_part); qq_part = fmaf(v.y, v.y, qq_part);
             qq_part = fmaf(v.z, v.z, qq_part); qq_part = fmaf(v.w, v.w, qq_part);
-        }
+        });
     }
     float *thr_w = thr_lds + wave * VGB_QPW;
     float *qn_w = qn_lds + wave * VGB_QPW;
@@ -108,40 +120,97 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     const int chunks_per_row = (int)(a.stride_f / 4);
     const long long tile_first = (long long)part * a.tiles_per_part;
     const long long tile_last = min(tile_first + a.tiles_per_part, (a.n_rows + VGB_TILE - 1) / VGB_TILE);
-    auto dma_tile = [&](long long tile, float *dst_tile) {
-        const long long row0 = tile * VGB_TILE;
-#pragma unroll
-        for (int i = 0; i < VGB_TILE / VGB_WAVES; ++i) {
-            const int rr = wave + i * VGB_WAVES;
-            const long long grow = min(row0 + rr, a.n_rows - 1);            // rows past the end are masked later
-            const float *src_row = a.rows + grow * a.stride_f;
-#pragma unroll
-            for (int p = 0; p < PIECES; ++p) {
-                const int c = p * 64 + lane;
-                if (c < chunks_per_row)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_row + c * 4),
-                                                     (__attribute__((address_space(3))) void *)(dst_tile + rr * PITCH + p * 256),
-                                                     16, 0, 0);
+    // one 1-KiB DMA piece: piece index pc in [0, 8*PIECES) = (row slot i, piece p) of this wavefront's 8 rows
+    auto dma_piece = [&](long long tile, float *dst_tile, int pc) {
+        const int i = pc / PIECES, p = pc - i * PIECES;
+        const int rr = wave + i * VGB_WAVES;
+        const long long grow = min(tile * VGB_TILE + rr, a.n_rows - 1);     // rows past the end are masked later
+        const int c = p * 64 + lane;
+        // LDS-DMA from inline asm: hipcc's waitcnt pass does not see it, so it cannot put "s_waitcnt vmcnt(0)" in
+        // front of every ds_read of the CURRENT tile while the NEXT tile is in flight (it did with the builtin: 16
+        // exposed HBM round trips per tile).  Completion is waited for explicitly before the tile barrier.
+        // M0 = wave-uniform LDS byte address of the piece; lane i lands at M0 + 16*i; inactive lanes write nothing.
+        if (c < chunks_per_row) {
+            const float *gsrc = a.rows + grow * a.stride_f + c * 4;
+            const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
+                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)(dst_tile + rr * PITCH + p * 256));
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+        }
+    };
+    constexpr int NPIECE = (VGB_TILE / VGB_WAVES) * PIECES;
+
+    // distance of ONE accumulator register: acc_r = <query i(r,h), row x>
+    auto reg_distance = [&](int r, float acc_r, float xnorm) -> float {
+        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float d;
+        if (a.cosine) d = vg_cosine_from_norms(acc_r, qn_w[qi], xnorm);
+        else d = -acc_r;
+        return vg_clamp(d);
+    };
+    // branch-free test (runs inside the MFMA loop): does any lane of this register beat its query's k-th best?
+    auto reg_pending = [&](int r, float acc_r, long long row, float xnorm) -> unsigned {
+        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float d = reg_distance(r, acc_r, xnorm);
+        const bool pass = (row < a.n_rows) && (d <= thr_w[qi]) && (d < INFINITY);
+        return __ballot(pass) ? (1u << r) : 0u;
+    };
+    // slow path (outside the MFMA loop, rare once the lists have warmed up): insert this register's survivors
+    auto reg_insert = [&](int r, float acc_r, long long row, float xnorm) {
+        const int q_lo = (r & 3) + 8 * (r >> 2);
+        const float d = reg_distance(r, acc_r, xnorm);
+        const bool pass = (row < a.n_rows) && (d <= thr_w[q_lo + 4 * h]) && (d < INFINITY);
+        unsigned long long m = __ballot(pass);
+        const uint64_t key = vg_make_key(d, (uint32_t)row);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int q = q_lo + 4 * (src >> 5);
+            uint64_t *list = wave_lists + q * k;
+            const uint64_t c = vg_readlane64(key, src);
+            if (c < list[k - 1]) {
+                uint64_t mine = (lane < k) ? list[lane] : 0ull;
+                const uint64_t prev = vg_wave_shr1(mine);
+                mine = (mine > c) ? ((prev > c) ? prev : c) : mine;
+                if (lane < k) list[lane] = mine;
+                const uint64_t kth = vg_readlane64(mine, k - 1);
+                if (lane == 0) thr_w[q] = vg_sortable_f32((uint32_t)(kth >> 32));
             }
         }
     };
 
-    if (tile_first < tile_last) dma_tile(tile_first, tile0);
-    __syncthreads();                                          // includes the vmcnt(0) that lands the DMA
+    if (tile_first < tile_last) {
+#pragma unroll
+        for (int pc = 0; pc < NPIECE; ++pc) dma_piece(tile_first, tile0, pc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // land this wavefront's DMA pieces ...
+    __syncthreads();                                          // ... and everybody else's
 
+    // Software pipeline: while tile t runs on the matrix core, the wavefront (a) issues the DMA pieces of tile t+1
+    // and (b) runs the threshold test of tile t-1's 16 accumulator registers, one every few MFMAs - both in the
+    // shadow of the 64-cycle MFMAs instead of in front of / behind them (that serialisation cost ~40% of the tile
+    // time).  The loop body stays branch free; registers that have survivors are handled after it.
+    vgb_f32x16 acc_prev;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_prev[r] = 0.0f;
+    float xnorm_prev = 0.0f;
+    long long row_prev = a.n_rows;                            // "no previous tile": every candidate masked
     for (long long tile = tile_first; tile < tile_last; ++tile) {
         const float *cur = ((tile - tile_first) & 1) ? tile1 : tile0;
         float *nxt = ((tile - tile_first) & 1) ? tile0 : tile1;
-        if (tile + 1 < tile_last) dma_tile(tile + 1, nxt);
+        const long long tile_next = min(tile + 1, tile_last - 1);   // the last iteration re-fetches its own tile: harmless
 
-        // 32 queries x 32 rows x D on the matrix core
         vgb_f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         float xx_part = 0.0f;
+        unsigned pend = 0;
         const float *brow = cur + x * PITCH + 4 * h;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        // compile-time unrolled k loop (a template recursion: the plain "#pragma unroll" gave up on a body this large
+        // and put areg[] in scratch memory)
+        vgb_static_for<0, NT>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
             const float4 b = *reinterpret_cast<const float4 *>(brow + 8 * t);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 0], b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 1], b.y, acc, 0, 0, 0);
@@ -151,44 +220,33 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
                 xx_part = fmaf(b.x, b.x, xx_part); xx_part = fmaf(b.y, b.y, xx_part);
                 xx_part = fmaf(b.z, b.z, xx_part); xx_part = fmaf(b.w, b.w, xx_part);
             }
-        }
-
-        // epilogue: acc[r] = <query i(r,h), row x of the tile>
-        const long long row = tile * VGB_TILE + x;
-        const bool row_ok = row < a.n_rows;
-        float xnorm = 0.0f;
-        if (a.cosine) xnorm = sqrtf(xx_part + __shfl_xor(xx_part, 32));
+            // DMA pieces of the next tile go out during the FIRST THIRD of the k loop (the remaining two thirds of
+            // the MFMAs cover their ~2 us HBM latency; spreading them over the whole loop left the last pieces
+            // exposed at the barrier); the 16 register tests are spread over the whole loop
+            constexpr int NTD = (NT + 2) / 3;
+            constexpr int pc_lo = (t >= NTD) ? NPIECE : (t * NPIECE + NTD - 1) / NTD;
+            constexpr int pc_hi = (t >= NTD) ? NPIECE : (t + 1 == NTD ? NPIECE : ((t + 1) * NPIECE + NTD - 1) / NTD);
+            vgb_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, nxt, decltype(pcc)::value); });
+            constexpr int r_lo = (t * 16 + NT - 1) / NT, r_hi = ((t + 1) * 16 + NT - 1) / NT;
+            vgb_static_for<r_lo, r_hi>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                pend |= reg_pending(r, acc_prev[r], row_prev, xnorm_prev);
+            });
+        });
+        if (pend) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q_lo = (r & 3) + 8 * (r >> 2);
-            const int qi = q_lo + 4 * h;
-            float d;
-            if (a.cosine) d = vg_cosine_from_norms(acc[r], qn_w[qi], xnorm);
-            else d = -acc[r];
-            d = vg_clamp(d);
-            const bool pass = row_ok && (d <= thr_w[qi]) && (d < INFINITY);
-            unsigned long long m = __ballot(pass);
-            if (m) {                                          // rare once the lists have warmed up
-                const uint64_t key = vg_make_key(d, (uint32_t)row);
-                while (m) {
-                    const int src = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const int q = q_lo + 4 * (src >> 5);
-                    uint64_t *list = wave_lists + q * k;
-                    const uint64_t c = vg_readlane64(key, src);
-                    if (c < list[k - 1]) {
-                        uint64_t mine = (lane < k) ? list[lane] : 0ull;
-                        const uint64_t prev = vg_wave_shr1(mine);
-                        mine = (mine > c) ? ((prev > c) ? prev : c) : mine;
-                        if (lane < k) list[lane] = mine;
-                        const uint64_t kth = vg_readlane64(mine, k - 1);
-                        if (lane == 0) thr_w[q] = vg_sortable_f32((uint32_t)(kth >> 32));
-                    }
-                }
-            }
+            for (int r = 0; r < 16; ++r)
+                if (pend & (1u << r)) reg_insert(r, acc_prev[r], row_prev, xnorm_prev);
         }
-        __syncthreads();                                      // tile t consumed by all, tile t+1 landed
+        acc_prev = acc;
+        row_prev = tile * VGB_TILE + x;
+        if (a.cosine) xnorm_prev = sqrtf(xx_part + __shfl_xor(xx_part, 32));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of tile t+1 have landed
+        __syncthreads();                                      // tile t consumed by all, tile t+1 landed for all
     }
+    // drain: the last tile's registers
+#pragma unroll
+    for (int r = 0; r < 16; ++r) reg_insert(r, acc_prev[r], row_prev, xnorm_prev);
 
     // ---- publish: [query][part][64] (a query's npart lists are contiguous for the merge)
     for (int s = lane; s < VGB_QPW * 64; s += 64) {
