@@ -164,6 +164,8 @@ def main():
                                          sync=stream.synchronize)
             if res is not None:
                 last["pos"], last["dist"] = res
+            else:
+                stream.synchronize()      # lockstep with rank 0: the pinned query buffer is reused next step
         else:
             h_keys[0].copy_(d_keys, non_blocking=True)
             stream.synchronize()

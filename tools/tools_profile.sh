@@ -4,7 +4,7 @@
 # the ones worth keeping are copied by hand into profiles/.
 #   usage: ./tools_profile.sh <tag> [bench.py args...]
 tag=${1:-r1}; shift
-REPO="$(cd "$(dirname "$0")" && pwd)"
+REPO="$(cd "$(dirname "$0")/.." && pwd)"
 export TMPDIR=/tmp
 OUT="$REPO/gpurun_out/prof_$tag"
 rm -rf "$OUT"; mkdir -p "$OUT"

@@ -1,14 +1,14 @@
 #!/bin/bash
 # GPU-box profiling of the batched MFMA kernel (config C5): kernel-trace stats, then PMC passes for MFMA busy cycles.
 tag=${1:-r1_c5}; shift
-REPO="$(cd "$(dirname "$0")" && pwd)"
+REPO="$(cd "$(dirname "$0")/.." && pwd)"
 export TMPDIR=/tmp
 OUT="$REPO/gpurun_out/prof_$tag"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o run -- python "$REPO/tools_batch_bench.py" --nq 1024 --reps 2 "$@" > "$OUT/bench_stats.log" 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -f csv -d "$OUT/pmc1" -o run -- python "$REPO/tools_batch_bench.py" --nq 1024 --reps 1 "$@" > "$OUT/bench_pmc1.log" 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace -f csv -d "$OUT/pmc2" -o run -- python "$REPO/tools_batch_bench.py" --nq 1024 --reps 1 "$@" > "$OUT/bench_pmc2.log" 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o run -- python "$REPO/tools/tools_batch_bench.py" --nq 1024 --reps 2 "$@" > "$OUT/bench_stats.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -f csv -d "$OUT/pmc1" -o run -- python "$REPO/tools/tools_batch_bench.py" --nq 1024 --reps 1 "$@" > "$OUT/bench_pmc1.log" 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace -f csv -d "$OUT/pmc2" -o run -- python "$REPO/tools/tools_batch_bench.py" --nq 1024 --reps 1 "$@" > "$OUT/bench_pmc2.log" 2>&1
 cd "$REPO"
 python - "$OUT" <<'PY' > "$OUT/summary.txt" 2>&1
 import csv, glob, os, sys

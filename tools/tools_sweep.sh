@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU-box experiment: A/B the scan kernel's launch shape on config C2 (10M x 384 f32 L2).  Scratch tool.
-cd "$(dirname "$0")"
+cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 out=gpurun_out/sweep.log; : > $out
 run() { echo "== $*" >> $out; env "$@" timeout 300 python bench.py --steps 15 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
