@@ -112,6 +112,14 @@ int vg_scan_topk_batch(vg_corpus *c, int metric, const void *queries, int nq, in
 /* ---- query-side quantizer (host, bit-exact with sqlite-vector.c:495-757) ---- */
 int vg_quantize_query(int src_type, const void *src, int dim, float scale, float offset, int qtype, void *dst);
 
+/* ---- vector_quantize on the staged corpus (sqlite-vector.c:1147-1336 moved to the GPU) ----
+ * pass 1: global min / max / any-negative over every element, widened to float like :1228-1254;
+ * pass 2: rows [row0, row0+n) quantized with (scale, offset, qtype) into n x dim tightly packed bytes on the host,
+ *         bit-exact with quantize_* (:495-757).  The caller interleaves rowids into the persisted record format. */
+int vg_corpus_minmax(vg_corpus *c, float *out_min, float *out_max, int *out_any_negative);
+int vg_corpus_quantize_rows(vg_corpus *c, float scale, float offset, int qtype, int64_t row0, int64_t n_rows,
+                            uint8_t *out_host);
+
 /* ---- instrumentation ---- */
 /* When enabled, every scan records HIP events around its kernels on the stream they run on (a ring of 1024
  * launches, no host synchronisation at launch time).  Enabling resets the launch counter. */

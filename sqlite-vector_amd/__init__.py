@@ -72,6 +72,8 @@ def lib():
         "vg_corpus_rowid_at": (i64, [vp, i64]),
         "vg_scan_topk_batch": (i32, [vp, i32, vp, i32, i32, vp, vp, vp]),
         "vg_quantize_query": (i32, [i32, vp, i32, C.c_float, C.c_float, i32, vp]),
+        "vg_corpus_minmax": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)]),
+        "vg_corpus_quantize_rows": (i32, [vp, C.c_float, C.c_float, i32, i64, i64, vp]),
         "vg_set_profiling": (i32, [vp, i32]),
         "vg_last_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "vg_profile_mean_ms": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -170,6 +172,17 @@ class Corpus:
         cnt = np.zeros(nq, dtype=np.int32)
         _check(lib().vg_scan_topk_batch(self.h, metric, _ptr(queries), nq, k, _ptr(ids), _ptr(dist), _ptr(cnt)))
         return ids, dist, cnt
+
+    def minmax(self):
+        lo, hi, neg = C.c_float(0), C.c_float(0), C.c_int(0)
+        _check(lib().vg_corpus_minmax(self.h, C.byref(lo), C.byref(hi), C.byref(neg)))
+        return lo.value, hi.value, bool(neg.value)
+
+    def quantize_rows(self, scale, offset, qtype, row0=0, n_rows=None):
+        n = self.rows - row0 if n_rows is None else n_rows
+        out = np.empty((n, self.dim), dtype=np.uint8)
+        _check(lib().vg_corpus_quantize_rows(self.h, scale, offset, qtype, row0, n, _ptr(out)))
+        return out
 
     def set_profiling(self, on=True):
         _check(lib().vg_set_profiling(self.h, 1 if on else 0))

@@ -872,6 +872,57 @@ extern "C" int vg_quantize_query(int src_type, const void *src, int dim, float s
     return VG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ corpus quantization
+// vector_quantize on the staged corpus (vg_quant.hip): min/max pass, then quantize pieces back to the host.
+
+extern "C" int vg_quant_minmax_launch(const uint8_t *rows, long long n_rows, long long stride, int dim, int vtype,
+                                      uint32_t *dev_out3, hipStream_t stream);
+extern "C" int vg_quant_quantize_launch(const uint8_t *rows, long long row0, long long n_rows, long long stride, int dim,
+                                        int vtype, float scale, float offset, int qtype_u8, uint8_t *dev_out,
+                                        hipStream_t stream);
+
+extern "C" int vg_corpus_minmax(vg_corpus *c, float *out_min, float *out_max, int *out_any_negative) {
+    if (!c || !out_min || !out_max || !out_any_negative) return vg_fail(VG_ERR_INVALID, "vg_corpus_minmax: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t h[3] = {vg_f32_sortable(3.402823466e+38f), vg_f32_sortable(-3.402823466e+38f), 0u};
+    if (c->n_rows > 0) {
+        uint32_t *d3 = nullptr;
+        HIP_TRY(hipMalloc(&d3, sizeof(h)));
+        int rc = vg_quant_minmax_launch(c->d_rows, c->n_rows, c->stride, c->dim, c->vtype, d3, c->stream);
+        hipError_t e = (rc == 0) ? hipMemcpyAsync(h, d3, sizeof(h), hipMemcpyDeviceToHost, c->stream) : (hipError_t)rc;
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(d3);
+        if (e != hipSuccess) return vg_fail(VG_ERR_HIP, "min/max pass failed: %s", hipGetErrorString(e));
+    }
+    *out_min = vg_sortable_f32(h[0]);
+    *out_max = vg_sortable_f32(h[1]);
+    *out_any_negative = (int)h[2];
+    return VG_OK;
+}
+
+extern "C" int vg_corpus_quantize_rows(vg_corpus *c, float scale, float offset, int qtype, int64_t row0, int64_t n_rows,
+                                       uint8_t *out_host) {
+    if (!c || !out_host) return vg_fail(VG_ERR_INVALID, "vg_corpus_quantize_rows: NULL argument");
+    if (qtype != VG_QUANT_U8 && qtype != VG_QUANT_S8) return vg_fail(VG_ERR_INVALID, "vg_corpus_quantize_rows: qtype must be UINT8 or INT8");
+    if (row0 < 0 || n_rows < 0 || row0 + n_rows > c->n_rows) return vg_fail(VG_ERR_INVALID, "vg_corpus_quantize_rows: row range out of bounds");
+    if (n_rows == 0) return VG_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t piece = std::max<int64_t>(1, (256ll << 20) / c->dim);
+    uint8_t *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, (size_t)(std::min(piece, n_rows) * c->dim)));
+    for (int64_t r = 0; r < n_rows; r += piece) {
+        const int64_t nr = std::min(piece, n_rows - r);
+        int rc = vg_quant_quantize_launch(c->d_rows, row0 + r, nr, c->stride, c->dim, c->vtype, scale, offset,
+                                          qtype == VG_QUANT_U8 ? 1 : 0, d_out, c->stream);
+        hipError_t e = (rc == 0) ? hipMemcpyAsync(out_host + r * c->dim, d_out, (size_t)(nr * c->dim), hipMemcpyDeviceToHost, c->stream)
+                                 : (hipError_t)rc;
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(d_out); return vg_fail(VG_ERR_HIP, "quantize pass failed: %s", hipGetErrorString(e)); }
+    }
+    hipFree(d_out);
+    return VG_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ instrumentation
 
 extern "C" int vg_set_profiling(vg_corpus *c, int enabled) {

@@ -62,6 +62,8 @@ typedef struct {
     int (*scan_distances)(vg_corpus *, int, const void *, float *);
     int64_t (*corpus_rowid_at)(const vg_corpus *, int64_t);
     int (*quantize_query)(int, const void *, int, float, float, int, void *);
+    int (*corpus_minmax)(vg_corpus *, float *, float *, int *);
+    int (*corpus_quantize_rows)(vg_corpus *, float, float, int, int64_t, int64_t, uint8_t *);
     char load_error[512];
 } gpu_api;
 
@@ -107,6 +109,8 @@ static int gpu_load(void) {
     G.scan_distances = (int (*)(vg_corpus *, int, const void *, float *))gpu_sym("vg_scan_distances");
     G.corpus_rowid_at = (int64_t (*)(const vg_corpus *, int64_t))gpu_sym("vg_corpus_rowid_at");
     G.quantize_query = (int (*)(int, const void *, int, float, float, int, void *))gpu_sym("vg_quantize_query");
+    G.corpus_minmax = (int (*)(vg_corpus *, float *, float *, int *))gpu_sym("vg_corpus_minmax");
+    G.corpus_quantize_rows = (int (*)(vg_corpus *, float, float, int, int64_t, int64_t, uint8_t *))gpu_sym("vg_corpus_quantize_rows");
     if (G.load_error[0]) { dlclose(G.handle); G.handle = NULL; return 0; }
     return 1;
 }
@@ -136,6 +140,7 @@ typedef struct {
     vg_corpus *full;            /* raw vectors for vector_full_scan[_stream] */
     int64_t full_data_version;  /* staleness stamps: PRAGMA data_version + sqlite3_total_changes() */
     int64_t full_changes;
+    int full_validated;         /* set when stage_full() (re)validated `full` during the current vector_quantize call */
     vg_corpus *quant;           /* quantized vectors for vector_quantize_scan[_stream] */
     int quant_preloaded;        /* explicit vector_quantize_preload() (kept until cleanup / re-quantize) */
     int64_t quant_data_version;
@@ -740,6 +745,68 @@ static int flush_chunk(sqlite3 *db, table_ctx *t, uint32_t n, const uint8_t *dat
     return rc;
 }
 
+/* vector_quantize with a GPU present: the raw vectors are staged into HBM once (the same corpus later serves
+ * vector_full_scan), min/max and the quantization run as kernels over it (vg_corpus_minmax /
+ * vg_corpus_quantize_rows, bit-exact with the host arithmetic below), and only the persisted records are assembled
+ * here: [int64 LE rowid | dim bytes] per row, flushed in max_memory-sized chunks exactly like the reference
+ * (sqlite-vector.c:1282-1327).  Returns -1 when the GPU path cannot be used (caller runs the host passes). */
+static int rebuild_quantization_gpu(sqlite3_context *ctx, table_ctx *t, int qtype, uint64_t max_memory, uint32_t *count) {
+    sqlite3 *db = sqlite3_context_db_handle(ctx);
+    if (!gpu_load() || G.device_count() <= 0) return -1;
+    char *err = NULL;
+    int rc = stage_full(db, t, &err);
+    if (rc != SQLITE_OK) {
+        ctx_error(ctx, rc, "%s", err ? err : "staging failed");
+        sqlite3_free(err);
+        return rc;
+    }
+    t->full_validated = 1;
+    const int64_t n = G.corpus_rows(t->full);
+    if (n <= 0) return -1;                                    /* empty table: the host path has the reference's defaults */
+    const int dim = t->opt.v_dim;
+    const int64_t rec = 8 + (int64_t)dim;
+    float lo, hi;
+    int negative;
+    if (G.corpus_minmax(t->full, &lo, &hi, &negative) != VG_OK) { ctx_error(ctx, SQLITE_ERROR, "%s", gpu_error()); return SQLITE_ERROR; }
+    if (qtype == VG_QUANT_AUTO) qtype = negative ? VG_QUANT_S8 : VG_QUANT_U8;
+    {
+        float amax = fmaxf(fabsf(lo), fabsf(hi));
+        t->scale = (qtype == VG_QUANT_U8) ? (255.0f / (hi - lo)) : (127.0f / amax);
+        t->offset = (qtype == VG_QUANT_U8) ? lo : 0.0f;
+        t->opt.q_type = qtype;
+    }
+    if (max_memory == 0) max_memory = (uint64_t)n * (uint64_t)rec;
+    int64_t per_chunk = (int64_t)(max_memory / (uint64_t)rec);
+    if (per_chunk <= 0) per_chunk = 1;
+    if (per_chunk > n) per_chunk = n;
+    uint8_t *qbuf = (uint8_t *)sqlite3_malloc64((sqlite3_uint64)per_chunk * (sqlite3_uint64)dim);
+    uint8_t *rbuf = (uint8_t *)sqlite3_malloc64((sqlite3_uint64)per_chunk * (sqlite3_uint64)rec);
+    if (!qbuf || !rbuf) { sqlite3_free(qbuf); sqlite3_free(rbuf); return SQLITE_NOMEM; }
+    *count = 0;
+    for (int64_t r0 = 0; r0 < n && rc == SQLITE_OK; r0 += per_chunk) {
+        const int64_t nr = (n - r0 < per_chunk) ? (n - r0) : per_chunk;
+        if (G.corpus_quantize_rows(t->full, t->scale, t->offset, qtype, r0, nr, qbuf) != VG_OK) {
+            ctx_error(ctx, SQLITE_ERROR, "%s", gpu_error());
+            rc = SQLITE_ERROR;
+            break;
+        }
+        int64_t first = 0, last = 0;
+        for (int64_t i = 0; i < nr; ++i) {
+            const int64_t id = G.corpus_rowid_at(t->full, r0 + i);
+            uint8_t *w = rbuf + i * rec;
+            for (int b = 0; b < 8; ++b) w[b] = (uint8_t)(((uint64_t)id >> (8 * b)) & 0xFF);
+            memcpy(w + 8, qbuf + i * dim, (size_t)dim);
+            if (i == 0) first = id;
+            last = id;
+        }
+        rc = flush_chunk(db, t, (uint32_t)nr, rbuf, nr * rec, first, last);
+        *count += (uint32_t)nr;
+    }
+    sqlite3_free(qbuf);
+    sqlite3_free(rbuf);
+    return rc;
+}
+
 /* Two passes over "SELECT pk, col FROM tbl ORDER BY pk" (sqlite-vector.c:1009): global min/max (+ any negative),
  * then quantize every row into [int64 LE rowid | dim bytes] records flushed in max_memory-sized chunks.
  * Same arithmetic and the same persisted bytes as the reference (:1147-1336); the per-element quantizer is the
@@ -751,6 +818,10 @@ static int rebuild_quantization(sqlite3_context *ctx, table_ctx *t, int qtype, u
     char sql[SQL_BUF];
     *count = 0;
     if (!gpu_load()) { ctx_error(ctx, SQLITE_ERROR, "%s", gpu_error()); return SQLITE_ERROR; }
+    {
+        int grc = rebuild_quantization_gpu(ctx, t, qtype, max_memory, count);
+        if (grc != -1) return grc;                           /* done (or failed) on the GPU; -1 = host passes below */
+    }
     if (max_memory == 0) {
         sqlite3_snprintf(sizeof(sql), sql, "SELECT COUNT(*) FROM %q;", t->t_name);
         int64_t n = read_int64(db, sql);
@@ -838,6 +909,8 @@ static void quantize_common(sqlite3_context *ctx, const char *tbl, const char *c
     sqlite3 *db = sqlite3_context_db_handle(ctx);
     char sql[SQL_BUF];
     uint32_t counter = 0;
+    int stamps_were_fresh = 0;
+    t->full_validated = 0;
     int rc = sqlite3_exec(db, "BEGIN;", NULL, NULL, NULL);          /* like the reference: fails inside a transaction */
     if (rc == SQLITE_OK) {
         sqlite3_snprintf(sizeof(sql), sql, "DROP TABLE IF EXISTS vector0_%q_%q;", tbl, col);
@@ -851,6 +924,7 @@ static void quantize_common(sqlite3_context *ctx, const char *tbl, const char *c
         vec_options o = t->opt;
         if (!options_parse(ctx, opts, &o)) { sqlite3_exec(db, "ROLLBACK;", NULL, NULL, NULL); return; }
         rc = rebuild_quantization(ctx, t, o.q_type, o.max_memory, &counter);
+        stamps_were_fresh = (rc == SQLITE_OK && t->full && t->full_validated);
     }
     if (rc == SQLITE_OK) rc = sqlite3_exec(db, "COMMIT;", NULL, NULL, NULL);
     if (rc == SQLITE_OK) rc = meta_put(ctx, tbl, col, "qtype", 1, t->opt.q_type, 0);
@@ -865,6 +939,7 @@ static void quantize_common(sqlite3_context *ctx, const char *tbl, const char *c
     }
     int was_preloaded = t->quant_preloaded;
     if (t->quant) { G.corpus_destroy(t->quant); t->quant = NULL; }   /* HBM copy is stale now */
+    if (t->full && stamps_were_fresh) db_stamps(db, &t->full_data_version, &t->full_changes);   /* only our own shadow-table writes happened */
     sqlite3_result_int64(ctx, (sqlite3_int64)counter);
     if (was_preloaded) do_preload(ctx, tbl, col);
 }

@@ -412,3 +412,41 @@ def test_long_row_kernel_forced_on_ordinary_rows(pkg, orc, monkeypatch):
     idb, db = c.scan_topk(dg.COSINE, q, 33)
     assert dg.same_float_bits(a, b) and ida.tolist() == idb.tolist() and np.array_equal(da, db)
     c.close()
+
+
+# ------------------------------------------------------------------------------------------------- GPU quantization
+
+@pytest.mark.parametrize("vt", dg.ALL_TYPES)
+def test_gpu_minmax_and_quantize_bit_exact(pkg, orc, vt):
+    """vector_quantize's two passes as kernels over the staged corpus: min / max / any-negative and every quantized
+    byte must equal the pinned oracle (= the reference's host arithmetic, sqlite-vector.c:495-757, :1210-1268),
+    including NaN / Inf / huge elements."""
+    n, dim = 1500, 77
+    rows = dg.corpus(vt, n, dim, 61)
+    if vt == dg.F32:
+        rows[3, 5] = np.float32(np.nan); rows[4, 6] = np.float32(3e9); rows[5, 7] = np.float32(-np.inf); rows[6, 8] = np.float32(-3e9)
+    if vt in (dg.F16, dg.BF16):
+        rows[3, 5] = dg.F16_NAN if vt == dg.F16 else dg.BF_NAN
+        rows[4, 6] = dg.F16_INF if vt == dg.F16 else dg.BF_INF
+        rows[5, 7] = dg.F16_NINF if vt == dg.F16 else dg.BF_NINF
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    finite = rows.copy()
+    qt, scale, offset = orc.quant_params(vt, finite, 0)
+    lo, hi, neg = c.minmax()
+    f = dg.storage_to_f64(vt, rows)
+    with np.errstate(invalid="ignore"):
+        want_lo = np.float32(np.nanmin(np.where(np.isnan(f), np.inf, f)))
+        want_hi = np.float32(np.nanmax(np.where(np.isnan(f), -np.inf, f)))
+    assert np.float32(lo) == max(want_lo, np.float32(-3.4028235e38)) or (np.isinf(want_lo) and lo == want_lo)
+    assert np.float32(hi) == min(want_hi, np.float32(3.4028235e38)) or (np.isinf(want_hi) and hi == want_hi)
+    assert neg == bool((f < 0).any())
+    for qtype, sc, off in ((pkg.QUANT_U8, 37.5, -1.25), (pkg.QUANT_S8, 21.0, 0.0), (qt, scale, offset)):
+        if not np.isfinite(sc):
+            continue
+        got = c.quantize_rows(sc, off, qtype)
+        want = np.stack([orc.quantize(vt, rows[i], off, sc, qtype).view(np.uint8) for i in range(n)])
+        assert np.array_equal(got, want), (dg.TYPE_NAMES[vt], qtype, np.argwhere(got != want)[:5])
+        part = c.quantize_rows(sc, off, qtype, row0=700, n_rows=300)
+        assert np.array_equal(part, want[700:1000])
+    c.close()
