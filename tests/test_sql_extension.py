@@ -282,3 +282,13 @@ def test_null_vectors_without_rowid_tables_and_k0(ext_path, orc):
     assert [g[0] for g in got] == [w[1] for w in want] and len(got) == 5
     assert np.allclose([g[1] for g in got], [w[0] for w in want], rtol=1e-5)
     assert db.execute("SELECT id FROM vector_full_scan('w','v',?,0)", (q.tobytes(),)).fetchall() == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", mg.SQL_QUANT_CASES, ids=[c[0] for c in mg.SQL_QUANT_CASES])
+def test_vector_quantize_on_gpu_persists_the_reference_bytes(ext_path, case):
+    """same check as the CPU test above, but on the GPU box vector_quantize takes the GPU path
+    (vg_corpus_minmax / vg_corpus_quantize_rows): the shadow table must still be byte-identical to the reference's."""
+    import __graft_entry__ as g
+    assert g.load_package().device_count() > 0
+    test_vector_quantize_persists_the_reference_bytes(ext_path, case)
