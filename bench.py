@@ -34,7 +34,10 @@ WORKLOADS = {
     # name: (type enum, numpy dtype, dim, metric enum, description)
     "c2": (1, np.float32, 384, 1, "10Mx384 f32 L2 top-20 single-query"),
     "c3": (4, np.uint8, 768, 3, "10Mx768 u8 quantized cosine top-20 single-query"),
+    # batched queries on the matrix cores (config #5); a step is one batch of --batch queries; single GPU
+    "c5": (1, np.float32, 384, 4, "batched 1024 queries x 10Mx384 f32 dot top-20 (MFMA Q x C^T + fused top-k)"),
 }
+F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
 
 
 def parse():
@@ -47,6 +50,7 @@ def parse():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--batch", type=int, default=1024, help="queries per batch (workload c5)")
     return ap.parse_args()
 
 
@@ -102,6 +106,38 @@ def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows):
                       (reps, sample_rows, dim, np.dtype(np_dtype).name, k, label, os.cpu_count())}
 
 
+def bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc):
+    """config #5 on one GPU: each step = one batch of queries through vg_scan_topk_batch (host queries in, host
+    (rowid, distance) lists out).  The dominant kernel is MFMA-bound: flops = 2 * Q * N * D per launch."""
+    nq = args.batch
+    rng = np.random.default_rng(44)
+    steps, warmup = min(args.steps, 10), min(args.warmup, 2)
+    batches = [rng.standard_normal((nq, dim), dtype=np.float32) for _ in range(2)]
+    for i in range(warmup):
+        corpus.scan_topk_batch(metric, batches[i % 2], k)
+    corpus.set_profiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        corpus.scan_topk_batch(metric, batches[i % 2], k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_launch, kern_ms, _ = corpus.profile_mean_ms()
+    flops = 2.0 * nq * n_rows * dim
+    tf = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    print(json.dumps({
+        "metric": "vectors scanned/sec (query x vector pairs), batched dot top-20 over Nx384 f32",
+        "value": nq * n_rows * steps / elapsed, "unit": "vectors/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "rows_per_gpu": n_rows, "dim": dim, "k": k, "queries_per_batch": nq,
+                   "backend": pkg.backend_name()},
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": tf / F32_MFMA_PEAK_TF, "traffic": None, "kernel": "vg_batch_kernel<%d>" % ((dim + 7) // 8),
+                     "kernel_ms": kern_ms, "launches_timed": n_launch, "flops_per_launch": flops}}))
+    corpus.close()
+
+
 def main():
     args = parse()
     import torch
@@ -132,6 +168,8 @@ def main():
     corpus = make_shard(pkg, torch, vt, dim, n_rows, 42 + rank, local_rank)
     corpus.set_rowid_base(1 + rank * n_rows)
     corpus.set_profiling(True)
+    if args.workload == "c5":
+        return bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc)
 
     # queries: a different one every step, pre-generated on the host
     rng = np.random.default_rng(43)
