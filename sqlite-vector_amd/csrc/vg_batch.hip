@@ -41,6 +41,9 @@ typedef float vgb_f32x16 __attribute__((ext_vector_type(16)));
 #define VGB_QPB (VGB_WAVES * VGB_QPW)   // queries per workgroup
 #define VGB_TILE 32                     // corpus rows per tile
 #define VGB_MAX_K 32
+#ifndef VGB_ABLATE
+#define VGB_ABLATE 0                    // probe builds only: 1 = no threshold tests, 2 = no DMA after tile 0, 4 = no barrier
+#endif
 
 struct BatchArgs {
     const float *rows;        // N x stride_f floats
@@ -63,7 +66,7 @@ __device__ __forceinline__ void vgb_static_for(F &&f) {
     }
 }
 
-template <int NT>
+template <int NT, bool COS>
 __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int PITCH = NT * 8 + 4;                         // floats per LDS tile row (16-byte pad: conflict-free b128)
@@ -120,23 +123,29 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     const int chunks_per_row = (int)(a.stride_f / 4);
     const long long tile_first = (long long)part * a.tiles_per_part;
     const long long tile_last = min(tile_first + a.tiles_per_part, (a.n_rows + VGB_TILE - 1) / VGB_TILE);
-    // one 1-KiB DMA piece: piece index pc in [0, 8*PIECES) = (row slot i, piece p) of this wavefront's 8 rows
-    auto dma_piece = [&](long long tile, float *dst_tile, int pc) {
+    // One 1-KiB DMA piece: piece index pc in [0, 8*PIECES) = (row slot i, piece p) of this wavefront's 8 rows.
+    // LDS-DMA from inline asm: hipcc's waitcnt pass does not see it, so it cannot put "s_waitcnt vmcnt(0)" in front
+    // of every ds_read of the CURRENT tile while the NEXT tile is in flight (it did with the builtin: 16 exposed HBM
+    // round trips per tile).  Completion is waited for explicitly before the tile barrier.
+    // Addressing is scalar: SGPR pair = row base, one VGPR per piece column = lane byte offset (computed once);
+    // M0 = wave-uniform LDS byte address of the piece; lane i lands at M0 + 16*i; inactive lanes write nothing.
+    const uint32_t n_rows32 = (uint32_t)a.n_rows;
+    const unsigned long long stride_b = (unsigned long long)a.stride_f * 4ull;
+    uint32_t lane_off[PIECES];
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) lane_off[p] = (uint32_t)(p * 64 + lane) * 16u;
+    const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)tile0;
+    auto dma_piece = [&](uint32_t tile32, int buf, int pc) {
         const int i = pc / PIECES, p = pc - i * PIECES;
         const int rr = wave + i * VGB_WAVES;
-        const long long grow = min(tile * VGB_TILE + rr, a.n_rows - 1);     // rows past the end are masked later
-        const int c = p * 64 + lane;
-        // LDS-DMA from inline asm: hipcc's waitcnt pass does not see it, so it cannot put "s_waitcnt vmcnt(0)" in
-        // front of every ds_read of the CURRENT tile while the NEXT tile is in flight (it did with the builtin: 16
-        // exposed HBM round trips per tile).  Completion is waited for explicitly before the tile barrier.
-        // M0 = wave-uniform LDS byte address of the piece; lane i lands at M0 + 16*i; inactive lanes write nothing.
-        if (c < chunks_per_row) {
-            const float *gsrc = a.rows + grow * a.stride_f + c * 4;
-            const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
-                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)(dst_tile + rr * PITCH + p * 256));
+        uint32_t grow = tile32 * VGB_TILE + (uint32_t)rr;                      // rows past the end are masked later
+        grow = grow < n_rows32 ? grow : n_rows32 - 1u;
+        const uint8_t *sbase = reinterpret_cast<const uint8_t *>(a.rows) + (unsigned long long)grow * stride_b;
+        const uint32_t lds_dst = lds_tile0 + (uint32_t)((buf * TILE_FLOATS + rr * PITCH + p * 256) * 4);
+        if (p * 64 + lane < chunks_per_row) {
             uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_off[p]), "s"(sbase), "s"(lds_dst) : "memory");
         }
     };
     constexpr int NPIECE = (VGB_TILE / VGB_WAVES) * PIECES;
@@ -145,17 +154,25 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     auto reg_distance = [&](int r, float acc_r, float xnorm) -> float {
         const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
         float d;
-        if (a.cosine) d = vg_cosine_from_norms(acc_r, qn_w[qi], xnorm);
+        if (COS) d = vg_cosine_from_norms(acc_r, qn_w[qi], xnorm);
         else d = -acc_r;
         return vg_clamp(d);
     };
-    // branch-free test (runs inside the MFMA loop): does any lane of this register beat its query's k-th best?
-    auto reg_pending = [&](int r, float acc_r, long long row, float xnorm) -> unsigned {
-        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float d = reg_distance(r, acc_r, xnorm);
-        const bool pass = (row < a.n_rows) && (d <= thr_w[qi]) && (d < INFINITY);
-        return __ballot(pass) ? (1u << r) : 0u;
+    // In-loop gate, ONE compare per register: a superset of "distance <= current k-th best" evaluated on the raw
+    // accumulator.  dot: d = -acc <= thr  <=>  acc >= -thr (minus a hair for the 8-eps clamp).  cosine:
+    // 1 - acc/(|q||x|) <= thr  <=>  acc >= (1-thr)|q| * |x|, tested with a relative + absolute slack.  The exact
+    // distance, clamp, row bound and key comparison happen in reg_insert (rare).  The full test with its LDS read
+    // and clamp cost 30% of the kernel when it ran 16 times per tile.
+    float gate[16];
+    auto reload_gates = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float t = thr_w[qi];
+            gate[r] = COS ? (1.0f - t) * qn_w[qi] : (-t - 1e-6f);
+        }
     };
+    reload_gates();
     // slow path (outside the MFMA loop, rare once the lists have warmed up): insert this register's survivors
     auto reg_insert = [&](int r, float acc_r, long long row, float xnorm) {
         const int q_lo = (r & 3) + 8 * (r >> 2);
@@ -182,30 +199,30 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
 
     if (tile_first < tile_last) {
 #pragma unroll
-        for (int pc = 0; pc < NPIECE; ++pc) dma_piece(tile_first, tile0, pc);
+        for (int pc = 0; pc < NPIECE; ++pc) dma_piece((uint32_t)tile_first, 0, pc);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // land this wavefront's DMA pieces ...
     __syncthreads();                                          // ... and everybody else's
 
     // Software pipeline: while tile t runs on the matrix core, the wavefront (a) issues the DMA pieces of tile t+1
-    // and (b) runs the threshold test of tile t-1's 16 accumulator registers, one every few MFMAs - both in the
-    // shadow of the 64-cycle MFMAs instead of in front of / behind them (that serialisation cost ~40% of the tile
-    // time).  The loop body stays branch free; registers that have survivors are handled after it.
+    // and (b) gates tile t-1's 16 accumulator registers, one compare every few MFMAs - both in the shadow of the
+    // 64-cycle MFMAs.  The loop body stays branch free; registers that pass the gate are handled after it.
     vgb_f32x16 acc_prev;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc_prev[r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc_prev[r] = -INFINITY;     // "no previous tile": nothing passes a gate
     float xnorm_prev = 0.0f;
-    long long row_prev = a.n_rows;                            // "no previous tile": every candidate masked
+    long long row_prev = a.n_rows;
     for (long long tile = tile_first; tile < tile_last; ++tile) {
-        const float *cur = ((tile - tile_first) & 1) ? tile1 : tile0;
-        float *nxt = ((tile - tile_first) & 1) ? tile0 : tile1;
-        const long long tile_next = min(tile + 1, tile_last - 1);   // the last iteration re-fetches its own tile: harmless
+        const int cur_buf = (int)((tile - tile_first) & 1);
+        const float *cur = cur_buf ? tile1 : tile0;
+        const uint32_t tile_next = (uint32_t)min(tile + 1, tile_last - 1);   // the last iteration re-fetches its own tile: harmless
 
         vgb_f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         float xx_part = 0.0f;
         unsigned pend = 0;
+        const float cos_slack = COS ? xnorm_prev : 0.0f;
         const float *brow = cur + x * PITCH + 4 * h;
         // compile-time unrolled k loop (a template recursion: the plain "#pragma unroll" gave up on a body this large
         // and put areg[] in scratch memory)
@@ -216,33 +233,40 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 1], b.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 2], b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 3], b.w, acc, 0, 0, 0);
-            if (a.cosine) {
+            if (COS) {
                 xx_part = fmaf(b.x, b.x, xx_part); xx_part = fmaf(b.y, b.y, xx_part);
                 xx_part = fmaf(b.z, b.z, xx_part); xx_part = fmaf(b.w, b.w, xx_part);
             }
-            // DMA pieces of the next tile go out during the FIRST THIRD of the k loop (the remaining two thirds of
-            // the MFMAs cover their ~2 us HBM latency; spreading them over the whole loop left the last pieces
-            // exposed at the barrier); the 16 register tests are spread over the whole loop
+            // DMA pieces of the next tile go out during the FIRST THIRD of the k loop (the rest of the MFMAs cover
+            // their HBM latency); the 16 register gates are spread over the whole loop
             constexpr int NTD = (NT + 2) / 3;
             constexpr int pc_lo = (t >= NTD) ? NPIECE : (t * NPIECE + NTD - 1) / NTD;
             constexpr int pc_hi = (t >= NTD) ? NPIECE : (t + 1 == NTD ? NPIECE : ((t + 1) * NPIECE + NTD - 1) / NTD);
-            vgb_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, nxt, decltype(pcc)::value); });
+            if (!(VGB_ABLATE & 2)) vgb_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, cur_buf ^ 1, decltype(pcc)::value); });
             constexpr int r_lo = (t * 16 + NT - 1) / NT, r_hi = ((t + 1) * 16 + NT - 1) / NT;
             vgb_static_for<r_lo, r_hi>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                pend |= reg_pending(r, acc_prev[r], row_prev, xnorm_prev);
+                if (!(VGB_ABLATE & 1)) {
+                    // cosine: gate*|x| with a slack that covers the rounding of the product and of the division
+                    const float g = COS ? (gate[r] * cos_slack - 1e-5f * fabsf(gate[r] * cos_slack) - 1e-6f * cos_slack - 1e-30f)
+                                             : gate[r];
+                    // negated '<' so that a NaN gate (zero-norm query / row: 0 * Inf) or a NaN score falls through to
+                    // the exact test instead of being silently dropped
+                    pend |= __ballot(!(acc_prev[r] < g)) ? (1u << r) : 0u;
+                }
             });
         });
         if (pend) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (pend & (1u << r)) reg_insert(r, acc_prev[r], row_prev, xnorm_prev);
+            reload_gates();
         }
         acc_prev = acc;
         row_prev = tile * VGB_TILE + x;
-        if (a.cosine) xnorm_prev = sqrtf(xx_part + __shfl_xor(xx_part, 32));
+        if (COS) xnorm_prev = sqrtf(xx_part + __shfl_xor(xx_part, 32));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of tile t+1 have landed
-        __syncthreads();                                      // tile t consumed by all, tile t+1 landed for all
+        if (!(VGB_ABLATE & 4)) __syncthreads();               // tile t consumed by all, tile t+1 landed for all
     }
     // drain: the last tile's registers
 #pragma unroll
@@ -264,13 +288,17 @@ __global__ __launch_bounds__(256) void vg_batch_merge_kernel(const uint64_t *can
     vg_select_lists(cand + (long long)q * npart * 64, npart, k, out_keys + (long long)q * 64, scratch);
 }
 
-template <int NT>
-static int launch_nt(const BatchArgs &a, int blocks, size_t smem, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_kernel<NT>),
+template <int NT, bool COS>
+static int launch_nt_cos(const BatchArgs &a, int blocks, size_t smem, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_kernel<NT, COS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(vg_batch_kernel<NT>, dim3((unsigned)blocks), dim3(VGB_THREADS), smem, stream, a);
+    hipLaunchKernelGGL((vg_batch_kernel<NT, COS>), dim3((unsigned)blocks), dim3(VGB_THREADS), smem, stream, a);
     return (int)hipGetLastError();
+}
+template <int NT>
+static int launch_nt(const BatchArgs &a, int blocks, size_t smem, hipStream_t stream) {
+    return a.cosine ? launch_nt_cos<NT, true>(a, blocks, smem, stream) : launch_nt_cos<NT, false>(a, blocks, smem, stream);
 }
 
 // LDS bytes of the batch kernel for a row of `stride_bytes` and k; 0 if the shape is not served
