@@ -59,6 +59,7 @@ const char *vg_last_error(void);                   /* thread-local message of th
 int     vg_corpus_create(int device, int vtype, int dim, int64_t capacity_rows_hint, vg_corpus **out);
 void    vg_corpus_destroy(vg_corpus *c);
 int     vg_corpus_clear(vg_corpus *c);
+int     vg_corpus_reserve(vg_corpus *c, int64_t capacity_rows);   /* grow HBM to hold that many rows (no-op if it does) */
 int64_t vg_corpus_rows(const vg_corpus *c);
 int     vg_corpus_dim(const vg_corpus *c);
 int     vg_corpus_type(const vg_corpus *c);
@@ -66,7 +67,9 @@ int     vg_corpus_device(const vg_corpus *c);
 int64_t vg_corpus_hbm_bytes(const vg_corpus *c);   /* bytes of HBM held by the row matrix */
 int     vg_corpus_set_rowid_base(vg_corpus *c, int64_t base);   /* implicit rowid = base + position (default 1) */
 
-/* host rows, any byte stride >= dim*elem_size (NULL rows in the SQL table are simply not appended, :2093) */
+/* host rows, any byte stride >= dim*elem_size (NULL rows in the SQL table are simply not appended, :2093).
+ * The rows are copied into a pinned bounce buffer before the call returns (the caller may reuse host_rows at once);
+ * the H2D transfer itself is only enqueued, so staging overlaps with the caller producing the next block. */
 int vg_corpus_append(vg_corpus *c, const void *host_rows, int64_t n_rows, int64_t row_stride_bytes,
                      const int64_t *rowids);
 /* the reference's persisted/preloaded quantized format: n records of [int64 LE rowid][dim bytes], stride 8+dim

@@ -53,6 +53,7 @@ def lib():
         "vg_corpus_create": (i32, [i32, i32, i32, i64, C.POINTER(vp)]),
         "vg_corpus_destroy": (None, [vp]),
         "vg_corpus_clear": (i32, [vp]),
+        "vg_corpus_reserve": (i32, [vp, i64]),
         "vg_corpus_rows": (i64, [vp]),
         "vg_corpus_dim": (i32, [vp]),
         "vg_corpus_type": (i32, [vp]),

@@ -107,6 +107,11 @@ struct vg_corpus {
     void *d_sel_temp = nullptr;
     size_t sel_temp_bytes = 0;
     int64_t sel_cap = 0;
+    uint8_t *pin[2] = {nullptr, nullptr};      // staging pipeline: pinned bounce buffers + their completion events
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_busy[2] = {false, false};
+    int pin_idx = 0;
+    uint8_t *d_stage = nullptr;                // device-side landing zone for rows that need de-interleaving
     void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
     uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;
     size_t bq_bytes = 0, bcand_bytes = 0, bkeys_bytes = 0;
@@ -189,6 +194,8 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_sel_keys) hipFree(c->d_sel_keys);
     if (c->d_sel_sorted) hipFree(c->d_sel_sorted);
     if (c->d_sel_temp) hipFree(c->d_sel_temp);
+    for (int i = 0; i < 2; ++i) { if (c->pin[i]) hipHostFree(c->pin[i]); if (c->pin_ev[i]) hipEventDestroy(c->pin_ev[i]); }
+    if (c->d_stage) hipFree(c->d_stage);
     if (c->d_bq) hipFree(c->d_bq);
     if (c->d_bcand) hipFree(c->d_bcand);
     if (c->d_bkeys) hipFree(c->d_bkeys);
@@ -237,6 +244,12 @@ static int corpus_reserve(vg_corpus *c, int64_t need_rows) {
     return VG_OK;
 }
 
+extern "C" int vg_corpus_reserve(vg_corpus *c, int64_t capacity_rows) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    return corpus_reserve(c, capacity_rows);
+}
+
 static void note_rowids(vg_corpus *c, const int64_t *rowids, int64_t n) {
     if (rowids) {
         if (c->rowids.empty() && c->n_rows > 0) {
@@ -272,6 +285,27 @@ __global__ void vg_repack_kernel(const uint8_t *src, long long src_stride, int s
     *reinterpret_cast<uint4 *>(dst + r * dst_stride + (long long)ch * 16) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// Host -> HBM staging pipeline: two pinned bounce buffers.  The caller's rows are memcpy'd into a pinned buffer and
+// the H2D copy (plus, when the layouts differ, the de-interleave kernel) is only ENQUEUED on the corpus stream, so
+// the call returns while the transfer runs and the caller's next sqlite3_step() batch overlaps with it.  A buffer is
+// reused only after the event recorded behind its last copy has fired.  Scans run on the same stream: ordered.
+#define VG_PIN_BYTES (16ll << 20)
+
+static int pin_acquire(vg_corpus *c, uint8_t **buf, int *slot) {
+    if (!c->pin[0]) {
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipHostMalloc(&c->pin[i], (size_t)VG_PIN_BYTES));
+            HIP_TRY(hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+        }
+        HIP_TRY(hipMalloc(&c->d_stage, (size_t)VG_PIN_BYTES));
+    }
+    *slot = c->pin_idx;
+    c->pin_idx ^= 1;
+    if (c->pin_busy[*slot]) { HIP_TRY(hipEventSynchronize(c->pin_ev[*slot])); c->pin_busy[*slot] = false; }
+    *buf = c->pin[*slot];
+    return VG_OK;
+}
+
 // copies [n_rows x src_stride] host or device bytes into the padded matrix at the current end of the corpus
 static int append_impl(vg_corpus *c, const void *src, bool src_on_device, int64_t n_rows, int64_t src_stride,
                        int src_off) {
@@ -280,36 +314,44 @@ static int append_impl(vg_corpus *c, const void *src, bool src_on_device, int64_
     int rc = corpus_reserve(c, c->n_rows + n_rows);
     if (rc != VG_OK) return rc;
     uint8_t *dst = c->d_rows + c->n_rows * c->stride;
-    if (src_off == 0 && src_stride == c->stride) {
-        HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(n_rows * c->stride),
-                               src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+    const bool same_layout = (src_off == 0 && src_stride == c->stride);
+    if (src_on_device) {
+        if (same_layout) {
+            HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(n_rows * c->stride), hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            long long total = n_rows * c->nch;
+            hipLaunchKernelGGL(vg_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                               (const uint8_t *)src, (long long)src_stride, src_off, (int)row_bytes, dst,
+                               (long long)c->stride, c->nch, (long long)n_rows);
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));          // the caller may free / overwrite its device buffer
         return VG_OK;
     }
-    // staged path: bounded pieces through a device staging buffer, then the repack kernel
-    const int64_t piece_rows = std::max<int64_t>(1, (256ll << 20) / src_stride);
-    uint8_t *stage = nullptr;
-    if (!src_on_device) HIP_TRY(hipMalloc(&stage, (size_t)(std::min(piece_rows, n_rows) * src_stride)));
+    if (src_stride > VG_PIN_BYTES) return vg_fail(VG_ERR_UNSUPPORTED, "row stride %lld exceeds the staging buffer", (long long)src_stride);
+    const int64_t piece_rows = std::max<int64_t>(1, VG_PIN_BYTES / src_stride);
     for (int64_t r0 = 0; r0 < n_rows; r0 += piece_rows) {
-        int64_t nr = std::min(piece_rows, n_rows - r0);
+        const int64_t nr = std::min(piece_rows, n_rows - r0);
         const uint8_t *s = (const uint8_t *)src + r0 * src_stride;
-        const uint8_t *dsrc = s;
-        if (!src_on_device) {
-            // the last row may be shorter than the stride in the caller's buffer: copy only what is addressable
-            size_t bytes = (size_t)((nr - 1) * src_stride + src_off + row_bytes);
-            hipError_t e = hipMemcpyAsync(stage, s, bytes, hipMemcpyHostToDevice, c->stream);
-            if (e != hipSuccess) { hipFree(stage); return vg_fail(VG_ERR_HIP, "H2D staging copy failed: %s", hipGetErrorString(e)); }
-            dsrc = stage;
+        // the last row may be shorter than the stride in the caller's buffer: copy only what is addressable
+        const size_t bytes = (size_t)((nr - 1) * src_stride + src_off + row_bytes);
+        uint8_t *pin;
+        int slot;
+        rc = pin_acquire(c, &pin, &slot);
+        if (rc != VG_OK) return rc;
+        memcpy(pin, s, bytes);
+        if (same_layout) {
+            HIP_TRY(hipMemcpyAsync(dst + r0 * c->stride, pin, bytes, hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(c->d_stage, pin, bytes, hipMemcpyHostToDevice, c->stream));
+            long long total = nr * c->nch;
+            hipLaunchKernelGGL(vg_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                               (const uint8_t *)c->d_stage, (long long)src_stride, src_off, (int)row_bytes,
+                               dst + r0 * c->stride, (long long)c->stride, c->nch, (long long)nr);
         }
-        long long total = nr * c->nch;
-        int threads = 256;
-        long long blocks = (total + threads - 1) / threads;
-        hipLaunchKernelGGL(vg_repack_kernel, dim3((unsigned)blocks), dim3(threads), 0, c->stream, dsrc, (long long)src_stride,
-                           src_off, (int)row_bytes, dst + r0 * c->stride, (long long)c->stride, c->nch, (long long)nr);
-        hipError_t e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { if (stage) hipFree(stage); return vg_fail(VG_ERR_HIP, "repack failed: %s", hipGetErrorString(e)); }
+        HIP_TRY(hipEventRecord(c->pin_ev[slot], c->stream));
+        c->pin_busy[slot] = true;
     }
-    if (stage) hipFree(stage);
+    HIP_TRY(hipGetLastError());
     return VG_OK;
 }
 

@@ -55,6 +55,7 @@ typedef struct {
     int (*corpus_create)(int, int, int, int64_t, vg_corpus **);
     void (*corpus_destroy)(vg_corpus *);
     int (*corpus_clear)(vg_corpus *);
+    int (*corpus_reserve)(vg_corpus *, int64_t);
     int64_t (*corpus_rows)(const vg_corpus *);
     int (*corpus_append)(vg_corpus *, const void *, int64_t, int64_t, const int64_t *);
     int (*corpus_append_records)(vg_corpus *, const void *, int64_t);
@@ -102,6 +103,7 @@ static int gpu_load(void) {
     G.corpus_create = (int (*)(int, int, int, int64_t, vg_corpus **))gpu_sym("vg_corpus_create");
     G.corpus_destroy = (void (*)(vg_corpus *))gpu_sym("vg_corpus_destroy");
     G.corpus_clear = (int (*)(vg_corpus *))gpu_sym("vg_corpus_clear");
+    G.corpus_reserve = (int (*)(vg_corpus *, int64_t))gpu_sym("vg_corpus_reserve");
     G.corpus_rows = (int64_t (*)(const vg_corpus *))gpu_sym("vg_corpus_rows");
     G.corpus_append = (int (*)(vg_corpus *, const void *, int64_t, int64_t, const int64_t *))gpu_sym("vg_corpus_append");
     G.corpus_append_records = (int (*)(vg_corpus *, const void *, int64_t))gpu_sym("vg_corpus_append_records");
@@ -604,6 +606,10 @@ static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
     if (t->full) G.corpus_clear(t->full);
     else if (G.corpus_create(0, t->opt.v_type, dim, 0, &t->full) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
 
+    {   /* one HBM allocation of the right size instead of geometric regrowth (COUNT(*) is an upper bound: NULLs) */
+        char *cnt = sqlite3_mprintf("SELECT COUNT(*) FROM %q;", t->t_name);
+        if (cnt) { int64_t n = read_int64(db, cnt); sqlite3_free(cnt); if (n > 0) G.corpus_reserve(t->full, n); }
+    }
     char *sql = sqlite3_mprintf("SELECT %q, %q FROM %q;", t->pk_name, t->c_name, t->t_name);
     if (!sql) return SQLITE_NOMEM;
     sqlite3_stmt *st = NULL;
