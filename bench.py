@@ -171,10 +171,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # VG_BENCH_FORCE_DIST=1 runs the collective path even with one rank (RCCL smoke test on a 1-GPU box)
+    use_dist = world > 1 or (os.environ.get("VG_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    torch.cuda.set_device(local_rank)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
@@ -212,7 +214,7 @@ def main():
     h_query = torch.zeros(qpad, dtype=torch.uint8).pin_memory()
     d_keys = torch.empty(64, dtype=torch.int64, device="cuda")
     h_keys = torch.empty((n_gpus, 64), dtype=torch.int64).pin_memory()
-    d_all = torch.empty((n_gpus, 64), dtype=torch.int64, device="cuda") if world > 1 else None
+    d_all = torch.empty((n_gpus, 64), dtype=torch.int64, device="cuda") if use_dist else None
     offsets = [i * n_rows for i in range(n_gpus)]
     last = {}
 
@@ -221,7 +223,7 @@ def main():
         h_query[: dim * es] = torch.from_numpy(queries[i].view(np.uint8))
         d_query.copy_(h_query, non_blocking=True)
         corpus.scan_topk_device(metric, d_query.data_ptr(), k, d_keys.data_ptr(), stream.cuda_stream)
-        if world > 1:
+        if use_dist:
             # the path's only exchange: 64 keys per rank, one RCCL all_gather, rank 0 merges (shard.py)
             res = shard.gather_and_merge(pkg, dist, d_keys, d_all, offsets, k, dst=0, host_buf=h_keys,
                                          sync=stream.synchronize)
@@ -237,7 +239,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     corpus.set_profiling(True)                    # reset the event ring: only timed steps are averaged
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     lat = []
@@ -246,11 +248,11 @@ def main():
         ts = time.perf_counter()
         step(args.warmup + i)
         lat.append(time.perf_counter() - ts)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -294,7 +296,7 @@ def main():
                                        "sample": "unavailable: %r" % (e,)}
         print(json.dumps(out))
     corpus.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
