@@ -87,7 +87,8 @@ int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k,
 
 /* Same scan, but the k candidates stay on the device as packed 64-bit keys
  * (hi 32 = order-preserving image of the float distance, lo 32 = scan position), ascending, padded with
- * VG_KEY_EMPTY.  dev_query / dev_out_keys are device pointers; stream is a hipStream_t (NULL = corpus stream).
+ * VG_KEY_EMPTY.  dev_query / dev_out_keys are device pointers (dev_query: the dim elements followed by ZERO bytes up
+ * to the next 16-byte multiple; dev_out_keys: 64 keys); stream is a hipStream_t (NULL = the corpus' own stream).
  * No host synchronisation: this is what one rank of a row-sharded multi-GPU scan runs before the candidate
  * gather (RCCL) and what bench.py times. */
 int vg_scan_topk_device(vg_corpus *c, int metric, const void *dev_query, int k,

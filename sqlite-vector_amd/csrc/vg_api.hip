@@ -112,6 +112,8 @@ struct vg_corpus {
     bool pin_busy[2] = {false, false};
     int pin_idx = 0;
     uint8_t *d_stage = nullptr;                // device-side landing zone for rows that need de-interleaving
+    hipEvent_t append_ev = nullptr;            // recorded behind the last enqueued host append (other streams wait on it)
+    bool append_pending = false;
     void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
     uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;
     size_t bq_bytes = 0, bcand_bytes = 0, bkeys_bytes = 0;
@@ -195,6 +197,7 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_sel_sorted) hipFree(c->d_sel_sorted);
     if (c->d_sel_temp) hipFree(c->d_sel_temp);
     for (int i = 0; i < 2; ++i) { if (c->pin[i]) hipHostFree(c->pin[i]); if (c->pin_ev[i]) hipEventDestroy(c->pin_ev[i]); }
+    if (c->append_ev) hipEventDestroy(c->append_ev);
     if (c->d_stage) hipFree(c->d_stage);
     if (c->d_bq) hipFree(c->d_bq);
     if (c->d_bcand) hipFree(c->d_bcand);
@@ -298,6 +301,7 @@ static int pin_acquire(vg_corpus *c, uint8_t **buf, int *slot) {
             HIP_TRY(hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
         }
         HIP_TRY(hipMalloc(&c->d_stage, (size_t)VG_PIN_BYTES));
+        HIP_TRY(hipEventCreateWithFlags(&c->append_ev, hipEventDisableTiming));
     }
     *slot = c->pin_idx;
     c->pin_idx ^= 1;
@@ -314,7 +318,9 @@ static int append_impl(vg_corpus *c, const void *src, bool src_on_device, int64_
     int rc = corpus_reserve(c, c->n_rows + n_rows);
     if (rc != VG_OK) return rc;
     uint8_t *dst = c->d_rows + c->n_rows * c->stride;
-    const bool same_layout = (src_off == 0 && src_stride == c->stride);
+    // a plain copy is only valid when source rows have no padding of their own: padding bytes must be ZERO in HBM
+    // (they are summed like data), so any row whose size is not a 16-byte multiple goes through the repack kernel
+    const bool same_layout = (src_off == 0 && src_stride == c->stride && row_bytes == c->stride);
     if (src_on_device) {
         if (same_layout) {
             HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(n_rows * c->stride), hipMemcpyDeviceToDevice, c->stream));
@@ -351,6 +357,8 @@ static int append_impl(vg_corpus *c, const void *src, bool src_on_device, int64_
         HIP_TRY(hipEventRecord(c->pin_ev[slot], c->stream));
         c->pin_busy[slot] = true;
     }
+    HIP_TRY(hipEventRecord(c->append_ev, c->stream));
+    c->append_pending = true;
     HIP_TRY(hipGetLastError());
     return VG_OK;
 }
@@ -576,6 +584,9 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
         qbytes = ((c->nch + slice - 1) / slice) * slice * 16;
     }
     size_t smem = std::max<size_t>(qbytes, (size_t)VG_PUBLISH_LDS_BYTES);
+
+    // host appends are only enqueued on the corpus stream: a scan on ANOTHER stream must wait for them
+    if (c->append_pending && stream != c->stream) HIP_TRY(hipStreamWaitEvent(stream, c->append_ev, 0));
 
     hipEvent_t *evs = nullptr;
     if (c->profiling) {

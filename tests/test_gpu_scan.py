@@ -190,14 +190,17 @@ def test_rowids_strides_and_reference_record_format(pkg, orc):
     assert ids.tolist() == oids.tolist() and np.array_equal(dist, odist)
     c1.close()
 
-    padded = np.zeros((n, 128), dtype=np.uint8)
-    padded[:, :dim] = rows
-    padded[:, dim:] = 0xAB                                     # garbage in the stride gap must be ignored
-    c2 = pkg.Corpus(pkg.U8, dim)
-    c2.append_strided(padded, n, 128, rowids)
-    ids, dist = c2.scan_topk(dg.COSINE, q, 20)
-    assert ids.tolist() == oids.tolist() and np.array_equal(dist, odist)
-    c2.close()
+    # 112 is exactly the corpus' own padded HBM stride for 100 bytes: the gap must still be zeroed, not imported
+    for stride in (112, 128, 101):
+        padded = np.zeros((n, stride), dtype=np.uint8)
+        padded[:, :dim] = rows
+        padded[:, dim:] = 0xAB                                 # garbage in the stride gap must be ignored
+        c2 = pkg.Corpus(pkg.U8, dim)
+        c2.append_strided(padded, n, stride, rowids)
+        ids, dist = c2.scan_topk(dg.COSINE, q, 20)
+        assert ids.tolist() == oids.tolist() and np.array_equal(dist, odist), stride
+        assert dg.same_float_bits(c2.scan_distances(dg.L2, q), orc.scan_distances(orc.AVX2, dg.L2, dg.U8, q, rows))
+        c2.close()
 
     rec = np.zeros((n, 8 + dim), dtype=np.uint8)
     rec[:, :8] = rowids.astype("<i8").view(np.uint8).reshape(n, 8)
@@ -449,4 +452,39 @@ def test_gpu_minmax_and_quantize_bit_exact(pkg, orc, vt):
         assert np.array_equal(got, want), (dg.TYPE_NAMES[vt], qtype, np.argwhere(got != want)[:5])
         part = c.quantize_rows(sc, off, qtype, row0=700, n_rows=300)
         assert np.array_equal(part, want[700:1000])
+    c.close()
+
+
+def test_device_appends_and_cross_stream_scan(pkg, orc):
+    """append_device with the corpus' own padded stride and garbage in the gap; then a scan on a caller stream that
+    was launched straight after an (asynchronous) host append must see every appended row."""
+    import torch
+    dim, n = 100, 70_000
+    rows = dg.corpus(dg.I8, n, dim, 77)
+    q = dg.query(dg.I8, dim, 78)
+    want = orc.scan_distances(orc.AVX2, dg.SQUARED_L2, dg.I8, q, rows)
+    oids, odist, _ = orc.topk_ordered(want, np.arange(1, n + 1, dtype=np.int64), 10)
+
+    padded = np.full((n, 112), 0x5A, dtype=np.uint8)
+    padded[:, :dim] = rows.view(np.uint8)
+    t = torch.from_numpy(padded).cuda()
+    c = pkg.Corpus(pkg.I8, dim)
+    c.append_device(t.data_ptr(), n, 112)
+    ids, dist = c.scan_topk(dg.SQUARED_L2, q, 10)
+    assert ids.tolist() == oids.tolist() and np.array_equal(dist, odist)
+    c.close()
+
+    c = pkg.Corpus(pkg.I8, dim)
+    qpad = np.zeros(112, dtype=np.uint8)
+    qpad[:dim] = q.view(np.uint8)
+    dq = torch.from_numpy(qpad).cuda()
+    keys = torch.zeros(64, dtype=torch.int64, device="cuda")
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    c.append(rows)                                              # host append: only enqueued on the corpus stream
+    c.scan_topk_device(dg.SQUARED_L2, dq.data_ptr(), 10, keys.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    k = keys.cpu().numpy().view(np.uint64)[:10]
+    pos = (k & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    assert (pos + 1).tolist() == oids.tolist()
     c.close()
