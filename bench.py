@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - vectors scanned / second for the sqlite-vector hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c2|c3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5]
 
 Workload (BASELINE.json): configs[1] = 10M x 384 f32, L2, top-20, single query, corpus resident in HBM.
 A "step" is ONE complete query: upload the query, scan the whole shard, reduce to k candidates, bring the k keys
@@ -32,6 +32,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 
 WORKLOADS = {
     # name: (type enum, numpy dtype, dim, metric enum, description)
+    # configs[0], the reference's own CPU-runnable case, driven through SQL (python sqlite3 + load_extension): the
+    # same statements against this repo's vector.so (GPU) and the reference's vector.so (oracle/_ref, CPU)
+    "c1": (1, np.float32, 384, 1, "10kx384 f32 L2 top-20 through SQL: SELECT ... FROM vector_full_scan(...)"),
     "c2": (1, np.float32, 384, 1, "10Mx384 f32 L2 top-20 single-query"),
     "c3": (4, np.uint8, 768, 3, "10Mx768 u8 quantized cosine top-20 single-query"),
     # batched queries on the matrix cores (config #5); a step is one batch of --batch queries; single GPU
@@ -163,6 +166,89 @@ def bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc):
     corpus.close()
 
 
+def sql_latency(ext_path, rows, queries, k, warmup, steps):
+    """p50 / mean seconds of `SELECT rowid, distance FROM vector_full_scan('t','v',?,k)` through `ext_path`"""
+    import sqlite3
+    db = sqlite3.connect(":memory:", isolation_level=None)
+    db.enable_load_extension(True)
+    db.load_extension(ext_path)
+    db.execute("CREATE TABLE t (id INTEGER PRIMARY KEY, v BLOB)")
+    db.executemany("INSERT INTO t(id, v) VALUES (?, ?)", [(i + 1, rows[i].tobytes()) for i in range(rows.shape[0])])
+    db.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2')" % rows.shape[1])
+    backend = db.execute("SELECT vector_backend()").fetchone()[0]
+    sql = "SELECT rowid, distance FROM vector_full_scan('t', 'v', ?, %d)" % k
+    res = None
+    for i in range(warmup):
+        res = db.execute(sql, (queries[i].tobytes(),)).fetchall()
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ts = time.perf_counter()
+        res = db.execute(sql, (queries[warmup + i].tobytes(),)).fetchall()
+        lat.append(time.perf_counter() - ts)
+    elapsed = time.perf_counter() - t0
+    res = db.execute(sql, (queries[0].tobytes(),)).fetchall()          # same query for every build: result check
+    db.close()
+    return elapsed, float(np.median(lat)), backend, res
+
+
+def bench_sql(args, pkg, torch):
+    """config #1: what a user of the reference types, unchanged, with this repo's vector.so loaded instead."""
+    vt, np_dtype, dim, metric, desc = WORKLOADS["c1"]
+    n_rows = 10_000 if args.rows == 10_000_000 else args.rows
+    k, steps, warmup = args.k, args.steps, args.warmup
+    rng = np.random.default_rng(42)
+    rows = rng.standard_normal((n_rows, dim), dtype=np.float32)
+    queries = np.random.default_rng(43).standard_normal((steps + warmup, dim), dtype=np.float32)
+    elapsed, p50, backend, res = sql_latency(pkg.EXT_PATH[:-3], rows, queries, k, warmup, steps)
+    # kernel-level roofline of the same shape, HIP events around the scan kernel (the extension's own corpus is private)
+    corpus = pkg.Corpus(vt, dim, capacity=n_rows)
+    corpus.append(rows)
+    for i in range(warmup):
+        corpus.scan_topk(metric, queries[i], k)
+    corpus.set_profiling(True)
+    for i in range(steps):
+        corpus.scan_topk(metric, queries[warmup + i], k)
+    n_launch, scan_ms, merge_ms = corpus.profile_mean_ms()
+    algo_bytes = n_rows * dim * 4
+    achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    out = {
+        "metric": "vectors scanned/sec, L2 top-20 over Nx384 f32 (SQL level)",
+        "value": n_rows * steps / elapsed, "unit": "vectors/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "p50_query_latency_ms": p50 * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": desc, "rows_per_gpu": n_rows, "dim": dim, "k": k, "backend": backend},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": corpus.kernel_name(metric),
+                     "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms, "launches_timed": n_launch,
+                     "algorithmic_bytes_per_launch": algo_bytes,
+                     "note": "a 15 MB scan is launch-latency bound, not HBM bound; see the c2 line for the roofline"},
+    }
+    corpus.close()
+    if not args.no_cpu_baseline:
+        try:
+            from oracle import orc
+            base = {}
+            for which in ("cpu", "avx2"):
+                ref = orc.ref_extension_path(which)
+                if ref:
+                    el, rp50, rbackend, rres = sql_latency(ref, rows, queries, k, min(warmup, 2), min(steps, 20))
+                    base[which] = {"value": n_rows * min(steps, 20) / el, "p50_query_latency_ms": rp50 * 1e3, "backend": rbackend,
+                                   "same_rowids_as_gpu": [r[0] for r in rres] == [r[0] for r in res]}
+            if base:
+                best = base.get("cpu") or base["avx2"]
+                out["cpu_baseline"] = {"value": best["value"], "unit": "vectors/s", "cores": 1, "kind": "reference",
+                                       "sample": "the same SQL through the reference's own vector.so built by oracle/Makefile "
+                                                 "(stock flags = what its Makefile ships; 'avx2' = same sources with -mavx2)",
+                                       "builds": base}
+            else:
+                out["cpu_baseline"] = {"value": None, "unit": "vectors/s", "cores": 0, "kind": "reference",
+                                       "sample": "oracle/_ref/*/vector.so not built"}
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "vectors/s", "cores": 0, "kind": "reference", "sample": "unavailable: %r" % (e,)}
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
     import torch
@@ -187,6 +273,8 @@ def main():
     spec = importlib.util.spec_from_file_location("vg_shard", os.path.join(ROOT, "sqlite-vector_amd", "shard.py"))
     shard = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(shard)
+    if args.workload == "c1":
+        return bench_sql(args, pkg, torch)
     vt, np_dtype, dim, metric, desc = WORKLOADS[args.workload]
     es = pkg.TYPE_SIZE[vt]
     k = args.k

@@ -609,6 +609,13 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     return VG_OK;
 }
 
+// latency path for small corpora (see vg_scan_topk): below this size the H2D/D2H staging copies dominate
+static bool host_direct(const vg_corpus *c) {
+    const int v = env_int("VG_HOST_DIRECT", -1);
+    if (v >= 0) return v != 0;
+    return c->n_rows * c->stride <= (64ll << 20);
+}
+
 static void stage_query(vg_corpus *c, const void *query) {
     memset(c->h_query, 0, (size_t)c->stride);
     memcpy(c->h_query, query, (size_t)c->dim * c->es);
@@ -728,10 +735,18 @@ extern "C" int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k, 
     HIP_TRY(hipSetDevice(c->device));
     if (k > VG_MAX_FUSED_K) return scan_topk_large_k(c, metric, query, k, out_rowids, out_dist, out_count);
     stage_query(c, query);
-    HIP_TRY(hipMemcpyAsync(c->d_query, c->h_query, (size_t)c->stride, hipMemcpyHostToDevice, c->stream));
-    int rc = launch_scan(c, metric, c->d_query, k, c->d_keys, nullptr, c->stream);
-    if (rc != VG_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(c->h_keys, c->d_keys, VG_WAVE * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    int rc;
+    if (host_direct(c)) {
+        // small corpus: the two staging copies cost more than the scan.  h_query / h_keys are pinned, device-mapped
+        // host buffers: the kernels read the query and write the k winners straight across the host link.
+        rc = launch_scan(c, metric, c->h_query, k, c->h_keys, nullptr, c->stream);
+        if (rc != VG_OK) return rc;
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->d_query, c->h_query, (size_t)c->stride, hipMemcpyHostToDevice, c->stream));
+        rc = launch_scan(c, metric, c->d_query, k, c->d_keys, nullptr, c->stream);
+        if (rc != VG_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->h_keys, c->d_keys, VG_WAVE * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     collect_timing(c);
     int cnt = 0;
