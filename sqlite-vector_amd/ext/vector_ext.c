@@ -43,7 +43,7 @@ SQLITE_EXTENSION_INIT1
 #define STAGE_ROWS 8192                           /* rows per host staging block while filling HBM */
 
 /* hidden/visible column indices of the TVF schema (sqlite-vector.c:98-103) */
-enum { COL_TBL = 0, COL_VECTOR = 1, COL_K = 2, COL_MEMIDX = 3, COL_ID = 4, COL_DISTANCE = 5 };
+enum { COL_TBL = 0, COL_VECTOR = 1, COL_K = 2, COL_MEMIDX = 3, COL_ID = 4, COL_DISTANCE = 5, COL_QUERY = 6 /* batch TVFs only */ };
 
 /* ------------------------------------------------------------------------------------------------ GPU library */
 
@@ -61,6 +61,7 @@ typedef struct {
     int (*corpus_append_records)(vg_corpus *, const void *, int64_t);
     int (*scan_topk)(vg_corpus *, int, const void *, int, int64_t *, double *, int *);
     int (*scan_distances)(vg_corpus *, int, const void *, float *);
+    int (*scan_topk_batch)(vg_corpus *, int, const void *, int, int, int64_t *, double *, int *);
     int64_t (*corpus_rowid_at)(const vg_corpus *, int64_t);
     int (*quantize_query)(int, const void *, int, float, float, int, void *);
     int (*corpus_minmax)(vg_corpus *, float *, float *, int *);
@@ -109,6 +110,7 @@ static int gpu_load(void) {
     G.corpus_append_records = (int (*)(vg_corpus *, const void *, int64_t))gpu_sym("vg_corpus_append_records");
     G.scan_topk = (int (*)(vg_corpus *, int, const void *, int, int64_t *, double *, int *))gpu_sym("vg_scan_topk");
     G.scan_distances = (int (*)(vg_corpus *, int, const void *, float *))gpu_sym("vg_scan_distances");
+    G.scan_topk_batch = (int (*)(vg_corpus *, int, const void *, int, int, int64_t *, double *, int *))gpu_sym("vg_scan_topk_batch");
     G.corpus_rowid_at = (int64_t (*)(const vg_corpus *, int64_t))gpu_sym("vg_corpus_rowid_at");
     G.quantize_query = (int (*)(int, const void *, int, float, float, int, void *))gpu_sym("vg_quantize_query");
     G.corpus_minmax = (int (*)(vg_corpus *, float *, float *, int *))gpu_sym("vg_corpus_minmax");
@@ -1030,6 +1032,7 @@ typedef struct {
     int64_t *rowids;
     double *distance;
     int row_index, row_count;
+    int *query_no;                     /* batch TVFs: which query of the batch each output row answers */
     /* streaming: all N distances computed by ONE kernel launch, paged out row by row */
     float *all_dist;
     vg_corpus *stream_corpus;
@@ -1090,6 +1093,7 @@ static int tvf_close(sqlite3_vtab_cursor *cur) {
     sqlite3_free(c->rowids);
     sqlite3_free(c->distance);
     sqlite3_free(c->all_dist);
+    sqlite3_free(c->query_no);
     sqlite3_free(c);
     return SQLITE_OK;
 }
@@ -1206,6 +1210,179 @@ static int quant_filter(sqlite3_vtab_cursor *c, int n, const char *s, int argc, 
 static int full_stream_filter(sqlite3_vtab_cursor *c, int n, const char *s, int argc, sqlite3_value **argv) { return filter_common(c, argc, argv, "vector_full_scan_stream", 1, 0); }
 static int quant_stream_filter(sqlite3_vtab_cursor *c, int n, const char *s, int argc, sqlite3_value **argv) { return filter_common(c, argc, argv, "vector_quantize_scan_stream", 1, 1); }
 
+
+/* ---- batched queries (the reference has no multi-query entry point: its equivalent is nq separate
+ * vector_full_scan statements).  vector_full_scan_batch(tbl, col, queries, k) / vector_quantize_scan_batch(...):
+ *   queries  BLOB of nq * dim elements (query vectors back to back), or TEXT JSON array of arrays
+ *   output   (query, id, distance): k rows per query, ordered by query number (0-based) then distance ascending
+ * Each query's rows are what the single-query function returns for it; f32 DOT/COSINE batches run as one
+ * matrix-core pass over the corpus (vg_scan_topk_batch), everything else as nq GPU scans. */
+
+static int batch_connect(sqlite3 *db, void *aux, int argc, const char *const *argv, sqlite3_vtab **out, char **err) {
+    int rc = sqlite3_declare_vtab(db, "CREATE TABLE x(tbl hidden, vector hidden, k hidden, memidx hidden, id, distance, query);");
+    if (rc != SQLITE_OK) return rc;
+    scan_vtab *v = (scan_vtab *)sqlite3_malloc(sizeof(scan_vtab));
+    if (!v) return SQLITE_NOMEM;
+    memset(v, 0, sizeof(*v));
+    v->db = db;
+    v->ctx = (vec_context *)aux;
+    *out = &v->base;
+    return SQLITE_OK;
+}
+
+static int batch_best_index(sqlite3_vtab *v, sqlite3_index_info *info) {
+    info->estimatedCost = 10.0;
+    info->estimatedRows = 1000;
+    info->idxNum = 2;
+    map_constraints(info);
+    /* rows come out as (query asc, distance asc): claim the order only when that is what was asked for */
+    if (info->nOrderBy == 2 && info->aOrderBy[0].iColumn == COL_QUERY && !info->aOrderBy[0].desc &&
+        info->aOrderBy[1].iColumn == COL_DISTANCE && !info->aOrderBy[1].desc) info->orderByConsumed = 1;
+    if (info->nOrderBy == 1 && info->aOrderBy[0].iColumn == COL_QUERY && !info->aOrderBy[0].desc) info->orderByConsumed = 1;
+    return SQLITE_OK;
+}
+
+/* "[[..],[..]]" -> nq vectors back to back; returns sqlite3_malloc'd buffer */
+static void *batch_from_json(sqlite3_vtab *vt, int type, const char *json, int dim, int *nq_out) {
+    const int es = elem_size(type);
+    const char *p = json;
+    while (*p && isspace((unsigned char)*p)) p++;
+    if (*p != '[') { vtab_error(vt, "Malformed JSON: expected '[' at the beginning of the array."); return NULL; }
+    p++;
+    int cap = 0, nq = 0;
+    char *buf = NULL;
+    while (1) {
+        while (*p && (isspace((unsigned char)*p) || *p == ',')) p++;
+        if (*p == ']' || !*p) break;
+        if (*p != '[') { vtab_error(vt, "Malformed JSON: expected an array of arrays."); sqlite3_free(buf); return NULL; }
+        int sz = 0;
+        void *one = vector_from_json(NULL, vt, type, p, &sz, dim);
+        if (!one) { sqlite3_free(buf); return NULL; }
+        if (nq == cap) {
+            cap = cap ? cap * 2 : 16;
+            char *nb = (char *)sqlite3_realloc64(buf, (sqlite3_uint64)cap * dim * es);
+            if (!nb) { sqlite3_free(one); sqlite3_free(buf); return NULL; }
+            buf = nb;
+        }
+        memcpy(buf + (size_t)nq * dim * es, one, (size_t)dim * es);
+        sqlite3_free(one);
+        nq++;
+        while (*p && *p != ']') p++;
+        if (*p == ']') p++;
+    }
+    *nq_out = nq;
+    return buf;
+}
+
+static int batch_filter_common(sqlite3_vtab_cursor *cur, int argc, sqlite3_value **argv, const char *fname, int quantized) {
+    scan_cursor *c = (scan_cursor *)cur;
+    scan_vtab *vt = (scan_vtab *)cur->pVtab;
+    c->streaming = 0;
+    c->row_index = 0;
+    c->row_count = 0;
+    if (argc != 4) return vtab_error(&vt->base, "%s expects %d arguments, but %d were provided.", fname, 4, argc);
+    for (int i = 0; i < argc; ++i) {
+        int t = sqlite3_value_type(argv[i]);
+        if (i < 2 && t != SQLITE_TEXT) return vtab_error(&vt->base, "%s: argument %d must be of type TEXT (got %s).", fname, i + 1, sql_type_name(t));
+        if (i == 2 && t != SQLITE_TEXT && t != SQLITE_BLOB) return vtab_error(&vt->base, "%s: argument %d must be of type TEXT or BLOB (got %s).", fname, i + 1, sql_type_name(t));
+        if (i == 3 && t != SQLITE_INTEGER) return vtab_error(&vt->base, "%s: argument %d must be of type INTEGER (got %s).", fname, i + 1, sql_type_name(t));
+    }
+    const char *tbl = (const char *)sqlite3_value_text(argv[0]);
+    const char *col = (const char *)sqlite3_value_text(argv[1]);
+    table_ctx *t = context_lookup(vt->ctx, tbl, col);
+    if (!t) return vtab_error(&vt->base, "%s: unable to retrieve context.", fname);
+    const int dim = t->opt.v_dim, es = elem_size(t->opt.v_type);
+    const int64_t qrow = (int64_t)dim * es;
+
+    const uint8_t *queries = NULL;
+    void *owned = NULL;
+    uint8_t *qquant = NULL;
+    int64_t *ids = NULL;
+    double *dist = NULL;
+    int *counts = NULL;
+    char *err = NULL;
+    int nq = 0, rc = SQLITE_OK;
+    if (sqlite3_value_type(argv[2]) == SQLITE_TEXT) {
+        owned = batch_from_json(&vt->base, t->opt.v_type, (const char *)sqlite3_value_text(argv[2]), dim, &nq);
+        if (!owned && nq == 0 && vt->base.zErrMsg) return SQLITE_ERROR;
+        queries = (const uint8_t *)owned;
+    } else {
+        queries = (const uint8_t *)sqlite3_value_blob(argv[2]);
+        const int64_t bytes = sqlite3_value_bytes(argv[2]);
+        if (!queries || bytes == 0 || bytes % qrow != 0)
+            return vtab_error(&vt->base, "%s: the query batch has %lld bytes, expected a multiple of %lld (dimension %d).", fname, (long long)bytes, (long long)qrow, dim);
+        nq = (int)(bytes / qrow);
+    }
+    const int k = sqlite3_value_int(argv[3]);
+    if (k == 0 || nq == 0) { rc = (k == 0) ? SQLITE_DONE : SQLITE_OK; goto out; }
+    if (k < 0) { rc = vtab_error(&vt->base, "%s: k must be positive.", fname); goto out; }
+
+    vg_corpus *corpus = NULL;
+    const void *scan_queries = queries;
+    if (quantized) {
+        char name[SQL_BUF];
+        sqlite3_snprintf(sizeof(name), name, "vector0_%q_%q", tbl, col);
+        if (!exists_in_master(vt->db, "table", name)) {
+            rc = vtab_error(&vt->base, "Quantization table not found for table '%s' and column '%s'. Ensure that vector_quantize() has been called before using vector_quantize_scan().", tbl, col);
+            goto out;
+        }
+        if (!t->quant_preloaded || !t->quant) rc = stage_quant(vt->db, t, 0, &err);
+        if (rc != SQLITE_OK) { rc = vtab_error(&vt->base, "%s: %s", fname, err ? err : "staging failed"); goto out; }
+        qquant = (uint8_t *)sqlite3_malloc64((sqlite3_uint64)nq * dim);
+        if (!qquant) { rc = SQLITE_NOMEM; goto out; }
+        for (int i = 0; i < nq; ++i) {
+            if (G.quantize_query(t->opt.v_type, queries + (int64_t)i * qrow, dim, t->scale, t->offset, t->opt.q_type, qquant + (int64_t)i * dim) != VG_OK) {
+                rc = vtab_error(&vt->base, "%s: %s", fname, gpu_error());
+                goto out;
+            }
+        }
+        scan_queries = qquant;
+        corpus = t->quant;
+    } else {
+        rc = stage_full(vt->db, t, &err);
+        if (rc != SQLITE_OK) { rc = vtab_error(&vt->base, "%s: %s", fname, err ? err : "staging failed"); goto out; }
+        corpus = t->full;
+    }
+    {
+        const int64_t n = G.corpus_rows(corpus);
+        const int kk = (int)((int64_t)k < n ? (int64_t)k : (n > 0 ? n : 1));     /* never more than N rows per query */
+        ids = (int64_t *)sqlite3_malloc64((sqlite3_uint64)nq * kk * sizeof(int64_t));
+        dist = (double *)sqlite3_malloc64((sqlite3_uint64)nq * kk * sizeof(double));
+        counts = (int *)sqlite3_malloc64((sqlite3_uint64)nq * sizeof(int));
+        if (!ids || !dist || !counts) { rc = SQLITE_NOMEM; goto out; }
+        if (G.scan_topk_batch(corpus, t->opt.v_distance, scan_queries, nq, kk, ids, dist, counts) != VG_OK) {
+            rc = vtab_error(&vt->base, "%s: %s", fname, gpu_error());
+            goto out;
+        }
+        int64_t total = 0;
+        for (int i = 0; i < nq; ++i) total += counts[i];
+        sqlite3_free(c->rowids); sqlite3_free(c->distance); sqlite3_free(c->query_no);
+        c->rowids = (int64_t *)sqlite3_malloc64((sqlite3_uint64)(total ? total : 1) * sizeof(int64_t));
+        c->distance = (double *)sqlite3_malloc64((sqlite3_uint64)(total ? total : 1) * sizeof(double));
+        c->query_no = (int *)sqlite3_malloc64((sqlite3_uint64)(total ? total : 1) * sizeof(int));
+        if (!c->rowids || !c->distance || !c->query_no) { rc = SQLITE_NOMEM; goto out; }
+        int w = 0;
+        for (int i = 0; i < nq; ++i)
+            for (int j = 0; j < counts[i]; ++j, ++w) {
+                c->rowids[w] = ids[(int64_t)i * kk + j];
+                c->distance[w] = dist[(int64_t)i * kk + j];
+                c->query_no[w] = i;
+            }
+        c->row_count = w;
+    }
+out:
+    sqlite3_free(err);
+    sqlite3_free(owned);
+    sqlite3_free(qquant);
+    sqlite3_free(ids);
+    sqlite3_free(dist);
+    sqlite3_free(counts);
+    return rc;
+}
+
+static int full_batch_filter(sqlite3_vtab_cursor *c, int n, const char *s, int argc, sqlite3_value **argv) { return batch_filter_common(c, argc, argv, "vector_full_scan_batch", 0); }
+static int quant_batch_filter(sqlite3_vtab_cursor *c, int n, const char *s, int argc, sqlite3_value **argv) { return batch_filter_common(c, argc, argv, "vector_quantize_scan_batch", 1); }
+
 static int tvf_next(sqlite3_vtab_cursor *cur) {
     scan_cursor *c = (scan_cursor *)cur;
     if (c->streaming) c->stream_pos++; else c->row_index++;
@@ -1225,6 +1402,7 @@ static int tvf_column(sqlite3_vtab_cursor *cur, sqlite3_context *ctx, int col) {
     scan_cursor *c = (scan_cursor *)cur;
     if (col == COL_ID) sqlite3_result_int64(ctx, cursor_rowid(c));
     else if (col == COL_DISTANCE) sqlite3_result_double(ctx, c->streaming ? (double)c->all_dist[c->stream_pos] : c->distance[c->row_index]);
+    else if (col == COL_QUERY && c->query_no) sqlite3_result_int(ctx, c->query_no[c->row_index]);
     return SQLITE_OK;
 }
 
@@ -1241,6 +1419,10 @@ SCAN_MODULE(full_scan_module, topk_best_index, full_filter);
 SCAN_MODULE(quant_scan_module, topk_best_index, quant_filter);
 SCAN_MODULE(full_stream_module, stream_best_index, full_stream_filter);
 SCAN_MODULE(quant_stream_module, stream_best_index, quant_stream_filter);
+static sqlite3_module full_batch_module = {0, 0, batch_connect, batch_best_index, tvf_disconnect, 0, tvf_open, tvf_close, full_batch_filter,
+                                           tvf_next, tvf_eof, tvf_column, tvf_rowid, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+static sqlite3_module quant_batch_module = {0, 0, batch_connect, batch_best_index, tvf_disconnect, 0, tvf_open, tvf_close, quant_batch_filter,
+                                            tvf_next, tvf_eof, tvf_column, tvf_rowid, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 /* ------------------------------------------------------------------------------------------------ registration */
 
@@ -1290,5 +1472,8 @@ int sqlite3_vector_init(sqlite3 *db, char **pzErrMsg, const sqlite3_api_routines
     if (rc == SQLITE_OK) rc = sqlite3_create_module(db, "vector_quantize_scan", &quant_scan_module, ctx);
     if (rc == SQLITE_OK) rc = sqlite3_create_module(db, "vector_full_scan_stream", &full_stream_module, ctx);
     if (rc == SQLITE_OK) rc = sqlite3_create_module(db, "vector_quantize_scan_stream", &quant_stream_module, ctx);
+    /* additions over the reference's surface (batched queries) */
+    if (rc == SQLITE_OK) rc = sqlite3_create_module(db, "vector_full_scan_batch", &full_batch_module, ctx);
+    if (rc == SQLITE_OK) rc = sqlite3_create_module(db, "vector_quantize_scan_batch", &quant_batch_module, ctx);
     return rc;
 }

@@ -61,6 +61,7 @@ def test_surface_matches_reference(ext_path, orc):
     mods = set(r[0] for r in db.execute("SELECT name FROM pragma_module_list WHERE name LIKE 'vector_%'").fetchall())
     want_mods = {"vector_full_scan", "vector_quantize_scan", "vector_full_scan_stream", "vector_quantize_scan_stream"}
     assert want_mods <= mods
+    assert {"vector_full_scan_batch", "vector_quantize_scan_batch"} <= mods      # additions (batched queries)
     want = {("vector_version", 0), ("vector_backend", 0), ("vector_init", 3), ("vector_quantize", 2),
             ("vector_quantize", 3), ("vector_quantize_memory", 2), ("vector_quantize_preload", 2),
             ("vector_quantize_cleanup", 2)} | {("vector_as_%s" % t, n) for t in ("f32", "f16", "bf16", "i8", "u8") for n in (1, 2)}
@@ -292,3 +293,54 @@ def test_vector_quantize_on_gpu_persists_the_reference_bytes(ext_path, case):
     import __graft_entry__ as g
     assert g.load_package().device_count() > 0
     test_vector_quantize_persists_the_reference_bytes(ext_path, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric", [dg.L2, dg.DOT, dg.COSINE])
+def test_batch_tvf_equals_one_statement_per_query(ext_path, metric):
+    """vector_full_scan_batch: (query, id, distance) rows == running vector_full_scan once per query (which is the
+    reference's only way to ask several questions).  L2 takes the per-query scan kernel (identical bits); DOT / COSINE
+    take the matrix-core pass, whose f32 sums associate differently (same tolerance as the f32 kernels: 1e-5)."""
+    n, dim, k, nq = 5000, 96, 7, 9
+    rows = dg.corpus(dg.F32, n, dim, 21)
+    qs = np.stack([dg.query(dg.F32, dim, 100 + i) for i in range(nq)])
+    db = connect(ext_path)
+    load_table(db, rows, dg.F32, metric)
+    got = db.execute("SELECT query, id, distance FROM vector_full_scan_batch('t','v',?,?)", (qs.tobytes(), k)).fetchall()
+    assert len(got) == nq * k and [g[0] for g in got] == [i for i in range(nq) for _ in range(k)]
+    for i in range(nq):
+        one = db.execute("SELECT id, distance FROM vector_full_scan('t','v',?,?)", (qs[i].tobytes(), k)).fetchall()
+        mine = [(g[1], g[2]) for g in got if g[0] == i]
+        if metric == dg.L2:
+            assert mine == one
+        else:
+            assert [m[0] for m in mine] == [o[0] for o in one]
+            assert np.allclose([m[1] for m in mine], [o[1] for o in one], rtol=1e-5, atol=1e-5)
+    # JSON array of arrays == BLOB batch; the usual SQL on top works (best hit per query)
+    js = "[" + ",".join("[" + ",".join(repr(float(x)) for x in q) + "]" for q in qs[:3]) + "]"
+    gotj = db.execute("SELECT query, id, distance FROM vector_full_scan_batch('t','v',?,?)", (js, k)).fetchall()
+    assert gotj == got[: 3 * k]
+    best = db.execute("SELECT query, id, min(distance) FROM vector_full_scan_batch('t','v',?,?) GROUP BY query ORDER BY query",
+                      (qs.tobytes(), k)).fetchall()
+    assert [(b[0], b[1]) for b in best] == [(i, got[i * k][1]) for i in range(nq)]
+    # errors and edges
+    with pytest.raises(sqlite3.OperationalError, match="multiple of"):
+        db.execute("SELECT * FROM vector_full_scan_batch('t','v',?,?)", (qs.tobytes()[:-1], k)).fetchall()
+    assert db.execute("SELECT id FROM vector_full_scan_batch('t','v',?,0)", (qs.tobytes(),)).fetchall() == []
+    big = db.execute("SELECT count(*) FROM vector_full_scan_batch('t','v',?,?)", (qs[:2].tobytes(), n + 50)).fetchone()[0]
+    assert big == 2 * n
+
+
+@pytest.mark.gpu
+def test_quantized_batch_tvf_equals_one_statement_per_query(ext_path):
+    n, dim, k, nq = 3000, 64, 5, 4
+    rows = np.abs(dg.corpus(dg.F32, n, dim, 31))
+    qs = np.abs(np.stack([dg.query(dg.F32, dim, 200 + i) for i in range(nq)]))
+    db = connect(ext_path)
+    load_table(db, rows, dg.F32, dg.COSINE)
+    db.execute("SELECT vector_quantize('t','v')")
+    db.execute("SELECT vector_quantize_preload('t','v')")
+    got = db.execute("SELECT query, id, distance FROM vector_quantize_scan_batch('t','v',?,?)", (qs.tobytes(), k)).fetchall()
+    for i in range(nq):
+        one = db.execute("SELECT id, distance FROM vector_quantize_scan('t','v',?,?)", (qs[i].tobytes(), k)).fetchall()
+        assert [(g[1], g[2]) for g in got if g[0] == i] == one
