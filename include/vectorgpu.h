@@ -103,6 +103,14 @@ uint32_t vg_key_position(uint64_t key);
 int vg_merge_keys(const uint64_t *keys, int n_lists, int list_len, const int64_t *pos_offsets, int k,
                   int64_t *out_global_pos, double *out_dist);
 
+/* The host-side scan again, but returning the packed keys (positions, not rowids) - the form a multi-shard caller
+ * merges.  vg_scan_topk_keys: any k, out_keys[min(k, rows)], synchronous.  enqueue / collect: the fused path
+ * (k <= 64) split in two, so that several corpora (one per device) are all in flight before the first wait;
+ * collect fills 64 keys (VG_KEY_EMPTY padded; all empty for an empty corpus). */
+int vg_scan_topk_keys(vg_corpus *c, int metric, const void *query, int k, uint64_t *out_keys, int *out_count);
+int vg_scan_topk_enqueue(vg_corpus *c, int metric, const void *query, int k);
+int vg_scan_topk_collect(vg_corpus *c, uint64_t *out_keys64);
+
 /* All N distances in scan order (clamp applied), for the *_stream table-valued functions. */
 int vg_scan_distances(vg_corpus *c, int metric, const void *query, float *out_dist_host);
 int vg_scan_distances_device(vg_corpus *c, int metric, const void *dev_query, float *dev_out_dist, void *stream);
@@ -112,6 +120,10 @@ int64_t vg_corpus_rowid_at(const vg_corpus *c, int64_t position);
 /* nq queries at once (row-major nq x dim, host).  out_rowids / out_dist are nq x k, out_counts nq. */
 int vg_scan_topk_batch(vg_corpus *c, int metric, const void *queries, int nq, int k,
                        int64_t *out_rowids, double *out_dist, int *out_counts);
+
+/* same, as keys: out_keys nq x k (positions local to this corpus) */
+int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *queries, int nq, int k,
+                            uint64_t *out_keys, int *out_counts);
 
 /* ---- query-side quantizer (host, bit-exact with sqlite-vector.c:495-757) ---- */
 int vg_quantize_query(int src_type, const void *src, int dim, float scale, float offset, int qtype, void *dst);
@@ -123,6 +135,32 @@ int vg_quantize_query(int src_type, const void *src, int dim, float scale, float
 int vg_corpus_minmax(vg_corpus *c, float *out_min, float *out_max, int *out_any_negative);
 int vg_corpus_quantize_rows(vg_corpus *c, float scale, float offset, int qtype, int64_t row0, int64_t n_rows,
                             uint8_t *out_host);
+
+/* ---- one logical corpus over several devices of ONE process (vg_shards.hip) ----
+ * What the SQLite extension holds per (table, column): a connection lives in one process, so its multi-GPU form
+ * is S per-device corpora driven from one host thread, not S processes.  Rows are dealt out
+ * block-cyclically in scan order (block_rows rows per block, 0 = 65536); every call below is the vg_corpus_* /
+ * vg_scan_* call of the same name with results merged by (distance, GLOBAL scan position): bit-identical to a
+ * single corpus holding all rows.  devices == NULL means devices 0..n-1; the same device may be listed more than
+ * once (logical shards - how the tests exercise this on a 1-GPU box).  With n_devices == 1 every call forwards. */
+typedef struct vg_shards vg_shards;
+int     vg_shards_create(const int *devices, int n_devices, int vtype, int dim, int64_t block_rows, vg_shards **out);
+void    vg_shards_destroy(vg_shards *s);
+int     vg_shards_clear(vg_shards *s);
+int     vg_shards_count(const vg_shards *s);
+int64_t vg_shards_rows(const vg_shards *s);
+vg_corpus *vg_shards_shard(const vg_shards *s, int i);          /* borrow shard i (profiling, introspection) */
+int     vg_shards_reserve(vg_shards *s, int64_t total_rows);
+int     vg_shards_set_rowid_base(vg_shards *s, int64_t base);
+int     vg_shards_append(vg_shards *s, const void *host_rows, int64_t n_rows, int64_t row_stride_bytes, const int64_t *rowids);
+int     vg_shards_append_records(vg_shards *s, const void *host_records, int64_t n_records);
+int64_t vg_shards_rowid_at(const vg_shards *s, int64_t position);
+int     vg_shards_scan_topk(vg_shards *s, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist, int *out_count);
+int     vg_shards_scan_topk_batch(vg_shards *s, int metric, const void *queries, int nq, int k,
+                                  int64_t *out_rowids, double *out_dist, int *out_counts);
+int     vg_shards_scan_distances(vg_shards *s, int metric, const void *query, float *out_dist_host);
+int     vg_shards_minmax(vg_shards *s, float *out_min, float *out_max, int *out_any_negative);
+int     vg_shards_quantize_rows(vg_shards *s, float scale, float offset, int qtype, int64_t row0, int64_t n_rows, uint8_t *out_host);
 
 /* ---- instrumentation ---- */
 /* When enabled, every scan records HIP events around its kernels on the stream they run on (a ring of 1024

@@ -68,6 +68,26 @@ def lib():
         "vg_key_distance": (C.c_float, [C.c_uint64]),
         "vg_key_position": (C.c_uint32, [C.c_uint64]),
         "vg_merge_keys": (i32, [vp, i32, i32, vp, i32, vp, vp]),
+        "vg_scan_topk_keys": (i32, [vp, i32, vp, i32, vp, C.POINTER(i32)]),
+        "vg_scan_topk_enqueue": (i32, [vp, i32, vp, i32]),
+        "vg_scan_topk_collect": (i32, [vp, vp]),
+        "vg_scan_topk_batch_keys": (i32, [vp, i32, vp, i32, i32, vp, vp]),
+        "vg_shards_create": (i32, [vp, i32, i32, i32, i64, C.POINTER(vp)]),
+        "vg_shards_destroy": (None, [vp]),
+        "vg_shards_clear": (i32, [vp]),
+        "vg_shards_count": (i32, [vp]),
+        "vg_shards_rows": (i64, [vp]),
+        "vg_shards_shard": (vp, [vp, i32]),
+        "vg_shards_reserve": (i32, [vp, i64]),
+        "vg_shards_set_rowid_base": (i32, [vp, i64]),
+        "vg_shards_append": (i32, [vp, vp, i64, i64, vp]),
+        "vg_shards_append_records": (i32, [vp, vp, i64]),
+        "vg_shards_rowid_at": (i64, [vp, i64]),
+        "vg_shards_scan_topk": (i32, [vp, i32, vp, i32, vp, vp, C.POINTER(i32)]),
+        "vg_shards_scan_topk_batch": (i32, [vp, i32, vp, i32, i32, vp, vp, vp]),
+        "vg_shards_scan_distances": (i32, [vp, i32, vp, vp]),
+        "vg_shards_minmax": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)]),
+        "vg_shards_quantize_rows": (i32, [vp, C.c_float, C.c_float, i32, i64, i64, vp]),
         "vg_scan_distances": (i32, [vp, i32, vp, vp]),
         "vg_scan_distances_device": (i32, [vp, i32, vp, vp, vp]),
         "vg_corpus_rowid_at": (i64, [vp, i64]),
@@ -200,6 +220,82 @@ class Corpus:
 
     def kernel_name(self, metric):
         return lib().vg_scan_kernel_name(self.h, metric).decode()
+
+
+class Shards:
+    """One logical corpus dealt block-cyclically over several devices of this process (opaque vg_shards handle)."""
+
+    def __init__(self, vtype, dim, devices, block_rows=0):
+        self.h = C.c_void_p()
+        self.vtype, self.dim = vtype, dim
+        devs = (C.c_int * len(devices))(*devices)
+        _check(lib().vg_shards_create(devs, len(devices), vtype, dim, block_rows, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().vg_shards_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    @property
+    def rows(self):
+        return lib().vg_shards_rows(self.h)
+
+    def shard_rows(self):
+        return [lib().vg_corpus_rows(lib().vg_shards_shard(self.h, i)) for i in range(lib().vg_shards_count(self.h))]
+
+    def reserve(self, n):
+        _check(lib().vg_shards_reserve(self.h, n))
+
+    def clear(self):
+        _check(lib().vg_shards_clear(self.h))
+
+    def append(self, rows, rowids=None):
+        rows = np.ascontiguousarray(rows)
+        ids = None if rowids is None else np.ascontiguousarray(rowids, dtype=np.int64)
+        _check(lib().vg_shards_append(self.h, _ptr(rows), rows.shape[0], rows.strides[0], _ptr(ids)))
+
+    def append_records(self, records, n):
+        records = np.ascontiguousarray(records)
+        _check(lib().vg_shards_append_records(self.h, _ptr(records), n))
+
+    def rowid_at(self, pos):
+        return lib().vg_shards_rowid_at(self.h, pos)
+
+    def scan_topk(self, metric, query, k):
+        query = np.ascontiguousarray(query)
+        ids = np.zeros(max(k, 1), dtype=np.int64)
+        dist = np.zeros(max(k, 1), dtype=np.float64)
+        cnt = C.c_int(0)
+        _check(lib().vg_shards_scan_topk(self.h, metric, _ptr(query), k, _ptr(ids), _ptr(dist), C.byref(cnt)))
+        return ids[:cnt.value], dist[:cnt.value]
+
+    def scan_topk_batch(self, metric, queries, k):
+        queries = np.ascontiguousarray(queries)
+        nq = queries.shape[0]
+        ids = np.zeros((nq, max(k, 1)), dtype=np.int64)
+        dist = np.zeros((nq, max(k, 1)), dtype=np.float64)
+        cnt = np.zeros(nq, dtype=np.int32)
+        _check(lib().vg_shards_scan_topk_batch(self.h, metric, _ptr(queries), nq, k, _ptr(ids), _ptr(dist), _ptr(cnt)))
+        return ids, dist, cnt
+
+    def scan_distances(self, metric, query):
+        query = np.ascontiguousarray(query)
+        out = np.empty(self.rows, dtype=np.float32)
+        _check(lib().vg_shards_scan_distances(self.h, metric, _ptr(query), _ptr(out)))
+        return out
+
+    def minmax(self):
+        lo, hi, neg = C.c_float(0), C.c_float(0), C.c_int(0)
+        _check(lib().vg_shards_minmax(self.h, C.byref(lo), C.byref(hi), C.byref(neg)))
+        return lo.value, hi.value, bool(neg.value)
+
+    def quantize_rows(self, scale, offset, qtype, row0=0, n_rows=None):
+        n = self.rows - row0 if n_rows is None else n_rows
+        out = np.empty((n, self.dim), dtype=np.uint8)
+        _check(lib().vg_shards_quantize_rows(self.h, scale, offset, qtype, row0, n, _ptr(out)))
+        return out
 
 
 def quantize_query(src_type, src, scale, offset, qtype):

@@ -43,6 +43,7 @@ static int vg_fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *vg_last_error(void) { return g_err.c_str(); }
+extern "C" void vg_set_last_error_(const char *msg) { g_err = msg ? msg : ""; }     // for vg_shards.hip
 
 extern "C" int vg_device_count(void) {
     int n = 0;
@@ -114,6 +115,7 @@ struct vg_corpus {
     uint8_t *d_stage = nullptr;                // device-side landing zone for rows that need de-interleaving
     hipEvent_t append_ev = nullptr;            // recorded behind the last enqueued host append (other streams wait on it)
     bool append_pending = false;
+    bool enqueued = false;                     // a vg_scan_topk_enqueue is in flight (vg_scan_topk_collect pending)
     void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
     uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;
     size_t bq_bytes = 0, bcand_bytes = 0, bkeys_bytes = 0;
@@ -688,8 +690,7 @@ extern "C" int vg_select_temp_bytes(long long n, size_t *bytes);
 extern "C" int vg_select_sorted_keys(const float *dist, long long n, uint64_t *keys_tmp, uint64_t *keys_sorted,
                                      void *temp, size_t temp_bytes, hipStream_t stream);
 
-static int scan_topk_large_k(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids,
-                             double *out_dist, int *out_count) {
+static int scan_topk_large_k(vg_corpus *c, int metric, const void *query, int k, uint64_t *out_keys, int *out_count) {
     int rc = ensure_dist_buffer(c);
     if (rc != VG_OK) return rc;
     if (c->sel_cap < c->n_rows) {
@@ -710,30 +711,24 @@ static int scan_topk_large_k(vg_corpus *c, int metric, const void *query, int k,
     if (vg_select_sorted_keys(c->d_dist, c->n_rows, c->d_sel_keys, c->d_sel_sorted, c->d_sel_temp, c->sel_temp_bytes, c->stream) != 0)
         return vg_fail(VG_ERR_HIP, "device key sort failed: %s", hipGetErrorString(hipGetLastError()));
     const size_t take = (size_t)std::min<int64_t>((int64_t)k, c->n_rows);
-    std::vector<uint64_t> keys(take);
-    HIP_TRY(hipMemcpyAsync(keys.data(), c->d_sel_sorted, take * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_keys, c->d_sel_sorted, take * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     collect_timing(c);
     int cnt = 0;
-    for (size_t i = 0; i < take; ++i) {
-        if (keys[i] == VG_EMPTY_KEY) break;                   // NaN / +Inf rows sort last and are not results
-        out_dist[cnt] = (double)vg_key_distance(keys[i]);
-        out_rowids[cnt] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(keys[i]));
-        ++cnt;
-    }
+    while ((size_t)cnt < take && out_keys[cnt] != VG_EMPTY_KEY) ++cnt;     // NaN / +Inf rows sort last and are not results
     *out_count = cnt;
     return VG_OK;
 }
 
-extern "C" int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist,
-                            int *out_count) {
-    if (!c || !query || !out_count) return vg_fail(VG_ERR_INVALID, "vg_scan_topk: NULL argument");
-    *out_count = 0;
-    if (k <= 0 || c->n_rows == 0) return VG_OK;
-    if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk: NULL output");
+// fused path (k <= 64), split in two so that a caller can put several shards in flight before waiting for any:
+// enqueue = stage the query + launch scan and merge (+ copy the 64 keys back); collect = wait + hand out the keys
+extern "C" int vg_scan_topk_enqueue(vg_corpus *c, int metric, const void *query, int k) {
+    if (!c || !query) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_enqueue: NULL argument");
+    if (k < 1 || k > VG_MAX_FUSED_K) return vg_fail(VG_ERR_UNSUPPORTED, "vg_scan_topk_enqueue: k must be in 1..%d", VG_MAX_FUSED_K);
     if (metric_to_acc(metric) < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
+    c->enqueued = false;
+    if (c->n_rows == 0) return VG_OK;
     HIP_TRY(hipSetDevice(c->device));
-    if (k > VG_MAX_FUSED_K) return scan_topk_large_k(c, metric, query, k, out_rowids, out_dist, out_count);
     stage_query(c, query);
     int rc;
     if (host_direct(c)) {
@@ -747,15 +742,55 @@ extern "C" int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k, 
         if (rc != VG_OK) return rc;
         HIP_TRY(hipMemcpyAsync(c->h_keys, c->d_keys, VG_WAVE * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     }
+    c->enqueued = true;
+    return VG_OK;
+}
+
+extern "C" int vg_scan_topk_collect(vg_corpus *c, uint64_t *out_keys64) {
+    if (!c || !out_keys64) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_collect: NULL argument");
+    if (!c->enqueued) {                                        // empty corpus (or nothing enqueued): no candidates
+        for (int i = 0; i < VG_WAVE; ++i) out_keys64[i] = VG_EMPTY_KEY;
+        return VG_OK;
+    }
+    c->enqueued = false;
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     collect_timing(c);
+    memcpy(out_keys64, c->h_keys, VG_WAVE * sizeof(uint64_t));
+    return VG_OK;
+}
+
+extern "C" int vg_scan_topk_keys(vg_corpus *c, int metric, const void *query, int k, uint64_t *out_keys, int *out_count) {
+    if (!c || !query || !out_count) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_keys: NULL argument");
+    *out_count = 0;
+    if (k <= 0 || c->n_rows == 0) return VG_OK;
+    if (!out_keys) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_keys: NULL output");
+    if (metric_to_acc(metric) < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
+    HIP_TRY(hipSetDevice(c->device));
+    if (k > VG_MAX_FUSED_K) return scan_topk_large_k(c, metric, query, k, out_keys, out_count);
+    uint64_t keys[VG_WAVE];
+    int rc = vg_scan_topk_enqueue(c, metric, query, k);
+    if (rc == VG_OK) rc = vg_scan_topk_collect(c, keys);
+    if (rc != VG_OK) return rc;
     int cnt = 0;
-    for (int i = 0; i < k; ++i) {
-        uint64_t key = c->h_keys[i];
-        if (key == VG_EMPTY_KEY) break;
-        out_dist[cnt] = (double)vg_key_distance(key);
-        out_rowids[cnt] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(key));
-        ++cnt;
+    while (cnt < k && keys[cnt] != VG_EMPTY_KEY) { out_keys[cnt] = keys[cnt]; ++cnt; }
+    *out_count = cnt;
+    return VG_OK;
+}
+
+extern "C" int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist,
+                            int *out_count) {
+    if (!c || !query || !out_count) return vg_fail(VG_ERR_INVALID, "vg_scan_topk: NULL argument");
+    *out_count = 0;
+    if (k <= 0 || c->n_rows == 0) return VG_OK;
+    if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk: NULL output");
+    std::vector<uint64_t> keys((size_t)std::min<int64_t>((int64_t)k, c->n_rows));
+    int cnt = 0;
+    int rc = vg_scan_topk_keys(c, metric, query, (int)keys.size(), keys.data(), &cnt);
+    if (rc != VG_OK) return rc;
+    for (int i = 0; i < cnt; ++i) {
+        out_dist[i] = (double)vg_key_distance(keys[(size_t)i]);
+        out_rowids[i] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(keys[(size_t)i]));
     }
     *out_count = cnt;
     return VG_OK;
@@ -774,8 +809,8 @@ static bool batch_mfma_eligible(const vg_corpus *c, int metric, int k) {
     return vg_batch_lds_bytes(c->stride, k) != 0;
 }
 
-static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, int nq, int k, int64_t *out_rowids,
-                                double *out_dist, int *out_counts) {
+static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys,
+                                int *out_counts) {
     const int QPB = 128;
     const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
     const int G = nq_pad / QPB;
@@ -823,11 +858,33 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
         for (int j = 0; j < k; ++j) {
             uint64_t key = keys[(size_t)i * 64 + j];
             if (key == VG_EMPTY_KEY) break;
-            out_dist[(size_t)i * k + cnt] = (double)vg_key_distance(key);
-            out_rowids[(size_t)i * k + cnt] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(key));
+            out_keys[(size_t)i * k + cnt] = key;
             ++cnt;
         }
         out_counts[i] = cnt;
+    }
+    return VG_OK;
+}
+
+extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys,
+                                       int *out_counts) {
+    if (!c || !queries || !out_counts) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch_keys: NULL argument");
+    if (nq <= 0) return VG_OK;
+    if (metric_to_acc(metric) < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
+    for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+    if (k <= 0 || c->n_rows == 0) return VG_OK;
+    if (!out_keys) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch_keys: NULL output");
+    HIP_TRY(hipSetDevice(c->device));
+    if (batch_mfma_eligible(c, metric, k)) {
+        int rc = scan_topk_batch_mfma(c, metric, queries, nq, k, out_keys, out_counts);
+        if (rc != -1) return rc;
+    }
+    // shapes the matrix-core kernel does not serve (other types / metrics, k > 32, rows > 512 floats):
+    // nq passes of the single-query kernel, still entirely on the GPU
+    const uint8_t *q = (const uint8_t *)queries;
+    for (int i = 0; i < nq; ++i) {
+        int rc = vg_scan_topk_keys(c, metric, q + (size_t)i * c->dim * c->es, k, out_keys + (size_t)i * k, out_counts + i);
+        if (rc != VG_OK) return rc;
     }
     return VG_OK;
 }
@@ -836,23 +893,18 @@ extern "C" int vg_scan_topk_batch(vg_corpus *c, int metric, const void *queries,
                                   double *out_dist, int *out_counts) {
     if (!c || !queries || !out_counts) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch: NULL argument");
     if (nq <= 0) return VG_OK;
-    if (metric_to_acc(metric) < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
     for (int i = 0; i < nq; ++i) out_counts[i] = 0;
     if (k <= 0 || c->n_rows == 0) return VG_OK;
     if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch: NULL output");
-    HIP_TRY(hipSetDevice(c->device));
-    if (batch_mfma_eligible(c, metric, k)) {
-        int rc = scan_topk_batch_mfma(c, metric, queries, nq, k, out_rowids, out_dist, out_counts);
-        if (rc != -1) return rc;
-    }
-    // shapes the matrix-core kernel does not serve (other types / metrics, k > 32, rows > 512 floats):
-    // nq passes of the single-query kernel, still entirely on the GPU
-    const uint8_t *q = (const uint8_t *)queries;
-    for (int i = 0; i < nq; ++i) {
-        int rc = vg_scan_topk(c, metric, q + (size_t)i * c->dim * c->es, k, out_rowids + (size_t)i * k,
-                              out_dist + (size_t)i * k, out_counts + i);
-        if (rc != VG_OK) return rc;
-    }
+    std::vector<uint64_t> keys((size_t)nq * k);
+    int rc = vg_scan_topk_batch_keys(c, metric, queries, nq, k, keys.data(), out_counts);
+    if (rc != VG_OK) return rc;
+    for (int i = 0; i < nq; ++i)
+        for (int j = 0; j < out_counts[i]; ++j) {
+            const uint64_t key = keys[(size_t)i * k + j];
+            out_dist[(size_t)i * k + j] = (double)vg_key_distance(key);
+            out_rowids[(size_t)i * k + j] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(key));
+        }
     return VG_OK;
 }
 

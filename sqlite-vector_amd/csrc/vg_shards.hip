@@ -1,0 +1,319 @@
+// vg_shards.hip - one logical corpus spread over several devices of ONE process (the SQLite extension's case: a
+// connection lives in one process).  Host code only: every distance is computed by the per-device
+// corpora of vg_api.hip; this file distributes rows, puts all shards in flight and merges their candidate keys.
+//
+// Distribution is block-cyclic in scan order: global position g lives in block b = g / B, on shard b % S, at local
+// position (b / S) * B + g % B.  Local order is therefore monotone in global order, so each shard's own
+// (distance, local position) ranking is consistent with the global (distance, scan position) contract and the
+// merge only has to compare (distance image, global position) - the result is bit-identical to one big shard.
+// Rows can be appended as they stream out of sqlite3_step() without knowing the final count (a contiguous
+// row-range split would need it), and every device gets work as soon as B * S rows exist.
+//
+// No collective is involved: the devices never talk to each other, the host gathers S x k keys (<= 512 B per
+// shard).  The one-process-per-GPU variant of the same exchange (torch.distributed / RCCL) is shard.py.
+#include "../../include/vectorgpu.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+extern "C" void vg_set_last_error_(const char *msg);          // vg_api.hip (thread-local error slot)
+
+#define VG_WAVE_KEYS 64
+
+struct vg_shards {
+    int S = 0;
+    int64_t B = 0;
+    int vtype = 0, dim = 0, es = 0;
+    int64_t n_rows = 0;
+    int64_t rowid_base = 1;
+    std::vector<vg_corpus *> sh;
+};
+
+static int fail(int code, const char *msg) {
+    vg_set_last_error_(msg);
+    return code;
+}
+
+static inline void locate(const vg_shards *s, int64_t g, int *shard, int64_t *local) {
+    const int64_t b = g / s->B;
+    *shard = (int)(b % s->S);
+    *local = (b / s->S) * s->B + g % s->B;
+}
+
+static inline int64_t global_of(const vg_shards *s, int shard, int64_t local) {
+    return ((local / s->B) * s->S + shard) * s->B + local % s->B;
+}
+
+// run fn(shard) for every shard concurrently (one host thread each: the per-corpus calls block on their stream);
+// the first failure's code and message are re-raised on the calling thread
+template <typename F>
+static int for_each_shard(vg_shards *s, F fn) {
+    if (s->S == 1) return fn(0);
+    std::vector<int> rc((size_t)s->S, VG_OK);
+    std::vector<std::string> msg((size_t)s->S);
+    std::vector<std::thread> th;
+    for (int i = 0; i < s->S; ++i)
+        th.emplace_back([&, i] {
+            rc[(size_t)i] = fn(i);
+            if (rc[(size_t)i] != VG_OK) msg[(size_t)i] = vg_last_error();
+        });
+    for (auto &t : th) t.join();
+    for (int i = 0; i < s->S; ++i)
+        if (rc[(size_t)i] != VG_OK) return fail(rc[(size_t)i], msg[(size_t)i].c_str());
+    return VG_OK;
+}
+
+extern "C" int vg_shards_create(const int *devices, int n_devices, int vtype, int dim, int64_t block_rows, vg_shards **out) {
+    if (!out) return fail(VG_ERR_INVALID, "vg_shards_create: out is NULL");
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 64) return fail(VG_ERR_INVALID, "vg_shards_create: 1..64 shards");
+    vg_shards *s = new vg_shards();
+    s->S = n_devices;
+    s->B = block_rows > 0 ? block_rows : 65536;
+    s->vtype = vtype;
+    s->dim = dim;
+    for (int i = 0; i < n_devices; ++i) {
+        vg_corpus *c = nullptr;
+        int rc = vg_corpus_create(devices ? devices[i] : i, vtype, dim, 0, &c);
+        if (rc != VG_OK) {
+            for (auto *p : s->sh) vg_corpus_destroy(p);
+            delete s;
+            return rc;
+        }
+        s->sh.push_back(c);
+    }
+    s->es = (vtype == VG_TYPE_F32) ? 4 : (vtype == VG_TYPE_F16 || vtype == VG_TYPE_BF16) ? 2 : 1;
+    *out = s;
+    return VG_OK;
+}
+
+extern "C" void vg_shards_destroy(vg_shards *s) {
+    if (!s) return;
+    for (auto *p : s->sh) vg_corpus_destroy(p);
+    delete s;
+}
+
+extern "C" int vg_shards_clear(vg_shards *s) {
+    if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
+    for (auto *p : s->sh) {
+        int rc = vg_corpus_clear(p);
+        if (rc != VG_OK) return rc;
+    }
+    s->n_rows = 0;
+    return VG_OK;
+}
+
+extern "C" int vg_shards_count(const vg_shards *s) { return s ? s->S : 0; }
+extern "C" int64_t vg_shards_rows(const vg_shards *s) { return s ? s->n_rows : 0; }
+extern "C" vg_corpus *vg_shards_shard(const vg_shards *s, int i) { return (s && i >= 0 && i < s->S) ? s->sh[(size_t)i] : nullptr; }
+
+extern "C" int vg_shards_reserve(vg_shards *s, int64_t total_rows) {
+    if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
+    if (total_rows <= 0) return VG_OK;
+    const int64_t blocks = (total_rows + s->B - 1) / s->B;
+    for (int i = 0; i < s->S; ++i) {
+        const int64_t mine = (blocks + s->S - 1 - i) / s->S;                   // blocks i, i+S, i+2S, ...
+        if (mine <= 0) continue;
+        const int64_t rows = std::min<int64_t>(mine * s->B, total_rows);
+        int rc = vg_corpus_reserve(s->sh[(size_t)i], rows);
+        if (rc != VG_OK) return rc;
+    }
+    return VG_OK;
+}
+
+extern "C" int vg_shards_set_rowid_base(vg_shards *s, int64_t base) {
+    if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
+    s->rowid_base = base;
+    if (s->S == 1) return vg_corpus_set_rowid_base(s->sh[0], base);
+    return VG_OK;
+}
+
+// rows (or [rowid | vector] records when record_mode) are dealt out block by block
+static int append_common(vg_shards *s, const void *host, int64_t n, int64_t stride, const int64_t *rowids, bool record_mode) {
+    if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
+    if (n == 0) return VG_OK;
+    if (!host || n < 0) return fail(VG_ERR_INVALID, "vg_shards_append: bad rows pointer / count");
+    const uint8_t *p = (const uint8_t *)host;
+    std::vector<int64_t> gen;
+    int64_t done = 0;
+    while (done < n) {
+        const int64_t g = s->n_rows;
+        int shard;
+        int64_t local;
+        locate(s, g, &shard, &local);
+        const int64_t take = std::min<int64_t>(s->B - g % s->B, n - done);
+        int rc;
+        if (record_mode) {
+            rc = vg_corpus_append_records(s->sh[(size_t)shard], p + done * stride, take);
+        } else {
+            const int64_t *ids = rowids ? rowids + done : nullptr;
+            if (!ids && s->S > 1) {                    // implicit rowids follow the GLOBAL position, not the shard's
+                gen.resize((size_t)take);
+                for (int64_t i = 0; i < take; ++i) gen[(size_t)i] = s->rowid_base + g + i;
+                ids = gen.data();
+            }
+            rc = vg_corpus_append(s->sh[(size_t)shard], p + done * stride, take, stride, ids);
+        }
+        if (rc != VG_OK) return rc;
+        s->n_rows += take;
+        done += take;
+    }
+    return VG_OK;
+}
+
+extern "C" int vg_shards_append(vg_shards *s, const void *host_rows, int64_t n_rows, int64_t row_stride_bytes, const int64_t *rowids) {
+    return append_common(s, host_rows, n_rows, row_stride_bytes, rowids, false);
+}
+
+extern "C" int vg_shards_append_records(vg_shards *s, const void *host_records, int64_t n_records) {
+    if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
+    return append_common(s, host_records, n_records, 8 + (int64_t)s->dim, nullptr, true);
+}
+
+extern "C" int64_t vg_shards_rowid_at(const vg_shards *s, int64_t position) {
+    if (!s || position < 0 || position >= s->n_rows) return 0;
+    int shard;
+    int64_t local;
+    locate(s, position, &shard, &local);
+    return vg_corpus_rowid_at(s->sh[(size_t)shard], local);
+}
+
+struct Cand { uint32_t img; int64_t gpos; int shard; uint32_t local; };
+
+static inline bool cand_less(const Cand &a, const Cand &b) { return a.img != b.img ? a.img < b.img : a.gpos < b.gpos; }
+
+// merge per-shard ascending key lists (list i = shard i, `len` keys each, `counts[i]` valid) into the global top-k
+static int merge_lists(const vg_shards *s, const uint64_t *keys, int len, const int *counts, int k, int64_t *out_rowids,
+                       double *out_dist) {
+    std::vector<Cand> all;
+    for (int i = 0; i < s->S; ++i)
+        for (int j = 0; j < counts[i]; ++j) {
+            const uint64_t key = keys[(size_t)i * len + j];
+            if (key == VG_KEY_EMPTY) break;
+            const uint32_t local = vg_key_position(key);
+            all.push_back(Cand{(uint32_t)(key >> 32), global_of(s, i, (int64_t)local), i, local});
+        }
+    const size_t take = std::min<size_t>((size_t)k, all.size());
+    std::partial_sort(all.begin(), all.begin() + (long)take, all.end(), cand_less);
+    for (size_t i = 0; i < take; ++i) {
+        out_dist[i] = (double)vg_key_distance((uint64_t)all[i].img << 32);
+        out_rowids[i] = vg_corpus_rowid_at(s->sh[(size_t)all[i].shard], (int64_t)all[i].local);
+    }
+    return (int)take;
+}
+
+extern "C" int vg_shards_scan_topk(vg_shards *s, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist,
+                                   int *out_count) {
+    if (!s || !query || !out_count) return fail(VG_ERR_INVALID, "vg_shards_scan_topk: NULL argument");
+    *out_count = 0;
+    if (s->S == 1) return vg_scan_topk(s->sh[0], metric, query, k, out_rowids, out_dist, out_count);
+    if (k <= 0 || s->n_rows == 0) return VG_OK;
+    if (!out_rowids || !out_dist) return fail(VG_ERR_INVALID, "vg_shards_scan_topk: NULL output");
+    if (k <= VG_WAVE_KEYS) {
+        // every shard in flight before the first wait: S scans run concurrently, one host thread
+        std::vector<uint64_t> keys((size_t)s->S * VG_WAVE_KEYS);
+        std::vector<int> counts((size_t)s->S, VG_WAVE_KEYS);
+        int rc = VG_OK;
+        for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue(s->sh[(size_t)i], metric, query, k);
+        for (int i = 0; i < s->S; ++i) {
+            int rc2 = vg_scan_topk_collect(s->sh[(size_t)i], &keys[(size_t)i * VG_WAVE_KEYS]);
+            if (rc == VG_OK) rc = rc2;
+        }
+        if (rc != VG_OK) return rc;
+        *out_count = merge_lists(s, keys.data(), VG_WAVE_KEYS, counts.data(), k, out_rowids, out_dist);
+        return VG_OK;
+    }
+    const int kk = (int)std::min<int64_t>((int64_t)k, s->n_rows);
+    std::vector<uint64_t> keys((size_t)s->S * kk);
+    std::vector<int> counts((size_t)s->S, 0);
+    int rc = for_each_shard(s, [&](int i) {
+        return vg_scan_topk_keys(s->sh[(size_t)i], metric, query, kk, &keys[(size_t)i * kk], &counts[(size_t)i]);
+    });
+    if (rc != VG_OK) return rc;
+    *out_count = merge_lists(s, keys.data(), kk, counts.data(), kk, out_rowids, out_dist);
+    return VG_OK;
+}
+
+extern "C" int vg_shards_scan_topk_batch(vg_shards *s, int metric, const void *queries, int nq, int k, int64_t *out_rowids,
+                                         double *out_dist, int *out_counts) {
+    if (!s || !queries || !out_counts) return fail(VG_ERR_INVALID, "vg_shards_scan_topk_batch: NULL argument");
+    if (s->S == 1) return vg_scan_topk_batch(s->sh[0], metric, queries, nq, k, out_rowids, out_dist, out_counts);
+    if (nq <= 0) return VG_OK;
+    for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+    if (k <= 0 || s->n_rows == 0) return VG_OK;
+    if (!out_rowids || !out_dist) return fail(VG_ERR_INVALID, "vg_shards_scan_topk_batch: NULL output");
+    const int kk = (int)std::min<int64_t>((int64_t)k, s->n_rows);
+    std::vector<uint64_t> keys((size_t)s->S * nq * kk);
+    std::vector<int> counts((size_t)s->S * nq, 0);
+    int rc = for_each_shard(s, [&](int i) {
+        return vg_scan_topk_batch_keys(s->sh[(size_t)i], metric, queries, nq, kk, &keys[(size_t)i * nq * kk], &counts[(size_t)i * nq]);
+    });
+    if (rc != VG_OK) return rc;
+    std::vector<uint64_t> qkeys((size_t)s->S * kk);
+    std::vector<int> qcounts((size_t)s->S);
+    for (int q = 0; q < nq; ++q) {
+        for (int i = 0; i < s->S; ++i) {
+            memcpy(&qkeys[(size_t)i * kk], &keys[((size_t)i * nq + q) * kk], (size_t)kk * sizeof(uint64_t));
+            qcounts[(size_t)i] = counts[(size_t)i * nq + q];
+        }
+        out_counts[q] = merge_lists(s, qkeys.data(), kk, qcounts.data(), kk, out_rowids + (size_t)q * k, out_dist + (size_t)q * k);
+    }
+    return VG_OK;
+}
+
+extern "C" int vg_shards_scan_distances(vg_shards *s, int metric, const void *query, float *out_dist_host) {
+    if (!s || !query || !out_dist_host) return fail(VG_ERR_INVALID, "vg_shards_scan_distances: NULL argument");
+    if (s->S == 1) return vg_scan_distances(s->sh[0], metric, query, out_dist_host);
+    if (s->n_rows == 0) return VG_OK;
+    return for_each_shard(s, [&](int i) {
+        vg_corpus *c = s->sh[(size_t)i];
+        const int64_t n = vg_corpus_rows(c);
+        if (n == 0) return (int)VG_OK;
+        std::vector<float> tmp((size_t)n);
+        int rc = vg_scan_distances(c, metric, query, tmp.data());
+        if (rc != VG_OK) return rc;
+        for (int64_t l0 = 0; l0 < n; l0 += s->B) {                                   // local block -> its global place
+            const int64_t len = std::min<int64_t>(s->B, n - l0);
+            memcpy(out_dist_host + global_of(s, i, l0), &tmp[(size_t)l0], (size_t)len * sizeof(float));
+        }
+        return (int)VG_OK;
+    });
+}
+
+extern "C" int vg_shards_minmax(vg_shards *s, float *out_min, float *out_max, int *out_any_negative) {
+    if (!s || !out_min || !out_max || !out_any_negative) return fail(VG_ERR_INVALID, "vg_shards_minmax: NULL argument");
+    if (s->S == 1) return vg_corpus_minmax(s->sh[0], out_min, out_max, out_any_negative);
+    std::vector<float> lo((size_t)s->S), hi((size_t)s->S);
+    std::vector<int> neg((size_t)s->S);
+    int rc = for_each_shard(s, [&](int i) { return vg_corpus_minmax(s->sh[(size_t)i], &lo[(size_t)i], &hi[(size_t)i], &neg[(size_t)i]); });
+    if (rc != VG_OK) return rc;
+    *out_min = lo[0]; *out_max = hi[0]; *out_any_negative = neg[0];
+    for (int i = 1; i < s->S; ++i) {
+        if (lo[(size_t)i] < *out_min) *out_min = lo[(size_t)i];
+        if (hi[(size_t)i] > *out_max) *out_max = hi[(size_t)i];
+        *out_any_negative |= neg[(size_t)i];
+    }
+    return VG_OK;
+}
+
+extern "C" int vg_shards_quantize_rows(vg_shards *s, float scale, float offset, int qtype, int64_t row0, int64_t n_rows,
+                                       uint8_t *out_host) {
+    if (!s || !out_host) return fail(VG_ERR_INVALID, "vg_shards_quantize_rows: NULL argument");
+    if (s->S == 1) return vg_corpus_quantize_rows(s->sh[0], scale, offset, qtype, row0, n_rows, out_host);
+    if (row0 < 0 || n_rows < 0 || row0 + n_rows > s->n_rows) return fail(VG_ERR_INVALID, "vg_shards_quantize_rows: row range out of bounds");
+    int64_t g = row0;
+    while (g < row0 + n_rows) {
+        int shard;
+        int64_t local;
+        locate(s, g, &shard, &local);
+        const int64_t take = std::min<int64_t>(s->B - g % s->B, row0 + n_rows - g);
+        int rc = vg_corpus_quantize_rows(s->sh[(size_t)shard], scale, offset, qtype, local, take, out_host + (g - row0) * s->dim);
+        if (rc != VG_OK) return rc;
+        g += take;
+    }
+    return VG_OK;
+}

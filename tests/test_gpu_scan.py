@@ -488,3 +488,53 @@ def test_device_appends_and_cross_stream_scan(pkg, orc):
     pos = (k & np.uint64(0xFFFFFFFF)).astype(np.int64)
     assert (pos + 1).tolist() == oids.tolist()
     c.close()
+
+
+@pytest.mark.parametrize("vt,metric", [(dg.F32, dg.L2), (dg.U8, dg.COSINE), (dg.I8, dg.L1), (dg.F32, dg.DOT)])
+def test_in_process_shards_equal_a_single_corpus(pkg, orc, vt, metric):
+    """vg_shards (one logical corpus dealt block-cyclically over several devices of one process - here three logical
+    shards on device 0): every call returns bit-for-bit what one corpus holding all rows returns."""
+    dim, n, block = 72, 20_011, 1000                       # ragged last block; low-entropy rows force distance ties
+    rows = dg.corpus(vt, n, dim, 61, low_entropy=vt != dg.F32)
+    q = dg.query(vt, dim, 62, low_entropy=vt != dg.F32)
+    rowids = np.arange(n, dtype=np.int64) * 3 - 1000
+    one = pkg.Corpus(vt, dim)
+    one.append(rows, rowids)
+    sh = pkg.Shards(vt, dim, [0, 0, 0], block_rows=block)
+    sh.reserve(n)
+    for r0 in range(0, n, 3333):                            # appends that straddle block boundaries
+        sh.append(rows[r0:r0 + 3333], rowids[r0:r0 + 3333])
+    assert sh.rows == n and sum(sh.shard_rows()) == n and min(sh.shard_rows()) > 6000
+    assert [sh.rowid_at(p) for p in (0, 999, 1000, 2999, 3000, n - 1)] == [int(rowids[p]) for p in (0, 999, 1000, 2999, 3000, n - 1)]
+    for k in (1, 20, 64, 200):
+        a_ids, a_d = one.scan_topk(metric, q, k)
+        b_ids, b_d = sh.scan_topk(metric, q, k)
+        assert a_ids.tolist() == b_ids.tolist() and np.array_equal(a_d, b_d), k
+    assert dg.same_float_bits(one.scan_distances(metric, q), sh.scan_distances(metric, q))
+    qs = np.stack([dg.query(vt, dim, 70 + i, low_entropy=vt != dg.F32) for i in range(5)])
+    a = one.scan_topk_batch(metric, qs, 10)
+    b = sh.scan_topk_batch(metric, qs, 10)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    if vt == dg.F32:
+        assert one.minmax() == sh.minmax()
+        lo, hi, _ = one.minmax()
+        scale = 255.0 / (hi - lo)
+        assert np.array_equal(one.quantize_rows(scale, lo, pkg.QUANT_U8, 500, 4100), sh.quantize_rows(scale, lo, pkg.QUANT_U8, 500, 4100))
+    # implicit rowids follow the global position; clear + refill works
+    sh.clear()
+    sh.append(rows[:2500])
+    ids, _ = sh.scan_topk(metric, q, 5)
+    one2 = pkg.Corpus(vt, dim)
+    one2.append(rows[:2500])
+    assert ids.tolist() == one2.scan_topk(metric, q, 5)[0].tolist()
+    # the reference's persisted record format goes through the same dealing
+    if vt in (dg.U8, dg.I8):
+        rec = np.zeros((n, 8 + dim), dtype=np.uint8)
+        rec[:, :8] = rowids.astype("<i8").view(np.uint8).reshape(n, 8)
+        rec[:, 8:] = rows.view(np.uint8)
+        sh.clear()
+        sh.append_records(rec, n)
+        b_ids, b_d = sh.scan_topk(metric, q, 20)
+        a_ids, a_d = one.scan_topk(metric, q, 20)
+        assert a_ids.tolist() == b_ids.tolist() and np.array_equal(a_d, b_d)
+    one.close(); one2.close(); sh.close()
