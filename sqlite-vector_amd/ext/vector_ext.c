@@ -52,20 +52,20 @@ typedef struct {
     int (*device_count)(void);
     const char *(*backend_name)(void);
     const char *(*last_error)(void);
-    int (*corpus_create)(int, int, int, int64_t, vg_corpus **);
-    void (*corpus_destroy)(vg_corpus *);
-    int (*corpus_clear)(vg_corpus *);
-    int (*corpus_reserve)(vg_corpus *, int64_t);
-    int64_t (*corpus_rows)(const vg_corpus *);
-    int (*corpus_append)(vg_corpus *, const void *, int64_t, int64_t, const int64_t *);
-    int (*corpus_append_records)(vg_corpus *, const void *, int64_t);
-    int (*scan_topk)(vg_corpus *, int, const void *, int, int64_t *, double *, int *);
-    int (*scan_distances)(vg_corpus *, int, const void *, float *);
-    int (*scan_topk_batch)(vg_corpus *, int, const void *, int, int, int64_t *, double *, int *);
-    int64_t (*corpus_rowid_at)(const vg_corpus *, int64_t);
+    int (*corpus_create)(const int *, int, int, int, int64_t, vg_shards **);
+    void (*corpus_destroy)(vg_shards *);
+    int (*corpus_clear)(vg_shards *);
+    int (*corpus_reserve)(vg_shards *, int64_t);
+    int64_t (*corpus_rows)(const vg_shards *);
+    int (*corpus_append)(vg_shards *, const void *, int64_t, int64_t, const int64_t *);
+    int (*corpus_append_records)(vg_shards *, const void *, int64_t);
+    int (*scan_topk)(vg_shards *, int, const void *, int, int64_t *, double *, int *);
+    int (*scan_distances)(vg_shards *, int, const void *, float *);
+    int (*scan_topk_batch)(vg_shards *, int, const void *, int, int, int64_t *, double *, int *);
+    int64_t (*corpus_rowid_at)(const vg_shards *, int64_t);
     int (*quantize_query)(int, const void *, int, float, float, int, void *);
-    int (*corpus_minmax)(vg_corpus *, float *, float *, int *);
-    int (*corpus_quantize_rows)(vg_corpus *, float, float, int, int64_t, int64_t, uint8_t *);
+    int (*corpus_minmax)(vg_shards *, float *, float *, int *);
+    int (*corpus_quantize_rows)(vg_shards *, float, float, int, int64_t, int64_t, uint8_t *);
     char load_error[512];
 } gpu_api;
 
@@ -101,20 +101,20 @@ static int gpu_load(void) {
     G.device_count = (int (*)(void))gpu_sym("vg_device_count");
     G.backend_name = (const char *(*)(void))gpu_sym("vg_backend_name");
     G.last_error = (const char *(*)(void))gpu_sym("vg_last_error");
-    G.corpus_create = (int (*)(int, int, int, int64_t, vg_corpus **))gpu_sym("vg_corpus_create");
-    G.corpus_destroy = (void (*)(vg_corpus *))gpu_sym("vg_corpus_destroy");
-    G.corpus_clear = (int (*)(vg_corpus *))gpu_sym("vg_corpus_clear");
-    G.corpus_reserve = (int (*)(vg_corpus *, int64_t))gpu_sym("vg_corpus_reserve");
-    G.corpus_rows = (int64_t (*)(const vg_corpus *))gpu_sym("vg_corpus_rows");
-    G.corpus_append = (int (*)(vg_corpus *, const void *, int64_t, int64_t, const int64_t *))gpu_sym("vg_corpus_append");
-    G.corpus_append_records = (int (*)(vg_corpus *, const void *, int64_t))gpu_sym("vg_corpus_append_records");
-    G.scan_topk = (int (*)(vg_corpus *, int, const void *, int, int64_t *, double *, int *))gpu_sym("vg_scan_topk");
-    G.scan_distances = (int (*)(vg_corpus *, int, const void *, float *))gpu_sym("vg_scan_distances");
-    G.scan_topk_batch = (int (*)(vg_corpus *, int, const void *, int, int, int64_t *, double *, int *))gpu_sym("vg_scan_topk_batch");
-    G.corpus_rowid_at = (int64_t (*)(const vg_corpus *, int64_t))gpu_sym("vg_corpus_rowid_at");
+    G.corpus_create = (int (*)(const int *, int, int, int, int64_t, vg_shards **))gpu_sym("vg_shards_create");
+    G.corpus_destroy = (void (*)(vg_shards *))gpu_sym("vg_shards_destroy");
+    G.corpus_clear = (int (*)(vg_shards *))gpu_sym("vg_shards_clear");
+    G.corpus_reserve = (int (*)(vg_shards *, int64_t))gpu_sym("vg_shards_reserve");
+    G.corpus_rows = (int64_t (*)(const vg_shards *))gpu_sym("vg_shards_rows");
+    G.corpus_append = (int (*)(vg_shards *, const void *, int64_t, int64_t, const int64_t *))gpu_sym("vg_shards_append");
+    G.corpus_append_records = (int (*)(vg_shards *, const void *, int64_t))gpu_sym("vg_shards_append_records");
+    G.scan_topk = (int (*)(vg_shards *, int, const void *, int, int64_t *, double *, int *))gpu_sym("vg_shards_scan_topk");
+    G.scan_distances = (int (*)(vg_shards *, int, const void *, float *))gpu_sym("vg_shards_scan_distances");
+    G.scan_topk_batch = (int (*)(vg_shards *, int, const void *, int, int, int64_t *, double *, int *))gpu_sym("vg_shards_scan_topk_batch");
+    G.corpus_rowid_at = (int64_t (*)(const vg_shards *, int64_t))gpu_sym("vg_shards_rowid_at");
     G.quantize_query = (int (*)(int, const void *, int, float, float, int, void *))gpu_sym("vg_quantize_query");
-    G.corpus_minmax = (int (*)(vg_corpus *, float *, float *, int *))gpu_sym("vg_corpus_minmax");
-    G.corpus_quantize_rows = (int (*)(vg_corpus *, float, float, int, int64_t, int64_t, uint8_t *))gpu_sym("vg_corpus_quantize_rows");
+    G.corpus_minmax = (int (*)(vg_shards *, float *, float *, int *))gpu_sym("vg_shards_minmax");
+    G.corpus_quantize_rows = (int (*)(vg_shards *, float, float, int, int64_t, int64_t, uint8_t *))gpu_sym("vg_shards_quantize_rows");
     if (G.load_error[0]) { dlclose(G.handle); G.handle = NULL; return 0; }
     return 1;
 }
@@ -122,6 +122,37 @@ static int gpu_load(void) {
 static const char *gpu_error(void) {
     if (!G.handle) return G.load_error[0] ? G.load_error : "GPU engine not loaded";
     return G.last_error();
+}
+
+/* Which devices hold a corpus.  VECTORGPU_DEVICES = "all" | a count ("4" = devices 0..3) | a list ("0,2,5"; a device
+ * may repeat).  Default: device 0.  More than one entry deals the rows block-cyclically over the devices
+ * (VECTORGPU_SHARD_ROWS rows per block, default 65536) and every scan runs on all of them at once (vg_shards). */
+static int corpus_open(int vtype, int dim, vg_shards **out) {
+    int devs[64], n = 0;
+    const char *e = getenv("VECTORGPU_DEVICES");
+    if (e && *e) {
+        if (!strcasecmp(e, "all")) {
+            n = G.device_count();
+            if (n > 64) n = 64;
+            for (int i = 0; i < n; ++i) devs[i] = i;
+        } else if (strchr(e, ',')) {
+            const char *p = e;
+            while (*p && n < 64) {
+                char *end;
+                long v = strtol(p, &end, 10);
+                if (end == p) break;
+                devs[n++] = (int)v;
+                p = (*end == ',') ? end + 1 : end;
+            }
+        } else {
+            n = atoi(e);
+            if (n > 64) n = 64;
+            for (int i = 0; i < n; ++i) devs[i] = i;
+        }
+    }
+    if (n <= 0) { devs[0] = 0; n = 1; }
+    const char *b = getenv("VECTORGPU_SHARD_ROWS");
+    return G.corpus_create(devs, n, vtype, dim, (b && *b) ? (int64_t)atoll(b) : 0, out);
 }
 
 /* ------------------------------------------------------------------------------------------------ context */
@@ -141,11 +172,11 @@ typedef struct {
     float scale, offset;        /* quantization parameters (persisted as qscale / qoffset) */
 
     /* HBM-resident state owned by this (table, column) */
-    vg_corpus *full;            /* raw vectors for vector_full_scan[_stream] */
+    vg_shards *full;            /* raw vectors for vector_full_scan[_stream] */
     int64_t full_data_version;  /* staleness stamps: PRAGMA data_version + sqlite3_total_changes() */
     int64_t full_changes;
     int full_validated;         /* set when stage_full() (re)validated `full` during the current vector_quantize call */
-    vg_corpus *quant;           /* quantized vectors for vector_quantize_scan[_stream] */
+    vg_shards *quant;           /* quantized vectors for vector_quantize_scan[_stream] */
     int quant_preloaded;        /* explicit vector_quantize_preload() (kept until cleanup / re-quantize) */
     int64_t quant_data_version;
     int64_t quant_changes;
@@ -606,7 +637,7 @@ static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
     const int es = elem_size(t->opt.v_type), dim = t->opt.v_dim;
     const int64_t row_bytes = (int64_t)es * dim;
     if (t->full) G.corpus_clear(t->full);
-    else if (G.corpus_create(0, t->opt.v_type, dim, 0, &t->full) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
+    else if (corpus_open(t->opt.v_type, dim, &t->full) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
 
     {   /* one HBM allocation of the right size instead of geometric regrowth (COUNT(*) is an upper bound: NULLs) */
         char *cnt = sqlite3_mprintf("SELECT COUNT(*) FROM %q;", t->t_name);
@@ -663,7 +694,7 @@ static int stage_quant(sqlite3 *db, table_ctx *t, int force, char **err) {
     if (!gpu_load()) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
     const int vt = (t->opt.q_type == VG_QUANT_U8) ? VG_TYPE_U8 : VG_TYPE_I8;
     if (t->quant) { G.corpus_destroy(t->quant); t->quant = NULL; }
-    if (G.corpus_create(0, vt, t->opt.v_dim, 0, &t->quant) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
+    if (corpus_open(vt, t->opt.v_dim, &t->quant) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
     char sql[SQL_BUF];
     sqlite3_snprintf(sizeof(sql), sql, "SELECT counter, data FROM vector0_%q_%q;", t->t_name, t->c_name);
     sqlite3_stmt *st = NULL;
@@ -754,8 +785,8 @@ static int flush_chunk(sqlite3 *db, table_ctx *t, uint32_t n, const uint8_t *dat
 }
 
 /* vector_quantize with a GPU present: the raw vectors are staged into HBM once (the same corpus later serves
- * vector_full_scan), min/max and the quantization run as kernels over it (vg_corpus_minmax /
- * vg_corpus_quantize_rows, bit-exact with the host arithmetic below), and only the persisted records are assembled
+ * vector_full_scan), min/max and the quantization run as kernels over it (vg_shards_minmax /
+ * vg_shards_quantize_rows, bit-exact with the host arithmetic below), and only the persisted records are assembled
  * here: [int64 LE rowid | dim bytes] per row, flushed in max_memory-sized chunks exactly like the reference
  * (sqlite-vector.c:1282-1327).  Returns -1 when the GPU path cannot be used (caller runs the host passes). */
 static int rebuild_quantization_gpu(sqlite3_context *ctx, table_ctx *t, int qtype, uint64_t max_memory, uint32_t *count) {
@@ -1035,7 +1066,7 @@ typedef struct {
     int *query_no;                     /* batch TVFs: which query of the batch each output row answers */
     /* streaming: all N distances computed by ONE kernel launch, paged out row by row */
     float *all_dist;
-    vg_corpus *stream_corpus;
+    vg_shards *stream_corpus;
     int64_t stream_pos, stream_n;
 } scan_cursor;
 
@@ -1153,7 +1184,7 @@ static int filter_common(sqlite3_vtab_cursor *cur, int argc, sqlite3_value **arg
     if (!streaming && k < 0) { rc = vtab_error(&vt->base, "%s: k must be positive.", fname); goto out; }
 
     /* the corpus to scan + the query in its element type */
-    vg_corpus *corpus = NULL;
+    vg_shards *corpus = NULL;
     const void *scan_query = query;
     if (quantized) {
         if (!t->quant_preloaded || !t->quant) rc = stage_quant(vt->db, t, 0, &err);   /* not preloaded: stage on first use */
@@ -1317,7 +1348,7 @@ static int batch_filter_common(sqlite3_vtab_cursor *cur, int argc, sqlite3_value
     if (k == 0 || nq == 0) { rc = (k == 0) ? SQLITE_DONE : SQLITE_OK; goto out; }
     if (k < 0) { rc = vtab_error(&vt->base, "%s: k must be positive.", fname); goto out; }
 
-    vg_corpus *corpus = NULL;
+    vg_shards *corpus = NULL;
     const void *scan_queries = queries;
     if (quantized) {
         char name[SQL_BUF];

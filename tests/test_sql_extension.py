@@ -344,3 +344,35 @@ def test_quantized_batch_tvf_equals_one_statement_per_query(ext_path):
     for i in range(nq):
         one = db.execute("SELECT id, distance FROM vector_quantize_scan('t','v',?,?)", (qs[i].tobytes(), k)).fetchall()
         assert [(g[1], g[2]) for g in got if g[0] == i] == one
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", mg.SQL_SCAN_CASES[:4], ids=[c[0] for c in mg.SQL_SCAN_CASES[:4]])
+def test_extension_over_several_shards_matches_golden(ext_path, case, monkeypatch):
+    """VECTORGPU_DEVICES with more than one entry (here three logical shards on device 0): same golden results,
+    same stream output, same quantize bytes as the single-device run."""
+    monkeypatch.setenv("VECTORGPU_DEVICES", "0,0,0")
+    monkeypatch.setenv("VECTORGPU_SHARD_ROWS", "64")
+    name, vt, metric, n, dim, k, seed, low = case
+    sql = np.load(os.path.join(HERE, "golden", "sql.npz"))
+    rows = dg.corpus(vt, n, dim, seed, low_entropy=low)
+    q = dg.query(vt, dim, seed + 1, low_entropy=low)
+    db = connect(ext_path)
+    load_table(db, rows, vt, metric)
+    got = db.execute("SELECT rowid, distance FROM vector_full_scan('t','v',?,?)", (q.tobytes(), k)).fetchall()
+    _check_vs_golden(got, sql["avx2/%s/rowids" % name], sql["avx2/%s/dist" % name], exact=vt in (dg.U8, dg.I8))
+    stream = db.execute("SELECT rowid, distance FROM vector_full_scan_stream('t','v',?)", (q.tobytes(),)).fetchall()
+    assert [s[0] for s in stream] == list(range(1, n + 1))
+    top = sorted(stream, key=lambda r: (r[1], r[0]))[:k]
+    assert [t[0] for t in top] == [g[0] for g in got]
+    monkeypatch.delenv("VECTORGPU_DEVICES")
+    db1 = connect(ext_path)
+    load_table(db1, rows, vt, metric)
+    for d in (db, db1):
+        d.execute("SELECT vector_quantize('t','v')")
+    a = db.execute("SELECT rowid1, rowid2, counter, data FROM vector0_t_v ORDER BY rowid1").fetchall()
+    b = db1.execute("SELECT rowid1, rowid2, counter, data FROM vector0_t_v ORDER BY rowid1").fetchall()
+    assert a == b
+    ga = db.execute("SELECT rowid, distance FROM vector_quantize_scan('t','v',?,?)", (q.tobytes(), k)).fetchall()
+    gb = db1.execute("SELECT rowid, distance FROM vector_quantize_scan('t','v',?,?)", (q.tobytes(), k)).fetchall()
+    assert ga == gb
