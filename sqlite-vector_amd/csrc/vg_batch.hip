@@ -41,6 +41,9 @@ typedef float vgb_f32x16 __attribute__((ext_vector_type(16)));
 #define VGB_QPB (VGB_WAVES * VGB_QPW)   // queries per workgroup
 #define VGB_TILE 32                     // corpus rows per tile
 #define VGB_MAX_K 32
+#ifndef VGB_DUAL_ACC
+#define VGB_DUAL_ACC 0                  // experiment: two independent accumulator chains per tile
+#endif
 #ifndef VGB_ABLATE
 #define VGB_ABLATE 0                    // probe builds only: 1 = no threshold tests, 2 = no DMA after tile 0, 4 = no barrier
 #endif
@@ -57,6 +60,21 @@ struct BatchArgs {
     int cosine;               // 0: dot, 1: cosine
     int tiles_per_part;
 };
+
+typedef float vgb_f32x4 __attribute__((ext_vector_type(4)));
+#ifndef VGB_BPIPE
+#define VGB_BPIPE 4                      // B-operand ring depth, in k-steps of 4 MFMAs
+#endif
+
+// (free functions: clang rejects asm operands that name captured variables inside a generic lambda)
+template <int OFF>
+__device__ __forceinline__ void vgb_lds_read128(vgb_f32x4 &dst, uint32_t lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vgb_wait_lds(vgb_f32x4 &v) {        // v is usable once at most N later LDS reads are in flight
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void vgb_static_for(F &&f) {
@@ -134,6 +152,9 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     uint32_t lane_off[PIECES];
 #pragma unroll
     for (int p = 0; p < PIECES; ++p) lane_off[p] = (uint32_t)(p * 64 + lane) * 16u;
+    uint64_t piece_mask[PIECES];
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) piece_mask[p] = __ballot(p * 64 + lane < chunks_per_row);
     const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)tile0;
     auto dma_piece = [&](uint32_t tile32, int buf, int pc) {
         const int i = pc / PIECES, p = pc - i * PIECES;
@@ -142,11 +163,13 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         grow = grow < n_rows32 ? grow : n_rows32 - 1u;
         const uint8_t *sbase = reinterpret_cast<const uint8_t *>(a.rows) + (unsigned long long)grow * stride_b;
         const uint32_t lds_dst = lds_tile0 + (uint32_t)((buf * TILE_FLOATS + rr * PITCH + p * 256) * 4);
-        if (p * 64 + lane < chunks_per_row) {
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(lane_off[p]), "s"(sbase), "s"(lds_dst) : "memory");
-        }
+        // lanes past the end of the row are switched off by EXEC inside the asm (no branch: the k loop stays ONE
+        // basic block, so the scheduler can keep the B-operand ds_reads several MFMAs ahead of their use)
+        uint32_t keep;
+        uint64_t keep_exec;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_and_b64 exec, exec, %5\n\t"
+                     "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(keep_exec) : "v"(lane_off[p]), "s"(sbase), "s"(lds_dst), "s"(piece_mask[p]) : "memory", "scc");
     };
     constexpr int NPIECE = (VGB_TILE / VGB_WAVES) * PIECES;
 
@@ -207,6 +230,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     // Software pipeline: while tile t runs on the matrix core, the wavefront (a) issues the DMA pieces of tile t+1
     // and (b) gates tile t-1's 16 accumulator registers, one compare every few MFMAs - both in the shadow of the
     // 64-cycle MFMAs.  The loop body stays branch free; registers that pass the gate are handled after it.
+    unsigned dbg_tiles = 0, dbg_pend = 0, dbg_regs = 0;        // probe builds (VGB_ABLATE & 32) only
     vgb_f32x16 acc_prev;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_prev[r] = -INFINITY;     // "no previous tile": nothing passes a gate
@@ -220,19 +244,43 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         vgb_f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#if VGB_DUAL_ACC
+        vgb_f32x16 acc2 = acc;
+#endif
         float xx_part = 0.0f;
         unsigned pend = 0;
         const float cos_slack = COS ? xnorm_prev : 0.0f;
         const float *brow = cur + x * PITCH + 4 * h;
+        // B operand pipeline: ds_read_b128 issued from inline asm BP steps (= 4*BP MFMAs) ahead of its use into a ring
+        // of BP register quads, with an exact "s_waitcnt lgkmcnt(n)" in front of the consumer.  Left to the compiler
+        // the dot variant re-used ONE register quad: read, lgkmcnt(0), 4 MFMAs, read ... - an exposed LDS round trip
+        // every 4-8 MFMAs with a single wavefront per SIMD and nothing else to issue (22% of the matrix pipe idle).
+        constexpr int BP = VGB_BPIPE < NT ? VGB_BPIPE : NT;
+        const uint32_t baddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)brow;
+        vgb_f32x4 bq[BP];
+        vgb_static_for<0, BP>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            vgb_lds_read128<32 * t>(bq[t], baddr);
+        });
         // compile-time unrolled k loop (a template recursion: the plain "#pragma unroll" gave up on a body this large
         // and put areg[] in scratch memory)
         vgb_static_for<0, NT>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            const float4 b = *reinterpret_cast<const float4 *>(brow + 8 * t);
+            constexpr int in_flight_after = (NT - 1 - t) < (BP - 1) ? (NT - 1 - t) : (BP - 1);
+            vgb_wait_lds<in_flight_after>(bq[t % BP]);
+            const vgb_f32x4 b = bq[t % BP];
+#if VGB_DUAL_ACC
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 0], b.x, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 1], b.y, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 2], b.z, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 3], b.w, acc2, 0, 0, 0);
+#else
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 0], b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 1], b.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 2], b.z, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 3], b.w, acc, 0, 0, 0);
+#endif
+            if constexpr (t + BP < NT) vgb_lds_read128<32 * (t + BP)>(bq[t % BP], baddr);
             if (COS) {
                 xx_part = fmaf(b.x, b.x, xx_part); xx_part = fmaf(b.y, b.y, xx_part);
                 xx_part = fmaf(b.z, b.z, xx_part); xx_part = fmaf(b.w, b.w, xx_part);
@@ -256,13 +304,30 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
                 }
             });
         });
+        if (VGB_ABLATE & 8) { asm volatile("" ::"s"(pend)); pend = 0; }          // probe: gates computed, never acted on
+        if (VGB_ABLATE & 16) {                                                     // probe: accumulators copied out, unused
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc_prev[r]));
+        }
+        if (VGB_ABLATE & 32) {
+            dbg_tiles++; dbg_pend += pend ? 1 : 0; dbg_regs += __builtin_popcount(pend);
+            if (blockIdx.x == 0 && wave == 0 && tile == tile_first + 5000) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!(acc_prev[r] < gate[r])) printf("tile+5000 lane %d r %d acc %.9g gate %.9g thr %.9g\n", lane, r, acc_prev[r], gate[r], thr_w[(r & 3) + 8 * (r >> 2) + 4 * h]);
+            }
+        }
         if (pend) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (pend & (1u << r)) reg_insert(r, acc_prev[r], row_prev, xnorm_prev);
             reload_gates();
         }
+#if VGB_DUAL_ACC
+        acc_prev = acc + acc2;
+#else
         acc_prev = acc;
+#endif
         row_prev = tile * VGB_TILE + x;
         if (COS) xnorm_prev = sqrtf(xx_part + __shfl_xor(xx_part, 32));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of tile t+1 have landed
@@ -271,6 +336,8 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     // drain: the last tile's registers
 #pragma unroll
     for (int r = 0; r < 16; ++r) reg_insert(r, acc_prev[r], row_prev, xnorm_prev);
+    if ((VGB_ABLATE & 32) && lane == 0 && blockIdx.x < 2)
+        printf("block %d wave %d: tiles %u with-pend %u flagged-regs %u\n", blockIdx.x, wave, dbg_tiles, dbg_pend, dbg_regs);
 
     // ---- publish: [query][part][64] (a query's npart lists are contiguous for the merge)
     for (int s = lane; s < VGB_QPW * 64; s += 64) {
