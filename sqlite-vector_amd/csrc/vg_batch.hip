@@ -187,35 +187,48 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     // distance, clamp, row bound and key comparison happen in reg_insert (rare).  The full test with its LDS read
     // and clamp cost 30% of the kernel when it ran 16 times per tile.
     float gate[16];
+    float thr_reg[16];                    // dot variant only: the k-th best distance itself (the slow path never reads LDS for it)
     auto reload_gates = [&]() {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
             const float t = thr_w[qi];
             gate[r] = COS ? (1.0f - t) * qn_w[qi] : (-t - 1e-6f);
+            thr_reg[r] = t;
         }
     };
     reload_gates();
+    // a list that is not full yet (fewer than k finite distances so far) accepts everything
+    auto kth_distance = [](uint64_t kth) -> float {
+        return (kth == VG_EMPTY_KEY) ? INFINITY : vg_sortable_f32((uint32_t)(kth >> 32));
+    };
     // slow path (outside the MFMA loop, rare once the lists have warmed up): insert this register's survivors
-    auto reg_insert = [&](int r, float acc_r, long long row, float xnorm) {
+    auto reg_insert = [&](auto rc, float acc_r, long long row, float xnorm) {
+        constexpr int r = decltype(rc)::value;
         const int q_lo = (r & 3) + 8 * (r >> 2);
         const float d = reg_distance(r, acc_r, xnorm);
-        const bool pass = (row < a.n_rows) && (d <= thr_w[q_lo + 4 * h]) && (d < INFINITY);
+        const float thr_now = COS ? thr_w[q_lo + 4 * h] : thr_reg[r];
+        const bool pass = (row < a.n_rows) && (d <= thr_now) && (d < INFINITY);
         unsigned long long m = __ballot(pass);
         const uint64_t key = vg_make_key(d, (uint32_t)row);
         while (m) {
             const int src = __ffsll((long long)m) - 1;
             m &= m - 1;
-            const int q = q_lo + 4 * (src >> 5);
+            const int hh = src >> 5;
+            const int q = q_lo + 4 * hh;
             uint64_t *list = wave_lists + q * k;
             const uint64_t c = vg_readlane64(key, src);
-            if (c < list[k - 1]) {
-                uint64_t mine = (lane < k) ? list[lane] : 0ull;
-                const uint64_t prev = vg_wave_shr1(mine);
-                mine = (mine > c) ? ((prev > c) ? prev : c) : mine;
-                if (lane < k) list[lane] = mine;
-                const uint64_t kth = vg_readlane64(mine, k - 1);
-                if (lane == 0) thr_w[q] = vg_sortable_f32((uint32_t)(kth >> 32));
+            // one LDS round trip per candidate: a key that no longer beats the tail simply changes nothing below
+            uint64_t mine = (lane < k) ? list[lane] : 0ull;
+            const uint64_t prev = vg_wave_shr1(mine);
+            mine = (mine > c) ? ((prev > c) ? prev : c) : mine;
+            if (lane < k) list[lane] = mine;
+            const float nt = kth_distance(vg_readlane64(mine, k - 1));
+            if (COS) {
+                if (lane == 0) thr_w[q] = nt;
+            } else if (h == hh) {
+                thr_reg[r] = nt;
+                gate[r] = -nt - 1e-6f;
             }
         }
     };
@@ -318,10 +331,11 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
             }
         }
         if (pend) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (pend & (1u << r)) reg_insert(r, acc_prev[r], row_prev, xnorm_prev);
-            reload_gates();
+            vgb_static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if (pend & (1u << r)) reg_insert(rc, acc_prev[r], row_prev, xnorm_prev);
+            });
+            if (COS) reload_gates();          // dot: reg_insert already updated the registers it changed
         }
 #if VGB_DUAL_ACC
         acc_prev = acc + acc2;
@@ -334,8 +348,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         if (!(VGB_ABLATE & 4)) __syncthreads();               // tile t consumed by all, tile t+1 landed for all
     }
     // drain: the last tile's registers
-#pragma unroll
-    for (int r = 0; r < 16; ++r) reg_insert(r, acc_prev[r], row_prev, xnorm_prev);
+    vgb_static_for<0, 16>([&](auto rc) { reg_insert(rc, acc_prev[decltype(rc)::value], row_prev, xnorm_prev); });
     if ((VGB_ABLATE & 32) && lane == 0 && blockIdx.x < 2)
         printf("block %d wave %d: tiles %u with-pend %u flagged-regs %u\n", blockIdx.x, wave, dbg_tiles, dbg_pend, dbg_regs);
 

@@ -538,3 +538,23 @@ def test_in_process_shards_equal_a_single_corpus(pkg, orc, vt, metric):
         a_ids, a_d = one.scan_topk(metric, q, 20)
         assert a_ids.tolist() == b_ids.tolist() and np.array_equal(a_d, b_d)
     one.close(); one2.close(); sh.close()
+
+
+@pytest.mark.parametrize("metric", (dg.DOT, dg.COSINE))
+def test_batch_mfma_rows_with_nan_inf_at_the_start_of_a_partition(pkg, orc, metric):
+    """rows whose score is NaN / +Inf never enter a list; when they sit in the first tile of a partition the list is
+    not full after that tile and must keep accepting every finite row (threshold stays +Inf, not NaN)."""
+    dim, n = 64, 40_000
+    rows = dg.corpus(dg.F32, n, dim, 91)
+    rows[0:30, 3] = np.nan                      # first tile of the first partition: only 2 finite rows
+    rows[64:90, 5] = np.inf
+    rows[5000:5031, 7] = np.nan
+    qs = dg.corpus(dg.F32, 6, dim, 92)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    ids, dist, cnt = c.scan_topk_batch(metric, qs, 20)
+    for i in range(6):
+        one_ids, one_dist = c.scan_topk(metric, qs[i], 20)        # per-query kernel (oracle-checked elsewhere)
+        assert cnt[i] == 20 and ids[i].tolist() == one_ids.tolist()
+        assert np.allclose(dist[i], one_dist, rtol=1e-5, atol=1e-5)
+    c.close()
