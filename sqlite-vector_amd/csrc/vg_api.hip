@@ -116,6 +116,8 @@ struct vg_corpus {
     hipEvent_t append_ev = nullptr;            // recorded behind the last enqueued host append (other streams wait on it)
     bool append_pending = false;
     bool enqueued = false;                     // a vg_scan_topk_enqueue is in flight (vg_scan_topk_collect pending)
+    float *d_xnorm = nullptr;                  // f32 corpora, lazily: ||row|| for rows [0, xnorm_rows) (batched cosine)
+    int64_t xnorm_rows = 0, xnorm_cap = 0;
     void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
     uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;
     size_t bq_bytes = 0, bcand_bytes = 0, bkeys_bytes = 0;
@@ -202,6 +204,7 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->append_ev) hipEventDestroy(c->append_ev);
     if (c->d_stage) hipFree(c->d_stage);
     if (c->d_bq) hipFree(c->d_bq);
+    if (c->d_xnorm) hipFree(c->d_xnorm);
     if (c->d_bcand) hipFree(c->d_bcand);
     if (c->d_bkeys) hipFree(c->d_bkeys);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
@@ -212,6 +215,7 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
 extern "C" int vg_corpus_clear(vg_corpus *c) {
     if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
     c->n_rows = 0;
+    c->xnorm_rows = 0;
     c->rowids.clear();
     return VG_OK;
 }
@@ -799,8 +803,31 @@ extern "C" int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k, 
 // ---- batched queries: the MFMA path (vg_batch.hip) when the shape allows it, otherwise nq single-query scans
 extern "C" size_t vg_batch_lds_bytes(long long stride_bytes, int k);
 extern "C" int vg_batch_launch(const float *dev_rows, long long n_rows, long long stride_bytes,
-                               const float *dev_queries, int nq_pad, int k, int cosine, uint64_t *dev_cand,
-                               int npart, int tiles_per_part, uint64_t *dev_out_keys, hipStream_t stream);
+                               const float *dev_queries, int nq_pad, int k, int cosine, const float *dev_xnorm,
+                               uint64_t *dev_cand, int npart, int tiles_per_part, uint64_t *dev_out_keys,
+                               hipStream_t stream);
+extern "C" int vg_rownorm_launch(const float *dev_rows, long long row0, long long n, long long stride_bytes, float *dev_out,
+                                 hipStream_t stream);
+
+// cosine batches need ||row|| for every row: computed once per appended row and kept next to the corpus
+static int ensure_row_norms(vg_corpus *c) {
+    if (c->xnorm_cap < c->n_rows) {
+        float *nb = nullptr;
+        const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
+        HIP_TRY(hipMalloc(&nb, (size_t)cap * sizeof(float)));
+        if (c->d_xnorm && c->xnorm_rows > 0)
+            HIP_TRY(hipMemcpyAsync(nb, c->d_xnorm, (size_t)c->xnorm_rows * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        if (c->d_xnorm) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->d_xnorm); }
+        c->d_xnorm = nb;
+        c->xnorm_cap = cap;
+    }
+    if (c->xnorm_rows < c->n_rows) {
+        int rc = vg_rownorm_launch((const float *)c->d_rows, c->xnorm_rows, c->n_rows - c->xnorm_rows, c->stride, c->d_xnorm, c->stream);
+        if (rc != 0) return vg_fail(VG_ERR_HIP, "row-norm pass failed: %s", hipGetErrorString((hipError_t)rc));
+        c->xnorm_rows = c->n_rows;
+    }
+    return VG_OK;
+}
 
 static bool batch_mfma_eligible(const vg_corpus *c, int metric, int k) {
     if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
@@ -835,6 +862,10 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     const size_t row_bytes = (size_t)c->dim * c->es;
     for (int i = 0; i < nq; ++i) memcpy(hq.data() + (size_t)i * c->stride, (const uint8_t *)queries + (size_t)i * row_bytes, row_bytes);
     HIP_TRY(hipMemcpyAsync(c->d_bq, hq.data(), qbytes, hipMemcpyHostToDevice, c->stream));
+    if (metric == VG_DIST_COSINE) {
+        int rcn = ensure_row_norms(c);
+        if (rcn != VG_OK) return rcn;
+    }
 
     hipEvent_t *evs = nullptr;
     if (c->profiling) {
@@ -845,7 +876,8 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
         hipEventRecord(evs[0], c->stream);
     }
     int rc = vg_batch_launch((const float *)c->d_rows, c->n_rows, c->stride, (const float *)c->d_bq, nq_pad, k,
-                             metric == VG_DIST_COSINE ? 1 : 0, c->d_bcand, npart, tiles_per_part, c->d_bkeys, c->stream);
+                             metric == VG_DIST_COSINE ? 1 : 0, metric == VG_DIST_COSINE ? c->d_xnorm : nullptr,
+                             c->d_bcand, npart, tiles_per_part, c->d_bkeys, c->stream);
     if (evs) { hipEventRecord(evs[1], c->stream); hipEventRecord(evs[2], c->stream); }
     if (rc == -1) return -1;
     if (rc != 0) return vg_fail(VG_ERR_HIP, "batched scan launch failed: %s", hipGetErrorString((hipError_t)rc));

@@ -24,7 +24,7 @@
 // HBM traffic = corpus x (Q / 128) (each query group re-reads the corpus; the groups sharing a partition are placed
 // on one XCD so the re-reads hit its L2); at ~100+ TF the kernel is MFMA-bound, not bandwidth-bound.
 //
-// Metrics: DOT and COSINE (row norms accumulated from the same LDS reads).  L2/L1 and the other element types are
+// Metrics: DOT and COSINE (row norms: vg_rownorm_kernel, cached per corpus).  L2/L1 and the other element types are
 // served by the single-query scan path (exact reference arithmetic) - see vg_api.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -59,6 +59,7 @@ struct BatchArgs {
     int k;
     int cosine;               // 0: dot, 1: cosine
     int tiles_per_part;
+    const float *xnorm;       // cosine: ||row|| for every row (vg_rownorm_kernel, cached by the corpus)
 };
 
 typedef float vgb_f32x4 __attribute__((ext_vector_type(4)));
@@ -173,31 +174,37 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     };
     constexpr int NPIECE = (VGB_TILE / VGB_WAVES) * PIECES;
 
-    // distance of ONE accumulator register: acc_r = <query i(r,h), row x>
-    auto reg_distance = [&](int r, float acc_r, float xnorm) -> float {
+    // Per-register state, all in VGPRs (register r of lane (x, h) belongs to query qi(r, h) = (r&3) + 8*(r>>2) + 4*h):
+    //   thr_reg[r]  current k-th best distance of that query (+Inf until its list is full)
+    //   qn_reg[r]   ||q|| (cosine)
+    //   gate[r]     in-loop gate on the RAW accumulator, a superset of "distance <= thr":
+    //               dot:    d = -acc <= thr  <=>  acc >= -thr (minus a hair for the 8-eps clamp)
+    //               cosine: 1 - acc/(|q||x|) <= thr  <=>  acc >= (1-thr)|q| * |x|; with G = (1-thr)|q| the test is
+    //                       acc >= |x| * (G - 1e-5|G| - 1e-6) - 1e-30 (slack for the product / division roundings);
+    //                       the |x|-independent factor is what gate[r] holds, one FMA per register remains in the loop.
+    // The exact distance, clamp, row bound and key comparison happen in reg_insert (rare).  The full test with its LDS
+    // read and clamp cost 30% of the kernel when it ran 16 times per tile.
+    float gate[16], thr_reg[16], qn_reg[16];
+    auto make_gate = [](float thr, float qn) -> float {
+        if (!COS) return -thr - 1e-6f;
+        const float G = (1.0f - thr) * qn;
+        return G - 1e-5f * fabsf(G) - 1e-6f;
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
         const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        thr_reg[r] = INFINITY;
+        qn_reg[r] = qn_w[qi];
+        gate[r] = make_gate(INFINITY, qn_reg[r]);
+    }
+    // distance of ONE accumulator register: acc_r = <query qi(r,h), row x>
+    auto reg_distance = [&](auto rc, float acc_r, float xnorm) -> float {
+        constexpr int r = decltype(rc)::value;
         float d;
-        if (COS) d = vg_cosine_from_norms(acc_r, qn_w[qi], xnorm);
+        if (COS) d = vg_cosine_from_norms(acc_r, qn_reg[r], xnorm);
         else d = -acc_r;
         return vg_clamp(d);
     };
-    // In-loop gate, ONE compare per register: a superset of "distance <= current k-th best" evaluated on the raw
-    // accumulator.  dot: d = -acc <= thr  <=>  acc >= -thr (minus a hair for the 8-eps clamp).  cosine:
-    // 1 - acc/(|q||x|) <= thr  <=>  acc >= (1-thr)|q| * |x|, tested with a relative + absolute slack.  The exact
-    // distance, clamp, row bound and key comparison happen in reg_insert (rare).  The full test with its LDS read
-    // and clamp cost 30% of the kernel when it ran 16 times per tile.
-    float gate[16];
-    float thr_reg[16];                    // dot variant only: the k-th best distance itself (the slow path never reads LDS for it)
-    auto reload_gates = [&]() {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float t = thr_w[qi];
-            gate[r] = COS ? (1.0f - t) * qn_w[qi] : (-t - 1e-6f);
-            thr_reg[r] = t;
-        }
-    };
-    reload_gates();
     // a list that is not full yet (fewer than k finite distances so far) accepts everything
     auto kth_distance = [](uint64_t kth) -> float {
         return (kth == VG_EMPTY_KEY) ? INFINITY : vg_sortable_f32((uint32_t)(kth >> 32));
@@ -206,17 +213,15 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     auto reg_insert = [&](auto rc, float acc_r, long long row, float xnorm) {
         constexpr int r = decltype(rc)::value;
         const int q_lo = (r & 3) + 8 * (r >> 2);
-        const float d = reg_distance(r, acc_r, xnorm);
-        const float thr_now = COS ? thr_w[q_lo + 4 * h] : thr_reg[r];
-        const bool pass = (row < a.n_rows) && (d <= thr_now) && (d < INFINITY);
+        const float d = reg_distance(rc, acc_r, xnorm);
+        const bool pass = (row < a.n_rows) && (d <= thr_reg[r]) && (d < INFINITY);
         unsigned long long m = __ballot(pass);
         const uint64_t key = vg_make_key(d, (uint32_t)row);
         while (m) {
             const int src = __ffsll((long long)m) - 1;
             m &= m - 1;
             const int hh = src >> 5;
-            const int q = q_lo + 4 * hh;
-            uint64_t *list = wave_lists + q * k;
+            uint64_t *list = wave_lists + (q_lo + 4 * hh) * k;
             const uint64_t c = vg_readlane64(key, src);
             // one LDS round trip per candidate: a key that no longer beats the tail simply changes nothing below
             uint64_t mine = (lane < k) ? list[lane] : 0ull;
@@ -224,11 +229,9 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
             mine = (mine > c) ? ((prev > c) ? prev : c) : mine;
             if (lane < k) list[lane] = mine;
             const float nt = kth_distance(vg_readlane64(mine, k - 1));
-            if (COS) {
-                if (lane == 0) thr_w[q] = nt;
-            } else if (h == hh) {
+            if (h == hh) {
                 thr_reg[r] = nt;
-                gate[r] = -nt - 1e-6f;
+                gate[r] = make_gate(nt, qn_reg[r]);
             }
         }
     };
@@ -260,7 +263,13 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
 #if VGB_DUAL_ACC
         vgb_f32x16 acc2 = acc;
 #endif
-        float xx_part = 0.0f;
+        // cosine: ||x|| of this lane's row comes from the corpus' cached norm vector (one global load per tile, consumed
+        // after the k loop); accumulating it here from the B reads cost 4 VALU FMAs per k-step and ~20 TFLOP/s
+        float xnorm_cur = 0.0f;
+        if (COS) {
+            const long long rr = tile * VGB_TILE + x;
+            xnorm_cur = a.xnorm[rr < a.n_rows ? rr : a.n_rows - 1];
+        }
         unsigned pend = 0;
         const float cos_slack = COS ? xnorm_prev : 0.0f;
         const float *brow = cur + x * PITCH + 4 * h;
@@ -294,10 +303,6 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[4 * t + 3], b.w, acc, 0, 0, 0);
 #endif
             if constexpr (t + BP < NT) vgb_lds_read128<32 * (t + BP)>(bq[t % BP], baddr);
-            if (COS) {
-                xx_part = fmaf(b.x, b.x, xx_part); xx_part = fmaf(b.y, b.y, xx_part);
-                xx_part = fmaf(b.z, b.z, xx_part); xx_part = fmaf(b.w, b.w, xx_part);
-            }
             // DMA pieces of the next tile go out during the FIRST THIRD of the k loop (the rest of the MFMAs cover
             // their HBM latency); the 16 register gates are spread over the whole loop
             constexpr int NTD = (NT + 2) / 3;
@@ -309,8 +314,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
                 constexpr int r = decltype(rc)::value;
                 if (!(VGB_ABLATE & 1)) {
                     // cosine: gate*|x| with a slack that covers the rounding of the product and of the division
-                    const float g = COS ? (gate[r] * cos_slack - 1e-5f * fabsf(gate[r] * cos_slack) - 1e-6f * cos_slack - 1e-30f)
-                                             : gate[r];
+                    const float g = COS ? fmaf(gate[r], cos_slack, -1e-30f) : gate[r];
                     // negated '<' so that a NaN gate (zero-norm query / row: 0 * Inf) or a NaN score falls through to
                     // the exact test instead of being silently dropped
                     pend |= __ballot(!(acc_prev[r] < g)) ? (1u << r) : 0u;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
             if (blockIdx.x == 0 && wave == 0 && tile == tile_first + 5000) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (!(acc_prev[r] < gate[r])) printf("tile+5000 lane %d r %d acc %.9g gate %.9g thr %.9g\n", lane, r, acc_prev[r], gate[r], thr_w[(r & 3) + 8 * (r >> 2) + 4 * h]);
+                    if (!(acc_prev[r] < gate[r])) printf("tile+5000 lane %d r %d acc %.9g gate %.9g thr %.9g\n", lane, r, acc_prev[r], gate[r], thr_reg[r]);
             }
         }
         if (pend) {
@@ -335,7 +339,6 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
                 constexpr int r = decltype(rc)::value;
                 if (pend & (1u << r)) reg_insert(rc, acc_prev[r], row_prev, xnorm_prev);
             });
-            if (COS) reload_gates();          // dot: reg_insert already updated the registers it changed
         }
 #if VGB_DUAL_ACC
         acc_prev = acc + acc2;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         acc_prev = acc;
 #endif
         row_prev = tile * VGB_TILE + x;
-        if (COS) xnorm_prev = sqrtf(xx_part + __shfl_xor(xx_part, 32));
+        if (COS) xnorm_prev = xnorm_cur;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of tile t+1 have landed
         if (!(VGB_ABLATE & 4)) __syncthreads();               // tile t consumed by all, tile t+1 landed for all
     }
@@ -357,6 +360,37 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         const int qi = s >> 6, slot = s & 63;
         a.cand[((long long)(q0 + qi) * a.npart + part) * 64 + slot] = (slot < k) ? wave_lists[qi * k + slot] : VG_EMPTY_KEY;
     }
+}
+
+// ||row|| for rows [row0, row0 + n): 16 lanes per row, float4 loads, f32 FMA partials + butterfly (the batched cosine
+// path is a <= 1e-5 path; the bit-exact reference order lives in the single-query kernels).  HBM-bound, run once per
+// appended row: the corpus caches the vector.
+__global__ __launch_bounds__(256) void vg_rownorm_kernel(const float *rows, long long row0, long long n, long long stride_f,
+                                                         float *out) {
+    const int sub = threadIdx.x & 15;
+    const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long long ngroups = ((long long)gridDim.x * blockDim.x) >> 4;
+    const int nch = (int)(stride_f / 4);
+    for (long long r = group; r < n; r += ngroups) {
+        const float4 *p = reinterpret_cast<const float4 *>(rows + (row0 + r) * stride_f);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int c = sub; c < nch; c += 16) {
+            const float4 v = p[c];
+            s0 = fmaf(v.x, v.x, s0); s1 = fmaf(v.y, v.y, s1); s2 = fmaf(v.z, v.z, s2); s3 = fmaf(v.w, v.w, s3);
+        }
+        float s = (s0 + s1) + (s2 + s3);
+        s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+        if (sub == 0) out[row0 + r] = sqrtf(s);
+    }
+}
+
+extern "C" int vg_rownorm_launch(const float *dev_rows, long long row0, long long n, long long stride_bytes, float *dev_out,
+                                 hipStream_t stream) {
+    if (n <= 0) return 0;
+    long long blocks = (n * 16 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(vg_rownorm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dev_rows, row0, n, stride_bytes / 4, dev_out);
+    return (int)hipGetLastError();
 }
 
 // per query: its npart sorted lists (contiguous in `cand`) -> final k (ascending, EMPTY padded to 64).
@@ -397,14 +431,17 @@ extern "C" size_t vg_batch_lds_bytes(long long stride_bytes, int k) {
 // single-query path), a hipError_t otherwise.  dev_cand: nq_pad x npart x 64 keys; dev_out_keys: nq_pad x 64 keys.
 // A lives in 4*NT VGPRs per lane, so rows up to 512 floats are served; longer rows use the single-query path.
 extern "C" int vg_batch_launch(const float *dev_rows, long long n_rows, long long stride_bytes,
-                               const float *dev_queries, int nq_pad, int k, int cosine, uint64_t *dev_cand,
-                               int npart, int tiles_per_part, uint64_t *dev_out_keys, hipStream_t stream) {
+                               const float *dev_queries, int nq_pad, int k, int cosine, const float *dev_xnorm,
+                               uint64_t *dev_cand, int npart, int tiles_per_part, uint64_t *dev_out_keys,
+                               hipStream_t stream) {
     const size_t smem = vg_batch_lds_bytes(stride_bytes, k);
     if (!smem || nq_pad % VGB_QPB != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
     BatchArgs a;
     a.rows = dev_rows; a.queries = dev_queries; a.cand = dev_cand; a.n_rows = n_rows;
     a.stride_f = stride_bytes / 4; a.nq_pad = nq_pad; a.npart = npart; a.k = k; a.cosine = cosine;
     a.tiles_per_part = tiles_per_part;
+    a.xnorm = dev_xnorm;
+    if (cosine && !dev_xnorm) return -1;
     const int nt = (int)((a.stride_f + 7) / 8);
     const int G = nq_pad / VGB_QPB;
     const int blocks = G * ((npart + 7) / 8) * 8;

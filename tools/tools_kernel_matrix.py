@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--rows", type=int, default=4_000_000)
     ap.add_argument("--dims", type=str, default="384,768")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--types", type=str, default="1,2,3,4,5")
+    ap.add_argument("--bytes", type=float, default=0, help="if set: rows = bytes / row size (same HBM footprint for every dim)")
     args = ap.parse_args()
     import torch
     torch.cuda.init()
@@ -26,9 +28,9 @@ def main():
     names = {1: "f32", 2: "f16", 3: "bf16", 4: "u8", 5: "i8"}
     mnames = {1: "l2", 2: "sql2", 3: "cos", 4: "dot", 5: "l1"}
     for dim in [int(x) for x in args.dims.split(",")]:
-        for vt in (1, 2, 3, 4, 5):
+        for vt in [int(x) for x in args.types.split(",")]:
             es = pkg.TYPE_SIZE[vt]
-            n = args.rows
+            n = args.rows if not args.bytes else int(args.bytes // (dim * es))
             c = pkg.Corpus(vt, dim, capacity=n)
             blk = 1_000_000
             for r0 in range(0, n, blk):
