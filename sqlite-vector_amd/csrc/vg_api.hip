@@ -803,7 +803,7 @@ extern "C" int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k, 
 // ---- batched queries: the MFMA path (vg_batch.hip) when the shape allows it, otherwise nq single-query scans
 extern "C" size_t vg_batch_lds_bytes(long long stride_bytes, int k);
 extern "C" int vg_batch_launch(const float *dev_rows, long long n_rows, long long stride_bytes,
-                               const float *dev_queries, int nq_pad, int k, int cosine, const float *dev_xnorm,
+                               const float *dev_queries, int nq_pad, int k, int mode, int root, const float *dev_xnorm,
                                uint64_t *dev_cand, int npart, int tiles_per_part, uint64_t *dev_out_keys,
                                hipStream_t stream);
 extern "C" int vg_rownorm_launch(const float *dev_rows, long long row0, long long n, long long stride_bytes, float *dev_out,
@@ -832,7 +832,7 @@ static int ensure_row_norms(vg_corpus *c) {
 static bool batch_mfma_eligible(const vg_corpus *c, int metric, int k) {
     if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
     if (c->vtype != VG_TYPE_F32) return false;
-    if (metric != VG_DIST_DOT && metric != VG_DIST_COSINE) return false;
+    if (metric == VG_DIST_L1) return false;                       // no matrix form
     return vg_batch_lds_bytes(c->stride, k) != 0;
 }
 
@@ -862,7 +862,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     const size_t row_bytes = (size_t)c->dim * c->es;
     for (int i = 0; i < nq; ++i) memcpy(hq.data() + (size_t)i * c->stride, (const uint8_t *)queries + (size_t)i * row_bytes, row_bytes);
     HIP_TRY(hipMemcpyAsync(c->d_bq, hq.data(), qbytes, hipMemcpyHostToDevice, c->stream));
-    if (metric == VG_DIST_COSINE) {
+    if (metric != VG_DIST_DOT) {
         int rcn = ensure_row_norms(c);
         if (rcn != VG_OK) return rcn;
     }
@@ -876,7 +876,8 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
         hipEventRecord(evs[0], c->stream);
     }
     int rc = vg_batch_launch((const float *)c->d_rows, c->n_rows, c->stride, (const float *)c->d_bq, nq_pad, k,
-                             metric == VG_DIST_COSINE ? 1 : 0, metric == VG_DIST_COSINE ? c->d_xnorm : nullptr,
+                             metric == VG_DIST_DOT ? 0 : (metric == VG_DIST_COSINE ? 1 : 2), metric == VG_DIST_L2 ? 1 : 0,
+                             metric == VG_DIST_DOT ? nullptr : c->d_xnorm,
                              c->d_bcand, npart, tiles_per_part, c->d_bkeys, c->stream);
     if (evs) { hipEventRecord(evs[1], c->stream); hipEventRecord(evs[2], c->stream); }
     if (rc == -1) return -1;

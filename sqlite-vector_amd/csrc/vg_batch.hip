@@ -24,8 +24,9 @@
 // HBM traffic = corpus x (Q / 128) (each query group re-reads the corpus; the groups sharing a partition are placed
 // on one XCD so the re-reads hit its L2); at ~100+ TF the kernel is MFMA-bound, not bandwidth-bound.
 //
-// Metrics: DOT and COSINE (row norms: vg_rownorm_kernel, cached per corpus).  L2/L1 and the other element types are
-// served by the single-query scan path (exact reference arithmetic) - see vg_api.hip.
+// Metrics: DOT, COSINE and L2 / squared L2 (row norms: vg_rownorm_kernel, cached per corpus; for L2 the GEMM is only
+// the filter - survivors are re-evaluated with the reference formula).  L1 and the other element types are served
+// by the single-query scan path (exact reference arithmetic) - see vg_api.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -57,10 +58,12 @@ struct BatchArgs {
     int nq_pad;
     int npart;
     int k;
-    int cosine;               // 0: dot, 1: cosine
+    int mode;                 // VGB_DOT / VGB_COS / VGB_L2
+    int root;                 // L2 mode: 1 = L2 (sqrt), 0 = squared L2
     int tiles_per_part;
-    const float *xnorm;       // cosine: ||row|| for every row (vg_rownorm_kernel, cached by the corpus)
+    const float *xnorm;       // cosine, L2: ||row|| for every row (vg_rownorm_kernel, cached by the corpus)
 };
+enum { VGB_DOT = 0, VGB_COS = 1, VGB_L2 = 2 };
 
 typedef float vgb_f32x4 __attribute__((ext_vector_type(4)));
 #ifndef VGB_BPIPE
@@ -85,8 +88,9 @@ __device__ __forceinline__ void vgb_static_for(F &&f) {
     }
 }
 
-template <int NT, bool COS>
+template <int NT, int MODE>
 __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
+    constexpr bool COS = (MODE == VGB_COS), L2M = (MODE == VGB_L2);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int PITCH = NT * 8 + 4;                         // floats per LDS tile row (16-byte pad: conflict-free b128)
     constexpr int TILE_FLOATS = VGB_TILE * PITCH;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     {
         // ||q|| of query (q0+x): the two halves of the k range live in lanes x and x+32
         const float qq_x = qq_part + __shfl_xor(qq_part, 32);
-        if (h == 0) { qn_w[x] = sqrtf(qq_x); thr_w[x] = INFINITY; }
+        if (h == 0) { qn_w[x] = L2M ? qq_x : sqrtf(qq_x); thr_w[x] = INFINITY; }     // L2 keeps |q|^2, cosine |q|
         for (int s = lane; s < VGB_QPW * k; s += 64) wave_lists[s] = VG_EMPTY_KEY;
     }
     // zero both tile buffers once: the k-padding columns [stride_f, NT*8) are never touched by the DMA
@@ -184,11 +188,23 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     //                       the |x|-independent factor is what gate[r] holds, one FMA per register remains in the loop.
     // The exact distance, clamp, row bound and key comparison happen in reg_insert (rare).  The full test with its LDS
     // read and clamp cost 30% of the kernel when it ran 16 times per tile.
+    //               L2:     d2 = |q|^2 + |x|^2 - 2 acc <= thr2  <=>  acc >= (|q|^2 + |x|^2 - thr2) / 2; the gate keeps
+    //                       the |x|-independent part, |q|^2 * 0.4999 - thr2 / 2, and the loop adds |x|^2 * 0.4999 (the
+    //                       1e-4 relative slack covers the f32 error of acc).  The norm identity is ONLY this filter:
+    //                       a survivor's distance is re-evaluated as sum (q-x)^2 from HBM in reg_insert, because the
+    //                       identity cancels catastrophically for near-duplicates and the bar is 1e-5 relative.
     float gate[16], thr_reg[16], qn_reg[16];
-    auto make_gate = [](float thr, float qn) -> float {
-        if (!COS) return -thr - 1e-6f;
-        const float G = (1.0f - thr) * qn;
-        return G - 1e-5f * fabsf(G) - 1e-6f;
+    const bool l2_root = a.root != 0;
+    auto make_gate = [&](float thr, float qn) -> float {
+        if (COS) {
+            const float G = (1.0f - thr) * qn;
+            return G - 1e-5f * fabsf(G) - 1e-6f;
+        }
+        if (L2M) {
+            const float thr2 = l2_root ? thr * thr : thr;
+            return fmaf(qn, 0.4999f, -0.5f * thr2) - 1e-6f;
+        }
+        return -thr - 1e-6f;
     };
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -197,13 +213,28 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         qn_reg[r] = qn_w[qi];
         gate[r] = make_gate(INFINITY, qn_reg[r]);
     }
-    // distance of ONE accumulator register: acc_r = <query qi(r,h), row x>
+    // distance of ONE accumulator register: acc_r = <query qi(r,h), row x>   (dot / cosine)
     auto reg_distance = [&](auto rc, float acc_r, float xnorm) -> float {
         constexpr int r = decltype(rc)::value;
         float d;
         if (COS) d = vg_cosine_from_norms(acc_r, qn_reg[r], xnorm);
         else d = -acc_r;
         return vg_clamp(d);
+    };
+    // L2: the reference's own formula for ONE (query, row) pair, computed by the whole wavefront from HBM / L2
+    // (wave-uniform arguments): lane-strided float4 loads, 4 f32 FMA partials, butterfly - the single-query kernel's
+    // arithmetic.  ~1 us of latency per survivor; survivors are k*ln(n/k) per list.
+    auto exact_l2 = [&](int q_uniform, long long row_uniform) -> float {
+        const float4 *qp = reinterpret_cast<const float4 *>(a.queries + (long long)(q0 + q_uniform) * a.stride_f);
+        const float4 *xp = reinterpret_cast<const float4 *>(a.rows + row_uniform * a.stride_f);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int c = lane; c < chunks_per_row; c += 64) {
+            const float4 qv = qp[c], xv = xp[c];
+            const float d0 = qv.x - xv.x, d1 = qv.y - xv.y, d2 = qv.z - xv.z, d3 = qv.w - xv.w;
+            s0 = fmaf(d0, d0, s0); s1 = fmaf(d1, d1, s1); s2 = fmaf(d2, d2, s2); s3 = fmaf(d3, d3, s3);
+        }
+        const float s = vg_group_sum((s0 + s1) + (s2 + s3), 6);
+        return vg_clamp(l2_root ? sqrtf(s) : s);
     };
     // a list that is not full yet (fewer than k finite distances so far) accepts everything
     auto kth_distance = [](uint64_t kth) -> float {
@@ -213,16 +244,32 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     auto reg_insert = [&](auto rc, float acc_r, long long row, float xnorm) {
         constexpr int r = decltype(rc)::value;
         const int q_lo = (r & 3) + 8 * (r >> 2);
-        const float d = reg_distance(rc, acc_r, xnorm);
-        const bool pass = (row < a.n_rows) && (d <= thr_reg[r]) && (d < INFINITY);
+        float d = 0.0f;
+        bool pass;
+        if (L2M) {
+            // the gate again (per lane this time); the distance itself comes from exact_l2 below
+            pass = (row < a.n_rows) && !(acc_r < fmaf(xnorm * xnorm, 0.4999f, gate[r]));
+        } else {
+            d = reg_distance(rc, acc_r, xnorm);
+            pass = (row < a.n_rows) && (d <= thr_reg[r]) && (d < INFINITY);
+        }
         unsigned long long m = __ballot(pass);
-        const uint64_t key = vg_make_key(d, (uint32_t)row);
+        uint64_t key = vg_make_key(d, (uint32_t)row);
         while (m) {
             const int src = __ffsll((long long)m) - 1;
             m &= m - 1;
             const int hh = src >> 5;
             uint64_t *list = wave_lists + (q_lo + 4 * hh) * k;
-            const uint64_t c = vg_readlane64(key, src);
+            uint64_t c;
+            if (L2M) {
+                const long long row_u = __builtin_amdgcn_readlane((int)row, src);          // rows < 2^32 per shard, and
+                const float thr_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thr_reg[r]), src));
+                const float de = exact_l2(q_lo + 4 * hh, (long long)(uint32_t)row_u);       // positive as u32
+                if (!(de <= thr_u) || !(de < INFINITY)) continue;
+                c = vg_make_key(de, (uint32_t)row_u);
+            } else {
+                c = vg_readlane64(key, src);
+            }
             // one LDS round trip per candidate: a key that no longer beats the tail simply changes nothing below
             uint64_t mine = (lane < k) ? list[lane] : 0ull;
             const uint64_t prev = vg_wave_shr1(mine);
@@ -266,12 +313,12 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         // cosine: ||x|| of this lane's row comes from the corpus' cached norm vector (one global load per tile, consumed
         // after the k loop); accumulating it here from the B reads cost 4 VALU FMAs per k-step and ~20 TFLOP/s
         float xnorm_cur = 0.0f;
-        if (COS) {
+        if (COS || L2M) {
             const long long rr = tile * VGB_TILE + x;
             xnorm_cur = a.xnorm[rr < a.n_rows ? rr : a.n_rows - 1];
         }
         unsigned pend = 0;
-        const float cos_slack = COS ? xnorm_prev : 0.0f;
+        const float cos_slack = COS ? xnorm_prev : (L2M ? xnorm_prev * xnorm_prev * 0.4999f : 0.0f);
         const float *brow = cur + x * PITCH + 4 * h;
         // B operand pipeline: ds_read_b128 issued from inline asm BP steps (= 4*BP MFMAs) ahead of its use into a ring
         // of BP register quads, with an exact "s_waitcnt lgkmcnt(n)" in front of the consumer.  Left to the compiler
@@ -314,7 +361,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
                 constexpr int r = decltype(rc)::value;
                 if (!(VGB_ABLATE & 1)) {
                     // cosine: gate*|x| with a slack that covers the rounding of the product and of the division
-                    const float g = COS ? fmaf(gate[r], cos_slack, -1e-30f) : gate[r];
+                    const float g = COS ? fmaf(gate[r], cos_slack, -1e-30f) : (L2M ? gate[r] + cos_slack : gate[r]);
                     // negated '<' so that a NaN gate (zero-norm query / row: 0 * Inf) or a NaN score falls through to
                     // the exact test instead of being silently dropped
                     pend |= __ballot(!(acc_prev[r] < g)) ? (1u << r) : 0u;
@@ -346,7 +393,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         acc_prev = acc;
 #endif
         row_prev = tile * VGB_TILE + x;
-        if (COS) xnorm_prev = xnorm_cur;
+        if (COS || L2M) xnorm_prev = xnorm_cur;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of tile t+1 have landed
         if (!(VGB_ABLATE & 4)) __syncthreads();               // tile t consumed by all, tile t+1 landed for all
     }
@@ -402,17 +449,19 @@ __global__ __launch_bounds__(256) void vg_batch_merge_kernel(const uint64_t *can
     vg_select_lists(cand + (long long)q * npart * 64, npart, k, out_keys + (long long)q * 64, scratch);
 }
 
-template <int NT, bool COS>
-static int launch_nt_cos(const BatchArgs &a, int blocks, size_t smem, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_kernel<NT, COS>),
+template <int NT, int MODE>
+static int launch_nt_mode(const BatchArgs &a, int blocks, size_t smem, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_kernel<NT, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((vg_batch_kernel<NT, COS>), dim3((unsigned)blocks), dim3(VGB_THREADS), smem, stream, a);
+    hipLaunchKernelGGL((vg_batch_kernel<NT, MODE>), dim3((unsigned)blocks), dim3(VGB_THREADS), smem, stream, a);
     return (int)hipGetLastError();
 }
 template <int NT>
 static int launch_nt(const BatchArgs &a, int blocks, size_t smem, hipStream_t stream) {
-    return a.cosine ? launch_nt_cos<NT, true>(a, blocks, smem, stream) : launch_nt_cos<NT, false>(a, blocks, smem, stream);
+    if (a.mode == VGB_COS) return launch_nt_mode<NT, VGB_COS>(a, blocks, smem, stream);
+    if (a.mode == VGB_L2) return launch_nt_mode<NT, VGB_L2>(a, blocks, smem, stream);
+    return launch_nt_mode<NT, VGB_DOT>(a, blocks, smem, stream);
 }
 
 // LDS bytes of the batch kernel for a row of `stride_bytes` and k; 0 if the shape is not served
@@ -431,17 +480,17 @@ extern "C" size_t vg_batch_lds_bytes(long long stride_bytes, int k) {
 // single-query path), a hipError_t otherwise.  dev_cand: nq_pad x npart x 64 keys; dev_out_keys: nq_pad x 64 keys.
 // A lives in 4*NT VGPRs per lane, so rows up to 512 floats are served; longer rows use the single-query path.
 extern "C" int vg_batch_launch(const float *dev_rows, long long n_rows, long long stride_bytes,
-                               const float *dev_queries, int nq_pad, int k, int cosine, const float *dev_xnorm,
+                               const float *dev_queries, int nq_pad, int k, int mode, int root, const float *dev_xnorm,
                                uint64_t *dev_cand, int npart, int tiles_per_part, uint64_t *dev_out_keys,
                                hipStream_t stream) {
     const size_t smem = vg_batch_lds_bytes(stride_bytes, k);
     if (!smem || nq_pad % VGB_QPB != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
     BatchArgs a;
     a.rows = dev_rows; a.queries = dev_queries; a.cand = dev_cand; a.n_rows = n_rows;
-    a.stride_f = stride_bytes / 4; a.nq_pad = nq_pad; a.npart = npart; a.k = k; a.cosine = cosine;
+    a.stride_f = stride_bytes / 4; a.nq_pad = nq_pad; a.npart = npart; a.k = k; a.mode = mode; a.root = root;
     a.tiles_per_part = tiles_per_part;
     a.xnorm = dev_xnorm;
-    if (cosine && !dev_xnorm) return -1;
+    if (mode < VGB_DOT || mode > VGB_L2 || (mode != VGB_DOT && !dev_xnorm)) return -1;
     const int nt = (int)((a.stride_f + 7) / 8);
     const int G = nq_pad / VGB_QPB;
     const int blocks = G * ((npart + 7) / 8) * 8;

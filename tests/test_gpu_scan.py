@@ -261,7 +261,7 @@ def _assert_topk_close(ids, dist, all_dist, k, tol):
 
 
 @pytest.mark.parametrize("dim", (16, 100, 128, 384, 500, 512))
-@pytest.mark.parametrize("metric", (dg.DOT, dg.COSINE))
+@pytest.mark.parametrize("metric", (dg.DOT, dg.COSINE, dg.L2, dg.SQUARED_L2))
 def test_batch_mfma_path_vs_oracle(pkg, orc, dim, metric):
     """vg_scan_topk_batch on f32 dot / cosine runs Q x C^T on the matrix cores (v_mfma_f32_32x32x2_f32) with the
     fused per-query top-k; every query is checked against the reference arithmetic (<= 1e-5 relative to the
@@ -276,7 +276,8 @@ def test_batch_mfma_path_vs_oracle(pkg, orc, dim, metric):
         ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
         for i in range(nq):
             want = orc.scan_distances(orc.AVX2, metric, dg.F32, qs[i], rows)
-            scale = np.abs(rows.astype(np.float64) * qs[i].astype(np.float64)).sum(axis=1) if metric == dg.DOT else np.ones(n)
+            scale = (np.abs(rows.astype(np.float64) * qs[i].astype(np.float64)).sum(axis=1) if metric == dg.DOT
+                     else np.ones(n) if metric == dg.COSINE else np.zeros(n))          # L2: purely relative
             tol = REL_TOL * (np.abs(want.astype(np.float64)) + scale) + 1e-6
             _assert_topk_close(ids[i][:cnt[i]], dist[i][:cnt[i]], want, k, tol)
     c.close()
@@ -300,7 +301,7 @@ def test_batch_small_corpus_and_fallback_shapes(pkg, orc):
     qs = dg.corpus(dg.F32, 5, dim, 34)
     c = pkg.Corpus(pkg.F32, dim)
     c.append(rows)
-    for metric, k in ((dg.L2, 10), (dg.L1, 10), (dg.DOT, 40)):
+    for metric, k in ((dg.L1, 10), (dg.DOT, 40), (dg.L2, 40)):
         ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
         for i in range(5):
             one_ids, one_dist = c.scan_topk(metric, qs[i], k)
@@ -540,7 +541,7 @@ def test_in_process_shards_equal_a_single_corpus(pkg, orc, vt, metric):
     one.close(); one2.close(); sh.close()
 
 
-@pytest.mark.parametrize("metric", (dg.DOT, dg.COSINE))
+@pytest.mark.parametrize("metric", (dg.DOT, dg.COSINE, dg.L2))
 def test_batch_mfma_rows_with_nan_inf_at_the_start_of_a_partition(pkg, orc, metric):
     """rows whose score is NaN / +Inf never enter a list; when they sit in the first tile of a partition the list is
     not full after that tile and must keep accepting every finite row (threshold stays +Inf, not NaN)."""
@@ -557,4 +558,27 @@ def test_batch_mfma_rows_with_nan_inf_at_the_start_of_a_partition(pkg, orc, metr
         one_ids, one_dist = c.scan_topk(metric, qs[i], 20)        # per-query kernel (oracle-checked elsewhere)
         assert cnt[i] == 20 and ids[i].tolist() == one_ids.tolist()
         assert np.allclose(dist[i], one_dist, rtol=1e-5, atol=1e-5)
+    c.close()
+
+
+@pytest.mark.parametrize("metric", (dg.L2, dg.SQUARED_L2))
+def test_batch_l2_near_duplicates_keep_the_relative_bar(pkg, orc, metric):
+    """batched L2 filters with |q|^2 + |x|^2 - 2<q,x> on the matrix cores, which cancels catastrophically when a row
+    almost equals the query; survivors are re-evaluated with the reference's sum (q-x)^2, so even distances 1e-6 of the
+    norms away are within 1e-5 RELATIVE of the reference (an identity-only kernel is off by orders of magnitude)."""
+    dim, n, nq, k = 384, 6000, 40, 10
+    rng = np.random.default_rng(77)
+    rows = dg.corpus(dg.F32, n, dim, 71)
+    qs = dg.corpus(dg.F32, nq, dim, 72)
+    for i in range(nq):                                  # plant near-duplicates of every query at several scales
+        for j, eps in enumerate((1e-1, 1e-2, 1e-3, 1e-4, 0.0)):
+            rows[(i * 131 + j * 1009) % n] = qs[i] + eps * rng.standard_normal(dim).astype(np.float32)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+    for i in range(nq):
+        want = orc.scan_distances(orc.AVX2, metric, dg.F32, qs[i], rows)
+        tol = REL_TOL * np.abs(want.astype(np.float64)) + 8 * np.finfo(np.float32).eps * 1.01     # clamp straddle only
+        _assert_topk_close(ids[i][:cnt[i]], dist[i][:cnt[i]], want, k, tol)
+        assert dist[i][0] <= 1e-3 * float(np.sqrt(dim))                  # the planted rows are what was found
     c.close()

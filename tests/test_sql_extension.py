@@ -299,8 +299,9 @@ def test_vector_quantize_on_gpu_persists_the_reference_bytes(ext_path, case):
 @pytest.mark.parametrize("metric", [dg.L2, dg.DOT, dg.COSINE])
 def test_batch_tvf_equals_one_statement_per_query(ext_path, metric):
     """vector_full_scan_batch: (query, id, distance) rows == running vector_full_scan once per query (which is the
-    reference's only way to ask several questions).  L2 takes the per-query scan kernel (identical bits); DOT / COSINE
-    take the matrix-core pass, whose f32 sums associate differently (same tolerance as the f32 kernels: 1e-5)."""
+    reference's only way to ask several questions).  All three take the matrix-core pass, whose f32 sums associate
+    differently from the per-query kernel (same tolerance as the f32 kernels: 1e-5; L2 survivors are re-evaluated with
+    the direct formula, so L2 is held to a pure relative bound)."""
     n, dim, k, nq = 5000, 96, 7, 9
     rows = dg.corpus(dg.F32, n, dim, 21)
     qs = np.stack([dg.query(dg.F32, dim, 100 + i) for i in range(nq)])
@@ -311,11 +312,8 @@ def test_batch_tvf_equals_one_statement_per_query(ext_path, metric):
     for i in range(nq):
         one = db.execute("SELECT id, distance FROM vector_full_scan('t','v',?,?)", (qs[i].tobytes(), k)).fetchall()
         mine = [(g[1], g[2]) for g in got if g[0] == i]
-        if metric == dg.L2:
-            assert mine == one
-        else:
-            assert [m[0] for m in mine] == [o[0] for o in one]
-            assert np.allclose([m[1] for m in mine], [o[1] for o in one], rtol=1e-5, atol=1e-5)
+        assert [m[0] for m in mine] == [o[0] for o in one]
+        assert np.allclose([m[1] for m in mine], [o[1] for o in one], rtol=1e-5, atol=1e-5 if metric != dg.L2 else 0)
     # JSON array of arrays == BLOB batch; the usual SQL on top works (best hit per query)
     js = "[" + ",".join("[" + ",".join(repr(float(x)) for x in q) + "]" for q in qs[:3]) + "]"
     gotj = db.execute("SELECT query, id, distance FROM vector_full_scan_batch('t','v',?,?)", (js, k)).fetchall()

@@ -57,7 +57,7 @@ def main():
         one_ids, one_dist = c.scan_topk(args.metric, qs[0], args.k)
         agree = float(np.mean(np.isin(ids[0], one_ids)))
         print(json.dumps({
-            "workload": "%d queries x %dx%d f32 %s top-%d, batched MFMA" % (nq, n, dim, "dot" if args.metric == 4 else "cosine", args.k),
+            "workload": "%d queries x %dx%d f32 %s top-%d, batched MFMA" % (nq, n, dim, {1: "L2", 2: "squared L2", 3: "cosine", 4: "dot", 5: "L1"}[args.metric], args.k),
             "kernel_ms": kern_ms, "wall_ms_per_batch": wall * 1e3, "queries_per_s": nq / wall,
             "query_vector_pairs_per_s": nq * n / wall,
             "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
