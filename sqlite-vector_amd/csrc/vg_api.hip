@@ -806,6 +806,7 @@ extern "C" int vg_batch_launch(const float *dev_rows, long long n_rows, long lon
                                const float *dev_queries, int nq_pad, int k, int mode, int root, const float *dev_xnorm,
                                uint64_t *dev_cand, int npart, int tiles_per_part, uint64_t *dev_out_keys,
                                hipStream_t stream);
+extern "C" int vg_batch_lists_per_query(long long n_rows, int npart);
 extern "C" int vg_rownorm_launch(const float *dev_rows, long long row0, long long n, long long stride_bytes, float *dev_out,
                                  hipStream_t stream);
 
@@ -849,7 +850,8 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     npart = (int)std::min<long long>(npart, ntiles);
     const int tiles_per_part = (int)((ntiles + npart - 1) / npart);
 
-    const size_t qbytes = (size_t)nq_pad * c->stride, candbytes = (size_t)nq_pad * npart * 64 * sizeof(uint64_t);
+    const size_t qbytes = (size_t)nq_pad * c->stride;
+    const size_t candbytes = (size_t)nq_pad * vg_batch_lists_per_query(c->n_rows, npart) * 64 * sizeof(uint64_t);
     const size_t keybytes = (size_t)nq_pad * 64 * sizeof(uint64_t);
     if (c->bq_bytes < qbytes) { if (c->d_bq) hipFree(c->d_bq); c->d_bq = nullptr; c->bq_bytes = 0;
                                 HIP_TRY(hipMalloc(&c->d_bq, qbytes)); c->bq_bytes = qbytes; }

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "vg_lists.h"
@@ -62,6 +63,11 @@ struct BatchArgs {
     int root;                 // L2 mode: 1 = L2 (sqrt), 0 = squared L2
     int tiles_per_part;
     const float *xnorm;       // cosine, L2: ||row|| for every row (vg_rownorm_kernel, cached by the corpus)
+    // this launch covers tiles [tile_begin, tile_end) in npart partitions and writes lists part_base .. part_base+npart-1
+    // of the npart_total lists each query owns in `cand`
+    long long tile_begin, tile_end;
+    int part_base, npart_total;
+    const uint64_t *init_keys; // optional [nq_pad][64]: a query's k-th key over rows scanned EARLIER bounds its answer
 };
 enum { VGB_DOT = 0, VGB_COS = 1, VGB_L2 = 2 };
 
@@ -144,8 +150,8 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
 
     // ---- tile streaming by LDS-DMA: wavefront w moves rows w, w+4, ... of the tile, one 1-KiB piece per instruction
     const int chunks_per_row = (int)(a.stride_f / 4);
-    const long long tile_first = (long long)part * a.tiles_per_part;
-    const long long tile_last = min(tile_first + a.tiles_per_part, (a.n_rows + VGB_TILE - 1) / VGB_TILE);
+    const long long tile_first = a.tile_begin + (long long)part * a.tiles_per_part;
+    const long long tile_last = min(tile_first + a.tiles_per_part, a.tile_end);
     // One 1-KiB DMA piece: piece index pc in [0, 8*PIECES) = (row slot i, piece p) of this wavefront's 8 rows.
     // LDS-DMA from inline asm: hipcc's waitcnt pass does not see it, so it cannot put "s_waitcnt vmcnt(0)" in front
     // of every ds_read of the CURRENT tile while the NEXT tile is in flight (it did with the builtin: 16 exposed HBM
@@ -206,12 +212,17 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         }
         return -thr - 1e-6f;
     };
+    // a list that is not full yet (fewer than k finite distances so far) accepts everything - up to the bound a
+    // pre-pass over other rows established (init_keys): the final k-th best can only be smaller than that
+    auto kth_distance = [](uint64_t kth) -> float {
+        return (kth == VG_EMPTY_KEY) ? INFINITY : vg_sortable_f32((uint32_t)(kth >> 32));
+    };
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
-        thr_reg[r] = INFINITY;
+        thr_reg[r] = a.init_keys ? kth_distance(a.init_keys[(long long)(q0 + qi) * 64 + (k - 1)]) : INFINITY;
         qn_reg[r] = qn_w[qi];
-        gate[r] = make_gate(INFINITY, qn_reg[r]);
+        gate[r] = make_gate(thr_reg[r], qn_reg[r]);
     }
     // distance of ONE accumulator register: acc_r = <query qi(r,h), row x>   (dot / cosine)
     auto reg_distance = [&](auto rc, float acc_r, float xnorm) -> float {
@@ -235,10 +246,6 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         }
         const float s = vg_group_sum((s0 + s1) + (s2 + s3), 6);
         return vg_clamp(l2_root ? sqrtf(s) : s);
-    };
-    // a list that is not full yet (fewer than k finite distances so far) accepts everything
-    auto kth_distance = [](uint64_t kth) -> float {
-        return (kth == VG_EMPTY_KEY) ? INFINITY : vg_sortable_f32((uint32_t)(kth >> 32));
     };
     // slow path (outside the MFMA loop, rare once the lists have warmed up): insert this register's survivors
     auto reg_insert = [&](auto rc, float acc_r, long long row, float xnorm) {
@@ -277,8 +284,8 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
             if (lane < k) list[lane] = mine;
             const float nt = kth_distance(vg_readlane64(mine, k - 1));
             if (h == hh) {
-                thr_reg[r] = nt;
-                gate[r] = make_gate(nt, qn_reg[r]);
+                thr_reg[r] = fminf(nt, thr_reg[r]);          // never loosens (a pre-pass bound outlives a not-yet-full list)
+                gate[r] = make_gate(thr_reg[r], qn_reg[r]);
             }
         }
     };
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     // ---- publish: [query][part][64] (a query's npart lists are contiguous for the merge)
     for (int s = lane; s < VGB_QPW * 64; s += 64) {
         const int qi = s >> 6, slot = s & 63;
-        a.cand[((long long)(q0 + qi) * a.npart + part) * 64 + slot] = (slot < k) ? wave_lists[qi * k + slot] : VG_EMPTY_KEY;
+        a.cand[((long long)(q0 + qi) * a.npart_total + a.part_base + part) * 64 + slot] = (slot < k) ? wave_lists[qi * k + slot] : VG_EMPTY_KEY;
     }
 }
 
@@ -442,11 +449,11 @@ extern "C" int vg_rownorm_launch(const float *dev_rows, long long row0, long lon
 
 // per query: its npart sorted lists (contiguous in `cand`) -> final k (ascending, EMPTY padded to 64).
 // One workgroup per query, same parallel rank-select as the single-query path.
-__global__ __launch_bounds__(256) void vg_batch_merge_kernel(const uint64_t *cand, int nq_pad, int npart, int k,
-                                                             uint64_t *out_keys) {
+__global__ __launch_bounds__(256) void vg_batch_merge_kernel(const uint64_t *cand, int nq_pad, int lists_per_query,
+                                                             int npart, int k, uint64_t *out_keys) {
     __shared__ __attribute__((aligned(16))) uint8_t scratch[VG_SEL_SCRATCH_BYTES];
     const int q = blockIdx.x;
-    vg_select_lists(cand + (long long)q * npart * 64, npart, k, out_keys + (long long)q * 64, scratch);
+    vg_select_lists(cand + (long long)q * lists_per_query * 64, npart, k, out_keys + (long long)q * 64, scratch);
 }
 
 template <int NT, int MODE>
@@ -476,31 +483,68 @@ extern "C" size_t vg_batch_lds_bytes(long long stride_bytes, int k) {
     return b <= 160 * 1024 ? b : 0;
 }
 
+// How many candidate lists a query owns in `dev_cand` for this shape (the caller sizes the buffer with it): npart for
+// a single pass, 2 * npart with the pre-pass (see vg_batch_launch).
+extern "C" int vg_batch_prepass_tiles(long long n_rows, int npart) {
+    const char *e = getenv("VG_BATCH_PREPASS");
+    const int denom = (e && *e) ? atoi(e) : 64;                  // pre-pass over 1/denom of the corpus; 0 = off
+    const long long ntiles = (n_rows + VGB_TILE - 1) / VGB_TILE;
+    if (denom <= 0 || ntiles < 65536 || 2 * npart > VG_SEL_MAX_HEADS) return 0;   // < 2M rows: a single pass
+    long long t = ntiles / denom;
+    t = ((t + npart - 1) / npart) * npart;                        // whole partitions
+    return (int)t;
+}
+extern "C" int vg_batch_lists_per_query(long long n_rows, int npart) {
+    return vg_batch_prepass_tiles(n_rows, npart) > 0 ? 2 * npart : npart;
+}
+
 // Host launcher.  Returns 0 on success, -1 if the shape is not served by this kernel (caller falls back to the
-// single-query path), a hipError_t otherwise.  dev_cand: nq_pad x npart x 64 keys; dev_out_keys: nq_pad x 64 keys.
-// A lives in 4*NT VGPRs per lane, so rows up to 512 floats are served; longer rows use the single-query path.
+// single-query path), a hipError_t otherwise.  dev_cand: nq_pad x vg_batch_lists_per_query() x 64 keys;
+// dev_out_keys: nq_pad x 64 keys.  A lives in 4*NT VGPRs per lane, so rows up to 512 floats are served.
+//
+// Large corpora run in TWO passes.  Every (query, partition) list costs k*ln(n/k) inserts (193 at C5), and an insert
+// stalls its wavefront - and through the per-tile barrier its workgroup - with the matrix pipe idle.  Pass 1 scans
+// the first 1/64 of the corpus and merges; each query's k-th best there is an upper bound on its final k-th best, so
+// pass 2 starts every list at that threshold instead of +Inf: ~k*(1 + ln(rows_per_partition / rows_in_pass_1)) inserts
+// per list.  The final merge takes the lists of both passes.
 extern "C" int vg_batch_launch(const float *dev_rows, long long n_rows, long long stride_bytes,
                                const float *dev_queries, int nq_pad, int k, int mode, int root, const float *dev_xnorm,
                                uint64_t *dev_cand, int npart, int tiles_per_part, uint64_t *dev_out_keys,
                                hipStream_t stream) {
     const size_t smem = vg_batch_lds_bytes(stride_bytes, k);
     if (!smem || nq_pad % VGB_QPB != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
+    if (mode < VGB_DOT || mode > VGB_L2 || (mode != VGB_DOT && !dev_xnorm)) return -1;
     BatchArgs a;
     a.rows = dev_rows; a.queries = dev_queries; a.cand = dev_cand; a.n_rows = n_rows;
     a.stride_f = stride_bytes / 4; a.nq_pad = nq_pad; a.npart = npart; a.k = k; a.mode = mode; a.root = root;
-    a.tiles_per_part = tiles_per_part;
     a.xnorm = dev_xnorm;
-    if (mode < VGB_DOT || mode > VGB_L2 || (mode != VGB_DOT && !dev_xnorm)) return -1;
     const int nt = (int)((a.stride_f + 7) / 8);
     const int G = nq_pad / VGB_QPB;
     const int blocks = G * ((npart + 7) / 8) * 8;
+    const long long ntiles = (n_rows + VGB_TILE - 1) / VGB_TILE;
+    auto launch = [&](const BatchArgs &b) -> int {
+        if (nt <= 16) return launch_nt<16>(b, blocks, smem, stream);
+        if (nt <= 32) return launch_nt<32>(b, blocks, smem, stream);
+        if (nt <= 48) return launch_nt<48>(b, blocks, smem, stream);
+        return launch_nt<64>(b, blocks, smem, stream);
+    };
+    const long long pre = vg_batch_prepass_tiles(n_rows, npart);
     int rc;
-    if (nt <= 16) rc = launch_nt<16>(a, blocks, smem, stream);
-    else if (nt <= 32) rc = launch_nt<32>(a, blocks, smem, stream);
-    else if (nt <= 48) rc = launch_nt<48>(a, blocks, smem, stream);
-    else rc = launch_nt<64>(a, blocks, smem, stream);
-    if (rc != 0) return rc;
+    if (pre > 0) {
+        a.npart_total = 2 * npart;
+        a.tile_begin = 0; a.tile_end = pre; a.tiles_per_part = (int)(pre / npart); a.part_base = 0; a.init_keys = nullptr;
+        if ((rc = launch(a)) != 0) return rc;
+        hipLaunchKernelGGL(vg_batch_merge_kernel, dim3((unsigned)nq_pad), dim3(256), 0, stream, (const uint64_t *)dev_cand,
+                           nq_pad, a.npart_total, npart, k, dev_out_keys);
+        a.tile_begin = pre; a.tile_end = ntiles; a.tiles_per_part = (int)((ntiles - pre + npart - 1) / npart);
+        a.part_base = npart; a.init_keys = dev_out_keys;
+        if ((rc = launch(a)) != 0) return rc;
+    } else {
+        a.npart_total = npart;
+        a.tile_begin = 0; a.tile_end = ntiles; a.tiles_per_part = tiles_per_part; a.part_base = 0; a.init_keys = nullptr;
+        if ((rc = launch(a)) != 0) return rc;
+    }
     hipLaunchKernelGGL(vg_batch_merge_kernel, dim3((unsigned)nq_pad), dim3(256), 0, stream, (const uint64_t *)dev_cand,
-                       nq_pad, npart, k, dev_out_keys);
+                       nq_pad, a.npart_total, a.npart_total, k, dev_out_keys);
     return (int)hipGetLastError();
 }
