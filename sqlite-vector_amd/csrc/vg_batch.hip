@@ -201,16 +201,20 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     //                       identity cancels catastrophically for near-duplicates and the bar is 1e-5 relative.
     float gate[16], thr_reg[16], qn_reg[16];
     const bool l2_root = a.root != 0;
+    // "accept everything" (list not full, zero-norm query) is a huge negative FINITE gate: -Inf would turn into NaN
+    // against a zero-norm row (-Inf * 0) and a NaN margin is indistinguishable from "no" in the max reduction below
     auto make_gate = [&](float thr, float qn) -> float {
+        float g;
         if (COS) {
             const float G = (1.0f - thr) * qn;
-            return G - 1e-5f * fabsf(G) - 1e-6f;
-        }
-        if (L2M) {
+            g = G - 1e-5f * fabsf(G) - 1e-6f;
+        } else if (L2M) {
             const float thr2 = l2_root ? thr * thr : thr;
-            return fmaf(qn, 0.4999f, -0.5f * thr2) - 1e-6f;
+            g = fmaf(qn, 0.4999f, -0.5f * thr2) - 1e-6f;
+        } else {
+            g = -thr - 1e-6f;
         }
-        return -thr - 1e-6f;
+        return fmaxf(g, -3.0e38f);                 // also maps a NaN gate to "accept"
     };
     // a list that is not full yet (fewer than k finite distances so far) accepts everything - up to the bound a
     // pre-pass over other rows established (init_keys): the final k-th best can only be smaller than that
@@ -224,6 +228,11 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         qn_reg[r] = qn_w[qi];
         gate[r] = make_gate(thr_reg[r], qn_reg[r]);
     }
+    // the gate of register r for a tile whose rows have norm term `xterm` (cosine: |x|; L2: 0.4999 |x|^2)
+    auto reg_gate = [&](auto rc, float xterm) -> float {
+        constexpr int r = decltype(rc)::value;
+        return COS ? fmaf(gate[r], xterm, -1e-30f) : (L2M ? gate[r] + xterm : gate[r]);
+    };
     // distance of ONE accumulator register: acc_r = <query qi(r,h), row x>   (dot / cosine)
     auto reg_distance = [&](auto rc, float acc_r, float xnorm) -> float {
         constexpr int r = decltype(rc)::value;
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         bool pass;
         if (L2M) {
             // the gate again (per lane this time); the distance itself comes from exact_l2 below
-            pass = (row < a.n_rows) && !(acc_r < fmaf(xnorm * xnorm, 0.4999f, gate[r]));
+            pass = (row < a.n_rows) && (acc_r >= gate[r] + xnorm * xnorm * 0.4999f);
         } else {
             d = reg_distance(rc, acc_r, xnorm);
             pass = (row < a.n_rows) && (d <= thr_reg[r]) && (d < INFINITY);
@@ -306,8 +315,25 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
     for (int r = 0; r < 16; ++r) acc_prev[r] = -INFINITY;     // "no previous tile": nothing passes a gate
     float xnorm_prev = 0.0f;
     long long row_prev = a.n_rows;
+    // B operand pipeline: ds_read_b128 issued from inline asm BP steps (= 4*BP MFMAs) ahead of its use into a ring
+    // of BP register quads, with an exact "s_waitcnt lgkmcnt(n)" in front of the consumer.  Left to the compiler
+    // the dot variant re-used ONE register quad: read, lgkmcnt(0), 4 MFMAs, read ... - an exposed LDS round trip
+    // every 4-8 MFMAs with a single wavefront per SIMD and nothing else to issue (22% of the matrix pipe idle).
+    // (Tried and measured slower: issuing the first reads of tile t+1 before the score copy-out of tile t, and
+    // alternating two accumulator sets so that nothing drains at the tile boundary - the compiler shuffles the sets.)
+    constexpr int BP = VGB_BPIPE < NT ? VGB_BPIPE : NT;
+    vgb_f32x4 bq[BP];
+    auto ring_prologue = [&](int buf) {
+        const float *brow_n = (buf ? tile1 : tile0) + x * PITCH + 4 * h;
+        const uint32_t baddr_n = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)brow_n;
+        vgb_static_for<0, BP>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            vgb_lds_read128<32 * t>(bq[t], baddr_n);
+        });
+    };
     for (long long tile = tile_first; tile < tile_last; ++tile) {
         const int cur_buf = (int)((tile - tile_first) & 1);
+        ring_prologue(cur_buf);
         const float *cur = cur_buf ? tile1 : tile0;
         const uint32_t tile_next = (uint32_t)min(tile + 1, tile_last - 1);   // the last iteration re-fetches its own tile: harmless
 
@@ -325,19 +351,10 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
             xnorm_cur = a.xnorm[rr < a.n_rows ? rr : a.n_rows - 1];
         }
         unsigned pend = 0;
+        float margin = -INFINITY;
         const float cos_slack = COS ? xnorm_prev : (L2M ? xnorm_prev * xnorm_prev * 0.4999f : 0.0f);
         const float *brow = cur + x * PITCH + 4 * h;
-        // B operand pipeline: ds_read_b128 issued from inline asm BP steps (= 4*BP MFMAs) ahead of its use into a ring
-        // of BP register quads, with an exact "s_waitcnt lgkmcnt(n)" in front of the consumer.  Left to the compiler
-        // the dot variant re-used ONE register quad: read, lgkmcnt(0), 4 MFMAs, read ... - an exposed LDS round trip
-        // every 4-8 MFMAs with a single wavefront per SIMD and nothing else to issue (22% of the matrix pipe idle).
-        constexpr int BP = VGB_BPIPE < NT ? VGB_BPIPE : NT;
         const uint32_t baddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)brow;
-        vgb_f32x4 bq[BP];
-        vgb_static_for<0, BP>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            vgb_lds_read128<32 * t>(bq[t], baddr);
-        });
         // compile-time unrolled k loop (a template recursion: the plain "#pragma unroll" gave up on a body this large
         // and put areg[] in scratch memory)
         vgb_static_for<0, NT>([&](auto tc) {
@@ -366,16 +383,21 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
             constexpr int r_lo = (t * 16 + NT - 1) / NT, r_hi = ((t + 1) * 16 + NT - 1) / NT;
             vgb_static_for<r_lo, r_hi>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                if (!(VGB_ABLATE & 1)) {
-                    // cosine: gate*|x| with a slack that covers the rounding of the product and of the division
-                    const float g = COS ? fmaf(gate[r], cos_slack, -1e-30f) : (L2M ? gate[r] + cos_slack : gate[r]);
-                    // negated '<' so that a NaN gate (zero-norm query / row: 0 * Inf) or a NaN score falls through to
-                    // the exact test instead of being silently dropped
-                    pend |= __ballot(!(acc_prev[r] < g)) ? (1u << r) : 0u;
-                }
+                // VALU only, no scalar work in the loop: margin = score - gate, max-reduced over the 16 registers; ONE
+                // ballot after the loop decides whether anything needs the slow path.  A NaN margin (NaN score = NaN
+                // distance, never a result) is ignored by the max.
+                if (!(VGB_ABLATE & 1)) margin = fmaxf(margin, acc_prev[r] - reg_gate(rc, cos_slack));
             });
         });
+        if (__ballot(margin >= 0.0f)) {
+            // which registers: the same test per register (rare path)
+            vgb_static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                pend |= __ballot(acc_prev[r] >= reg_gate(rc, cos_slack)) ? (1u << r) : 0u;
+            });
+        }
         if (VGB_ABLATE & 8) { asm volatile("" ::"s"(pend)); pend = 0; }          // probe: gates computed, never acted on
+        if (VGB_ABLATE & 64) pend &= (unsigned)(k >> 10);                          // probe: slow path compiled in, never run
         if (VGB_ABLATE & 16) {                                                     // probe: accumulators copied out, unused
 #pragma unroll
             for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc_prev[r]));
@@ -385,7 +407,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
             if (blockIdx.x == 0 && wave == 0 && tile == tile_first + 5000) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (!(acc_prev[r] < gate[r])) printf("tile+5000 lane %d r %d acc %.9g gate %.9g thr %.9g\n", lane, r, acc_prev[r], gate[r], thr_reg[r]);
+                    if (acc_prev[r] >= gate[r]) printf("tile+5000 lane %d r %d acc %.9g gate %.9g thr %.9g\n", lane, r, acc_prev[r], gate[r], thr_reg[r]);
             }
         }
         if (pend) {
