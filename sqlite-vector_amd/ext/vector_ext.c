@@ -175,11 +175,13 @@ typedef struct {
     vg_shards *full;            /* raw vectors for vector_full_scan[_stream] */
     int64_t full_data_version;  /* staleness stamps: PRAGMA data_version + sqlite3_total_changes() */
     int64_t full_changes;
+    int full_in_txn;            /* staged inside an open transaction: a ROLLBACK leaves both stamps unchanged */
     int full_validated;         /* set when stage_full() (re)validated `full` during the current vector_quantize call */
     vg_shards *quant;           /* quantized vectors for vector_quantize_scan[_stream] */
     int quant_preloaded;        /* explicit vector_quantize_preload() (kept until cleanup / re-quantize) */
     int64_t quant_data_version;
     int64_t quant_changes;
+    int quant_in_txn;
 } table_ctx;
 
 typedef struct {
@@ -632,7 +634,9 @@ static void db_stamps(sqlite3 *db, int64_t *data_version, int64_t *changes) {
 static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
     int64_t dv, ch;
     db_stamps(db, &dv, &ch);
-    if (t->full && t->full_data_version == dv && t->full_changes == ch) return SQLITE_OK;
+    /* rows staged inside an open transaction may be rolled back without either stamp moving (total_changes never
+     * decreases): such a copy is good for one scan only - which is what the reference does for every scan anyway */
+    if (t->full && !t->full_in_txn && t->full_data_version == dv && t->full_changes == ch) return SQLITE_OK;
     if (!gpu_load()) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
     const int es = elem_size(t->opt.v_type), dim = t->opt.v_dim;
     const int64_t row_bytes = (int64_t)es * dim;
@@ -680,7 +684,7 @@ static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
     sqlite3_free(stage);
     sqlite3_free(ids);
     sqlite3_finalize(st);
-    if (rc == SQLITE_OK) { t->full_data_version = dv; t->full_changes = ch; }
+    if (rc == SQLITE_OK) { t->full_data_version = dv; t->full_changes = ch; t->full_in_txn = !sqlite3_get_autocommit(db); }
     else { G.corpus_destroy(t->full); t->full = NULL; }
     return rc;
 }
@@ -690,7 +694,7 @@ static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
 static int stage_quant(sqlite3 *db, table_ctx *t, int force, char **err) {
     int64_t dv, ch;
     db_stamps(db, &dv, &ch);
-    if (!force && t->quant && t->quant_data_version == dv && t->quant_changes == ch) return SQLITE_OK;
+    if (!force && t->quant && !t->quant_in_txn && t->quant_data_version == dv && t->quant_changes == ch) return SQLITE_OK;
     if (!gpu_load()) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
     const int vt = (t->opt.q_type == VG_QUANT_U8) ? VG_TYPE_U8 : VG_TYPE_I8;
     if (t->quant) { G.corpus_destroy(t->quant); t->quant = NULL; }
@@ -711,7 +715,7 @@ static int stage_quant(sqlite3 *db, table_ctx *t, int force, char **err) {
     }
     sqlite3_finalize(st);
     if (rc == SQLITE_DONE) rc = SQLITE_OK;
-    if (rc == SQLITE_OK) { t->quant_data_version = dv; t->quant_changes = ch; }
+    if (rc == SQLITE_OK) { t->quant_data_version = dv; t->quant_changes = ch; t->quant_in_txn = !sqlite3_get_autocommit(db); }
     else { G.corpus_destroy(t->quant); t->quant = NULL; }
     return rc;
 }
@@ -978,7 +982,10 @@ static void quantize_common(sqlite3_context *ctx, const char *tbl, const char *c
     }
     int was_preloaded = t->quant_preloaded;
     if (t->quant) { G.corpus_destroy(t->quant); t->quant = NULL; }   /* HBM copy is stale now */
-    if (t->full && stamps_were_fresh) db_stamps(db, &t->full_data_version, &t->full_changes);   /* only our own shadow-table writes happened */
+    if (t->full && stamps_were_fresh) {       /* only our own shadow-table writes happened, and they are committed */
+        db_stamps(db, &t->full_data_version, &t->full_changes);
+        t->full_in_txn = 0;
+    }
     sqlite3_result_int64(ctx, (sqlite3_int64)counter);
     if (was_preloaded) do_preload(ctx, tbl, col);
 }

@@ -374,3 +374,48 @@ def test_extension_over_several_shards_matches_golden(ext_path, case, monkeypatc
     ga = db.execute("SELECT rowid, distance FROM vector_quantize_scan('t','v',?,?)", (q.tobytes(), k)).fetchall()
     gb = db1.execute("SELECT rowid, distance FROM vector_quantize_scan('t','v',?,?)", (q.tobytes(), k)).fetchall()
     assert ga == gb
+
+
+@pytest.mark.gpu
+def test_staged_copy_follows_rollbacks_and_other_connections(ext_path, tmp_path):
+    """The HBM copy must always equal what "SELECT pk, col FROM tbl" returns NOW (the reference re-reads the table on
+    every scan): rows of a rolled-back transaction disappear again (neither PRAGMA data_version nor
+    sqlite3_total_changes() moves on ROLLBACK), and another connection's commit is seen."""
+    dim, n = 16, 300
+    rows = dg.corpus(dg.F32, n, dim, 41)
+    q = dg.query(dg.F32, dim, 42)
+    path = str(tmp_path / "shared.db")
+
+    def open_db():
+        db = sqlite3.connect(path, isolation_level=None)
+        db.enable_load_extension(True)
+        db.load_extension(ext_path)
+        return db
+
+    a = open_db()
+    load_table(a, rows, dg.F32, dg.L2)
+    sql = "SELECT rowid FROM vector_full_scan('t','v',?,3)"
+    base = [r[0] for r in a.execute(sql, (q.tobytes(),)).fetchall()]
+    # an exact copy of the query inside a transaction is the nearest row ... until the transaction is rolled back
+    a.execute("BEGIN")
+    a.execute("INSERT INTO t(id, v) VALUES (100001, ?)", (q.tobytes(),))
+    assert a.execute(sql, (q.tobytes(),)).fetchall()[0][0] == 100001
+    a.execute("ROLLBACK")
+    assert [r[0] for r in a.execute(sql, (q.tobytes(),)).fetchall()] == base
+    # savepoints roll back without leaving the transaction
+    a.execute("BEGIN")
+    a.execute("SAVEPOINT s1")
+    a.execute("INSERT INTO t(id, v) VALUES (100002, ?)", (q.tobytes(),))
+    assert a.execute(sql, (q.tobytes(),)).fetchall()[0][0] == 100002
+    a.execute("ROLLBACK TO s1")
+    assert [r[0] for r in a.execute(sql, (q.tobytes(),)).fetchall()] == base
+    a.execute("COMMIT")
+    assert [r[0] for r in a.execute(sql, (q.tobytes(),)).fetchall()] == base
+    # a second connection commits a closer row: connection A's next scan returns it
+    b = open_db()
+    b.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2')" % dim)
+    b.execute("INSERT INTO t(id, v) VALUES (100003, ?)", (q.tobytes(),))
+    assert a.execute(sql, (q.tobytes(),)).fetchall()[0][0] == 100003
+    b.execute("DELETE FROM t WHERE id = 100003")
+    assert [r[0] for r in a.execute(sql, (q.tobytes(),)).fetchall()] == base
+    a.close(); b.close()
