@@ -582,3 +582,25 @@ def test_batch_l2_near_duplicates_keep_the_relative_bar(pkg, orc, metric):
         _assert_topk_close(ids[i][:cnt[i]], dist[i][:cnt[i]], want, k, tol)
         assert dist[i][0] <= 1e-3 * float(np.sqrt(dim))                  # the planted rows are what was found
     c.close()
+
+
+def test_maximum_row_size_and_the_limit_beyond_it(pkg, orc):
+    """the largest supported row is 128 KiB (the query must fit the CU's LDS next to the merge scratch): f32 dim
+    32768 and u8 dim 131072 scan correctly; one element more is refused with a message, not a crash."""
+    for vt, dim, metric in ((dg.F32, 32768, dg.L2), (dg.U8, 131072, dg.COSINE), (dg.BF16, 65536, dg.DOT)):
+        rows = dg.corpus(vt, 70, dim, 5)
+        q = dg.query(vt, dim, 6)
+        c = pkg.Corpus(vt, dim)
+        c.append(rows)
+        got = c.scan_distances(metric, q)
+        want = orc.scan_distances(orc.AVX2, metric, vt, q, rows)
+        if vt == dg.U8:
+            assert dg.same_float_bits(got, want)
+        else:
+            _check_float_distances(got, want, vt, metric, q, rows)
+        ids, dist = c.scan_topk(metric, q, 5)
+        order = np.lexsort((np.arange(70), got))[:5]
+        assert ids.tolist() == (order + 1).tolist()
+        c.close()
+    with pytest.raises(pkg.VectorGpuError, match="128 KiB"):
+        pkg.Corpus(pkg.F32, 32769)
