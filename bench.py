@@ -360,7 +360,8 @@ def main():
             "p50_query_latency_ms": float(np.median(lat) * 1e3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if vt == pkg.F32 else "u8", "data": "synthetic",
-            "config": {"workload": desc, "rows_per_gpu": n_rows, "dim": dim, "k": k,
+            "config": {"workload": desc if n_rows == 10_000_000 else desc.replace("10M", "%gM" % (n_rows / 1e6)),
+                       "rows_per_gpu": n_rows, "dim": dim, "k": k,
                        "sharding": "row-range shard per GPU, RCCL all_gather of 64 candidate keys per rank" if n_gpus > 1 else "single shard",
                        "backend": pkg.backend_name()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
