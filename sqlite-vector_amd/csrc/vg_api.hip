@@ -116,8 +116,9 @@ struct vg_corpus {
     hipEvent_t append_ev = nullptr;            // recorded behind the last enqueued host append (other streams wait on it)
     bool append_pending = false;
     bool enqueued = false;                     // a vg_scan_topk_enqueue is in flight (vg_scan_topk_collect pending)
-    float *d_xnorm = nullptr;                  // f32 corpora, lazily: ||row|| for rows [0, xnorm_rows) (batched cosine)
+    float *d_xnorm = nullptr;                  // lazily: row norms for rows [0, xnorm_rows) (see ensure_row_norms)
     int64_t xnorm_rows = 0, xnorm_cap = 0;
+    hipEvent_t norm_ev = nullptr;              // orders a caller-stream scan behind a norm pass on the corpus stream
     void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
     uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;
     size_t bq_bytes = 0, bcand_bytes = 0, bkeys_bytes = 0;
@@ -205,6 +206,7 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_stage) hipFree(c->d_stage);
     if (c->d_bq) hipFree(c->d_bq);
     if (c->d_xnorm) hipFree(c->d_xnorm);
+    if (c->norm_ev) hipEventDestroy(c->norm_ev);
     if (c->d_bcand) hipFree(c->d_bcand);
     if (c->d_bkeys) hipFree(c->d_bkeys);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
@@ -473,6 +475,9 @@ static scan_fn_t pick_acc(int acc, int U) {
         case A_COS: return pick_u<VT, A_COS, NT>(U);
         case A_DOT: return pick_u<VT, A_DOT, NT>(U);
         case A_L1: return pick_u<VT, A_L1, NT>(U);
+        case A_COSN:
+            if constexpr (VT == T_F16 || VT == T_BF16) return pick_u<VT, A_COSN, NT>(U);
+            return nullptr;
     }
     return nullptr;
 }
@@ -540,7 +545,7 @@ static const char *type_tag(int t) {
     return "?";
 }
 static const char *acc_tag(int a) {
-    switch (a) { case A_L2: return "l2"; case A_COS: return "cos"; case A_DOT: return "dot"; case A_L1: return "l1"; }
+    switch (a) { case A_L2: return "l2"; case A_COS: return "cos"; case A_DOT: return "dot"; case A_L1: return "l1"; case A_COSN: return "cosn"; }
     return "?";
 }
 
@@ -549,10 +554,13 @@ extern "C" const char *vg_scan_kernel_name(vg_corpus *c, int metric) {
     Shape s;
     int acc = metric_to_acc(metric);
     if (acc < 0 || !choose_shape(c->nch, c->es, &s)) return "";
+    if (acc == A_COS && (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) && !s.long_rows && env_int("VG_HALF_COSN", 1)) acc = A_COSN;
     snprintf(c->kernel_name, sizeof(c->kernel_name), "scan%s_%s_%s_u%d_lpr%d%s", s.long_rows ? "_long" : "",
              type_tag(c->vtype), acc_tag(acc), s.U, 1 << s.lpr_log2, use_nt_loads(c) ? "_nt" : "");
     return c->kernel_name;
 }
+
+static int ensure_row_norms(vg_corpus *c);
 
 // Launch the scan (+ merge in top-k mode) on `stream`.  dev_query holds nch*16 zero-padded bytes.
 static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys,
@@ -561,6 +569,18 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     if (acc < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
     Shape s;
     choose_shape(c->nch, c->es, &s);
+    // f16 / bf16 cosine: the row norms come from a cached vector (computed once per appended row) instead of being
+    // re-accumulated in f64 on every scan - the f64 chain is what bounds these kernels, not HBM
+    if (acc == A_COS && (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) && !s.long_rows && env_int("VG_HALF_COSN", 1)) {
+        int rcn = ensure_row_norms(c);
+        if (rcn != VG_OK) return rcn;
+        acc = A_COSN;
+        if (stream != c->stream) {                       // the norm pass ran on the corpus stream
+            if (!c->norm_ev) HIP_TRY(hipEventCreateWithFlags(&c->norm_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(c->norm_ev, c->stream));
+            HIP_TRY(hipStreamWaitEvent(stream, c->norm_ev, 0));
+        }
+    }
     scan_fn_t fn = pick_kernel(c->vtype, acc, s, use_nt_loads(c));
     if (!fn) return vg_fail(VG_ERR_UNSUPPORTED, "no scan kernel for type %s", type_tag(c->vtype));
 
@@ -584,6 +604,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     a.k = k;
     a.root = (metric == VG_DIST_L2) ? 1 : 0;
     a.dim = c->dim;
+    a.row_nn = (acc == A_COSN) ? c->d_xnorm : nullptr;
     size_t qbytes = (size_t)c->nch * 16;
     if (s.long_rows) {
         const size_t slice = (size_t)VG_WAVE * VG_LONG_U;               // the long kernel pads the query to whole slices
@@ -810,7 +831,8 @@ extern "C" int vg_batch_lists_per_query(long long n_rows, int npart);
 extern "C" int vg_rownorm_launch(const float *dev_rows, long long row0, long long n, long long stride_bytes, float *dev_out,
                                  hipStream_t stream);
 
-// cosine batches need ||row|| for every row: computed once per appended row and kept next to the corpus
+// Row norms, computed once per appended row and kept next to the corpus.  f32 corpora: ||row|| (batched cosine / L2);
+// f16 / bf16 corpora: (float) sum x^2 (single-query cosine, A_COSN).
 static int ensure_row_norms(vg_corpus *c) {
     if (c->xnorm_cap < c->n_rows) {
         float *nb = nullptr;
@@ -823,7 +845,20 @@ static int ensure_row_norms(vg_corpus *c) {
         c->xnorm_cap = cap;
     }
     if (c->xnorm_rows < c->n_rows) {
-        int rc = vg_rownorm_launch((const float *)c->d_rows, c->xnorm_rows, c->n_rows - c->xnorm_rows, c->stride, c->d_xnorm, c->stream);
+        const long long n = c->n_rows - c->xnorm_rows;
+        int rc = 0;
+        if (c->vtype == VG_TYPE_F32) {
+            rc = vg_rownorm_launch((const float *)c->d_rows, c->xnorm_rows, n, c->stride, c->d_xnorm, c->stream);
+        } else {                                   // f16 / bf16: (float) sum x^2, vg_half_rownorm_kernel (vg_scan.h)
+            long long blocks = std::min<long long>((n * 16 + 255) / 256, 256 * 32);
+            if (c->vtype == VG_TYPE_F16)
+                hipLaunchKernelGGL((vg_half_rownorm_kernel<T_F16>), dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_rows,
+                                   (long long)c->xnorm_rows, n, (long long)c->stride, c->nch, c->d_xnorm);
+            else
+                hipLaunchKernelGGL((vg_half_rownorm_kernel<T_BF16>), dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_rows,
+                                   (long long)c->xnorm_rows, n, (long long)c->stride, c->nch, c->d_xnorm);
+            rc = (int)hipGetLastError();
+        }
         if (rc != 0) return vg_fail(VG_ERR_HIP, "row-norm pass failed: %s", hipGetErrorString((hipError_t)rc));
         c->xnorm_rows = c->n_rows;
     }

@@ -18,7 +18,7 @@
 enum { T_F32 = 1, T_F16 = 2, T_BF16 = 3, T_U8 = 4, T_I8 = 5 };
 enum { M_L2 = 1, M_SQL2 = 2, M_COS = 3, M_DOT = 4, M_L1 = 5 };
 // accumulation kinds (L2 and squared-L2 share one; the root is an epilogue flag)
-enum { A_L2 = 0, A_COS = 1, A_DOT = 2, A_L1 = 3 };
+enum { A_L2 = 0, A_COS = 1, A_DOT = 2, A_L1 = 3, A_COSN = 4 /* f16/bf16 cosine with the row norms read from a cached vector */ };
 
 struct ScanArgs {
     const uint8_t *rows;       // N x stride bytes, 16-byte-multiple stride, zero padded
@@ -32,6 +32,7 @@ struct ScanArgs {
     int k;                     // <= 64 in top-k mode
     int root;                  // 1: L2 (sqrt), 0: squared L2
     int dim;                   // elements per row (for the special-value slow paths)
+    const float *row_nn;       // A_COSN: (float) sum x^2 per row (vg_half_rownorm_kernel); nullptr otherwise
 };
 
 // ------------------------------------------------------------------------------------------ keys

@@ -76,7 +76,7 @@ template <int VT, int ACC> struct AccumHalf {
             else { s0 += fabs((double)q0 - (double)x0); s1 += fabs((double)q1 - (double)x1); }
         } else {                             // f32 product (exact for finite halves / bf16 unless it over/underflows)
             s0 += (double)(q0 * x0); s1 += (double)(q1 * x1);
-            if (ACC == A_COS) { m0 += (double)(x0 * x0); m1 += (double)(x1 * x1); }
+            if (ACC == A_COS) { m0 += (double)(x0 * x0); m1 += (double)(x1 * x1); }      // A_COSN: cached per row
         }
     }
     __device__ inline void chunk(const uint4 &qv, const uint4 &xv) {
@@ -101,7 +101,7 @@ template <int VT, int ACC> struct AccumHalf {
             }
         }
         s.qspecial = vg_group_or(sp, lpr_log2);
-        if (ACC == A_COS) s.qq = vg_group_sum(t, lpr_log2);
+        if (ACC == A_COS || ACC == A_COSN) s.qq = vg_group_sum(t, lpr_log2);
         return s;
     }
 
@@ -116,9 +116,16 @@ template <int VT, int ACC> struct AccumHalf {
         if (ACC == A_L1) return (float)s;
         if (ACC == A_DOT) return (float)(-s);
         const double nn = vg_group_sum((n0 + n1) + (n2 + n3), lpr_log2);
+        return cosine_epilogue(qs, (float)s, (float)nn);
+    }
+    // A_COSN: the row's (float) sum x^2 comes from the corpus' cached vector (same f64 accumulation, done once per row)
+    __device__ inline float finish_cached_norm(const QStat &qs, int lpr_log2, float nn_row) {
+        const double s = vg_group_sum((a0 + a1) + (a2 + a3), lpr_log2);
+        return cosine_epilogue(qs, (float)s, nn_row);
+    }
+    __device__ static inline float cosine_epilogue(const QStat &qs, float dot, float nnf) {
         // distance-avx2.c:343-364 / :571-582: float epilogue on the three rounded dot products
-        const float dot = (float)s;
-        const float na = sqrtf((float)qs.qq), nb = sqrtf((float)nn);
+        const float na = sqrtf((float)qs.qq), nb = sqrtf(nnf);
         if (!(na > 0.0f) || !(nb > 0.0f) || !isfinite(na) || !isfinite(nb) || !isfinite(dot)) return 1.0f;
         float cs = __fdiv_rn(dot, na * nb);
         if (cs > 1.0f) cs = 1.0f;

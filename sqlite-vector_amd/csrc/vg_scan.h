@@ -92,9 +92,13 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
 
     uint4 cur[U], nxt[U];
     vg_load_batch<U, NT>(cur, a.rows, b * rpb + rib, (b < nbatch) ? a.n_rows : 0, a.stride, sub, lpr, a.nch);
+    // A_COSN: the row's squared norm rides along with the batch prefetch (one dword per row from the cached vector)
+    float nn_cur = 0.0f, nn_nxt = 0.0f;
+    if constexpr (ACC == A_COSN) { const long long r0 = b * rpb + rib; if (b < nbatch && r0 < a.n_rows) nn_cur = a.row_nn[r0]; }
     while (b < nbatch) {
         const long long bn = b + wstride;
         vg_load_batch<U, NT>(nxt, a.rows, bn * rpb + rib, (bn < nbatch) ? a.n_rows : 0, a.stride, sub, lpr, a.nch);
+        if constexpr (ACC == A_COSN) { const long long rn = bn * rpb + rib; nn_nxt = (bn < nbatch && rn < a.n_rows) ? a.row_nn[rn] : 0.0f; }
 
         Accum<VT, ACC> acc;
         acc.init();
@@ -102,11 +106,13 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
         for (int u = 0; u < U; ++u) acc.chunk(q[u], cur[u]);
         const long long row = b * rpb + rib;
         const bool owner = (sub == 0) && (row < a.n_rows);
-        float d = acc.finish(qstat, lpr_log2, a.root);
+        float d;
+        if constexpr (ACC == A_COSN) d = acc.finish_cached_norm(qstat, lpr_log2, nn_cur);
+        else d = acc.finish(qstat, lpr_log2, a.root);
         if constexpr (VT == T_F16 || VT == T_BF16) {
             // rows (or a query) holding Inf/NaN: the owning lane replays the reference algorithm exactly (vg_half.h)
             if (acc.special(qstat, lpr_log2) && owner)
-                d = vg_slow_distance<VT, ACC>(reinterpret_cast<const uint16_t *>(qs),
+                d = vg_slow_distance<VT, (ACC == A_COSN ? A_COS : ACC)>(reinterpret_cast<const uint16_t *>(qs),
                                               reinterpret_cast<const uint16_t *>(a.rows + row * a.stride), a.dim, a.root);
         }
         d = vg_clamp(d);
@@ -118,6 +124,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        nn_cur = nn_nxt;
         b = bn;
     }
     if (store_mode) return;
@@ -223,4 +230,34 @@ __global__ __launch_bounds__(VG_MERGE_THREADS) void vg_merge_kernel(const uint64
                                                                     uint64_t *out_keys) {
     __shared__ __attribute__((aligned(16))) uint8_t scratch[VG_SEL_SCRATCH_BYTES];
     vg_select_lists(cand, nlists, k, out_keys, scratch);
+}
+
+
+// (float) sum x^2 per row of an f16 / bf16 corpus, accumulated exactly like AccumHalf<.., A_COS> does it during a scan
+// (f32 squares - exact for halves - widened to f64, f64 sums, one rounding to float at the end): the cosine scan then
+// only has to accumulate the dot product (A_COSN).  16 lanes per row.  Rows holding Inf/NaN get whatever comes out:
+// the scan sends them to the exact slow path anyway.
+template <int VT>
+__global__ __launch_bounds__(256) void vg_half_rownorm_kernel(const uint8_t *rows, long long row0, long long n, long long stride,
+                                                              int nch, float *out) {
+    const int sub = threadIdx.x & 15;
+    const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long long ngroups = ((long long)gridDim.x * blockDim.x) >> 4;
+    for (long long r = group; r < n; r += ngroups) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(rows + (row0 + r) * stride);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (int c = sub; c < nch; c += 16) {
+            const uint4 v = p[c];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float lo, hi;
+                vg_unpack2<VT>(w[j], lo, hi);
+                if (j & 1) { s2 += (double)(lo * lo); s3 += (double)(hi * hi); }
+                else { s0 += (double)(lo * lo); s1 += (double)(hi * hi); }
+            }
+        }
+        const double s = vg_group_sum((s0 + s1) + (s2 + s3), 4);
+        if (sub == 0) out[row0 + r] = (float)s;
+    }
 }
