@@ -37,7 +37,7 @@ WORKLOADS = {
     "c1": (1, np.float32, 384, 1, "10kx384 f32 L2 top-20 through SQL: SELECT ... FROM vector_full_scan(...)"),
     "c2": (1, np.float32, 384, 1, "10Mx384 f32 L2 top-20 single-query"),
     "c3": (4, np.uint8, 768, 3, "10Mx768 u8 quantized cosine top-20 single-query"),
-    # batched queries on the matrix cores (config #5); a step is one batch of --batch queries; single GPU
+    # batched queries on the matrix cores (config #5); a step is one batch of --batch queries (the same batch on every shard)
     "c5": (1, np.float32, 384, 4, "batched 1024 queries x 10Mx384 f32 dot top-20 (MFMA Q x C^T + fused top-k)"),
 }
 F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
@@ -134,36 +134,66 @@ def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows):
     return out
 
 
-def bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc):
-    """config #5 on one GPU: each step = one batch of queries through vg_scan_topk_batch (host queries in, host
-    (rowid, distance) lists out).  The dominant kernel is MFMA-bound: flops = 2 * Q * N * D per launch."""
+def bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc, dist=None, shard=None, n_gpus=1, rank=0):
+    """config #5: each step = one batch of queries through the batched scan (host queries in, host (position,
+    distance) lists out).  The dominant kernel is MFMA-bound: flops = 2 * Q * N * D per launch.
+    N > 1: every rank scans its own row-range shard with the same batch, ONE all_gather of nq x k keys per rank
+    (160 KB at 1024 x 20), rank 0 merges every query (shard.gather_and_merge_batch) - SURVEY 8e."""
     nq = args.batch
     rng = np.random.default_rng(44)
     steps, warmup = min(args.steps, 10), min(args.warmup, 2)
     batches = [rng.standard_normal((nq, dim), dtype=np.float32) for _ in range(2)]
+    use_dist = dist is not None
+    offsets = [i * n_rows for i in range(n_gpus)]
+    gathered = torch.empty((n_gpus, nq, k), dtype=torch.int64, device="cuda") if use_dist else None
+    last = {}
+
+    def step(i):
+        if not use_dist:
+            last["res"] = corpus.scan_topk_batch(metric, batches[i % 2], k)
+            return
+        keys, _ = corpus.scan_topk_batch_keys(metric, batches[i % 2], k)
+        local = torch.from_numpy(keys.view(np.int64)).cuda()
+        res = shard.gather_and_merge_batch(pkg, dist, local, gathered, offsets, k, dst=0)
+        if res is not None:
+            last["res"] = res
+
     for i in range(warmup):
-        corpus.scan_topk_batch(metric, batches[i % 2], k)
+        step(i)
     corpus.set_profiling(True)
+    if use_dist:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        corpus.scan_topk_batch(metric, batches[i % 2], k)
+        step(i)
+    if use_dist:
+        dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
     n_launch, kern_ms, _ = corpus.profile_mean_ms()
     flops = 2.0 * nq * n_rows * dim
     tf = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-    print(json.dumps({
-        "metric": "vectors scanned/sec (query x vector pairs), batched dot top-20 over Nx384 f32",
-        "value": nq * n_rows * steps / elapsed, "unit": "vectors/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
-        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": desc, "rows_per_gpu": n_rows, "dim": dim, "k": k, "queries_per_batch": nq,
-                   "backend": pkg.backend_name()},
-        "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": tf / F32_MFMA_PEAK_TF, "traffic": None, "kernel": "vg_batch_kernel<%d>" % ((dim + 7) // 8),
-                     "kernel_ms": kern_ms, "launches_timed": n_launch, "flops_per_launch": flops}}))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "vectors scanned/sec (query x vector pairs), batched dot top-20 over Nx384 f32",
+            "value": nq * n_rows * n_gpus * steps / elapsed, "unit": "vectors/s", "n_gpus": n_gpus, "steps": steps,
+            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "rows_per_gpu": n_rows, "dim": dim, "k": k, "queries_per_batch": nq,
+                       "sharding": "row-range shard per GPU, RCCL all_gather of nq x k candidate keys per rank" if n_gpus > 1 else "single shard",
+                       "backend": pkg.backend_name()},
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": tf / F32_MFMA_PEAK_TF, "traffic": None, "kernel": "vg_batch_kernel<%d>" % ((dim + 7) // 8),
+                         "kernel_ms": kern_ms, "launches_timed": n_launch, "flops_per_launch": flops,
+                         "note": "kernel_ms = pre-pass + main pass + merges of one batch on one shard"}}))
     corpus.close()
+    if use_dist:
+        dist.destroy_process_group()
 
 
 def sql_latency(ext_path, rows, queries, k, warmup, steps):
@@ -284,7 +314,8 @@ def main():
     corpus.set_rowid_base(1 + rank * n_rows)
     corpus.set_profiling(True)
     if args.workload == "c5":
-        return bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc)
+        return bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc, dist if use_dist else None, shard,
+                             n_gpus, rank)
 
     # queries: a different one every step, pre-generated on the host
     rng = np.random.default_rng(43)

@@ -103,6 +103,11 @@ uint32_t vg_key_position(uint64_t key);
 int vg_merge_keys(const uint64_t *keys, int n_lists, int list_len, const int64_t *pos_offsets, int k,
                   int64_t *out_global_pos, double *out_dist);
 
+/* the same merge for nq queries at once: keys[list][query][list_len] (an all_gather of every shard's
+ * vg_scan_topk_batch_keys output), out_global_pos / out_dist are nq x k, out_counts nq.  Returns 0, -1 on bad arguments. */
+int vg_merge_keys_batch(const uint64_t *keys, int n_lists, int nq, int list_len, const int64_t *pos_offsets, int k,
+                        int64_t *out_global_pos, double *out_dist, int *out_counts);
+
 /* The host-side scan again, but returning the packed keys (positions, not rowids) - the form a multi-shard caller
  * merges.  vg_scan_topk_keys: any k, out_keys[min(k, rows)], synchronous.  enqueue / collect: the fused path
  * (k <= 64) split in two, so that several corpora (one per device) are all in flight before the first wait;

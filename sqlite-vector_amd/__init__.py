@@ -88,6 +88,7 @@ def lib():
         "vg_shards_scan_distances": (i32, [vp, i32, vp, vp]),
         "vg_shards_minmax": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)]),
         "vg_shards_quantize_rows": (i32, [vp, C.c_float, C.c_float, i32, i64, i64, vp]),
+        "vg_merge_keys_batch": (i32, [vp, i32, i32, i32, vp, i32, vp, vp, vp]),
         "vg_scan_distances": (i32, [vp, i32, vp, vp]),
         "vg_scan_distances_device": (i32, [vp, i32, vp, vp, vp]),
         "vg_corpus_rowid_at": (i64, [vp, i64]),
@@ -193,6 +194,17 @@ class Corpus:
         cnt = np.zeros(nq, dtype=np.int32)
         _check(lib().vg_scan_topk_batch(self.h, metric, _ptr(queries), nq, k, _ptr(ids), _ptr(dist), _ptr(cnt)))
         return ids, dist, cnt
+
+    def scan_topk_batch_keys(self, metric, queries, k):
+        """per-query packed keys (positions local to this corpus): uint64 [nq, k] (VG_KEY_EMPTY padded), counts [nq]"""
+        queries = np.ascontiguousarray(queries)
+        nq = queries.shape[0]
+        keys = np.full((nq, max(k, 1)), KEY_EMPTY, dtype=np.uint64)
+        cnt = np.zeros(nq, dtype=np.int32)
+        _check(lib().vg_scan_topk_batch_keys(self.h, metric, _ptr(queries), nq, k, _ptr(keys), _ptr(cnt)))
+        for i in range(nq):                                    # entries past the count are unspecified: pad them
+            keys[i, cnt[i]:] = KEY_EMPTY
+        return keys, cnt
 
     def minmax(self):
         lo, hi, neg = C.c_float(0), C.c_float(0), C.c_int(0)
@@ -303,6 +315,19 @@ def quantize_query(src_type, src, scale, offset, qtype):
     dst = np.empty(src.shape[0], dtype=np.uint8 if qtype == QUANT_U8 else np.int8)
     _check(lib().vg_quantize_query(src_type, _ptr(src), src.shape[0], scale, offset, qtype, _ptr(dst)))
     return dst
+
+
+def merge_keys_batch(keys, pos_offsets, k):
+    """keys: (n_lists, nq, list_len) uint64 -> (global positions [nq, k], distances [nq, k], counts [nq])."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    n_lists, nq, list_len = keys.shape
+    off = None if pos_offsets is None else np.ascontiguousarray(pos_offsets, dtype=np.int64)
+    pos = np.zeros((nq, max(k, 1)), dtype=np.int64)
+    dist = np.zeros((nq, max(k, 1)), dtype=np.float64)
+    cnt = np.zeros(nq, dtype=np.int32)
+    if lib().vg_merge_keys_batch(_ptr(keys), n_lists, nq, list_len, _ptr(off), k, _ptr(pos), _ptr(dist), _ptr(cnt)) != 0:
+        raise VectorGpuError("vg_merge_keys_batch: bad arguments")
+    return pos, dist, cnt
 
 
 def merge_keys(keys, pos_offsets, k):

@@ -1004,6 +1004,20 @@ extern "C" int vg_merge_keys(const uint64_t *keys, int n_lists, int list_len, co
     return cnt;
 }
 
+// nq queries at once: keys[list][query][list_len] (what an all_gather of every rank's vg_scan_topk_batch_keys output
+// looks like) -> out_global_pos / out_dist [nq][k], out_counts [nq]
+extern "C" int vg_merge_keys_batch(const uint64_t *keys, int n_lists, int nq, int list_len, const int64_t *pos_offsets,
+                                   int k, int64_t *out_global_pos, double *out_dist, int *out_counts) {
+    if (!keys || !out_global_pos || !out_dist || !out_counts || n_lists <= 0 || nq <= 0 || list_len <= 0 || k <= 0) return -1;
+    std::vector<uint64_t> one((size_t)n_lists * list_len);
+    for (int q = 0; q < nq; ++q) {
+        for (int l = 0; l < n_lists; ++l)
+            memcpy(&one[(size_t)l * list_len], keys + ((size_t)l * nq + q) * list_len, (size_t)list_len * sizeof(uint64_t));
+        out_counts[q] = vg_merge_keys(one.data(), n_lists, list_len, pos_offsets, k, out_global_pos + (size_t)q * k, out_dist + (size_t)q * k);
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ query quantizer
 // Host C, once per query.  Same arithmetic as the reference (sqlite-vector.c:495-757): s = (v - offset) * scale,
 // round half away from zero, clamp; f32 sources use the unguarded int conversion (:524-538), the other source

@@ -36,3 +36,18 @@ def gather_and_merge(pkg, dist, local_keys, gathered, offsets, k, dst=0, host_bu
     else:
         keys = gathered.cpu().numpy()
     return pkg.merge_keys(keys.view(np.uint64), offsets, k)
+
+
+def gather_and_merge_batch(pkg, dist, local_keys, gathered, offsets, k, dst=0):
+    """The same exchange for a batch of queries (config C5 sharded by rows).
+
+    local_keys : int64 tensor [nq, k] on this rank's device - vg_scan_topk_batch_keys of this shard, EMPTY padded
+    gathered   : int64 tensor [world, nq, k] on the same device
+    One all_gather_into_tensor of nq * k * 8 bytes per rank (160 KB at 1024 x 20); rank `dst` merges every query by
+    (distance, shard, position).  Returns (global_positions [nq, k], distances [nq, k], counts [nq]) on `dst`.
+    """
+    dist.all_gather_into_tensor(gathered.view(-1), local_keys.reshape(-1))
+    if dist.get_rank() != dst:
+        return None
+    keys = gathered.cpu().numpy().view(np.uint64)
+    return pkg.merge_keys_batch(keys, offsets, k)
