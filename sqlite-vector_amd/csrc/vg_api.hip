@@ -106,6 +106,7 @@ struct vg_corpus {
     int64_t d_dist_cap = 0;
     uint64_t *d_sel_keys = nullptr, *d_sel_sorted = nullptr;   // k > 64 path: N keys, unsorted / sorted
     void *d_sel_temp = nullptr;
+    uint32_t *d_sel_state = nullptr;   // radix-select state + histogram (vg_select.hip)
     size_t sel_temp_bytes = 0;
     int64_t sel_cap = 0;
     uint8_t *pin[2] = {nullptr, nullptr};      // staging pipeline: pinned bounce buffers + their completion events
@@ -206,6 +207,7 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_stage) hipFree(c->d_stage);
     if (c->d_bq) hipFree(c->d_bq);
     if (c->d_xnorm) hipFree(c->d_xnorm);
+    if (c->d_sel_state) hipFree(c->d_sel_state);
     if (c->norm_ev) hipEventDestroy(c->norm_ev);
     if (c->d_bcand) hipFree(c->d_bcand);
     if (c->d_bkeys) hipFree(c->d_bkeys);
@@ -611,6 +613,11 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
         qbytes = ((c->nch + slice - 1) / slice) * slice * 16;
     }
     size_t smem = std::max<size_t>(qbytes, (size_t)VG_PUBLISH_LDS_BYTES);
+    a.store_lds_off = 0;
+    if (dev_out_dist && !s.long_rows) {             // store mode: a staging area per wavefront behind the query
+        a.store_lds_off = (int)((qbytes + 255) / 256 * 256);
+        smem = std::max<size_t>(smem, (size_t)a.store_lds_off + (size_t)VG_WAVES_PER_BLOCK * VG_STORE_FLOATS * sizeof(float));
+    }
 
     // host appends are only enqueued on the corpus stream: a scan on ANOTHER stream must wait for them
     if (c->append_pending && stream != c->stream) HIP_TRY(hipStreamWaitEvent(stream, c->append_ev, 0));
@@ -715,6 +722,10 @@ extern "C" int vg_select_temp_bytes(long long n, size_t *bytes);
 extern "C" int vg_select_sorted_keys(const float *dist, long long n, uint64_t *keys_tmp, uint64_t *keys_sorted,
                                      void *temp, size_t temp_bytes, hipStream_t stream);
 
+extern "C" int vg_select_topk_keys(const float *dist, long long n, uint32_t k, uint64_t *keys_tmp, uint64_t *keys_sorted,
+                                   uint32_t cap, void *temp, size_t temp_bytes, uint32_t *state, hipStream_t stream,
+                                   uint32_t *out_count);
+
 static int scan_topk_large_k(vg_corpus *c, int metric, const void *query, int k, uint64_t *out_keys, int *out_count) {
     int rc = ensure_dist_buffer(c);
     if (rc != VG_OK) return rc;
@@ -733,10 +744,21 @@ static int scan_topk_large_k(vg_corpus *c, int metric, const void *query, int k,
     HIP_TRY(hipMemcpyAsync(c->d_query, c->h_query, (size_t)c->stride, hipMemcpyHostToDevice, c->stream));
     rc = launch_scan(c, metric, c->d_query, 0, nullptr, c->d_dist, c->stream);
     if (rc != VG_OK) return rc;
-    if (vg_select_sorted_keys(c->d_dist, c->n_rows, c->d_sel_keys, c->d_sel_sorted, c->d_sel_temp, c->sel_temp_bytes, c->stream) != 0)
+    size_t take = (size_t)std::min<int64_t>((int64_t)k, c->n_rows);
+    // radix select (three histogram passes + gather + a sort of ~k keys); the full N-key sort only when the k-th
+    // distance has so many ties that the gathered set would not fit
+    int sel = 1;
+    if (env_int("VG_RADIX_SELECT", 1)) {
+        if (!c->d_sel_state) HIP_TRY(hipMalloc(&c->d_sel_state, (4 + 2048) * sizeof(uint32_t)));
+        uint32_t got = 0;
+        sel = vg_select_topk_keys(c->d_dist, c->n_rows, (uint32_t)take, c->d_sel_keys, c->d_sel_sorted, (uint32_t)std::min<int64_t>(c->sel_cap, 0xFFFFFFFFll),
+                                  c->d_sel_temp, c->sel_temp_bytes, c->d_sel_state, c->stream, &got);
+        if (sel > 1) return vg_fail(VG_ERR_HIP, "device radix select failed: %s", hipGetErrorString((hipError_t)sel));
+        if (sel == 0) take = got;
+    }
+    if (sel != 0 && vg_select_sorted_keys(c->d_dist, c->n_rows, c->d_sel_keys, c->d_sel_sorted, c->d_sel_temp, c->sel_temp_bytes, c->stream) != 0)
         return vg_fail(VG_ERR_HIP, "device key sort failed: %s", hipGetErrorString(hipGetLastError()));
-    const size_t take = (size_t)std::min<int64_t>((int64_t)k, c->n_rows);
-    HIP_TRY(hipMemcpyAsync(out_keys, c->d_sel_sorted, take * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    if (take) HIP_TRY(hipMemcpyAsync(out_keys, c->d_sel_sorted, take * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     collect_timing(c);
     int cnt = 0;

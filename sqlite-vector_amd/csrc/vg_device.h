@@ -33,6 +33,7 @@ struct ScanArgs {
     int root;                  // 1: L2 (sqrt), 0: squared L2
     int dim;                   // elements per row (for the special-value slow paths)
     const float *row_nn;       // A_COSN: (float) sum x^2 per row (vg_half_rownorm_kernel); nullptr otherwise
+    int store_lds_off;         // store mode: byte offset in dynamic LDS of the per-wavefront staging areas
 };
 
 // ------------------------------------------------------------------------------------------ keys

@@ -604,3 +604,34 @@ def test_maximum_row_size_and_the_limit_beyond_it(pkg, orc):
         c.close()
     with pytest.raises(pkg.VectorGpuError, match="128 KiB"):
         pkg.Corpus(pkg.F32, 32769)
+
+
+def test_large_k_radix_select_equals_full_sort_and_oracle(pkg, orc, monkeypatch):
+    """k > 64: radix select (3 histogram passes + gather + small sort) must return exactly what the full device sort
+    and the oracle's ordered top-k return - with NaN / +-Inf distances, negative distances (dot), massive ties
+    (every distance equal) and k beyond the number of finite rows."""
+    dim, n = 32, 50_000
+    rows = dg.corpus(dg.F32, n, dim, 81)
+    rows[100:140, 3] = np.nan
+    rows[200:230, 5] = np.inf
+    rows[300:310, 7] = -np.inf
+    q = dg.query(dg.F32, dim, 82)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    for metric in (dg.L2, dg.DOT):
+        alld = c.scan_distances(metric, q)
+        for k in (65, 100, 1000, 20_000, n):
+            oids, odist, _ = orc.topk_ordered(alld, None, k)
+            monkeypatch.setenv("VG_RADIX_SELECT", "1")
+            ids, dist = c.scan_topk(metric, q, k)
+            monkeypatch.setenv("VG_RADIX_SELECT", "0")
+            ids0, dist0 = c.scan_topk(metric, q, k)
+            assert ids.tolist() == ids0.tolist() == oids.tolist() and np.array_equal(dist, dist0) and np.array_equal(dist, odist), (metric, k)
+    c.close()
+    monkeypatch.setenv("VG_RADIX_SELECT", "1")
+    same = np.tile(dg.corpus(dg.U8, 1, 16, 83), (30_000, 1))            # every row identical: one giant tie class
+    c = pkg.Corpus(pkg.U8, 16)
+    c.append(same)
+    ids, dist = c.scan_topk(dg.L2, dg.query(dg.U8, 16, 84), 500)
+    assert ids.tolist() == list(range(1, 501)) and len(set(dist.tolist())) == 1
+    c.close()
