@@ -92,7 +92,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
     // one burst of 16-byte-per-lane stores.  Stores share the load counter (vmcnt) and retire out of order with
     // loads, so the wait for the prefetched batch that follows a store drains EVERYTHING, prefetch included: with a
     // store every batch - or even every 16 batches - the kernel ran 10% slower than the top-k mode.  One burst per
-    // 1024 rows makes that drain rare (measured: 2.46 -> 2.24 ms at 10M x 384).
+    // 1024 rows makes that drain rare (measured: 2.46 -> 2.27 ms at 10M x 384; top-k mode 2.24).
     const long long nbatch = (a.n_rows + rpb - 1) / rpb;
     const long long nwaves = (long long)gridDim.x * VG_WAVES_PER_BLOCK;
     const long long gw = (long long)blockIdx.x * VG_WAVES_PER_BLOCK + wave;
