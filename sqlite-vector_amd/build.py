@@ -84,7 +84,7 @@ def build_extension(force=False, verbose=False):
             return VEC            # prebuilt artefact travelled here (GPU box): keep it
         raise RuntimeError("sqlite3ext.h not found: cannot build the SQLite extension host")
     cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-missing-field-initializers",
-           "-I" + inc, "-I" + os.path.join(ROOT, "include"), "-o", VEC, src, "-ldl", "-lm"]
+           "-I" + inc, "-I" + os.path.join(ROOT, "include"), "-o", VEC, src, "-ldl", "-lm", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

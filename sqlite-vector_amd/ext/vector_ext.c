@@ -27,6 +27,7 @@ SQLITE_EXTENSION_INIT1
 #include <float.h>
 #include <limits.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -49,6 +50,7 @@ enum { COL_TBL = 0, COL_VECTOR = 1, COL_K = 2, COL_MEMIDX = 3, COL_ID = 4, COL_D
 
 typedef struct {
     void *handle;
+    int ready;                  /* every symbol below is bound */
     int (*device_count)(void);
     const char *(*backend_name)(void);
     const char *(*last_error)(void);
@@ -77,15 +79,26 @@ static void *gpu_sym(const char *name) {
     return p;
 }
 
+static pthread_mutex_t gpu_load_lock = PTHREAD_MUTEX_INITIALIZER;
+static int gpu_load_locked(void);
+
+/* several connections (threads) may load the extension at once: the process-wide table is filled under a lock */
 static int gpu_load(void) {
-    if (G.handle) return 1;
+    pthread_mutex_lock(&gpu_load_lock);
+    int ok = gpu_load_locked();
+    pthread_mutex_unlock(&gpu_load_lock);
+    return ok;
+}
+
+static int gpu_load_locked(void) {
+    if (G.ready) return 1;
     if (G.load_error[0]) return 0;
     char path[PATH_MAX + 32];
     const char *env = getenv("VECTORGPU_LIB");
     Dl_info info;
     if (env && *env) {
         snprintf(path, sizeof(path), "%s", env);
-    } else if (dladdr((void *)&gpu_load, &info) && info.dli_fname) {
+    } else if (dladdr((void *)&gpu_load_locked, &info) && info.dli_fname) {
         snprintf(path, sizeof(path), "%s", info.dli_fname);
         char *slash = strrchr(path, '/');
         if (slash) slash[1] = 0; else path[0] = 0;
@@ -116,6 +129,7 @@ static int gpu_load(void) {
     G.corpus_minmax = (int (*)(vg_shards *, float *, float *, int *))gpu_sym("vg_shards_minmax");
     G.corpus_quantize_rows = (int (*)(vg_shards *, float, float, int, int64_t, int64_t, uint8_t *))gpu_sym("vg_shards_quantize_rows");
     if (G.load_error[0]) { dlclose(G.handle); G.handle = NULL; return 0; }
+    G.ready = 1;
     return 1;
 }
 

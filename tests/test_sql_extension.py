@@ -419,3 +419,45 @@ def test_staged_copy_follows_rollbacks_and_other_connections(ext_path, tmp_path)
     b.execute("DELETE FROM t WHERE id = 100003")
     assert [r[0] for r in a.execute(sql, (q.tobytes(),)).fetchall()] == base
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_concurrent_connections_from_threads(ext_path, orc):
+    """one connection per thread (SQLite's multi-thread mode), all scanning at once: every connection owns its
+    context, corpora and HIP stream; results must equal the single-threaded ones."""
+    import threading
+    dim, n, k, nthreads, reps = 64, 4000, 10, 6, 30
+    data = []
+    for t in range(nthreads):
+        rows = dg.corpus(dg.F32, n, dim, 300 + t)
+        qs = [dg.query(dg.F32, dim, 400 + 10 * t + i) for i in range(4)]
+        want = []
+        for q in qs:
+            d = orc.scan_distances(orc.AVX2, dg.L2, dg.F32, q, rows)
+            want.append(orc.topk_ordered(d, None, k)[0].tolist())
+        data.append((rows, qs, want))
+    errors = []
+
+    def worker(t):
+        try:
+            rows, qs, want = data[t]
+            db = sqlite3.connect(":memory:", isolation_level=None, check_same_thread=False)
+            db.enable_load_extension(True)
+            db.load_extension(ext_path)
+            load_table(db, rows, dg.F32, dg.L2)
+            for r in range(reps):
+                i = r % len(qs)
+                got = [x[0] for x in db.execute("SELECT rowid FROM vector_full_scan('t','v',?,?)", (qs[i].tobytes(), k)).fetchall()]
+                if got != want[i]:
+                    errors.append((t, r, got, want[i]))
+                    return
+            db.close()
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not errors, errors[:2]
