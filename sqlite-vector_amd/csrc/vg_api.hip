@@ -119,7 +119,12 @@ struct vg_corpus {
     bool enqueued = false;                     // a vg_scan_topk_enqueue is in flight (vg_scan_topk_collect pending)
     float *d_xnorm = nullptr;                  // lazily: row norms for rows [0, xnorm_rows) (see ensure_row_norms)
     int64_t xnorm_rows = 0, xnorm_cap = 0;
-    hipEvent_t norm_ev = nullptr;              // orders a caller-stream scan behind a norm pass on the corpus stream
+    hipEvent_t norm_ev = nullptr;
+    // quantized batches (vg_batch_i8.hip): per-row sum x / sum x^2 and, for uint8, the XOR-0x80 copy the matrix core reads
+    int32_t *d_sx = nullptr;
+    uint32_t *d_sxx = nullptr;
+    uint8_t *d_rows_s8 = nullptr;
+    int64_t i8_rows = 0, i8_cap = 0;              // orders a caller-stream scan behind a norm pass on the corpus stream
     void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
     uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;
     size_t bq_bytes = 0, bcand_bytes = 0, bkeys_bytes = 0;
@@ -208,6 +213,9 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_bq) hipFree(c->d_bq);
     if (c->d_xnorm) hipFree(c->d_xnorm);
     if (c->d_sel_state) hipFree(c->d_sel_state);
+    if (c->d_sx) hipFree(c->d_sx);
+    if (c->d_sxx) hipFree(c->d_sxx);
+    if (c->d_rows_s8) hipFree(c->d_rows_s8);
     if (c->norm_ev) hipEventDestroy(c->norm_ev);
     if (c->d_bcand) hipFree(c->d_bcand);
     if (c->d_bkeys) hipFree(c->d_bkeys);
@@ -220,6 +228,7 @@ extern "C" int vg_corpus_clear(vg_corpus *c) {
     if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
     c->n_rows = 0;
     c->xnorm_rows = 0;
+    c->i8_rows = 0;
     c->rowids.clear();
     return VG_OK;
 }
@@ -887,6 +896,46 @@ static int ensure_row_norms(vg_corpus *c) {
     return VG_OK;
 }
 
+// ---- quantized batches on the integer matrix cores (vg_batch_i8.hip)
+extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k);
+extern "C" int vg_i8_rowstat_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int is_u8,
+                                    int32_t *dev_sx, uint32_t *dev_sxx, uint8_t *dev_flipped, hipStream_t stream);
+extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_rows, long long stride_bytes,
+                                  const uint8_t *dev_queries, int nq_pad, int k, int mode, int root, int is_u8,
+                                  const int32_t *dev_sx, const uint32_t *dev_sxx, uint64_t *dev_cand, int npart,
+                                  int tiles_per_part, uint64_t *dev_out_keys, hipStream_t stream);
+
+static bool batch_i8_eligible(const vg_corpus *c, int metric, int k) {
+    if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
+    if (c->vtype != VG_TYPE_U8 && c->vtype != VG_TYPE_I8) return false;
+    if (metric == VG_DIST_L1) return false;
+    return vg_batch_i8_lds_bytes(c->stride, k) != 0;
+}
+
+// row sums (+ the flipped copy for uint8), once per appended row
+static int ensure_i8_row_stats(vg_corpus *c) {
+    const bool u8 = (c->vtype == VG_TYPE_U8);
+    if (c->i8_cap < c->n_rows) {
+        const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_sx) hipFree(c->d_sx);
+        if (c->d_sxx) hipFree(c->d_sxx);
+        if (c->d_rows_s8) hipFree(c->d_rows_s8);
+        c->d_sx = nullptr; c->d_sxx = nullptr; c->d_rows_s8 = nullptr; c->i8_cap = 0; c->i8_rows = 0;
+        HIP_TRY(hipMalloc(&c->d_sx, (size_t)cap * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&c->d_sxx, (size_t)cap * sizeof(uint32_t)));
+        if (u8) HIP_TRY(hipMalloc(&c->d_rows_s8, (size_t)cap * c->stride));
+        c->i8_cap = cap;
+    }
+    if (c->i8_rows < c->n_rows) {
+        int rc = vg_i8_rowstat_launch(c->d_rows, c->i8_rows, c->n_rows - c->i8_rows, c->stride, u8 ? 1 : 0, c->d_sx, c->d_sxx,
+                                      c->d_rows_s8, c->stream);
+        if (rc != 0) return vg_fail(VG_ERR_HIP, "row-statistics pass failed: %s", hipGetErrorString((hipError_t)rc));
+        c->i8_rows = c->n_rows;
+    }
+    return VG_OK;
+}
+
 static bool batch_mfma_eligible(const vg_corpus *c, int metric, int k) {
     if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
     if (c->vtype != VG_TYPE_F32) return false;
@@ -921,7 +970,11 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     const size_t row_bytes = (size_t)c->dim * c->es;
     for (int i = 0; i < nq; ++i) memcpy(hq.data() + (size_t)i * c->stride, (const uint8_t *)queries + (size_t)i * row_bytes, row_bytes);
     HIP_TRY(hipMemcpyAsync(c->d_bq, hq.data(), qbytes, hipMemcpyHostToDevice, c->stream));
-    if (metric != VG_DIST_DOT) {
+    const bool quantized = (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8);
+    if (quantized) {
+        int rcn = ensure_i8_row_stats(c);
+        if (rcn != VG_OK) return rcn;
+    } else if (metric != VG_DIST_DOT) {
         int rcn = ensure_row_norms(c);
         if (rcn != VG_OK) return rcn;
     }
@@ -934,10 +987,16 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
         ++c->prof_launches;
         hipEventRecord(evs[0], c->stream);
     }
-    int rc = vg_batch_launch((const float *)c->d_rows, c->n_rows, c->stride, (const float *)c->d_bq, nq_pad, k,
-                             metric == VG_DIST_DOT ? 0 : (metric == VG_DIST_COSINE ? 1 : 2), metric == VG_DIST_L2 ? 1 : 0,
-                             metric == VG_DIST_DOT ? nullptr : c->d_xnorm,
-                             c->d_bcand, npart, tiles_per_part, c->d_bkeys, c->stream);
+    const int mode = metric == VG_DIST_DOT ? 0 : (metric == VG_DIST_COSINE ? 1 : 2), root = metric == VG_DIST_L2 ? 1 : 0;
+    int rc;
+    if (quantized)
+        rc = vg_batch_i8_launch(c->vtype == VG_TYPE_U8 ? c->d_rows_s8 : c->d_rows, c->n_rows, c->stride, (const uint8_t *)c->d_bq,
+                                nq_pad, k, mode, root, c->vtype == VG_TYPE_U8 ? 1 : 0, c->d_sx, c->d_sxx, c->d_bcand, npart,
+                                tiles_per_part, c->d_bkeys, c->stream);
+    else
+        rc = vg_batch_launch((const float *)c->d_rows, c->n_rows, c->stride, (const float *)c->d_bq, nq_pad, k, mode, root,
+                             metric == VG_DIST_DOT ? nullptr : c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys,
+                             c->stream);
     if (evs) { hipEventRecord(evs[1], c->stream); hipEventRecord(evs[2], c->stream); }
     if (rc == -1) return -1;
     if (rc != 0) return vg_fail(VG_ERR_HIP, "batched scan launch failed: %s", hipGetErrorString((hipError_t)rc));
@@ -967,7 +1026,7 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     if (k <= 0 || c->n_rows == 0) return VG_OK;
     if (!out_keys) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch_keys: NULL output");
     HIP_TRY(hipSetDevice(c->device));
-    if (batch_mfma_eligible(c, metric, k)) {
+    if (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k)) {
         int rc = scan_topk_batch_mfma(c, metric, queries, nq, k, out_keys, out_counts);
         if (rc != -1) return rc;
     }

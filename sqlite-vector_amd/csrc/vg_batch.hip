@@ -436,6 +436,13 @@ __global__ __launch_bounds__(256) void vg_batch_merge_kernel(const uint64_t *can
     vg_select_lists(cand + (long long)q * lists_per_query * 64, npart, k, out_keys + (long long)q * 64, scratch);
 }
 
+extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
+                                     uint64_t *dev_out_keys, hipStream_t stream) {
+    hipLaunchKernelGGL(vg_batch_merge_kernel, dim3((unsigned)nq_pad), dim3(256), 0, stream, dev_cand, nq_pad, lists_per_query,
+                       npart, k, dev_out_keys);
+    return (int)hipGetLastError();
+}
+
 template <int NT, int MODE>
 static int launch_nt_mode(const BatchArgs &a, int blocks, size_t smem, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_kernel<NT, MODE>),

@@ -1,0 +1,437 @@
+// vg_batch_i8.hip - batched queries over a QUANTIZED corpus (uint8 / int8 rows, the vector_quantize format): Q x C^T
+// on the integer matrix cores (v_mfma_i32_32x32x32_i8) with the same fused per-query top-k as the f32 kernel
+// (vg_batch.hip).  Integer dot products are exact, so every distance is the single-query kernel's distance bit for
+// bit (vg_accum.h AccumInt: exact 32-bit sums, one int->float conversion, correctly rounded sqrt / divide) and the
+// result lists equal Q separate vector_quantize_scan calls exactly, ties included.
+//
+//   * a workgroup = 4 wavefronts owns 128 queries x one partition of the corpus; A (32 queries per wavefront) is
+//     stationary in registers: lane (x, h) keeps bytes [32t + 16h, +16) of query x in a[t] (4 VGPRs per k-step);
+//   * B streams through LDS in tiles of 32 rows by LDS-DMA (double buffered), one ds_read_b128 feeds one MFMA;
+//   * uint8: the matrix core multiplies SIGNED bytes, so it runs on x' = x - 128 (a second, XOR-0x80 copy of the corpus
+//     made once per corpus; queries are flipped while they are loaded) and the true dot product is restored exactly:
+//         sum q x = sum q'x' + 128 (sum q + sum x) - 16384 L        (L = padded row length, pads are 0 <-> -128)
+//     with sum x, sum x^2 per row from cached vectors (vg_i8_rowstat_kernel) and sum q, sum q^2 per query;
+//   * gates are integer margins on the raw accumulator where the metric allows it (dot, L2: one v_add3 per register)
+//     and a float margin for cosine (row norms differ per lane); survivors get the exact distance and go through the
+//     same list insert as in vg_batch.hip; the two-pass launch (thresholds from a pre-pass) is the same as well.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "vg_lists.h"
+
+typedef int vgi_i32x16 __attribute__((ext_vector_type(16)));
+typedef int vgi_i32x4 __attribute__((ext_vector_type(4)));
+
+#define VGI_THREADS 256
+#define VGI_WAVES 4
+#define VGI_QPW 32
+#define VGI_QPB (VGI_WAVES * VGI_QPW)
+#define VGI_TILE 32
+#define VGI_MAX_K 32
+#define VGI_BPIPE 4
+
+enum { VGI_DOT = 0, VGI_COS = 1, VGI_L2 = 2 };
+
+struct BatchArgsI8 {
+    const uint8_t *rows;      // N x stride bytes, SIGNED representation (int8 corpus as is, uint8 corpus XOR 0x80)
+    const uint8_t *queries;   // nq_pad x stride bytes in the corpus' own (unflipped) representation, zero padded
+    const int32_t *row_sx;    // sum x per row (original representation)
+    const uint32_t *row_sxx;  // sum x^2 per row
+    uint64_t *cand;
+    long long n_rows;
+    long long stride;         // bytes per row (multiple of 16)
+    int nq_pad, npart, k;
+    int mode, root, is_u8;
+    int tiles_per_part;
+    long long tile_begin, tile_end;
+    int part_base, npart_total;
+    const uint64_t *init_keys;
+};
+
+template <int OFF>
+__device__ __forceinline__ void vgi_lds_read128(vgi_i32x4 &dst, uint32_t lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vgi_wait_lds(vgi_i32x4 &v) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void vgi_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        vgi_static_for<I + 1, N>(f);
+    }
+}
+
+// NTB = 32-byte k-steps per row (rows up to NTB * 32 bytes)
+template <int NTB, int MODE, bool IS_U8>
+__global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8 a) {
+    constexpr bool COS = (MODE == VGI_COS), L2M = (MODE == VGI_L2);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int PITCH = NTB * 32 + 16;                        // bytes per LDS tile row (16-byte pad: conflict-free b128)
+    constexpr int TILE_BYTES = VGI_TILE * PITCH;
+    constexpr int L = NTB * 32;                                 // padded row length the matrix core sees
+    uint8_t *tile0 = smem;
+    uint32_t *qstat_lds = reinterpret_cast<uint32_t *>(smem + 2 * TILE_BYTES);           // [4][32][2]: sum q, sum q^2
+    uint64_t *lists = reinterpret_cast<uint64_t *>(qstat_lds + VGI_WAVES * VGI_QPW * 2);  // [4][32][k]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = lane & 31, h = lane >> 5;
+    const int k = a.k;
+
+    const int G = a.nq_pad / VGI_QPB;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int g = idx % G;
+    const int part = (idx / G) * 8 + xcd;
+    if (part >= a.npart) return;
+    const int q0 = g * VGI_QPB + wave * VGI_QPW;
+
+    // ---- A operand (+ the query's sums in its ORIGINAL representation)
+    vgi_i32x4 areg[NTB];
+    uint32_t sq_part = 0, sqq_part = 0;
+    {
+        const uint8_t *qrow = a.queries + (long long)(q0 + x) * a.stride;
+        vgi_static_for<0, NTB>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int off = 32 * t + 16 * h;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (off < a.stride) v = *reinterpret_cast<const uint4 *>(qrow + off);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (IS_U8) {
+                    sq_part = __builtin_amdgcn_udot4(w[j], 0x01010101u, sq_part, false);
+                    sqq_part = __builtin_amdgcn_udot4(w[j], w[j], sqq_part, false);
+                } else {
+                    sq_part = (uint32_t)__builtin_amdgcn_sdot4((int)w[j], 0x01010101, (int)sq_part, false);
+                    sqq_part = (uint32_t)__builtin_amdgcn_sdot4((int)w[j], (int)w[j], (int)sqq_part, false);
+                }
+            }
+            const uint32_t flip = IS_U8 ? 0x80808080u : 0u;
+            areg[t] = vgi_i32x4{(int)(v.x ^ flip), (int)(v.y ^ flip), (int)(v.z ^ flip), (int)(v.w ^ flip)};
+        });
+    }
+    uint32_t *qs_w = qstat_lds + wave * VGI_QPW * 2;
+    uint64_t *wave_lists = lists + (size_t)wave * VGI_QPW * k;
+    {
+        const uint32_t sq = sq_part + __shfl_xor(sq_part, 32), sqq = sqq_part + __shfl_xor(sqq_part, 32);
+        if (h == 0) { qs_w[2 * x] = sq; qs_w[2 * x + 1] = sqq; }
+        for (int s = lane; s < VGI_QPW * k; s += 64) wave_lists[s] = VG_EMPTY_KEY;
+    }
+    // pad columns never touched by the DMA must read as "0" of the original representation
+    for (int s = tid; s < 2 * TILE_BYTES / 4; s += VGI_THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = IS_U8 ? 0x80808080u : 0u;
+    __syncthreads();
+
+    // ---- tile streaming by LDS-DMA (rows <= 1 KiB: one piece per row; wavefront w moves rows w, w+4, ...)
+    const int chunks_per_row = (int)(a.stride / 16);
+    const long long tile_first = a.tile_begin + (long long)part * a.tiles_per_part;
+    const long long tile_last = min(tile_first + a.tiles_per_part, a.tile_end);
+    const uint32_t n_rows32 = (uint32_t)a.n_rows;
+    const unsigned long long stride_b = (unsigned long long)a.stride;
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    const uint64_t piece_mask = __ballot(lane < chunks_per_row);
+    const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)tile0;
+    auto dma_piece = [&](uint32_t tile32, int buf, int i) {
+        const int rr = wave + i * VGI_WAVES;
+        uint32_t grow = tile32 * VGI_TILE + (uint32_t)rr;
+        grow = grow < n_rows32 ? grow : n_rows32 - 1u;
+        const uint8_t *sbase = a.rows + (unsigned long long)grow * stride_b;
+        const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + rr * PITCH);
+        uint32_t keep;
+        uint64_t keep_exec;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_and_b64 exec, exec, %5\n\t"
+                     "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(keep_exec) : "v"(lane_off), "s"(sbase), "s"(lds_dst), "s"(piece_mask) : "memory", "scc");
+    };
+    constexpr int NPIECE = VGI_TILE / VGI_WAVES;
+
+    // ---- per-register query state (register r of lane (x, h) belongs to query qi(r, h) = (r&3) + 8*(r>>2) + 4*h)
+    //   qq_reg   sum q^2                          cq_reg   what turns the raw accumulator into sum q x, query part
+    //   thr_reg  current k-th best distance       gate_i   integer gate (dot, L2)     gate_f  float gate (cosine)
+    uint32_t qq_reg[16];
+    int cq_reg[16], gate_i[16];
+    float thr_reg[16], gate_f[16], na_reg[16];
+    const bool l2_root = a.root != 0;
+    auto as_float_like = [](uint32_t v) -> float { return IS_U8 ? (float)v : (float)(int32_t)v; };
+    auto kth_distance = [](uint64_t kth) -> float {
+        return (kth == VG_EMPTY_KEY) ? INFINITY : vg_sortable_f32((uint32_t)(kth >> 32));
+    };
+    // gates are supersets of "distance <= thr" (exact test in reg_insert):
+    //   dot     -(float)qx <= thr          <=  qx >= floor(-thr) - 8             margin = acc + cx - (G - cq)
+    //   L2      (float)(qq+xx-2qx) <= thr2 <=  qq+xx-2qx <= ceil(thr2*(1+1e-6)) + 8   margin = 2 acc - (qq - 2cq - T) - (xx - 2cx)
+    //   cosine  1 - qx/(na nb) <= thr      <=  (float)qx >= (1-thr) na nb (1 -+ 1e-5) - 1
+    auto set_gate = [&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const float thr = thr_reg[r];
+        if (COS) {
+            const float Gf = (1.0f - thr) * na_reg[r];
+            gate_f[r] = fmaxf(Gf - 1e-5f * fabsf(Gf), -3.0e38f);
+        } else if (L2M) {
+            const float thr2 = l2_root ? thr * thr : thr;
+            float Tf = thr2 * (1.0f + 1e-6f) + 8.0f;
+            const int T = (Tf < 1.5e9f) ? (int)Tf : 1500000000;           // +Inf / NaN: accept everything (totals < 2^27)
+            gate_i[r] = (int)qq_reg[r] - 2 * cq_reg[r] - T;
+        } else {
+            float Gf = -thr - 8.0f;
+            const int Gq = (Gf > -1.5e9f) ? (int)floorf(Gf) : -1500000000;  // thr = +Inf: accept everything (|qx| < 2^27)
+            gate_i[r] = Gq - cq_reg[r];
+        }
+    };
+    vgi_static_for<0, 16>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const uint32_t sq = qs_w[2 * qi], sqq = qs_w[2 * qi + 1];
+        qq_reg[r] = sqq;
+        cq_reg[r] = IS_U8 ? (int)(128u * sq) - 16384 * L : 0;
+        na_reg[r] = sqrtf(as_float_like(sqq));
+        thr_reg[r] = a.init_keys ? kth_distance(a.init_keys[(long long)(q0 + qi) * 64 + (k - 1)]) : INFINITY;
+        set_gate(rc);
+    });
+
+    // exact distance of one (query, row) pair from the raw accumulator - the single-query kernel's epilogue (vg_accum.h)
+    auto reg_distance = [&](auto rc, int acc_r, int cx, uint32_t xx) -> float {
+        constexpr int r = decltype(rc)::value;
+        const uint32_t qx = (uint32_t)(acc_r + cq_reg[r] + cx);            // sum q x, modulo 2^32 like the reference
+        float d;
+        if (COS) {
+            d = vg_cosine_from_norms(as_float_like(qx), na_reg[r], sqrtf(as_float_like(xx)));
+        } else if (L2M) {
+            const float t = (float)(uint32_t)(qq_reg[r] + xx - 2u * qx);
+            d = l2_root ? sqrtf(t) : t;
+        } else {
+            d = -as_float_like(qx);
+        }
+        return vg_clamp(d);
+    };
+    auto reg_insert = [&](auto rc, int acc_r, long long row, int cx, uint32_t xx) {
+        constexpr int r = decltype(rc)::value;
+        const int q_lo = (r & 3) + 8 * (r >> 2);
+        const float d = reg_distance(rc, acc_r, cx, xx);
+        const bool pass = (row < a.n_rows) && (d <= thr_reg[r]) && (d < INFINITY);
+        unsigned long long m = __ballot(pass);
+        const uint64_t key = vg_make_key(d, (uint32_t)row);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int hh = src >> 5;
+            uint64_t *list = wave_lists + (q_lo + 4 * hh) * k;
+            const uint64_t c = vg_readlane64(key, src);
+            uint64_t mine = (lane < k) ? list[lane] : 0ull;
+            const uint64_t prev = vg_wave_shr1(mine);
+            mine = (mine > c) ? ((prev > c) ? prev : c) : mine;
+            if (lane < k) list[lane] = mine;
+            const float nt = kth_distance(vg_readlane64(mine, k - 1));
+            if (h == hh) {
+                thr_reg[r] = fminf(nt, thr_reg[r]);
+                set_gate(rc);
+            }
+        }
+    };
+
+    if (tile_first < tile_last) {
+#pragma unroll
+        for (int pc = 0; pc < NPIECE; ++pc) dma_piece((uint32_t)tile_first, 0, pc);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    constexpr int BP = VGI_BPIPE < NTB ? VGI_BPIPE : NTB;
+    vgi_i32x4 bq[BP];
+    for (long long tile = tile_first; tile < tile_last; ++tile) {
+        const int cur_buf = (int)((tile - tile_first) & 1);
+        const uint32_t tile_next = (uint32_t)min(tile + 1, tile_last - 1);
+        const long long row_cur = tile * VGI_TILE + x;
+        const long long row_ld = row_cur < a.n_rows ? row_cur : a.n_rows - 1;
+        const int sx = a.row_sx[row_ld];
+        const uint32_t xx = a.row_sxx[row_ld];
+
+        vgi_i32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0;
+        const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + x * PITCH + 16 * h);
+        vgi_static_for<0, BP>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            vgi_lds_read128<32 * t>(bq[t], baddr);
+        });
+        vgi_static_for<0, NTB>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int in_flight_after = (NTB - 1 - t) < (BP - 1) ? (NTB - 1 - t) : (BP - 1);
+            vgi_wait_lds<in_flight_after>(bq[t % BP]);
+            const vgi_i32x4 b = bq[t % BP];
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[t], b, acc, 0, 0, 0);
+            if constexpr (t + BP < NTB) vgi_lds_read128<32 * (t + BP)>(bq[t % BP], baddr);
+            // the 8 DMA pieces of the next tile, spread over the first half of the k loop
+            constexpr int NTD = (NTB + 1) / 2;
+            constexpr int pc_lo = (t >= NTD) ? NPIECE : (t * NPIECE + NTD - 1) / NTD;
+            constexpr int pc_hi = (t >= NTD) ? NPIECE : (t + 1 == NTD ? NPIECE : ((t + 1) * NPIECE + NTD - 1) / NTD);
+            vgi_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, cur_buf ^ 1, decltype(pcc)::value); });
+        });
+
+        // ---- tile boundary: margins (integer for dot / L2, float for cosine), one ballot
+        const int cx = IS_U8 ? 128 * sx : 0;
+        unsigned pend = 0;
+        bool any;
+        if (COS) {
+            const float nb = sqrtf(as_float_like(xx));
+            float margin = -INFINITY;
+            vgi_static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const float qxf = as_float_like((uint32_t)(acc[r] + cq_reg[r] + cx));
+                margin = fmaxf(margin, qxf + 1.0f - gate_f[r] * nb);
+            });
+            any = __ballot(margin >= 0.0f) != 0;
+            if (any) {
+                vgi_static_for<0, 16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const float qxf = as_float_like((uint32_t)(acc[r] + cq_reg[r] + cx));
+                    pend |= __ballot(qxf + 1.0f - gate_f[r] * nb >= 0.0f) ? (1u << r) : 0u;
+                });
+            }
+        } else {
+            const int hx = L2M ? (int)xx - 2 * cx : -cx;
+            int margin = -0x7FFFFFFF;
+            vgi_static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const int m = (L2M ? 2 * acc[r] : acc[r]) - gate_i[r] - hx;
+                margin = m > margin ? m : margin;
+            });
+            any = __ballot(margin >= 0) != 0;
+            if (any) {
+                vgi_static_for<0, 16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    pend |= __ballot((L2M ? 2 * acc[r] : acc[r]) - gate_i[r] - hx >= 0) ? (1u << r) : 0u;
+                });
+            }
+        }
+        if (pend) {
+            vgi_static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if (pend & (1u << r)) reg_insert(rc, acc[r], row_cur, cx, xx);
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    for (int s = lane; s < VGI_QPW * 64; s += 64) {
+        const int qi = s >> 6, slot = s & 63;
+        a.cand[((long long)(q0 + qi) * a.npart_total + a.part_base + part) * 64 + slot] = (slot < k) ? wave_lists[qi * k + slot] : VG_EMPTY_KEY;
+    }
+}
+
+// ---- per-row sums of the ORIGINAL representation + (uint8) the XOR-0x80 copy the matrix core reads
+template <bool IS_U8>
+__global__ __launch_bounds__(256) void vg_i8_rowstat_kernel(const uint8_t *rows, long long row0, long long n, long long stride,
+                                                            int32_t *sx, uint32_t *sxx, uint8_t *flipped) {
+    const int sub = threadIdx.x & 15;
+    const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long long ngroups = ((long long)gridDim.x * blockDim.x) >> 4;
+    const int nch = (int)(stride / 16);
+    for (long long r = group; r < n; r += ngroups) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(rows + (row0 + r) * stride);
+        uint4 *o = flipped ? reinterpret_cast<uint4 *>(flipped + (row0 + r) * stride) : nullptr;
+        uint32_t s1 = 0, s2 = 0;
+        for (int c = sub; c < nch; c += 16) {
+            const uint4 v = p[c];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (IS_U8) { s1 = __builtin_amdgcn_udot4(w[j], 0x01010101u, s1, false); s2 = __builtin_amdgcn_udot4(w[j], w[j], s2, false); }
+                else { s1 = (uint32_t)__builtin_amdgcn_sdot4((int)w[j], 0x01010101, (int)s1, false); s2 = (uint32_t)__builtin_amdgcn_sdot4((int)w[j], (int)w[j], (int)s2, false); }
+            }
+            if (o) o[c] = make_uint4(v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u);
+        }
+        s1 += __shfl_xor(s1, 8); s1 += __shfl_xor(s1, 4); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 1);
+        s2 += __shfl_xor(s2, 8); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 1);
+        if (sub == 0) { sx[row0 + r] = (int32_t)s1; sxx[row0 + r] = s2; }
+    }
+}
+
+extern "C" int vg_i8_rowstat_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int is_u8,
+                                    int32_t *dev_sx, uint32_t *dev_sxx, uint8_t *dev_flipped, hipStream_t stream) {
+    if (n <= 0) return 0;
+    long long blocks = (n * 16 + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (is_u8) hipLaunchKernelGGL((vg_i8_rowstat_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, stream, dev_rows, row0, n, stride, dev_sx, dev_sxx, dev_flipped);
+    else hipLaunchKernelGGL((vg_i8_rowstat_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, stream, dev_rows, row0, n, stride, dev_sx, dev_sxx, (uint8_t *)nullptr);
+    return (int)hipGetLastError();
+}
+
+// ---- host side
+extern "C" int vg_batch_prepass_tiles(long long n_rows, int npart);                       // vg_batch.hip
+extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
+                                     uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
+
+extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k) {
+    const int ntb = (int)((stride_bytes + 31) / 32);
+    int NTB;
+    if (ntb <= 8) NTB = 8; else if (ntb <= 16) NTB = 16; else if (ntb <= 24) NTB = 24; else if (ntb <= 32) NTB = 32;
+    else return 0;
+    if (k < 1 || k > VGI_MAX_K) return 0;
+    return (size_t)2 * VGI_TILE * (NTB * 32 + 16) + (size_t)VGI_WAVES * VGI_QPW * 2 * 4 + (size_t)VGI_WAVES * VGI_QPW * k * 8;
+}
+
+template <int NTB, int MODE, bool IS_U8>
+static int launch_i8(const BatchArgsI8 &a, int blocks, size_t smem, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_i8_kernel<NTB, MODE, IS_U8>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((vg_batch_i8_kernel<NTB, MODE, IS_U8>), dim3((unsigned)blocks), dim3(VGI_THREADS), smem, stream, a);
+    return (int)hipGetLastError();
+}
+template <int NTB, int MODE>
+static int launch_i8_sign(const BatchArgsI8 &a, int blocks, size_t smem, hipStream_t stream) {
+    return a.is_u8 ? launch_i8<NTB, MODE, true>(a, blocks, smem, stream) : launch_i8<NTB, MODE, false>(a, blocks, smem, stream);
+}
+template <int NTB>
+static int launch_i8_mode(const BatchArgsI8 &a, int blocks, size_t smem, hipStream_t stream) {
+    if (a.mode == VGI_COS) return launch_i8_sign<NTB, VGI_COS>(a, blocks, smem, stream);
+    if (a.mode == VGI_L2) return launch_i8_sign<NTB, VGI_L2>(a, blocks, smem, stream);
+    return launch_i8_sign<NTB, VGI_DOT>(a, blocks, smem, stream);
+}
+
+// dev_rows_signed: the corpus in signed representation; dev_queries: nq_pad x stride bytes (original representation).
+// Returns 0, -1 if the shape is not served, a hipError_t otherwise.  dev_cand sized like the f32 kernel's.
+extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_rows, long long stride_bytes,
+                                  const uint8_t *dev_queries, int nq_pad, int k, int mode, int root, int is_u8,
+                                  const int32_t *dev_sx, const uint32_t *dev_sxx, uint64_t *dev_cand, int npart,
+                                  int tiles_per_part, uint64_t *dev_out_keys, hipStream_t stream) {
+    const size_t smem = vg_batch_i8_lds_bytes(stride_bytes, k);
+    if (!smem || nq_pad % VGI_QPB != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
+    if (mode < VGI_DOT || mode > VGI_L2 || !dev_sx || !dev_sxx) return -1;
+    BatchArgsI8 a;
+    a.rows = dev_rows_signed; a.queries = dev_queries; a.row_sx = dev_sx; a.row_sxx = dev_sxx; a.cand = dev_cand;
+    a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.npart = npart; a.k = k;
+    a.mode = mode; a.root = root; a.is_u8 = is_u8;
+    const int ntb = (int)((stride_bytes + 31) / 32);
+    const int G = nq_pad / VGI_QPB;
+    const int blocks = G * ((npart + 7) / 8) * 8;
+    const long long ntiles = (n_rows + VGI_TILE - 1) / VGI_TILE;
+    auto launch = [&](const BatchArgsI8 &b) -> int {
+        if (ntb <= 8) return launch_i8_mode<8>(b, blocks, smem, stream);
+        if (ntb <= 16) return launch_i8_mode<16>(b, blocks, smem, stream);
+        if (ntb <= 24) return launch_i8_mode<24>(b, blocks, smem, stream);
+        return launch_i8_mode<32>(b, blocks, smem, stream);
+    };
+    const long long pre = vg_batch_prepass_tiles(n_rows, npart);
+    int rc;
+    if (pre > 0) {
+        a.npart_total = 2 * npart;
+        a.tile_begin = 0; a.tile_end = pre; a.tiles_per_part = (int)(pre / npart); a.part_base = 0; a.init_keys = nullptr;
+        if ((rc = launch(a)) != 0) return rc;
+        if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream)) != 0) return rc;
+        a.tile_begin = pre; a.tile_end = ntiles; a.tiles_per_part = (int)((ntiles - pre + npart - 1) / npart);
+        a.part_base = npart; a.init_keys = dev_out_keys;
+        if ((rc = launch(a)) != 0) return rc;
+    } else {
+        a.npart_total = npart;
+        a.tile_begin = 0; a.tile_end = ntiles; a.tiles_per_part = tiles_per_part; a.part_base = 0; a.init_keys = nullptr;
+        if ((rc = launch(a)) != 0) return rc;
+    }
+    return vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, a.npart_total, k, dev_out_keys, stream);
+}

@@ -635,3 +635,31 @@ def test_large_k_radix_select_equals_full_sort_and_oracle(pkg, orc, monkeypatch)
     ids, dist = c.scan_topk(dg.L2, dg.query(dg.U8, 16, 84), 500)
     assert ids.tolist() == list(range(1, 501)) and len(set(dist.tolist())) == 1
     c.close()
+
+
+@pytest.mark.parametrize("vt", (dg.U8, dg.I8))
+@pytest.mark.parametrize("dim", (16, 100, 384, 768, 1000, 1024))
+def test_quantized_batch_on_integer_matrix_cores_is_bit_exact(pkg, orc, vt, dim):
+    """uint8 / int8 batches run Q x C^T on the integer matrix cores (v_mfma_i32_32x32x32_i8; uint8 through the
+    x - 128 identity).  Integer sums are exact, so every query's list must equal the single-query scan - itself
+    bit-exact with distance-avx2.c - rowid for rowid and bit for bit, ties (low-entropy rows) included."""
+    n = 4133
+    for low in (False, True):
+        rows = dg.corpus(vt, n, dim, 700 + dim, low_entropy=low)
+        rows[17] = 0                                  # zero-norm row (cosine -> 1.0)
+        c = pkg.Corpus(vt, dim)
+        c.append(rows)
+        for metric in (dg.DOT, dg.COSINE, dg.L2, dg.SQUARED_L2):
+            for nq, k in ((3, 20), (130, 1), (70, 32)):
+                qs = dg.corpus(vt, nq, dim, 701 + dim + nq, low_entropy=low)
+                ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+                for i in (0, 1, nq // 2, nq - 1):
+                    one_ids, one_dist = c.scan_topk(metric, qs[i], k)
+                    assert cnt[i] == len(one_ids) and ids[i][:cnt[i]].tolist() == one_ids.tolist(), (metric, low, nq, k, i)
+                    assert np.array_equal(dist[i][:cnt[i]], one_dist), (metric, low, nq, k, i)
+        # against the oracle directly for one query / metric
+        want = orc.scan_distances(orc.AVX2, dg.COSINE, vt, qs[0], rows)
+        oids, odist, _ = orc.topk_ordered(want, None, 20)
+        ids, dist, cnt = c.scan_topk_batch(dg.COSINE, qs[:1], 20)
+        assert ids[0].tolist() == oids.tolist() and np.array_equal(dist[0], odist)
+        c.close()

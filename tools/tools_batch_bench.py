@@ -25,25 +25,38 @@ def main():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--metric", type=int, default=4)
+    ap.add_argument("--type", type=str, default="f32", choices=("f32", "u8", "i8"))
     args = ap.parse_args()
     import torch
     torch.cuda.init()
     import __graft_entry__ as g
     pkg = g.load_package()
     n, dim = args.rows, args.dim
-    c = pkg.Corpus(pkg.F32, dim, capacity=n)
+    vt = {"f32": pkg.F32, "u8": pkg.U8, "i8": pkg.I8}[args.type]
+    es = pkg.TYPE_SIZE[vt]
+    c = pkg.Corpus(vt, dim, capacity=n)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(42)
     for r0 in range(0, n, 1_000_000):
         nr = min(1_000_000, n - r0)
-        t = torch.randn((nr, dim), generator=gen, device="cuda", dtype=torch.float32)
+        if vt == pkg.F32:
+            t = torch.randn((nr, dim), generator=gen, device="cuda", dtype=torch.float32)
+        elif vt == pkg.U8:
+            t = torch.randint(0, 256, (nr, dim), generator=gen, device="cuda", dtype=torch.uint8)
+        else:
+            t = torch.randint(-128, 128, (nr, dim), generator=gen, device="cuda", dtype=torch.int8)
         torch.cuda.synchronize()
-        c.append_device(t.data_ptr(), nr, dim * 4)
+        c.append_device(t.data_ptr(), nr, dim * es)
         del t
     c.set_profiling(True)
     rng = np.random.default_rng(44)
     for nq in [int(x) for x in args.nq.split(",")]:
-        qs = rng.standard_normal((nq, dim), dtype=np.float32)
+        if vt == pkg.F32:
+            qs = rng.standard_normal((nq, dim), dtype=np.float32)
+        elif vt == pkg.U8:
+            qs = rng.integers(0, 256, (nq, dim)).astype(np.uint8)
+        else:
+            qs = rng.integers(-128, 128, (nq, dim)).astype(np.int8)
         c.scan_topk_batch(args.metric, qs, args.k)                  # warm-up
         c.set_profiling(True)
         t0 = time.perf_counter()
@@ -57,7 +70,7 @@ def main():
         one_ids, one_dist = c.scan_topk(args.metric, qs[0], args.k)
         agree = float(np.mean(np.isin(ids[0], one_ids)))
         print(json.dumps({
-            "workload": "%d queries x %dx%d f32 %s top-%d, batched MFMA" % (nq, n, dim, {1: "L2", 2: "squared L2", 3: "cosine", 4: "dot", 5: "L1"}[args.metric], args.k),
+            "workload": "%d queries x %dx%d %s %s top-%d, batched MFMA" % (nq, n, dim, args.type, {1: "L2", 2: "squared L2", 3: "cosine", 4: "dot", 5: "L1"}[args.metric], args.k),
             "kernel_ms": kern_ms, "wall_ms_per_batch": wall * 1e3, "queries_per_s": nq / wall,
             "query_vector_pairs_per_s": nq * n / wall,
             "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
