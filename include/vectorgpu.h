@@ -125,7 +125,9 @@ int64_t vg_corpus_rowid_at(const vg_corpus *c, int64_t position);
 /* nq queries at once (row-major nq x dim, host).  out_rowids / out_dist are nq x k, out_counts nq.
  * f32 corpora, k <= 32, rows <= 512 floats, metric DOT / COSINE / L2 / SQUARED_L2: one pass over the corpus on the
  * matrix cores (Q x C^T tiles feed per-query candidate lists; L2 survivors are re-evaluated with the direct formula).
- * Everything else: nq single-query scans.  Same result contract as vg_scan_topk, f32 tolerance 1e-5. */
+ * uint8 / int8 corpora, k <= 32, rows <= 1024 bytes, same metrics: the integer matrix cores, results identical to
+ * nq vg_scan_topk calls.  Everything else: nq single-query scans.  Same result contract as vg_scan_topk (f32
+ * batches: tolerance 1e-5). */
 int vg_scan_topk_batch(vg_corpus *c, int metric, const void *queries, int nq, int k,
                        int64_t *out_rowids, double *out_dist, int *out_counts);
 

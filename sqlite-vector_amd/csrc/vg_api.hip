@@ -898,6 +898,7 @@ static int ensure_row_norms(vg_corpus *c) {
 
 // ---- quantized batches on the integer matrix cores (vg_batch_i8.hip)
 extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k);
+extern "C" int vg_batch_i8_queries_per_block(void);
 extern "C" int vg_i8_rowstat_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int is_u8,
                                     int32_t *dev_sx, uint32_t *dev_sxx, uint8_t *dev_flipped, hipStream_t stream);
 extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_rows, long long stride_bytes,
@@ -945,7 +946,8 @@ static bool batch_mfma_eligible(const vg_corpus *c, int metric, int k) {
 
 static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys,
                                 int *out_counts) {
-    const int QPB = 128;
+    const bool quantized = (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8);
+    const int QPB = quantized ? vg_batch_i8_queries_per_block() : 128;
     const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
     const int G = nq_pad / QPB;
     // partitions: enough workgroups to cover the chip (G * npart ~ CUs), a multiple of 8 (one per XCD), <= 256
@@ -970,7 +972,6 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     const size_t row_bytes = (size_t)c->dim * c->es;
     for (int i = 0; i < nq; ++i) memcpy(hq.data() + (size_t)i * c->stride, (const uint8_t *)queries + (size_t)i * row_bytes, row_bytes);
     HIP_TRY(hipMemcpyAsync(c->d_bq, hq.data(), qbytes, hipMemcpyHostToDevice, c->stream));
-    const bool quantized = (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8);
     if (quantized) {
         int rcn = ensure_i8_row_stats(c);
         if (rcn != VG_OK) return rcn;

@@ -25,8 +25,10 @@
 typedef int vgi_i32x16 __attribute__((ext_vector_type(16)));
 typedef int vgi_i32x4 __attribute__((ext_vector_type(4)));
 
-#define VGI_THREADS 256
-#define VGI_WAVES 4
+#ifndef VGI_WAVES
+#define VGI_WAVES 8                     // two wavefronts per SIMD: one gates / inserts / issues DMA while the other's MFMAs run
+#endif
+#define VGI_THREADS (64 * VGI_WAVES)
 #define VGI_QPW 32
 #define VGI_QPB (VGI_WAVES * VGI_QPW)
 #define VGI_TILE 32
@@ -367,13 +369,16 @@ extern "C" int vg_batch_prepass_tiles(long long n_rows, int npart);             
 extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
                                      uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
 
+extern "C" int vg_batch_i8_queries_per_block(void) { return VGI_QPB; }
+
 extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k) {
     const int ntb = (int)((stride_bytes + 31) / 32);
     int NTB;
     if (ntb <= 8) NTB = 8; else if (ntb <= 16) NTB = 16; else if (ntb <= 24) NTB = 24; else if (ntb <= 32) NTB = 32;
     else return 0;
     if (k < 1 || k > VGI_MAX_K) return 0;
-    return (size_t)2 * VGI_TILE * (NTB * 32 + 16) + (size_t)VGI_WAVES * VGI_QPW * 2 * 4 + (size_t)VGI_WAVES * VGI_QPW * k * 8;
+    const size_t b = (size_t)2 * VGI_TILE * (NTB * 32 + 16) + (size_t)VGI_WAVES * VGI_QPW * 2 * 4 + (size_t)VGI_WAVES * VGI_QPW * k * 8;
+    return b <= 160 * 1024 ? b : 0;
 }
 
 template <int NTB, int MODE, bool IS_U8>
