@@ -923,8 +923,9 @@ static int ensure_i8_row_stats(vg_corpus *c) {
         if (c->d_sxx) hipFree(c->d_sxx);
         if (c->d_rows_s8) hipFree(c->d_rows_s8);
         c->d_sx = nullptr; c->d_sxx = nullptr; c->d_rows_s8 = nullptr; c->i8_cap = 0; c->i8_rows = 0;
-        HIP_TRY(hipMalloc(&c->d_sx, (size_t)cap * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&c->d_sxx, (size_t)cap * sizeof(uint32_t)));
+        // + one tile of slack: the batch kernel fetches the sums of a whole 32-row tile, also behind the last row
+        HIP_TRY(hipMalloc(&c->d_sx, (size_t)(cap + 64) * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&c->d_sxx, (size_t)(cap + 64) * sizeof(uint32_t)));
         if (u8) HIP_TRY(hipMalloc(&c->d_rows_s8, (size_t)cap * c->stride));
         c->i8_cap = cap;
     }

@@ -6,7 +6,8 @@
 //
 //   * a workgroup = 4 wavefronts owns 128 queries x one partition of the corpus; A (32 queries per wavefront) is
 //     stationary in registers: lane (x, h) keeps bytes [32t + 16h, +16) of query x in a[t] (4 VGPRs per k-step);
-//   * B streams through LDS in tiles of 32 rows by LDS-DMA (double buffered), one ds_read_b128 feeds one MFMA;
+//   * B streams through LDS in tiles of 32 rows by LDS-DMA (double buffered, transposed by 16-byte chunk - see the
+//     kernel), one ds_read_b128 feeds one MFMA;
 //   * uint8: the matrix core multiplies SIGNED bytes, so it runs on x' = x - 128 (a second, XOR-0x80 copy of the corpus
 //     made once per corpus; queries are flipped while they are loaded) and the true dot product is restored exactly:
 //         sum q x = sum q'x' + 128 (sum q + sum x) - 16384 L        (L = padded row length, pads are 0 <-> -128)
@@ -74,11 +75,17 @@ template <int NTB, int MODE, bool IS_U8>
 __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8 a) {
     constexpr bool COS = (MODE == VGI_COS), L2M = (MODE == VGI_L2);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int PITCH = NTB * 32 + 16;                        // bytes per LDS tile row (16-byte pad: conflict-free b128)
-    constexpr int TILE_BYTES = VGI_TILE * PITCH;
+    // LDS tile, TRANSPOSED BY 16-BYTE CHUNK: chunk column c of the 32 rows is one contiguous 512-byte run
+    // (address c * 512 + row * 16).  A lane's b128 read of (row x, chunk 2t + h) sits next to its neighbours' - no
+    // bank conflicts, no row padding - and one LDS-DMA instruction (64 lanes x 16 bytes = two chunk columns) carries
+    // 64 (row, chunk) pairs whatever the row length.  With one instruction per ROW (the f32 kernel's layout) a
+    // 128-byte row used 8 of the 64 lanes, and the ~100-cycle issue cost of an LDS-DMA instruction made the kernel's
+    // time proportional to the row COUNT, not to the bytes.
+    constexpr int TILE_BYTES = NTB * 2 * 512;
     constexpr int L = NTB * 32;                                 // padded row length the matrix core sees
     uint8_t *tile0 = smem;
-    uint32_t *qstat_lds = reinterpret_cast<uint32_t *>(smem + 2 * TILE_BYTES);           // [4][32][2]: sum q, sum q^2
+    uint32_t *rstat_lds = reinterpret_cast<uint32_t *>(smem + 2 * TILE_BYTES);           // [2 buffers][sum x: 32 | sum x^2: 32]
+    uint32_t *qstat_lds = rstat_lds + 2 * 64;                                            // [waves][32][2]: sum q, sum q^2
     uint64_t *lists = reinterpret_cast<uint64_t *>(qstat_lds + VGI_WAVES * VGI_QPW * 2);  // [4][32][k]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -129,28 +136,56 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
     for (int s = tid; s < 2 * TILE_BYTES / 4; s += VGI_THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = IS_U8 ? 0x80808080u : 0u;
     __syncthreads();
 
-    // ---- tile streaming by LDS-DMA (rows <= 1 KiB: one piece per row; wavefront w moves rows w, w+4, ...)
+    // ---- tile streaming by LDS-DMA: piece p = chunk columns 2p and 2p+1 of all 32 rows; wavefront w moves pieces
+    // w, w + WAVES, ...  Lane l reads 16 bytes of row (l & 31) at chunk 2p + (l >> 5); it lands at M0 + 16 * l.
     const int chunks_per_row = (int)(a.stride / 16);
+    const int npieces = (chunks_per_row + 1) / 2;               // pieces that carry data (<= NTB)
     const long long tile_first = a.tile_begin + (long long)part * a.tiles_per_part;
     const long long tile_last = min(tile_first + a.tiles_per_part, a.tile_end);
-    const uint32_t n_rows32 = (uint32_t)a.n_rows;
     const unsigned long long stride_b = (unsigned long long)a.stride;
-    const uint32_t lane_off = (uint32_t)lane * 16u;
-    const uint64_t piece_mask = __ballot(lane < chunks_per_row);
     const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)tile0;
-    auto dma_piece = [&](uint32_t tile32, int buf, int i) {
-        const int rr = wave + i * VGI_WAVES;
-        uint32_t grow = tile32 * VGI_TILE + (uint32_t)rr;
-        grow = grow < n_rows32 ? grow : n_rows32 - 1u;
-        const uint8_t *sbase = a.rows + (unsigned long long)grow * stride_b;
-        const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + rr * PITCH);
+    constexpr int NPIECE = (NTB + VGI_WAVES - 1) / VGI_WAVES;  // piece slots per wavefront and tile (compile time)
+    uint64_t piece_mask[NPIECE];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int p = wave + i * VGI_WAVES;
+        piece_mask[i] = __ballot(p < npieces && (2 * p + h) < chunks_per_row);
+    }
+    // rows past the end of the corpus (last tile only) re-read the last row: their scores are masked by the row bound
+    auto lane_offset = [&](long long tile) -> uint32_t {
+        const long long row0 = tile * VGI_TILE;
+        const long long last = a.n_rows - 1 - row0;             // >= 0: the tile exists
+        const uint32_t xr = (uint32_t)((long long)x < last ? (long long)x : last);
+        return xr * (uint32_t)a.stride + (uint32_t)h * 16u;
+    };
+    // The per-row sums of a tile ride the same pipeline (two 128-byte pieces, issued by the last wavefront): read
+    // with ordinary loads at the tile boundary they cost a full L2 / HBM round trip per tile - with only 8..32
+    // MFMAs per tile that latency WAS the kernel time (7 ms of the 10.7 at D = 768, and independent of D).
+    const uint32_t lds_rstat0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)rstat_lds;
+    const uint64_t stat_mask = __ballot(wave == VGI_WAVES - 1 && lane < 8);
+    const uint32_t stat_goff = (uint32_t)lane * 16u;
+    auto dma_stats = [&](long long tile, int buf) {
+        const uint8_t *b0 = reinterpret_cast<const uint8_t *>(a.row_sx + tile * VGI_TILE);
+        const uint8_t *b1 = reinterpret_cast<const uint8_t *>(a.row_sxx + tile * VGI_TILE);
+        const uint32_t d0 = lds_rstat0 + (uint32_t)(buf * 256), d1 = d0 + 128u;
+        uint32_t keep;
+        uint64_t keep_exec;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %7\n\t"
+                     "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                     "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n\t"
+                     "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(keep_exec) : "v"(stat_goff), "s"(b0), "s"(b1), "s"(d0), "s"(d1), "s"(stat_mask) : "memory", "scc");
+    };
+    auto dma_piece = [&](long long tile, uint32_t lane_goff, int buf, int i) {
+        const int p = wave + i * VGI_WAVES;
+        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGI_TILE) * stride_b + (unsigned)p * 32u;
+        const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + p * 1024);
         uint32_t keep;
         uint64_t keep_exec;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_and_b64 exec, exec, %5\n\t"
                      "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep), "=&s"(keep_exec) : "v"(lane_off), "s"(sbase), "s"(lds_dst), "s"(piece_mask) : "memory", "scc");
+                     : "=&s"(keep), "=&s"(keep_exec) : "v"(lane_goff), "s"(sbase), "s"(lds_dst), "s"(piece_mask[i]) : "memory", "scc");
     };
-    constexpr int NPIECE = VGI_TILE / VGI_WAVES;
 
     // ---- per-register query state (register r of lane (x, h) belongs to query qi(r, h) = (r&3) + 8*(r>>2) + 4*h)
     //   qq_reg   sum q^2                          cq_reg   what turns the raw accumulator into sum q x, query part
@@ -236,8 +271,10 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
     };
 
     if (tile_first < tile_last) {
+        const uint32_t goff0 = lane_offset(tile_first);
 #pragma unroll
-        for (int pc = 0; pc < NPIECE; ++pc) dma_piece((uint32_t)tile_first, 0, pc);
+        for (int pc = 0; pc < NPIECE; ++pc) dma_piece(tile_first, goff0, 0, pc);
+        dma_stats(tile_first, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -246,19 +283,17 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
     vgi_i32x4 bq[BP];
     for (long long tile = tile_first; tile < tile_last; ++tile) {
         const int cur_buf = (int)((tile - tile_first) & 1);
-        const uint32_t tile_next = (uint32_t)min(tile + 1, tile_last - 1);
+        const long long tile_next = min(tile + 1, tile_last - 1);         // the last iteration re-fetches its own tile
+        const uint32_t goff_next = lane_offset(tile_next);
         const long long row_cur = tile * VGI_TILE + x;
-        const long long row_ld = row_cur < a.n_rows ? row_cur : a.n_rows - 1;
-        const int sx = a.row_sx[row_ld];
-        const uint32_t xx = a.row_sxx[row_ld];
 
         vgi_i32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0;
-        const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + x * PITCH + 16 * h);
+        const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
         vgi_static_for<0, BP>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            vgi_lds_read128<32 * t>(bq[t], baddr);
+            vgi_lds_read128<1024 * t>(bq[t], baddr);
         });
         vgi_static_for<0, NTB>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
@@ -266,13 +301,17 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
             vgi_wait_lds<in_flight_after>(bq[t % BP]);
             const vgi_i32x4 b = bq[t % BP];
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[t], b, acc, 0, 0, 0);
-            if constexpr (t + BP < NTB) vgi_lds_read128<32 * (t + BP)>(bq[t % BP], baddr);
-            // the 8 DMA pieces of the next tile, spread over the first half of the k loop
+            if constexpr (t + BP < NTB) vgi_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
+            // the DMA pieces of the next tile, spread over the first half of the k loop
             constexpr int NTD = (NTB + 1) / 2;
             constexpr int pc_lo = (t >= NTD) ? NPIECE : (t * NPIECE + NTD - 1) / NTD;
             constexpr int pc_hi = (t >= NTD) ? NPIECE : (t + 1 == NTD ? NPIECE : ((t + 1) * NPIECE + NTD - 1) / NTD);
-            vgi_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, cur_buf ^ 1, decltype(pcc)::value); });
+            vgi_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, goff_next, cur_buf ^ 1, decltype(pcc)::value); });
+            if constexpr (t == 0) dma_stats(tile_next, cur_buf ^ 1);
         });
+        // this tile's row sums (landed with the tile, one barrier ago)
+        const int sx = (int)rstat_lds[cur_buf * 64 + x];
+        const uint32_t xx = rstat_lds[cur_buf * 64 + 32 + x];
 
         // ---- tile boundary: margins (integer for dot / L2, float for cosine), one ballot
         const int cx = IS_U8 ? 128 * sx : 0;
@@ -377,7 +416,7 @@ extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k) {
     if (ntb <= 8) NTB = 8; else if (ntb <= 16) NTB = 16; else if (ntb <= 24) NTB = 24; else if (ntb <= 32) NTB = 32;
     else return 0;
     if (k < 1 || k > VGI_MAX_K) return 0;
-    const size_t b = (size_t)2 * VGI_TILE * (NTB * 32 + 16) + (size_t)VGI_WAVES * VGI_QPW * 2 * 4 + (size_t)VGI_WAVES * VGI_QPW * k * 8;
+    const size_t b = (size_t)2 * NTB * 1024 + 512 + (size_t)VGI_WAVES * VGI_QPW * 2 * 4 + (size_t)VGI_WAVES * VGI_QPW * k * 8;
     return b <= 160 * 1024 ? b : 0;
 }
 
