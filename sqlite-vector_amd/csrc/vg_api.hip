@@ -855,9 +855,9 @@ extern "C" int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k, 
 // ---- batched queries: the MFMA path (vg_batch.hip) when the shape allows it, otherwise nq single-query scans
 extern "C" size_t vg_batch_lds_bytes(long long stride_bytes, int k);
 extern "C" int vg_batch_launch(const float *dev_rows, long long n_rows, long long stride_bytes,
-                               const float *dev_queries, int nq_pad, int k, int mode, int root, const float *dev_xnorm,
-                               uint64_t *dev_cand, int npart, int tiles_per_part, uint64_t *dev_out_keys,
-                               hipStream_t stream);
+                               const float *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
+                               const float *dev_xnorm, uint64_t *dev_cand, int npart, int tiles_per_part,
+                               uint64_t *dev_out_keys, hipStream_t stream);
 extern "C" int vg_batch_lists_per_query(long long n_rows, int npart);
 extern "C" int vg_rownorm_launch(const float *dev_rows, long long row0, long long n, long long stride_bytes, float *dev_out,
                                  hipStream_t stream);
@@ -902,7 +902,7 @@ extern "C" int vg_batch_i8_queries_per_block(void);
 extern "C" int vg_i8_rowstat_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int is_u8,
                                     int32_t *dev_sx, uint32_t *dev_sxx, uint8_t *dev_flipped, hipStream_t stream);
 extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_rows, long long stride_bytes,
-                                  const uint8_t *dev_queries, int nq_pad, int k, int mode, int root, int is_u8,
+                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root, int is_u8,
                                   const int32_t *dev_sx, const uint32_t *dev_sxx, uint64_t *dev_cand, int npart,
                                   int tiles_per_part, uint64_t *dev_out_keys, hipStream_t stream);
 
@@ -993,10 +993,10 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     int rc;
     if (quantized)
         rc = vg_batch_i8_launch(c->vtype == VG_TYPE_U8 ? c->d_rows_s8 : c->d_rows, c->n_rows, c->stride, (const uint8_t *)c->d_bq,
-                                nq_pad, k, mode, root, c->vtype == VG_TYPE_U8 ? 1 : 0, c->d_sx, c->d_sxx, c->d_bcand, npart,
+                                nq_pad, nq, k, mode, root, c->vtype == VG_TYPE_U8 ? 1 : 0, c->d_sx, c->d_sxx, c->d_bcand, npart,
                                 tiles_per_part, c->d_bkeys, c->stream);
     else
-        rc = vg_batch_launch((const float *)c->d_rows, c->n_rows, c->stride, (const float *)c->d_bq, nq_pad, k, mode, root,
+        rc = vg_batch_launch((const float *)c->d_rows, c->n_rows, c->stride, (const float *)c->d_bq, nq_pad, nq, k, mode, root,
                              metric == VG_DIST_DOT ? nullptr : c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys,
                              c->stream);
     if (evs) { hipEventRecord(evs[1], c->stream); hipEventRecord(evs[2], c->stream); }

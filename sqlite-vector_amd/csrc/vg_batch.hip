@@ -57,6 +57,7 @@ struct BatchArgs {
     long long n_rows;
     long long stride_f;       // floats between rows (multiple of 4)
     int nq_pad;
+    int nq_real;              // queries [nq_real, nq_pad) are padding: they never accept a candidate
     int npart;
     int k;
     int mode;                 // VGB_DOT / VGB_COS / VGB_L2
@@ -227,7 +228,8 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         thr_reg[r] = a.init_keys ? kth_distance(a.init_keys[(long long)(q0 + qi) * 64 + (k - 1)]) : INFINITY;
         qn_reg[r] = qn_w[qi];
         gate[r] = make_gate(thr_reg[r], qn_reg[r]);
-    }
+        if (q0 + qi >= a.nq_real) { thr_reg[r] = -INFINITY; gate[r] = 3.0e38f; }      // padding: an all-zero query would
+    }                                                                                    // tie every row at cosine 1.0
     // the gate of register r for a tile whose rows have norm term `xterm` (cosine: |x|; L2: 0.4999 |x|^2)
     auto reg_gate = [&](auto rc, float xterm) -> float {
         constexpr int r = decltype(rc)::value;
@@ -267,7 +269,9 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
             pass = (row < a.n_rows) && (acc_r >= gate[r] + xnorm * xnorm * 0.4999f);
         } else {
             d = reg_distance(rc, acc_r, xnorm);
-            pass = (row < a.n_rows) && (d <= thr_reg[r]) && (d < INFINITY);
+            // strict: rows arrive in scan order, so a row that only TIES the k-th best (here or in the pre-pass,
+            // whose rows all come earlier) has the larger position and loses; +Inf thresholds accept every finite d
+            pass = (row < a.n_rows) && (d < thr_reg[r]);
         }
         unsigned long long m = __ballot(pass);
         uint64_t key = vg_make_key(d, (uint32_t)row);
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
                 const long long row_u = __builtin_amdgcn_readlane((int)row, src);          // rows < 2^32 per shard, and
                 const float thr_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thr_reg[r]), src));
                 const float de = exact_l2(q_lo + 4 * hh, (long long)(uint32_t)row_u);       // positive as u32
-                if (!(de <= thr_u) || !(de < INFINITY)) continue;
+                if (!(de < thr_u)) continue;
                 c = vg_make_key(de, (uint32_t)row_u);
             } else {
                 c = vg_readlane64(key, src);
@@ -495,15 +499,15 @@ extern "C" int vg_batch_lists_per_query(long long n_rows, int npart) {
 // pass 2 starts every list at that threshold instead of +Inf: ~k*(1 + ln(rows_per_partition / rows_in_pass_1)) inserts
 // per list.  The final merge takes the lists of both passes.
 extern "C" int vg_batch_launch(const float *dev_rows, long long n_rows, long long stride_bytes,
-                               const float *dev_queries, int nq_pad, int k, int mode, int root, const float *dev_xnorm,
-                               uint64_t *dev_cand, int npart, int tiles_per_part, uint64_t *dev_out_keys,
-                               hipStream_t stream) {
+                               const float *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
+                               const float *dev_xnorm, uint64_t *dev_cand, int npart, int tiles_per_part,
+                               uint64_t *dev_out_keys, hipStream_t stream) {
     const size_t smem = vg_batch_lds_bytes(stride_bytes, k);
     if (!smem || nq_pad % VGB_QPB != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
     if (mode < VGB_DOT || mode > VGB_L2 || (mode != VGB_DOT && !dev_xnorm)) return -1;
     BatchArgs a;
     a.rows = dev_rows; a.queries = dev_queries; a.cand = dev_cand; a.n_rows = n_rows;
-    a.stride_f = stride_bytes / 4; a.nq_pad = nq_pad; a.npart = npart; a.k = k; a.mode = mode; a.root = root;
+    a.stride_f = stride_bytes / 4; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k; a.mode = mode; a.root = root;
     a.xnorm = dev_xnorm;
     const int nt = (int)((a.stride_f + 7) / 8);
     const int G = nq_pad / VGB_QPB;

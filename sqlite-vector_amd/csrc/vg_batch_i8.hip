@@ -46,7 +46,7 @@ struct BatchArgsI8 {
     uint64_t *cand;
     long long n_rows;
     long long stride;         // bytes per row (multiple of 16)
-    int nq_pad, npart, k;
+    int nq_pad, nq_real, npart, k;   // queries [nq_real, nq_pad) are padding
     int mode, root, is_u8;
     int tiles_per_part;
     long long tile_begin, tile_end;
@@ -228,6 +228,10 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
         na_reg[r] = sqrtf(as_float_like(sqq));
         thr_reg[r] = a.init_keys ? kth_distance(a.init_keys[(long long)(q0 + qi) * 64 + (k - 1)]) : INFINITY;
         set_gate(rc);
+        if (q0 + qi >= a.nq_real) {                      // padding (an all-zero query ties every row at cosine 1.0)
+            thr_reg[r] = -INFINITY;
+            if (COS) gate_f[r] = 3.0e38f; else gate_i[r] = 1500000000;
+        }
     });
 
     // exact distance of one (query, row) pair from the raw accumulator - the single-query kernel's epilogue (vg_accum.h)
@@ -249,7 +253,8 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
         constexpr int r = decltype(rc)::value;
         const int q_lo = (r & 3) + 8 * (r >> 2);
         const float d = reg_distance(rc, acc_r, cx, xx);
-        const bool pass = (row < a.n_rows) && (d <= thr_reg[r]) && (d < INFINITY);
+        // strict: rows arrive in scan order, a row that only ties the k-th best has the larger position and loses
+        const bool pass = (row < a.n_rows) && (d < thr_reg[r]);
         unsigned long long m = __ballot(pass);
         const uint64_t key = vg_make_key(d, (uint32_t)row);
         while (m) {
@@ -442,7 +447,7 @@ static int launch_i8_mode(const BatchArgsI8 &a, int blocks, size_t smem, hipStre
 // dev_rows_signed: the corpus in signed representation; dev_queries: nq_pad x stride bytes (original representation).
 // Returns 0, -1 if the shape is not served, a hipError_t otherwise.  dev_cand sized like the f32 kernel's.
 extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_rows, long long stride_bytes,
-                                  const uint8_t *dev_queries, int nq_pad, int k, int mode, int root, int is_u8,
+                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root, int is_u8,
                                   const int32_t *dev_sx, const uint32_t *dev_sxx, uint64_t *dev_cand, int npart,
                                   int tiles_per_part, uint64_t *dev_out_keys, hipStream_t stream) {
     const size_t smem = vg_batch_i8_lds_bytes(stride_bytes, k);
@@ -450,7 +455,7 @@ extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_ro
     if (mode < VGI_DOT || mode > VGI_L2 || !dev_sx || !dev_sxx) return -1;
     BatchArgsI8 a;
     a.rows = dev_rows_signed; a.queries = dev_queries; a.row_sx = dev_sx; a.row_sxx = dev_sxx; a.cand = dev_cand;
-    a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.npart = npart; a.k = k;
+    a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;
     a.mode = mode; a.root = root; a.is_u8 = is_u8;
     const int ntb = (int)((stride_bytes + 31) / 32);
     const int G = nq_pad / VGI_QPB;

@@ -663,3 +663,27 @@ def test_quantized_batch_on_integer_matrix_cores_is_bit_exact(pkg, orc, vt, dim)
         ids, dist, cnt = c.scan_topk_batch(dg.COSINE, qs[:1], 20)
         assert ids[0].tolist() == oids.tolist() and np.array_equal(dist[0], odist)
         c.close()
+
+
+@pytest.mark.parametrize("vt", (dg.F32, dg.U8))
+def test_batch_with_zero_queries_and_exact_duplicate_rows(pkg, orc, vt):
+    """an all-zero query makes EVERY row tie (cosine 1.0, dot 0): the answer is the first k rows in scan order, also
+    across partitions and through the pre-pass rule "a tie with the k-th best never wins"; duplicated rows tie too."""
+    dim, n, k = 64, 9000, 20
+    rows = dg.corpus(vt, n, dim, 95)
+    rows[4000:4040] = rows[10]                      # 40 exact copies of one row, far from the original
+    qs = dg.corpus(vt, 5, dim, 96)
+    qs[1] = 0
+    qs[3] = rows[10]                                # its best hits are the 41 identical rows: ties by position
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    for metric in (dg.COSINE, dg.DOT, dg.L2):
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        for i in range(5):
+            one_ids, one_dist = c.scan_topk(metric, qs[i], k)
+            assert cnt[i] == k and ids[i].tolist() == one_ids.tolist(), (metric, i)
+            if vt == dg.U8:
+                assert np.array_equal(dist[i], one_dist)
+            else:
+                assert np.allclose(dist[i], one_dist, rtol=1e-5, atol=1e-5)
+    c.close()
