@@ -1029,8 +1029,17 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     if (!out_keys) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch_keys: NULL output");
     HIP_TRY(hipSetDevice(c->device));
     if (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k)) {
-        int rc = scan_topk_batch_mfma(c, metric, queries, nq, k, out_keys, out_counts);
+        // very large batches go through in slices: the per-(query, partition) candidate lists are nq x ~128 x 512 B
+        const int slice = std::max(256, env_int("VG_BATCH_SLICE", 4096));
+        int rc = VG_OK;
+        const size_t qbytes = (size_t)c->dim * c->es;
+        for (int q0 = 0; q0 < nq && rc == VG_OK; q0 += slice) {
+            const int nqs = std::min(slice, nq - q0);
+            rc = scan_topk_batch_mfma(c, metric, (const uint8_t *)queries + (size_t)q0 * qbytes, nqs, k, out_keys + (size_t)q0 * k,
+                                      out_counts + q0);
+        }
         if (rc != -1) return rc;
+        for (int i = 0; i < nq; ++i) out_counts[i] = 0;
     }
     // shapes the matrix-core kernel does not serve (other types / metrics, k > 32, rows > 512 floats):
     // nq passes of the single-query kernel, still entirely on the GPU

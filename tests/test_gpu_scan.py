@@ -687,3 +687,17 @@ def test_batch_with_zero_queries_and_exact_duplicate_rows(pkg, orc, vt):
             else:
                 assert np.allclose(dist[i], one_dist, rtol=1e-5, atol=1e-5)
     c.close()
+
+
+def test_batch_larger_than_one_slice(pkg, monkeypatch):
+    """batches beyond VG_BATCH_SLICE queries run slice by slice; the result does not depend on the slicing"""
+    dim, n, k, nq = 32, 3000, 5, 700
+    rows = dg.corpus(dg.F32, n, dim, 97)
+    qs = dg.corpus(dg.F32, nq, dim, 98)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    a = c.scan_topk_batch(dg.DOT, qs, k)
+    monkeypatch.setenv("VG_BATCH_SLICE", "256")
+    b = c.scan_topk_batch(dg.DOT, qs, k)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    c.close()
