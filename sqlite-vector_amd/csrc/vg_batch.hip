@@ -33,7 +33,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "vg_lists.h"
+#include "vg_batch_common.h"
 
 typedef float vgb_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -87,13 +87,6 @@ __device__ __forceinline__ void vgb_wait_lds(vgb_f32x4 &v) {        // v is usab
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
 }
 
-template <int I, int N, typename F>
-__device__ __forceinline__ void vgb_static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        vgb_static_for<I + 1, N>(f);
-    }
-}
 
 template <int NT, int MODE>
 __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
@@ -217,15 +210,10 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
         }
         return fmaxf(g, -3.0e38f);                 // also maps a NaN gate to "accept"
     };
-    // a list that is not full yet (fewer than k finite distances so far) accepts everything - up to the bound a
-    // pre-pass over other rows established (init_keys): the final k-th best can only be smaller than that
-    auto kth_distance = [](uint64_t kth) -> float {
-        return (kth == VG_EMPTY_KEY) ? INFINITY : vg_sortable_f32((uint32_t)(kth >> 32));
-    };
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
-        thr_reg[r] = a.init_keys ? kth_distance(a.init_keys[(long long)(q0 + qi) * 64 + (k - 1)]) : INFINITY;
+        thr_reg[r] = a.init_keys ? vgb_kth_distance(a.init_keys[(long long)(q0 + qi) * 64 + (k - 1)]) : INFINITY;
         qn_reg[r] = qn_w[qi];
         gate[r] = make_gate(thr_reg[r], qn_reg[r]);
         if (q0 + qi >= a.nq_real) { thr_reg[r] = -INFINITY; gate[r] = 3.0e38f; }      // padding: an all-zero query would
@@ -291,11 +279,7 @@ __global__ __launch_bounds__(VGB_THREADS, 1) void vg_batch_kernel(BatchArgs a) {
                 c = vg_readlane64(key, src);
             }
             // one LDS round trip per candidate: a key that no longer beats the tail simply changes nothing below
-            uint64_t mine = (lane < k) ? list[lane] : 0ull;
-            const uint64_t prev = vg_wave_shr1(mine);
-            mine = (mine > c) ? ((prev > c) ? prev : c) : mine;
-            if (lane < k) list[lane] = mine;
-            const float nt = kth_distance(vg_readlane64(mine, k - 1));
+            const float nt = vgb_kth_distance(vgb_list_insert(list, k, lane, c));
             if (h == hh) {
                 thr_reg[r] = fminf(nt, thr_reg[r]);          // never loosens (a pre-pass bound outlives a not-yet-full list)
                 gate[r] = make_gate(thr_reg[r], qn_reg[r]);

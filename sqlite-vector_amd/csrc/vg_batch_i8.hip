@@ -21,7 +21,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "vg_lists.h"
+#include "vg_batch_common.h"
 
 typedef int vgi_i32x16 __attribute__((ext_vector_type(16)));
 typedef int vgi_i32x4 __attribute__((ext_vector_type(4)));
@@ -62,13 +62,6 @@ template <int N>
 __device__ __forceinline__ void vgi_wait_lds(vgi_i32x4 &v) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
 }
-template <int I, int N, typename F>
-__device__ __forceinline__ void vgi_static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        vgi_static_for<I + 1, N>(f);
-    }
-}
 
 // NTB = 32-byte k-steps per row (rows up to NTB * 32 bytes)
 template <int NTB, int MODE, bool IS_U8>
@@ -105,7 +98,7 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
     uint32_t sq_part = 0, sqq_part = 0;
     {
         const uint8_t *qrow = a.queries + (long long)(q0 + x) * a.stride;
-        vgi_static_for<0, NTB>([&](auto tc) {
+        vgb_static_for<0, NTB>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             const int off = 32 * t + 16 * h;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -195,9 +188,6 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
     float thr_reg[16], gate_f[16], na_reg[16];
     const bool l2_root = a.root != 0;
     auto as_float_like = [](uint32_t v) -> float { return IS_U8 ? (float)v : (float)(int32_t)v; };
-    auto kth_distance = [](uint64_t kth) -> float {
-        return (kth == VG_EMPTY_KEY) ? INFINITY : vg_sortable_f32((uint32_t)(kth >> 32));
-    };
     // gates are supersets of "distance <= thr" (exact test in reg_insert):
     //   dot     -(float)qx <= thr          <=  qx >= floor(-thr) - 8             margin = acc + cx - (G - cq)
     //   L2      (float)(qq+xx-2qx) <= thr2 <=  qq+xx-2qx <= ceil(thr2*(1+1e-6)) + 8   margin = 2 acc - (qq - 2cq - T) - (xx - 2cx)
@@ -219,14 +209,14 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
             gate_i[r] = Gq - cq_reg[r];
         }
     };
-    vgi_static_for<0, 16>([&](auto rc) {
+    vgb_static_for<0, 16>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
         const uint32_t sq = qs_w[2 * qi], sqq = qs_w[2 * qi + 1];
         qq_reg[r] = sqq;
         cq_reg[r] = IS_U8 ? (int)(128u * sq) - 16384 * L : 0;
         na_reg[r] = sqrtf(as_float_like(sqq));
-        thr_reg[r] = a.init_keys ? kth_distance(a.init_keys[(long long)(q0 + qi) * 64 + (k - 1)]) : INFINITY;
+        thr_reg[r] = a.init_keys ? vgb_kth_distance(a.init_keys[(long long)(q0 + qi) * 64 + (k - 1)]) : INFINITY;
         set_gate(rc);
         if (q0 + qi >= a.nq_real) {                      // padding (an all-zero query ties every row at cosine 1.0)
             thr_reg[r] = -INFINITY;
@@ -263,11 +253,7 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
             const int hh = src >> 5;
             uint64_t *list = wave_lists + (q_lo + 4 * hh) * k;
             const uint64_t c = vg_readlane64(key, src);
-            uint64_t mine = (lane < k) ? list[lane] : 0ull;
-            const uint64_t prev = vg_wave_shr1(mine);
-            mine = (mine > c) ? ((prev > c) ? prev : c) : mine;
-            if (lane < k) list[lane] = mine;
-            const float nt = kth_distance(vg_readlane64(mine, k - 1));
+            const float nt = vgb_kth_distance(vgb_list_insert(list, k, lane, c));
             if (h == hh) {
                 thr_reg[r] = fminf(nt, thr_reg[r]);
                 set_gate(rc);
@@ -296,11 +282,11 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0;
         const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
-        vgi_static_for<0, BP>([&](auto tc) {
+        vgb_static_for<0, BP>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             vgi_lds_read128<1024 * t>(bq[t], baddr);
         });
-        vgi_static_for<0, NTB>([&](auto tc) {
+        vgb_static_for<0, NTB>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             constexpr int in_flight_after = (NTB - 1 - t) < (BP - 1) ? (NTB - 1 - t) : (BP - 1);
             vgi_wait_lds<in_flight_after>(bq[t % BP]);
@@ -311,7 +297,7 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
             constexpr int NTD = (NTB + 1) / 2;
             constexpr int pc_lo = (t >= NTD) ? NPIECE : (t * NPIECE + NTD - 1) / NTD;
             constexpr int pc_hi = (t >= NTD) ? NPIECE : (t + 1 == NTD ? NPIECE : ((t + 1) * NPIECE + NTD - 1) / NTD);
-            vgi_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, goff_next, cur_buf ^ 1, decltype(pcc)::value); });
+            vgb_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, goff_next, cur_buf ^ 1, decltype(pcc)::value); });
             if constexpr (t == 0) dma_stats(tile_next, cur_buf ^ 1);
         });
         // this tile's row sums (landed with the tile, one barrier ago)
@@ -325,14 +311,14 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
         if (COS) {
             const float nb = sqrtf(as_float_like(xx));
             float margin = -INFINITY;
-            vgi_static_for<0, 16>([&](auto rc) {
+            vgb_static_for<0, 16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 const float qxf = as_float_like((uint32_t)(acc[r] + cq_reg[r] + cx));
                 margin = fmaxf(margin, qxf + 1.0f - gate_f[r] * nb);
             });
             any = __ballot(margin >= 0.0f) != 0;
             if (any) {
-                vgi_static_for<0, 16>([&](auto rc) {
+                vgb_static_for<0, 16>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     const float qxf = as_float_like((uint32_t)(acc[r] + cq_reg[r] + cx));
                     pend |= __ballot(qxf + 1.0f - gate_f[r] * nb >= 0.0f) ? (1u << r) : 0u;
@@ -341,21 +327,21 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
         } else {
             const int hx = L2M ? (int)xx - 2 * cx : -cx;
             int margin = -0x7FFFFFFF;
-            vgi_static_for<0, 16>([&](auto rc) {
+            vgb_static_for<0, 16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 const int m = (L2M ? 2 * acc[r] : acc[r]) - gate_i[r] - hx;
                 margin = m > margin ? m : margin;
             });
             any = __ballot(margin >= 0) != 0;
             if (any) {
-                vgi_static_for<0, 16>([&](auto rc) {
+                vgb_static_for<0, 16>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     pend |= __ballot((L2M ? 2 * acc[r] : acc[r]) - gate_i[r] - hx >= 0) ? (1u << r) : 0u;
                 });
             }
         }
         if (pend) {
-            vgi_static_for<0, 16>([&](auto rc) {
+            vgb_static_for<0, 16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 if (pend & (1u << r)) reg_insert(rc, acc[r], row_cur, cx, xx);
             });
