@@ -440,12 +440,20 @@ static const int kAllowedU[] = {1, 2, 3, 4, 6, 8};
 
 // Pick (lanes per row, chunks per lane): cover nch chunks with lpr*U slots, wasting as few lane slots as
 // possible; prefer >= 128 contiguous bytes per row per load instruction, then U = 6/4/3 (bytes in flight per lane).
-// 2-byte types cap U at 3: their f64 arithmetic (query pre-widened to f64 in VGPRs + 8 f64 accumulators) does not
-// fit the 128-VGPR budget of a 16-wave workgroup beyond that (U=6 spilled 200 B/lane and ran at 2.3 TB/s).
 // Rows that no (lpr <= 64, U <= cap) shape covers take the long-row kernel (query in LDS, one row per wavefront).
-static bool choose_shape(int nch, int elem_bytes, Shape *out) {
+// f16 / bf16: the f64 arithmetic (4 f64 accumulators + the widening temporaries) leaves room for fewer chunks per lane
+// under the 128-VGPR cap of 16 wavefronts per CU.  The query stays in registers as RAW halves (vg_scan.h launders it
+// every batch so the compiler cannot hoist widened copies out of the loop); with that U = 6 fits for everything but
+// bf16 dot / cosine, which spill beyond U = 3 (measured 2.4 TB/s at U = 6).
+static int max_chunks_per_lane(int vtype, int acc) {
+    if (vtype == VG_TYPE_F16) return 6;
+    if (vtype == VG_TYPE_BF16) return (acc == A_L2 || acc == A_L1) ? 6 : 3;
+    return 8;
+}
+
+static bool choose_shape(int nch, int vtype, int acc, Shape *out) {
     static const int pref[9] = {0, 1, 2, 4, 5, 0, 6, 0, 3};   // preference rank by U (higher is better)
-    const int max_u = (elem_bytes == 2) ? 3 : 8;
+    const int max_u = max_chunks_per_lane(vtype, acc);
     double best_eff = -1.0; int best_flag = -1, best_pref = -1; Shape best = {0, 0, false};
     for (int l2 = 0; l2 <= 6; ++l2) {
         int lpr = 1 << l2;
@@ -564,7 +572,7 @@ extern "C" const char *vg_scan_kernel_name(vg_corpus *c, int metric) {
     if (!c) return "";
     Shape s;
     int acc = metric_to_acc(metric);
-    if (acc < 0 || !choose_shape(c->nch, c->es, &s)) return "";
+    if (acc < 0 || !choose_shape(c->nch, c->vtype, acc, &s)) return "";
     if (acc == A_COS && (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) && !s.long_rows && env_int("VG_HALF_COSN", 1)) acc = A_COSN;
     snprintf(c->kernel_name, sizeof(c->kernel_name), "scan%s_%s_%s_u%d_lpr%d%s", s.long_rows ? "_long" : "",
              type_tag(c->vtype), acc_tag(acc), s.U, 1 << s.lpr_log2, use_nt_loads(c) ? "_nt" : "");
@@ -579,7 +587,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     int acc = metric_to_acc(metric);
     if (acc < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
     Shape s;
-    choose_shape(c->nch, c->es, &s);
+    choose_shape(c->nch, c->vtype, acc, &s);
     // f16 / bf16 cosine: the row norms come from a cached vector (computed once per appended row) instead of being
     // re-accumulated in f64 on every scan - the f64 chain is what bounds these kernels, not HBM
     if (acc == A_COS && (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) && !s.long_rows && env_int("VG_HALF_COSN", 1)) {

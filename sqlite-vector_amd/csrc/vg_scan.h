@@ -57,6 +57,9 @@ __device__ inline void vg_load_batch(uint4 (&dst)[U], const uint8_t *rows, long 
     }
 }
 
+#ifndef VG_HALF_LAUNDER
+#define VG_HALF_LAUNDER 1
+#endif
 #define VG_STORE_FLOATS 1024          // store mode: distances parked in LDS per wavefront between bursts of stores
 
 template <int VT, int ACC, int U, bool NT>
@@ -117,6 +120,14 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
 
         Accum<VT, ACC> acc;
         acc.init();
+        if constexpr (VT == T_F16 || VT == T_BF16) {
+            // keep the query as RAW halves in registers: without this the compiler hoists the widened (f32 / f64)
+            // copies out of the loop - up to 48 more VGPRs per lane, which is what capped U (bytes in flight)
+            if (VG_HALF_LAUNDER) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) asm volatile("" : "+v"(q[u].x), "+v"(q[u].y), "+v"(q[u].z), "+v"(q[u].w));
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) acc.chunk(q[u], cur[u]);
         const long long row = b * rpb + rib;

@@ -370,8 +370,8 @@ def test_half_types_special_values_bit_exact(pkg, orc, vt, dim):
 
 # ------------------------------------------------------------------------------------------------- long rows
 
-@pytest.mark.parametrize("vt,dim", [(dg.F32, 2304), (dg.F32, 5000), (dg.U8, 10000), (dg.I8, 8200), (dg.F16, 2048),
-                                    (dg.BF16, 4100), (dg.F16, 1600), (dg.F32, 20000)])
+@pytest.mark.parametrize("vt,dim", [(dg.F32, 2304), (dg.F32, 5000), (dg.U8, 10000), (dg.I8, 8200), (dg.F16, 4000),
+                                    (dg.BF16, 4100), (dg.F16, 3200), (dg.F32, 20000)])
 def test_long_row_kernel_vs_oracle(pkg, orc, vt, dim):
     """rows with more 16-byte chunks than a register-resident shape covers go through vg_scan_long_kernel
     (query in LDS, one row per wavefront, sliced)."""
