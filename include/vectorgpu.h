@@ -47,6 +47,9 @@ enum {
 };
 
 typedef struct vg_corpus vg_corpus;    /* one HBM-resident N x D matrix + host rowid map, on one device */
+/* Threading: different handles may be used from different threads at the same time (each owns its stream and
+ * buffers; vg_last_error is thread-local).  ONE handle must not be used by two threads at once - the extension
+ * keeps one set of handles per connection, like the reference keeps one context per connection. */
 
 /* ---- process / device ---- */
 int         vg_device_count(void);                 /* number of visible HIP devices (0 if none) */
