@@ -254,12 +254,18 @@ static char *dup_str(const char *s) {
     return r;
 }
 
+/* the message of the last ctx_error() on this thread: callers that post-process a failure (vector_quantize rolls back
+ * and would otherwise report sqlite3_errmsg() = "not an error" for a failure that did not come from SQLite) keep it */
+static __thread char last_ctx_error[1024];
+
 static void ctx_error(sqlite3_context *ctx, int rc, const char *fmt, ...) {
     char buf[4096];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
+    strncpy(last_ctx_error, buf, sizeof(last_ctx_error) - 1);
+    last_ctx_error[sizeof(last_ctx_error) - 1] = 0;
     sqlite3_result_error(ctx, buf, -1);
     sqlite3_result_error_code(ctx, rc);
 }
@@ -968,6 +974,7 @@ static void quantize_common(sqlite3_context *ctx, const char *tbl, const char *c
     uint32_t counter = 0;
     int stamps_were_fresh = 0;
     t->full_validated = 0;
+    last_ctx_error[0] = 0;
     int rc = sqlite3_exec(db, "BEGIN;", NULL, NULL, NULL);          /* like the reference: fails inside a transaction */
     if (rc == SQLITE_OK) {
         sqlite3_snprintf(sizeof(sql), sql, "DROP TABLE IF EXISTS vector0_%q_%q;", tbl, col);
@@ -988,7 +995,7 @@ static void quantize_common(sqlite3_context *ctx, const char *tbl, const char *c
     if (rc == SQLITE_OK) rc = meta_put(ctx, tbl, col, "qscale", 0, 0, t->scale);
     if (rc == SQLITE_OK) rc = meta_put(ctx, tbl, col, "qoffset", 0, 0, t->offset);
     if (rc != SQLITE_OK) {
-        char *msg = sqlite3_mprintf("%s", sqlite3_errmsg(db));
+        char *msg = sqlite3_mprintf("%s", last_ctx_error[0] ? last_ctx_error : sqlite3_errmsg(db));
         sqlite3_exec(db, "ROLLBACK;", NULL, NULL, NULL);
         if (msg) { sqlite3_result_error(ctx, msg, -1); sqlite3_free(msg); }
         sqlite3_result_error_code(ctx, rc);

@@ -461,3 +461,69 @@ def test_concurrent_connections_from_threads(ext_path, orc):
     for th in threads:
         th.join(timeout=120)
     assert not errors, errors[:2]
+
+
+def test_vector_quantize_without_the_engine_reports_why(ext_path, tmp_path):
+    """libvectorgpu.so holds the quantizer too: when it cannot be loaded vector_quantize must fail with the loader's
+    message and leave no transaction open (it used to report SQLite's "not an error")."""
+    script = tmp_path / "q.py"
+    script.write_text(
+        "import sqlite3, sys\n"
+        "db = sqlite3.connect(':memory:', isolation_level=None)\n"
+        "db.enable_load_extension(True)\n"
+        "db.load_extension(sys.argv[1])\n"
+        "db.execute('CREATE TABLE t (id INTEGER PRIMARY KEY, v BLOB)')\n"
+        "db.execute('INSERT INTO t VALUES (1, zeroblob(16))')\n"
+        "db.execute(\"SELECT vector_init('t','v','type=FLOAT32,dimension=4')\")\n"
+        "try:\n"
+        "    db.execute(\"SELECT vector_quantize('t','v')\")\n"
+        "    print('NOERROR')\n"
+        "except sqlite3.OperationalError as e:\n"
+        "    print('ERR', e)\n"
+        "print('INTXN', db.in_transaction)\n")
+    env = dict(os.environ, VECTORGPU_LIB=str(tmp_path / "missing.so"))
+    out = subprocess.run([sys.executable, str(script), ext_path], capture_output=True, text=True, env=env).stdout
+    assert "ERR cannot load the GPU engine" in out and "INTXN False" in out, out
+
+
+RECALL_SQL = """
+WITH
+exact_knn AS (
+    SELECT e.rowid FROM t AS e JOIN vector_full_scan('t', 'v', ?1, ?2) AS v ON e.rowid = v.rowid
+),
+approx_knn AS (
+    SELECT e.rowid FROM t AS e JOIN vector_quantize_scan('t', 'v', ?1, ?2) AS v ON e.rowid = v.rowid
+),
+matches AS (SELECT COUNT(*) AS match_count FROM exact_knn WHERE rowid IN (SELECT rowid FROM approx_knn)),
+total AS (SELECT COUNT(*) AS total_count FROM exact_knn)
+SELECT (SELECT match_count FROM matches), (SELECT total_count FROM total),
+       CAST((SELECT match_count FROM matches) AS FLOAT) / CAST((SELECT total_count FROM total) AS FLOAT) AS recall;
+"""
+
+
+@pytest.mark.gpu
+def test_the_reference_recall_recipe_runs_unchanged(ext_path, orc):
+    """QUANTIZATION.md's recall query (the reference's only documented correctness recipe: the table-valued functions
+    JOINed with the base table, full scan vs quantized scan) runs as written and gives the same numbers as the
+    reference's own extension on the same table."""
+    dim, n, k = 64, 3000, 20
+    rng = np.random.default_rng(55)
+    centers = rng.standard_normal((30, dim)).astype(np.float32)
+    rows = (centers[rng.integers(0, 30, n)] + 0.15 * rng.standard_normal((n, dim))).astype(np.float32)   # clustered, like embeddings
+    queries = (centers[:5] + 0.15 * rng.standard_normal((5, dim))).astype(np.float32)
+    mine = connect(ext_path)
+    load_table(mine, rows, dg.F32, dg.COSINE)
+    mine.execute("SELECT vector_quantize('t','v')")
+    mine.execute("SELECT vector_quantize_preload('t','v')")
+    ref_path = orc.ref_extension_path("avx2")
+    ref = None
+    if ref_path:
+        ref = connect(ref_path)
+        load_table(ref, rows, dg.F32, dg.COSINE)
+        ref.execute("SELECT vector_quantize('t','v')")
+        ref.execute("SELECT vector_quantize_preload('t','v')")
+    for q in queries:
+        m, tot, recall = mine.execute(RECALL_SQL, (q.tobytes(), k)).fetchone()
+        assert tot == k and recall >= 0.8, (m, tot, recall)
+        if ref is not None:
+            assert (m, tot) == ref.execute(RECALL_SQL, (q.tobytes(), k)).fetchone()[:2]
