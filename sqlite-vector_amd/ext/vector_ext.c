@@ -138,25 +138,28 @@ static const char *gpu_error(void) {
     return G.last_error();
 }
 
-/* Which devices hold a corpus.  VECTORGPU_DEVICES = "all" | a count ("4" = devices 0..3) | a list ("0,2,5"; a device
- * may repeat).  Default: device 0.  More than one entry deals the rows block-cyclically over the devices
- * (VECTORGPU_SHARD_ROWS rows per block, default 65536) and every scan runs on all of them at once (vg_shards). */
-static int corpus_open(int vtype, int dim, vg_shards **out) {
+/* Which devices hold a corpus.  Either the vector_init option gpu_devices=... (the reference ignores unknown option
+ * keys, sqlite-vector.c:990-991, so a database initialised this way still opens there) or the environment variable
+ * VECTORGPU_DEVICES: "all" | a count ("4" = devices 0..3) | a list ("0+2+5" in the option string, "0,2,5" or "0+2+5"
+ * in the environment; a device may repeat).  Default: device 0.  More than one entry deals the rows block-cyclically
+ * over the devices (gpu_shard_rows / VECTORGPU_SHARD_ROWS rows per block, default 65536) and every scan runs on all
+ * of them at once (vg_shards). */
+static int corpus_open_spec(const char *spec, int64_t shard_rows, int vtype, int dim, vg_shards **out) {
     int devs[64], n = 0;
-    const char *e = getenv("VECTORGPU_DEVICES");
+    const char *e = (spec && *spec) ? spec : getenv("VECTORGPU_DEVICES");
     if (e && *e) {
         if (!strcasecmp(e, "all")) {
             n = G.device_count();
             if (n > 64) n = 64;
             for (int i = 0; i < n; ++i) devs[i] = i;
-        } else if (strchr(e, ',')) {
+        } else if (strchr(e, ',') || strchr(e, '+')) {
             const char *p = e;
             while (*p && n < 64) {
                 char *end;
                 long v = strtol(p, &end, 10);
                 if (end == p) break;
                 devs[n++] = (int)v;
-                p = (*end == ',') ? end + 1 : end;
+                p = (*end == ',' || *end == '+') ? end + 1 : end;
             }
         } else {
             n = atoi(e);
@@ -166,7 +169,8 @@ static int corpus_open(int vtype, int dim, vg_shards **out) {
     }
     if (n <= 0) { devs[0] = 0; n = 1; }
     const char *b = getenv("VECTORGPU_SHARD_ROWS");
-    return G.corpus_create(devs, n, vtype, dim, (b && *b) ? (int64_t)atoll(b) : 0, out);
+    if (shard_rows <= 0 && b && *b) shard_rows = (int64_t)atoll(b);
+    return G.corpus_create(devs, n, vtype, dim, shard_rows > 0 ? shard_rows : 0, out);
 }
 
 /* ------------------------------------------------------------------------------------------------ context */
@@ -178,6 +182,8 @@ typedef struct {
     int v_distance;             /* VG_DIST_* */
     int q_type;                 /* VG_QUANT_* */
     uint64_t max_memory;
+    char gpu_devices[64];       /* additions (ignored by the reference): where the corpus lives */
+    int64_t gpu_shard_rows;
 } vec_options;
 
 typedef struct {
@@ -469,6 +475,10 @@ static int option_apply(sqlite3_context *ctx, vec_options *o, const char *key, i
         int d = distance_from_name(v);
         if (!d) { ctx_error(ctx, SQLITE_ERROR, "Invalid distance name: '%s' is not a recognized or supported distance.", v); return 0; }
         o->v_distance = d;
+    } else if (!strncasecmp(key, "gpu_devices", (size_t)klen) && klen == 11) {
+        snprintf(o->gpu_devices, sizeof(o->gpu_devices), "%s", v);
+    } else if (!strncasecmp(key, "gpu_shard_rows", (size_t)klen) && klen == 14) {
+        o->gpu_shard_rows = (int64_t)strtoll(v, NULL, 0);
     }
     return 1;                                                   /* unknown keys are ignored */
 }
@@ -661,7 +671,7 @@ static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
     const int es = elem_size(t->opt.v_type), dim = t->opt.v_dim;
     const int64_t row_bytes = (int64_t)es * dim;
     if (t->full) G.corpus_clear(t->full);
-    else if (corpus_open(t->opt.v_type, dim, &t->full) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
+    else if (corpus_open_spec(t->opt.gpu_devices, t->opt.gpu_shard_rows, t->opt.v_type, dim, &t->full) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
 
     {   /* one HBM allocation of the right size instead of geometric regrowth (COUNT(*) is an upper bound: NULLs) */
         char *cnt = sqlite3_mprintf("SELECT COUNT(*) FROM %q;", t->t_name);
@@ -718,7 +728,7 @@ static int stage_quant(sqlite3 *db, table_ctx *t, int force, char **err) {
     if (!gpu_load()) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
     const int vt = (t->opt.q_type == VG_QUANT_U8) ? VG_TYPE_U8 : VG_TYPE_I8;
     if (t->quant) { G.corpus_destroy(t->quant); t->quant = NULL; }
-    if (corpus_open(vt, t->opt.v_dim, &t->quant) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
+    if (corpus_open_spec(t->opt.gpu_devices, t->opt.gpu_shard_rows, vt, t->opt.v_dim, &t->quant) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
     char sql[SQL_BUF];
     sqlite3_snprintf(sizeof(sql), sql, "SELECT counter, data FROM vector0_%q_%q;", t->t_name, t->c_name);
     sqlite3_stmt *st = NULL;

@@ -364,6 +364,11 @@ def test_extension_over_several_shards_matches_golden(ext_path, case, monkeypatc
     top = sorted(stream, key=lambda r: (r[1], r[0]))[:k]
     assert [t[0] for t in top] == [g[0] for g in got]
     monkeypatch.delenv("VECTORGPU_DEVICES")
+    # the same through the option string (the reference ignores unknown keys, so the database stays portable)
+    db2 = connect(ext_path)
+    load_table(db2, rows, vt, metric, extra=",gpu_devices=0+0,gpu_shard_rows=50")
+    got2 = db2.execute("SELECT rowid, distance FROM vector_full_scan('t','v',?,?)", (q.tobytes(), k)).fetchall()
+    assert got2 == got
     db1 = connect(ext_path)
     load_table(db1, rows, vt, metric)
     for d in (db, db1):
