@@ -1,0 +1,192 @@
+// vg_batch_api.hip - host side of the batched scans (vg_scan_topk_batch[_keys]): partition planning, the cached per-row
+// statistics of the quantized kernels, query staging, launches of vg_batch.hip / vg_batch_i8.hip, slicing of very
+// large batches, fallback to per-query scans.
+#include "vg_internal.h"
+
+#include "vg_device.h"
+
+// ---- batched queries: the MFMA path (vg_batch.hip) when the shape allows it, otherwise nq single-query scans
+extern "C" size_t vg_batch_lds_bytes(long long stride_bytes, int k);
+extern "C" int vg_batch_launch(const float *dev_rows, long long n_rows, long long stride_bytes,
+                               const float *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
+                               const float *dev_xnorm, uint64_t *dev_cand, int npart, int tiles_per_part,
+                               uint64_t *dev_out_keys, hipStream_t stream);
+extern "C" int vg_batch_lists_per_query(long long n_rows, int npart);
+extern "C" int vg_rownorm_launch(const float *dev_rows, long long row0, long long n, long long stride_bytes, float *dev_out,
+                                 hipStream_t stream);
+
+// Row norms, computed once per appended row and kept next to the corpus.  f32 corpora: ||row|| (batched cosine / L2);
+// f16 / bf16 corpora: (float) sum x^2 (single-query cosine, A_COSN).
+// ---- quantized batches on the integer matrix cores (vg_batch_i8.hip)
+extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k);
+extern "C" int vg_batch_i8_queries_per_block(void);
+extern "C" int vg_i8_rowstat_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int is_u8,
+                                    int32_t *dev_sx, uint32_t *dev_sxx, uint8_t *dev_flipped, hipStream_t stream);
+extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_rows, long long stride_bytes,
+                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root, int is_u8,
+                                  const int32_t *dev_sx, const uint32_t *dev_sxx, uint64_t *dev_cand, int npart,
+                                  int tiles_per_part, uint64_t *dev_out_keys, hipStream_t stream);
+
+static bool batch_i8_eligible(const vg_corpus *c, int metric, int k) {
+    if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
+    if (c->vtype != VG_TYPE_U8 && c->vtype != VG_TYPE_I8) return false;
+    if (metric == VG_DIST_L1) return false;
+    return vg_batch_i8_lds_bytes(c->stride, k) != 0;
+}
+
+// row sums (+ the flipped copy for uint8), once per appended row
+static int ensure_i8_row_stats(vg_corpus *c) {
+    const bool u8 = (c->vtype == VG_TYPE_U8);
+    if (c->i8_cap < c->n_rows) {
+        const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_sx) hipFree(c->d_sx);
+        if (c->d_sxx) hipFree(c->d_sxx);
+        if (c->d_rows_s8) hipFree(c->d_rows_s8);
+        c->d_sx = nullptr; c->d_sxx = nullptr; c->d_rows_s8 = nullptr; c->i8_cap = 0; c->i8_rows = 0;
+        // + one tile of slack: the batch kernel fetches the sums of a whole 32-row tile, also behind the last row
+        HIP_TRY(hipMalloc(&c->d_sx, (size_t)(cap + 64) * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&c->d_sxx, (size_t)(cap + 64) * sizeof(uint32_t)));
+        if (u8) HIP_TRY(hipMalloc(&c->d_rows_s8, (size_t)cap * c->stride));
+        c->i8_cap = cap;
+    }
+    if (c->i8_rows < c->n_rows) {
+        int rc = vg_i8_rowstat_launch(c->d_rows, c->i8_rows, c->n_rows - c->i8_rows, c->stride, u8 ? 1 : 0, c->d_sx, c->d_sxx,
+                                      c->d_rows_s8, c->stream);
+        if (rc != 0) return vg_fail(VG_ERR_HIP, "row-statistics pass failed: %s", hipGetErrorString((hipError_t)rc));
+        c->i8_rows = c->n_rows;
+    }
+    return VG_OK;
+}
+
+static bool batch_mfma_eligible(const vg_corpus *c, int metric, int k) {
+    if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
+    if (c->vtype != VG_TYPE_F32) return false;
+    if (metric == VG_DIST_L1) return false;                       // no matrix form
+    return vg_batch_lds_bytes(c->stride, k) != 0;
+}
+
+static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys,
+                                int *out_counts) {
+    const bool quantized = (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8);
+    const int QPB = quantized ? vg_batch_i8_queries_per_block() : 128;
+    const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
+    const int G = nq_pad / QPB;
+    // partitions: enough workgroups to cover the chip (G * npart ~ CUs), a multiple of 8 (one per XCD), <= 256
+    int npart = std::max(1, c->cu_count / G);
+    if (npart >= 8) npart = (npart / 8) * 8;
+    npart = std::min(npart, 256);
+    const long long ntiles = (c->n_rows + 31) / 32;
+    npart = (int)std::min<long long>(npart, ntiles);
+    const int tiles_per_part = (int)((ntiles + npart - 1) / npart);
+
+    const size_t qbytes = (size_t)nq_pad * c->stride;
+    const size_t candbytes = (size_t)nq_pad * vg_batch_lists_per_query(c->n_rows, npart) * 64 * sizeof(uint64_t);
+    const size_t keybytes = (size_t)nq_pad * 64 * sizeof(uint64_t);
+    if (c->bq_bytes < qbytes) { if (c->d_bq) hipFree(c->d_bq); c->d_bq = nullptr; c->bq_bytes = 0;
+                                HIP_TRY(hipMalloc(&c->d_bq, qbytes)); c->bq_bytes = qbytes; }
+    if (c->bcand_bytes < candbytes) { if (c->d_bcand) hipFree(c->d_bcand); c->d_bcand = nullptr; c->bcand_bytes = 0;
+                                      HIP_TRY(hipMalloc(&c->d_bcand, candbytes)); c->bcand_bytes = candbytes; }
+    if (c->bkeys_bytes < keybytes) { if (c->d_bkeys) hipFree(c->d_bkeys); c->d_bkeys = nullptr; c->bkeys_bytes = 0;
+                                     HIP_TRY(hipMalloc(&c->d_bkeys, keybytes)); c->bkeys_bytes = keybytes; }
+    // queries: zero-padded rows of the corpus stride, zero rows up to nq_pad
+    std::vector<uint8_t> hq(qbytes, 0);
+    const size_t row_bytes = (size_t)c->dim * c->es;
+    for (int i = 0; i < nq; ++i) memcpy(hq.data() + (size_t)i * c->stride, (const uint8_t *)queries + (size_t)i * row_bytes, row_bytes);
+    HIP_TRY(hipMemcpyAsync(c->d_bq, hq.data(), qbytes, hipMemcpyHostToDevice, c->stream));
+    if (quantized) {
+        int rcn = ensure_i8_row_stats(c);
+        if (rcn != VG_OK) return rcn;
+    } else if (metric != VG_DIST_DOT) {
+        int rcn = vg_ensure_row_norms(c);
+        if (rcn != VG_OK) return rcn;
+    }
+
+    hipEvent_t *evs = nullptr;
+    if (c->profiling) {
+        int slot = (int)(c->prof_launches % VG_PROF_RING);
+        evs = &c->ev[(size_t)slot * 3];
+        c->ev_had_merge[(size_t)slot] = 0;
+        ++c->prof_launches;
+        hipEventRecord(evs[0], c->stream);
+    }
+    const int mode = metric == VG_DIST_DOT ? 0 : (metric == VG_DIST_COSINE ? 1 : 2), root = metric == VG_DIST_L2 ? 1 : 0;
+    int rc;
+    if (quantized)
+        rc = vg_batch_i8_launch(c->vtype == VG_TYPE_U8 ? c->d_rows_s8 : c->d_rows, c->n_rows, c->stride, (const uint8_t *)c->d_bq,
+                                nq_pad, nq, k, mode, root, c->vtype == VG_TYPE_U8 ? 1 : 0, c->d_sx, c->d_sxx, c->d_bcand, npart,
+                                tiles_per_part, c->d_bkeys, c->stream);
+    else
+        rc = vg_batch_launch((const float *)c->d_rows, c->n_rows, c->stride, (const float *)c->d_bq, nq_pad, nq, k, mode, root,
+                             metric == VG_DIST_DOT ? nullptr : c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys,
+                             c->stream);
+    if (evs) { hipEventRecord(evs[1], c->stream); hipEventRecord(evs[2], c->stream); }
+    if (rc == -1) return -1;
+    if (rc != 0) return vg_fail(VG_ERR_HIP, "batched scan launch failed: %s", hipGetErrorString((hipError_t)rc));
+    std::vector<uint64_t> keys((size_t)nq * 64);
+    HIP_TRY(hipMemcpyAsync(keys.data(), c->d_bkeys, (size_t)nq * 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    vg_collect_timing(c);
+    for (int i = 0; i < nq; ++i) {
+        int cnt = 0;
+        for (int j = 0; j < k; ++j) {
+            uint64_t key = keys[(size_t)i * 64 + j];
+            if (key == VG_EMPTY_KEY) break;
+            out_keys[(size_t)i * k + cnt] = key;
+            ++cnt;
+        }
+        out_counts[i] = cnt;
+    }
+    return VG_OK;
+}
+
+extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys,
+                                       int *out_counts) {
+    if (!c || !queries || !out_counts) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch_keys: NULL argument");
+    if (nq <= 0) return VG_OK;
+    if (vg_metric_to_acc(metric) < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
+    for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+    if (k <= 0 || c->n_rows == 0) return VG_OK;
+    if (!out_keys) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch_keys: NULL output");
+    HIP_TRY(hipSetDevice(c->device));
+    if (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k)) {
+        // very large batches go through in slices: the per-(query, partition) candidate lists are nq x ~128 x 512 B
+        const int slice = std::max(256, env_int("VG_BATCH_SLICE", 4096));
+        int rc = VG_OK;
+        const size_t qbytes = (size_t)c->dim * c->es;
+        for (int q0 = 0; q0 < nq && rc == VG_OK; q0 += slice) {
+            const int nqs = std::min(slice, nq - q0);
+            rc = scan_topk_batch_mfma(c, metric, (const uint8_t *)queries + (size_t)q0 * qbytes, nqs, k, out_keys + (size_t)q0 * k,
+                                      out_counts + q0);
+        }
+        if (rc != -1) return rc;
+        for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+    }
+    // shapes the matrix-core kernel does not serve (other types / metrics, k > 32, rows > 512 floats):
+    // nq passes of the single-query kernel, still entirely on the GPU
+    const uint8_t *q = (const uint8_t *)queries;
+    for (int i = 0; i < nq; ++i) {
+        int rc = vg_scan_topk_keys(c, metric, q + (size_t)i * c->dim * c->es, k, out_keys + (size_t)i * k, out_counts + i);
+        if (rc != VG_OK) return rc;
+    }
+    return VG_OK;
+}
+
+extern "C" int vg_scan_topk_batch(vg_corpus *c, int metric, const void *queries, int nq, int k, int64_t *out_rowids,
+                                  double *out_dist, int *out_counts) {
+    if (!c || !queries || !out_counts) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch: NULL argument");
+    if (nq <= 0) return VG_OK;
+    for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+    if (k <= 0 || c->n_rows == 0) return VG_OK;
+    if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch: NULL output");
+    std::vector<uint64_t> keys((size_t)nq * k);
+    int rc = vg_scan_topk_batch_keys(c, metric, queries, nq, k, keys.data(), out_counts);
+    if (rc != VG_OK) return rc;
+    for (int i = 0; i < nq; ++i)
+        for (int j = 0; j < out_counts[i]; ++j) {
+            const uint64_t key = keys[(size_t)i * k + j];
+            out_dist[(size_t)i * k + j] = (double)vg_key_distance(key);
+            out_rowids[(size_t)i * k + j] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(key));
+        }
+    return VG_OK;
+}

@@ -1,0 +1,483 @@
+// vg_corpus.hip - the corpus object of the C-ABI (include/vectorgpu.h): device memory for the staged rows, the host
+// rowid map, the pinned staging pipeline, plus the small host-side helpers of the ABI that need no scan kernel (key
+// decoding / merging, the query quantizer, the vector_quantize wrappers, instrumentation read-out).
+// No distance is ever computed on the host: if the HIP runtime / a gfx950 device is missing every entry point fails
+// with VG_ERR_NO_DEVICE.
+#include "vg_internal.h"
+
+#include "vg_device.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+
+static thread_local std::string g_err;
+
+int vg_fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+extern "C" const char *vg_last_error(void) { return g_err.c_str(); }
+extern "C" void vg_set_last_error_(const char *msg) { g_err = msg ? msg : ""; }     // for vg_shards.hip
+
+extern "C" int vg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *vg_backend_name(void) {
+    static char name[128] = {0};
+    if (name[0]) return name;
+    int n = vg_device_count();
+    if (n <= 0) {
+        snprintf(name, sizeof(name), "HIP (no device)");
+        return name;
+    }
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, 0) == hipSuccess) {
+        char arch[64];
+        snprintf(arch, sizeof(arch), "%s", p.gcnArchName);
+        char *colon = strchr(arch, ':');
+        if (colon) *colon = 0;
+        snprintf(name, sizeof(name), "HIP %s x%d", arch, n);
+    } else {
+        snprintf(name, sizeof(name), "HIP");
+    }
+    return name;
+}
+
+extern "C" int vg_corpus_create(int device, int vtype, int dim, int64_t capacity_rows_hint, vg_corpus **out) {
+    if (!out) return vg_fail(VG_ERR_INVALID, "vg_corpus_create: out is NULL");
+    *out = nullptr;
+    int es = vg_elem_size(vtype);
+    if (es == 0) return vg_fail(VG_ERR_INVALID, "vg_corpus_create: unknown vector type %d", vtype);
+    if (dim <= 0) return vg_fail(VG_ERR_INVALID, "vg_corpus_create: dimension must be positive (got %d)", dim);
+    int ndev = vg_device_count();
+    if (ndev <= 0) return vg_fail(VG_ERR_NO_DEVICE, "no HIP device available (the scan path is GPU-only)");
+    if (device < 0 || device >= ndev) return vg_fail(VG_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+    int64_t row_bytes = (int64_t)dim * es;
+    if (row_bytes > 128 * 1024) return vg_fail(VG_ERR_UNSUPPORTED, "rows larger than 128 KiB are not supported (dim=%d): the query must fit the CU's 160 KiB LDS", dim);
+    HIP_TRY(hipSetDevice(device));
+    vg_corpus *c = new vg_corpus();
+    c->device = device;
+    c->vtype = vtype;
+    c->dim = dim;
+    c->es = es;
+    c->nch = (int)((row_bytes + 15) / 16);
+    c->stride = (int64_t)c->nch * 16;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) { delete c; return vg_fail(VG_ERR_HIP, "hipGetDeviceProperties failed"); }
+    c->cu_count = p.multiProcessorCount;
+    c->max_blocks = c->cu_count * 8;
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc(&c->d_query, (size_t)c->stride)) != hipSuccess ||
+        (e = hipHostMalloc(&c->h_query, (size_t)c->stride)) != hipSuccess ||
+        (e = hipMalloc(&c->d_cand, (size_t)c->max_blocks * VG_WAVE * sizeof(uint64_t))) != hipSuccess ||
+        (e = hipMalloc(&c->d_keys, VG_WAVE * sizeof(uint64_t))) != hipSuccess ||
+        (e = hipHostMalloc(&c->h_keys, VG_WAVE * sizeof(uint64_t))) != hipSuccess) {
+        vg_corpus_destroy(c);
+        return vg_fail(VG_ERR_HIP, "vg_corpus_create: device setup failed: %s", hipGetErrorString(e));
+    }
+    if (capacity_rows_hint > 0) {
+        e = hipMalloc(&c->d_rows, (size_t)(capacity_rows_hint * c->stride));
+        if (e != hipSuccess) {
+            vg_corpus_destroy(c);
+            return vg_fail(VG_ERR_NOMEM, "vg_corpus_create: cannot allocate %lld bytes of HBM: %s",
+                           (long long)(capacity_rows_hint * c->stride), hipGetErrorString(e));
+        }
+        c->cap_rows = capacity_rows_hint;
+    }
+    *out = c;
+    return VG_OK;
+}
+
+extern "C" void vg_corpus_destroy(vg_corpus *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->d_rows) hipFree(c->d_rows);
+    if (c->d_query) hipFree(c->d_query);
+    if (c->h_query) hipHostFree(c->h_query);
+    if (c->d_cand) hipFree(c->d_cand);
+    if (c->d_keys) hipFree(c->d_keys);
+    if (c->h_keys) hipHostFree(c->h_keys);
+    if (c->d_dist) hipFree(c->d_dist);
+    if (c->d_sel_keys) hipFree(c->d_sel_keys);
+    if (c->d_sel_sorted) hipFree(c->d_sel_sorted);
+    if (c->d_sel_temp) hipFree(c->d_sel_temp);
+    for (int i = 0; i < 2; ++i) { if (c->pin[i]) hipHostFree(c->pin[i]); if (c->pin_ev[i]) hipEventDestroy(c->pin_ev[i]); }
+    if (c->append_ev) hipEventDestroy(c->append_ev);
+    if (c->d_stage) hipFree(c->d_stage);
+    if (c->d_bq) hipFree(c->d_bq);
+    if (c->d_xnorm) hipFree(c->d_xnorm);
+    if (c->d_sel_state) hipFree(c->d_sel_state);
+    if (c->d_sx) hipFree(c->d_sx);
+    if (c->d_sxx) hipFree(c->d_sxx);
+    if (c->d_rows_s8) hipFree(c->d_rows_s8);
+    if (c->norm_ev) hipEventDestroy(c->norm_ev);
+    if (c->d_bcand) hipFree(c->d_bcand);
+    if (c->d_bkeys) hipFree(c->d_bkeys);
+    for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int vg_corpus_clear(vg_corpus *c) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    c->n_rows = 0;
+    c->xnorm_rows = 0;
+    c->i8_rows = 0;
+    c->rowids.clear();
+    return VG_OK;
+}
+
+extern "C" int64_t vg_corpus_rows(const vg_corpus *c) { return c ? c->n_rows : 0; }
+extern "C" int vg_corpus_dim(const vg_corpus *c) { return c ? c->dim : 0; }
+extern "C" int vg_corpus_type(const vg_corpus *c) { return c ? c->vtype : 0; }
+extern "C" int vg_corpus_device(const vg_corpus *c) { return c ? c->device : -1; }
+extern "C" int64_t vg_corpus_hbm_bytes(const vg_corpus *c) { return c ? c->cap_rows * c->stride : 0; }
+extern "C" int vg_corpus_set_rowid_base(vg_corpus *c, int64_t base) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    c->rowid_base = base;
+    return VG_OK;
+}
+extern "C" int64_t vg_corpus_rowid_at(const vg_corpus *c, int64_t position) {
+    if (!c || position < 0 || position >= c->n_rows) return 0;
+    return c->rowids.empty() ? c->rowid_base + position : c->rowids[(size_t)position];
+}
+
+static int corpus_reserve(vg_corpus *c, int64_t need_rows) {
+    if (need_rows <= c->cap_rows) return VG_OK;
+    if (need_rows >= (1ll << 32)) return vg_fail(VG_ERR_UNSUPPORTED, "a corpus shard holds at most 2^32-1 rows");
+    int64_t new_cap = std::max<int64_t>(need_rows, c->cap_rows + c->cap_rows / 2);
+    new_cap = std::max<int64_t>(new_cap, 1024);
+    uint8_t *nb = nullptr;
+    HIP_TRY(hipMalloc(&nb, (size_t)(new_cap * c->stride)));
+    if (c->n_rows > 0) {
+        hipError_t e = hipMemcpyAsync(nb, c->d_rows, (size_t)(c->n_rows * c->stride), hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(nb); return vg_fail(VG_ERR_HIP, "corpus grow copy failed: %s", hipGetErrorString(e)); }
+    }
+    if (c->d_rows) hipFree(c->d_rows);
+    c->d_rows = nb;
+    c->cap_rows = new_cap;
+    return VG_OK;
+}
+
+extern "C" int vg_corpus_reserve(vg_corpus *c, int64_t capacity_rows) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    return corpus_reserve(c, capacity_rows);
+}
+
+static void note_rowids(vg_corpus *c, const int64_t *rowids, int64_t n) {
+    if (rowids) {
+        if (c->rowids.empty() && c->n_rows > 0) {
+            c->rowids.resize((size_t)c->n_rows);
+            for (int64_t i = 0; i < c->n_rows; ++i) c->rowids[(size_t)i] = c->rowid_base + i;
+        }
+        c->rowids.insert(c->rowids.end(), rowids, rowids + n);
+    } else if (!c->rowids.empty()) {
+        for (int64_t i = 0; i < n; ++i) c->rowids.push_back(c->rowid_base + c->n_rows + i);
+    }
+}
+
+// De-interleave / pad: src rows (byte stride src_stride, payload at src_off, row_bytes long) -> 16-byte-multiple
+// rows.  One thread per destination 16-byte chunk; byte gathers because the source is arbitrarily aligned
+// (the reference's quantized records have a stride of 8+dim).
+__global__ void vg_repack_kernel(const uint8_t *src, long long src_stride, int src_off, int row_bytes,
+                                 uint8_t *dst, long long dst_stride, int nch, long long n_rows) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = n_rows * nch;
+    if (t >= total) return;
+    long long r = t / nch;
+    int ch = (int)(t - r * nch);
+    const uint8_t *s = src + r * src_stride + src_off + (long long)ch * 16;
+    int remain = row_bytes - ch * 16;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (remain >= 16 && ((reinterpret_cast<uintptr_t>(s) & 3) == 0)) {
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(s);
+        w[0] = s4[0]; w[1] = s4[1]; w[2] = s4[2]; w[3] = s4[3];
+    } else {
+        int nb = remain < 16 ? remain : 16;
+        for (int j = 0; j < nb; ++j) w[j >> 2] |= (uint32_t)s[j] << ((j & 3) * 8);
+    }
+    *reinterpret_cast<uint4 *>(dst + r * dst_stride + (long long)ch * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Host -> HBM staging pipeline: two pinned bounce buffers.  The caller's rows are memcpy'd into a pinned buffer and
+// the H2D copy (plus, when the layouts differ, the de-interleave kernel) is only ENQUEUED on the corpus stream, so
+// the call returns while the transfer runs and the caller's next sqlite3_step() batch overlaps with it.  A buffer is
+// reused only after the event recorded behind its last copy has fired.  Scans run on the same stream: ordered.
+#define VG_PIN_BYTES (16ll << 20)
+
+static int pin_acquire(vg_corpus *c, uint8_t **buf, int *slot) {
+    if (!c->pin[0]) {
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipHostMalloc(&c->pin[i], (size_t)VG_PIN_BYTES));
+            HIP_TRY(hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+        }
+        HIP_TRY(hipMalloc(&c->d_stage, (size_t)VG_PIN_BYTES));
+        HIP_TRY(hipEventCreateWithFlags(&c->append_ev, hipEventDisableTiming));
+    }
+    *slot = c->pin_idx;
+    c->pin_idx ^= 1;
+    if (c->pin_busy[*slot]) { HIP_TRY(hipEventSynchronize(c->pin_ev[*slot])); c->pin_busy[*slot] = false; }
+    *buf = c->pin[*slot];
+    return VG_OK;
+}
+
+// copies [n_rows x src_stride] host or device bytes into the padded matrix at the current end of the corpus
+static int append_impl(vg_corpus *c, const void *src, bool src_on_device, int64_t n_rows, int64_t src_stride,
+                       int src_off) {
+    const int64_t row_bytes = (int64_t)c->dim * c->es;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = corpus_reserve(c, c->n_rows + n_rows);
+    if (rc != VG_OK) return rc;
+    uint8_t *dst = c->d_rows + c->n_rows * c->stride;
+    // a plain copy is only valid when source rows have no padding of their own: padding bytes must be ZERO in HBM
+    // (they are summed like data), so any row whose size is not a 16-byte multiple goes through the repack kernel
+    const bool same_layout = (src_off == 0 && src_stride == c->stride && row_bytes == c->stride);
+    if (src_on_device) {
+        if (same_layout) {
+            HIP_TRY(hipMemcpyAsync(dst, src, (size_t)(n_rows * c->stride), hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            long long total = n_rows * c->nch;
+            hipLaunchKernelGGL(vg_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                               (const uint8_t *)src, (long long)src_stride, src_off, (int)row_bytes, dst,
+                               (long long)c->stride, c->nch, (long long)n_rows);
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));          // the caller may free / overwrite its device buffer
+        return VG_OK;
+    }
+    if (src_stride > VG_PIN_BYTES) return vg_fail(VG_ERR_UNSUPPORTED, "row stride %lld exceeds the staging buffer", (long long)src_stride);
+    const int64_t piece_rows = std::max<int64_t>(1, VG_PIN_BYTES / src_stride);
+    for (int64_t r0 = 0; r0 < n_rows; r0 += piece_rows) {
+        const int64_t nr = std::min(piece_rows, n_rows - r0);
+        const uint8_t *s = (const uint8_t *)src + r0 * src_stride;
+        // the last row may be shorter than the stride in the caller's buffer: copy only what is addressable
+        const size_t bytes = (size_t)((nr - 1) * src_stride + src_off + row_bytes);
+        uint8_t *pin;
+        int slot;
+        rc = pin_acquire(c, &pin, &slot);
+        if (rc != VG_OK) return rc;
+        memcpy(pin, s, bytes);
+        if (same_layout) {
+            HIP_TRY(hipMemcpyAsync(dst + r0 * c->stride, pin, bytes, hipMemcpyHostToDevice, c->stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(c->d_stage, pin, bytes, hipMemcpyHostToDevice, c->stream));
+            long long total = nr * c->nch;
+            hipLaunchKernelGGL(vg_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                               (const uint8_t *)c->d_stage, (long long)src_stride, src_off, (int)row_bytes,
+                               dst + r0 * c->stride, (long long)c->stride, c->nch, (long long)nr);
+        }
+        HIP_TRY(hipEventRecord(c->pin_ev[slot], c->stream));
+        c->pin_busy[slot] = true;
+    }
+    HIP_TRY(hipEventRecord(c->append_ev, c->stream));
+    c->append_pending = true;
+    HIP_TRY(hipGetLastError());
+    return VG_OK;
+}
+
+extern "C" int vg_corpus_append(vg_corpus *c, const void *host_rows, int64_t n_rows, int64_t row_stride_bytes,
+                                const int64_t *rowids) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    if (n_rows == 0) return VG_OK;
+    if (!host_rows || n_rows < 0) return vg_fail(VG_ERR_INVALID, "vg_corpus_append: bad rows pointer / count");
+    if (row_stride_bytes < (int64_t)c->dim * c->es) return vg_fail(VG_ERR_INVALID, "vg_corpus_append: stride %lld smaller than a row (%lld bytes)", (long long)row_stride_bytes, (long long)c->dim * c->es);
+    int rc = append_impl(c, host_rows, false, n_rows, row_stride_bytes, 0);
+    if (rc != VG_OK) return rc;
+    note_rowids(c, rowids, n_rows);
+    c->n_rows += n_rows;
+    return VG_OK;
+}
+
+extern "C" int vg_corpus_append_device(vg_corpus *c, const void *dev_rows, int64_t n_rows, int64_t row_stride_bytes,
+                                       const int64_t *host_rowids) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    if (n_rows == 0) return VG_OK;
+    if (!dev_rows || n_rows < 0) return vg_fail(VG_ERR_INVALID, "vg_corpus_append_device: bad rows pointer / count");
+    if (row_stride_bytes < (int64_t)c->dim * c->es) return vg_fail(VG_ERR_INVALID, "vg_corpus_append_device: stride smaller than a row");
+    int rc = append_impl(c, dev_rows, true, n_rows, row_stride_bytes, 0);
+    if (rc != VG_OK) return rc;
+    note_rowids(c, host_rowids, n_rows);
+    c->n_rows += n_rows;
+    return VG_OK;
+}
+
+extern "C" int vg_corpus_append_records(vg_corpus *c, const void *host_records, int64_t n_records) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    if (c->vtype != VG_TYPE_U8 && c->vtype != VG_TYPE_I8) return vg_fail(VG_ERR_INVALID, "vg_corpus_append_records: corpus must be UINT8 or INT8");
+    if (n_records == 0) return VG_OK;
+    if (!host_records || n_records < 0) return vg_fail(VG_ERR_INVALID, "vg_corpus_append_records: bad pointer / count");
+    const int64_t rec = 8 + (int64_t)c->dim;
+    int rc = append_impl(c, host_records, false, n_records, rec, 8);
+    if (rc != VG_OK) return rc;
+    // rowids: little-endian int64 in front of every record (sqlite-vector.c:86-94, INT64_FROM_INT8PTR)
+    std::vector<int64_t> ids((size_t)n_records);
+    const uint8_t *p = (const uint8_t *)host_records;
+    for (int64_t i = 0; i < n_records; ++i) {
+        const uint8_t *q = p + i * rec;
+        uint64_t v = 0;
+        for (int b = 0; b < 8; ++b) v |= (uint64_t)q[b] << (8 * b);
+        ids[(size_t)i] = (int64_t)v;
+    }
+    note_rowids(c, ids.data(), n_records);
+    c->n_rows += n_records;
+    return VG_OK;
+}
+extern "C" int vg_merge_keys(const uint64_t *keys, int n_lists, int list_len, const int64_t *pos_offsets, int k,
+                             int64_t *out_global_pos, double *out_dist) {
+    if (!keys || n_lists <= 0 || list_len <= 0 || k <= 0) return 0;
+    // heads-of-lists merge; lists are ascending.  Tie on distance -> lower list index first, then lower position:
+    // for contiguous row-range shards that IS global scan order.
+    std::vector<int> head((size_t)n_lists, 0);
+    int cnt = 0;
+    while (cnt < k) {
+        int best = -1;
+        uint64_t bk = VG_EMPTY_KEY;
+        for (int l = 0; l < n_lists; ++l) {
+            if (head[(size_t)l] >= list_len) continue;
+            uint64_t key = keys[(size_t)l * list_len + head[(size_t)l]];
+            if (key == VG_EMPTY_KEY) continue;
+            // compare by distance image only across lists (positions are list-local)
+            if (best < 0 || (key >> 32) < (bk >> 32)) { best = l; bk = key; }
+        }
+        if (best < 0) break;
+        out_dist[cnt] = (double)vg_key_distance(bk);
+        out_global_pos[cnt] = (pos_offsets ? pos_offsets[best] : 0) + (int64_t)vg_key_position(bk);
+        ++cnt;
+        ++head[(size_t)best];
+    }
+    return cnt;
+}
+
+// nq queries at once: keys[list][query][list_len] (what an all_gather of every rank's vg_scan_topk_batch_keys output
+// looks like) -> out_global_pos / out_dist [nq][k], out_counts [nq]
+extern "C" int vg_merge_keys_batch(const uint64_t *keys, int n_lists, int nq, int list_len, const int64_t *pos_offsets,
+                                   int k, int64_t *out_global_pos, double *out_dist, int *out_counts) {
+    if (!keys || !out_global_pos || !out_dist || !out_counts || n_lists <= 0 || nq <= 0 || list_len <= 0 || k <= 0) return -1;
+    std::vector<uint64_t> one((size_t)n_lists * list_len);
+    for (int q = 0; q < nq; ++q) {
+        for (int l = 0; l < n_lists; ++l)
+            memcpy(&one[(size_t)l * list_len], keys + ((size_t)l * nq + q) * list_len, (size_t)list_len * sizeof(uint64_t));
+        out_counts[q] = vg_merge_keys(one.data(), n_lists, list_len, pos_offsets, k, out_global_pos + (size_t)q * k, out_dist + (size_t)q * k);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ query quantizer
+// Host C, once per query.  Same arithmetic as the reference (sqlite-vector.c:495-757): s = (v - offset) * scale,
+// round half away from zero, clamp; f32 sources use the unguarded int conversion (:524-538), the other source
+// types go through the NaN/Inf-aware rounding (:495-515).
+
+static inline float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu, out;
+    if (exp == 0x1F) out = sign | 0x7F800000u | (man << 13);
+    else if (exp) out = sign | ((exp + 112u) << 23) | (man << 13);
+    else if (!man) out = sign;
+    else { float v = (float)man * 0x1.0p-24f; memcpy(&out, &v, 4); out |= sign; }
+    float f; memcpy(&f, &out, 4); return f;
+}
+static inline float bf16_to_float(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+static inline int cvt_trunc_x86(float r) {          // cvttss2si: NaN / out of range -> INT_MIN
+    if (!(r >= -2147483648.0f && r < 2147483648.0f)) return (int)0x80000000u;
+    return (int)r;
+}
+
+extern "C" int vg_quantize_query(int src_type, const void *src, int dim, float scale, float offset, int qtype, void *dst) {
+    if (!src || !dst || dim <= 0) return vg_fail(VG_ERR_INVALID, "vg_quantize_query: bad argument");
+    if (qtype != VG_QUANT_U8 && qtype != VG_QUANT_S8) return vg_fail(VG_ERR_INVALID, "vg_quantize_query: qtype must be UINT8 or INT8");
+    if (!vg_elem_size(src_type)) return vg_fail(VG_ERR_INVALID, "vg_quantize_query: unknown source type");
+    for (int i = 0; i < dim; ++i) {
+        float v;
+        switch (src_type) {
+            case VG_TYPE_F32: v = ((const float *)src)[i]; break;
+            case VG_TYPE_F16: v = half_to_float(((const uint16_t *)src)[i]); break;
+            case VG_TYPE_BF16: v = bf16_to_float(((const uint16_t *)src)[i]); break;
+            case VG_TYPE_U8: v = (float)((const uint8_t *)src)[i]; break;
+            default: v = (float)((const int8_t *)src)[i]; break;
+        }
+        float s = (v - offset) * scale;
+        float r = s + 0.5f * (1.0f - 2.0f * (s < 0.0f));
+        if (src_type == VG_TYPE_F32) {
+            int ir = cvt_trunc_x86(r);
+            if (qtype == VG_QUANT_U8) ((uint8_t *)dst)[i] = (uint8_t)(ir > 255 ? 255 : (ir < 0 ? 0 : ir));
+            else ((int8_t *)dst)[i] = (int8_t)(ir > 127 ? 127 : (ir < -128 ? -128 : ir));
+        } else if (qtype == VG_QUANT_U8) {
+            uint8_t o;
+            if (!std::isfinite(s)) o = (s > 0.0f) ? 255u : 0u;
+            else if (r >= 255.0f) o = 255u;
+            else if (r <= 0.0f) o = 0u;
+            else o = (uint8_t)(int)r;
+            ((uint8_t *)dst)[i] = o;
+        } else {
+            int8_t o;
+            if (!std::isfinite(s)) o = (s > 0.0f) ? 127 : (s < 0.0f ? -128 : 0);
+            else if (r >= 127.0f) o = 127;
+            else if (r <= -128.0f) o = -128;
+            else o = (int8_t)(int)r;
+            ((int8_t *)dst)[i] = o;
+        }
+    }
+    return VG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ corpus quantization
+// vector_quantize on the staged corpus (vg_quant.hip): min/max pass, then quantize pieces back to the host.
+
+extern "C" int vg_quant_minmax_launch(const uint8_t *rows, long long n_rows, long long stride, int dim, int vtype,
+                                      uint32_t *dev_out3, hipStream_t stream);
+extern "C" int vg_quant_quantize_launch(const uint8_t *rows, long long row0, long long n_rows, long long stride, int dim,
+                                        int vtype, float scale, float offset, int qtype_u8, uint8_t *dev_out,
+                                        hipStream_t stream);
+
+extern "C" int vg_corpus_minmax(vg_corpus *c, float *out_min, float *out_max, int *out_any_negative) {
+    if (!c || !out_min || !out_max || !out_any_negative) return vg_fail(VG_ERR_INVALID, "vg_corpus_minmax: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    uint32_t h[3] = {vg_f32_sortable(3.402823466e+38f), vg_f32_sortable(-3.402823466e+38f), 0u};
+    if (c->n_rows > 0) {
+        uint32_t *d3 = nullptr;
+        HIP_TRY(hipMalloc(&d3, sizeof(h)));
+        int rc = vg_quant_minmax_launch(c->d_rows, c->n_rows, c->stride, c->dim, c->vtype, d3, c->stream);
+        hipError_t e = (rc == 0) ? hipMemcpyAsync(h, d3, sizeof(h), hipMemcpyDeviceToHost, c->stream) : (hipError_t)rc;
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(d3);
+        if (e != hipSuccess) return vg_fail(VG_ERR_HIP, "min/max pass failed: %s", hipGetErrorString(e));
+    }
+    *out_min = vg_sortable_f32(h[0]);
+    *out_max = vg_sortable_f32(h[1]);
+    *out_any_negative = (int)h[2];
+    return VG_OK;
+}
+
+extern "C" int vg_corpus_quantize_rows(vg_corpus *c, float scale, float offset, int qtype, int64_t row0, int64_t n_rows,
+                                       uint8_t *out_host) {
+    if (!c || !out_host) return vg_fail(VG_ERR_INVALID, "vg_corpus_quantize_rows: NULL argument");
+    if (qtype != VG_QUANT_U8 && qtype != VG_QUANT_S8) return vg_fail(VG_ERR_INVALID, "vg_corpus_quantize_rows: qtype must be UINT8 or INT8");
+    if (row0 < 0 || n_rows < 0 || row0 + n_rows > c->n_rows) return vg_fail(VG_ERR_INVALID, "vg_corpus_quantize_rows: row range out of bounds");
+    if (n_rows == 0) return VG_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t piece = std::max<int64_t>(1, (256ll << 20) / c->dim);
+    uint8_t *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_out, (size_t)(std::min(piece, n_rows) * c->dim)));
+    for (int64_t r = 0; r < n_rows; r += piece) {
+        const int64_t nr = std::min(piece, n_rows - r);
+        int rc = vg_quant_quantize_launch(c->d_rows, row0 + r, nr, c->stride, c->dim, c->vtype, scale, offset,
+                                          qtype == VG_QUANT_U8 ? 1 : 0, d_out, c->stream);
+        hipError_t e = (rc == 0) ? hipMemcpyAsync(out_host + r * c->dim, d_out, (size_t)(nr * c->dim), hipMemcpyDeviceToHost, c->stream)
+                                 : (hipError_t)rc;
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(d_out); return vg_fail(VG_ERR_HIP, "quantize pass failed: %s", hipGetErrorString(e)); }
+    }
+    hipFree(d_out);
+    return VG_OK;
+}

@@ -1,0 +1,111 @@
+// vg_internal.h - what the host-side translation units of libvectorgpu.so share: the corpus object, the error
+// helpers and the few internal entry points that cross files.  Not part of the C-ABI (include/vectorgpu.h is).
+//   vg_corpus.hip     corpus lifetime + staging, key / quantizer / instrumentation helpers
+//   vg_api.hip        kernel selection, the scan launches (needs the kernel templates of vg_scan.h)
+//   vg_batch_api.hip  batched queries: planning, cached row statistics, launches of vg_batch*.hip
+#pragma once
+
+#include "../../include/vectorgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define VG_PROF_RING 1024
+#define VG_WAVE_HOST 64
+
+int vg_fail(int code, const char *fmt, ...);         // sets the thread-local message, returns code (vg_corpus.hip)
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess)                                                                            \
+            return vg_fail(e__ == hipErrorOutOfMemory ? VG_ERR_NOMEM : VG_ERR_HIP, "%s failed: %s (%s:%d)", \
+                           #expr, hipGetErrorString(e__), __FILE__, __LINE__);                            \
+    } while (0)
+
+
+static inline int vg_elem_size(int vtype) {
+    switch (vtype) {
+        case VG_TYPE_F32: return 4;
+        case VG_TYPE_F16: case VG_TYPE_BF16: return 2;
+        case VG_TYPE_U8: case VG_TYPE_I8: return 1;
+    }
+    return 0;
+}
+
+struct vg_corpus {
+    int device = 0;
+    int vtype = 0;
+    int dim = 0;
+    int es = 0;
+    int nch = 0;               // 16-byte chunks per stored row
+    int64_t stride = 0;        // bytes per stored row (nch * 16)
+    int64_t n_rows = 0;
+    int64_t cap_rows = 0;
+    uint8_t *d_rows = nullptr;
+    std::vector<int64_t> rowids;   // empty => implicit rowid_base + position
+    int64_t rowid_base = 1;
+
+    hipStream_t stream = nullptr;
+    uint8_t *d_query = nullptr;    // nch*16 bytes
+    uint8_t *h_query = nullptr;    // pinned
+    uint64_t *d_cand = nullptr;    // max_blocks * 64 keys
+    uint64_t *d_keys = nullptr;    // 64 keys
+    uint64_t *h_keys = nullptr;    // pinned, 64 keys
+    float *d_dist = nullptr;       // lazily sized to n_rows (stream scans / large k)
+    int64_t d_dist_cap = 0;
+    uint64_t *d_sel_keys = nullptr, *d_sel_sorted = nullptr;   // k > 64 path: N keys, unsorted / sorted
+    void *d_sel_temp = nullptr;
+    uint32_t *d_sel_state = nullptr;   // radix-select state + histogram (vg_select.hip)
+    size_t sel_temp_bytes = 0;
+    int64_t sel_cap = 0;
+    uint8_t *pin[2] = {nullptr, nullptr};      // staging pipeline: pinned bounce buffers + their completion events
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_busy[2] = {false, false};
+    int pin_idx = 0;
+    uint8_t *d_stage = nullptr;                // device-side landing zone for rows that need de-interleaving
+    hipEvent_t append_ev = nullptr;            // recorded behind the last enqueued host append (other streams wait on it)
+    bool append_pending = false;
+    bool enqueued = false;                     // a vg_scan_topk_enqueue is in flight (vg_scan_topk_collect pending)
+    float *d_xnorm = nullptr;                  // lazily: row norms for rows [0, xnorm_rows) (see ensure_row_norms)
+    int64_t xnorm_rows = 0, xnorm_cap = 0;
+    hipEvent_t norm_ev = nullptr;
+    // quantized batches (vg_batch_i8.hip): per-row sum x / sum x^2 and, for uint8, the XOR-0x80 copy the matrix core reads
+    int32_t *d_sx = nullptr;
+    uint32_t *d_sxx = nullptr;
+    uint8_t *d_rows_s8 = nullptr;
+    int64_t i8_rows = 0, i8_cap = 0;              // orders a caller-stream scan behind a norm pass on the corpus stream
+    void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
+    uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;
+    size_t bq_bytes = 0, bcand_bytes = 0, bkeys_bytes = 0;
+    int max_blocks = 0;
+    int cu_count = 0;
+
+    // instrumentation: a ring of event triples (before scan | after scan | after merge), recorded on the stream
+    // each launch runs on, read back only when asked - no host synchronisation inside a timed region
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;            // 3 * VG_PROF_RING events, created on first enable
+    std::vector<uint8_t> ev_had_merge;
+    long long prof_launches = 0;           // launches recorded since profiling was (re)enabled
+    float last_scan_ms = 0.f, last_merge_ms = 0.f;
+    char kernel_name[64] = {0};
+};
+
+static inline int env_int(const char *name, int dflt) {
+    const char *s = getenv(name);
+    if (!s || !*s) return dflt;
+    return atoi(s);
+}
+
+// ---- internal entry points that cross translation units
+int vg_metric_to_acc(int metric);                                  // vg_api.hip; -1 for an unknown metric
+void vg_collect_timing(vg_corpus *c);                              // vg_api.hip: event times of the last launch
+int vg_ensure_row_norms(vg_corpus *c);                             // vg_api.hip (uses the f16 / bf16 norm kernel of vg_scan.h)
