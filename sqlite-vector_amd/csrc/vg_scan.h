@@ -108,16 +108,23 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
     float *line = reinterpret_cast<float *>(smem + a.store_lds_off) + wave * VG_STORE_FLOATS;    // store mode only
     int in_line = 0;
     long long line_row0 = b * rpb;                                    // a multiple of VG_STORE_FLOATS: 16-byte aligned
-    uint4 cur[U], nxt[U];
-    vg_load_batch<U, NT>(cur, a.rows, b * rpb + rib, (b < b_end) ? a.n_rows : 0, a.stride, sub, lpr, a.nch);
-    // A_COSN: the row's squared norm rides along with the batch prefetch (one dword per row from the cached vector)
-    float nn_cur = 0.0f, nn_nxt = 0.0f;
-    if constexpr (ACC == A_COSN) { const long long r0 = b * rpb + rib; if (b < b_end && r0 < a.n_rows) nn_cur = a.row_nn[r0]; }
-    while (b < b_end) {
-        const long long bn = b + wstride;
-        vg_load_batch<U, NT>(nxt, a.rows, bn * rpb + rib, (bn < b_end) ? a.n_rows : 0, a.stride, sub, lpr, a.nch);
-        if constexpr (ACC == A_COSN) { const long long rn = bn * rpb + rib; nn_nxt = (bn < b_end && rn < a.n_rows) ? a.row_nn[rn] : 0.0f; }
-
+    // Short uint8 / int8 rows (U <= 2) use a prefetch ring: NB buffers of U chunks, the loop unrolled NB times so that
+    // every buffer keeps its registers (no copies); while buffer j is reduced the NB-1 others are in flight.  With
+    // plain double buffering such rows have 1-2 KB per wavefront in flight and sit in s_waitcnt (dim-64 uint8 rows:
+    // 4.0 -> 4.9 TB/s for L2, 4.8 -> 6.2 for dot).  Measured slower for f32 short rows and for U >= 3, which keep the
+    // double buffer.
+    constexpr bool RING = (U <= 2) && (VT == T_U8 || VT == T_I8);
+    constexpr int NB = !RING ? 2 : (U == 2) ? 4 : 6;
+    uint4 buf[NB][U];
+    float nn[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) nn[j] = 0.0f;
+    auto load = [&](uint4 (&dst)[U], float &nn_dst, long long batch) {
+        vg_load_batch<U, NT>(dst, a.rows, batch * rpb + rib, (batch < b_end) ? a.n_rows : 0, a.stride, sub, lpr, a.nch);
+        // A_COSN: the row's squared norm rides along with the batch prefetch (one dword per row from the cached vector)
+        if constexpr (ACC == A_COSN) { const long long r0 = batch * rpb + rib; nn_dst = (batch < b_end && r0 < a.n_rows) ? a.row_nn[r0] : 0.0f; }
+    };
+    auto process = [&](uint4 (&cur)[U], float nn_cur, long long bcur) {
         Accum<VT, ACC> acc;
         acc.init();
         if constexpr (VT == T_F16 || VT == T_BF16) {
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) acc.chunk(q[u], cur[u]);
-        const long long row = b * rpb + rib;
+        const long long row = bcur * rpb + rib;
         const bool owner = (sub == 0) && (row < a.n_rows);
         float d;
         if constexpr (ACC == A_COSN) d = acc.finish_cached_norm(qstat, lpr_log2, nn_cur);
@@ -154,16 +161,36 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
                     for (int j = lane; j < VG_STORE_FLOATS && line_row0 + j < a.n_rows; j += VG_WAVE) a.out_dist[line_row0 + j] = line[j];
                 }
                 in_line = 0;
-                line_row0 = bn * rpb;
+                line_row0 = (bcur + wstride) * rpb;
             }
         } else {
             // NaN and +Inf never enter (strict '<' against INFINITY-initialised slots, sqlite-vector.c:1809,2102)
             vg_list_offer(vg_make_key(d, (uint32_t)row), owner && (d < INFINITY), mine, thr, lane, k);
         }
+    };
+    if constexpr (RING) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-        nn_cur = nn_nxt;
-        b = bn;
+        for (int j = 0; j < NB - 1; ++j) load(buf[j], nn[j], b + j * wstride);
+        while (b < b_end) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const long long bj = b + j * wstride;             // the batch in buffer j
+                load(buf[(j + NB - 1) % NB], nn[(j + NB - 1) % NB], bj + (NB - 1) * wstride);
+                if (bj < b_end) process(buf[j], nn[j], bj);
+            }
+            b += NB * wstride;
+        }
+    } else {
+        load(buf[0], nn[0], b);
+        while (b < b_end) {
+            const long long bn = b + wstride;
+            load(buf[1], nn[1], bn);
+            process(buf[0], nn[0], b);
+#pragma unroll
+            for (int u = 0; u < U; ++u) buf[0][u] = buf[1][u];
+            nn[0] = nn[1];
+            b = bn;
+        }
     }
     if (store_mode) {
         // the run's last, partly filled staging area
