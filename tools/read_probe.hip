@@ -51,6 +51,14 @@ int main(int argc, char **argv) {
     hipMalloc(&sink, 4);
     hipMemset(d, 0x5A, n16 * 16);
     hipDeviceSynchronize();
+    hipDeviceProp_t pr;
+    if (hipGetDeviceProperties(&pr, 0) == hipSuccess) {
+        printf("device: %s (%s)  CUs %d  core clock %.0f MHz  memory clock %.0f MHz  bus %d bit  L2 %.1f MiB  HBM %.1f GiB\n", pr.name,
+               pr.gcnArchName, pr.multiProcessorCount, pr.clockRate / 1e3, pr.memoryClockRate / 1e3, pr.memoryBusWidth,
+               pr.l2CacheSize / 1048576.0, pr.totalGlobalMem / 1073741824.0);
+        printf("spec-sheet style peak from these: %.2f TB/s (bus/8 x memory clock x 2, DDR)\n",
+               pr.memoryBusWidth / 8.0 * pr.memoryClockRate * 1e3 * 2 / 1e12);
+    }
     printf("pure read of %.2f GB\n", n16 * 16 / 1e9);
     for (int blocks : {256, 512, 1024}) {
         run<4, true>(d, n16, sink, blocks, "U=4  nontemporal");
