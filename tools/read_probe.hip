@@ -56,8 +56,8 @@ int main(int argc, char **argv) {
         printf("device: %s (%s)  CUs %d  core clock %.0f MHz  memory clock %.0f MHz  bus %d bit  L2 %.1f MiB  HBM %.1f GiB\n", pr.name,
                pr.gcnArchName, pr.multiProcessorCount, pr.clockRate / 1e3, pr.memoryClockRate / 1e3, pr.memoryBusWidth,
                pr.l2CacheSize / 1048576.0, pr.totalGlobalMem / 1073741824.0);
-        printf("spec-sheet style peak from these: %.2f TB/s (bus/8 x memory clock x 2, DDR)\n",
-               pr.memoryBusWidth / 8.0 * pr.memoryClockRate * 1e3 * 2 / 1e12);
+        printf("peak from these: %.2f TB/s (bus / 8 x reported memory clock x 4 transfers per clock = 8 Gb/s per pin)\n",
+               pr.memoryBusWidth / 8.0 * pr.memoryClockRate * 1e3 * 4 / 1e12);
     }
     printf("pure read of %.2f GB\n", n16 * 16 / 1e9);
     for (int blocks : {256, 512, 1024}) {
