@@ -11,7 +11,7 @@
 
 typedef void (*scan_fn_t)(ScanArgs);
 
-struct Shape { int lpr_log2; int U; bool long_rows; };
+typedef VgShape Shape;
 
 static const int kAllowedU[] = {1, 2, 3, 4, 6, 8};
 
@@ -28,9 +28,9 @@ static int max_chunks_per_lane(int vtype, int acc) {
     return 8;
 }
 
-static bool choose_shape(int nch, int vtype, int acc, Shape *out) {
+bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap) {
     static const int pref[9] = {0, 1, 2, 4, 5, 0, 6, 0, 3};   // preference rank by U (higher is better)
-    const int max_u = max_chunks_per_lane(vtype, acc);
+    const int max_u = std::min(max_chunks_per_lane(vtype, acc), u_cap);
     double best_eff = -1.0; int best_flag = -1, best_pref = -1; Shape best = {0, 0, false};
     for (int l2 = 0; l2 <= 6; ++l2) {
         int lpr = 1 << l2;
@@ -50,6 +50,7 @@ static bool choose_shape(int nch, int vtype, int acc, Shape *out) {
     *out = best;
     return true;
 }
+static bool choose_shape(int nch, int vtype, int acc, Shape *out) { return vg_choose_shape(nch, vtype, acc, out, 8); }
 
 template <int VT, int ACC, bool NT>
 static scan_fn_t pick_u(int U) {
@@ -157,6 +158,22 @@ extern "C" const char *vg_scan_kernel_name(vg_corpus *c, int metric) {
 }
 
 
+
+// Final reduction of the per-CU lists (nlists <= 256) to the k best: one workgroup, parallel rank-select
+// (vg_lists.h).  out_keys receives k keys ascending, VG_EMPTY_KEY padded to 64.
+#define VG_MERGE_THREADS 1024
+__global__ __launch_bounds__(VG_MERGE_THREADS) void vg_merge_kernel(const uint64_t *cand, int nlists, int k,
+                                                                    uint64_t *out_keys) {
+    __shared__ __attribute__((aligned(16))) uint8_t scratch[VG_SEL_SCRATCH_BYTES];
+    // one workgroup per query (gridDim.x = 1 for the single-query scan, NQ for vg_scan_multi_kernel)
+    vg_select_lists(cand + (long long)blockIdx.x * nlists * VG_WAVE, nlists, k, out_keys + (long long)blockIdx.x * VG_WAVE, scratch);
+}
+
+// merge launch shared with vg_multi.hip: one workgroup per query
+int vg_launch_merge(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, int nq, hipStream_t stream) {
+    hipLaunchKernelGGL(vg_merge_kernel, dim3((unsigned)nq), dim3(VG_MERGE_THREADS), 0, stream, dev_cand, nlists, k, dev_out_keys);
+    return (int)hipGetLastError();
+}
 
 // Launch the scan (+ merge in top-k mode) on `stream`.  dev_query holds nch*16 zero-padded bytes.
 static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys,

@@ -140,6 +140,42 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     return VG_OK;
 }
 
+// nq queries, NQ per pass of the multi-query scan kernel; all passes are enqueued back to back, one wait at the end
+static int scan_topk_batch_multi(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys, int *out_counts) {
+    const int NQ = vg_multi_queries_per_pass(c, metric);
+    if (NQ == 0) return -1;
+    const int ngroups = (nq + NQ - 1) / NQ, nq_pad = ngroups * NQ;
+    const size_t qbytes = (size_t)nq_pad * c->stride, keybytes = (size_t)nq_pad * 64 * sizeof(uint64_t);
+    if (c->bq_bytes < qbytes) { if (c->d_bq) hipFree(c->d_bq); c->d_bq = nullptr; c->bq_bytes = 0;
+                                HIP_TRY(hipMalloc(&c->d_bq, qbytes)); c->bq_bytes = qbytes; }
+    if (c->bkeys_bytes < keybytes) { if (c->d_bkeys) hipFree(c->d_bkeys); c->d_bkeys = nullptr; c->bkeys_bytes = 0;
+                                     HIP_TRY(hipMalloc(&c->d_bkeys, keybytes)); c->bkeys_bytes = keybytes; }
+    std::vector<uint8_t> hq(qbytes, 0);                       // zero-padded rows of the corpus stride; pad queries are zero
+    const size_t row_bytes = (size_t)c->dim * c->es;
+    for (int i = 0; i < nq; ++i) memcpy(hq.data() + (size_t)i * c->stride, (const uint8_t *)queries + (size_t)i * row_bytes, row_bytes);
+    HIP_TRY(hipMemcpyAsync(c->d_bq, hq.data(), qbytes, hipMemcpyHostToDevice, c->stream));
+    for (int g = 0; g < ngroups; ++g) {
+        int rc = vg_launch_scan_multi(c, metric, (const uint8_t *)c->d_bq + (size_t)g * NQ * c->stride, k, c->d_cand,
+                                      c->d_bkeys + (size_t)g * NQ * 64, c->stream);
+        if (rc == -1) { hipStreamSynchronize(c->stream); return -1; }
+        if (rc != VG_OK) return rc;
+    }
+    std::vector<uint64_t> keys((size_t)nq * 64);
+    HIP_TRY(hipMemcpyAsync(keys.data(), c->d_bkeys, (size_t)nq * 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < nq; ++i) {
+        int cnt = 0;
+        for (int j = 0; j < k; ++j) {
+            const uint64_t key = keys[(size_t)i * 64 + j];
+            if (key == VG_KEY_EMPTY) break;
+            out_keys[(size_t)i * k + cnt] = key;
+            ++cnt;
+        }
+        out_counts[i] = cnt;
+    }
+    return VG_OK;
+}
+
 extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys,
                                        int *out_counts) {
     if (!c || !queries || !out_counts) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch_keys: NULL argument");
@@ -162,8 +198,14 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
         if (rc != -1) return rc;
         for (int i = 0; i < nq; ++i) out_counts[i] = 0;
     }
-    // shapes the matrix-core kernel does not serve (other types / metrics, k > 32, rows > 512 floats):
-    // nq passes of the single-query kernel, still entirely on the GPU
+    // shapes the matrix-core kernels do not serve (f16 / bf16, L1, k > 32, rows > 512 floats / 1 KiB): the multi-query
+    // scan (vg_scan_multi_kernel: 4 - or 2 for f16 / bf16 - queries share every row load of the HBM-bound pass) ...
+    if (k <= 64 && nq >= 2 && env_int("VG_MULTI_SCAN", 1)) {
+        int rc = scan_topk_batch_multi(c, metric, queries, nq, k, out_keys, out_counts);
+        if (rc != -1) return rc;
+        for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+    }
+    // ... or, when that has no kernel for the shape either (very long rows, k > 64), nq single-query scans
     const uint8_t *q = (const uint8_t *)queries;
     for (int i = 0; i < nq; ++i) {
         int rc = vg_scan_topk_keys(c, metric, q + (size_t)i * c->dim * c->es, k, out_keys + (size_t)i * k, out_counts + i);

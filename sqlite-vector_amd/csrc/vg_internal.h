@@ -109,3 +109,9 @@ static inline int env_int(const char *name, int dflt) {
 int vg_metric_to_acc(int metric);                                  // vg_api.hip; -1 for an unknown metric
 void vg_collect_timing(vg_corpus *c);                              // vg_api.hip: event times of the last launch
 int vg_ensure_row_norms(vg_corpus *c);                             // vg_api.hip (uses the f16 / bf16 norm kernel of vg_scan.h)
+struct VgShape { int lpr_log2; int U; bool long_rows; };           // launch shape of a scan: lanes per row, chunks per lane
+bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap);   // vg_api.hip
+int vg_launch_merge(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, int nq, hipStream_t stream);   // vg_api.hip
+int vg_multi_queries_per_pass(const vg_corpus *c, int metric);     // vg_multi.hip: queries per pass of the multi-query scan, 0 = none
+int vg_launch_scan_multi(vg_corpus *c, int metric, const uint8_t *dev_queries, int k, uint64_t *dev_cand,
+                         uint64_t *dev_out_keys, hipStream_t stream);   // vg_multi.hip; -1: no multi-query kernel for this shape

@@ -292,15 +292,6 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_long_kernel(ScanArgs a) {
     vg_block_publish(smem, mine, k, a.cand + (long long)blockIdx.x * VG_WAVE);
 }
 
-// Final reduction of the per-CU lists (nlists <= 256) to the k best: one workgroup, parallel rank-select
-// (vg_lists.h).  out_keys receives k keys ascending, VG_EMPTY_KEY padded to 64.
-#define VG_MERGE_THREADS 1024
-__global__ __launch_bounds__(VG_MERGE_THREADS) void vg_merge_kernel(const uint64_t *cand, int nlists, int k,
-                                                                    uint64_t *out_keys) {
-    __shared__ __attribute__((aligned(16))) uint8_t scratch[VG_SEL_SCRATCH_BYTES];
-    vg_select_lists(cand, nlists, k, out_keys, scratch);
-}
-
 
 // (float) sum x^2 per row of an f16 / bf16 corpus, accumulated exactly like AccumHalf<.., A_COS> does it during a scan
 // (f32 squares - exact for halves - widened to f64, f64 sums, one rounding to float at the end): the cosine scan then

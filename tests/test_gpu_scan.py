@@ -304,8 +304,8 @@ def test_batch_small_corpus_and_fallback_shapes(pkg, orc):
     for metric, k in ((dg.L1, 10), (dg.DOT, 40), (dg.L2, 40)):
         ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
         for i in range(5):
-            one_ids, one_dist = c.scan_topk(metric, qs[i], k)
-            assert cnt[i] == k and ids[i].tolist() == one_ids.tolist() and np.array_equal(dist[i], one_dist)
+            one_ids, one_dist = c.scan_topk(metric, qs[i], k)       # the multi-query scan may sum in another order
+            assert cnt[i] == k and ids[i].tolist() == one_ids.tolist() and np.allclose(dist[i], one_dist, rtol=1e-5, atol=1e-6)
     c.close()
     r8 = dg.corpus(dg.I8, 1500, 64, 35)
     q8 = dg.corpus(dg.I8, 4, 64, 36)
@@ -316,6 +316,36 @@ def test_batch_small_corpus_and_fallback_shapes(pkg, orc):
         one_ids, one_dist = c8.scan_topk(dg.DOT, q8[i], 10)
         assert ids[i].tolist() == one_ids.tolist() and np.array_equal(dist[i], one_dist)
     c8.close()
+
+
+@pytest.mark.parametrize("vt", [dg.F32, dg.F16, dg.BF16, dg.I8, dg.U8])
+def test_batch_multi_query_scan_vs_single_scans(pkg, orc, vt, monkeypatch):
+    """Batches the matrix-core kernels do not serve (f16 / bf16, L1, k > 32, long rows) run vg_scan_multi_kernel: 4
+    (2 for f16 / bf16) queries share every pass over the rows.  Same arithmetic per (query, row) as the single scan:
+    int8 / uint8 bit-exact, floats <= 1e-5 relative (summation order), same total order of the results."""
+    for dim, n in ((7, 300), (100, 5000), (384, 9001), (1000, 2500), (1536, 1200)):
+        rows = dg.corpus(vt, n, dim, 7000 + dim)
+        c = pkg.Corpus(vt, dim)
+        c.append(rows)
+        for metric in (dg.L2, dg.SQUARED_L2, dg.L1, dg.COSINE, dg.DOT):
+            for nq, k in ((2, 1), (5, 20), (9, 64), (3, 7000)):
+                qs = dg.corpus(vt, nq, dim, 7100 + dim + nq)
+                monkeypatch.setenv("VG_MULTI_SCAN", "1")
+                monkeypatch.setenv("VG_BATCH_MFMA", "0")
+                ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+                monkeypatch.setenv("VG_MULTI_SCAN", "0")
+                ids0, dist0, cnt0 = c.scan_topk_batch(metric, qs, k)
+                assert np.array_equal(cnt, cnt0)
+                for i in range(nq):
+                    m = cnt[i]
+                    if vt in (dg.I8, dg.U8):
+                        assert np.array_equal(ids[i][:m], ids0[i][:m]) and np.array_equal(dist[i][:m], dist0[i][:m])
+                        continue
+                    want = orc.scan_distances(orc.AVX2, metric, vt, qs[i], rows)
+                    _check_float_distances(dist[i][:m].astype(np.float32), want[ids[i][:m] - 1], vt, metric, qs[i], rows[ids[i][:m] - 1])
+                    assert np.allclose(dist[i][:m], dist0[i][:m], rtol=1e-5, atol=1e-6)
+                    assert np.all(np.diff(dist[i][:m]) >= 0)
+        c.close()
 
 
 # ------------------------------------------------------------------------------------------------- f16 / bf16
