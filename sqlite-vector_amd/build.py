@@ -19,7 +19,7 @@ EXT = os.path.join(HERE, "ext")
 LIB = os.path.join(HERE, "libvectorgpu.so")
 VEC = os.path.join(HERE, "vector.so")
 
-HIP_SOURCES = ["vg_api.hip", "vg_corpus.hip", "vg_batch_api.hip", "vg_select.hip", "vg_batch.hip", "vg_quant.hip", "vg_shards.hip", "vg_batch_i8.hip", "vg_multi.hip"]
+HIP_SOURCES = ["vg_api.hip", "vg_corpus.hip", "vg_batch_api.hip", "vg_select.hip", "vg_batch.hip", "vg_quant.hip", "vg_shards.hip", "vg_batch_i8.hip", "vg_multi.hip", "vg_batch_h.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 

@@ -27,6 +27,21 @@ extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_ro
                                   const int32_t *dev_sx, const uint32_t *dev_sxx, uint64_t *dev_cand, int npart,
                                   int tiles_per_part, uint64_t *dev_out_keys, hipStream_t stream);
 
+// ---- f16 / bf16 batches: matrix-core filter + exact f64 re-evaluation (vg_batch_h.hip)
+extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k);
+extern "C" int vg_batch_h_queries_per_block(void);
+extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long long stride_bytes, int dim, int is_bf16,
+                                 const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
+                                 const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
+                                 uint64_t *dev_out_keys, hipStream_t stream);
+
+static bool batch_h_eligible(const vg_corpus *c, int metric, int k) {
+    if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
+    if (c->vtype != VG_TYPE_F16 && c->vtype != VG_TYPE_BF16) return false;
+    if (metric == VG_DIST_L1) return false;
+    return vg_batch_h_lds_bytes(c->stride, k) != 0;
+}
+
 static bool batch_i8_eligible(const vg_corpus *c, int metric, int k) {
     if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
     if (c->vtype != VG_TYPE_U8 && c->vtype != VG_TYPE_I8) return false;
@@ -69,7 +84,8 @@ static bool batch_mfma_eligible(const vg_corpus *c, int metric, int k) {
 static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys,
                                 int *out_counts) {
     const bool quantized = (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8);
-    const int QPB = quantized ? vg_batch_i8_queries_per_block() : 128;
+    const bool half = (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16);
+    const int QPB = quantized ? vg_batch_i8_queries_per_block() : (half ? vg_batch_h_queries_per_block() : 128);
     const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
     const int G = nq_pad / QPB;
     // partitions: enough workgroups to cover the chip (G * npart ~ CUs), a multiple of 8 (one per XCD), <= 256
@@ -97,7 +113,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     if (quantized) {
         int rcn = ensure_i8_row_stats(c);
         if (rcn != VG_OK) return rcn;
-    } else if (metric != VG_DIST_DOT) {
+    } else if (half || metric != VG_DIST_DOT) {            // f16 / bf16: every metric's filter needs sum x^2 per row
         int rcn = vg_ensure_row_norms(c);
         if (rcn != VG_OK) return rcn;
     }
@@ -116,6 +132,9 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
         rc = vg_batch_i8_launch(c->vtype == VG_TYPE_U8 ? c->d_rows_s8 : c->d_rows, c->n_rows, c->stride, (const uint8_t *)c->d_bq,
                                 nq_pad, nq, k, mode, root, c->vtype == VG_TYPE_U8 ? 1 : 0, c->d_sx, c->d_sxx, c->d_bcand, npart,
                                 tiles_per_part, c->d_bkeys, c->stream);
+    else if (half)
+        rc = vg_batch_h_launch(c->d_rows, c->n_rows, c->stride, c->dim, c->vtype == VG_TYPE_BF16 ? 1 : 0, (const uint8_t *)c->d_bq,
+                               nq_pad, nq, k, mode, root, c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys, c->stream);
     else
         rc = vg_batch_launch((const float *)c->d_rows, c->n_rows, c->stride, (const float *)c->d_bq, nq_pad, nq, k, mode, root,
                              metric == VG_DIST_DOT ? nullptr : c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys,
@@ -185,7 +204,7 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     if (k <= 0 || c->n_rows == 0) return VG_OK;
     if (!out_keys) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch_keys: NULL output");
     HIP_TRY(hipSetDevice(c->device));
-    if (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k)) {
+    if (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k) || batch_h_eligible(c, metric, k)) {
         // very large batches go through in slices: the per-(query, partition) candidate lists are nq x ~128 x 512 B
         const int slice = std::max(256, env_int("VG_BATCH_SLICE", 4096));
         int rc = VG_OK;

@@ -1,0 +1,432 @@
+// vg_batch_h.hip - batched queries over an f16 / bf16 corpus: Q x C^T on the matrix cores
+// (v_mfma_f32_32x32x16_f16 / _bf16) as a FILTER, the reference's own f64 arithmetic for what passes it.
+//
+// The reference accumulates half-precision distances in f64 (distance-avx2.c:166-582) and the single-query kernel
+// (vg_scan.h, vg_half.h) follows it; that arithmetic is what bounds those scans (~6 TB/s of 8), and a batch of Q
+// queries costs Q of them.  Here the matrix core computes s~ = sum q x for 256 queries x 32 rows at a time: products of
+// two halves are exact in f32, the f32 accumulation is off by at most ~D * 2^-24 * |q| |x| (measured behaviour of the
+// instruction: tools/mfma_half_probe.hip - subnormal inputs are kept, each instruction rounds one aligned 16-term sum).
+// s~ only decides which (query, row) pairs CAN beat the query's current k-th best, with that bound (x4) as slack:
+//     dot      -(s~ + E) <= thr                     E = c |q| |x|,  c = (D + 64) * 2^-21
+//     cosine   s~ + E >= (1 - thr) |q| |x| (1 - 1e-5)
+//     L2       |q|^2 + |x|^2 - 2 (s~ + E) <= thr^2 (1 + 1e-5)         (|x|^2 per row from the corpus' cached vector)
+// Every pair that passes is re-evaluated by the whole wavefront with the single-query kernel's accumulator
+// (AccumHalf: f32 difference / product widened to f64, f64 sums, the Inf/NaN slow path of vg_half.h), so the distances
+// that reach the lists are the single scan's distances; pairs the filter cannot judge (rows or queries with Inf / NaN,
+// norms outside [1e-15, 1e15]) always pass.  After the lists have warmed up (two-pass launch as in vg_batch.hip) a
+// handful of pairs per query and partition take that path; the rest of the corpus costs one MFMA per 32 x 32 x 16 block.
+//
+// Skeleton = vg_batch_i8.hip (same operand bytes per lane: 16 bytes = 8 halves of one row per k-step): 8 wavefronts x
+// 32 queries stationary in registers, tiles of 32 rows through LDS by LDS-DMA, transposed by 16-byte chunk.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "vg_accum.h"
+#include "vg_batch_common.h"
+
+typedef _Float16 vgh_f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 vgh_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float vgh_f32x16 __attribute__((ext_vector_type(16)));
+typedef int vgh_i32x4 __attribute__((ext_vector_type(4)));
+
+#define VGH_WAVES 8
+#define VGH_THREADS (64 * VGH_WAVES)
+#define VGH_QPW 32
+#define VGH_QPB (VGH_WAVES * VGH_QPW)
+#define VGH_TILE 32
+#define VGH_MAX_K 32
+#define VGH_BPIPE 4
+#define VGH_NORM_LO 1.0e-30f            // sum x^2 outside [LO, HI] (or NaN): the filter does not judge the row / query
+#define VGH_NORM_HI 1.0e30f
+#define VGH_ACCEPT 3.0e38f
+
+enum { VGH_DOT = 0, VGH_COS = 1, VGH_L2 = 2 };
+
+struct BatchArgsH {
+    const uint8_t *rows;      // N x stride bytes (f16 / bf16 elements, zero padded to 16 bytes)
+    const uint8_t *queries;   // nq_pad x stride bytes, zero padded
+    const float *row_nn;      // (float) sum x^2 per row (vg_half_rownorm_kernel), readable up to the end of the last tile
+    uint64_t *cand;
+    long long n_rows;
+    long long stride;
+    int nq_pad, nq_real, npart, k;
+    int mode, root, dim;
+    int tiles_per_part;
+    long long tile_begin, tile_end;
+    int part_base, npart_total;
+    const uint64_t *init_keys;
+};
+
+template <int OFF>
+__device__ __forceinline__ void vgh_lds_read128(vgh_i32x4 &dst, uint32_t lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vgh_wait_lds(vgh_i32x4 &v) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
+template <int VT>
+__device__ __forceinline__ vgh_f32x16 vgh_mfma(const vgh_i32x4 &a, const vgh_i32x4 &b, const vgh_f32x16 &c) {
+    if constexpr (VT == T_F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vgh_f16x8, a), __builtin_bit_cast(vgh_f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vgh_bf16x8, a), __builtin_bit_cast(vgh_bf16x8, b), c, 0, 0, 0);
+}
+
+// NTB = 32-byte k-steps per row (rows up to NTB * 16 elements)
+template <int VT, int NTB, int MODE>
+__global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a) {
+    constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);
+    constexpr int ACC = COS ? A_COSN : (L2M ? A_L2 : A_DOT);            // the exact evaluation's accumulator
+    typedef Accum<VT, ACC> Exact;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int TILE_BYTES = NTB * 2 * 512;                           // chunk column c of the 32 rows at c * 512 + row * 16
+    uint8_t *tile0 = smem;
+    float *rstat_lds = reinterpret_cast<float *>(smem + 2 * TILE_BYTES);                 // [2 buffers][32]: sum x^2
+    double *qq_lds = reinterpret_cast<double *>(rstat_lds + 2 * 32);                     // [waves][32]: sum q^2 (f64)
+    uint32_t *qsp_lds = reinterpret_cast<uint32_t *>(qq_lds + VGH_WAVES * VGH_QPW);       // [waves][32]: query holds Inf / NaN
+    float *thr_lds = reinterpret_cast<float *>(qsp_lds + VGH_WAVES * VGH_QPW);            // [waves][32]: k-th best so far
+    uint64_t *lists = reinterpret_cast<uint64_t *>(thr_lds + VGH_WAVES * VGH_QPW);        // [waves][32][k]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = lane & 31, h = lane >> 5;
+    const int k = a.k;
+
+    const int G = a.nq_pad / VGH_QPB;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int g = idx % G;
+    const int part = (idx / G) * 8 + xcd;
+    if (part >= a.npart) return;
+    const int q0 = g * VGH_QPB + wave * VGH_QPW;
+    const int chunks_per_row = (int)(a.stride / 16);
+
+    // ---- A operand: lane (x, h) keeps bytes [32t + 16h, +16) of query x
+    vgh_i32x4 areg[NTB];
+    {
+        const uint8_t *qrow = a.queries + (long long)(q0 + x) * a.stride;
+        vgb_static_for<0, NTB>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int off = 32 * t + 16 * h;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (off < a.stride) v = *reinterpret_cast<const uint4 *>(qrow + off);
+            areg[t] = vgh_i32x4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+        });
+    }
+    // ---- per-query statistics of the exact path (the single-query kernel's query_stat with 64 lanes per row)
+    double *qq_w = qq_lds + wave * VGH_QPW;
+    uint32_t *qsp_w = qsp_lds + wave * VGH_QPW;
+    float *thr_w = thr_lds + wave * VGH_QPW;
+    uint64_t *wave_lists = lists + (size_t)wave * VGH_QPW * k;
+    for (int qi = 0; qi < VGH_QPW; ++qi) {
+        uint4 qv[1] = {make_uint4(0u, 0u, 0u, 0u)};
+        if (lane < chunks_per_row) qv[0] = reinterpret_cast<const uint4 *>(a.queries + (long long)(q0 + qi) * a.stride)[lane];
+        const typename Accum<VT, A_COSN>::QStat s = Accum<VT, A_COSN>::template query_stat<1>(qv, 6);
+        if (lane == 0) { qq_w[qi] = s.qq; qsp_w[qi] = s.qspecial; }
+    }
+    {   // a query the filter cannot judge (Inf / NaN elements, norm out of range) multiplies as ZERO: its accumulators
+        // then hold the "accept everything" start value instead of Inf / NaN, and every row takes the exact path
+        const float qqx = (float)qq_w[x];
+        if ((qsp_w[x] != 0u) || !(qqx >= VGH_NORM_LO && qqx <= VGH_NORM_HI)) {
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) areg[t] = vgh_i32x4{0, 0, 0, 0};
+        }
+    }
+    if (lane < VGH_QPW) {                               // thresholds: the pre-pass bound; padding queries never accept
+        float t = a.init_keys ? vgb_kth_distance(a.init_keys[(long long)(q0 + lane) * 64 + (k - 1)]) : INFINITY;
+        if (q0 + lane >= a.nq_real) t = -INFINITY;
+        thr_w[lane] = t;
+    }
+    for (int s = lane; s < VGH_QPW * k; s += 64) wave_lists[s] = VG_EMPTY_KEY;
+    for (int s = tid; s < 2 * TILE_BYTES / 4; s += VGH_THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = 0u;   // pad columns
+    __syncthreads();
+
+    // ---- tile streaming by LDS-DMA (vg_batch_i8.hip): piece p = chunk columns 2p, 2p+1 of all 32 rows
+    const int npieces = (chunks_per_row + 1) / 2;
+    const long long tile_first = a.tile_begin + (long long)part * a.tiles_per_part;
+    const long long tile_last = min(tile_first + a.tiles_per_part, a.tile_end);
+    const unsigned long long stride_b = (unsigned long long)a.stride;
+    const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)tile0;
+    constexpr int NPIECE = (NTB + VGH_WAVES - 1) / VGH_WAVES;
+    uint64_t piece_mask[NPIECE];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int p = wave + i * VGH_WAVES;
+        piece_mask[i] = __ballot(p < npieces && (2 * p + h) < chunks_per_row);
+    }
+    auto lane_offset = [&](long long tile) -> uint32_t {            // rows past the end re-read the last row (masked later)
+        const long long row0 = tile * VGH_TILE;
+        const long long last = a.n_rows - 1 - row0;
+        const uint32_t xr = (uint32_t)((long long)x < last ? (long long)x : last);
+        return xr * (uint32_t)a.stride + (uint32_t)h * 16u;
+    };
+    const uint32_t lds_rstat0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)rstat_lds;
+    const uint64_t stat_mask = __ballot(wave == VGH_WAVES - 1 && lane < 8);
+    const uint32_t stat_goff = (uint32_t)lane * 16u;
+    auto dma_stats = [&](long long tile, int buf) {                 // the tile's 32 row norms ride the same pipeline
+        const uint8_t *b0 = reinterpret_cast<const uint8_t *>(a.row_nn + tile * VGH_TILE);
+        const uint32_t d0 = lds_rstat0 + (uint32_t)(buf * 128);
+        uint32_t keep;
+        uint64_t keep_exec;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %5\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                     "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(keep_exec) : "v"(stat_goff), "s"(b0), "s"(d0), "s"(stat_mask) : "memory", "scc");
+    };
+    auto dma_piece = [&](long long tile, uint32_t lane_goff, int buf, int i) {
+        const int p = wave + i * VGH_WAVES;
+        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGH_TILE) * stride_b + (unsigned)p * 32u;
+        const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + p * 1024);
+        uint32_t keep;
+        uint64_t keep_exec;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_and_b64 exec, exec, %5\n\t"
+                     "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(keep_exec) : "v"(lane_goff), "s"(sbase), "s"(lds_dst), "s"(piece_mask[i]) : "memory", "scc");
+    };
+
+    // ---- per-register filter state (register r of lane (x, h) belongs to query qi(r, h) = (r&3) + 8*(r>>2) + 4*h).
+    // The accumulator of register r STARTS at init_reg[r] and the test after the k loop is
+    //     acc[r] + gmul[r] * lane_term >= 0         lane_term: |x| (dot, cosine), (1 - c)/2 |x|^2 (L2)
+    //   dot     init = thr (1 + 1e-5) + tiny        gmul = c |q|
+    //   cosine  init = 0                            gmul = -((1 - thr) |q| (1 - 1e-5 sgn) - c |q|)
+    //   L2      init = (thr2 (1 + 1e-5) - (1 - c) |q|^2) / 2 + tiny    gmul = -1
+    // "accept everything" (list not full, query the filter cannot judge) = a huge FINITE init / gmul.
+    const float cerr = (float)(a.dim + 64) * 4.76837158203125e-7f;          // (D + 64) * 2^-21
+    // Only init_reg / gmul live in registers (A alone takes up to 128 of the 256): the thresholds and the query norms
+    // they derive from stay in LDS and are read again when a list changes.
+    float init_reg[16], gmul[16];
+    const bool l2_root = a.root != 0;
+    auto set_gate = [&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float thr = thr_w[qi];
+        const float qqf = (float)qq_w[qi];
+        const float na = sqrtf(qqf);
+        const bool qforce = (qsp_w[qi] != 0u) || !(qqf >= VGH_NORM_LO && qqf <= VGH_NORM_HI);
+        const bool open = qforce || !(thr < VGH_ACCEPT);                     // +Inf / NaN threshold: accept everything
+        if (COS) {
+            const float Gf = (1.0f - thr) * na;
+            const float gq = Gf - 1e-5f * fabsf(Gf) - cerr * na;
+            init_reg[r] = 1e-30f;
+            gmul[r] = open ? VGH_ACCEPT : -gq;
+        } else if (L2M) {
+            const float thr2 = l2_root ? thr * thr : thr;
+            const float v = 0.5f * (thr2 * (1.0f + 1e-5f) - (1.0f - cerr) * qqf) + 1e-30f;
+            init_reg[r] = (open || !(v < VGH_ACCEPT)) ? VGH_ACCEPT : v;
+            gmul[r] = -1.0f;
+        } else {
+            init_reg[r] = open ? VGH_ACCEPT : thr + 1e-5f * fabsf(thr) + 1e-30f;
+            gmul[r] = qforce ? 0.0f : cerr * na;                            // (na may be NaN / Inf for such a query)
+        }
+        if (thr == -INFINITY) {                          // padding queries never pass
+            init_reg[r] = COS ? 0.0f : -VGH_ACCEPT;
+            gmul[r] = COS ? -VGH_ACCEPT : (L2M ? -1.0f : 0.0f);
+        }
+    };
+    vgb_static_for<0, 16>([&](auto rc) { set_gate(rc); });
+
+    // ---- the exact distance of ONE (query, row) pair, by the whole wavefront (wave-uniform arguments): lane c takes
+    // chunk c of the row - the single-query kernel with 64 lanes per row and one chunk per lane
+    auto exact_distance = [&](int qi_u, uint32_t row_u, float nn_u) -> float {
+        const uint8_t *qp = a.queries + (long long)(q0 + qi_u) * a.stride;
+        const uint8_t *xp = a.rows + (unsigned long long)row_u * stride_b;
+        uint4 qv = make_uint4(0u, 0u, 0u, 0u), xv = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < chunks_per_row) { qv = reinterpret_cast<const uint4 *>(qp)[lane]; xv = reinterpret_cast<const uint4 *>(xp)[lane]; }
+        typename Exact::QStat qs;
+        qs.qq = qq_w[qi_u]; qs.qspecial = qsp_w[qi_u];
+        Exact acc;
+        acc.init();
+        acc.chunk(qv, xv);
+        float d;
+        if constexpr (COS) d = acc.finish_cached_norm(qs, 6, nn_u);
+        else d = acc.finish(qs, 6, a.root);
+        // Inf / NaN in the row or the query: the reference, replayed (every lane computes the same thing; the flag is
+        // the same in all lanes too - as a declared-uniform value it keeps this branch out of the divergence analysis)
+        if (__builtin_amdgcn_readfirstlane((int)acc.special(qs, 6)) != 0)
+            d = vg_slow_distance<VT, (COS ? A_COS : ACC)>(reinterpret_cast<const uint16_t *>(qp), reinterpret_cast<const uint16_t *>(xp), a.dim, a.root);
+        return vg_clamp(d);
+    };
+    // slow path: the pairs of register r that passed the filter
+    auto reg_insert = [&](auto rc, float acc_r, long long row, float lane_term, bool force, float nn_row) {
+        constexpr int r = decltype(rc)::value;
+        const int q_lo = (r & 3) + 8 * (r >> 2);
+        const bool pass = (row < a.n_rows) && (q0 + q_lo + 4 * h < a.nq_real) && (force || fmaf(gmul[r], lane_term, acc_r) >= 0.0f);
+        unsigned long long m = __ballot(pass);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int hh = src >> 5, qi_u = q_lo + 4 * hh;
+            const uint32_t row_u = (uint32_t)__builtin_amdgcn_readlane((int)row, src);
+            const float nn_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nn_row), src));
+            const float thr_u = thr_w[qi_u];
+            // every lane holds the same value (butterfly sums): say so, or the branch below counts as divergent
+            const float de = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, exact_distance(qi_u, row_u, nn_u))));
+            // strict: rows arrive in scan order, a row that only ties the k-th best has the larger position and loses
+            if (!(de < thr_u)) continue;
+            uint64_t *list = wave_lists + qi_u * k;
+            const float nt = vgb_kth_distance(vgb_list_insert(list, k, lane, vg_make_key(de, row_u)));
+            if (nt < thr_u) {                                     // never loosens (a pre-pass bound outlives a not-yet-full list)
+                if (lane == 0) thr_w[qi_u] = nt;
+                if (h == hh) set_gate(rc);
+            }
+        }
+    };
+
+    if (tile_first < tile_last) {
+        const uint32_t goff0 = lane_offset(tile_first);
+#pragma unroll
+        for (int pc = 0; pc < NPIECE; ++pc) dma_piece(tile_first, goff0, 0, pc);
+        dma_stats(tile_first, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    constexpr int BP = VGH_BPIPE < NTB ? VGH_BPIPE : NTB;
+    vgh_i32x4 bq[BP];
+    for (long long tile = tile_first; tile < tile_last; ++tile) {
+        const int cur_buf = (int)((tile - tile_first) & 1);
+        const long long tile_next = min(tile + 1, tile_last - 1);
+        const uint32_t goff_next = lane_offset(tile_next);
+        const long long row_cur = tile * VGH_TILE + x;
+
+        vgh_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = init_reg[r];
+        const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
+        vgb_static_for<0, BP>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            vgh_lds_read128<1024 * t>(bq[t], baddr);
+        });
+        vgb_static_for<0, NTB>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int in_flight_after = (NTB - 1 - t) < (BP - 1) ? (NTB - 1 - t) : (BP - 1);
+            vgh_wait_lds<in_flight_after>(bq[t % BP]);
+            const vgh_i32x4 b = bq[t % BP];
+            acc = vgh_mfma<VT>(areg[t], b, acc);
+            if constexpr (t + BP < NTB) vgh_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
+            constexpr int NTD = (NTB + 1) / 2;                       // next tile's DMA pieces over the first half of the k loop
+            constexpr int pc_lo = (t >= NTD) ? NPIECE : (t * NPIECE + NTD - 1) / NTD;
+            constexpr int pc_hi = (t >= NTD) ? NPIECE : (t + 1 == NTD ? NPIECE : ((t + 1) * NPIECE + NTD - 1) / NTD);
+            vgb_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, goff_next, cur_buf ^ 1, decltype(pcc)::value); });
+            if constexpr (t == 0) dma_stats(tile_next, cur_buf ^ 1);
+        });
+        const float nn_row = rstat_lds[cur_buf * 32 + x];            // landed with the tile, one barrier ago
+
+        // ---- tile boundary: one fused multiply-add + max per register, one ballot
+        const bool force = !(nn_row >= VGH_NORM_LO && nn_row <= VGH_NORM_HI);   // NaN / Inf / zero / out of range
+        const float lane_term = force ? 0.0f : (L2M ? 0.5f * (1.0f - cerr) * nn_row : sqrtf(nn_row));
+        float margin = -INFINITY;
+        vgb_static_for<0, 16>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            margin = fmaxf(margin, fmaf(gmul[r], lane_term, acc[r]));
+        });
+        unsigned pend = 0;
+        if (__ballot(force || margin >= 0.0f) != 0) {
+            vgb_static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                pend |= __ballot(force || fmaf(gmul[r], lane_term, acc[r]) >= 0.0f) ? (1u << r) : 0u;
+            });
+        }
+        if (pend) {
+            vgb_static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if (pend & (1u << r)) reg_insert(rc, acc[r], row_cur, lane_term, force, nn_row);
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    for (int s = lane; s < VGH_QPW * 64; s += 64) {
+        const int qi = s >> 6, slot = s & 63;
+        a.cand[((long long)(q0 + qi) * a.npart_total + a.part_base + part) * 64 + slot] = (slot < k) ? wave_lists[qi * k + slot] : VG_EMPTY_KEY;
+    }
+}
+
+// ---- host side
+extern "C" int vg_batch_prepass_tiles(long long n_rows, int npart);                       // vg_batch.hip
+extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
+                                     uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
+
+extern "C" int vg_batch_h_queries_per_block(void) { return VGH_QPB; }
+
+static int vgh_ntb(long long stride_bytes) {
+    const int ntb = (int)((stride_bytes + 31) / 32);
+    if (ntb <= 8) return 8;
+    if (ntb <= 16) return 16;
+    if (ntb <= 24) return 24;
+    if (ntb <= 32) return 32;
+    return 0;
+}
+
+extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k) {
+    const int NTB = vgh_ntb(stride_bytes);
+    if (!NTB || k < 1 || k > VGH_MAX_K) return 0;
+    const size_t b = (size_t)2 * NTB * 1024 + 256 + (size_t)VGH_WAVES * VGH_QPW * (8 + 4 + 4) + (size_t)VGH_WAVES * VGH_QPW * k * 8;
+    return b <= 160 * 1024 ? b : 0;
+}
+
+template <int VT, int NTB, int MODE>
+static int launch_h(const BatchArgsH &a, int blocks, size_t smem, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_h_kernel<VT, NTB, MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((vg_batch_h_kernel<VT, NTB, MODE>), dim3((unsigned)blocks), dim3(VGH_THREADS), smem, stream, a);
+    return (int)hipGetLastError();
+}
+template <int VT, int NTB>
+static int launch_h_mode(const BatchArgsH &a, int blocks, size_t smem, hipStream_t stream) {
+    if (a.mode == VGH_COS) return launch_h<VT, NTB, VGH_COS>(a, blocks, smem, stream);
+    if (a.mode == VGH_L2) return launch_h<VT, NTB, VGH_L2>(a, blocks, smem, stream);
+    return launch_h<VT, NTB, VGH_DOT>(a, blocks, smem, stream);
+}
+template <int VT>
+static int launch_h_ntb(const BatchArgsH &a, int ntb, int blocks, size_t smem, hipStream_t stream) {
+    if (ntb == 8) return launch_h_mode<VT, 8>(a, blocks, smem, stream);
+    if (ntb == 16) return launch_h_mode<VT, 16>(a, blocks, smem, stream);
+    if (ntb == 24) return launch_h_mode<VT, 24>(a, blocks, smem, stream);
+    return launch_h_mode<VT, 32>(a, blocks, smem, stream);
+}
+
+// dev_rows / dev_queries: f16 (is_bf16 = 0) or bf16 elements, zero padded rows of stride_bytes; dev_row_nn: (float) sum x^2
+// per row, readable for 32 floats past the last whole tile.  Returns 0, -1 if the shape is not served, a hipError_t
+// otherwise.  dev_cand sized like the f32 kernel's (vg_batch_lists_per_query).
+extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long long stride_bytes, int dim, int is_bf16,
+                                 const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
+                                 const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
+                                 uint64_t *dev_out_keys, hipStream_t stream) {
+    const size_t smem = vg_batch_h_lds_bytes(stride_bytes, k);
+    if (!smem || nq_pad % VGH_QPB != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
+    if (mode < VGH_DOT || mode > VGH_L2 || !dev_row_nn) return -1;
+    BatchArgsH a;
+    a.rows = dev_rows; a.queries = dev_queries; a.row_nn = dev_row_nn; a.cand = dev_cand;
+    a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;
+    a.mode = mode; a.root = root; a.dim = dim;
+    const int ntb = vgh_ntb(stride_bytes);
+    const int G = nq_pad / VGH_QPB;
+    const int blocks = G * ((npart + 7) / 8) * 8;
+    const long long ntiles = (n_rows + VGH_TILE - 1) / VGH_TILE;
+    auto launch = [&](const BatchArgsH &b) -> int {
+        return is_bf16 ? launch_h_ntb<T_BF16>(b, ntb, blocks, smem, stream) : launch_h_ntb<T_F16>(b, ntb, blocks, smem, stream);
+    };
+    const long long pre = vg_batch_prepass_tiles(n_rows, npart);
+    int rc;
+    if (pre > 0) {
+        a.npart_total = 2 * npart;
+        a.tile_begin = 0; a.tile_end = pre; a.tiles_per_part = (int)(pre / npart); a.part_base = 0; a.init_keys = nullptr;
+        if ((rc = launch(a)) != 0) return rc;
+        if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream)) != 0) return rc;
+        a.tile_begin = pre; a.tile_end = ntiles; a.tiles_per_part = (int)((ntiles - pre + npart - 1) / npart);
+        a.part_base = npart; a.init_keys = dev_out_keys;
+        if ((rc = launch(a)) != 0) return rc;
+    } else {
+        a.npart_total = npart;
+        a.tile_begin = 0; a.tile_end = ntiles; a.tiles_per_part = tiles_per_part; a.part_base = 0; a.init_keys = nullptr;
+        if ((rc = launch(a)) != 0) return rc;
+    }
+    return vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, a.npart_total, k, dev_out_keys, stream);
+}

@@ -348,6 +348,73 @@ def test_batch_multi_query_scan_vs_single_scans(pkg, orc, vt, monkeypatch):
         c.close()
 
 
+def _same_topk_up_to_ties(ids, dist, ids0, dist0, rtol=1e-6):
+    """two result lists of one query agree: same distances (summation order only) and the same rows except where
+    neighbouring distances tie within that tolerance"""
+    assert len(ids) == len(ids0)
+    assert np.allclose(dist, dist0, rtol=rtol, atol=1e-7), (dist[:5], dist0[:5])
+    diff = np.nonzero(ids != ids0)[0]
+    for j in diff:
+        near = np.abs(dist0 - dist0[j]) <= rtol * np.abs(dist0[j]) + 1e-7
+        assert ids[j] in ids0[near], (j, ids[j], ids0[near], dist0[near])
+
+
+@pytest.mark.parametrize("vt", [dg.F16, dg.BF16])
+@pytest.mark.parametrize("metric", (dg.DOT, dg.COSINE, dg.L2, dg.SQUARED_L2))
+def test_batch_half_matrix_core_filter_vs_single_scans(pkg, orc, vt, metric, monkeypatch):
+    """f16 / bf16 batches: the matrix cores (v_mfma_f32_32x32x16_f16 / _bf16) only FILTER; every (query, row) pair
+    that can beat the current k-th best is re-evaluated with the single-query kernel's f64 arithmetic, so the results
+    are the single scans' results - including rows / queries with Inf, NaN, zeros, huge and subnormal values."""
+    for dim in (8, 100, 128, 384, 500, 512):
+        n = 4133
+        rows = dg.corpus(vt, n, dim, 8200 + dim)
+        _, edge = dg.edge_rows(vt, dim, 8300 + dim)                       # Inf / NaN / max / subnormal / zero rows
+        rows[100:100 + len(edge)] = edge
+        rows[2000] = rows[17]                                              # exact duplicates: ties
+        rows[3000:3010] = dg.to_storage(vt, dg.storage_to_f64(vt, rows[3000:3010]).astype(np.float32) * np.float32(1e-3))
+        c = pkg.Corpus(vt, dim)
+        c.append(rows)
+        for nq, k in ((1, 20), (7, 1), (300, 20), (40, 32)):
+            qs = dg.corpus(vt, nq, dim, 8400 + dim + nq)
+            eq = dg.edge_queries(vt, dim, 8500 + dim)
+            for i, q in enumerate(eq[:min(len(eq), nq - 1)]):
+                qs[1 + i] = q                                              # zero / Inf / NaN queries
+            qs[0] = rows[17]                                               # a query that IS a row (distance 0, twice)
+            monkeypatch.setenv("VG_BATCH_MFMA", "1")
+            ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+            monkeypatch.setenv("VG_BATCH_MFMA", "0")
+            ids0, dist0, cnt0 = c.scan_topk_batch(metric, qs, k)           # nq single-query scans
+            assert np.array_equal(cnt, cnt0)
+            for i in range(nq):
+                m = cnt[i]
+                _same_topk_up_to_ties(ids[i][:m], dist[i][:m], ids0[i][:m], dist0[i][:m])
+            want = orc.scan_distances(orc.AVX2, metric, vt, qs[0], rows)
+            m = cnt[0]
+            _check_float_distances(dist[0][:m].astype(np.float32), want[ids[0][:m] - 1], vt, metric, qs[0], rows[ids[0][:m] - 1])
+        c.close()
+
+
+@pytest.mark.parametrize("vt", [dg.F16, dg.BF16])
+def test_batch_half_two_pass_launch_and_partitions(pkg, vt, monkeypatch):
+    """enough rows for the two-pass launch (pre-pass thresholds) and many partitions; clustered data so that the
+    filter sees near-duplicates of the queries"""
+    dim, n, nq, k = 64, 2_200_000, 260, 10
+    rng = np.random.default_rng(91)
+    centers = rng.standard_normal((50, dim), dtype=np.float32)
+    rows = dg.to_storage(vt, centers[rng.integers(0, 50, n)] + 0.05 * rng.standard_normal((n, dim), dtype=np.float32))
+    qs = dg.to_storage(vt, centers[rng.integers(0, 50, nq)] + 0.05 * rng.standard_normal((nq, dim), dtype=np.float32))
+    c = pkg.Corpus(vt, dim, capacity=n)
+    c.append(rows)
+    for metric in (dg.L2, dg.COSINE, dg.DOT):
+        monkeypatch.setenv("VG_BATCH_MFMA", "1")
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        assert np.all(cnt == k)
+        for i in range(0, nq, 13):
+            one_ids, one_dist = c.scan_topk(metric, qs[i], k)
+            _same_topk_up_to_ties(ids[i], dist[i], one_ids, one_dist)
+    c.close()
+
+
 # ------------------------------------------------------------------------------------------------- f16 / bf16
 
 @pytest.mark.parametrize("vt", [dg.F16, dg.BF16])

@@ -25,22 +25,23 @@ def main():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--metric", type=int, default=4)
-    ap.add_argument("--type", type=str, default="f32", choices=("f32", "u8", "i8"))
+    ap.add_argument("--type", type=str, default="f32", choices=("f32", "u8", "i8", "f16", "bf16"))
     args = ap.parse_args()
     import torch
     torch.cuda.init()
     import __graft_entry__ as g
     pkg = g.load_package()
     n, dim = args.rows, args.dim
-    vt = {"f32": pkg.F32, "u8": pkg.U8, "i8": pkg.I8}[args.type]
+    vt = {"f32": pkg.F32, "u8": pkg.U8, "i8": pkg.I8, "f16": pkg.F16, "bf16": pkg.BF16}[args.type]
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}.get(args.type)
     es = pkg.TYPE_SIZE[vt]
     c = pkg.Corpus(vt, dim, capacity=n)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(42)
     for r0 in range(0, n, 1_000_000):
         nr = min(1_000_000, n - r0)
-        if vt == pkg.F32:
-            t = torch.randn((nr, dim), generator=gen, device="cuda", dtype=torch.float32)
+        if tdt is not None:
+            t = torch.randn((nr, dim), generator=gen, device="cuda", dtype=torch.float32).to(tdt)
         elif vt == pkg.U8:
             t = torch.randint(0, 256, (nr, dim), generator=gen, device="cuda", dtype=torch.uint8)
         else:
@@ -53,6 +54,8 @@ def main():
     for nq in [int(x) for x in args.nq.split(",")]:
         if vt == pkg.F32:
             qs = rng.standard_normal((nq, dim), dtype=np.float32)
+        elif tdt is not None:
+            qs = torch.from_numpy(rng.standard_normal((nq, dim), dtype=np.float32)).to(tdt).view(torch.int16).numpy().view(np.uint16)
         elif vt == pkg.U8:
             qs = rng.integers(0, 256, (nq, dim)).astype(np.uint8)
         else:
