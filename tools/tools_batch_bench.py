@@ -15,6 +15,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TF = 157.3
+PEAK_TF = {"f32": 157.3, "f16": 2500.0, "bf16": 2500.0, "u8": 3944.0, "i8": 3944.0}   # dense MFMA peaks (MI355X_MICROARCH.md)
 
 
 def main():
@@ -76,7 +77,7 @@ def main():
             "workload": "%d queries x %dx%d %s %s top-%d, batched MFMA" % (nq, n, dim, args.type, {1: "L2", 2: "squared L2", 3: "cosine", 4: "dot", 5: "L1"}[args.metric], args.k),
             "kernel_ms": kern_ms, "wall_ms_per_batch": wall * 1e3, "queries_per_s": nq / wall,
             "query_vector_pairs_per_s": nq * n / wall,
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_TF[args.type], "unit": "TFLOP/s", "frac": tf / PEAK_TF[args.type],
                          "flops_per_launch": flops},
             "speedup_vs_single_query_scans": (nq * 2.28e-3) / wall,
             "top20_overlap_with_single_query_path_q0": agree}), flush=True)

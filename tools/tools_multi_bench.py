@@ -17,7 +17,6 @@ sys.path.insert(0, ROOT)
 
 CASES = [  # type, dim, metric, k
     ("f32", 384, 5, 20), ("f32", 768, 1, 20), ("f32", 1536, 4, 20), ("f32", 384, 1, 50),
-    ("f16", 384, 1, 20), ("f16", 768, 3, 20), ("bf16", 384, 4, 20), ("bf16", 768, 3, 20),
     ("u8", 768, 5, 20), ("i8", 1536, 1, 20), ("u8", 128, 5, 20),
 ]
 
