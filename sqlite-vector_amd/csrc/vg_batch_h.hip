@@ -42,6 +42,9 @@ typedef int vgh_i32x4 __attribute__((ext_vector_type(4)));
 #define VGH_NORM_LO 1.0e-30f            // sum x^2 outside [LO, HI] (or NaN): the filter does not judge the row / query
 #define VGH_NORM_HI 1.0e30f
 #define VGH_ACCEPT 3.0e38f
+#ifndef VGH_ABLATE
+#define VGH_ABLATE 0                    // measurement builds (wrong results): 1 = filter computed, survivors dropped; 2 = no filter
+#endif
 
 enum { VGH_DOT = 0, VGH_COS = 1, VGH_L2 = 2 };
 
@@ -78,7 +81,10 @@ __device__ __forceinline__ vgh_f32x16 vgh_mfma(const vgh_i32x4 &a, const vgh_i32
 }
 
 // NTB = 32-byte k-steps per row (rows up to NTB * 16 elements)
-template <int VT, int NTB, int MODE>
+// BOUND = the pre-pass variant: no exact evaluation at all.  A pair that passes the filter enters its list with an UPPER
+// BOUND of its distance (the filter's own estimate plus its error bound); the k-th smallest bound of a query is then an
+// upper bound of its final k-th best distance - the start threshold of the real pass, which scans every row.
+template <int VT, int NTB, int MODE, bool BOUND>
 __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a) {
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);
     constexpr int ACC = COS ? A_COSN : (L2M ? A_L2 : A_DOT);            // the exact evaluation's accumulator
@@ -222,6 +228,10 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
             init_reg[r] = open ? VGH_ACCEPT : thr + 1e-5f * fabsf(thr) + 1e-30f;
             gmul[r] = qforce ? 0.0f : cerr * na;                            // (na may be NaN / Inf for such a query)
         }
+        if (BOUND && open) {                             // the bound pass reads s~ back out of the accumulator: it cannot
+            init_reg[r] = COS ? 1e-30f : 0.0f;           // start at 3e38; "accept everything" is a huge multiplier instead
+            gmul[r] = VGH_ACCEPT;
+        }
         if (thr == -INFINITY) {                          // padding queries never pass
             init_reg[r] = COS ? 0.0f : -VGH_ACCEPT;
             gmul[r] = COS ? -VGH_ACCEPT : (L2M ? -1.0f : 0.0f);
@@ -254,6 +264,32 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
     auto reg_insert = [&](auto rc, float acc_r, long long row, float lane_term, bool force, float nn_row) {
         constexpr int r = decltype(rc)::value;
         const int q_lo = (r & 3) + 8 * (r >> 2);
+        if constexpr (BOUND) {
+            // upper bound of the distance from the filter's estimate s~ (the accumulator minus its start value)
+            const int qi_lane = q_lo + 4 * h;
+            const float qqf = (float)qq_w[qi_lane], na = sqrtf(qqf), nb = sqrtf(nn_row);
+            const float st = acc_r - init_reg[r], E = cerr * na * nb;
+            float ub;
+            if (COS) ub = fminf(1.0f - st / (na * nb) + cerr + 1e-5f, 2.0f);
+            else if (L2M) { const float d2 = fmaxf(qqf + nn_row - 2.0f * st + 2.0f * E + 1e-5f * (qqf + nn_row), 0.0f); ub = l2_root ? sqrtf(d2) : d2; }
+            else ub = -st + E;
+            ub = ub + 1e-5f * fabsf(ub) + 4.76837158203125e-7f * fabsf(init_reg[r]) + 1e-30f;   // (+ what s~ lost next to the start value)
+            const bool qforce = (qsp_w[qi_lane] != 0u) || !(qqf >= VGH_NORM_LO && qqf <= VGH_NORM_HI);
+            const bool ok = (row < a.n_rows) && (q0 + qi_lane < a.nq_real) && !force && !qforce && (ub < thr_w[qi_lane]);
+            unsigned long long mb = __ballot(ok);
+            const uint64_t key = vg_make_key(ub, (uint32_t)row);
+            while (mb) {
+                const int src = __ffsll((long long)mb) - 1;
+                mb &= mb - 1;
+                const int hh = src >> 5, qi_u = q_lo + 4 * hh;
+                const float nt = vgb_kth_distance(vgb_list_insert(wave_lists + qi_u * k, k, lane, vg_readlane64(key, src)));
+                if (nt < thr_w[qi_u]) {
+                    if (lane == 0) thr_w[qi_u] = nt;
+                    if (h == hh) set_gate(rc);
+                }
+            }
+            return;
+        }
         const bool pass = (row < a.n_rows) && (q0 + q_lo + 4 * h < a.nq_real) && (force || fmaf(gmul[r], lane_term, acc_r) >= 0.0f);
         unsigned long long m = __ballot(pass);
         while (m) {
@@ -325,12 +361,13 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
             margin = fmaxf(margin, fmaf(gmul[r], lane_term, acc[r]));
         });
         unsigned pend = 0;
-        if (__ballot(force || margin >= 0.0f) != 0) {
+        if (VGH_ABLATE != 2 && __ballot(force || margin >= 0.0f) != 0) {
             vgb_static_for<0, 16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 pend |= __ballot(force || fmaf(gmul[r], lane_term, acc[r]) >= 0.0f) ? (1u << r) : 0u;
             });
         }
+        if (VGH_ABLATE == 1) { if (pend) asm volatile("" :: "s"(pend)); pend = 0; }
         if (pend) {
             vgb_static_for<0, 16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
@@ -348,7 +385,6 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
 }
 
 // ---- host side
-extern "C" int vg_batch_prepass_tiles(long long n_rows, int npart);                       // vg_batch.hip
 extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
                                      uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
 
@@ -370,26 +406,26 @@ extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k) {
     return b <= 160 * 1024 ? b : 0;
 }
 
-template <int VT, int NTB, int MODE>
+template <int VT, int NTB, int MODE, bool BOUND>
 static int launch_h(const BatchArgsH &a, int blocks, size_t smem, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_h_kernel<VT, NTB, MODE>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_h_kernel<VT, NTB, MODE, BOUND>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((vg_batch_h_kernel<VT, NTB, MODE>), dim3((unsigned)blocks), dim3(VGH_THREADS), smem, stream, a);
+    hipLaunchKernelGGL((vg_batch_h_kernel<VT, NTB, MODE, BOUND>), dim3((unsigned)blocks), dim3(VGH_THREADS), smem, stream, a);
     return (int)hipGetLastError();
 }
-template <int VT, int NTB>
+template <int VT, int NTB, bool BOUND>
 static int launch_h_mode(const BatchArgsH &a, int blocks, size_t smem, hipStream_t stream) {
-    if (a.mode == VGH_COS) return launch_h<VT, NTB, VGH_COS>(a, blocks, smem, stream);
-    if (a.mode == VGH_L2) return launch_h<VT, NTB, VGH_L2>(a, blocks, smem, stream);
-    return launch_h<VT, NTB, VGH_DOT>(a, blocks, smem, stream);
+    if (a.mode == VGH_COS) return launch_h<VT, NTB, VGH_COS, BOUND>(a, blocks, smem, stream);
+    if (a.mode == VGH_L2) return launch_h<VT, NTB, VGH_L2, BOUND>(a, blocks, smem, stream);
+    return launch_h<VT, NTB, VGH_DOT, BOUND>(a, blocks, smem, stream);
 }
-template <int VT>
+template <int VT, bool BOUND>
 static int launch_h_ntb(const BatchArgsH &a, int ntb, int blocks, size_t smem, hipStream_t stream) {
-    if (ntb == 8) return launch_h_mode<VT, 8>(a, blocks, smem, stream);
-    if (ntb == 16) return launch_h_mode<VT, 16>(a, blocks, smem, stream);
-    if (ntb == 24) return launch_h_mode<VT, 24>(a, blocks, smem, stream);
-    return launch_h_mode<VT, 32>(a, blocks, smem, stream);
+    if (ntb == 8) return launch_h_mode<VT, 8, BOUND>(a, blocks, smem, stream);
+    if (ntb == 16) return launch_h_mode<VT, 16, BOUND>(a, blocks, smem, stream);
+    if (ntb == 24) return launch_h_mode<VT, 24, BOUND>(a, blocks, smem, stream);
+    return launch_h_mode<VT, 32, BOUND>(a, blocks, smem, stream);
 }
 
 // dev_rows / dev_queries: f16 (is_bf16 = 0) or bf16 elements, zero padded rows of stride_bytes; dev_row_nn: (float) sum x^2
@@ -410,23 +446,32 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long
     const int G = nq_pad / VGH_QPB;
     const int blocks = G * ((npart + 7) / 8) * 8;
     const long long ntiles = (n_rows + VGH_TILE - 1) / VGH_TILE;
-    auto launch = [&](const BatchArgsH &b) -> int {
-        return is_bf16 ? launch_h_ntb<T_BF16>(b, ntb, blocks, smem, stream) : launch_h_ntb<T_F16>(b, ntb, blocks, smem, stream);
+    auto launch = [&](const BatchArgsH &b, bool bound) -> int {
+        if (bound) return is_bf16 ? launch_h_ntb<T_BF16, true>(b, ntb, blocks, smem, stream) : launch_h_ntb<T_F16, true>(b, ntb, blocks, smem, stream);
+        return is_bf16 ? launch_h_ntb<T_BF16, false>(b, ntb, blocks, smem, stream) : launch_h_ntb<T_F16, false>(b, ntb, blocks, smem, stream);
     };
-    const long long pre = vg_batch_prepass_tiles(n_rows, npart);
-    int rc;
-    if (pre > 0) {
-        a.npart_total = 2 * npart;
-        a.tile_begin = 0; a.tile_end = pre; a.tiles_per_part = (int)(pre / npart); a.part_base = 0; a.init_keys = nullptr;
-        if ((rc = launch(a)) != 0) return rc;
-        if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream)) != 0) return rc;
-        a.tile_begin = pre; a.tile_end = ntiles; a.tiles_per_part = (int)((ntiles - pre + npart - 1) / npart);
-        a.part_base = npart; a.init_keys = dev_out_keys;
-        if ((rc = launch(a)) != 0) return rc;
-    } else {
-        a.npart_total = npart;
-        a.tile_begin = 0; a.tile_end = ntiles; a.tiles_per_part = tiles_per_part; a.part_base = 0; a.init_keys = nullptr;
-        if ((rc = launch(a)) != 0) return rc;
+    // Large corpora: a BOUND pre-pass over the first 1/32 of the rows gives every query an upper bound of its final
+    // k-th best distance (no exact evaluations - with thresholds starting at +Inf they were a quarter of the whole
+    // time); the real pass then scans EVERY row starting from those thresholds.  (1/16 .. 1/32 measured best: 11.7 ms
+    // at 1024 x 10M x 384; 1/64 12.2, 1/8 12.4, 1/4 13.9.)
+    long long pre = 0;
+    {
+        const char *e = getenv("VG_BATCH_PREPASS");
+        const int denom = (e && *e) ? atoi(e) : 32;
+        if (denom > 0 && ntiles >= 65536) pre = ((ntiles / denom + npart - 1) / npart) * npart;      // whole partitions; < 2M rows: one pass
     }
-    return vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, a.npart_total, k, dev_out_keys, stream);
+    int rc;
+    a.npart_total = npart;                                        // both passes write (and the merges read) lists 0 .. npart-1
+    a.part_base = 0;
+    if (pre > 0) {
+        a.tile_begin = 0; a.tile_end = pre; a.tiles_per_part = (int)(pre / npart); a.init_keys = nullptr;
+        if ((rc = launch(a, true)) != 0) return rc;
+        if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream)) != 0) return rc;
+        a.init_keys = dev_out_keys;
+    } else {
+        a.init_keys = nullptr;
+    }
+    a.tile_begin = 0; a.tile_end = ntiles; a.tiles_per_part = (int)((ntiles + npart - 1) / npart);
+    if ((rc = launch(a, false)) != 0) return rc;
+    return vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream);
 }

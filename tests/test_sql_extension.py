@@ -330,6 +330,27 @@ def test_batch_tvf_equals_one_statement_per_query(ext_path, metric):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("vt", [dg.F16, dg.BF16])
+def test_half_precision_batch_tvf_equals_one_statement_per_query(ext_path, vt):
+    """f16 / bf16 tables: the batch takes the matrix-core filter + exact re-evaluation (vg_batch_h.hip) and must give
+    what one vector_full_scan statement per query gives (same f64 arithmetic, another summation order)."""
+    n, dim, k, nq = 6000, 200, 9, 11
+    rows = dg.corpus(vt, n, dim, 41)
+    qs = np.stack([dg.query(vt, dim, 300 + i) for i in range(nq)])
+    for metric in (dg.L2, dg.COSINE, dg.DOT):
+        db = connect(ext_path)
+        load_table(db, rows, vt, metric)
+        got = db.execute("SELECT query, id, distance FROM vector_full_scan_batch('t','v',?,?)", (qs.tobytes(), k)).fetchall()
+        assert len(got) == nq * k
+        for i in range(nq):
+            one = db.execute("SELECT id, distance FROM vector_full_scan('t','v',?,?)", (qs[i].tobytes(), k)).fetchall()
+            mine = [(g[1], g[2]) for g in got if g[0] == i]
+            assert [m[0] for m in mine] == [o[0] for o in one]
+            assert np.allclose([m[1] for m in mine], [o[1] for o in one], rtol=1e-6, atol=1e-7)
+        db.close()
+
+
+@pytest.mark.gpu
 def test_quantized_batch_tvf_equals_one_statement_per_query(ext_path):
     n, dim, k, nq = 3000, 64, 5, 4
     rows = np.abs(dg.corpus(dg.F32, n, dim, 31))
