@@ -48,6 +48,23 @@ typedef int vgh_i32x4 __attribute__((ext_vector_type(4)));
 
 enum { VGH_DOT = 0, VGH_COS = 1, VGH_L2 = 2 };
 
+#ifndef VGH_TIMING
+#define VGH_TIMING 0                    // measurement builds (tools/tools_half_timing.py): where a wavefront's time goes
+#endif
+#if VGH_TIMING
+// s_memtime ticks summed over all wavefronts: k loop | filter | survivors | DMA wait | barrier | whole kernel | wave-tiles |
+// (exact evaluations << 32) + wave-tiles with survivors
+__device__ unsigned long long vgh_ticks[8];
+extern "C" int vg_batch_h_timing(unsigned long long *out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(vgh_ticks), sizeof(vgh_ticks)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vgh_ticks), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define VGH_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define VGH_TICK(var)
+#endif
+
 struct BatchArgsH {
     const uint8_t *rows;      // N x stride bytes (f16 / bf16 elements, zero padded to 16 bytes)
     const uint8_t *queries;   // nq_pad x stride bytes, zero padded
@@ -194,6 +211,9 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
                      : "=&s"(keep), "=&s"(keep_exec) : "v"(lane_goff), "s"(sbase), "s"(lds_dst), "s"(piece_mask[i]) : "memory", "scc");
     };
 
+    // (every lambda of this kernel is always_inline: left to its heuristics the compiler may keep one of the survivor-path
+    // lambdas as a real function, which puts everything it captures - gates, A - in scratch memory and makes the tile
+    // counter a VGPR, i.e. breaks the "s" operands of the DMA asm)
     // ---- per-register filter state (register r of lane (x, h) belongs to query qi(r, h) = (r&3) + 8*(r>>2) + 4*h).
     // The accumulator of register r STARTS at init_reg[r] and the test after the k loop is
     //     acc[r] + gmul[r] * lane_term >= 0         lane_term: |x| (dot, cosine), (1 - c)/2 |x|^2 (L2)
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
     // they derive from stay in LDS and are read again when a list changes.
     float init_reg[16], gmul[16];
     const bool l2_root = a.root != 0;
-    auto set_gate = [&](auto rc) {
+    auto set_gate = [&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
         const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
         const float thr = thr_w[qi];
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
 
     // ---- the exact distance of ONE (query, row) pair, by the whole wavefront (wave-uniform arguments): lane c takes
     // chunk c of the row - the single-query kernel with 64 lanes per row and one chunk per lane
-    auto exact_distance = [&](int qi_u, uint32_t row_u, float nn_u) -> float {
+    auto exact_distance = [&](int qi_u, uint32_t row_u, float nn_u) __attribute__((always_inline)) -> float {
         const uint8_t *qp = a.queries + (long long)(q0 + qi_u) * a.stride;
         const uint8_t *xp = a.rows + (unsigned long long)row_u * stride_b;
         uint4 qv = make_uint4(0u, 0u, 0u, 0u), xv = make_uint4(0u, 0u, 0u, 0u);
@@ -260,8 +280,12 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
             d = vg_slow_distance<VT, (COS ? A_COS : ACC)>(reinterpret_cast<const uint16_t *>(qp), reinterpret_cast<const uint16_t *>(xp), a.dim, a.root);
         return vg_clamp(d);
     };
+    bool bound_changed = false;
+#if VGH_TIMING
+    unsigned long long tk_cnt = 0;
+#endif
     // slow path: the pairs of register r that passed the filter
-    auto reg_insert = [&](auto rc, float acc_r, long long row, float lane_term, bool force, float nn_row) {
+    auto reg_insert = [&](auto rc, float acc_r, long long row, float lane_term, bool force, float nn_row) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
         const int q_lo = (r & 3) + 8 * (r >> 2);
         if constexpr (BOUND) {
@@ -283,11 +307,9 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
                 mb &= mb - 1;
                 const int hh = src >> 5, qi_u = q_lo + 4 * hh;
                 const float nt = vgb_kth_distance(vgb_list_insert(wave_lists + qi_u * k, k, lane, vg_readlane64(key, src)));
-                if (nt < thr_w[qi_u]) {
-                    if (lane == 0) thr_w[qi_u] = nt;
-                    if (h == hh) set_gate(rc);
-                }
-            }
+                if (lane == 0 && nt < thr_w[qi_u]) thr_w[qi_u] = nt;     // (the test above reads it back; the gates of
+            }                                                            //  the filter are refreshed once per tile)
+            bound_changed |= (__ballot(ok) != 0);
             return;
         }
         const bool pass = (row < a.n_rows) && (q0 + q_lo + 4 * h < a.nq_real) && (force || fmaf(gmul[r], lane_term, acc_r) >= 0.0f);
@@ -301,6 +323,9 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
             const float thr_u = thr_w[qi_u];
             // every lane holds the same value (butterfly sums): say so, or the branch below counts as divergent
             const float de = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, exact_distance(qi_u, row_u, nn_u))));
+#if VGH_TIMING
+            tk_cnt += 1ull << 32;
+#endif
             // strict: rows arrive in scan order, a row that only ties the k-th best has the larger position and loses
             if (!(de < thr_u)) continue;
             uint64_t *list = wave_lists + qi_u * k;
@@ -323,7 +348,12 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
 
     constexpr int BP = VGH_BPIPE < NTB ? VGH_BPIPE : NTB;
     vgh_i32x4 bq[BP];
+#if VGH_TIMING
+    unsigned long long tk_loop = 0, tk_gate = 0, tk_surv = 0, tk_dma = 0, tk_bar = 0;
+    const unsigned long long tk_begin = __builtin_readcyclecounter();
+#endif
     for (long long tile = tile_first; tile < tile_last; ++tile) {
+        VGH_TICK(t0);
         const int cur_buf = (int)((tile - tile_first) & 1);
         const long long tile_next = min(tile + 1, tile_last - 1);
         const uint32_t goff_next = lane_offset(tile_next);
@@ -351,6 +381,10 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
             if constexpr (t == 0) dma_stats(tile_next, cur_buf ^ 1);
         });
         const float nn_row = rstat_lds[cur_buf * 32 + x];            // landed with the tile, one barrier ago
+#if VGH_TIMING
+        asm volatile("s_nop 0" :: "v"(acc[15]));                      // the k loop's last MFMA has retired
+#endif
+        VGH_TICK(t1);
 
         // ---- tile boundary: one fused multiply-add + max per register, one ballot
         const bool force = !(nn_row >= VGH_NORM_LO && nn_row <= VGH_NORM_HI);   // NaN / Inf / zero / out of range
@@ -368,15 +402,37 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
             });
         }
         if (VGH_ABLATE == 1) { if (pend) asm volatile("" :: "s"(pend)); pend = 0; }
+        VGH_TICK(t2);
+#if VGH_TIMING
+        if (pend) tk_cnt += 1;
+#endif
         if (pend) {
             vgb_static_for<0, 16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
                 if (pend & (1u << r)) reg_insert(rc, acc[r], row_cur, lane_term, force, nn_row);
             });
         }
+        if constexpr (BOUND) {
+            if (bound_changed) { vgb_static_for<0, 16>([&](auto rc) { set_gate(rc); }); bound_changed = false; }
+        }
+        VGH_TICK(t3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VGH_TICK(t4);
         __syncthreads();
+#if VGH_TIMING
+        const unsigned long long t5 = __builtin_readcyclecounter();
+        tk_loop += t1 - t0; tk_gate += t2 - t1; tk_surv += t3 - t2; tk_dma += t4 - t3; tk_bar += t5 - t4;
+#endif
     }
+#if VGH_TIMING
+    if (lane == 0) {
+        atomicAdd(&vgh_ticks[0], tk_loop); atomicAdd(&vgh_ticks[1], tk_gate); atomicAdd(&vgh_ticks[2], tk_surv);
+        atomicAdd(&vgh_ticks[3], tk_dma); atomicAdd(&vgh_ticks[4], tk_bar);
+        atomicAdd(&vgh_ticks[5], __builtin_readcyclecounter() - tk_begin);
+        atomicAdd(&vgh_ticks[6], (unsigned long long)(tile_last - tile_first));
+        atomicAdd(&vgh_ticks[7], tk_cnt);
+    }
+#endif
 
     for (int s = lane; s < VGH_QPW * 64; s += 64) {
         const int qi = s >> 6, slot = s & 63;

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Where a wavefront of the half-precision batch kernel spends its time (needs a -DVGH_TIMING=1 build of
+vg_batch_h.hip: tools/build_half_variants.sh timing -DVGH_TIMING=1; VG_LIB_PATH=.../libvectorgpu_timing.so).
+    python tools/tools_half_timing.py [--rows 10000000] [--dim 384] [--nq 1024] [--type f16] [--metric 4]"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--nq", type=int, default=1024)
+    ap.add_argument("--metric", type=int, default=4)
+    ap.add_argument("--type", default="f16", choices=("f16", "bf16"))
+    args = ap.parse_args()
+    import torch
+    torch.cuda.init()
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    lib = pkg.lib()
+    tdt = torch.float16 if args.type == "f16" else torch.bfloat16
+    vt = pkg.F16 if args.type == "f16" else pkg.BF16
+    c = pkg.Corpus(vt, args.dim, capacity=args.rows)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(42)
+    for r0 in range(0, args.rows, 1_000_000):
+        nr = min(1_000_000, args.rows - r0)
+        t = torch.randn((nr, args.dim), generator=gen, device="cuda", dtype=torch.float32).to(tdt)
+        torch.cuda.synchronize()
+        c.append_device(t.data_ptr(), nr, args.dim * 2)
+        del t
+    rng = np.random.default_rng(44)
+    qs = torch.from_numpy(rng.standard_normal((args.nq, args.dim), dtype=np.float32)).to(tdt).view(torch.int16).numpy().view(np.uint16)
+    c.scan_topk_batch(args.metric, qs, 20)
+    out = (C.c_ulonglong * 8)()
+    lib.vg_batch_h_timing(out, 1)
+    c.set_profiling(True)
+    c.scan_topk_batch(args.metric, qs, 20)
+    lib.vg_batch_h_timing(out, 0)
+    v = [int(x) for x in out]
+    names = ["k loop", "filter", "survivors", "DMA wait", "barrier"]
+    tot = sum(v[:5])
+    print("kernel ms (events):", c.profile_mean_ms()[1], " wave-tiles:", v[6], " ticks per wave-tile:", tot / max(v[6], 1))
+    for n, x in zip(names, v[:5]):
+        print("  %-10s %5.1f %%   %8.1f ticks per wave-tile" % (n, 100.0 * x / tot, x / max(v[6], 1)))
+    print("  whole kernel vs sum of phases: %.3f" % (v[5] / tot))
+    print("  wave-tiles with survivors: %.2f %%   exact evaluations: %d (%.2f per query and partition-list of the run)" %
+          (100.0 * (v[7] & 0xFFFFFFFF) / max(v[6], 1), v[7] >> 32, (v[7] >> 32) / max(args.nq, 1)))
+    c.close()
+
+
+if __name__ == "__main__":
+    main()
