@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - vectors scanned / second for the sqlite-vector hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b|c5h]
 
 Workload (BASELINE.json): configs[1] = 10M x 384 f32, L2, top-20, single query, corpus resident in HBM.
 A "step" is ONE complete query: upload the query, scan the whole shard, reduce to k candidates, bring the k keys
@@ -41,7 +41,10 @@ WORKLOADS = {
     "c5": (1, np.float32, 384, 4, "batched 1024 queries x 10Mx384 f32 dot top-20 (MFMA Q x C^T + fused top-k)"),
     # the quantized counterpart of c5 (not a BASELINE config): config #3's corpus, a batch of queries, int8 matrix cores
     "c3b": (4, np.uint8, 768, 3, "batched 1024 queries x 10Mx768 u8 quantized cosine top-20 (int8 MFMA Q x C^T + fused top-k)"),
+    # c5 over an f16 corpus (not a BASELINE config): matrix cores as a filter, the reference's f64 arithmetic for survivors
+    "c5h": (2, np.float16, 384, 4, "batched 1024 queries x 10Mx384 f16 dot top-20 (f16 MFMA filter + exact f64 re-evaluation + fused top-k)"),
 }
+F16_MFMA_PEAK_TF = 2500.0      # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
 I8_MFMA_PEAK_TOPS = 3944.0     # int8 MFMA: no spec figure in the guide, its micro-benchmark ceiling (>= 3944 TOP/s)
 
@@ -71,6 +74,8 @@ def make_shard(pkg, torch, vt, dim, n_rows, seed, device):
         nr = min(block, n_rows - r0)
         if vt == pkg.F32:
             t = torch.randn((nr, dim), generator=gen, device="cuda", dtype=torch.float32)
+        elif vt == pkg.F16:
+            t = torch.randn((nr, dim), generator=gen, device="cuda", dtype=torch.float32).to(torch.float16)
         else:
             t = torch.randint(0, 256, (nr, dim), generator=gen, device="cuda", dtype=torch.uint8)
         torch.cuda.synchronize()
@@ -145,12 +150,15 @@ def bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc, dist=N
     nq = args.batch
     rng = np.random.default_rng(44)
     steps, warmup = min(args.steps, 10), min(args.warmup, 2)
-    quantized = corpus.vtype != pkg.F32
+    quantized = corpus.vtype in (pkg.U8, pkg.I8)
+    half = corpus.vtype == pkg.F16
     if quantized:
         batches = [rng.integers(0, 256, (nq, dim)).astype(np.uint8) for _ in range(2)]
+    elif half:
+        batches = [rng.standard_normal((nq, dim), dtype=np.float32).astype(np.float16) for _ in range(2)]
     else:
         batches = [rng.standard_normal((nq, dim), dtype=np.float32) for _ in range(2)]
-    peak = I8_MFMA_PEAK_TOPS if quantized else F32_MFMA_PEAK_TF
+    peak = I8_MFMA_PEAK_TOPS if quantized else (F16_MFMA_PEAK_TF if half else F32_MFMA_PEAK_TF)
     use_dist = dist is not None
     offsets = [i * n_rows for i in range(n_gpus)]
     gathered = torch.empty((n_gpus, nq, k), dtype=torch.int64, device="cuda") if use_dist else None
@@ -188,16 +196,18 @@ def bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc, dist=N
     tf = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
     if rank == 0:
         print(json.dumps({
-            "metric": "vectors scanned/sec (query x vector pairs), batched %s" % ("quantized cosine top-20 over Nx768 u8" if quantized else "dot top-20 over Nx384 f32"),
+            "metric": "vectors scanned/sec (query x vector pairs), batched %s" % ("quantized cosine top-20 over Nx768 u8" if quantized else
+                                                                                  ("dot top-20 over Nx384 f16" if half else "dot top-20 over Nx384 f32")),
             "value": nq * n_rows * n_gpus * steps / elapsed, "unit": "vectors/s", "n_gpus": n_gpus, "steps": steps,
             "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8" if quantized else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8" if quantized else ("f16" if half else "f32"), "data": "synthetic",
             "config": {"workload": desc, "rows_per_gpu": n_rows, "dim": dim, "k": k, "queries_per_batch": nq,
                        "sharding": "row-range shard per GPU, RCCL all_gather of nq x k candidate keys per rank" if n_gpus > 1 else "single shard",
                        "backend": pkg.backend_name()},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TOP/s" if quantized else "TFLOP/s",
                          "frac": tf / peak, "traffic": None,
-                         "kernel": ("vg_batch_i8_kernel<%d>" % ((dim + 31) // 32)) if quantized else ("vg_batch_kernel<%d>" % ((dim + 7) // 8)),
+                         "kernel": ("vg_batch_i8_kernel<%d>" % ((dim + 31) // 32)) if quantized else
+                                   (("vg_batch_h_kernel<%d>" % ((dim + 15) // 16)) if half else ("vg_batch_kernel<%d>" % ((dim + 7) // 8))),
                          "kernel_ms": kern_ms, "launches_timed": n_launch, "flops_per_launch": flops,
                          "note": "kernel_ms = pre-pass + main pass + merges of one batch on one shard"}}))
     corpus.close()
@@ -322,7 +332,7 @@ def main():
     corpus = make_shard(pkg, torch, vt, dim, n_rows, 42 + rank, local_rank)
     corpus.set_rowid_base(1 + rank * n_rows)
     corpus.set_profiling(True)
-    if args.workload in ("c5", "c3b"):
+    if args.workload in ("c5", "c3b", "c5h"):
         return bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc, dist if use_dist else None, shard,
                              n_gpus, rank)
 

@@ -89,7 +89,9 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
     const int G = nq_pad / QPB;
     // partitions: enough workgroups to cover the chip (G * npart ~ CUs), a multiple of 8 (one per XCD), <= 256
-    int npart = std::max(1, c->cu_count / G);
+    // (VG_BATCH_BPC: workgroups per CU the partition count aims at - an experiment switch for kernels built with
+    // 4-wavefront workgroups, two of which fit a CU)
+    int npart = std::max(1, c->cu_count * std::max(1, env_int("VG_BATCH_BPC", 1)) / G);
     if (npart >= 8) npart = (npart / 8) * 8;
     npart = std::min(npart, 256);
     const long long ntiles = (c->n_rows + 31) / 32;

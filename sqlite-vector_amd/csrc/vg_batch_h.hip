@@ -32,7 +32,9 @@ typedef __bf16 vgh_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float vgh_f32x16 __attribute__((ext_vector_type(16)));
 typedef int vgh_i32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef VGH_WAVES
 #define VGH_WAVES 8
+#endif
 #define VGH_THREADS (64 * VGH_WAVES)
 #define VGH_QPW 32
 #define VGH_QPB (VGH_WAVES * VGH_QPW)
