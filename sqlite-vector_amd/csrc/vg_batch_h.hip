@@ -91,6 +91,11 @@ __device__ __forceinline__ void vgh_wait_lds(vgh_i32x4 &v) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
 }
 
+template <int CTRL> __device__ __forceinline__ uint64_t vgh_dpp64(uint64_t v) {
+    return ((uint64_t)vg_dpp_u32<CTRL>((uint32_t)(v >> 32)) << 32) | vg_dpp_u32<CTRL>((uint32_t)v);
+}
+__device__ __forceinline__ uint64_t vgh_min64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+
 template <int VT>
 __device__ __forceinline__ vgh_f32x16 vgh_mfma(const vgh_i32x4 &a, const vgh_i32x4 &b, const vgh_f32x16 &c) {
     if constexpr (VT == T_F16)
@@ -302,16 +307,27 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
             ub = ub + 1e-5f * fabsf(ub) + 4.76837158203125e-7f * fabsf(init_reg[r]) + 1e-30f;   // (+ what s~ lost next to the start value)
             const bool qforce = (qsp_w[qi_lane] != 0u) || !(qqf >= VGH_NORM_LO && qqf <= VGH_NORM_HI);
             const bool ok = (row < a.n_rows) && (q0 + qi_lane < a.nq_real) && !force && !qforce && (ub < thr_w[qi_lane]);
-            unsigned long long mb = __ballot(ok);
-            const uint64_t key = vg_make_key(ub, (uint32_t)row);
-            while (mb) {
-                const int src = __ffsll((long long)mb) - 1;
-                mb &= mb - 1;
-                const int hh = src >> 5, qi_u = q_lo + 4 * hh;
-                const float nt = vgb_kth_distance(vgb_list_insert(wave_lists + qi_u * k, k, lane, vg_readlane64(key, src)));
-                if (lane == 0 && nt < thr_w[qi_u]) thr_w[qi_u] = nt;     // (the test above reads it back; the gates of
-            }                                                            //  the filter are refreshed once per tile)
-            bound_changed |= (__ballot(ok) != 0);
+            if (__ballot(ok) != 0) {
+                // only the SMALLEST bound of each query in this tile enters its list: k entries then stand for k
+                // different rows all the same, the k-th smallest of them is still an upper bound of the final k-th best,
+                // and a list costs one insert per (query, tile) instead of one per passing row (half the inserts of
+                // the warm-up; each is an LDS round trip of the whole wavefront)
+                uint64_t key = ok ? vg_make_key(ub, (uint32_t)row) : VG_EMPTY_KEY;
+                key = vgh_min64(key, vgh_dpp64<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(key));
+                key = vgh_min64(key, vgh_dpp64<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(key));
+                key = vgh_min64(key, vgh_dpp64<VG_DPP_ROW_HALF_MIRROR>(key));
+                key = vgh_min64(key, vgh_dpp64<VG_DPP_ROW_MIRROR>(key));
+                key = vgh_min64(key, (uint64_t)__shfl_xor((unsigned long long)key, 16));       // lanes 0-31 / 32-63: one query each
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const uint64_t c = vg_readlane64(key, 32 * hh);
+                    if (c == VG_EMPTY_KEY) continue;
+                    const int qi_u = q_lo + 4 * hh;
+                    const float nt = vgb_kth_distance(vgb_list_insert(wave_lists + qi_u * k, k, lane, c));
+                    if (lane == 0) thr_w[qi_u] = nt;                 // (a list's k-th bound never grows)
+                }
+                bound_changed = true;                                // the filter's gates are refreshed once per tile
+            }
             return;
         }
         const bool pass = (row < a.n_rows) && (q0 + q_lo + 4 * h < a.nq_real) && (force || fmaf(gmul[r], lane_term, acc_r) >= 0.0f);
