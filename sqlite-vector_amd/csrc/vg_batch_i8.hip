@@ -54,6 +54,11 @@ struct BatchArgsI8 {
     const uint64_t *init_keys;
 };
 
+template <int CTRL> __device__ __forceinline__ uint64_t vgi_dpp64(uint64_t v) {
+    return ((uint64_t)vg_dpp_u32<CTRL>((uint32_t)(v >> 32)) << 32) | vg_dpp_u32<CTRL>((uint32_t)v);
+}
+__device__ __forceinline__ uint64_t vgi_min64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+
 template <int OFF>
 __device__ __forceinline__ void vgi_lds_read128(vgi_i32x4 &dst, uint32_t lds_addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF) : "memory");
@@ -64,7 +69,11 @@ __device__ __forceinline__ void vgi_wait_lds(vgi_i32x4 &v) {
 }
 
 // NTB = 32-byte k-steps per row (rows up to NTB * 32 bytes)
-template <int NTB, int MODE, bool IS_U8>
+// PRE = the pre-pass variant (large corpora): only the SMALLEST distance of each query in a tile enters its list.  k
+// entries then stand for k different rows, so the k-th of them bounds the query's final k-th best distance from above:
+// the start threshold of the real pass, which scans EVERY row.  A list warms up with one insert per (query, tile)
+// instead of one per passing row (each insert is an LDS round trip of the whole wavefront).
+template <int NTB, int MODE, bool IS_U8, bool PRE>
 __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8 a) {
     constexpr bool COS = (MODE == VGI_COS), L2M = (MODE == VGI_L2);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -216,7 +225,9 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
         qq_reg[r] = sqq;
         cq_reg[r] = IS_U8 ? (int)(128u * sq) - 16384 * L : 0;
         na_reg[r] = sqrtf(as_float_like(sqq));
-        thr_reg[r] = a.init_keys ? vgb_kth_distance(a.init_keys[(long long)(q0 + qi) * 64 + (k - 1)]) : INFINITY;
+        // the pre-pass bound is the distance of an actual row, which this pass meets again: one ulp up, so that the
+        // strict comparison below lets a row AT the bound in
+        thr_reg[r] = a.init_keys ? nextafterf(vgb_kth_distance(a.init_keys[(long long)(q0 + qi) * 64 + (k - 1)]), INFINITY) : INFINITY;
         set_gate(rc);
         if (q0 + qi >= a.nq_real) {                      // padding (an all-zero query ties every row at cosine 1.0)
             thr_reg[r] = -INFINITY;
@@ -246,6 +257,27 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
         // strict: rows arrive in scan order, a row that only ties the k-th best has the larger position and loses
         const bool pass = (row < a.n_rows) && (d < thr_reg[r]);
         unsigned long long m = __ballot(pass);
+        if constexpr (PRE) {
+            if (m) {
+                uint64_t kmin = pass ? vg_make_key(d, (uint32_t)row) : VG_EMPTY_KEY;     // min over the 32 rows of each query
+                kmin = vgi_min64(kmin, vgi_dpp64<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(kmin));
+                kmin = vgi_min64(kmin, vgi_dpp64<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(kmin));
+                kmin = vgi_min64(kmin, vgi_dpp64<VG_DPP_ROW_HALF_MIRROR>(kmin));
+                kmin = vgi_min64(kmin, vgi_dpp64<VG_DPP_ROW_MIRROR>(kmin));
+                kmin = vgi_min64(kmin, (uint64_t)__shfl_xor((unsigned long long)kmin, 16));
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const uint64_t c = vg_readlane64(kmin, 32 * hh);
+                    if (c == VG_EMPTY_KEY) continue;
+                    const float nt = vgb_kth_distance(vgb_list_insert(wave_lists + (q_lo + 4 * hh) * k, k, lane, c));
+                    if (h == hh) {
+                        thr_reg[r] = fminf(nt, thr_reg[r]);
+                        set_gate(rc);
+                    }
+                }
+            }
+            return;
+        }
         const uint64_t key = vg_make_key(d, (uint32_t)row);
         while (m) {
             const int src = __ffsll((long long)m) - 1;
@@ -395,7 +427,6 @@ extern "C" int vg_i8_rowstat_launch(const uint8_t *dev_rows, long long row0, lon
 }
 
 // ---- host side
-extern "C" int vg_batch_prepass_tiles(long long n_rows, int npart);                       // vg_batch.hip
 extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
                                      uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
 
@@ -411,23 +442,30 @@ extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k) {
     return b <= 160 * 1024 ? b : 0;
 }
 
-template <int NTB, int MODE, bool IS_U8>
+template <int NTB, int MODE, bool IS_U8, bool PRE>
 static int launch_i8(const BatchArgsI8 &a, int blocks, size_t smem, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_i8_kernel<NTB, MODE, IS_U8>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_i8_kernel<NTB, MODE, IS_U8, PRE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((vg_batch_i8_kernel<NTB, MODE, IS_U8>), dim3((unsigned)blocks), dim3(VGI_THREADS), smem, stream, a);
+    hipLaunchKernelGGL((vg_batch_i8_kernel<NTB, MODE, IS_U8, PRE>), dim3((unsigned)blocks), dim3(VGI_THREADS), smem, stream, a);
     return (int)hipGetLastError();
 }
-template <int NTB, int MODE>
+template <int NTB, int MODE, bool PRE>
 static int launch_i8_sign(const BatchArgsI8 &a, int blocks, size_t smem, hipStream_t stream) {
-    return a.is_u8 ? launch_i8<NTB, MODE, true>(a, blocks, smem, stream) : launch_i8<NTB, MODE, false>(a, blocks, smem, stream);
+    return a.is_u8 ? launch_i8<NTB, MODE, true, PRE>(a, blocks, smem, stream) : launch_i8<NTB, MODE, false, PRE>(a, blocks, smem, stream);
 }
-template <int NTB>
+template <int NTB, bool PRE>
 static int launch_i8_mode(const BatchArgsI8 &a, int blocks, size_t smem, hipStream_t stream) {
-    if (a.mode == VGI_COS) return launch_i8_sign<NTB, VGI_COS>(a, blocks, smem, stream);
-    if (a.mode == VGI_L2) return launch_i8_sign<NTB, VGI_L2>(a, blocks, smem, stream);
-    return launch_i8_sign<NTB, VGI_DOT>(a, blocks, smem, stream);
+    if (a.mode == VGI_COS) return launch_i8_sign<NTB, VGI_COS, PRE>(a, blocks, smem, stream);
+    if (a.mode == VGI_L2) return launch_i8_sign<NTB, VGI_L2, PRE>(a, blocks, smem, stream);
+    return launch_i8_sign<NTB, VGI_DOT, PRE>(a, blocks, smem, stream);
+}
+template <bool PRE>
+static int launch_i8_ntb(const BatchArgsI8 &a, int ntb, int blocks, size_t smem, hipStream_t stream) {
+    if (ntb <= 8) return launch_i8_mode<8, PRE>(a, blocks, smem, stream);
+    if (ntb <= 16) return launch_i8_mode<16, PRE>(a, blocks, smem, stream);
+    if (ntb <= 24) return launch_i8_mode<24, PRE>(a, blocks, smem, stream);
+    return launch_i8_mode<32, PRE>(a, blocks, smem, stream);
 }
 
 // dev_rows_signed: the corpus in signed representation; dev_queries: nq_pad x stride bytes (original representation).
@@ -447,26 +485,23 @@ extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_ro
     const int G = nq_pad / VGI_QPB;
     const int blocks = G * ((npart + 7) / 8) * 8;
     const long long ntiles = (n_rows + VGI_TILE - 1) / VGI_TILE;
-    auto launch = [&](const BatchArgsI8 &b) -> int {
-        if (ntb <= 8) return launch_i8_mode<8>(b, blocks, smem, stream);
-        if (ntb <= 16) return launch_i8_mode<16>(b, blocks, smem, stream);
-        if (ntb <= 24) return launch_i8_mode<24>(b, blocks, smem, stream);
-        return launch_i8_mode<32>(b, blocks, smem, stream);
-    };
-    const long long pre = vg_batch_prepass_tiles(n_rows, npart);
-    int rc;
-    if (pre > 0) {
-        a.npart_total = 2 * npart;
-        a.tile_begin = 0; a.tile_end = pre; a.tiles_per_part = (int)(pre / npart); a.part_base = 0; a.init_keys = nullptr;
-        if ((rc = launch(a)) != 0) return rc;
-        if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream)) != 0) return rc;
-        a.tile_begin = pre; a.tile_end = ntiles; a.tiles_per_part = (int)((ntiles - pre + npart - 1) / npart);
-        a.part_base = npart; a.init_keys = dev_out_keys;
-        if ((rc = launch(a)) != 0) return rc;
-    } else {
-        a.npart_total = npart;
-        a.tile_begin = 0; a.tile_end = ntiles; a.tiles_per_part = tiles_per_part; a.part_base = 0; a.init_keys = nullptr;
-        if ((rc = launch(a)) != 0) return rc;
+    // Large corpora: the PRE pass over the first 1/32 of the rows (one insert per query and tile) hands every query a
+    // start threshold; the real pass scans every row from there.  Both write lists 0 .. npart-1 of the candidate buffer.
+    long long pre = 0;
+    {
+        const char *e = getenv("VG_BATCH_PREPASS");
+        const int denom = (e && *e) ? atoi(e) : 32;
+        if (denom > 0 && ntiles >= 65536) pre = ((ntiles / denom + npart - 1) / npart) * npart;      // < 2M rows: one pass
     }
-    return vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, a.npart_total, k, dev_out_keys, stream);
+    int rc;
+    a.npart_total = npart; a.part_base = 0; a.init_keys = nullptr;
+    if (pre > 0) {
+        a.tile_begin = 0; a.tile_end = pre; a.tiles_per_part = (int)(pre / npart);
+        if ((rc = launch_i8_ntb<true>(a, ntb, blocks, smem, stream)) != 0) return rc;
+        if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream)) != 0) return rc;
+        a.init_keys = dev_out_keys;
+    }
+    a.tile_begin = 0; a.tile_end = ntiles; a.tiles_per_part = (int)((ntiles + npart - 1) / npart);
+    if ((rc = launch_i8_ntb<false>(a, ntb, blocks, smem, stream)) != 0) return rc;
+    return vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream);
 }
