@@ -35,6 +35,13 @@ typedef int vgi_i32x4 __attribute__((ext_vector_type(4)));
 #define VGI_TILE 32
 #define VGI_MAX_K 32
 #define VGI_BPIPE 4
+#ifndef VGI_PHASED
+#define VGI_PHASED 0                    // experiment, measured SLOWER (u8 cosine 15.0 vs 9.9 ms): the two wavefronts of a SIMD alternate, 3 tile buffers
+#endif
+#ifndef VGI_DEPTH2
+#define VGI_DEPTH2 0                    // experiment, measured NEUTRAL (10.5 / 8.95 / 6.1 vs 9.9 / 9.3 / 5.5 ms): DMA two tiles ahead, counted vmcnt waits
+#endif
+#define VGI_NBUF ((VGI_PHASED || VGI_DEPTH2) ? 3 : 2)
 
 enum { VGI_DOT = 0, VGI_COS = 1, VGI_L2 = 2 };
 
@@ -86,8 +93,8 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
     constexpr int TILE_BYTES = NTB * 2 * 512;
     constexpr int L = NTB * 32;                                 // padded row length the matrix core sees
     uint8_t *tile0 = smem;
-    uint32_t *rstat_lds = reinterpret_cast<uint32_t *>(smem + 2 * TILE_BYTES);           // [2 buffers][sum x: 32 | sum x^2: 32]
-    uint32_t *qstat_lds = rstat_lds + 2 * 64;                                            // [waves][32][2]: sum q, sum q^2
+    uint32_t *rstat_lds = reinterpret_cast<uint32_t *>(smem + VGI_NBUF * TILE_BYTES);    // [buffers][sum x: 32 | sum x^2: 32]
+    uint32_t *qstat_lds = rstat_lds + VGI_NBUF * 64;                                     // [waves][32][2]: sum q, sum q^2
     uint64_t *lists = reinterpret_cast<uint64_t *>(qstat_lds + VGI_WAVES * VGI_QPW * 2);  // [4][32][k]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
         for (int s = lane; s < VGI_QPW * k; s += 64) wave_lists[s] = VG_EMPTY_KEY;
     }
     // pad columns never touched by the DMA must read as "0" of the original representation
-    for (int s = tid; s < 2 * TILE_BYTES / 4; s += VGI_THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = IS_U8 ? 0x80808080u : 0u;
+    for (int s = tid; s < VGI_NBUF * TILE_BYTES / 4; s += VGI_THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = IS_U8 ? 0x80808080u : 0u;
     __syncthreads();
 
     // ---- tile streaming by LDS-DMA: piece p = chunk columns 2p and 2p+1 of all 32 rows; wavefront w moves pieces
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
         }
         return vg_clamp(d);
     };
-    auto reg_insert = [&](auto rc, int acc_r, long long row, int cx, uint32_t xx) {
+    auto reg_insert = [&](auto rc, int acc_r, long long row, int cx, uint32_t xx) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
         const int q_lo = (r & 3) + 8 * (r >> 2);
         const float d = reg_distance(rc, acc_r, cx, xx);
@@ -293,24 +300,12 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
         }
     };
 
-    if (tile_first < tile_last) {
-        const uint32_t goff0 = lane_offset(tile_first);
-#pragma unroll
-        for (int pc = 0; pc < NPIECE; ++pc) dma_piece(tile_first, goff0, 0, pc);
-        dma_stats(tile_first, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     constexpr int BP = VGI_BPIPE < NTB ? VGI_BPIPE : NTB;
     vgi_i32x4 bq[BP];
-    for (long long tile = tile_first; tile < tile_last; ++tile) {
-        const int cur_buf = (int)((tile - tile_first) & 1);
-        const long long tile_next = min(tile + 1, tile_last - 1);         // the last iteration re-fetches its own tile
+    vgi_i32x16 acc;
+    // the k loop of one tile: nothing but MFMAs, the B-operand LDS reads and the DMA issue of a later tile
+    auto k_loop = [&](int cur_buf, long long tile_next, int next_buf) __attribute__((always_inline)) {
         const uint32_t goff_next = lane_offset(tile_next);
-        const long long row_cur = tile * VGI_TILE + x;
-
-        vgi_i32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0;
         const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
@@ -325,18 +320,19 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
             const vgi_i32x4 b = bq[t % BP];
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[t], b, acc, 0, 0, 0);
             if constexpr (t + BP < NTB) vgi_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
-            // the DMA pieces of the next tile, spread over the first half of the k loop
+            // the DMA pieces of the later tile, spread over the first half of the k loop
             constexpr int NTD = (NTB + 1) / 2;
             constexpr int pc_lo = (t >= NTD) ? NPIECE : (t * NPIECE + NTD - 1) / NTD;
             constexpr int pc_hi = (t >= NTD) ? NPIECE : (t + 1 == NTD ? NPIECE : ((t + 1) * NPIECE + NTD - 1) / NTD);
-            vgb_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, goff_next, cur_buf ^ 1, decltype(pcc)::value); });
-            if constexpr (t == 0) dma_stats(tile_next, cur_buf ^ 1);
+            vgb_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, goff_next, next_buf, decltype(pcc)::value); });
+            if constexpr (t == 0) dma_stats(tile_next, next_buf);
         });
-        // this tile's row sums (landed with the tile, one barrier ago)
-        const int sx = (int)rstat_lds[cur_buf * 64 + x];
+    };
+    // the tile boundary: margins (integer for dot / L2, float for cosine), one ballot, the rare inserts
+    auto boundary = [&](long long tile, int cur_buf) __attribute__((always_inline)) {
+        const long long row_cur = tile * VGI_TILE + x;
+        const int sx = (int)rstat_lds[cur_buf * 64 + x];                  // this tile's row sums (landed with the tile)
         const uint32_t xx = rstat_lds[cur_buf * 64 + 32 + x];
-
-        // ---- tile boundary: margins (integer for dot / L2, float for cosine), one ballot
         const int cx = IS_U8 ? 128 * sx : 0;
         unsigned pend = 0;
         bool any;
@@ -378,9 +374,102 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
                 if (pend & (1u << r)) reg_insert(rc, acc[r], row_cur, cx, xx);
             });
         }
+    };
+
+#if VGI_PHASED
+    // PHASED schedule (experiment, slower).  The workgroup's wavefronts form two groups (waves 0-3 / 4-7: one of each per SIMD).  A step is
+    // one barrier interval; on even steps group 0 runs the k loop of tile s/2 while group 1 is at the boundary of the
+    // tile it multiplied one step earlier, on odd steps the roles swap - the matrix pipe of a SIMD always has a
+    // wavefront in its k loop instead of both idling at the boundary together.  Tile t sits in buffer t % 3; during its
+    // k loop of tile t group 0 fetches its DMA pieces of tile t+1, group 1 (one step later) its pieces of tile t+2;
+    // everybody waits for its own DMA at the end of its BOUNDARY step, a full step after issuing it.
+    {
+        const int grp = wave >> 2;
+        const long long T = tile_last - tile_first;
+        if (T > 0) {
+            const uint32_t goff0 = lane_offset(tile_first);
+#pragma unroll
+            for (int pc = 0; pc < NPIECE; ++pc) dma_piece(tile_first, goff0, 0, pc);
+            dma_stats(tile_first, 0);
+            if (grp == 1) {
+                const long long t1 = min(tile_first + 1, tile_last - 1);
+                const uint32_t goff1 = lane_offset(t1);
+#pragma unroll
+                for (int pc = 0; pc < NPIECE; ++pc) dma_piece(t1, goff1, 1, pc);
+                dma_stats(t1, 1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (long long s = 0; s <= 2 * T; ++s) {
+            const bool kl = (grp == 0) ? ((s & 1) == 0 && s < 2 * T) : ((s & 1) == 1);
+            const bool bd = (grp == 0) ? ((s & 1) == 1) : ((s & 1) == 0 && s >= 2);
+            if (kl) {
+                const long long ti = (s - grp) >> 1;
+                k_loop((int)(ti % 3), min(tile_first + ti + 1 + grp, tile_last - 1), (int)((ti + 1 + grp) % 3));
+            } else if (bd) {
+                const long long ti = (s - 1 - grp) >> 1;
+                boundary(tile_first + ti, (int)(ti % 3));
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        }
+    }
+#elif VGI_DEPTH2
+    // Prefetch distance TWO tiles (experiment: the hypothesis "a tile costs the DMA's latency plus its transfer time" was
+    // wrong - no gain, so the DMA is not what a tile waits for).  The k loop of tile t issues the DMA of tile t+2 (three
+    // buffers) and the wait at the end of tile t leaves exactly those instructions outstanding (loads return in order).
+    {
+        int n_mine = (stat_mask != 0) ? 2 : 0;                           // DMA instructions this wavefront issues per tile
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) n_mine += (piece_mask[i] != 0) ? 1 : 0;
+        if (tile_first < tile_last) {
+            const long long t1 = min(tile_first + 1, tile_last - 1);
+            const uint32_t goff0 = lane_offset(tile_first), goff1 = lane_offset(t1);
+#pragma unroll
+            for (int pc = 0; pc < NPIECE; ++pc) dma_piece(tile_first, goff0, 0, pc);
+            dma_stats(tile_first, 0);
+#pragma unroll
+            for (int pc = 0; pc < NPIECE; ++pc) dma_piece(t1, goff1, 1, pc);
+            dma_stats(t1, 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (long long tile = tile_first; tile < tile_last; ++tile) {
+            const long long ti = tile - tile_first;
+            const int cur_buf = (int)(ti % 3);
+            k_loop(cur_buf, min(tile + 2, tile_last - 1), (int)((ti + 2) % 3));
+            boundary(tile, cur_buf);
+            switch (n_mine) {                                            // everything but this tile's own DMA issue has landed
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            }
+            __syncthreads();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#else
+    if (tile_first < tile_last) {
+        const uint32_t goff0 = lane_offset(tile_first);
+#pragma unroll
+        for (int pc = 0; pc < NPIECE; ++pc) dma_piece(tile_first, goff0, 0, pc);
+        dma_stats(tile_first, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (long long tile = tile_first; tile < tile_last; ++tile) {
+        const int cur_buf = (int)((tile - tile_first) & 1);
+        k_loop(cur_buf, min(tile + 1, tile_last - 1), cur_buf ^ 1);      // (the last iteration re-fetches its own tile)
+        boundary(tile, cur_buf);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+#endif
 
     for (int s = lane; s < VGI_QPW * 64; s += 64) {
         const int qi = s >> 6, slot = s & 63;
@@ -438,7 +527,7 @@ extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k) {
     if (ntb <= 8) NTB = 8; else if (ntb <= 16) NTB = 16; else if (ntb <= 24) NTB = 24; else if (ntb <= 32) NTB = 32;
     else return 0;
     if (k < 1 || k > VGI_MAX_K) return 0;
-    const size_t b = (size_t)2 * NTB * 1024 + 512 + (size_t)VGI_WAVES * VGI_QPW * 2 * 4 + (size_t)VGI_WAVES * VGI_QPW * k * 8;
+    const size_t b = (size_t)VGI_NBUF * (NTB * 1024 + 256) + (size_t)VGI_WAVES * VGI_QPW * 2 * 4 + (size_t)VGI_WAVES * VGI_QPW * k * 8;
     return b <= 160 * 1024 ? b : 0;
 }
 
