@@ -38,6 +38,9 @@ typedef int vgi_i32x4 __attribute__((ext_vector_type(4)));
 #ifndef VGI_PHASED
 #define VGI_PHASED 0                    // experiment, measured SLOWER (u8 cosine 15.0 vs 9.9 ms): the two wavefronts of a SIMD alternate, 3 tile buffers
 #endif
+#ifndef VGI_CHAINS
+#define VGI_CHAINS 1                    // 2: even / odd k-steps accumulate in two independent chains (one wavefront can then issue an MFMA every 32 cycles)
+#endif
 #ifndef VGI_DEPTH2
 #define VGI_DEPTH2 0                    // experiment, measured NEUTRAL (10.5 / 8.95 / 6.1 vs 9.9 / 9.3 / 5.5 ms): DMA two tiles ahead, counted vmcnt waits
 #endif
@@ -308,6 +311,11 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
         const uint32_t goff_next = lane_offset(tile_next);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0;
+#if VGI_CHAINS == 2
+        vgi_i32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0;
+#endif
         const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
         vgb_static_for<0, BP>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
@@ -318,7 +326,12 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
             constexpr int in_flight_after = (NTB - 1 - t) < (BP - 1) ? (NTB - 1 - t) : (BP - 1);
             vgi_wait_lds<in_flight_after>(bq[t % BP]);
             const vgi_i32x4 b = bq[t % BP];
+#if VGI_CHAINS == 2
+            if constexpr (t & 1) acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[t], b, acc2, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[t], b, acc, 0, 0, 0);
+#else
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[t], b, acc, 0, 0, 0);
+#endif
             if constexpr (t + BP < NTB) vgi_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
             // the DMA pieces of the later tile, spread over the first half of the k loop
             constexpr int NTD = (NTB + 1) / 2;
@@ -327,6 +340,10 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
             vgb_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, goff_next, next_buf, decltype(pcc)::value); });
             if constexpr (t == 0) dma_stats(tile_next, next_buf);
         });
+#if VGI_CHAINS == 2
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += acc2[r];                   // (exact: integer sums)
+#endif
     };
     // the tile boundary: margins (integer for dot / L2, float for cosine), one ballot, the rare inserts
     auto boundary = [&](long long tile, int cur_buf) __attribute__((always_inline)) {
