@@ -56,10 +56,10 @@ enum { VGH_DOT = 0, VGH_COS = 1, VGH_L2 = 2 };
 #if VGH_TIMING
 // s_memtime ticks summed over all wavefronts: k loop | filter | survivors | DMA wait | barrier | whole kernel | wave-tiles |
 // (exact evaluations << 32) + wave-tiles with survivors
-__device__ unsigned long long vgh_ticks[8];
+__device__ unsigned long long vgh_ticks[16];  // [8..13] real pass only: pending registers | entries | exact ticks | offer ticks | phase ticks | passing pairs
 extern "C" int vg_batch_h_timing(unsigned long long *out8, int reset) {
     if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(vgh_ticks), sizeof(vgh_ticks)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vgh_ticks), z, sizeof(z)) != hipSuccess) return -1; }
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vgh_ticks), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #define VGH_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
     };
     bool bound_changed = false;
 #if VGH_TIMING
-    unsigned long long tk_cnt = 0;
+    unsigned long long tk_cnt = 0, tk_regs = 0, tk_entries = 0, tk_exact = 0, tk_offer = 0, tk_phase = 0, tk_pairs = 0;
 #endif
     // slow path: the pairs of register r that passed the filter
     auto reg_insert = [&](auto rc, float acc_r, long long row, float lane_term, bool force, float nn_row) __attribute__((always_inline)) {
@@ -340,9 +340,12 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
             const float nn_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nn_row), src));
             const float thr_u = thr_w[qi_u];
             // every lane holds the same value (butterfly sums): say so, or the branch below counts as divergent
+            VGH_TICK(te0);
             const float de = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, exact_distance(qi_u, row_u, nn_u))));
 #if VGH_TIMING
             tk_cnt += 1ull << 32;
+            const unsigned long long te1 = __builtin_readcyclecounter();
+            tk_exact += te1 - te0; tk_pairs += 1;
 #endif
             // strict: rows arrive in scan order, a row that only ties the k-th best has the larger position and loses
             if (!(de < thr_u)) continue;
@@ -434,6 +437,9 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
             if (bound_changed) { vgb_static_for<0, 16>([&](auto rc) { set_gate(rc); }); bound_changed = false; }
         }
         VGH_TICK(t3);
+#if VGH_TIMING
+        if (!BOUND && pend) { tk_regs += __builtin_popcount(pend); tk_entries += 1; tk_phase += t3 - t2; }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         VGH_TICK(t4);
         __syncthreads();
@@ -449,6 +455,8 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
         atomicAdd(&vgh_ticks[5], __builtin_readcyclecounter() - tk_begin);
         atomicAdd(&vgh_ticks[6], (unsigned long long)(tile_last - tile_first));
         atomicAdd(&vgh_ticks[7], tk_cnt);
+        atomicAdd(&vgh_ticks[8], tk_regs); atomicAdd(&vgh_ticks[9], tk_entries); atomicAdd(&vgh_ticks[10], tk_exact);
+        atomicAdd(&vgh_ticks[12], tk_phase); atomicAdd(&vgh_ticks[13], tk_pairs);
     }
 #endif
 

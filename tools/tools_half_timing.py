@@ -40,7 +40,7 @@ def main():
     rng = np.random.default_rng(44)
     qs = torch.from_numpy(rng.standard_normal((args.nq, args.dim), dtype=np.float32)).to(tdt).view(torch.int16).numpy().view(np.uint16)
     c.scan_topk_batch(args.metric, qs, 20)
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 16)()
     lib.vg_batch_h_timing(out, 1)
     c.set_profiling(True)
     c.scan_topk_batch(args.metric, qs, 20)
@@ -54,6 +54,10 @@ def main():
     print("  whole kernel vs sum of phases: %.3f" % (v[5] / tot))
     print("  wave-tiles with survivors: %.2f %%   exact evaluations: %d (%.2f per query and partition-list of the run)" %
           (100.0 * (v[7] & 0xFFFFFFFF) / max(v[6], 1), v[7] >> 32, (v[7] >> 32) / max(args.nq, 1)))
+    ne = max(v[9], 1)
+    print("  real pass: %d survivor-phase entries (%.2f %% of wave-tiles), %.2f pending registers and %.2f evaluated pairs per entry;"
+          % (v[9], 100.0 * v[9] / max(v[6], 1), v[8] / ne, v[13] / ne))
+    print("             %.0f ticks per entry, of which exact evaluation (loads + f64 sums) %.0f per pair" % (v[12] / ne, v[10] / max(v[13], 1)))
     c.close()
 
 
