@@ -1,6 +1,7 @@
 // vg_batch_api.hip - host side of the batched scans (vg_scan_topk_batch[_keys]): partition planning, the cached per-row
-// statistics of the quantized kernels, query staging, launches of vg_batch.hip / vg_batch_i8.hip, slicing of very
-// large batches, fallback to per-query scans.
+// statistics the matrix-core kernels need, query staging, launches of vg_batch.hip (f32) / vg_batch_i8.hip (uint8, int8) /
+// vg_batch_h.hip (f16, bf16), slicing of very large batches; shapes none of them serves go through the multi-query scan
+// (vg_multi.hip) or, last, one single-query scan per query.
 #include "vg_internal.h"
 
 #include "vg_device.h"

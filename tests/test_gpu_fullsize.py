@@ -38,6 +38,9 @@ def _build(pkg, torch, vt, dim, seed, keep_blocks=False):
     for r0 in range(0, N, 1_000_000):
         if vt == pkg.F32:
             t = torch.randn((1_000_000, dim), generator=gen, device="cuda", dtype=torch.float32)
+        elif vt in (pkg.F16, pkg.BF16):
+            t = torch.randn((1_000_000, dim), generator=gen, device="cuda", dtype=torch.float32).to(
+                torch.float16 if vt == pkg.F16 else torch.bfloat16)
         else:
             t = torch.randint(0, 256, (1_000_000, dim), generator=gen, device="cuda", dtype=torch.uint8)
         torch.cuda.synchronize()
@@ -169,4 +172,26 @@ def test_c5_batched_10m(env, metric):
             scale = float(np.abs(qs[i]).sum()) * 4.0                           # ~ sum |q_i x_i| for N(0,1) rows
         assert np.all(np.abs(dist[i] - one_dist) <= 1e-5 * (np.abs(one_dist) + scale)), i
     assert swapped <= 3, swapped
+    c.close()
+
+
+@pytest.mark.parametrize("vt_name", ("f16", "bf16"))
+def test_half_precision_batch_10m(env, vt_name):
+    """10M x 384 f16 / bf16, a batch of 300 queries (two query groups, bound-only pre-pass + real pass): the matrix cores
+    only filter, the survivors carry the single scan's f64 arithmetic - so every list must be the single scan's list
+    (distances within one rounding of the float result, rows equal unless two distances tie within that)."""
+    pkg, torch = env
+    vt = pkg.F16 if vt_name == "f16" else pkg.BF16
+    tdt = torch.float16 if vt_name == "f16" else torch.bfloat16
+    dim, k, nq = 384, 20, 300
+    c, blocks = _build(pkg, torch, vt, dim, 47)
+    del blocks
+    qs = torch.from_numpy(np.random.default_rng(48).standard_normal((nq, dim), dtype=np.float32)).to(tdt).view(torch.int16).numpy().view(np.uint16)
+    for metric in (dg.DOT, dg.COSINE, dg.L2):
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        assert np.all(cnt == k) and np.all(np.diff(dist, axis=1) >= 0)
+        for i in range(0, nq, 7):
+            one_ids, one_dist = c.scan_topk(metric, qs[i], k)
+            assert np.allclose(dist[i], one_dist, rtol=1e-6, atol=1e-7), (metric, i)
+            assert len(set(ids[i].tolist()) ^ set(one_ids.tolist())) <= 2, (metric, i)
     c.close()
