@@ -19,7 +19,15 @@ EXT = os.path.join(HERE, "ext")
 LIB = os.path.join(HERE, "libvectorgpu.so")
 VEC = os.path.join(HERE, "vector.so")
 
-HIP_SOURCES = ["vg_api.hip", "vg_corpus.hip", "vg_batch_api.hip", "vg_select.hip", "vg_batch.hip", "vg_quant.hip", "vg_shards.hip", "vg_batch_i8.hip", "vg_multi.hip", "vg_batch_h.hip"]
+# (source, object, extra flags): the two kernel families with the most template instantiations are compiled as several
+# translation units from one source file each, so that a from-scratch build is bounded by ~1.5 min instead of ~4
+HIP_UNITS = [("vg_api.hip", "vg_api.hip.o", []), ("vg_corpus.hip", "vg_corpus.hip.o", []), ("vg_batch_api.hip", "vg_batch_api.hip.o", []),
+             ("vg_select.hip", "vg_select.hip.o", []), ("vg_batch.hip", "vg_batch.hip.o", []), ("vg_quant.hip", "vg_quant.hip.o", []),
+             ("vg_shards.hip", "vg_shards.hip.o", []), ("vg_multi.hip", "vg_multi.hip.o", []),
+             ("vg_batch_i8.hip", "vg_batch_i8.hip.o", []), ("vg_batch_i8.hip", "vg_batch_i8_pre.o", ["-DVGI_TU_PRE"]),
+             ("vg_batch_h.hip", "vg_batch_h.hip.o", []), ("vg_batch_h.hip", "vg_batch_h_bf16.o", ["-DVGH_TU=1"]),
+             ("vg_batch_h.hip", "vg_batch_h_bound.o", ["-DVGH_TU=2"])]
+HIP_SOURCES = sorted(set(u[0] for u in HIP_UNITS))
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -46,11 +54,12 @@ def build_gpu_library(force=False, verbose=False):
     # one object per translation unit (compiled concurrently), then one link
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     objs, procs = [], []
-    for src in srcs:
-        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+    for name, objname, extra in HIP_UNITS:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(HERE, "build", objname)
         objs.append(obj)
         if force or _newer(obj, [src] + deps):
-            cmd = [_hipcc()] + HIPCC_FLAGS + ["-c", src, "-o", obj]
+            cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))

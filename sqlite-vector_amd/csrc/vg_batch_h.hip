@@ -54,6 +54,7 @@ enum { VGH_DOT = 0, VGH_COS = 1, VGH_L2 = 2 };
 #define VGH_TIMING 0                    // measurement builds (tools/tools_half_timing.py): where a wavefront's time goes
 #endif
 #if VGH_TIMING
+// (timing builds are single-unit: tools/build_half_variants.sh compiles this file once with all instantiations - see there)
 // s_memtime ticks summed over all wavefronts: k loop | filter | survivors | DMA wait | barrier | whole kernel | wave-tiles |
 // (exact evaluations << 32) + wave-tiles with survivors
 __device__ unsigned long long vgh_ticks[16];  // [8..13] real pass only: pending registers | entries | exact ticks | offer ticks | phase ticks | passing pairs
@@ -467,26 +468,15 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
 }
 
 // ---- host side
-extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
-                                     uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
-
-extern "C" int vg_batch_h_queries_per_block(void) { return VGH_QPB; }
-
-static int vgh_ntb(long long stride_bytes) {
-    const int ntb = (int)((stride_bytes + 31) / 32);
-    if (ntb <= 8) return 8;
-    if (ntb <= 16) return 16;
-    if (ntb <= 24) return 24;
-    if (ntb <= 32) return 32;
-    return 0;
-}
-
-extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k) {
-    const int NTB = vgh_ntb(stride_bytes);
-    if (!NTB || k < 1 || k > VGH_MAX_K) return 0;
-    const size_t b = (size_t)2 * NTB * 1024 + 256 + (size_t)VGH_WAVES * VGH_QPW * (8 + 4 + 4) + (size_t)VGH_WAVES * VGH_QPW * k * 8;
-    return b <= 160 * 1024 ? b : 0;
-}
+// The kernel instantiations are split over three translation units compiled from this file (build.py): the real-pass
+// kernels for f16 here (with the host entry points), for bf16 with -DVGH_TU=1, the bound-pass kernels with -DVGH_TU=2
+// (-DVGH_TU_ALL: everything in this one unit - the measurement builds of tools/build_half_variants.sh).
+#ifndef VGH_TU
+#define VGH_TU 0
+#endif
+extern "C" int vgh_launch_real_f16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);
+extern "C" int vgh_launch_real_bf16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);
+extern "C" int vgh_launch_bound(const BatchArgsH *a, int is_bf16, int ntb, int blocks, size_t smem, hipStream_t stream);
 
 template <int VT, int NTB, int MODE, bool BOUND>
 static int launch_h(const BatchArgsH &a, int blocks, size_t smem, hipStream_t stream) {
@@ -510,6 +500,42 @@ static int launch_h_ntb(const BatchArgsH &a, int ntb, int blocks, size_t smem, h
     return launch_h_mode<VT, 32, BOUND>(a, blocks, smem, stream);
 }
 
+#if VGH_TU == 1 || defined(VGH_TU_ALL)
+extern "C" int vgh_launch_real_bf16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_BF16, false>(*a, ntb, blocks, smem, stream);
+}
+#endif
+#if VGH_TU == 2 || defined(VGH_TU_ALL)
+extern "C" int vgh_launch_bound(const BatchArgsH *a, int is_bf16, int ntb, int blocks, size_t smem, hipStream_t stream) {
+    return is_bf16 ? launch_h_ntb<T_BF16, true>(*a, ntb, blocks, smem, stream) : launch_h_ntb<T_F16, true>(*a, ntb, blocks, smem, stream);
+}
+#endif
+#if VGH_TU == 0
+extern "C" int vgh_launch_real_f16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_F16, false>(*a, ntb, blocks, smem, stream);
+}
+
+extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
+                                     uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
+
+extern "C" int vg_batch_h_queries_per_block(void) { return VGH_QPB; }
+
+static int vgh_ntb(long long stride_bytes) {
+    const int ntb = (int)((stride_bytes + 31) / 32);
+    if (ntb <= 8) return 8;
+    if (ntb <= 16) return 16;
+    if (ntb <= 24) return 24;
+    if (ntb <= 32) return 32;
+    return 0;
+}
+
+extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k) {
+    const int NTB = vgh_ntb(stride_bytes);
+    if (!NTB || k < 1 || k > VGH_MAX_K) return 0;
+    const size_t b = (size_t)2 * NTB * 1024 + 256 + (size_t)VGH_WAVES * VGH_QPW * (8 + 4 + 4) + (size_t)VGH_WAVES * VGH_QPW * k * 8;
+    return b <= 160 * 1024 ? b : 0;
+}
+
 // dev_rows / dev_queries: f16 (is_bf16 = 0) or bf16 elements, zero padded rows of stride_bytes; dev_row_nn: (float) sum x^2
 // per row, readable for 32 floats past the last whole tile.  Returns 0, -1 if the shape is not served, a hipError_t
 // otherwise.  dev_cand sized like the f32 kernel's (vg_batch_lists_per_query).
@@ -529,8 +555,8 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long
     const int blocks = G * ((npart + 7) / 8) * 8;
     const long long ntiles = (n_rows + VGH_TILE - 1) / VGH_TILE;
     auto launch = [&](const BatchArgsH &b, bool bound) -> int {
-        if (bound) return is_bf16 ? launch_h_ntb<T_BF16, true>(b, ntb, blocks, smem, stream) : launch_h_ntb<T_F16, true>(b, ntb, blocks, smem, stream);
-        return is_bf16 ? launch_h_ntb<T_BF16, false>(b, ntb, blocks, smem, stream) : launch_h_ntb<T_F16, false>(b, ntb, blocks, smem, stream);
+        if (bound) return vgh_launch_bound(&b, is_bf16, ntb, blocks, smem, stream);
+        return is_bf16 ? vgh_launch_real_bf16(&b, ntb, blocks, smem, stream) : vgh_launch_real_f16(&b, ntb, blocks, smem, stream);
     };
     // Large corpora: a BOUND pre-pass over the first 1/32 of the rows gives every query an upper bound of its final
     // k-th best distance (no exact evaluations - with thresholds starting at +Inf they were a quarter of the whole
@@ -557,3 +583,4 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long
     if ((rc = launch(a, false)) != 0) return rc;
     return vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream);
 }
+#endif   // VGH_TU

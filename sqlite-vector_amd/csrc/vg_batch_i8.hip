@@ -494,6 +494,7 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
     }
 }
 
+#ifndef VGI_TU_PRE
 // ---- per-row sums of the ORIGINAL representation + (uint8) the XOR-0x80 copy the matrix core reads
 template <bool IS_U8>
 __global__ __launch_bounds__(256) void vg_i8_rowstat_kernel(const uint8_t *rows, long long row0, long long n, long long stride,
@@ -532,21 +533,14 @@ extern "C" int vg_i8_rowstat_launch(const uint8_t *dev_rows, long long row0, lon
     return (int)hipGetLastError();
 }
 
+#endif   // !VGI_TU_PRE
+
 // ---- host side
-extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
-                                     uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
-
-extern "C" int vg_batch_i8_queries_per_block(void) { return VGI_QPB; }
-
-extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k) {
-    const int ntb = (int)((stride_bytes + 31) / 32);
-    int NTB;
-    if (ntb <= 8) NTB = 8; else if (ntb <= 16) NTB = 16; else if (ntb <= 24) NTB = 24; else if (ntb <= 32) NTB = 32;
-    else return 0;
-    if (k < 1 || k > VGI_MAX_K) return 0;
-    const size_t b = (size_t)VGI_NBUF * (NTB * 1024 + 256) + (size_t)VGI_WAVES * VGI_QPW * 2 * 4 + (size_t)VGI_WAVES * VGI_QPW * k * 8;
-    return b <= 160 * 1024 ? b : 0;
-}
+// The kernel instantiations are split over two translation units compiled from this file (build.py): the real-pass
+// kernels here, the PRE kernels with -DVGI_TU_PRE (vg_batch_i8_pre.o); -DVGI_TU_ALL: both in this one unit (the
+// measurement builds of tools/build_i8_variants.sh).
+extern "C" int vgi_launch_pre(const BatchArgsI8 *a, int ntb, int blocks, size_t smem, hipStream_t stream);
+extern "C" int vgi_launch_real(const BatchArgsI8 *a, int ntb, int blocks, size_t smem, hipStream_t stream);
 
 template <int NTB, int MODE, bool IS_U8, bool PRE>
 static int launch_i8(const BatchArgsI8 &a, int blocks, size_t smem, hipStream_t stream) {
@@ -572,6 +566,30 @@ static int launch_i8_ntb(const BatchArgsI8 &a, int ntb, int blocks, size_t smem,
     if (ntb <= 16) return launch_i8_mode<16, PRE>(a, blocks, smem, stream);
     if (ntb <= 24) return launch_i8_mode<24, PRE>(a, blocks, smem, stream);
     return launch_i8_mode<32, PRE>(a, blocks, smem, stream);
+}
+#if defined(VGI_TU_PRE) || defined(VGI_TU_ALL)
+extern "C" int vgi_launch_pre(const BatchArgsI8 *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
+    return launch_i8_ntb<true>(*a, ntb, blocks, smem, stream);
+}
+#endif
+#ifndef VGI_TU_PRE
+extern "C" int vgi_launch_real(const BatchArgsI8 *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
+    return launch_i8_ntb<false>(*a, ntb, blocks, smem, stream);
+}
+
+extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
+                                     uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
+
+extern "C" int vg_batch_i8_queries_per_block(void) { return VGI_QPB; }
+
+extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k) {
+    const int ntb = (int)((stride_bytes + 31) / 32);
+    int NTB;
+    if (ntb <= 8) NTB = 8; else if (ntb <= 16) NTB = 16; else if (ntb <= 24) NTB = 24; else if (ntb <= 32) NTB = 32;
+    else return 0;
+    if (k < 1 || k > VGI_MAX_K) return 0;
+    const size_t b = (size_t)VGI_NBUF * (NTB * 1024 + 256) + (size_t)VGI_WAVES * VGI_QPW * 2 * 4 + (size_t)VGI_WAVES * VGI_QPW * k * 8;
+    return b <= 160 * 1024 ? b : 0;
 }
 
 // dev_rows_signed: the corpus in signed representation; dev_queries: nq_pad x stride bytes (original representation).
@@ -603,11 +621,12 @@ extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_ro
     a.npart_total = npart; a.part_base = 0; a.init_keys = nullptr;
     if (pre > 0) {
         a.tile_begin = 0; a.tile_end = pre; a.tiles_per_part = (int)(pre / npart);
-        if ((rc = launch_i8_ntb<true>(a, ntb, blocks, smem, stream)) != 0) return rc;
+        if ((rc = vgi_launch_pre(&a, ntb, blocks, smem, stream)) != 0) return rc;
         if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream)) != 0) return rc;
         a.init_keys = dev_out_keys;
     }
     a.tile_begin = 0; a.tile_end = ntiles; a.tiles_per_part = (int)((ntiles + npart - 1) / npart);
-    if ((rc = launch_i8_ntb<false>(a, ntb, blocks, smem, stream)) != 0) return rc;
+    if ((rc = vgi_launch_real(&a, ntb, blocks, smem, stream)) != 0) return rc;
     return vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream);
 }
+#endif   // !VGI_TU_PRE
