@@ -195,3 +195,23 @@ def test_half_precision_batch_10m(env, vt_name):
             assert np.allclose(dist[i], one_dist, rtol=1e-6, atol=1e-7), (metric, i)
             assert len(set(ids[i].tolist()) ^ set(one_ids.tolist())) <= 2, (metric, i)
     c.close()
+
+
+@pytest.mark.parametrize("nq", (200, 520))
+def test_quantized_batch_10m_bit_exact(env, nq):
+    """10M x 768 uint8, batches on the integer matrix cores with the two-pass launch (tile-minimum pre-pass + real pass
+    over every row): one query group over 256 partitions (nq = 200) and three groups (nq = 520).  Integer arithmetic:
+    every list must equal the single scan's list bit for bit, ties included."""
+    pkg, torch = env
+    dim, k = 768, 20
+    c, blocks = _build(pkg, torch, pkg.U8, dim, 49)
+    del blocks
+    qs = np.random.default_rng(50).integers(0, 256, (nq, dim)).astype(np.uint8)
+    qs[1] = 0                                                     # zero query: cosine ties every row at 1.0
+    for metric in (dg.COSINE, dg.L2, dg.DOT):
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        assert np.all(cnt == k)
+        for i in list(range(0, nq, 23)) + [1]:
+            one_ids, one_dist = c.scan_topk(metric, qs[i], k)
+            assert ids[i].tolist() == one_ids.tolist() and np.array_equal(dist[i], one_dist), (metric, i)
+    c.close()
