@@ -30,7 +30,7 @@ extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_ro
 
 // ---- f16 / bf16 batches: matrix-core filter + exact f64 re-evaluation (vg_batch_h.hip)
 extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k);
-extern "C" int vg_batch_h_queries_per_block(void);
+extern "C" int vg_batch_h_queries_per_block(long long stride_bytes);
 extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long long stride_bytes, int dim, int is_bf16,
                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
                                  const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
@@ -86,7 +86,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
                                 int *out_counts) {
     const bool quantized = (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8);
     const bool half = (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16);
-    const int QPB = quantized ? vg_batch_i8_queries_per_block() : (half ? vg_batch_h_queries_per_block() : 128);
+    const int QPB = quantized ? vg_batch_i8_queries_per_block() : (half ? vg_batch_h_queries_per_block(c->stride) : 128);
     const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
     const int G = nq_pad / QPB;
     // partitions: enough workgroups to cover the chip (G * npart ~ CUs), a multiple of 8 (one per XCD), <= 256

@@ -17,7 +17,8 @@
 // handful of pairs per query and partition take that path; the rest of the corpus costs one MFMA per 32 x 32 x 16 block.
 //
 // Skeleton = vg_batch_i8.hip (same operand bytes per lane: 16 bytes = 8 halves of one row per k-step): 8 wavefronts x
-// 32 queries stationary in registers, tiles of 32 rows through LDS by LDS-DMA, transposed by 16-byte chunk.
+// 32 queries stationary in registers, tiles of 32 rows through LDS by LDS-DMA, transposed by 16-byte chunk.  Rows of
+// 1 - 2 KiB (up to 1024 elements) run with 4 wavefronts per workgroup: A is then up to 256 registers per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,11 +34,11 @@ typedef float vgh_f32x16 __attribute__((ext_vector_type(16)));
 typedef int vgh_i32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef VGH_WAVES
-#define VGH_WAVES 8
+#define VGH_WAVES 8                     // wavefronts per workgroup for rows up to 1 KiB (two per SIMD) ...
 #endif
-#define VGH_THREADS (64 * VGH_WAVES)
+#define VGH_WAVES_LONG 4                // ... and for rows up to 2 KiB: A alone is up to 256 registers, one wavefront per SIMD
+#define VGH_WAVES_OF(NTB) ((NTB) <= 32 ? VGH_WAVES : VGH_WAVES_LONG)
 #define VGH_QPW 32
-#define VGH_QPB (VGH_WAVES * VGH_QPW)
 #define VGH_TILE 32
 #define VGH_MAX_K 32
 #define VGH_BPIPE 4
@@ -110,7 +111,9 @@ __device__ __forceinline__ vgh_f32x16 vgh_mfma(const vgh_i32x4 &a, const vgh_i32
 // BOUND of its distance (the filter's own estimate plus its error bound); the k-th smallest bound of a query is then an
 // upper bound of its final k-th best distance - the start threshold of the real pass, which scans every row.
 template <int VT, int NTB, int MODE, bool BOUND>
-__global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a) {
+__global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(BatchArgsH a) {
+    constexpr int WAVES = VGH_WAVES_OF(NTB), THREADS = 64 * WAVES, QPB = WAVES * VGH_QPW;
+    constexpr int XU = (NTB <= 32) ? 1 : 2;                              // 16-byte chunks per lane in the exact evaluation
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);
     constexpr int ACC = COS ? A_COSN : (L2M ? A_L2 : A_DOT);            // the exact evaluation's accumulator
     typedef Accum<VT, ACC> Exact;
@@ -119,21 +122,21 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
     uint8_t *tile0 = smem;
     float *rstat_lds = reinterpret_cast<float *>(smem + 2 * TILE_BYTES);                 // [2 buffers][32]: sum x^2
     double *qq_lds = reinterpret_cast<double *>(rstat_lds + 2 * 32);                     // [waves][32]: sum q^2 (f64)
-    uint32_t *qsp_lds = reinterpret_cast<uint32_t *>(qq_lds + VGH_WAVES * VGH_QPW);       // [waves][32]: query holds Inf / NaN
-    float *thr_lds = reinterpret_cast<float *>(qsp_lds + VGH_WAVES * VGH_QPW);            // [waves][32]: k-th best so far
-    uint64_t *lists = reinterpret_cast<uint64_t *>(thr_lds + VGH_WAVES * VGH_QPW);        // [waves][32][k]
+    uint32_t *qsp_lds = reinterpret_cast<uint32_t *>(qq_lds + WAVES * VGH_QPW);       // [waves][32]: query holds Inf / NaN
+    float *thr_lds = reinterpret_cast<float *>(qsp_lds + WAVES * VGH_QPW);            // [waves][32]: k-th best so far
+    uint64_t *lists = reinterpret_cast<uint64_t *>(thr_lds + WAVES * VGH_QPW);        // [waves][32][k]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x = lane & 31, h = lane >> 5;
     const int k = a.k;
 
-    const int G = a.nq_pad / VGH_QPB;
+    const int G = a.nq_pad / QPB;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int g = idx % G;
     const int part = (idx / G) * 8 + xcd;
     if (part >= a.npart) return;
-    const int q0 = g * VGH_QPB + wave * VGH_QPW;
+    const int q0 = g * QPB + wave * VGH_QPW;
     const int chunks_per_row = (int)(a.stride / 16);
 
     // ---- A operand: lane (x, h) keeps bytes [32t + 16h, +16) of query x
@@ -154,9 +157,13 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
     float *thr_w = thr_lds + wave * VGH_QPW;
     uint64_t *wave_lists = lists + (size_t)wave * VGH_QPW * k;
     for (int qi = 0; qi < VGH_QPW; ++qi) {
-        uint4 qv[1] = {make_uint4(0u, 0u, 0u, 0u)};
-        if (lane < chunks_per_row) qv[0] = reinterpret_cast<const uint4 *>(a.queries + (long long)(q0 + qi) * a.stride)[lane];
-        const typename Accum<VT, A_COSN>::QStat s = Accum<VT, A_COSN>::template query_stat<1>(qv, 6);
+        uint4 qv[XU];
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            qv[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (lane + 64 * u < chunks_per_row) qv[u] = reinterpret_cast<const uint4 *>(a.queries + (long long)(q0 + qi) * a.stride)[lane + 64 * u];
+        }
+        const typename Accum<VT, A_COSN>::QStat s = Accum<VT, A_COSN>::template query_stat<XU>(qv, 6);
         if (lane == 0) { qq_w[qi] = s.qq; qsp_w[qi] = s.qspecial; }
     }
     {   // a query the filter cannot judge (Inf / NaN elements, norm out of range) multiplies as ZERO: its accumulators
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
         thr_w[lane] = t;
     }
     for (int s = lane; s < VGH_QPW * k; s += 64) wave_lists[s] = VG_EMPTY_KEY;
-    for (int s = tid; s < 2 * TILE_BYTES / 4; s += VGH_THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = 0u;   // pad columns
+    for (int s = tid; s < 2 * TILE_BYTES / 4; s += THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = 0u;   // pad columns
     __syncthreads();
 
     // ---- tile streaming by LDS-DMA (vg_batch_i8.hip): piece p = chunk columns 2p, 2p+1 of all 32 rows
@@ -182,11 +189,11 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
     const long long tile_last = min(tile_first + a.tiles_per_part, a.tile_end);
     const unsigned long long stride_b = (unsigned long long)a.stride;
     const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)tile0;
-    constexpr int NPIECE = (NTB + VGH_WAVES - 1) / VGH_WAVES;
+    constexpr int NPIECE = (NTB + WAVES - 1) / WAVES;
     uint64_t piece_mask[NPIECE];
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
-        const int p = wave + i * VGH_WAVES;
+        const int p = wave + i * WAVES;
         piece_mask[i] = __ballot(p < npieces && (2 * p + h) < chunks_per_row);
     }
     auto lane_offset = [&](long long tile) -> uint32_t {            // rows past the end re-read the last row (masked later)
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
         return xr * (uint32_t)a.stride + (uint32_t)h * 16u;
     };
     const uint32_t lds_rstat0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)rstat_lds;
-    const uint64_t stat_mask = __ballot(wave == VGH_WAVES - 1 && lane < 8);
+    const uint64_t stat_mask = __ballot(wave == WAVES - 1 && lane < 8);
     const uint32_t stat_goff = (uint32_t)lane * 16u;
     auto dma_stats = [&](long long tile, int buf) {                 // the tile's 32 row norms ride the same pipeline
         const uint8_t *b0 = reinterpret_cast<const uint8_t *>(a.row_nn + tile * VGH_TILE);
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
                      : "=&s"(keep), "=&s"(keep_exec) : "v"(stat_goff), "s"(b0), "s"(d0), "s"(stat_mask) : "memory", "scc");
     };
     auto dma_piece = [&](long long tile, uint32_t lane_goff, int buf, int i) {
-        const int p = wave + i * VGH_WAVES;
+        const int p = wave + i * WAVES;
         const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGH_TILE) * stride_b + (unsigned)p * 32u;
         const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + p * 1024);
         uint32_t keep;
@@ -272,13 +279,18 @@ __global__ __launch_bounds__(VGH_THREADS, 1) void vg_batch_h_kernel(BatchArgsH a
     auto exact_distance = [&](int qi_u, uint32_t row_u, float nn_u) __attribute__((always_inline)) -> float {
         const uint8_t *qp = a.queries + (long long)(q0 + qi_u) * a.stride;
         const uint8_t *xp = a.rows + (unsigned long long)row_u * stride_b;
-        uint4 qv = make_uint4(0u, 0u, 0u, 0u), xv = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < chunks_per_row) { qv = reinterpret_cast<const uint4 *>(qp)[lane]; xv = reinterpret_cast<const uint4 *>(xp)[lane]; }
+        uint4 qv[XU], xv[XU];
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            qv[u] = make_uint4(0u, 0u, 0u, 0u); xv[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (lane + 64 * u < chunks_per_row) { qv[u] = reinterpret_cast<const uint4 *>(qp)[lane + 64 * u]; xv[u] = reinterpret_cast<const uint4 *>(xp)[lane + 64 * u]; }
+        }
         typename Exact::QStat qs;
         qs.qq = qq_w[qi_u]; qs.qspecial = qsp_w[qi_u];
         Exact acc;
         acc.init();
-        acc.chunk(qv, xv);
+#pragma unroll
+        for (int u = 0; u < XU; ++u) acc.chunk(qv[u], xv[u]);
         float d;
         if constexpr (COS) d = acc.finish_cached_norm(qs, 6, nn_u);
         else d = acc.finish(qs, 6, a.root);
@@ -483,7 +495,7 @@ static int launch_h(const BatchArgsH &a, int blocks, size_t smem, hipStream_t st
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_h_kernel<VT, NTB, MODE, BOUND>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((vg_batch_h_kernel<VT, NTB, MODE, BOUND>), dim3((unsigned)blocks), dim3(VGH_THREADS), smem, stream, a);
+    hipLaunchKernelGGL((vg_batch_h_kernel<VT, NTB, MODE, BOUND>), dim3((unsigned)blocks), dim3(64 * VGH_WAVES_OF(NTB)), smem, stream, a);
     return (int)hipGetLastError();
 }
 template <int VT, int NTB, bool BOUND>
@@ -497,7 +509,9 @@ static int launch_h_ntb(const BatchArgsH &a, int ntb, int blocks, size_t smem, h
     if (ntb == 8) return launch_h_mode<VT, 8, BOUND>(a, blocks, smem, stream);
     if (ntb == 16) return launch_h_mode<VT, 16, BOUND>(a, blocks, smem, stream);
     if (ntb == 24) return launch_h_mode<VT, 24, BOUND>(a, blocks, smem, stream);
-    return launch_h_mode<VT, 32, BOUND>(a, blocks, smem, stream);
+    if (ntb == 32) return launch_h_mode<VT, 32, BOUND>(a, blocks, smem, stream);
+    if (ntb == 48) return launch_h_mode<VT, 48, BOUND>(a, blocks, smem, stream);
+    return launch_h_mode<VT, 64, BOUND>(a, blocks, smem, stream);
 }
 
 #if VGH_TU == 1 || defined(VGH_TU_ALL)
@@ -518,7 +532,6 @@ extern "C" int vgh_launch_real_f16(const BatchArgsH *a, int ntb, int blocks, siz
 extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
                                      uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
 
-extern "C" int vg_batch_h_queries_per_block(void) { return VGH_QPB; }
 
 static int vgh_ntb(long long stride_bytes) {
     const int ntb = (int)((stride_bytes + 31) / 32);
@@ -526,13 +539,18 @@ static int vgh_ntb(long long stride_bytes) {
     if (ntb <= 16) return 16;
     if (ntb <= 24) return 24;
     if (ntb <= 32) return 32;
+    if (ntb <= 48) return 48;                                     // rows up to 768 / 1024 elements: 4-wavefront workgroups
+    if (ntb <= 64) return 64;
     return 0;
 }
+
+extern "C" int vg_batch_h_queries_per_block(long long stride_bytes) { return VGH_WAVES_OF(vgh_ntb(stride_bytes)) * VGH_QPW; }
 
 extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k) {
     const int NTB = vgh_ntb(stride_bytes);
     if (!NTB || k < 1 || k > VGH_MAX_K) return 0;
-    const size_t b = (size_t)2 * NTB * 1024 + 256 + (size_t)VGH_WAVES * VGH_QPW * (8 + 4 + 4) + (size_t)VGH_WAVES * VGH_QPW * k * 8;
+    const size_t waves = (size_t)VGH_WAVES_OF(NTB);
+    const size_t b = (size_t)2 * NTB * 1024 + 256 + waves * VGH_QPW * (8 + 4 + 4) + waves * VGH_QPW * k * 8;
     return b <= 160 * 1024 ? b : 0;
 }
 
@@ -544,14 +562,14 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long
                                  const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
                                  uint64_t *dev_out_keys, hipStream_t stream) {
     const size_t smem = vg_batch_h_lds_bytes(stride_bytes, k);
-    if (!smem || nq_pad % VGH_QPB != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
+    if (!smem || nq_pad % vg_batch_h_queries_per_block(stride_bytes) != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
     if (mode < VGH_DOT || mode > VGH_L2 || !dev_row_nn) return -1;
     BatchArgsH a;
     a.rows = dev_rows; a.queries = dev_queries; a.row_nn = dev_row_nn; a.cand = dev_cand;
     a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;
     a.mode = mode; a.root = root; a.dim = dim;
     const int ntb = vgh_ntb(stride_bytes);
-    const int G = nq_pad / VGH_QPB;
+    const int G = nq_pad / vg_batch_h_queries_per_block(stride_bytes);
     const int blocks = G * ((npart + 7) / 8) * 8;
     const long long ntiles = (n_rows + VGH_TILE - 1) / VGH_TILE;
     auto launch = [&](const BatchArgsH &b, bool bound) -> int {

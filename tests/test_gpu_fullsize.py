@@ -177,13 +177,13 @@ def test_c5_batched_10m(env, metric):
 
 @pytest.mark.parametrize("vt_name", ("f16", "bf16"))
 def test_half_precision_batch_10m(env, vt_name):
-    """10M x 384 f16 / bf16, a batch of 300 queries (two query groups, bound-only pre-pass + real pass): the matrix cores
+    """10M x 384 f16 / 10M x 768 bf16, a batch of 300 queries (two query groups, bound-only pre-pass + real pass): the matrix cores
     only filter, the survivors carry the single scan's f64 arithmetic - so every list must be the single scan's list
     (distances within one rounding of the float result, rows equal unless two distances tie within that)."""
     pkg, torch = env
     vt = pkg.F16 if vt_name == "f16" else pkg.BF16
     tdt = torch.float16 if vt_name == "f16" else torch.bfloat16
-    dim, k, nq = 384, 20, 300
+    dim, k, nq = (384, 20, 300) if vt_name == "f16" else (768, 20, 300)     # bf16: the long-row (4-wavefront) kernels
     c, blocks = _build(pkg, torch, vt, dim, 47)
     del blocks
     qs = torch.from_numpy(np.random.default_rng(48).standard_normal((nq, dim), dtype=np.float32)).to(tdt).view(torch.int16).numpy().view(np.uint16)

@@ -365,7 +365,7 @@ def test_batch_half_matrix_core_filter_vs_single_scans(pkg, orc, vt, metric, mon
     """f16 / bf16 batches: the matrix cores (v_mfma_f32_32x32x16_f16 / _bf16) only FILTER; every (query, row) pair
     that can beat the current k-th best is re-evaluated with the single-query kernel's f64 arithmetic, so the results
     are the single scans' results - including rows / queries with Inf, NaN, zeros, huge and subnormal values."""
-    for dim in (8, 100, 128, 384, 500, 512):
+    for dim in (8, 100, 128, 384, 500, 512, 520, 768, 1000, 1024):       # > 512: the 4-wavefront kernels (rows up to 2 KiB)
         n = 4133
         rows = dg.corpus(vt, n, dim, 8200 + dim)
         _, edge = dg.edge_rows(vt, dim, 8300 + dim)                       # Inf / NaN / max / subnormal / zero rows
