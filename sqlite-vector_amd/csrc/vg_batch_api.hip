@@ -20,7 +20,7 @@ extern "C" int vg_rownorm_launch(const float *dev_rows, long long row0, long lon
 // f16 / bf16 corpora: (float) sum x^2 (single-query cosine, A_COSN).
 // ---- quantized batches on the integer matrix cores (vg_batch_i8.hip)
 extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k);
-extern "C" int vg_batch_i8_queries_per_block(void);
+extern "C" int vg_batch_i8_queries_per_block(long long stride_bytes);
 extern "C" int vg_i8_rowstat_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int is_u8,
                                     int32_t *dev_sx, uint32_t *dev_sxx, uint8_t *dev_flipped, hipStream_t stream);
 extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_rows, long long stride_bytes,
@@ -86,7 +86,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
                                 int *out_counts) {
     const bool quantized = (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8);
     const bool half = (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16);
-    const int QPB = quantized ? vg_batch_i8_queries_per_block() : (half ? vg_batch_h_queries_per_block(c->stride) : 128);
+    const int QPB = quantized ? vg_batch_i8_queries_per_block(c->stride) : (half ? vg_batch_h_queries_per_block(c->stride) : 128);
     const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
     const int G = nq_pad / QPB;
     // partitions: enough workgroups to cover the chip (G * npart ~ CUs), a multiple of 8 (one per XCD), <= 256

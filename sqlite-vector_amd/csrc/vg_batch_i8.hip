@@ -29,9 +29,9 @@ typedef int vgi_i32x4 __attribute__((ext_vector_type(4)));
 #ifndef VGI_WAVES
 #define VGI_WAVES 8                     // two wavefronts per SIMD: one gates / inserts / issues DMA while the other's MFMAs run
 #endif
-#define VGI_THREADS (64 * VGI_WAVES)
+#define VGI_WAVES_LONG 4                // rows of 1 - 2 KiB: A alone is up to 256 registers, one wavefront per SIMD
+#define VGI_WAVES_OF(NTB) ((NTB) <= 32 ? VGI_WAVES : VGI_WAVES_LONG)
 #define VGI_QPW 32
-#define VGI_QPB (VGI_WAVES * VGI_QPW)
 #define VGI_TILE 32
 #define VGI_MAX_K 32
 #define VGI_BPIPE 4
@@ -84,8 +84,9 @@ __device__ __forceinline__ void vgi_wait_lds(vgi_i32x4 &v) {
 // the start threshold of the real pass, which scans EVERY row.  A list warms up with one insert per (query, tile)
 // instead of one per passing row (each insert is an LDS round trip of the whole wavefront).
 template <int NTB, int MODE, bool IS_U8, bool PRE>
-__global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8 a) {
-    constexpr bool COS = (MODE == VGI_COS), L2M = (MODE == VGI_L2);
+__global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(BatchArgsI8 a) {
+    constexpr int WAVES = VGI_WAVES_OF(NTB), THREADS = 64 * WAVES, QPB = WAVES * VGI_QPW;
+        constexpr bool COS = (MODE == VGI_COS), L2M = (MODE == VGI_L2);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // LDS tile, TRANSPOSED BY 16-BYTE CHUNK: chunk column c of the 32 rows is one contiguous 512-byte run
     // (address c * 512 + row * 16).  A lane's b128 read of (row x, chunk 2t + h) sits next to its neighbours' - no
@@ -98,19 +99,19 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
     uint8_t *tile0 = smem;
     uint32_t *rstat_lds = reinterpret_cast<uint32_t *>(smem + VGI_NBUF * TILE_BYTES);    // [buffers][sum x: 32 | sum x^2: 32]
     uint32_t *qstat_lds = rstat_lds + VGI_NBUF * 64;                                     // [waves][32][2]: sum q, sum q^2
-    uint64_t *lists = reinterpret_cast<uint64_t *>(qstat_lds + VGI_WAVES * VGI_QPW * 2);  // [4][32][k]
+    uint64_t *lists = reinterpret_cast<uint64_t *>(qstat_lds + WAVES * VGI_QPW * 2);  // [4][32][k]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x = lane & 31, h = lane >> 5;
     const int k = a.k;
 
-    const int G = a.nq_pad / VGI_QPB;
+    const int G = a.nq_pad / QPB;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int g = idx % G;
     const int part = (idx / G) * 8 + xcd;
     if (part >= a.npart) return;
-    const int q0 = g * VGI_QPB + wave * VGI_QPW;
+    const int q0 = g * QPB + wave * VGI_QPW;
 
     // ---- A operand (+ the query's sums in its ORIGINAL representation)
     vgi_i32x4 areg[NTB];
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
         for (int s = lane; s < VGI_QPW * k; s += 64) wave_lists[s] = VG_EMPTY_KEY;
     }
     // pad columns never touched by the DMA must read as "0" of the original representation
-    for (int s = tid; s < VGI_NBUF * TILE_BYTES / 4; s += VGI_THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = IS_U8 ? 0x80808080u : 0u;
+    for (int s = tid; s < VGI_NBUF * TILE_BYTES / 4; s += THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = IS_U8 ? 0x80808080u : 0u;
     __syncthreads();
 
     // ---- tile streaming by LDS-DMA: piece p = chunk columns 2p and 2p+1 of all 32 rows; wavefront w moves pieces
@@ -156,11 +157,11 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
     const long long tile_last = min(tile_first + a.tiles_per_part, a.tile_end);
     const unsigned long long stride_b = (unsigned long long)a.stride;
     const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)tile0;
-    constexpr int NPIECE = (NTB + VGI_WAVES - 1) / VGI_WAVES;  // piece slots per wavefront and tile (compile time)
+    constexpr int NPIECE = (NTB + WAVES - 1) / WAVES;  // piece slots per wavefront and tile (compile time)
     uint64_t piece_mask[NPIECE];
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
-        const int p = wave + i * VGI_WAVES;
+        const int p = wave + i * WAVES;
         piece_mask[i] = __ballot(p < npieces && (2 * p + h) < chunks_per_row);
     }
     // rows past the end of the corpus (last tile only) re-read the last row: their scores are masked by the row bound
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
     // with ordinary loads at the tile boundary they cost a full L2 / HBM round trip per tile - with only 8..32
     // MFMAs per tile that latency WAS the kernel time (7 ms of the 10.7 at D = 768, and independent of D).
     const uint32_t lds_rstat0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)rstat_lds;
-    const uint64_t stat_mask = __ballot(wave == VGI_WAVES - 1 && lane < 8);
+    const uint64_t stat_mask = __ballot(wave == WAVES - 1 && lane < 8);
     const uint32_t stat_goff = (uint32_t)lane * 16u;
     auto dma_stats = [&](long long tile, int buf) {
         const uint8_t *b0 = reinterpret_cast<const uint8_t *>(a.row_sx + tile * VGI_TILE);
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(VGI_THREADS, 1) void vg_batch_i8_kernel(BatchArgsI8
                      : "=&s"(keep), "=&s"(keep_exec) : "v"(stat_goff), "s"(b0), "s"(b1), "s"(d0), "s"(d1), "s"(stat_mask) : "memory", "scc");
     };
     auto dma_piece = [&](long long tile, uint32_t lane_goff, int buf, int i) {
-        const int p = wave + i * VGI_WAVES;
+        const int p = wave + i * WAVES;
         const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGI_TILE) * stride_b + (unsigned)p * 32u;
         const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + p * 1024);
         uint32_t keep;
@@ -547,7 +548,7 @@ static int launch_i8(const BatchArgsI8 &a, int blocks, size_t smem, hipStream_t 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_i8_kernel<NTB, MODE, IS_U8, PRE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((vg_batch_i8_kernel<NTB, MODE, IS_U8, PRE>), dim3((unsigned)blocks), dim3(VGI_THREADS), smem, stream, a);
+    hipLaunchKernelGGL((vg_batch_i8_kernel<NTB, MODE, IS_U8, PRE>), dim3((unsigned)blocks), dim3(64 * VGI_WAVES_OF(NTB)), smem, stream, a);
     return (int)hipGetLastError();
 }
 template <int NTB, int MODE, bool PRE>
@@ -565,7 +566,13 @@ static int launch_i8_ntb(const BatchArgsI8 &a, int ntb, int blocks, size_t smem,
     if (ntb <= 8) return launch_i8_mode<8, PRE>(a, blocks, smem, stream);
     if (ntb <= 16) return launch_i8_mode<16, PRE>(a, blocks, smem, stream);
     if (ntb <= 24) return launch_i8_mode<24, PRE>(a, blocks, smem, stream);
-    return launch_i8_mode<32, PRE>(a, blocks, smem, stream);
+    if (ntb <= 32) return launch_i8_mode<32, PRE>(a, blocks, smem, stream);
+#if !VGI_PHASED                                                       // (the phased experiment assumes 8 wavefronts)
+    if (ntb <= 48) return launch_i8_mode<48, PRE>(a, blocks, smem, stream);
+    return launch_i8_mode<64, PRE>(a, blocks, smem, stream);
+#else
+    return -1;
+#endif
 }
 #if defined(VGI_TU_PRE) || defined(VGI_TU_ALL)
 extern "C" int vgi_launch_pre(const BatchArgsI8 *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
@@ -580,15 +587,25 @@ extern "C" int vgi_launch_real(const BatchArgsI8 *a, int ntb, int blocks, size_t
 extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
                                      uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
 
-extern "C" int vg_batch_i8_queries_per_block(void) { return VGI_QPB; }
+static int vgi_ntb(long long stride_bytes) {                      // the instantiated k-step counts (32 bytes each)
+    const int ntb = (int)((stride_bytes + 31) / 32);
+    if (ntb <= 8) return 8;
+    if (ntb <= 16) return 16;
+    if (ntb <= 24) return 24;
+    if (ntb <= 32) return 32;
+    if (ntb <= 48) return 48;                                     // rows of 1 - 2 KiB: 4-wavefront workgroups
+    if (ntb <= 64) return 64;
+    return 0;
+}
+
+extern "C" int vg_batch_i8_queries_per_block(long long stride_bytes) { return VGI_WAVES_OF(vgi_ntb(stride_bytes)) * VGI_QPW; }
 
 extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k) {
-    const int ntb = (int)((stride_bytes + 31) / 32);
-    int NTB;
-    if (ntb <= 8) NTB = 8; else if (ntb <= 16) NTB = 16; else if (ntb <= 24) NTB = 24; else if (ntb <= 32) NTB = 32;
-    else return 0;
-    if (k < 1 || k > VGI_MAX_K) return 0;
-    const size_t b = (size_t)VGI_NBUF * (NTB * 1024 + 256) + (size_t)VGI_WAVES * VGI_QPW * 2 * 4 + (size_t)VGI_WAVES * VGI_QPW * k * 8;
+    const int NTB = vgi_ntb(stride_bytes);
+    if (!NTB || k < 1 || k > VGI_MAX_K) return 0;
+    if (VGI_PHASED && NTB > 32) return 0;
+    const size_t waves = (size_t)VGI_WAVES_OF(NTB);
+    const size_t b = (size_t)VGI_NBUF * (NTB * 1024 + 256) + waves * VGI_QPW * 2 * 4 + waves * VGI_QPW * k * 8;
     return b <= 160 * 1024 ? b : 0;
 }
 
@@ -599,14 +616,14 @@ extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_ro
                                   const int32_t *dev_sx, const uint32_t *dev_sxx, uint64_t *dev_cand, int npart,
                                   int tiles_per_part, uint64_t *dev_out_keys, hipStream_t stream) {
     const size_t smem = vg_batch_i8_lds_bytes(stride_bytes, k);
-    if (!smem || nq_pad % VGI_QPB != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
+    if (!smem || nq_pad % vg_batch_i8_queries_per_block(stride_bytes) != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
     if (mode < VGI_DOT || mode > VGI_L2 || !dev_sx || !dev_sxx) return -1;
     BatchArgsI8 a;
     a.rows = dev_rows_signed; a.queries = dev_queries; a.row_sx = dev_sx; a.row_sxx = dev_sxx; a.cand = dev_cand;
     a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;
     a.mode = mode; a.root = root; a.is_u8 = is_u8;
     const int ntb = (int)((stride_bytes + 31) / 32);
-    const int G = nq_pad / VGI_QPB;
+    const int G = nq_pad / vg_batch_i8_queries_per_block(stride_bytes);
     const int blocks = G * ((npart + 7) / 8) * 8;
     const long long ntiles = (n_rows + VGI_TILE - 1) / VGI_TILE;
     // Large corpora: the PRE pass over the first 1/32 of the rows (one insert per query and tile) hands every query a

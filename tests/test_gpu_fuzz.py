@@ -57,7 +57,7 @@ def test_random_batches_vs_single_scans(pkg, chunk):
     for _ in range(20):
         vt = int(rng.choice([dg.F32, dg.U8, dg.I8, dg.F16, dg.BF16]))
         metric = int(rng.choice(dg.ALL_METRICS))
-        dim = int(rng.integers(1, 513)) if vt == dg.F32 else (int(rng.integers(1, 1100)) if vt in (dg.U8, dg.I8) else int(rng.integers(1, 1100)))
+        dim = int(rng.integers(1, 513)) if vt == dg.F32 else (int(rng.integers(1, 2200)) if vt in (dg.U8, dg.I8) else int(rng.integers(1, 1100)))
         n = int(rng.choice([rng.integers(1, 100), rng.integers(100, 5000), rng.integers(5000, 30000)]))
         nq = int(rng.choice([1, 3, 33, 129, 260]))
         k = int(rng.choice([1, 5, 20, 32, 40]))

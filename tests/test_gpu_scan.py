@@ -735,7 +735,7 @@ def test_large_k_radix_select_equals_full_sort_and_oracle(pkg, orc, monkeypatch)
 
 
 @pytest.mark.parametrize("vt", (dg.U8, dg.I8))
-@pytest.mark.parametrize("dim", (16, 100, 384, 768, 1000, 1024))
+@pytest.mark.parametrize("dim", (16, 100, 384, 768, 1000, 1024, 1030, 1536, 2048))     # > 1024: the 4-wavefront kernels
 def test_quantized_batch_on_integer_matrix_cores_is_bit_exact(pkg, orc, vt, dim):
     """uint8 / int8 batches run Q x C^T on the integer matrix cores (v_mfma_i32_32x32x32_i8; uint8 through the
     x - 128 identity).  Integer sums are exact, so every query's list must equal the single-query scan - itself
