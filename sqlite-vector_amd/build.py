@@ -26,7 +26,7 @@ HIP_UNITS = [("vg_api.hip", "vg_api.hip.o", []), ("vg_corpus.hip", "vg_corpus.hi
              ("vg_shards.hip", "vg_shards.hip.o", []), ("vg_multi.hip", "vg_multi.hip.o", []),
              ("vg_batch_i8.hip", "vg_batch_i8.hip.o", []), ("vg_batch_i8.hip", "vg_batch_i8_pre.o", ["-DVGI_TU_PRE"]),
              ("vg_batch_h.hip", "vg_batch_h.hip.o", []), ("vg_batch_h.hip", "vg_batch_h_bf16.o", ["-DVGH_TU=1"]),
-             ("vg_batch_h.hip", "vg_batch_h_bound.o", ["-DVGH_TU=2"])]
+             ("vg_batch_h.hip", "vg_batch_h_bound.o", ["-DVGH_TU=2"]), ("vg_batch_h.hip", "vg_batch_h_f32.o", ["-DVGH_TU=3"])]
 HIP_SOURCES = sorted(set(u[0] for u in HIP_UNITS))
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 

@@ -31,10 +31,41 @@ extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_ro
 // ---- f16 / bf16 batches: matrix-core filter + exact f64 re-evaluation (vg_batch_h.hip)
 extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k);
 extern "C" int vg_batch_h_queries_per_block(long long stride_bytes);
-extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long long stride_bytes, int dim, int is_bf16,
+extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long long stride_bytes, int dim, int type_code,
+                                 const uint8_t *dev_xrows, long long xstride_bytes,
                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
                                  const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
                                  uint64_t *dev_out_keys, hipStream_t stream);
+extern "C" int vg_f32_to_bf16_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int dim,
+                                     uint8_t *dev_out, long long ostride, hipStream_t stream);
+
+// f32 corpora with rows of 513 .. 1024 floats have no f32 matrix-core kernel (A does not fit the register file, the tiles not
+// the LDS): they run through the half-precision kernel with a bf16 SHADOW copy as the filter's input and the f32 rows for the
+// exact evaluation.  VG_F32_FILTER=1 sends shorter rows the same way (5x the f32 MFMA kernel at D = 384: the filter runs at
+// the bf16 rate, the survivors carry the single-query kernel's f32 arithmetic).
+static long long bf16_shadow_stride(const vg_corpus *c) { return (((long long)c->dim * 2 + 15) / 16) * 16; }
+static bool batch_f32_filter_eligible(const vg_corpus *c, int metric, int k) {
+    if (env_int("VG_BATCH_MFMA", 1) == 0 || c->vtype != VG_TYPE_F32 || metric == VG_DIST_L1) return false;
+    if (c->dim <= 512 && env_int("VG_F32_FILTER", 0) == 0) return false;
+    return vg_batch_h_lds_bytes(bf16_shadow_stride(c), k) != 0;
+}
+static int ensure_bf16_shadow(vg_corpus *c) {
+    const long long bs = bf16_shadow_stride(c);
+    if (c->bf_cap < c->n_rows) {
+        const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_rows_bf) hipFree(c->d_rows_bf);
+        c->d_rows_bf = nullptr; c->bf_cap = 0; c->bf_rows = 0;
+        HIP_TRY(hipMalloc(&c->d_rows_bf, (size_t)cap * bs));
+        c->bf_cap = cap;
+    }
+    if (c->bf_rows < c->n_rows) {
+        int rc = vg_f32_to_bf16_launch(c->d_rows, c->bf_rows, c->n_rows - c->bf_rows, c->stride, c->dim, c->d_rows_bf, bs, c->stream);
+        if (rc != 0) return vg_fail(VG_ERR_HIP, "bf16 shadow pass failed: %s", hipGetErrorString((hipError_t)rc));
+        c->bf_rows = c->n_rows;
+    }
+    return VG_OK;
+}
 
 static bool batch_h_eligible(const vg_corpus *c, int metric, int k) {
     if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
@@ -85,8 +116,12 @@ static bool batch_mfma_eligible(const vg_corpus *c, int metric, int k) {
 static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys,
                                 int *out_counts) {
     const bool quantized = (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8);
-    const bool half = (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16);
-    const int QPB = quantized ? vg_batch_i8_queries_per_block(c->stride) : (half ? vg_batch_h_queries_per_block(c->stride) : 128);
+    // f32 through the half-precision kernel (bf16 shadow copy): rows the f32 matrix-core kernel does not serve, or on request
+    const bool f32_filter = (c->vtype == VG_TYPE_F32) && batch_f32_filter_eligible(c, metric, k) &&
+                            (vg_batch_lds_bytes(c->stride, k) == 0 || env_int("VG_F32_FILTER", 0) != 0);
+    const bool half = (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) || f32_filter;
+    const long long fstride = f32_filter ? bf16_shadow_stride(c) : c->stride;       // row stride of what the matrix core reads
+    const int QPB = quantized ? vg_batch_i8_queries_per_block(c->stride) : (half ? vg_batch_h_queries_per_block(fstride) : 128);
     const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
     const int G = nq_pad / QPB;
     // partitions: enough workgroups to cover the chip (G * npart ~ CUs), a multiple of 8 (one per XCD), <= 256
@@ -119,6 +154,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     } else if (half || metric != VG_DIST_DOT) {            // f16 / bf16: every metric's filter needs sum x^2 per row
         int rcn = vg_ensure_row_norms(c);
         if (rcn != VG_OK) return rcn;
+        if (f32_filter && (rcn = ensure_bf16_shadow(c)) != VG_OK) return rcn;
     }
 
     hipEvent_t *evs = nullptr;
@@ -136,7 +172,8 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
                                 nq_pad, nq, k, mode, root, c->vtype == VG_TYPE_U8 ? 1 : 0, c->d_sx, c->d_sxx, c->d_bcand, npart,
                                 tiles_per_part, c->d_bkeys, c->stream);
     else if (half)
-        rc = vg_batch_h_launch(c->d_rows, c->n_rows, c->stride, c->dim, c->vtype == VG_TYPE_BF16 ? 1 : 0, (const uint8_t *)c->d_bq,
+        rc = vg_batch_h_launch(f32_filter ? c->d_rows_bf : c->d_rows, c->n_rows, fstride, c->dim,
+                               f32_filter ? 2 : (c->vtype == VG_TYPE_BF16 ? 1 : 0), c->d_rows, c->stride, (const uint8_t *)c->d_bq,
                                nq_pad, nq, k, mode, root, c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys, c->stream);
     else
         rc = vg_batch_launch((const float *)c->d_rows, c->n_rows, c->stride, (const float *)c->d_bq, nq_pad, nq, k, mode, root,
@@ -207,7 +244,8 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     if (k <= 0 || c->n_rows == 0) return VG_OK;
     if (!out_keys) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch_keys: NULL output");
     HIP_TRY(hipSetDevice(c->device));
-    if (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k) || batch_h_eligible(c, metric, k)) {
+    if (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k) || batch_h_eligible(c, metric, k) ||
+        batch_f32_filter_eligible(c, metric, k)) {
         // very large batches go through in slices: the per-(query, partition) candidate lists are nq x ~128 x 512 B
         const int slice = std::max(256, env_int("VG_BATCH_SLICE", 4096));
         int rc = VG_OK;

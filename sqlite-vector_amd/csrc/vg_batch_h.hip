@@ -70,9 +70,13 @@ extern "C" int vg_batch_h_timing(unsigned long long *out8, int reset) {
 #endif
 
 struct BatchArgsH {
-    const uint8_t *rows;      // N x stride bytes (f16 / bf16 elements, zero padded to 16 bytes)
-    const uint8_t *queries;   // nq_pad x stride bytes, zero padded
-    const float *row_nn;      // (float) sum x^2 per row (vg_half_rownorm_kernel), readable up to the end of the last tile
+    const uint8_t *rows;      // N x stride bytes (f16 / bf16 elements, zero padded to 16 bytes): what the matrix core reads
+    const uint8_t *queries;   // nq_pad x stride bytes, zero padded (f32 corpora: unused, the A operand is converted from xqueries)
+    const uint8_t *xrows;     // what the exact evaluation reads: = rows, or the f32 corpus behind a bf16 shadow copy
+    const uint8_t *xqueries;  // = queries, or the f32 queries (nq_pad x xstride bytes, zero padded)
+    long long xstride;
+    float cerr;               // relative error bound of the filter's s~ (times |q||x|)
+    const float *row_nn;      // (float) sum x^2 per row - f32 corpora: ||x|| - readable up to the end of the last tile
     uint64_t *cand;
     long long n_rows;
     long long stride;
@@ -113,9 +117,14 @@ __device__ __forceinline__ vgh_f32x16 vgh_mfma(const vgh_i32x4 &a, const vgh_i32
 template <int VT, int NTB, int MODE, bool BOUND>
 __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(BatchArgsH a) {
     constexpr int WAVES = VGH_WAVES_OF(NTB), THREADS = 64 * WAVES, QPB = WAVES * VGH_QPW;
-    constexpr int XU = (NTB <= 32) ? 1 : 2;                              // 16-byte chunks per lane in the exact evaluation
+    constexpr int XU = ((NTB <= 32) ? 1 : 2) * (VT == T_F32 ? 2 : 1);    // 16-byte chunks per lane in the exact evaluation
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);
-    constexpr int ACC = COS ? A_COSN : (L2M ? A_L2 : A_DOT);            // the exact evaluation's accumulator
+    // VT == T_F32: an f32 corpus.  The matrix core reads a bf16 SHADOW copy of it (inputs rounded to 8 bits: the filter's
+    // error bound grows to 2^-8 |q||x|, still only a fraction of a candidate per query on random data), the exact
+    // evaluation reads the f32 rows with the single-query kernel's f32 arithmetic.
+    constexpr bool XF32 = (VT == T_F32);
+    constexpr int FT = XF32 ? T_BF16 : VT;                               // element type the matrix core multiplies
+    constexpr int ACC = COS ? (XF32 ? A_COS : A_COSN) : (L2M ? A_L2 : A_DOT);   // the exact evaluation's accumulator
     typedef Accum<VT, ACC> Exact;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int TILE_BYTES = NTB * 2 * 512;                           // chunk column c of the 32 rows at c * 512 + row * 16
@@ -138,18 +147,35 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
     if (part >= a.npart) return;
     const int q0 = g * QPB + wave * VGH_QPW;
     const int chunks_per_row = (int)(a.stride / 16);
+    const int xchunks = (int)(a.xstride / 16);                           // 16-byte chunks of an exact-evaluation row
 
     // ---- A operand: lane (x, h) keeps bytes [32t + 16h, +16) of query x
     vgh_i32x4 areg[NTB];
     {
-        const uint8_t *qrow = a.queries + (long long)(q0 + x) * a.stride;
-        vgb_static_for<0, NTB>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            const int off = 32 * t + 16 * h;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (off < a.stride) v = *reinterpret_cast<const uint4 *>(qrow + off);
-            areg[t] = vgh_i32x4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-        });
+        if constexpr (XF32) {                                             // f32 query -> bf16 (round to nearest even) on the fly
+            const uint8_t *qrow = a.xqueries + (long long)(q0 + x) * a.xstride;
+            auto bf = [](uint32_t lo, uint32_t hi) -> int {
+                const uint32_t l = (lo + 0x7FFFu + ((lo >> 16) & 1u)) >> 16, u = (hi + 0x7FFFu + ((hi >> 16) & 1u)) & 0xFFFF0000u;
+                return (int)(l | u);
+            };
+            vgb_static_for<0, NTB>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const int off = (32 * t + 16 * h) * 2;                    // byte offset of the same 8 elements in the f32 row
+                uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = make_uint4(0u, 0u, 0u, 0u);
+                if (off + 16 <= a.xstride) v0 = *reinterpret_cast<const uint4 *>(qrow + off);
+                if (off + 32 <= a.xstride) v1 = *reinterpret_cast<const uint4 *>(qrow + off + 16);
+                areg[t] = vgh_i32x4{bf(v0.x, v0.y), bf(v0.z, v0.w), bf(v1.x, v1.y), bf(v1.z, v1.w)};
+            });
+        } else {
+            const uint8_t *qrow = a.queries + (long long)(q0 + x) * a.stride;
+            vgb_static_for<0, NTB>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const int off = 32 * t + 16 * h;
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (off < a.stride) v = *reinterpret_cast<const uint4 *>(qrow + off);
+                areg[t] = vgh_i32x4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+            });
+        }
     }
     // ---- per-query statistics of the exact path (the single-query kernel's query_stat with 64 lanes per row)
     double *qq_w = qq_lds + wave * VGH_QPW;
@@ -161,10 +187,15 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             qv[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (lane + 64 * u < chunks_per_row) qv[u] = reinterpret_cast<const uint4 *>(a.queries + (long long)(q0 + qi) * a.stride)[lane + 64 * u];
+            if (lane + 64 * u < xchunks) qv[u] = reinterpret_cast<const uint4 *>(a.xqueries + (long long)(q0 + qi) * a.xstride)[lane + 64 * u];
         }
-        const typename Accum<VT, A_COSN>::QStat s = Accum<VT, A_COSN>::template query_stat<XU>(qv, 6);
-        if (lane == 0) { qq_w[qi] = s.qq; qsp_w[qi] = s.qspecial; }
+        if constexpr (XF32) {
+            const typename Accum<T_F32, A_COS>::QStat s = Accum<T_F32, A_COS>::template query_stat<XU>(qv, 6);
+            if (lane == 0) { qq_w[qi] = (double)s.qq; qsp_w[qi] = 0u; }       // (Inf / NaN queries: the norm check below)
+        } else {
+            const typename Accum<VT, A_COSN>::QStat s = Accum<VT, A_COSN>::template query_stat<XU>(qv, 6);
+            if (lane == 0) { qq_w[qi] = s.qq; qsp_w[qi] = s.qspecial; }
+        }
     }
     {   // a query the filter cannot judge (Inf / NaN elements, norm out of range) multiplies as ZERO: its accumulators
         // then hold the "accept everything" start value instead of Inf / NaN, and every row takes the exact path
@@ -236,7 +267,7 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
     //   cosine  init = 0                            gmul = -((1 - thr) |q| (1 - 1e-5 sgn) - c |q|)
     //   L2      init = (thr2 (1 + 1e-5) - (1 - c) |q|^2) / 2 + tiny    gmul = -1
     // "accept everything" (list not full, query the filter cannot judge) = a huge FINITE init / gmul.
-    const float cerr = (float)(a.dim + 64) * 4.76837158203125e-7f;          // (D + 64) * 2^-21
+    const float cerr = a.cerr;                                              // halves: (D + 64) * 2^-21; f32 behind bf16: + 2^-8
     // Only init_reg / gmul live in registers (A alone takes up to 128 of the 256): the thresholds and the query norms
     // they derive from stay in LDS and are read again when a list changes.
     float init_reg[16], gmul[16];
@@ -277,27 +308,32 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
     // ---- the exact distance of ONE (query, row) pair, by the whole wavefront (wave-uniform arguments): lane c takes
     // chunk c of the row - the single-query kernel with 64 lanes per row and one chunk per lane
     auto exact_distance = [&](int qi_u, uint32_t row_u, float nn_u) __attribute__((always_inline)) -> float {
-        const uint8_t *qp = a.queries + (long long)(q0 + qi_u) * a.stride;
-        const uint8_t *xp = a.rows + (unsigned long long)row_u * stride_b;
+        const uint8_t *qp = a.xqueries + (long long)(q0 + qi_u) * a.xstride;
+        const uint8_t *xp = a.xrows + (unsigned long long)row_u * (unsigned long long)a.xstride;
         uint4 qv[XU], xv[XU];
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             qv[u] = make_uint4(0u, 0u, 0u, 0u); xv[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (lane + 64 * u < chunks_per_row) { qv[u] = reinterpret_cast<const uint4 *>(qp)[lane + 64 * u]; xv[u] = reinterpret_cast<const uint4 *>(xp)[lane + 64 * u]; }
+            if (lane + 64 * u < xchunks) { qv[u] = reinterpret_cast<const uint4 *>(qp)[lane + 64 * u]; xv[u] = reinterpret_cast<const uint4 *>(xp)[lane + 64 * u]; }
         }
         typename Exact::QStat qs;
-        qs.qq = qq_w[qi_u]; qs.qspecial = qsp_w[qi_u];
+        if constexpr (XF32) qs.qq = (float)qq_w[qi_u];
+        else { qs.qq = qq_w[qi_u]; qs.qspecial = qsp_w[qi_u]; }
         Exact acc;
         acc.init();
 #pragma unroll
         for (int u = 0; u < XU; ++u) acc.chunk(qv[u], xv[u]);
         float d;
-        if constexpr (COS) d = acc.finish_cached_norm(qs, 6, nn_u);
-        else d = acc.finish(qs, 6, a.root);
-        // Inf / NaN in the row or the query: the reference, replayed (every lane computes the same thing; the flag is
-        // the same in all lanes too - as a declared-uniform value it keeps this branch out of the divergence analysis)
-        if (__builtin_amdgcn_readfirstlane((int)acc.special(qs, 6)) != 0)
-            d = vg_slow_distance<VT, (COS ? A_COS : ACC)>(reinterpret_cast<const uint16_t *>(qp), reinterpret_cast<const uint16_t *>(xp), a.dim, a.root);
+        if constexpr (XF32) {
+            d = acc.finish(qs, 6, a.root);                            // the single-query f32 kernel's arithmetic (Inf / NaN propagate)
+        } else {
+            if constexpr (COS) d = acc.finish_cached_norm(qs, 6, nn_u);
+            else d = acc.finish(qs, 6, a.root);
+            // Inf / NaN in the row or the query: the reference, replayed (every lane computes the same thing; the flag is
+            // the same in all lanes too - as a declared-uniform value it keeps this branch out of the divergence analysis)
+            if (__builtin_amdgcn_readfirstlane((int)acc.special(qs, 6)) != 0)
+                d = vg_slow_distance<VT, (COS ? A_COS : ACC)>(reinterpret_cast<const uint16_t *>(qp), reinterpret_cast<const uint16_t *>(xp), a.dim, a.root);
+        }
         return vg_clamp(d);
     };
     bool bound_changed = false;
@@ -406,7 +442,7 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
             constexpr int in_flight_after = (NTB - 1 - t) < (BP - 1) ? (NTB - 1 - t) : (BP - 1);
             vgh_wait_lds<in_flight_after>(bq[t % BP]);
             const vgh_i32x4 b = bq[t % BP];
-            acc = vgh_mfma<VT>(areg[t], b, acc);
+            acc = vgh_mfma<FT>(areg[t], b, acc);
             if constexpr (t + BP < NTB) vgh_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
             constexpr int NTD = (NTB + 1) / 2;                       // next tile's DMA pieces over the first half of the k loop
             constexpr int pc_lo = (t >= NTD) ? NPIECE : (t * NPIECE + NTD - 1) / NTD;
@@ -414,7 +450,8 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
             vgb_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, goff_next, cur_buf ^ 1, decltype(pcc)::value); });
             if constexpr (t == 0) dma_stats(tile_next, cur_buf ^ 1);
         });
-        const float nn_row = rstat_lds[cur_buf * 32 + x];            // landed with the tile, one barrier ago
+        float nn_row = rstat_lds[cur_buf * 32 + x];                  // landed with the tile, one barrier ago
+        if constexpr (XF32) nn_row = nn_row * nn_row;                // (the f32 corpus caches ||x||, not sum x^2)
 #if VGH_TIMING
         asm volatile("s_nop 0" :: "v"(acc[15]));                      // the k loop's last MFMA has retired
 #endif
@@ -481,14 +518,16 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
 
 // ---- host side
 // The kernel instantiations are split over three translation units compiled from this file (build.py): the real-pass
-// kernels for f16 here (with the host entry points), for bf16 with -DVGH_TU=1, the bound-pass kernels with -DVGH_TU=2
+// kernels for f16 here (with the host entry points), for bf16 with -DVGH_TU=1, for f32 corpora with -DVGH_TU=3, the
+// bound-pass kernels with -DVGH_TU=2
 // (-DVGH_TU_ALL: everything in this one unit - the measurement builds of tools/build_half_variants.sh).
 #ifndef VGH_TU
 #define VGH_TU 0
 #endif
 extern "C" int vgh_launch_real_f16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);
 extern "C" int vgh_launch_real_bf16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);
-extern "C" int vgh_launch_bound(const BatchArgsH *a, int is_bf16, int ntb, int blocks, size_t smem, hipStream_t stream);
+extern "C" int vgh_launch_real_f32(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);   // -DVGH_TU=3
+extern "C" int vgh_launch_bound(const BatchArgsH *a, int type_code, int ntb, int blocks, size_t smem, hipStream_t stream);   // 0 f16, 1 bf16, 2 f32
 
 template <int VT, int NTB, int MODE, bool BOUND>
 static int launch_h(const BatchArgsH &a, int blocks, size_t smem, hipStream_t stream) {
@@ -520,8 +559,14 @@ extern "C" int vgh_launch_real_bf16(const BatchArgsH *a, int ntb, int blocks, si
 }
 #endif
 #if VGH_TU == 2 || defined(VGH_TU_ALL)
-extern "C" int vgh_launch_bound(const BatchArgsH *a, int is_bf16, int ntb, int blocks, size_t smem, hipStream_t stream) {
-    return is_bf16 ? launch_h_ntb<T_BF16, true>(*a, ntb, blocks, smem, stream) : launch_h_ntb<T_F16, true>(*a, ntb, blocks, smem, stream);
+extern "C" int vgh_launch_bound(const BatchArgsH *a, int type_code, int ntb, int blocks, size_t smem, hipStream_t stream) {
+    if (type_code == 2) return launch_h_ntb<T_F32, true>(*a, ntb, blocks, smem, stream);
+    return type_code == 1 ? launch_h_ntb<T_BF16, true>(*a, ntb, blocks, smem, stream) : launch_h_ntb<T_F16, true>(*a, ntb, blocks, smem, stream);
+}
+#endif
+#if VGH_TU == 3 || defined(VGH_TU_ALL)
+extern "C" int vgh_launch_real_f32(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_F32, false>(*a, ntb, blocks, smem, stream);
 }
 #endif
 #if VGH_TU == 0
@@ -554,10 +599,40 @@ extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k) {
     return b <= 160 * 1024 ? b : 0;
 }
 
-// dev_rows / dev_queries: f16 (is_bf16 = 0) or bf16 elements, zero padded rows of stride_bytes; dev_row_nn: (float) sum x^2
-// per row, readable for 32 floats past the last whole tile.  Returns 0, -1 if the shape is not served, a hipError_t
-// otherwise.  dev_cand sized like the f32 kernel's (vg_batch_lists_per_query).
-extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long long stride_bytes, int dim, int is_bf16,
+// f32 rows -> their bf16 shadow copy (round to nearest even; zero padded to the shadow stride): 8 elements per thread
+__global__ __launch_bounds__(256) void vg_f32_to_bf16_kernel(const uint8_t *rows, long long row0, long long n, long long stride,
+                                                             int dim, uint8_t *out, long long ostride) {
+    const int groups = (int)(ostride / 16);                               // 16-byte groups (8 elements) per shadow row
+    const long long total = n * groups;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = row0 + i / groups;
+        const int g = (int)(i % groups);
+        const float *src = reinterpret_cast<const float *>(rows + r * stride) + 8 * g;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = 8 * g + 2 * j;
+            const uint32_t lo = (e < dim) ? __float_as_uint(src[2 * j]) : 0u, hi = (e + 1 < dim) ? __float_as_uint(src[2 * j + 1]) : 0u;
+            w[j] = ((lo + 0x7FFFu + ((lo >> 16) & 1u)) >> 16) | ((hi + 0x7FFFu + ((hi >> 16) & 1u)) & 0xFFFF0000u);
+        }
+        *reinterpret_cast<uint4 *>(out + r * ostride + 16 * g) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+extern "C" int vg_f32_to_bf16_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int dim,
+                                     uint8_t *dev_out, long long ostride, hipStream_t stream) {
+    if (n <= 0) return 0;
+    long long blocks = (n * (ostride / 16) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(vg_f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dev_rows, row0, n, stride, dim, dev_out, ostride);
+    return (int)hipGetLastError();
+}
+
+// type_code 0 / 1: dev_rows / dev_queries hold f16 / bf16 elements, zero padded rows of stride_bytes; dev_xrows = dev_rows.
+// type_code 2: an f32 corpus - dev_rows is its bf16 shadow copy (stride_bytes per row), dev_xrows / dev_queries the f32 rows /
+// queries (xstride_bytes per row).  dev_row_nn: (float) sum x^2 per row (f32: ||x||), readable for 32 floats past the last
+// whole tile.  Returns 0, -1 if the shape is not served, a hipError_t otherwise.  dev_cand sized like the f32 kernel's.
+extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long long stride_bytes, int dim, int type_code,
+                                 const uint8_t *dev_xrows, long long xstride_bytes,
                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
                                  const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
                                  uint64_t *dev_out_keys, hipStream_t stream) {
@@ -566,6 +641,8 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long
     if (mode < VGH_DOT || mode > VGH_L2 || !dev_row_nn) return -1;
     BatchArgsH a;
     a.rows = dev_rows; a.queries = dev_queries; a.row_nn = dev_row_nn; a.cand = dev_cand;
+    a.xrows = dev_xrows; a.xqueries = dev_queries; a.xstride = xstride_bytes;
+    a.cerr = (float)(dim + 64) * 4.76837158203125e-7f + (type_code == 2 ? 0.00390625f + 1.6e-5f : 0.0f);   // (D+64) 2^-21 [+ 2^-8 (1 + 2^-8)]
     a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;
     a.mode = mode; a.root = root; a.dim = dim;
     const int ntb = vgh_ntb(stride_bytes);
@@ -573,8 +650,9 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long
     const int blocks = G * ((npart + 7) / 8) * 8;
     const long long ntiles = (n_rows + VGH_TILE - 1) / VGH_TILE;
     auto launch = [&](const BatchArgsH &b, bool bound) -> int {
-        if (bound) return vgh_launch_bound(&b, is_bf16, ntb, blocks, smem, stream);
-        return is_bf16 ? vgh_launch_real_bf16(&b, ntb, blocks, smem, stream) : vgh_launch_real_f16(&b, ntb, blocks, smem, stream);
+        if (bound) return vgh_launch_bound(&b, type_code, ntb, blocks, smem, stream);
+        if (type_code == 2) return vgh_launch_real_f32(&b, ntb, blocks, smem, stream);
+        return type_code == 1 ? vgh_launch_real_bf16(&b, ntb, blocks, smem, stream) : vgh_launch_real_f16(&b, ntb, blocks, smem, stream);
     };
     // Large corpora: a BOUND pre-pass over the first 1/32 of the rows gives every query an upper bound of its final
     // k-th best distance (no exact evaluations - with thresholds starting at +Inf they were a quarter of the whole

@@ -120,6 +120,7 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_sx) hipFree(c->d_sx);
     if (c->d_sxx) hipFree(c->d_sxx);
     if (c->d_rows_s8) hipFree(c->d_rows_s8);
+    if (c->d_rows_bf) hipFree(c->d_rows_bf);
     if (c->norm_ev) hipEventDestroy(c->norm_ev);
     if (c->d_bcand) hipFree(c->d_bcand);
     if (c->d_bkeys) hipFree(c->d_bkeys);
@@ -133,6 +134,7 @@ extern "C" int vg_corpus_clear(vg_corpus *c) {
     c->n_rows = 0;
     c->xnorm_rows = 0;
     c->i8_rows = 0;
+    c->bf_rows = 0;
     c->rowids.clear();
     return VG_OK;
 }

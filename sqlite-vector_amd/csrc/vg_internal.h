@@ -82,6 +82,8 @@ struct vg_corpus {
     int32_t *d_sx = nullptr;
     uint32_t *d_sxx = nullptr;
     uint8_t *d_rows_s8 = nullptr;
+    uint8_t *d_rows_bf = nullptr;                 // f32 corpora: bf16 shadow copy for the matrix-core filter (vg_batch_h.hip)
+    int64_t bf_rows = 0, bf_cap = 0;
     int64_t i8_rows = 0, i8_cap = 0;              // orders a caller-stream scan behind a norm pass on the corpus stream
     void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
     uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;

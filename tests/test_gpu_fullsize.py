@@ -215,3 +215,23 @@ def test_quantized_batch_10m_bit_exact(env, nq):
             one_ids, one_dist = c.scan_topk(metric, qs[i], k)
             assert ids[i].tolist() == one_ids.tolist() and np.array_equal(dist[i], one_dist), (metric, i)
     c.close()
+
+
+def test_f32_768_batch_10m_through_the_bf16_filter(env):
+    """10M x 768 f32 (30.7 GB + a 15.4 GB bf16 shadow copy), 200 queries: rows too long for the f32 matrix-core kernel run
+    the half-precision kernel as a filter; every list must be the single f32 scan's list within the f32 bar."""
+    pkg, torch = env
+    dim, k, nq = 768, 20, 200
+    c, blocks = _build(pkg, torch, pkg.F32, dim, 51)
+    del blocks
+    torch.cuda.empty_cache()
+    qs = np.random.default_rng(52).standard_normal((nq, dim), dtype=np.float32)
+    for metric in (dg.DOT, dg.L2, dg.COSINE):
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        assert np.all(cnt == k) and np.all(np.diff(dist, axis=1) >= 0)
+        for i in range(0, nq, 11):
+            one_ids, one_dist = c.scan_topk(metric, qs[i], k)
+            scale = float(np.abs(qs[i]).sum()) * 4.0 if metric == dg.DOT else (1.0 if metric == dg.COSINE else 0.0)
+            assert np.all(np.abs(dist[i] - one_dist) <= 1e-5 * (np.abs(one_dist) + scale) + 1e-6), (metric, i)
+            assert len(set(ids[i].tolist()) ^ set(one_ids.tolist())) <= 2, (metric, i)
+    c.close()

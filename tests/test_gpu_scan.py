@@ -348,6 +348,52 @@ def test_batch_multi_query_scan_vs_single_scans(pkg, orc, vt, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("metric", (dg.DOT, dg.COSINE, dg.L2, dg.SQUARED_L2))
+def test_batch_f32_long_rows_through_the_bf16_filter(pkg, orc, metric, monkeypatch):
+    """f32 rows of 513 .. 1024 floats (768- / 1024-dimensional embeddings) have no f32 matrix-core kernel: the batch runs
+    the half-precision kernel on a bf16 SHADOW copy as a filter and re-evaluates every candidate on the f32 rows with the
+    single-query kernel's arithmetic - the lists are the single scans' lists (f32 summation order aside).  With
+    VG_F32_FILTER=1 shorter rows take the same path."""
+    for dim, force in ((520, "0"), (768, "0"), (1000, "0"), (1024, "0"), (384, "1"), (100, "1")):
+        monkeypatch.setenv("VG_F32_FILTER", force)
+        n = 4133
+        rows = dg.corpus(dg.F32, n, dim, 9200 + dim)
+        _, edge = dg.edge_rows(dg.F32, dim, 9300 + dim)                   # zeros, huge / tiny magnitudes, NaN, Inf rows
+        rows[100:100 + len(edge)] = edge
+        rows[2000] = rows[17]
+        rows[3000:3010] *= np.float32(1e-3)
+        c = pkg.Corpus(pkg.F32, dim)
+        c.append(rows)
+        for nq, k in ((1, 20), (7, 1), (150, 20), (40, 32 if dim <= 768 else 16)):
+            qs = dg.corpus(dg.F32, nq, dim, 9400 + dim + nq)
+            eq = dg.edge_queries(dg.F32, dim, 9500 + dim)
+            for i, q in enumerate(eq[:min(len(eq), nq - 1)]):
+                qs[1 + i] = q
+            qs[0] = rows[17]
+            monkeypatch.setenv("VG_BATCH_MFMA", "1")
+            ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+            monkeypatch.setenv("VG_BATCH_MFMA", "0")
+            monkeypatch.setenv("VG_MULTI_SCAN", "0")
+            ids0, dist0, cnt0 = c.scan_topk_batch(metric, qs, k)           # nq single-query scans
+            monkeypatch.delenv("VG_MULTI_SCAN")
+            assert np.array_equal(cnt, cnt0), (dim, nq, k)
+            for i in range(nq):
+                m = cnt[i]
+                if metric == dg.DOT:        # cancelling sums: the bar is relative to the magnitude of the summed terms
+                    both = np.intersect1d(ids[i][:m], ids0[i][:m])
+                    assert len(both) >= m - 2, (dim, i)
+                    for r in both:
+                        a, b = dist[i][:m][ids[i][:m] == r][0], dist0[i][:m][ids0[i][:m] == r][0]
+                        scale = float(np.abs(rows[r - 1].astype(np.float64) * qs[i].astype(np.float64)).sum())
+                        assert (np.isinf(a) and a == b) or abs(a - b) <= 1e-5 * (abs(b) + scale) + 1e-6, (dim, i, r, a, b)
+                else:
+                    _same_topk_up_to_ties(ids[i][:m], dist[i][:m], ids0[i][:m], dist0[i][:m], rtol=1e-5)
+            want = orc.scan_distances(orc.AVX2, metric, dg.F32, qs[0], rows)
+            m = cnt[0]
+            _check_float_distances(dist[0][:m].astype(np.float32), want[ids[0][:m] - 1], dg.F32, metric, qs[0], rows[ids[0][:m] - 1])
+        c.close()
+
+
 def _same_topk_up_to_ties(ids, dist, ids0, dist0, rtol=1e-6):
     """two result lists of one query agree: same distances (summation order only) and the same rows except where
     neighbouring distances tie within that tolerance"""
