@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - vectors scanned / second for the sqlite-vector hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b|c5h]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b|c5h|c5f]
 
 Workload (BASELINE.json): configs[1] = 10M x 384 f32, L2, top-20, single query, corpus resident in HBM.
 A "step" is ONE complete query: upload the query, scan the whole shard, reduce to k candidates, bring the k keys
@@ -43,6 +43,9 @@ WORKLOADS = {
     "c3b": (4, np.uint8, 768, 3, "batched 1024 queries x 10Mx768 u8 quantized cosine top-20 (int8 MFMA Q x C^T + fused top-k)"),
     # c5 over an f16 corpus (not a BASELINE config): matrix cores as a filter, the reference's f64 arithmetic for survivors
     "c5h": (2, np.float16, 384, 4, "batched 1024 queries x 10Mx384 f16 dot top-20 (f16 MFMA filter + exact f64 re-evaluation + fused top-k)"),
+    # c5 answered through the bf16 filter (VG_F32_FILTER=1: bf16 shadow copy on the matrix cores, f32 exact re-evaluation of the
+    # survivors) instead of the f32 MFMA kernel - same question, same f32 distances, the GEMM at the bf16 rate
+    "c5f": (1, np.float32, 384, 4, "batched 1024 queries x 10Mx384 f32 dot top-20 (bf16 MFMA filter over a shadow copy + exact f32 re-evaluation + fused top-k)"),
 }
 F16_MFMA_PEAK_TF = 2500.0      # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
@@ -152,13 +155,14 @@ def bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc, dist=N
     steps, warmup = min(args.steps, 10), min(args.warmup, 2)
     quantized = corpus.vtype in (pkg.U8, pkg.I8)
     half = corpus.vtype == pkg.F16
+    filt = args.workload == "c5f"
     if quantized:
         batches = [rng.integers(0, 256, (nq, dim)).astype(np.uint8) for _ in range(2)]
     elif half:
         batches = [rng.standard_normal((nq, dim), dtype=np.float32).astype(np.float16) for _ in range(2)]
     else:
         batches = [rng.standard_normal((nq, dim), dtype=np.float32) for _ in range(2)]
-    peak = I8_MFMA_PEAK_TOPS if quantized else (F16_MFMA_PEAK_TF if half else F32_MFMA_PEAK_TF)
+    peak = I8_MFMA_PEAK_TOPS if quantized else (F16_MFMA_PEAK_TF if (half or filt) else F32_MFMA_PEAK_TF)
     use_dist = dist is not None
     offsets = [i * n_rows for i in range(n_gpus)]
     gathered = torch.empty((n_gpus, nq, k), dtype=torch.int64, device="cuda") if use_dist else None
@@ -207,9 +211,10 @@ def bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc, dist=N
             "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TOP/s" if quantized else "TFLOP/s",
                          "frac": tf / peak, "traffic": None,
                          "kernel": ("vg_batch_i8_kernel<%d>" % ((dim + 31) // 32)) if quantized else
-                                   (("vg_batch_h_kernel<%d>" % ((dim + 15) // 16)) if half else ("vg_batch_kernel<%d>" % ((dim + 7) // 8))),
+                                   (("vg_batch_h_kernel<%d>" % ((dim + 15) // 16)) if (half or filt) else ("vg_batch_kernel<%d>" % ((dim + 7) // 8))),
                          "kernel_ms": kern_ms, "launches_timed": n_launch, "flops_per_launch": flops,
-                         "note": "kernel_ms = pre-pass + main pass + merges of one batch on one shard"}}))
+                         "note": "kernel_ms = pre-pass + main pass + merges of one batch on one shard" +
+                                 ("; peak = the bf16 MFMA rate the filter runs at" if filt else "")}}))
     corpus.close()
     if use_dist:
         dist.destroy_process_group()
@@ -325,6 +330,8 @@ def main():
     if args.workload == "c1":
         return bench_sql(args, pkg, torch)
     vt, np_dtype, dim, metric, desc = WORKLOADS[args.workload]
+    if args.workload == "c5f":
+        os.environ["VG_F32_FILTER"] = "1"
     es = pkg.TYPE_SIZE[vt]
     k = args.k
     n_rows = args.rows
@@ -332,7 +339,7 @@ def main():
     corpus = make_shard(pkg, torch, vt, dim, n_rows, 42 + rank, local_rank)
     corpus.set_rowid_base(1 + rank * n_rows)
     corpus.set_profiling(True)
-    if args.workload in ("c5", "c3b", "c5h"):
+    if args.workload in ("c5", "c3b", "c5h", "c5f"):
         return bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc, dist if use_dist else None, shard,
                              n_gpus, rank)
 

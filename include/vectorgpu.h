@@ -127,7 +127,9 @@ int64_t vg_corpus_rowid_at(const vg_corpus *c, int64_t position);
 
 /* nq queries at once (row-major nq x dim, host).  out_rowids / out_dist are nq x k, out_counts nq.
  * f32 corpora, k <= 32, rows <= 512 floats, metric DOT / COSINE / L2 / SQUARED_L2: one pass over the corpus on the
- * matrix cores (Q x C^T tiles feed per-query candidate lists; L2 survivors are re-evaluated with the direct formula).
+ * matrix cores (Q x C^T tiles feed per-query candidate lists; L2 survivors are re-evaluated with the direct formula);
+ * rows of 513 .. 1024 floats: a bf16 shadow copy of the corpus feeds the matrix cores as a filter, every candidate is
+ * re-evaluated on the f32 rows with the single scan's arithmetic.
  * uint8 / int8 corpora, k <= 32, rows <= 2048 bytes, same metrics: the integer matrix cores, results identical to
  * nq vg_scan_topk calls.  f16 / bf16 corpora, k <= 32, rows <= 1024 elements, same metrics: the matrix cores filter,
  * every candidate is re-evaluated with the single scan's f64 arithmetic.  Other shapes on f32 / uint8 / int8 corpora
