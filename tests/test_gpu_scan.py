@@ -391,6 +391,18 @@ def test_batch_f32_long_rows_through_the_bf16_filter(pkg, orc, metric, monkeypat
             want = orc.scan_distances(orc.AVX2, metric, dg.F32, qs[0], rows)
             m = cnt[0]
             _check_float_distances(dist[0][:m].astype(np.float32), want[ids[0][:m] - 1], dg.F32, metric, qs[0], rows[ids[0][:m] - 1])
+        if dim == 768:                           # rows appended after a batch extend the shadow copy and the cached norms
+            more = dg.corpus(dg.F32, 500, dim, 9600)
+            more[7] = qs[20] if metric != dg.DOT else qs[20] * np.float32(50.0)    # a new best row for query 20
+            c.append(more)
+            monkeypatch.setenv("VG_BATCH_MFMA", "1")
+            ids, dist, cnt = c.scan_topk_batch(metric, qs, 5)
+            assert (n + 8) in ids[20].tolist(), (ids[20], dist[20])   # (dot: the Inf / 1e18 edge rows still rank before it)
+            one_ids, one_dist = c.scan_topk(metric, qs[20], 5)
+            if metric == dg.DOT:
+                assert ids[20].tolist() == one_ids.tolist()
+            else:        # (the 1e-3-scaled rows nearly tie: a swap at the k-th place is a summation-order effect)
+                assert np.allclose(dist[20], one_dist, rtol=1e-5, atol=1e-7) and len(set(ids[20].tolist()) ^ set(one_ids.tolist())) <= 2
         c.close()
 
 
