@@ -6,6 +6,7 @@
 #include "vg_internal.h"
 
 #include "vg_scan.h"
+#include "vg_scan_filter.h"
 
 // ------------------------------------------------------------------------------------------------ kernel selection
 
@@ -175,11 +176,84 @@ int vg_launch_merge(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_o
     return (int)hipGetLastError();
 }
 
+// ---- f32 through the bf16 shadow copy (vg_scan_filter.h; VG_SCAN_FILTER=1): half the bytes per row, exact answers.
+// Returns -1 when the shape is not served (caller takes the plain f32 scan).
+typedef void (*filter_fn_t)(FilterScanArgs);
+template <bool NT>
+static filter_fn_t pick_filter_u(int U) {
+    switch (U) {
+        case 1: return vg_scan_filter_kernel<1, NT>;
+        case 2: return vg_scan_filter_kernel<2, NT>;
+        case 3: return vg_scan_filter_kernel<3, NT>;
+        case 4: return vg_scan_filter_kernel<4, NT>;
+        case 6: return vg_scan_filter_kernel<6, NT>;
+        case 8: return vg_scan_filter_kernel<8, NT>;
+    }
+    return nullptr;
+}
+static int launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream) {
+    if (c->vtype != VG_TYPE_F32 || (metric != VG_DIST_L2 && metric != VG_DIST_SQUARED_L2 && metric != VG_DIST_DOT)) return -1;
+    const long long bs = vg_bf16_shadow_stride(c);
+    const int nch_b = (int)(bs / 16);
+    Shape s;
+    vg_choose_shape(nch_b, VG_TYPE_U8, A_DOT, &s, 8);
+    if (s.long_rows) return -1;
+    int rc = vg_ensure_row_norms(c);
+    if (rc != VG_OK) return rc;
+    if ((rc = vg_ensure_bf16_shadow(c)) != VG_OK) return rc;
+    if (stream != c->stream) {                           // both passes ran on the corpus stream
+        if (!c->norm_ev) HIP_TRY(hipEventCreateWithFlags(&c->norm_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->norm_ev, c->stream));
+        HIP_TRY(hipStreamWaitEvent(stream, c->norm_ev, 0));
+    }
+    const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (c->n_rows * bs > (256ll << 20));
+    filter_fn_t fn = nt ? pick_filter_u<true>(s.U) : pick_filter_u<false>(s.U);
+    if (!fn) return -1;
+    const int rpb = VG_WAVE >> s.lpr_log2;
+    const long long nbatch = (c->n_rows + rpb - 1) / rpb;
+    long long blocks = (nbatch + VG_WAVES_PER_BLOCK - 1) / VG_WAVES_PER_BLOCK;
+    blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count));
+    blocks = std::min<long long>(blocks, VG_SEL_MAX_HEADS);
+    FilterScanArgs a;
+    a.shadow = c->d_rows_bf; a.rows = c->d_rows; a.query = dev_query; a.row_norm = c->d_xnorm; a.cand = c->d_cand;
+    a.n_rows = c->n_rows; a.stride = c->stride; a.bstride = bs; a.nch = c->nch; a.nch_b = nch_b;
+    a.lpr_log2 = s.lpr_log2; a.k = k; a.root = (metric == VG_DIST_L2) ? 1 : 0; a.dot = (metric == VG_DIST_DOT) ? 1 : 0; a.dim = c->dim;
+    a.cerr = 0.00390625f + 1.6e-5f + (float)(c->dim + 64) * 4.76837158203125e-7f;
+    a.rel = (float)(c->dim + 64) * 2.384185791015625e-7f;
+    {
+        Shape xs;                                        // the f32 kernel's own shape: the exact evaluation sums in its order
+        choose_shape(c->nch, c->vtype, vg_metric_to_acc(metric), &xs);
+        if (xs.long_rows) return -1;
+        a.xlpr_log2 = xs.lpr_log2; a.xU = xs.U;
+    }
+    const size_t smem = std::max<size_t>((size_t)c->nch * 16, (size_t)VG_PUBLISH_LDS_BYTES);
+    if (c->append_pending && stream != c->stream) HIP_TRY(hipStreamWaitEvent(stream, c->append_ev, 0));
+    hipEvent_t *evs = nullptr;
+    if (c->profiling) {
+        int slot = (int)(c->prof_launches % VG_PROF_RING);
+        evs = &c->ev[(size_t)slot * 3];
+        c->ev_had_merge[(size_t)slot] = 1;
+        ++c->prof_launches;
+        hipEventRecord(evs[0], stream);
+    }
+    if (smem > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
+    if (evs) hipEventRecord(evs[1], stream);
+    hipLaunchKernelGGL(vg_merge_kernel, dim3(1), dim3(VG_MERGE_THREADS), 0, stream, (const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys);
+    if (evs) hipEventRecord(evs[2], stream);
+    HIP_TRY(hipGetLastError());
+    return VG_OK;
+}
+
 // Launch the scan (+ merge in top-k mode) on `stream`.  dev_query holds nch*16 zero-padded bytes.
 static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys,
                        float *dev_out_dist, hipStream_t stream) {
     int acc = vg_metric_to_acc(metric);
     if (acc < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
+    if (!dev_out_dist && k <= VG_MAX_FUSED_K && c->vtype == VG_TYPE_F32 && env_int("VG_SCAN_FILTER", 1) != 0) {
+        int rcf = launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream);
+        if (rcf != -1) return rcf;
+    }
     Shape s;
     choose_shape(c->nch, c->vtype, acc, &s);
     // f16 / bf16 cosine: the row norms come from a cached vector (computed once per appended row) instead of being

@@ -43,13 +43,14 @@ extern "C" int vg_f32_to_bf16_launch(const uint8_t *dev_rows, long long row0, lo
 // the LDS): they run through the half-precision kernel with a bf16 SHADOW copy as the filter's input and the f32 rows for the
 // exact evaluation.  VG_F32_FILTER=1 sends shorter rows the same way (5x the f32 MFMA kernel at D = 384: the filter runs at
 // the bf16 rate, the survivors carry the single-query kernel's f32 arithmetic).
-static long long bf16_shadow_stride(const vg_corpus *c) { return (((long long)c->dim * 2 + 15) / 16) * 16; }
+long long vg_bf16_shadow_stride(const vg_corpus *c) { return (((long long)c->dim * 2 + 15) / 16) * 16; }
+static long long bf16_shadow_stride(const vg_corpus *c) { return vg_bf16_shadow_stride(c); }
 static bool batch_f32_filter_eligible(const vg_corpus *c, int metric, int k) {
     if (env_int("VG_BATCH_MFMA", 1) == 0 || c->vtype != VG_TYPE_F32 || metric == VG_DIST_L1) return false;
     if (c->dim <= 512 && env_int("VG_F32_FILTER", 0) == 0) return false;
     return vg_batch_h_lds_bytes(bf16_shadow_stride(c), k) != 0;
 }
-static int ensure_bf16_shadow(vg_corpus *c) {
+int vg_ensure_bf16_shadow(vg_corpus *c) {
     const long long bs = bf16_shadow_stride(c);
     if (c->bf_cap < c->n_rows) {
         const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
@@ -154,7 +155,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     } else if (half || metric != VG_DIST_DOT) {            // f16 / bf16: every metric's filter needs sum x^2 per row
         int rcn = vg_ensure_row_norms(c);
         if (rcn != VG_OK) return rcn;
-        if (f32_filter && (rcn = ensure_bf16_shadow(c)) != VG_OK) return rcn;
+        if (f32_filter && (rcn = vg_ensure_bf16_shadow(c)) != VG_OK) return rcn;
     }
 
     hipEvent_t *evs = nullptr;

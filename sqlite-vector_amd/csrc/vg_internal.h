@@ -114,6 +114,8 @@ int vg_ensure_row_norms(vg_corpus *c);                             // vg_api.hip
 struct VgShape { int lpr_log2; int U; bool long_rows; };           // launch shape of a scan: lanes per row, chunks per lane
 bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap);   // vg_api.hip
 int vg_launch_merge(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, int nq, hipStream_t stream);   // vg_api.hip
+long long vg_bf16_shadow_stride(const vg_corpus *c);               // vg_batch_api.hip: row stride of the bf16 shadow copy of an f32 corpus
+int vg_ensure_bf16_shadow(vg_corpus *c);                           // vg_batch_api.hip: build / extend it (corpus stream)
 int vg_multi_queries_per_pass(const vg_corpus *c, int metric);     // vg_multi.hip: queries per pass of the multi-query scan, 0 = none
 int vg_launch_scan_multi(vg_corpus *c, int metric, const uint8_t *dev_queries, int k, uint64_t *dev_cand,
                          uint64_t *dev_out_keys, hipStream_t stream);   // vg_multi.hip; -1: no multi-query kernel for this shape
