@@ -153,6 +153,16 @@ extern "C" const char *vg_scan_kernel_name(vg_corpus *c, int metric) {
     int acc = vg_metric_to_acc(metric);
     if (acc < 0 || !choose_shape(c->nch, c->vtype, acc, &s)) return "";
     if (acc == A_COS && (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) && !s.long_rows && env_int("VG_HALF_COSN", 1)) acc = A_COSN;
+    if (c->vtype == VG_TYPE_F32 && (acc == A_L2 || acc == A_DOT) && !s.long_rows && env_int("VG_SCAN_FILTER", 1) != 0) {
+        const long long bs = vg_bf16_shadow_stride(c);           // the top-k scan reads the bf16 shadow copy (vg_scan_filter.h)
+        Shape fs;
+        vg_choose_shape((int)(bs / 16), VG_TYPE_U8, A_DOT, &fs, 8);
+        if (!fs.long_rows) {
+            const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (c->n_rows * bs > (256ll << 20));
+            snprintf(c->kernel_name, sizeof(c->kernel_name), "scan_filter_f32_%s_bf16_u%d_lpr%d%s", acc_tag(acc), fs.U, 1 << fs.lpr_log2, nt ? "_nt" : "");
+            return c->kernel_name;
+        }
+    }
     snprintf(c->kernel_name, sizeof(c->kernel_name), "scan%s_%s_%s_u%d_lpr%d%s", s.long_rows ? "_long" : "",
              type_tag(c->vtype), acc_tag(acc), s.U, 1 << s.lpr_log2, use_nt_loads(c) ? "_nt" : "");
     return c->kernel_name;
@@ -198,6 +208,10 @@ static int launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query
     Shape s;
     vg_choose_shape(nch_b, VG_TYPE_U8, A_DOT, &s, 8);
     if (s.long_rows) return -1;
+    {   // experiment override of the filter's own launch shape
+        const int fl = env_int("VG_FILTER_LPR_LOG2", -1), fu = env_int("VG_FILTER_U", -1);
+        if (fl >= 0 && fl <= 6 && fu > 0 && (nch_b + (1 << fl) - 1) / (1 << fl) <= fu && pick_filter_u<true>(fu)) { s.lpr_log2 = fl; s.U = fu; }
+    }
     int rc = vg_ensure_row_norms(c);
     if (rc != VG_OK) return rc;
     if ((rc = vg_ensure_bf16_shadow(c)) != VG_OK) return rc;
