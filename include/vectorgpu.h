@@ -84,7 +84,10 @@ int vg_corpus_append_device(vg_corpus *c, const void *dev_rows, int64_t n_rows, 
 
 /* ---- the hot path ---- */
 /* One query (dim elements of the corpus type, host memory) -> the k best rows.
- * out_rowids[k], out_dist[k] (float values widened to double, like vFullScanCursor.distance), *out_count <= k. */
+ * out_rowids[k], out_dist[k] (float values widened to double, like vFullScanCursor.distance), *out_count <= k.
+ * f32 corpora, L2 / SQUARED_L2 / DOT, k <= 64: the scan streams a bf16 shadow copy of the corpus (built on the first such
+ * scan after rows were appended; + 50 % device memory) as a lower-bound filter and re-evaluates the candidates on the f32
+ * rows - the same rowids and distance bits as the plain f32 scan, from half the bytes.  VG_SCAN_FILTER=0 turns it off. */
 int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k,
                  int64_t *out_rowids, double *out_dist, int *out_count);
 

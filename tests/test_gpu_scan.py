@@ -348,6 +348,40 @@ def test_batch_multi_query_scan_vs_single_scans(pkg, orc, vt, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("dim", (3, 33, 100, 384, 768, 1024, 1536))
+def test_f32_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, dim, monkeypatch):
+    """f32 L2 / squared-L2 / dot top-k scans read the bf16 shadow copy as a lower-bound filter and re-evaluate the candidates
+    on the f32 rows in the plain kernel's summation order (vg_scan_filter.h): rowids and distance BITS must equal the plain
+    f32 scan's (VG_SCAN_FILTER=0), for ordinary rows, edge rows (NaN / Inf / huge / tiny / zero) and edge queries."""
+    n = 60_007
+    rows = dg.corpus(dg.F32, n, dim, 9700 + dim)
+    _, edge = dg.edge_rows(dg.F32, dim, 9800 + dim)
+    rows[500:500 + len(edge)] = edge
+    rows[40000] = rows[17]                                   # an exact duplicate: a tie decided by position
+    rows[30000:30050] *= np.float32(1e-4)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    queries = [rows[17].copy()] + dg.edge_queries(dg.F32, dim, 9900 + dim) + [dg.query(dg.F32, dim, 9901 + i) for i in range(4)]
+    for metric in (dg.L2, dg.SQUARED_L2, dg.DOT):
+        monkeypatch.setenv("VG_SCAN_FILTER", "1")
+        assert c.kernel_name(metric).startswith("scan_filter_f32")
+        for q in queries:
+            for k in (1, 20, 64):
+                monkeypatch.setenv("VG_SCAN_FILTER", "1")
+                ids1, d1 = c.scan_topk(metric, q, k)
+                monkeypatch.setenv("VG_SCAN_FILTER", "0")
+                ids0, d0 = c.scan_topk(metric, q, k)
+                assert ids1.tolist() == ids0.tolist(), (metric, k)
+                assert dg.same_float_bits(d1, d0), (metric, k)
+    monkeypatch.setenv("VG_SCAN_FILTER", "1")
+    more = dg.corpus(dg.F32, 300, dim, 9950)                 # appended rows extend the shadow copy and the norms
+    more[5] = queries[-1]
+    c.append(more)
+    ids1, d1 = c.scan_topk(dg.L2, queries[-1], 3)
+    assert ids1[0] == n + 6 and d1[0] == 0.0
+    c.close()
+
+
 @pytest.mark.parametrize("metric", (dg.DOT, dg.COSINE, dg.L2, dg.SQUARED_L2))
 def test_batch_f32_long_rows_through_the_bf16_filter(pkg, orc, metric, monkeypatch):
     """f32 rows of 513 .. 1024 floats (768- / 1024-dimensional embeddings) have no f32 matrix-core kernel: the batch runs
