@@ -28,7 +28,8 @@ struct FilterScanArgs {
     float cerr;                // |s~ - s| <= cerr |q||x|: 2^-8 (1 + 2^-8) for the rounded inputs + (D + 64) 2^-21 for the f32 sums
     float rel;                 // (D + 64) 2^-22: what the cached norms and the exact f32 evaluation themselves may be off by
     int xlpr_log2, xU;         // the launch shape vg_scan_kernel would use for this corpus: the exact evaluation sums in ITS order
-};
+    const uint64_t *init_keys; // the k best of a plain f32 scan over the first rows (64 keys) or nullptr: its k-th distance is
+};                             //   an upper bound of the final k-th best - the lists do not have to warm up from +Inf
 
 typedef __bf16 vgf_bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -68,11 +69,20 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
     const bool q_ok = (qq >= 1.0e-30f && qq <= 1.0e30f);                  // else: every row takes the exact path
 
     uint64_t mine = VG_EMPTY_KEY, thr = VG_EMPTY_KEY;
-    float thr_gate = INFINITY;                                            // the bound must stay below this to go on
+    auto gate_of = [&](float t) -> float {                                // the bound must stay below this to go on
+        if (a.dot) return t + a.rel * fabsf(t) + 1e-30f;
+        const float t2 = a.root ? t * t : t;
+        return t2 * (1.0f + 2.0f * a.rel) + 1e-30f;
+    };
+    float gate_init = INFINITY;
+    if (a.init_keys) {
+        const uint64_t kk = a.init_keys[k - 1];
+        if (kk != VG_EMPTY_KEY) gate_init = gate_of(vg_sortable_f32((uint32_t)(kk >> 32)));
+    }
+    float thr_gate = gate_init;
     auto refresh_gate = [&]() {
         const float t = (thr == VG_EMPTY_KEY) ? INFINITY : vg_sortable_f32((uint32_t)(thr >> 32));
-        if (a.dot) thr_gate = t + a.rel * fabsf(t) + 1e-30f;
-        else { const float t2 = a.root ? t * t : t; thr_gate = t2 * (1.0f + 2.0f * a.rel) + 1e-30f; }
+        thr_gate = fminf(gate_of(t), gate_init);
     };
     // the exact distance of one row (wave-uniform): the single-query f32 kernel's arithmetic IN ITS ORDER - lane group of
     // 2^xlpr_log2 lanes, lane `xs` takes chunks xs + u * xlpr (u < xU), same butterfly - so the distance is bit for bit what

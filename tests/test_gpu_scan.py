@@ -353,6 +353,7 @@ def test_f32_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, dim, monke
     """f32 L2 / squared-L2 / dot top-k scans read the bf16 shadow copy as a lower-bound filter and re-evaluate the candidates
     on the f32 rows in the plain kernel's summation order (vg_scan_filter.h): rowids and distance BITS must equal the plain
     f32 scan's (VG_SCAN_FILTER=0), for ordinary rows, edge rows (NaN / Inf / huge / tiny / zero) and edge queries."""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")         # (by default only corpora >= 3 GB take the filter scan)
     n = 60_007
     rows = dg.corpus(dg.F32, n, dim, 9700 + dim)
     _, edge = dg.edge_rows(dg.F32, dim, 9800 + dim)

@@ -4,6 +4,7 @@ import torch; torch.cuda.init()
 import __graft_entry__ as g
 import datagen as dg
 pkg = g.load_package()
+os.environ['VG_SCAN_FILTER_MIN_MB'] = '0'
 bad = 0
 for dim in (384, 100, 768, 33, 1024):
     n = 200_003
