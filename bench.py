@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """bench.py - vectors scanned / second for the sqlite-vector hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b|c5h|c5f]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b|c5h|c5f] [--no-also]
 
-Workload (BASELINE.json): configs[1] = 10M x 384 f32, L2, top-20, single query, corpus resident in HBM.
-A "step" is ONE complete query: upload the query, scan the whole shard, reduce to k candidates, bring the k keys
-back and decode them - i.e. what vector_full_scan's xFilter costs once the corpus is staged.
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank holds its own row-range shard of the same
-size (weak scaling), each step = local scan -> all_gather of the per-shard candidate keys over RCCL/xGMI ->
-rank 0 merges.  value = rows scanned by ALL ranks / max-over-ranks time.
+Default line (BASELINE.json configs[1]): 10M x 384 f32, L2, top-20, single query, corpus resident in HBM, answered by
+the PLAIN f32 scan kernel (vg_scan_kernel; the bf16 shadow-copy filter is switched off for this corpus), so that
+`roofline` is SURVEY 8(d)'s figure: algorithmic bytes N*D*4 = 15.36 GB per launch / the kernel's mean duration from HIP
+events recorded around it on its own stream inside the timed region, against the 8 TB/s HBM3E peak.
+A "step" is ONE complete query: upload the query, scan the whole shard, reduce to k candidates, bring the k keys back
+and decode them - what vector_full_scan's xFilter costs once the corpus is staged.
 
-The JSON line also carries
-  roofline     achieved HBM GB/s of the scan kernel = algorithmic bytes per launch (N*D*elem_size) /
-               mean kernel duration from HIP events recorded around the kernel on its own stream inside the
-               timed region (vg_set_profiling ring), against the 8 TB/s HBM3E peak.
-  cpu_baseline the reference's own kernel + top-k loop (oracle/_ref/libref_avx2.so, built from /root/reference by
-               oracle/Makefile) on ONE host core - the reference is single-threaded - over a bounded sample.
+The same run appends (N = 1, default workload only; --no-also skips them):
+  filter_scan  the SAME queries over the SAME corpus through the product's default path for corpora >= 3 GB: the bf16
+               shadow-copy filter + exact f32 re-evaluation (vg_scan_filter.h).  It answers the f32 question with the
+               f32 scan's rowids and distance bits but STREAMS bf16: its rate is priced on the bytes it streams
+               (dtype_streamed / frac_on_streamed) and is never reported under dtype f32 / roofline.frac.
+  also.c3      10M x 768 uint8 cosine top-20 (configs[2]): own roofline (7.68 GB per launch) and cpu_baseline
+  also.c5      1024 queries x 10M x 384 f32 dot top-20 (configs[4]): own roofline (7.864 TFLOP per launch against the
+               157.3 TF f32 MFMA peak) and cpu_baseline
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): configs[3] - the corpus row-sharded over the ranks,
+12.5M x 384 f32 rows per rank (8 ranks = the stated 100M rows; weak scaling: every rank count uses that shard size),
+each step = local scan -> all_gather of the per-shard candidate keys over RCCL/xGMI -> rank 0 merges.
+value = rows scanned by ALL ranks / max-over-ranks time.
+
+cpu_baseline = the reference's own kernel + top-k loop (oracle/_ref/libref_avx2.so, built from /root/reference by
+oracle/Makefile) on ONE host core - the reference is single-threaded - over a bounded sample, timed in this run.
 """
 import argparse
 import json
@@ -57,12 +67,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU shard")
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU shard (default: 10M on one GPU, 12.5M per rank on several = config C4's shard)")
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=1024, help="queries per batch (workload c5)")
+    ap.add_argument("--no-also", action="store_true", help="default workload: skip the filter_scan / c3 / c5 sub-results")
     return ap.parse_args()
 
 
@@ -88,8 +99,8 @@ def make_shard(pkg, torch, vt, dim, n_rows, seed, device):
     return corpus
 
 
-def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows):
-    """reference kernel + reference top-k loop, one core, bounded sample (about 10-30 s of CPU work)."""
+def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows, seconds=10.0, all_cores=True):
+    """reference kernel + reference top-k loop, one core, bounded sample (`seconds` of CPU work)."""
     from oracle import orc
     rng = np.random.default_rng(42)
     if vt == 1:
@@ -102,60 +113,63 @@ def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows):
     if orc.have_ref():
         ref = orc.RefKernels("avx2")
         kind = "reference"
-        runner = lambda: ref.scan_topk(metric, vt, q, rows, k)           # noqa: E731
+        work = lambda v: ref.scan_topk(metric, vt, q, v, k)              # noqa: E731
         label = "oracle/_ref/libref_avx2.so (reference distance-avx2.c kernel via dispatch table, backend %s)" % ref.backend_name
     else:
-        runner = lambda: orc.scan_topk_reference(orc.AVX2, metric, vt, q, rows, None, k)   # noqa: E731
+        work = lambda v: orc.scan_topk_reference(orc.AVX2, metric, vt, q, v, None, k)   # noqa: E731
         label = "oracle/liboracle.so (C restatement, AVX2 order, scalar)"
+    runner = lambda: work(rows)                   # noqa: E731
     runner()                                     # warm (page in)
     reps, t0 = 0, time.perf_counter()
     while True:
         runner()
         reps += 1
         el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 40:
+        if el > seconds or reps >= 40:
             break
     out = {"value": sample_rows * reps / el, "unit": "vectors/s", "cores": 1, "kind": kind,
            "sample": "%d queries over a %dx%d %s sample, top-%d, %s; host has %d logical cores" %
                      (reps, sample_rows, dim, np.dtype(np_dtype).name, k, label, os.cpu_count())}
-    # generous upper bound: the same single-threaded reference loop run embarrassingly parallel over row
-    # ranges on every host core (ctypes releases the GIL), k-way merge of the per-range top-k not even counted
+    if not all_cores:
+        return out
+    # The same single-threaded reference loop run embarrassingly parallel over row ranges.  Every thread gets
+    # its OWN >= 64k rows (~9 ms of kernel work per call: the Python dispatch of a call is noise next to it) out of a
+    # sample made 4x larger by tiling, so the threads do not share cache lines; `cores` = the threads actually used.
     try:
         from concurrent.futures import ThreadPoolExecutor
-        ncores = os.cpu_count() or 1
-        parts = np.array_split(np.arange(sample_rows), ncores)
-        views = [rows[p[0]:p[-1] + 1] for p in parts if len(p)]
-        if kind == "reference":
-            work = lambda v: ref.scan_topk(metric, vt, q, v, k)             # noqa: E731
-        else:
-            work = lambda v: orc.scan_topk_reference(orc.AVX2, metric, vt, q, v, None, k)   # noqa: E731
-        with ThreadPoolExecutor(max_workers=ncores) as ex:
+        per_thread = 65536
+        big = np.tile(rows, (4, 1)) if sample_rows * 4 * dim * rows.itemsize <= (8 << 30) else rows
+        nthreads = max(1, min(os.cpu_count() or 1, big.shape[0] // per_thread))
+        views = [big[i * per_thread:(i + 1) * per_thread] for i in range(nthreads)]
+        with ThreadPoolExecutor(max_workers=nthreads) as ex:
             list(ex.map(work, views))                                        # warm
             reps2, t1 = 0, time.perf_counter()
             while True:
                 list(ex.map(work, views))
                 reps2 += 1
                 el2 = time.perf_counter() - t1
-                if el2 > 5.0 or reps2 >= 200:
+                if el2 > 4.0 or reps2 >= 400:
                     break
-        out["all_cores"] = {"value": sample_rows * reps2 / el2, "unit": "vectors/s", "cores": ncores,
-                            "note": "row-range split over %d threads, merge not counted" % ncores}
+        out["all_cores"] = {"value": nthreads * per_thread * reps2 / el2, "unit": "vectors/s", "cores": nthreads,
+                            "note": "%d threads x %d private rows each (ctypes releases the GIL), the per-range top-k lists are not "
+                                    "merged; the host has %d logical cores" % (nthreads, per_thread, os.cpu_count() or 1)}
     except Exception as e:
         out["all_cores"] = {"value": None, "note": "unavailable: %r" % (e,)}
     return out
 
 
-def bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc, dist=None, shard=None, n_gpus=1, rank=0):
+def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc, dist=None, shard=None, n_gpus=1, rank=0):
     """config #5: each step = one batch of queries through the batched scan (host queries in, host (position,
     distance) lists out).  The dominant kernel is MFMA-bound: flops = 2 * Q * N * D per launch.
     N > 1: every rank scans its own row-range shard with the same batch, ONE all_gather of nq x k keys per rank
-    (160 KB at 1024 x 20), rank 0 merges every query (shard.gather_and_merge_batch) - SURVEY 8e."""
+    (160 KB at 1024 x 20), rank 0 merges every query (shard.gather_and_merge_batch) - SURVEY 8e.
+    Returns the result line (a dict) on rank 0, None elsewhere."""
     nq = args.batch
     rng = np.random.default_rng(44)
     steps, warmup = min(args.steps, 10), min(args.warmup, 2)
     quantized = corpus.vtype in (pkg.U8, pkg.I8)
     half = corpus.vtype == pkg.F16
-    filt = args.workload == "c5f"
+    filt = workload == "c5f"
     if quantized:
         batches = [rng.integers(0, 256, (nq, dim)).astype(np.uint8) for _ in range(2)]
     elif half:
@@ -198,26 +212,24 @@ def bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc, dist=N
     n_launch, kern_ms, _ = corpus.profile_mean_ms()
     flops = 2.0 * nq * n_rows * dim
     tf = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-    if rank == 0:
-        print(json.dumps({
-            "metric": "vectors scanned/sec (query x vector pairs), batched %s" % ("quantized cosine top-20 over Nx768 u8" if quantized else
-                                                                                  ("dot top-20 over Nx384 f16" if half else "dot top-20 over Nx384 f32")),
-            "value": nq * n_rows * n_gpus * steps / elapsed, "unit": "vectors/s", "n_gpus": n_gpus, "steps": steps,
-            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8" if quantized else ("f16" if half else "f32"), "data": "synthetic",
-            "config": {"workload": desc, "rows_per_gpu": n_rows, "dim": dim, "k": k, "queries_per_batch": nq,
-                       "sharding": "row-range shard per GPU, RCCL all_gather of nq x k candidate keys per rank" if n_gpus > 1 else "single shard",
-                       "backend": pkg.backend_name()},
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TOP/s" if quantized else "TFLOP/s",
-                         "frac": tf / peak, "traffic": None,
-                         "kernel": ("vg_batch_i8_kernel<%d>" % ((dim + 31) // 32)) if quantized else
-                                   (("vg_batch_h_kernel<%d>" % ((dim + 15) // 16)) if (half or filt) else ("vg_batch_kernel<%d>" % ((dim + 7) // 8))),
-                         "kernel_ms": kern_ms, "launches_timed": n_launch, "flops_per_launch": flops,
-                         "note": "kernel_ms = pre-pass + main pass + merges of one batch on one shard" +
-                                 ("; peak = the bf16 MFMA rate the filter runs at" if filt else "")}}))
-    corpus.close()
-    if use_dist:
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    return {
+        "metric": "vectors scanned/sec (query x vector pairs), batched %s" % ("quantized cosine top-20 over Nx768 u8" if quantized else
+                                                                              ("dot top-20 over Nx384 f16" if half else "dot top-20 over Nx384 f32")),
+        "value": nq * n_rows * n_gpus * steps / elapsed, "unit": "vectors/s", "n_gpus": n_gpus, "steps": steps,
+        "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8" if quantized else ("f16" if half else "f32"), "data": "synthetic",
+        "config": {"workload": desc, "rows_per_gpu": n_rows, "dim": dim, "k": k, "queries_per_batch": nq,
+                   "sharding": "row-range shard per GPU, RCCL all_gather of nq x k candidate keys per rank" if n_gpus > 1 else "single shard",
+                   "backend": pkg.backend_name()},
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TOP/s" if quantized else "TFLOP/s",
+                     "frac": tf / peak, "traffic": None,
+                     "kernel": ("vg_batch_i8_kernel<%d>" % ((dim + 31) // 32)) if quantized else
+                               (("vg_batch_h_kernel<%d>" % ((dim + 15) // 16)) if (half or filt) else ("vg_batch_kernel<%d>" % ((dim + 7) // 8))),
+                     "kernel_ms": kern_ms, "launches_timed": n_launch, "flops_per_launch": flops,
+                     "note": "kernel_ms = pre-pass + main pass + merges of one batch on one shard" +
+                             ("; peak = the bf16 MFMA rate the filter runs at" if filt else "")}}
 
 
 def sql_latency(ext_path, rows, queries, k, warmup, steps):
@@ -249,7 +261,7 @@ def sql_latency(ext_path, rows, queries, k, warmup, steps):
 def bench_sql(args, pkg, torch):
     """config #1: what a user of the reference types, unchanged, with this repo's vector.so loaded instead."""
     vt, np_dtype, dim, metric, desc = WORKLOADS["c1"]
-    n_rows = 10_000 if args.rows == 10_000_000 else args.rows
+    n_rows = args.rows if args.rows else 10_000
     k, steps, warmup = args.k, args.steps, args.warmup
     rng = np.random.default_rng(42)
     rows = rng.standard_normal((n_rows, dim), dtype=np.float32)
@@ -303,6 +315,118 @@ def bench_sql(args, pkg, torch):
     print(json.dumps(out))
 
 
+class SingleQueryRunner:
+    """one resident shard + the per-step plumbing of a single-query scan (query upload -> scan + candidate reduction ->
+    [RCCL gather] -> k keys to the host -> merge); run() times K steps the way the contract prescribes"""
+
+    def __init__(self, pkg, torch, dist, shard, corpus, vt, dim, metric, k, n_rows, n_gpus, queries):
+        self.pkg, self.torch, self.dist, self.shard, self.corpus = pkg, torch, dist, shard, corpus
+        self.metric, self.k, self.n_rows, self.n_gpus = metric, k, n_rows, n_gpus
+        es = pkg.TYPE_SIZE[vt]
+        nq = queries.shape[0]
+        # a real (non-null) stream: handle 0 would mean "use the corpus' own stream" to the C-ABI
+        self.stream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.stream)
+        qpad = ((dim * es + 15) // 16) * 16
+        self.d_query = torch.zeros(qpad, dtype=torch.uint8, device="cuda")
+        # every query of the run zero-padded in ONE pinned host tensor: a step uploads its row (the upload stays in the
+        # timed region, the numpy -> torch conversion does not have to)
+        h = torch.zeros((nq, qpad), dtype=torch.uint8)
+        h[:, : dim * es] = torch.from_numpy(queries.view(np.uint8).reshape(nq, dim * es))
+        self.h_queries = h.pin_memory()
+        self.d_keys = torch.empty(64, dtype=torch.int64, device="cuda")
+        self.h_keys = torch.empty((n_gpus, 64), dtype=torch.int64).pin_memory()
+        self.d_all = torch.empty((n_gpus, 64), dtype=torch.int64, device="cuda") if dist is not None else None
+        self.offsets = [i * n_rows for i in range(n_gpus)]
+        self.last = {}
+
+    def step(self, i):
+        pkg, stream = self.pkg, self.stream
+        self.d_query.copy_(self.h_queries[i], non_blocking=True)
+        self.corpus.scan_topk_device(self.metric, self.d_query.data_ptr(), self.k, self.d_keys.data_ptr(), stream.cuda_stream)
+        if self.dist is not None:
+            # the path's only exchange: 64 keys per rank, one RCCL all_gather, rank 0 merges (shard.py)
+            res = self.shard.gather_and_merge(pkg, self.dist, self.d_keys, self.d_all, self.offsets, self.k, dst=0,
+                                              host_buf=self.h_keys, sync=stream.synchronize)
+            if res is not None:
+                self.last["pos"], self.last["dist"] = res
+            else:
+                stream.synchronize()      # lockstep with rank 0: the pinned query buffer is reused next step
+        else:
+            self.h_keys[0].copy_(self.d_keys, non_blocking=True)
+            stream.synchronize()
+            self.last["pos"], self.last["dist"] = pkg.merge_keys(self.h_keys.numpy().view(np.uint64), self.offsets, self.k)
+
+    def run(self, warmup, steps):
+        """W untimed steps, then exactly K steps between barrier + synchronize; returns (elapsed max over ranks, latencies)"""
+        torch, dist = self.torch, self.dist
+        for i in range(warmup):
+            self.step(i)
+        self.corpus.set_profiling(True)               # reset the event ring: only timed steps are averaged
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        lat = []
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ts = time.perf_counter()
+            self.step(warmup + i)
+            lat.append(time.perf_counter() - ts)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, lat
+
+
+def pmc_traffic(kernel_name, n_rows):
+    """HBM bytes per launch measured by the PMC pass committed under profiles/ (same kernel, same N), or (None, None)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            ent = json.load(f).get("%s@%d" % (kernel_name, n_rows))
+        if ent:
+            return ent["bytes_per_launch"], ent["source"]
+    except Exception:
+        pass
+    return None, None
+
+
+def single_query_line(args, pkg, runner, corpus, workload, vt, dim, metric, k, n_rows, n_gpus, desc):
+    """time the scan as it is currently switched on `corpus` and price it on SURVEY 8(d)'s algorithmic bytes"""
+    es = pkg.TYPE_SIZE[vt]
+    elapsed, lat = runner.run(args.warmup, args.steps)
+    n_launch, scan_ms, merge_ms, prepass_ms = corpus.profile_mean_ms_ex()
+    kname = corpus.kernel_name(metric)
+    algo_bytes = n_rows * dim * es                              # per launch (one shard): corpus read once
+    achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    traffic, source = pmc_traffic(kname, n_rows)
+    out = {
+        "metric": "vectors scanned/sec, L2 top-20 over Nx384 f32" if workload == "c2" else
+                  "vectors scanned/sec, quantized cosine top-20 over Nx768 u8",
+        "value": n_rows * n_gpus * args.steps / elapsed,
+        "unit": "vectors/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "p50_query_latency_ms": float(np.median(lat) * 1e3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if vt == pkg.F32 else "u8", "data": "synthetic",
+        "config": {"workload": desc, "rows_per_gpu": n_rows, "dim": dim, "k": k,
+                   "sharding": "row-range shard per GPU, RCCL all_gather of 64 candidate keys per rank" if n_gpus > 1 else "single shard",
+                   "backend": pkg.backend_name()},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": kname, "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms,
+                     "launches_timed": n_launch, "algorithmic_bytes_per_launch": algo_bytes},
+    }
+    if source:
+        out["roofline"]["traffic_source"] = source
+    return out, prepass_ms
+
+
 def main():
     args = parse()
     import torch
@@ -328,135 +452,128 @@ def main():
     shard = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(shard)
     if args.workload == "c1":
+        if not args.rows:
+            args.rows = 10_000
         return bench_sql(args, pkg, torch)
     vt, np_dtype, dim, metric, desc = WORKLOADS[args.workload]
     if args.workload == "c5f":
         os.environ["VG_F32_FILTER"] = "1"
-    es = pkg.TYPE_SIZE[vt]
     k = args.k
-    n_rows = args.rows
+    # one GPU: config C2 / C3 / C5 as stated (10M rows).  Several GPUs: config C4's shard, 12.5M rows per rank - 8 ranks scan
+    # the stated 100M rows; every rank count keeps that shard size (weak scaling)
+    n_rows = args.rows if args.rows else (10_000_000 if n_gpus == 1 else 12_500_000)
+    if n_gpus > 1 and args.workload == "c2":
+        desc = "%gMx384 f32 L2 top-20, corpus row-sharded across %d MI355X (%gM rows per rank) + RCCL candidate gather" % (
+            n_rows * n_gpus / 1e6, n_gpus, n_rows / 1e6)
+    elif n_rows != 10_000_000:
+        desc = desc.replace("10M", "%gM" % (n_rows / 1e6))
 
     corpus = make_shard(pkg, torch, vt, dim, n_rows, 42 + rank, local_rank)
     corpus.set_rowid_base(1 + rank * n_rows)
     corpus.set_profiling(True)
     if args.workload in ("c5", "c3b", "c5h", "c5f"):
-        return bench_batched(args, pkg, torch, corpus, n_rows, dim, metric, k, desc, dist if use_dist else None, shard,
-                             n_gpus, rank)
+        out = run_batched(args, pkg, torch, corpus, args.workload, n_rows, dim, metric, k, desc, dist if use_dist else None, shard,
+                          n_gpus, rank)
+        if out is not None:
+            if n_gpus == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = batch_cpu_baseline(args, vt, np_dtype, dim, metric, k)
+            print(json.dumps(out))
+        corpus.close()
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     # queries: a different one every step, pre-generated on the host
     rng = np.random.default_rng(43)
     nq = args.steps + args.warmup
-    if vt == pkg.F32:
-        queries = rng.standard_normal((nq, dim), dtype=np.float32)
-    else:
-        queries = rng.integers(0, 256, (nq, dim), dtype=np.uint8)
+    queries = rng.standard_normal((nq, dim), dtype=np.float32) if vt == pkg.F32 else rng.integers(0, 256, (nq, dim), dtype=np.uint8)
 
-    # a real (non-null) stream: handle 0 would mean "use the corpus' own stream" to the C-ABI
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    qpad = ((dim * es + 15) // 16) * 16
-    d_query = torch.zeros(qpad, dtype=torch.uint8, device="cuda")
-    # every query of the run zero-padded in ONE pinned host tensor: a step uploads its row (the upload stays in the
-    # timed region, the numpy -> torch conversion does not have to)
-    h_queries = torch.zeros((nq, qpad), dtype=torch.uint8)
-    h_queries[:, : dim * es] = torch.from_numpy(queries.view(np.uint8).reshape(nq, dim * es))
-    h_queries = h_queries.pin_memory()
-    d_keys = torch.empty(64, dtype=torch.int64, device="cuda")
-    h_keys = torch.empty((n_gpus, 64), dtype=torch.int64).pin_memory()
-    d_all = torch.empty((n_gpus, 64), dtype=torch.int64, device="cuda") if use_dist else None
-    offsets = [i * n_rows for i in range(n_gpus)]
-    last = {}
+    # THE line: the plain scan kernel on SURVEY 8(d)'s basis.  The bf16 shadow-copy filter is switched off for this corpus
+    # (it is the product's default for f32 corpora >= 3 GB and is reported on its own below).
+    corpus.set_scan_filter(0)
+    runner = SingleQueryRunner(pkg, torch, dist if use_dist else None, shard, corpus, vt, dim, metric, k, n_rows, n_gpus, queries)
+    out, _ = single_query_line(args, pkg, runner, corpus, args.workload, vt, dim, metric, k, n_rows, n_gpus, desc)
+    plain_last = dict(runner.last)
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(vt, np_dtype, dim, metric, k, args.cpu_sample_rows)
+        except Exception as e:                                        # the checker is optional on a bare box
+            out["cpu_baseline"] = {"value": None, "unit": "vectors/s", "cores": 0, "kind": "port", "sample": "unavailable: %r" % (e,)}
 
-    def step(i):
-        # query upload -> scan + candidate reduction on this shard -> (RCCL gather) -> k keys to the host -> merge
-        d_query.copy_(h_queries[i], non_blocking=True)
-        corpus.scan_topk_device(metric, d_query.data_ptr(), k, d_keys.data_ptr(), stream.cuda_stream)
-        if use_dist:
-            # the path's only exchange: 64 keys per rank, one RCCL all_gather, rank 0 merges (shard.py)
-            res = shard.gather_and_merge(pkg, dist, d_keys, d_all, offsets, k, dst=0, host_buf=h_keys,
-                                         sync=stream.synchronize)
-            if res is not None:
-                last["pos"], last["dist"] = res
-            else:
-                stream.synchronize()      # lockstep with rank 0: the pinned query buffer is reused next step
-        else:
-            h_keys[0].copy_(d_keys, non_blocking=True)
-            stream.synchronize()
-            last["pos"], last["dist"] = pkg.merge_keys(h_keys.numpy().view(np.uint64), offsets, k)
-
-    for i in range(args.warmup):
-        step(i)
-    corpus.set_profiling(True)                    # reset the event ring: only timed steps are averaged
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    lat = []
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ts = time.perf_counter()
-        step(args.warmup + i)
-        lat.append(time.perf_counter() - ts)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    n_launch, scan_ms, merge_ms = corpus.profile_mean_ms()
+    if n_gpus == 1 and args.workload == "c2" and not args.no_also:
+        # ---- the same queries through the filter scan (the product's default path for this corpus)
+        try:
+            corpus.set_scan_filter(1)
+            os.environ.setdefault("VG_SCAN_FILTER_MIN_MB", "0" if n_rows * dim * 4 < (3 << 30) else "3072")
+            runner.step(0)                                             # builds the shadow copy + norms (not timed)
+            corpus.filter_exact_evals()
+            felapsed, flat = runner.run(args.warmup, args.steps)
+            fn_launch, fscan_ms, fmerge_ms, fpre_ms = corpus.profile_mean_ms_ex()
+            evals = corpus.filter_exact_evals()
+            fname = corpus.kernel_name(metric)
+            streamed = n_rows * (((dim * 2 + 15) // 16) * 16 + 4)        # bf16 shadow row + one cached f32 norm per row
+            ftraffic, fsource = pmc_traffic(fname, n_rows)
+            same = (list(runner.last["pos"]) == list(plain_last["pos"]) and
+                    np.array_equal(np.asarray(runner.last["dist"]), np.asarray(plain_last["dist"])))
+            out["filter_scan"] = {
+                "what": "the same %d queries through vg_scan_filter_kernel: bf16 shadow copy as a lower-bound filter + exact f32 "
+                        "re-evaluation of the candidates (same rowids and distance bits as the plain scan)" % args.steps,
+                "value": n_rows * args.steps / felapsed, "unit": "vectors/s", "ms_per_step": felapsed / args.steps * 1e3,
+                "p50_query_latency_ms": float(np.median(flat) * 1e3),
+                "kernel": fname, "kernel_ms": fscan_ms, "prepass_ms": fpre_ms, "merge_kernel_ms": fmerge_ms, "launches_timed": fn_launch,
+                "dtype_streamed": "bf16", "streamed_bytes_per_launch": streamed,
+                "achieved_on_streamed_GBs": streamed / (fscan_ms * 1e-3) / 1e9 if fscan_ms > 0 else 0.0,
+                "frac_on_streamed": streamed / (fscan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fscan_ms > 0 else 0.0,
+                "traffic": ftraffic, "traffic_source": fsource,
+                "exact_f32_evaluations_per_query": evals / float(args.warmup + args.steps),
+                "last_query_same_answer_as_plain_scan": bool(same),
+                "extra_hbm_bytes": n_rows * (((dim * 2 + 15) // 16) * 16 + 4),
+            }
+        except Exception as e:
+            out["filter_scan"] = {"error": repr(e)}
+        # ---- configs[4] over the same corpus, configs[2] over its own
+        also = {}
+        try:
+            corpus.set_scan_filter(0)
+            v5, t5, d5, m5, desc5 = WORKLOADS["c5"]
+            line = run_batched(args, pkg, torch, corpus, "c5", n_rows, d5, m5, k, desc5)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = batch_cpu_baseline(args, v5, t5, d5, m5, k, seconds=5.0)
+            also["c5"] = line
+        except Exception as e:
+            also["c5"] = {"error": repr(e)}
+        corpus.close()
+        corpus = None
+        try:
+            v3, t3, d3, m3, desc3 = WORKLOADS["c3"]
+            c3 = make_shard(pkg, torch, v3, d3, n_rows, 42, local_rank)
+            q3 = np.random.default_rng(43).integers(0, 256, (nq, d3), dtype=np.uint8)
+            r3 = SingleQueryRunner(pkg, torch, None, shard, c3, v3, d3, m3, k, n_rows, 1, q3)
+            line, _ = single_query_line(args, pkg, r3, c3, "c3", v3, d3, m3, k, n_rows, 1, desc3)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(v3, t3, d3, m3, k, args.cpu_sample_rows, seconds=5.0, all_cores=False)
+            also["c3"] = line
+            c3.close()
+        except Exception as e:
+            also["c3"] = {"error": repr(e)}
+        out["also"] = also
     if rank == 0:
-        total_rows = n_rows * n_gpus
-        algo_bytes = n_rows * dim * es                         # per launch (one shard), SURVEY 8d
-        kname = corpus.kernel_name(metric)
-        filtered = kname.startswith("scan_filter")
-        # the filter scan streams the bf16 shadow copy (+ one cached norm per row) instead of the f32 rows: the roofline is
-        # priced on the bytes it streams; the f32 bytes it answers for are reported next to it
-        streamed = n_rows * (((dim * 2 + 15) // 16) * 16 + 4) if filtered else algo_bytes
-        achieved = streamed / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        out = {
-            "metric": "vectors scanned/sec, L2 top-20 over Nx384 f32" if args.workload == "c2" else
-                      "vectors scanned/sec, quantized cosine top-20 over Nx768 u8",
-            "value": total_rows * args.steps / elapsed,
-            "unit": "vectors/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "p50_query_latency_ms": float(np.median(lat) * 1e3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if vt == pkg.F32 else "u8", "data": "synthetic",
-            "config": {"workload": desc if n_rows == 10_000_000 else desc.replace("10M", "%gM" % (n_rows / 1e6)),
-                       "rows_per_gpu": n_rows, "dim": dim, "k": k,
-                       "sharding": "row-range shard per GPU, RCCL all_gather of 64 candidate keys per rank" if n_gpus > 1 else "single shard",
-                       "backend": pkg.backend_name()},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": corpus.kernel_name(metric), "kernel_ms": scan_ms, "merge_kernel_ms": merge_ms,
-                         "launches_timed": n_launch, "algorithmic_bytes_per_launch": algo_bytes},
-        }
-        if filtered:
-            out["roofline"]["streamed_bytes_per_launch"] = streamed
-            out["roofline"]["f32_bytes_answered_per_s_GB"] = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-            out["roofline"]["note"] = ("bf16 shadow-copy filter + exact f32 re-evaluation of the candidates: achieved / frac are priced on "
-                                       "the bytes the kernel streams (shadow rows + norms), not on the f32 bytes it answers for")
-        try:        # HBM bytes per launch measured by the PMC pass committed under profiles/ (same kernel, same N)
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                ent = json.load(f).get("%s@%d" % (corpus.kernel_name(metric), n_rows))
-            if ent:
-                out["roofline"]["traffic"] = ent["bytes_per_launch"]
-                out["roofline"]["traffic_source"] = ent["source"]
-        except Exception:
-            pass
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(vt, np_dtype, dim, metric, k, args.cpu_sample_rows)
-            except Exception as e:                                        # the checker is optional on a bare box
-                out["cpu_baseline"] = {"value": None, "unit": "vectors/s", "cores": 0, "kind": "port",
-                                       "sample": "unavailable: %r" % (e,)}
         print(json.dumps(out))
-    corpus.close()
+    if corpus is not None:
+        corpus.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def batch_cpu_baseline(args, vt, np_dtype, dim, metric, k, seconds=10.0):
+    """the reference has no batched entry point: its batch is Q independent scans, so its (query, vector) pair rate is its
+    single-scan rate for the batch's metric"""
+    try:
+        out = cpu_baseline(vt, np_dtype, dim, metric, k, args.cpu_sample_rows, seconds=seconds, all_cores=False)
+        out["sample"] += "; a batch of Q queries costs the reference Q such scans: (query, vector) pairs/s = this rate"
+        return out
+    except Exception as e:
+        return {"value": None, "unit": "vectors/s", "cores": 0, "kind": "port", "sample": "unavailable: %r" % (e,)}
 
 
 if __name__ == "__main__":

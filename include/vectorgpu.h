@@ -87,7 +87,8 @@ int vg_corpus_append_device(vg_corpus *c, const void *dev_rows, int64_t n_rows, 
  * out_rowids[k], out_dist[k] (float values widened to double, like vFullScanCursor.distance), *out_count <= k.
  * f32 corpora, L2 / SQUARED_L2 / DOT, k <= 64: the scan streams a bf16 shadow copy of the corpus (built on the first such
  * scan after rows were appended; + 50 % device memory) as a lower-bound filter and re-evaluates the candidates on the f32
- * rows - the same rowids and distance bits as the plain f32 scan, from half the bytes.  VG_SCAN_FILTER=0 turns it off. */
+ * rows - the same rowids and distance bits as the plain f32 scan, from half the bytes.  vg_corpus_set_scan_filter(c, 0) /
+ * VG_SCAN_FILTER=0 turn it off; a corpus whose shadow copy does not fit device memory keeps the plain scan by itself. */
 int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k,
                  int64_t *out_rowids, double *out_dist, int *out_count);
 
@@ -175,6 +176,8 @@ int     vg_shards_set_rowid_base(vg_shards *s, int64_t base);
 int     vg_shards_append(vg_shards *s, const void *host_rows, int64_t n_rows, int64_t row_stride_bytes, const int64_t *rowids);
 int     vg_shards_append_records(vg_shards *s, const void *host_records, int64_t n_records);
 int64_t vg_shards_rowid_at(const vg_shards *s, int64_t position);
+int     vg_shards_rowids(const vg_shards *s, int64_t pos0, int64_t n, int64_t *out);   /* rowids of positions [pos0, pos0 + n) */
+int     vg_shards_set_scan_filter(vg_shards *s, int mode);                             /* vg_corpus_set_scan_filter on every shard */
 int     vg_shards_scan_topk(vg_shards *s, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist, int *out_count);
 int     vg_shards_scan_topk_batch(vg_shards *s, int metric, const void *queries, int nq, int k,
                                   int64_t *out_rowids, double *out_dist, int *out_counts);
@@ -190,8 +193,46 @@ int vg_set_profiling(vg_corpus *c, int enabled);
 int vg_last_kernel_ms(vg_corpus *c, float *scan_ms, float *merge_ms);
 /* mean kernel milliseconds over the launches recorded since profiling was enabled (at most the last 1024) */
 int vg_profile_mean_ms(vg_corpus *c, int *n_launches, float *scan_ms, float *merge_ms);
+/* the same, with the filter scan's plain-f32 pre-pass (its scan + merge, run before the filter kernel) reported on its
+ * own: scan_ms is ONE kernel - the dominant one - whichever path served the scan */
+int vg_profile_mean_ms_ex(vg_corpus *c, int *n_launches, float *scan_ms, float *merge_ms, float *prepass_ms);
 /* name of the scan kernel variant chosen for (metric) on this corpus, e.g. "scan_f32_l2_u6_lpr16" */
 const char *vg_scan_kernel_name(vg_corpus *c, int metric);
+/* filter scan: f32 rows evaluated exactly by the filter-scan launches since the last call (then reset) - how selective the
+ * bf16 bound is on the data at hand */
+int vg_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals);
+
+/* rows sent to a device by every vg_corpus_append* / vg_shards_append* call of this process so far */
+long long vg_stat_rows_appended(void);
+
+/* ---- tie order ----
+ * VG_TIE_POSITION (default): results ordered by (distance, scan position) - deterministic, shard-invariant.
+ * VG_TIE_REFERENCE: the reference's own result among EQUAL distances, rowid for rowid: its k unsorted slots, strict '<'
+ * insertion into the FIRST slot holding the maximum and the final exchange sort (sqlite-vector.c:2022-2069, 2102-2106,
+ * 2138-2146) are replayed on the host over the rows that can enter at all - the first P rows, then only the rows the
+ * device finds below the bound reached so far (vg_reforder.hip).  Same distances either way; this mode makes
+ * int8 / uint8 scans (where ties are routine) identical to the reference in rowids and order too.  With the mode set,
+ * vg_scan_topk / vg_shards_scan_topk answer through vg_scan_topk_reference; the batch calls run one such scan per query. */
+enum { VG_TIE_POSITION = 0, VG_TIE_REFERENCE = 1 };
+int vg_corpus_set_tie_order(vg_corpus *c, int mode);
+int vg_corpus_tie_order(const vg_corpus *c);
+int vg_shards_set_tie_order(vg_shards *s, int mode);
+int vg_scan_topk_reference(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist, int *out_count);
+/* building blocks (what vg_shards composes over several devices): all N distances of a query left in device memory
+ * (enqueued, no wait); rows [pos0, pos0 + n) of them; every row >= pos0 whose distance is < bound as
+ * (position << 32 | float bits) pairs in any order - *out_count may exceed cap, then only cap pairs were written. */
+int vg_scan_distances_resident(vg_corpus *c, int metric, const void *query);
+int vg_resident_distances_fetch(vg_corpus *c, int64_t pos0, int64_t n, float *out_host);
+int vg_resident_distances_below(vg_corpus *c, int64_t pos0, float bound, uint64_t *out_pairs, int64_t cap, int64_t *out_count);
+
+/* host-only: the same replay over n distances the caller holds (scan order); returns the count (<= k) or -1.
+ * below_cap <= 0: the device path's candidate capacity. */
+int vg_reference_topk_replay(const float *dist, int64_t n, int k, int64_t below_cap, int64_t *out_pos, double *out_dist);
+
+/* ---- per-corpus switches ---- */
+/* single f32 queries through the bf16 shadow copy: 0 = off (plain f32 scans, no shadow copy is built), 1 = on where it
+ * serves, -1 = default (environment VG_SCAN_FILTER, else on).  The extension maps vector_init's scan_filter= option here. */
+int vg_corpus_set_scan_filter(vg_corpus *c, int mode);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,7 @@ EXT_PATH = os.path.join(HERE, "vector.so")         # must be named vector.* (ent
 F32, F16, BF16, U8, I8 = 1, 2, 3, 4, 5
 L2, SQUARED_L2, COSINE, DOT, L1 = 1, 2, 3, 4, 5
 QUANT_U8, QUANT_S8 = 1, 2
+TIE_POSITION, TIE_REFERENCE = 0, 1
 KEY_EMPTY = 0xFFFFFFFFFFFFFFFF
 HALF_TYPES = True            # f16 / bf16 scan kernels are built in
 TYPE_SIZE = {F32: 4, F16: 2, BF16: 2, U8: 1, I8: 1}
@@ -100,6 +101,20 @@ def lib():
         "vg_last_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "vg_profile_mean_ms": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "vg_scan_kernel_name": (C.c_char_p, [vp, i32]),
+        "vg_profile_mean_ms_ex": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "vg_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
+        "vg_corpus_set_scan_filter": (i32, [vp, i32]),
+        "vg_corpus_set_tie_order": (i32, [vp, i32]),
+        "vg_corpus_tie_order": (i32, [vp]),
+        "vg_shards_set_tie_order": (i32, [vp, i32]),
+        "vg_shards_set_scan_filter": (i32, [vp, i32]),
+        "vg_shards_rowids": (i32, [vp, i64, i64, vp]),
+        "vg_scan_topk_reference": (i32, [vp, i32, vp, i32, vp, vp, C.POINTER(i32)]),
+        "vg_stat_rows_appended": (C.c_longlong, []),
+        "vg_reference_topk_replay": (i32, [vp, i64, i32, i64, vp, vp]),
+        "vg_scan_distances_resident": (i32, [vp, i32, vp]),
+        "vg_resident_distances_fetch": (i32, [vp, i64, i64, vp]),
+        "vg_resident_distances_below": (i32, [vp, i64, C.c_float, vp, i64, C.POINTER(i64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -233,6 +248,24 @@ class Corpus:
     def kernel_name(self, metric):
         return lib().vg_scan_kernel_name(self.h, metric).decode()
 
+    def profile_mean_ms_ex(self):
+        """(launches, scan kernel ms, merge ms, pre-pass ms) - the scan figure is ONE kernel"""
+        n, a, b, p = C.c_int(0), C.c_float(0), C.c_float(0), C.c_float(0)
+        _check(lib().vg_profile_mean_ms_ex(self.h, C.byref(n), C.byref(a), C.byref(b), C.byref(p)))
+        return n.value, a.value, b.value, p.value
+
+    def filter_exact_evals(self):
+        v = C.c_ulonglong(0)
+        _check(lib().vg_filter_exact_evals(self.h, C.byref(v)))
+        return v.value
+
+    def set_scan_filter(self, mode):
+        _check(lib().vg_corpus_set_scan_filter(self.h, mode))
+
+    def set_tie_order(self, mode):
+        """TIE_POSITION (default) or TIE_REFERENCE: the reference's slot-history result among equal distances"""
+        _check(lib().vg_corpus_set_tie_order(self.h, mode))
+
 
 class Shards:
     """One logical corpus dealt block-cyclically over several devices of this process (opaque vg_shards handle)."""
@@ -275,6 +308,17 @@ class Shards:
     def rowid_at(self, pos):
         return lib().vg_shards_rowid_at(self.h, pos)
 
+    def rowids(self, pos0, n):
+        out = np.zeros(n, dtype=np.int64)
+        _check(lib().vg_shards_rowids(self.h, pos0, n, _ptr(out)))
+        return out
+
+    def set_tie_order(self, mode):
+        _check(lib().vg_shards_set_tie_order(self.h, mode))
+
+    def set_scan_filter(self, mode):
+        _check(lib().vg_shards_set_scan_filter(self.h, mode))
+
     def scan_topk(self, metric, query, k):
         query = np.ascontiguousarray(query)
         ids = np.zeros(max(k, 1), dtype=np.int64)
@@ -315,6 +359,17 @@ def quantize_query(src_type, src, scale, offset, qtype):
     dst = np.empty(src.shape[0], dtype=np.uint8 if qtype == QUANT_U8 else np.int8)
     _check(lib().vg_quantize_query(src_type, _ptr(src), src.shape[0], scale, offset, qtype, _ptr(dst)))
     return dst
+
+
+def reference_topk_replay(dist, k, below_cap=0):
+    """host replay of the reference's slot algorithm over a distance stream -> (positions, distances)"""
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    pos = np.zeros(max(k, 1), dtype=np.int64)
+    out = np.zeros(max(k, 1), dtype=np.float64)
+    cnt = lib().vg_reference_topk_replay(_ptr(dist), dist.shape[0], k, below_cap, _ptr(pos), _ptr(out))
+    if cnt < 0:
+        raise VectorGpuError("vg_reference_topk_replay: bad arguments")
+    return pos[:cnt], out[:cnt]
 
 
 def merge_keys_batch(keys, pos_offsets, k):

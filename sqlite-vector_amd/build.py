@@ -23,7 +23,7 @@ VEC = os.path.join(HERE, "vector.so")
 # translation units from one source file each, so that a from-scratch build is bounded by ~1.5 min instead of ~4
 HIP_UNITS = [("vg_api.hip", "vg_api.hip.o", []), ("vg_corpus.hip", "vg_corpus.hip.o", []), ("vg_batch_api.hip", "vg_batch_api.hip.o", []),
              ("vg_select.hip", "vg_select.hip.o", []), ("vg_batch.hip", "vg_batch.hip.o", []), ("vg_quant.hip", "vg_quant.hip.o", []),
-             ("vg_shards.hip", "vg_shards.hip.o", []), ("vg_multi.hip", "vg_multi.hip.o", []),
+             ("vg_shards.hip", "vg_shards.hip.o", []), ("vg_multi.hip", "vg_multi.hip.o", []), ("vg_reforder.hip", "vg_reforder.hip.o", []),
              ("vg_batch_i8.hip", "vg_batch_i8.hip.o", []), ("vg_batch_i8.hip", "vg_batch_i8_pre.o", ["-DVGI_TU_PRE"]),
              ("vg_batch_h.hip", "vg_batch_h.hip.o", []), ("vg_batch_h.hip", "vg_batch_h_bf16.o", ["-DVGH_TU=1"]),
              ("vg_batch_h.hip", "vg_batch_h_bound.o", ["-DVGH_TU=2"]), ("vg_batch_h.hip", "vg_batch_h_f32.o", ["-DVGH_TU=3"])]
@@ -47,9 +47,8 @@ def _hipcc():
 
 def build_gpu_library(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
-        [os.path.join(ROOT, "include", "vectorgpu.h")]
-    if not force and not _newer(LIB, deps):
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "vectorgpu.h")]
+    if not force and not _newer(LIB, srcs + hdrs):
         return LIB
     # one object per translation unit (compiled concurrently), then one link
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
@@ -58,7 +57,7 @@ def build_gpu_library(force=False, verbose=False):
         src = os.path.join(CSRC, name)
         obj = os.path.join(HERE, "build", objname)
         objs.append(obj)
-        if force or _newer(obj, [src] + deps):
+        if force or _newer(obj, [src] + hdrs):           # an object depends on its own source + every header
             cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

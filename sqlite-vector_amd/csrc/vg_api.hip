@@ -121,10 +121,10 @@ static scan_fn_t pick_kernel(int vtype, int acc, const Shape &s, bool nt) {
 }
 
 // stream with non-temporal loads once the corpus cannot live in the 256 MiB Infinity Cache anyway
-static bool use_nt_loads(const vg_corpus *c) {
+static bool use_nt_loads(const vg_corpus *c, int64_t n_rows) {
     int force = env_int("VG_NT", -1);
     if (force >= 0) return force != 0;
-    return c->n_rows * c->stride > (256ll << 20);
+    return n_rows * c->stride > (256ll << 20);
 }
 
 int vg_metric_to_acc(int metric) {
@@ -147,14 +147,15 @@ static const char *acc_tag(int a) {
     return "?";
 }
 
+static bool scan_filter_serves(const vg_corpus *c, int metric);
+
 extern "C" const char *vg_scan_kernel_name(vg_corpus *c, int metric) {
     if (!c) return "";
     Shape s;
     int acc = vg_metric_to_acc(metric);
     if (acc < 0 || !choose_shape(c->nch, c->vtype, acc, &s)) return "";
     if (acc == A_COS && (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) && !s.long_rows && env_int("VG_HALF_COSN", 1)) acc = A_COSN;
-    if (c->vtype == VG_TYPE_F32 && (acc == A_L2 || acc == A_DOT) && !s.long_rows && env_int("VG_SCAN_FILTER", 1) != 0 &&
-        c->n_rows * c->stride >= (long long)env_int("VG_SCAN_FILTER_MIN_MB", 3072) * (1ll << 20)) {
+    if (!s.long_rows && scan_filter_serves(c, metric)) {
         const long long bs = vg_bf16_shadow_stride(c);           // the top-k scan reads the bf16 shadow copy (vg_scan_filter.h)
         Shape fs;
         vg_choose_shape((int)(bs / 16), VG_TYPE_U8, A_DOT, &fs, 8);
@@ -165,7 +166,7 @@ extern "C" const char *vg_scan_kernel_name(vg_corpus *c, int metric) {
         }
     }
     snprintf(c->kernel_name, sizeof(c->kernel_name), "scan%s_%s_%s_u%d_lpr%d%s", s.long_rows ? "_long" : "",
-             type_tag(c->vtype), acc_tag(acc), s.U, 1 << s.lpr_log2, use_nt_loads(c) ? "_nt" : "");
+             type_tag(c->vtype), acc_tag(acc), s.U, 1 << s.lpr_log2, use_nt_loads(c, c->n_rows) ? "_nt" : "");
     return c->kernel_name;
 }
 
@@ -187,12 +188,33 @@ int vg_launch_merge(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_o
     return (int)hipGetLastError();
 }
 
-// ---- f32 through the bf16 shadow copy (vg_scan_filter.h; VG_SCAN_FILTER=1): half the bytes per row, exact answers.
-// Returns -1 when the shape is not served (caller takes the plain f32 scan).
+// ---- f32 through the bf16 shadow copy (vg_scan_filter.h): half the bytes per row, exact answers.
 typedef void (*filter_fn_t)(FilterScanArgs);
+
+// What one scan launch covers.  n_rows < 0: the whole corpus; a prefix otherwise (the filter scan's plain-f32 pre-pass).
+struct ScanPlan {
+    int64_t n_rows = -1;
+    bool allow_filter = true;      // false: the plain kernel of vg_scan.h whatever the corpus / the switches say
+    bool record = true;            // false: no entry in the profiling ring (a pre-pass is recorded by its parent launch)
+};
 static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys,
-                       float *dev_out_dist, hipStream_t stream);
-static thread_local bool t_plain_scan_only = false;     // set while the filter scan runs its plain-f32 pre-pass
+                       float *dev_out_dist, hipStream_t stream, const ScanPlan &plan = ScanPlan());
+
+// Is the filter scan switched on for this corpus?  vg_corpus_set_scan_filter (the extension's scan_filter= option) wins
+// over the VG_SCAN_FILTER environment switch; default on.
+static bool scan_filter_enabled(const vg_corpus *c) {
+    if (c->filter_disabled) return false;
+    if (c->scan_filter_mode >= 0) return c->scan_filter_mode != 0;
+    return env_int("VG_SCAN_FILTER", 1) != 0;
+}
+// Small corpora keep the plain f32 scan: the filter scan pays a pre-pass launch plus the exact evaluations of the lists'
+// warm-up (measured at D = 384: 3M rows 0.41 vs 0.70 ms, 1M rows - no pre-pass - 0.43 vs 0.26 ms, 10k rows 52 vs 34 us)
+static bool scan_filter_serves(const vg_corpus *c, int metric) {
+    if (c->vtype != VG_TYPE_F32 || (metric != VG_DIST_L2 && metric != VG_DIST_SQUARED_L2 && metric != VG_DIST_DOT)) return false;
+    if (!scan_filter_enabled(c)) return false;
+    return c->n_rows * c->stride >= (long long)env_int("VG_SCAN_FILTER_MIN_MB", 3072) * (1ll << 20);
+}
+
 template <bool NT>
 static filter_fn_t pick_filter_u(int U) {
     switch (U) {
@@ -205,11 +227,18 @@ static filter_fn_t pick_filter_u(int U) {
     }
     return nullptr;
 }
+
+static hipEvent_t *prof_slot(vg_corpus *c, uint8_t flags) {
+    if (!c->profiling) return nullptr;
+    const int slot = (int)(c->prof_launches % VG_PROF_RING);
+    c->ev_flags[(size_t)slot] = flags;
+    ++c->prof_launches;
+    return &c->ev[(size_t)slot * VG_PROF_EVS];
+}
+
+// Returns -1 when the shape is not served (caller takes the plain f32 scan).
 static int launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream) {
-    if (c->vtype != VG_TYPE_F32 || (metric != VG_DIST_L2 && metric != VG_DIST_SQUARED_L2 && metric != VG_DIST_DOT)) return -1;
-    // Small corpora keep the plain f32 scan: the filter scan pays a pre-pass launch plus the exact evaluations of the lists'
-    // warm-up (measured at D = 384: 3M rows 0.41 vs 0.70 ms, 1M rows - no pre-pass - 0.43 vs 0.26 ms, 10k rows 52 vs 34 us)
-    if (c->n_rows * c->stride < (long long)env_int("VG_SCAN_FILTER_MIN_MB", 3072) * (1ll << 20)) return -1;
+    if (!scan_filter_serves(c, metric)) return -1;
     const long long bs = vg_bf16_shadow_stride(c);
     const int nch_b = (int)(bs / 16);
     Shape s;
@@ -219,10 +248,24 @@ static int launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query
         const int fl = env_int("VG_FILTER_LPR_LOG2", -1), fu = env_int("VG_FILTER_U", -1);
         if (fl >= 0 && fl <= 6 && fu > 0 && (nch_b + (1 << fl) - 1) / (1 << fl) <= fu && pick_filter_u<true>(fu)) { s.lpr_log2 = fl; s.U = fu; }
     }
+    Shape xs;                                            // the f32 kernel's own shape: the exact evaluation sums in its order
+    choose_shape(c->nch, c->vtype, vg_metric_to_acc(metric), &xs);
+    if (xs.long_rows) return -1;
+    // The shadow copy and the norms cost +50 % of the corpus in HBM.  A corpus they do not fit next to keeps the plain
+    // f32 scan (which served it before the filter existed) instead of failing every query.
     int rc = vg_ensure_row_norms(c);
+    if (rc == VG_OK) rc = vg_ensure_bf16_shadow(c);
+    if (rc == VG_ERR_NOMEM) {
+        (void)hipGetLastError();                         // clear the sticky allocation error
+        c->filter_disabled = true;
+        return -1;
+    }
     if (rc != VG_OK) return rc;
-    if ((rc = vg_ensure_bf16_shadow(c)) != VG_OK) return rc;
-    if (stream != c->stream) {                           // both passes ran on the corpus stream
+    if (!c->d_filter_evals) {
+        HIP_TRY(hipMalloc(&c->d_filter_evals, sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(c->d_filter_evals, 0, sizeof(unsigned long long), c->stream));
+    }
+    if (stream != c->stream) {                           // both passes (and the memset) ran on the corpus stream
         if (!c->norm_ev) HIP_TRY(hipEventCreateWithFlags(&c->norm_ev, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(c->norm_ev, c->stream));
         HIP_TRY(hipStreamWaitEvent(stream, c->norm_ev, 0));
@@ -239,56 +282,50 @@ static int launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query
     a.shadow = c->d_rows_bf; a.rows = c->d_rows; a.query = dev_query; a.row_norm = c->d_xnorm; a.cand = c->d_cand;
     a.n_rows = c->n_rows; a.stride = c->stride; a.bstride = bs; a.nch = c->nch; a.nch_b = nch_b;
     a.lpr_log2 = s.lpr_log2; a.k = k; a.root = (metric == VG_DIST_L2) ? 1 : 0; a.dot = (metric == VG_DIST_DOT) ? 1 : 0; a.dim = c->dim;
+    // |s~ - s| <= cerr |q||x| (vg_scan_filter.h): BOTH factors of every product are rounded to bf16, unit roundoff u = 2^-8
+    // each, so the products are off by (1+u)^2 - 1 = 2u + u^2 = 2^-7 + 2^-16; + (D + 64) 2^-21 for the f32 sums
+    a.cerr = 0.0078125f + 1.52587890625e-5f + (float)(c->dim + 64) * 4.76837158203125e-7f;
+#ifdef VG_TEST_ROUND1_CERR     // tools/build_round1_cerr_variant.sh only: round 1's unsound constant, to show tests/test_gpu_filter_bound.py red on it
     a.cerr = 0.00390625f + 1.6e-5f + (float)(c->dim + 64) * 4.76837158203125e-7f;
+#endif
     a.rel = (float)(c->dim + 64) * 2.384185791015625e-7f;
-    {
-        Shape xs;                                        // the f32 kernel's own shape: the exact evaluation sums in its order
-        choose_shape(c->nch, c->vtype, vg_metric_to_acc(metric), &xs);
-        if (xs.long_rows) return -1;
-        a.xlpr_log2 = xs.lpr_log2; a.xU = xs.U;
-    }
+    a.xlpr_log2 = xs.lpr_log2; a.xU = xs.U;
+    a.evals = c->d_filter_evals;
     const size_t smem = std::max<size_t>((size_t)c->nch * 16, (size_t)VG_PUBLISH_LDS_BYTES);
     if (c->append_pending && stream != c->stream) HIP_TRY(hipStreamWaitEvent(stream, c->append_ev, 0));
-    hipEvent_t *evs = nullptr;
-    if (c->profiling) {
-        int slot = (int)(c->prof_launches % VG_PROF_RING);
-        evs = &c->ev[(size_t)slot * 3];
-        c->ev_had_merge[(size_t)slot] = 1;
-        ++c->prof_launches;
-        hipEventRecord(evs[0], stream);
-    }
     // Pre-pass: a plain f32 scan of the first 1/64 of the rows.  Its k-th best distance bounds the final k-th best from
     // above, so no wavefront has to warm its list up from +Inf (k ln(rows per wavefront / k) exact evaluations each,
-    // ~0.35 ms in all); the filter scan below still covers every row.  (Timed as part of the scan: evs[0] is above.)
+    // ~0.35 ms in all); the filter scan below still covers every row.
+    const bool prepass = env_int("VG_SCAN_FILTER_PREPASS", 1) != 0 && c->n_rows >= (1 << 20);
+    hipEvent_t *evs = prof_slot(c, (uint8_t)(VG_EVF_MERGE | (prepass ? VG_EVF_PREPASS : 0)));
+    if (evs) hipEventRecord(evs[0], stream);
     a.init_keys = nullptr;
-    if (env_int("VG_SCAN_FILTER_PREPASS", 1) != 0 && c->n_rows >= (1 << 20)) {
-        const int64_t keep_rows = c->n_rows;
-        const bool keep_prof = c->profiling;
-        c->n_rows = std::max<int64_t>(65536, keep_rows / 64);
-        c->profiling = false;
-        t_plain_scan_only = true;
-        const int rcp = launch_scan(c, metric, dev_query, k, dev_out_keys, nullptr, stream);
-        t_plain_scan_only = false;
-        c->n_rows = keep_rows;
-        c->profiling = keep_prof;
+    if (prepass) {
+        ScanPlan pre;
+        pre.n_rows = std::max<int64_t>(65536, c->n_rows / 64);
+        pre.allow_filter = false;
+        pre.record = false;
+        const int rcp = launch_scan(c, metric, dev_query, k, dev_out_keys, nullptr, stream, pre);
         if (rcp != VG_OK) return rcp;
         a.init_keys = dev_out_keys;                      // read by every workgroup before the final merge overwrites it
+        if (evs) hipEventRecord(evs[1], stream);
     }
     if (smem > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
-    if (evs) hipEventRecord(evs[1], stream);
-    hipLaunchKernelGGL(vg_merge_kernel, dim3(1), dim3(VG_MERGE_THREADS), 0, stream, (const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys);
     if (evs) hipEventRecord(evs[2], stream);
+    hipLaunchKernelGGL(vg_merge_kernel, dim3(1), dim3(VG_MERGE_THREADS), 0, stream, (const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys);
+    if (evs) hipEventRecord(evs[3], stream);
     HIP_TRY(hipGetLastError());
     return VG_OK;
 }
 
 // Launch the scan (+ merge in top-k mode) on `stream`.  dev_query holds nch*16 zero-padded bytes.
 static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys,
-                       float *dev_out_dist, hipStream_t stream) {
+                       float *dev_out_dist, hipStream_t stream, const ScanPlan &plan) {
     int acc = vg_metric_to_acc(metric);
     if (acc < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
-    if (!t_plain_scan_only && !dev_out_dist && k <= VG_MAX_FUSED_K && c->vtype == VG_TYPE_F32 && env_int("VG_SCAN_FILTER", 1) != 0) {
+    const int64_t n_rows = (plan.n_rows >= 0) ? std::min<int64_t>(plan.n_rows, c->n_rows) : c->n_rows;
+    if (plan.allow_filter && plan.n_rows < 0 && !dev_out_dist && k <= VG_MAX_FUSED_K) {
         int rcf = launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream);
         if (rcf != -1) return rcf;
     }
@@ -306,11 +343,11 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
             HIP_TRY(hipStreamWaitEvent(stream, c->norm_ev, 0));
         }
     }
-    scan_fn_t fn = pick_kernel(c->vtype, acc, s, use_nt_loads(c));
+    scan_fn_t fn = pick_kernel(c->vtype, acc, s, use_nt_loads(c, n_rows));
     if (!fn) return vg_fail(VG_ERR_UNSUPPORTED, "no scan kernel for type %s", type_tag(c->vtype));
 
     const int rpb = VG_WAVE >> s.lpr_log2;
-    const long long nbatch = (c->n_rows + rpb - 1) / rpb;
+    const long long nbatch = (n_rows + rpb - 1) / rpb;
     // 16-wave workgroups: one per CU is what ~96 VGPRs admit (5 waves/SIMD); a second one only queues behind it
     const int bpc = std::max(1, std::min(8, env_int("VG_BLOCKS_PER_CU", 1)));
     long long blocks = (nbatch + VG_WAVES_PER_BLOCK - 1) / VG_WAVES_PER_BLOCK;
@@ -322,7 +359,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     a.query = dev_query;
     a.cand = c->d_cand;
     a.out_dist = dev_out_dist;
-    a.n_rows = c->n_rows;
+    a.n_rows = n_rows;
     a.stride = c->stride;
     a.nch = c->nch;
     a.lpr_log2 = s.lpr_log2;
@@ -345,23 +382,17 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     // host appends are only enqueued on the corpus stream: a scan on ANOTHER stream must wait for them
     if (c->append_pending && stream != c->stream) HIP_TRY(hipStreamWaitEvent(stream, c->append_ev, 0));
 
-    hipEvent_t *evs = nullptr;
-    if (c->profiling) {
-        int slot = (int)(c->prof_launches % VG_PROF_RING);
-        evs = &c->ev[(size_t)slot * 3];
-        c->ev_had_merge[(size_t)slot] = (dev_out_dist == nullptr);
-        ++c->prof_launches;
-        hipEventRecord(evs[0], stream);
-    }
+    hipEvent_t *evs = plan.record ? prof_slot(c, (uint8_t)(dev_out_dist == nullptr ? VG_EVF_MERGE : 0)) : nullptr;
+    if (evs) hipEventRecord(evs[0], stream);
     if (smem > 64 * 1024)          // very long rows: the query alone needs more than the default dynamic-LDS window
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
-    if (evs) hipEventRecord(evs[1], stream);
+    if (evs) hipEventRecord(evs[2], stream);
     if (!dev_out_dist) {
         hipLaunchKernelGGL(vg_merge_kernel, dim3(1), dim3(VG_MERGE_THREADS), 0, stream,
                            (const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys);
     }
-    if (evs) hipEventRecord(evs[2], stream);
+    if (evs) hipEventRecord(evs[3], stream);
     HIP_TRY(hipGetLastError());
     return VG_OK;
 }
@@ -379,17 +410,20 @@ static void stage_query(vg_corpus *c, const void *query) {
 }
 
 // kernel times of ring slot `slot` (waits for that launch to finish)
-static void slot_times(vg_corpus *c, int slot, float *scan_ms, float *merge_ms) {
-    hipEvent_t *evs = &c->ev[(size_t)slot * 3];
-    hipEventSynchronize(evs[2]);
-    *scan_ms = 0.f; *merge_ms = 0.f;
-    hipEventElapsedTime(scan_ms, evs[0], evs[1]);
-    if (c->ev_had_merge[(size_t)slot]) hipEventElapsedTime(merge_ms, evs[1], evs[2]);
+// scan_ms is ONE kernel (the scan / filter-scan kernel); a filter scan's plain-f32 pre-pass (its scan + merge) is prepass_ms
+static void slot_times(vg_corpus *c, int slot, float *scan_ms, float *merge_ms, float *prepass_ms) {
+    hipEvent_t *evs = &c->ev[(size_t)slot * VG_PROF_EVS];
+    const uint8_t fl = c->ev_flags[(size_t)slot];
+    hipEventSynchronize(evs[3]);
+    *scan_ms = 0.f; *merge_ms = 0.f; *prepass_ms = 0.f;
+    if (fl & VG_EVF_PREPASS) hipEventElapsedTime(prepass_ms, evs[0], evs[1]);
+    hipEventElapsedTime(scan_ms, evs[(fl & VG_EVF_PREPASS) ? 1 : 0], evs[2]);
+    if (fl & VG_EVF_MERGE) hipEventElapsedTime(merge_ms, evs[2], evs[3]);
 }
 
 void vg_collect_timing(vg_corpus *c) {
     if (!c->profiling || c->prof_launches == 0) return;
-    slot_times(c, (int)((c->prof_launches - 1) % VG_PROF_RING), &c->last_scan_ms, &c->last_merge_ms);
+    slot_times(c, (int)((c->prof_launches - 1) % VG_PROF_RING), &c->last_scan_ms, &c->last_merge_ms, &c->last_prepass_ms);
 }
 
 extern "C" float vg_key_distance(uint64_t key) { return vg_sortable_f32((uint32_t)(key >> 32)); }
@@ -416,6 +450,7 @@ extern "C" int vg_scan_distances_device(vg_corpus *c, int metric, const void *de
 }
 
 static int ensure_dist_buffer(vg_corpus *c) {
+    c->dist_valid_rows = 0;
     if (c->d_dist_cap >= c->n_rows) return VG_OK;
     if (c->d_dist) { hipFree(c->d_dist); c->d_dist = nullptr; c->d_dist_cap = 0; }
     HIP_TRY(hipMalloc(&c->d_dist, (size_t)c->n_rows * sizeof(float)));
@@ -436,6 +471,22 @@ extern "C" int vg_scan_distances(vg_corpus *c, int metric, const void *query, fl
     HIP_TRY(hipMemcpyAsync(out_dist_host, c->d_dist, (size_t)c->n_rows * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     vg_collect_timing(c);
+    return VG_OK;
+}
+
+// All N distances of one query, left in the corpus' device buffer (enqueued only - the readers below synchronise):
+// the first half of the tie_order = reference scan (vg_reforder.hip) and of its multi-device form (vg_shards.hip).
+extern "C" int vg_scan_distances_resident(vg_corpus *c, int metric, const void *query) {
+    if (!c || !query) return vg_fail(VG_ERR_INVALID, "vg_scan_distances_resident: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->n_rows == 0) { c->dist_valid_rows = 0; return VG_OK; }
+    int rc = ensure_dist_buffer(c);
+    if (rc != VG_OK) return rc;
+    stage_query(c, query);
+    HIP_TRY(hipMemcpyAsync(c->d_query, c->h_query, (size_t)c->stride, hipMemcpyHostToDevice, c->stream));
+    rc = launch_scan(c, metric, c->d_query, 0, nullptr, c->d_dist, c->stream);
+    if (rc != VG_OK) return rc;
+    c->dist_valid_rows = c->n_rows;
     return VG_OK;
 }
 
@@ -554,6 +605,7 @@ extern "C" int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k, 
     *out_count = 0;
     if (k <= 0 || c->n_rows == 0) return VG_OK;
     if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk: NULL output");
+    if (c->tie_order == VG_TIE_REFERENCE) return vg_scan_topk_reference(c, metric, query, k, out_rowids, out_dist, out_count);
     std::vector<uint64_t> keys((size_t)std::min<int64_t>((int64_t)k, c->n_rows));
     int cnt = 0;
     int rc = vg_scan_topk_keys(c, metric, query, (int)keys.size(), keys.data(), &cnt);
@@ -609,8 +661,8 @@ extern "C" int vg_set_profiling(vg_corpus *c, int enabled) {
     if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
     HIP_TRY(hipSetDevice(c->device));
     if (enabled && c->ev.empty()) {
-        c->ev.assign((size_t)VG_PROF_RING * 3, nullptr);
-        c->ev_had_merge.assign((size_t)VG_PROF_RING, 0);
+        c->ev.assign((size_t)VG_PROF_RING * VG_PROF_EVS, nullptr);
+        c->ev_flags.assign((size_t)VG_PROF_RING, 0);
         for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     }
     c->profiling = enabled != 0;
@@ -618,18 +670,43 @@ extern "C" int vg_set_profiling(vg_corpus *c, int enabled) {
     return VG_OK;
 }
 
-extern "C" int vg_profile_mean_ms(vg_corpus *c, int *n_launches, float *scan_ms, float *merge_ms) {
+extern "C" int vg_profile_mean_ms_ex(vg_corpus *c, int *n_launches, float *scan_ms, float *merge_ms, float *prepass_ms) {
     if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
     long long n = std::min<long long>(c->prof_launches, VG_PROF_RING);
-    double s = 0.0, m = 0.0;
+    double s = 0.0, m = 0.0, p = 0.0;
     for (long long i = 0; i < n; ++i) {
-        float a = 0.f, b = 0.f;
-        slot_times(c, (int)((c->prof_launches - 1 - i) % VG_PROF_RING), &a, &b);
-        s += a; m += b;
+        float a = 0.f, b = 0.f, pp = 0.f;
+        slot_times(c, (int)((c->prof_launches - 1 - i) % VG_PROF_RING), &a, &b, &pp);
+        s += a; m += b; p += pp;
     }
     if (n_launches) *n_launches = (int)n;
     if (scan_ms) *scan_ms = n ? (float)(s / n) : 0.f;
     if (merge_ms) *merge_ms = n ? (float)(m / n) : 0.f;
+    if (prepass_ms) *prepass_ms = n ? (float)(p / n) : 0.f;
+    return VG_OK;
+}
+
+extern "C" int vg_profile_mean_ms(vg_corpus *c, int *n_launches, float *scan_ms, float *merge_ms) {
+    return vg_profile_mean_ms_ex(c, n_launches, scan_ms, merge_ms, nullptr);
+}
+
+// Filter scan instrumentation: exact (f32) evaluations done by the filter-scan launches since the last call; resets the counter.
+extern "C" int vg_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals) {
+    if (!c || !out_evals) return vg_fail(VG_ERR_INVALID, "vg_filter_exact_evals: NULL argument");
+    *out_evals = 0;
+    if (!c->d_filter_evals) return VG_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(out_evals, c->d_filter_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_filter_evals, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VG_OK;
+}
+
+// Per-corpus switch of the filter scan (the extension's scan_filter= option): 0 = plain f32 scans, 1 = filter scan where it
+// serves, -1 = default (the VG_SCAN_FILTER environment switch, else on).  Turning it off releases nothing by itself.
+extern "C" int vg_corpus_set_scan_filter(vg_corpus *c, int mode) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    c->scan_filter_mode = mode < 0 ? -1 : (mode ? 1 : 0);
     return VG_OK;
 }
 

@@ -161,8 +161,8 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     hipEvent_t *evs = nullptr;
     if (c->profiling) {
         int slot = (int)(c->prof_launches % VG_PROF_RING);
-        evs = &c->ev[(size_t)slot * 3];
-        c->ev_had_merge[(size_t)slot] = 0;
+        evs = &c->ev[(size_t)slot * VG_PROF_EVS];
+        c->ev_flags[(size_t)slot] = 0;
         ++c->prof_launches;
         hipEventRecord(evs[0], c->stream);
     }
@@ -180,7 +180,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
         rc = vg_batch_launch((const float *)c->d_rows, c->n_rows, c->stride, (const float *)c->d_bq, nq_pad, nq, k, mode, root,
                              metric == VG_DIST_DOT ? nullptr : c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys,
                              c->stream);
-    if (evs) { hipEventRecord(evs[1], c->stream); hipEventRecord(evs[2], c->stream); }
+    if (evs) { hipEventRecord(evs[2], c->stream); hipEventRecord(evs[3], c->stream); }
     if (rc == -1) return -1;
     if (rc != 0) return vg_fail(VG_ERR_HIP, "batched scan launch failed: %s", hipGetErrorString((hipError_t)rc));
     std::vector<uint64_t> keys((size_t)nq * 64);
@@ -282,6 +282,15 @@ extern "C" int vg_scan_topk_batch(vg_corpus *c, int metric, const void *queries,
     for (int i = 0; i < nq; ++i) out_counts[i] = 0;
     if (k <= 0 || c->n_rows == 0) return VG_OK;
     if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch: NULL output");
+    if (c->tie_order == VG_TIE_REFERENCE) {                // the reference's order is defined per scan: one replayed scan per query
+        const size_t qbytes = (size_t)c->dim * c->es;
+        for (int i = 0; i < nq; ++i) {
+            int rc1 = vg_scan_topk_reference(c, metric, (const uint8_t *)queries + (size_t)i * qbytes, k, out_rowids + (size_t)i * k,
+                                             out_dist + (size_t)i * k, &out_counts[i]);
+            if (rc1 != VG_OK) return rc1;
+        }
+        return VG_OK;
+    }
     std::vector<uint64_t> keys((size_t)nq * k);
     int rc = vg_scan_topk_batch_keys(c, metric, queries, nq, k, keys.data(), out_counts);
     if (rc != VG_OK) return rc;

@@ -119,8 +119,8 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
     constexpr int WAVES = VGH_WAVES_OF(NTB), THREADS = 64 * WAVES, QPB = WAVES * VGH_QPW;
     constexpr int XU = ((NTB <= 32) ? 1 : 2) * (VT == T_F32 ? 2 : 1);    // 16-byte chunks per lane in the exact evaluation
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);
-    // VT == T_F32: an f32 corpus.  The matrix core reads a bf16 SHADOW copy of it (inputs rounded to 8 bits: the filter's
-    // error bound grows to 2^-8 |q||x|, still only a fraction of a candidate per query on random data), the exact
+    // VT == T_F32: an f32 corpus.  The matrix core reads a bf16 SHADOW copy of it (BOTH inputs of every product rounded to
+    // 8 bits of precision, unit roundoff 2^-8 each: the filter's error bound grows by (2^-7 + 2^-16) |q||x|), the exact
     // evaluation reads the f32 rows with the single-query kernel's f32 arithmetic.
     constexpr bool XF32 = (VT == T_F32);
     constexpr int FT = XF32 ? T_BF16 : VT;                               // element type the matrix core multiplies
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
     //   cosine  init = 0                            gmul = -((1 - thr) |q| (1 - 1e-5 sgn) - c |q|)
     //   L2      init = (thr2 (1 + 1e-5) - (1 - c) |q|^2) / 2 + tiny    gmul = -1
     // "accept everything" (list not full, query the filter cannot judge) = a huge FINITE init / gmul.
-    const float cerr = a.cerr;                                              // halves: (D + 64) * 2^-21; f32 behind bf16: + 2^-8
+    const float cerr = a.cerr;                                              // halves: (D + 64) * 2^-21; f32 behind bf16: + 2^-7 (1 + 2^-9)
     // Only init_reg / gmul live in registers (A alone takes up to 128 of the 256): the thresholds and the query norms
     // they derive from stay in LDS and are read again when a list changes.
     float init_reg[16], gmul[16];
@@ -642,7 +642,7 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long
     BatchArgsH a;
     a.rows = dev_rows; a.queries = dev_queries; a.row_nn = dev_row_nn; a.cand = dev_cand;
     a.xrows = dev_xrows; a.xqueries = dev_queries; a.xstride = xstride_bytes;
-    a.cerr = (float)(dim + 64) * 4.76837158203125e-7f + (type_code == 2 ? 0.00390625f + 1.6e-5f : 0.0f);   // (D+64) 2^-21 [+ 2^-8 (1 + 2^-8)]
+    a.cerr = (float)(dim + 64) * 4.76837158203125e-7f + (type_code == 2 ? 0.0078125f + 1.52587890625e-5f : 0.0f);   // (D+64) 2^-21 [+ 2u + u^2, u = 2^-8: query AND row are rounded to bf16]
     a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;
     a.mode = mode; a.root = root; a.dim = dim;
     const int ntb = vgh_ntb(stride_bytes);

@@ -5,6 +5,8 @@
 // with VG_ERR_NO_DEVICE.
 #include "vg_internal.h"
 
+#include <atomic>
+
 #include "vg_device.h"
 
 // ------------------------------------------------------------------------------------------------ errors
@@ -121,6 +123,8 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_sxx) hipFree(c->d_sxx);
     if (c->d_rows_s8) hipFree(c->d_rows_s8);
     if (c->d_rows_bf) hipFree(c->d_rows_bf);
+    if (c->d_filter_evals) hipFree(c->d_filter_evals);
+    if (c->d_below) hipFree(c->d_below);
     if (c->norm_ev) hipEventDestroy(c->norm_ev);
     if (c->d_bcand) hipFree(c->d_bcand);
     if (c->d_bkeys) hipFree(c->d_bkeys);
@@ -132,6 +136,7 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
 extern "C" int vg_corpus_clear(vg_corpus *c) {
     if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
     c->n_rows = 0;
+    c->dist_valid_rows = 0;
     c->xnorm_rows = 0;
     c->i8_rows = 0;
     c->bf_rows = 0;
@@ -288,6 +293,11 @@ static int append_impl(vg_corpus *c, const void *src, bool src_on_device, int64_
     return VG_OK;
 }
 
+// process-wide count of rows that went to a device through any vg_corpus_append* call (tests observe staging with it:
+// an append-only re-stage of the extension must move it by the number of new rows, not by the table size)
+static std::atomic<long long> g_rows_appended{0};
+extern "C" long long vg_stat_rows_appended(void) { return g_rows_appended.load(); }
+
 extern "C" int vg_corpus_append(vg_corpus *c, const void *host_rows, int64_t n_rows, int64_t row_stride_bytes,
                                 const int64_t *rowids) {
     if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
@@ -296,6 +306,7 @@ extern "C" int vg_corpus_append(vg_corpus *c, const void *host_rows, int64_t n_r
     if (row_stride_bytes < (int64_t)c->dim * c->es) return vg_fail(VG_ERR_INVALID, "vg_corpus_append: stride %lld smaller than a row (%lld bytes)", (long long)row_stride_bytes, (long long)c->dim * c->es);
     int rc = append_impl(c, host_rows, false, n_rows, row_stride_bytes, 0);
     if (rc != VG_OK) return rc;
+    g_rows_appended += n_rows;
     note_rowids(c, rowids, n_rows);
     c->n_rows += n_rows;
     return VG_OK;
@@ -309,6 +320,7 @@ extern "C" int vg_corpus_append_device(vg_corpus *c, const void *dev_rows, int64
     if (row_stride_bytes < (int64_t)c->dim * c->es) return vg_fail(VG_ERR_INVALID, "vg_corpus_append_device: stride smaller than a row");
     int rc = append_impl(c, dev_rows, true, n_rows, row_stride_bytes, 0);
     if (rc != VG_OK) return rc;
+    g_rows_appended += n_rows;
     note_rowids(c, host_rowids, n_rows);
     c->n_rows += n_rows;
     return VG_OK;
@@ -322,6 +334,7 @@ extern "C" int vg_corpus_append_records(vg_corpus *c, const void *host_records, 
     const int64_t rec = 8 + (int64_t)c->dim;
     int rc = append_impl(c, host_records, false, n_records, rec, 8);
     if (rc != VG_OK) return rc;
+    g_rows_appended += n_records;
     // rowids: little-endian int64 in front of every record (sqlite-vector.c:86-94, INT64_FROM_INT8PTR)
     std::vector<int64_t> ids((size_t)n_records);
     const uint8_t *p = (const uint8_t *)host_records;

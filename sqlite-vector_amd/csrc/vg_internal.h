@@ -19,6 +19,9 @@
 #include <vector>
 
 #define VG_PROF_RING 1024
+#define VG_PROF_EVS 4             // events per recorded launch: start | after the pre-pass | after the scan kernel | after the merge
+#define VG_EVF_MERGE 1            // ev_flags bits: the launch had a merge kernel / a pre-pass of its own
+#define VG_EVF_PREPASS 2
 #define VG_WAVE_HOST 64
 
 int vg_fail(int code, const char *fmt, ...);         // sets the thread-local message, returns code (vg_corpus.hip)
@@ -60,8 +63,11 @@ struct vg_corpus {
     uint64_t *d_cand = nullptr;    // max_blocks * 64 keys
     uint64_t *d_keys = nullptr;    // 64 keys
     uint64_t *h_keys = nullptr;    // pinned, 64 keys
-    float *d_dist = nullptr;       // lazily sized to n_rows (stream scans / large k)
+    float *d_dist = nullptr;       // lazily sized to n_rows (stream scans / large k / tie_order = reference)
     int64_t d_dist_cap = 0;
+    int64_t dist_valid_rows = 0;   // rows of d_dist the last vg_scan_distances_resident filled (0: none)
+    unsigned long long *d_below = nullptr;   // vg_reforder.hip: [count | VG_BELOW_CAP (position, distance) pairs]
+    int tie_order = 0;             // VG_TIE_POSITION / VG_TIE_REFERENCE (vg_corpus_set_tie_order)
     uint64_t *d_sel_keys = nullptr, *d_sel_sorted = nullptr;   // k > 64 path: N keys, unsorted / sorted
     void *d_sel_temp = nullptr;
     uint32_t *d_sel_state = nullptr;   // radix-select state + histogram (vg_select.hip)
@@ -84,6 +90,9 @@ struct vg_corpus {
     uint8_t *d_rows_s8 = nullptr;
     uint8_t *d_rows_bf = nullptr;                 // f32 corpora: bf16 shadow copy for the matrix-core filter (vg_batch_h.hip)
     int64_t bf_rows = 0, bf_cap = 0;
+    bool filter_disabled = false;                 // the shadow copy / norms did not fit HBM: single queries keep the plain f32 scan
+    int scan_filter_mode = -1;                    // vg_corpus_set_scan_filter: -1 = default (env VG_SCAN_FILTER, else on), 0 = off, 1 = on
+    unsigned long long *d_filter_evals = nullptr; // filter scan: exact evaluations of the launches since the last read-out
     int64_t i8_rows = 0, i8_cap = 0;              // orders a caller-stream scan behind a norm pass on the corpus stream
     void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
     uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;
@@ -91,13 +100,13 @@ struct vg_corpus {
     int max_blocks = 0;
     int cu_count = 0;
 
-    // instrumentation: a ring of event triples (before scan | after scan | after merge), recorded on the stream
-    // each launch runs on, read back only when asked - no host synchronisation inside a timed region
+    // instrumentation: a ring of event quadruples (start | after the pre-pass | after the scan kernel | after the merge),
+    // recorded on the stream each launch runs on, read back only when asked - no host synchronisation inside a timed region
     bool profiling = false;
-    std::vector<hipEvent_t> ev;            // 3 * VG_PROF_RING events, created on first enable
-    std::vector<uint8_t> ev_had_merge;
+    std::vector<hipEvent_t> ev;            // VG_PROF_EVS * VG_PROF_RING events, created on first enable
+    std::vector<uint8_t> ev_flags;         // VG_EVF_* per slot
     long long prof_launches = 0;           // launches recorded since profiling was (re)enabled
-    float last_scan_ms = 0.f, last_merge_ms = 0.f;
+    float last_scan_ms = 0.f, last_merge_ms = 0.f, last_prepass_ms = 0.f;
     char kernel_name[64] = {0};
 };
 

@@ -1,0 +1,171 @@
+// vg_reforder.hip - tie_order = reference: the reference's history-dependent result among EQUAL distances, reproduced
+// rowid for rowid (north_star: "bit-exact rowid/top-k ordering for int8/uint8").
+//
+// One store-mode scan leaves all N distances in HBM (vg_scan_distances_resident, vg_api.hip).  The host replays the
+// reference's slot algorithm (vg_refslots.h) over the first P rows, then asks the device for every later row below the
+// bound reached so far - vg_below_kernel compacts them, typically a few thousand of millions - and replays those in scan
+// order with the exact rule.  Extra cost over the fused top-k scan: 4 bytes written per row, one 4-byte-per-row read
+// pass (N = 10M: ~10 us) and two small copies.
+#include "vg_internal.h"
+#include "vg_refslots.h"
+
+#define VG_BELOW_CAP (1 << 17)          // candidate pairs the device buffer holds (more: the host replays a stretch itself)
+
+// out[0] = number of rows with dist < bound in [from, n) (may exceed cap), out[1 + i] = (position << 32) | float bits
+__global__ __launch_bounds__(256) void vg_below_kernel(const float *dist, long long from, long long n, float bound,
+                                                       unsigned long long *out, unsigned cap) {
+    const int lane = threadIdx.x & 63;
+    const long long q0 = from >> 2, q1 = (n + 3) >> 2;                       // quads of 4 consecutive rows
+    for (long long qd = q0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; qd < ((q1 - q0 + 63) / 64 * 64 + q0);
+         qd += (long long)gridDim.x * blockDim.x) {
+        float v[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+        const long long base = qd * 4;
+        if (qd < q1) {
+            if (base + 3 < n) {
+                const float4 f = *reinterpret_cast<const float4 *>(dist + base);
+                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+            } else {
+                for (int j = 0; j < 4; ++j) if (base + j < n) v[j] = dist[base + j];
+            }
+        }
+        unsigned mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (base + j >= from && base + j < n && v[j] < bound) mine |= 1u << j;
+        const int cnt = __popc(mine);
+        // wave-level slot reservation: exclusive prefix of cnt over the lanes, one atomic per wavefront
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+        const int total = __shfl(incl, 63, 64);
+        if (total == 0) continue;
+        unsigned long long wbase = 0;
+        if (lane == 63) wbase = atomicAdd(out, (unsigned long long)total);
+        wbase = __shfl(wbase, 63, 64);
+        unsigned long long slot = wbase + (unsigned long long)(incl - cnt);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (mine & (1u << j)) {
+                if (slot < cap) out[1 + slot] = ((unsigned long long)(base + j) << 32) | (unsigned long long)__float_as_uint(v[j]);
+                ++slot;
+            }
+    }
+}
+
+extern "C" int vg_resident_distances_fetch(vg_corpus *c, int64_t pos0, int64_t n, float *out_host) {
+    if (!c || !out_host) return vg_fail(VG_ERR_INVALID, "vg_resident_distances_fetch: NULL argument");
+    if (n <= 0) return VG_OK;
+    if (!c->d_dist || pos0 < 0 || pos0 + n > c->dist_valid_rows) return vg_fail(VG_ERR_INVALID, "vg_resident_distances_fetch: no resident distances for rows %lld..%lld", (long long)pos0, (long long)(pos0 + n));
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_dist + pos0, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VG_OK;
+}
+
+extern "C" int vg_resident_distances_below(vg_corpus *c, int64_t pos0, float bound, uint64_t *out_pairs, int64_t cap, int64_t *out_count) {
+    if (!c || !out_pairs || !out_count) return vg_fail(VG_ERR_INVALID, "vg_resident_distances_below: NULL argument");
+    *out_count = 0;
+    const int64_t n = c->dist_valid_rows;
+    if (pos0 >= n) return VG_OK;
+    if (!c->d_dist || pos0 < 0) return vg_fail(VG_ERR_INVALID, "vg_resident_distances_below: no resident distances");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_below) HIP_TRY(hipMalloc(&c->d_below, (size_t)(VG_BELOW_CAP + 1) * sizeof(unsigned long long)));
+    const unsigned dcap = (unsigned)std::min<int64_t>(cap, VG_BELOW_CAP);
+    HIP_TRY(hipMemsetAsync(c->d_below, 0, sizeof(unsigned long long), c->stream));
+    const long long quads = ((n + 3) >> 2) - (pos0 >> 2);
+    const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((quads + 255) / 256, (long long)c->cu_count * 8));
+    hipLaunchKernelGGL(vg_below_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float *)c->d_dist, (long long)pos0, (long long)n, bound,
+                       c->d_below, dcap);
+    HIP_TRY(hipGetLastError());
+    // the count and the first pairs in one copy; the rest only when there are more
+    const size_t first = std::min<size_t>((size_t)dcap, 8191);
+    std::vector<unsigned long long> head(first + 1);
+    HIP_TRY(hipMemcpyAsync(head.data(), c->d_below, (first + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const unsigned long long count = head[0];
+    *out_count = (int64_t)count;
+    const size_t have = (size_t)std::min<unsigned long long>(count, dcap);
+    memcpy(out_pairs, head.data() + 1, std::min(have, first) * sizeof(uint64_t));
+    if (have > first) {
+        HIP_TRY(hipMemcpyAsync(out_pairs + first, c->d_below + 1 + first, (have - first) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return VG_OK;
+}
+
+namespace {
+struct CorpusSrc {
+    vg_corpus *c;
+    std::vector<uint64_t> pairs;
+    int fetch(int64_t g0, int64_t cnt, float *out) { return vg_resident_distances_fetch(c, g0, cnt, out); }
+    int below(int64_t g0, float bound, std::vector<VgRefCand> &out, bool *overflow) {
+        pairs.resize(VG_BELOW_CAP);
+        int64_t count = 0;
+        int rc = vg_resident_distances_below(c, g0, bound, pairs.data(), VG_BELOW_CAP, &count);
+        if (rc != VG_OK) return rc;
+        if (count > VG_BELOW_CAP) { *overflow = true; return VG_OK; }
+        for (int64_t i = 0; i < count; ++i) {
+            const uint32_t bits = (uint32_t)pairs[(size_t)i];
+            float d;
+            memcpy(&d, &bits, 4);
+            out.push_back(VgRefCand{(int64_t)(pairs[(size_t)i] >> 32), d});
+        }
+        return VG_OK;
+    }
+};
+}
+
+extern "C" int vg_scan_topk_reference(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist,
+                                      int *out_count) {
+    if (!c || !query || !out_count) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_reference: NULL argument");
+    *out_count = 0;
+    if (k <= 0 || c->n_rows == 0) return VG_OK;
+    if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_reference: NULL output");
+    int rc = vg_scan_distances_resident(c, metric, query);
+    if (rc != VG_OK) return rc;
+    CorpusSrc src{c, {}};
+    VgRefSlots slots;
+    if ((rc = vg_ref_replay(src, c->n_rows, k, slots)) != VG_OK) return rc;
+    vg_collect_timing(c);
+    const int cnt = slots.finish();
+    for (int i = 0; i < cnt; ++i) {
+        out_dist[i] = slots.dist[(size_t)i];
+        out_rowids[i] = vg_corpus_rowid_at(c, slots.pos[(size_t)i]);
+    }
+    *out_count = cnt;
+    return VG_OK;
+}
+
+// The same replay over distances the caller already holds on the host (e.g. a *_stream result): out_pos are scan
+// positions.  below_cap (> 0) bounds the candidate set the way the device buffer does - what the CPU tests use to drive
+// the "too many candidates" path of the driver without a GPU.
+namespace {
+struct HostSrc {
+    const float *d; int64_t n; int64_t cap;
+    int fetch(int64_t g0, int64_t cnt, float *out) { memcpy(out, d + g0, (size_t)cnt * sizeof(float)); return 0; }
+    int below(int64_t g0, float bound, std::vector<VgRefCand> &out, bool *overflow) {
+        for (int64_t i = n - 1; i >= g0; --i)                 // (any order: the driver sorts by position)
+            if (d[i] < bound) {
+                if ((int64_t)out.size() >= cap) { out.clear(); *overflow = true; return 0; }
+                out.push_back(VgRefCand{i, d[i]});
+            }
+        return 0;
+    }
+};
+}
+extern "C" int vg_reference_topk_replay(const float *dist, int64_t n, int k, int64_t below_cap, int64_t *out_pos, double *out_dist) {
+    if (!dist || n < 0 || k < 0 || !out_pos || !out_dist) { vg_fail(VG_ERR_INVALID, "vg_reference_topk_replay: bad argument"); return -1; }
+    HostSrc src{dist, n, below_cap > 0 ? below_cap : VG_BELOW_CAP};
+    VgRefSlots slots;
+    if (vg_ref_replay(src, n, k, slots) != 0) return -1;
+    const int cnt = slots.finish();
+    for (int i = 0; i < cnt; ++i) { out_pos[i] = slots.pos[(size_t)i]; out_dist[i] = slots.dist[(size_t)i]; }
+    return cnt;
+}
+
+extern "C" int vg_corpus_set_tie_order(vg_corpus *c, int mode) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    if (mode != VG_TIE_POSITION && mode != VG_TIE_REFERENCE) return vg_fail(VG_ERR_INVALID, "unknown tie order %d", mode);
+    c->tie_order = mode;
+    return VG_OK;
+}
+extern "C" int vg_corpus_tie_order(const vg_corpus *c) { return c ? c->tie_order : 0; }

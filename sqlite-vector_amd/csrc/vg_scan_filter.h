@@ -2,9 +2,12 @@
 //
 // The f32 scan (vg_scan.h) is HBM-bound at ~85 % of the peak: the only way to answer faster is to read fewer bytes.
 // This kernel streams the bf16 SHADOW copy of the corpus (half the bytes; built once per appended row for the batch
-// path, vg_batch_h.hip) and computes s~ = sum q~ x~ with v_dot2c_f32_bf16.  Both inputs are rounded to 8 mantissa
-// bits, so |s~ - s| <= c |q||x| with c = 2^-8 (1 + 2^-8) + (D + 64) 2^-21; with the cached ||x|| that gives a LOWER
-// bound of the row's distance.  A row whose bound cannot beat the wavefront's current k-th best is dropped; the others -
+// path, vg_batch_h.hip) and computes s~ = sum q~ x~ with v_dot2c_f32_bf16.  bf16 keeps 8 bits of precision (7 stored):
+// rounding to nearest has unit roundoff u = 2^-8, and BOTH the query and the row are rounded, so every product is off by
+// a factor (1 + dq)(1 + dx), |dq|, |dx| <= u:  |s~ - s| <= (2u + u^2) sum |q_i x_i| <= 2^-7 (1 + 2^-9) |q||x|.  With the
+// f32 summation error that gives |s~ - s| <= c |q||x|, c = 2^-7 (1 + 2^-9) + (D + 64) 2^-21, and with the cached ||x|| a
+// LOWER bound of the row's distance.  (Round 1 used 2^-8 (1 + 2^-8) - one input's worth: rows whose elements all round
+// the same way, e.g. a constant 1 + 2^-8 - 2^-20, could lose an exact duplicate of the query.  tests/test_gpu_filter_bound.py.)  A row whose bound cannot beat the wavefront's current k-th best is dropped; the others -
 // k ln(N/k) per list plus a fraction of a row per query on random data - are re-evaluated by the whole wavefront on the
 // f32 rows with the single-query kernel's accumulator (Accum<T_F32, ..>), and only that distance enters the list.  The
 // answers are the f32 scan's answers bit for bit (the evaluation sums in vg_scan_kernel's order).  Rows the bound cannot judge (norm not finite or out of
@@ -25,11 +28,13 @@ struct FilterScanArgs {
     long long n_rows, stride, bstride;
     int nch, nch_b;            // 16-byte chunks per f32 / bf16 row
     int lpr_log2, k, root, dot, dim;
-    float cerr;                // |s~ - s| <= cerr |q||x|: 2^-8 (1 + 2^-8) for the rounded inputs + (D + 64) 2^-21 for the f32 sums
+    float cerr;                // |s~ - s| <= cerr |q||x|: 2^-7 (1 + 2^-9) for the two rounded inputs + (D + 64) 2^-21 for the f32 sums
     float rel;                 // (D + 64) 2^-22: what the cached norms and the exact f32 evaluation themselves may be off by
     int xlpr_log2, xU;         // the launch shape vg_scan_kernel would use for this corpus: the exact evaluation sums in ITS order
     const uint64_t *init_keys; // the k best of a plain f32 scan over the first rows (64 keys) or nullptr: its k-th distance is
-};                             //   an upper bound of the final k-th best - the lists do not have to warm up from +Inf
+                               //   an upper bound of the final k-th best - the lists do not have to warm up from +Inf
+    unsigned long long *evals; // instrumentation: += exact evaluations of this launch (one atomic per workgroup)
+};
 
 typedef __bf16 vgf_bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -69,6 +74,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
     const bool q_ok = (qq >= 1.0e-30f && qq <= 1.0e30f);                  // else: every row takes the exact path
 
     uint64_t mine = VG_EMPTY_KEY, thr = VG_EMPTY_KEY;
+    unsigned n_exact = 0;                                                 // exact evaluations of this wavefront
     auto gate_of = [&](float t) -> float {                                // the bound must stay below this to go on
         if (a.dot) return t + a.rel * fabsf(t) + 1e-30f;
         const float t2 = a.root ? t * t : t;
@@ -143,6 +149,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
             m &= m - 1;
             const uint32_t row_u = (uint32_t)__builtin_amdgcn_readlane((int)row, src);
             const float de = exact(row_u);
+            ++n_exact;
             const uint64_t key = vg_make_key(de, row_u);
             if (de < INFINITY && key < thr) {                             // NaN / +Inf never enter (sqlite-vector.c:2102)
                 vg_list_insert(mine, thr, key, lane, k);
@@ -155,5 +162,14 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
         b = bn;
     }
     __syncthreads();                                   // everyone is done with the query staging area
+    if (a.evals) {                                     // one counter update per workgroup, nobody waits for it
+        unsigned *blk = reinterpret_cast<unsigned *>(smem + VG_PUBLISH_LDS_BYTES - sizeof(unsigned));   // tail of the selection scratch: free until the publish
+        if (threadIdx.x == 0) *blk = 0u;
+        __syncthreads();
+        if (lane == 0 && n_exact) atomicAdd(blk, n_exact);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(a.evals, (unsigned long long)*blk);
+        __syncthreads();
+    }
     vg_block_publish(smem, mine, k, a.cand + (long long)blockIdx.x * VG_WAVE);
 }

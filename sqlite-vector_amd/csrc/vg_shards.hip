@@ -12,6 +12,7 @@
 // No collective is involved: the devices never talk to each other, the host gathers S x k keys (<= 512 B per
 // shard).  The one-process-per-GPU variant of the same exchange (torch.distributed / RCCL) is shard.py.
 #include "../../include/vectorgpu.h"
+#include "vg_refslots.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -30,6 +31,7 @@ struct vg_shards {
     int vtype = 0, dim = 0, es = 0;
     int64_t n_rows = 0;
     int64_t rowid_base = 1;
+    int tie_order = VG_TIE_POSITION;
     std::vector<vg_corpus *> sh;
 };
 
@@ -182,6 +184,30 @@ extern "C" int64_t vg_shards_rowid_at(const vg_shards *s, int64_t position) {
     return vg_corpus_rowid_at(s->sh[(size_t)shard], local);
 }
 
+extern "C" int vg_shards_rowids(const vg_shards *s, int64_t pos0, int64_t n, int64_t *out) {
+    if (!s || !out || pos0 < 0 || n < 0 || pos0 + n > s->n_rows) return fail(VG_ERR_INVALID, "vg_shards_rowids: bad range");
+    int64_t g = pos0;
+    while (g < pos0 + n) {                                   // block by block: one shard, consecutive local positions
+        int shard;
+        int64_t local;
+        locate(s, g, &shard, &local);
+        const int64_t take = std::min<int64_t>(s->B - g % s->B, pos0 + n - g);
+        const vg_corpus *c = s->sh[(size_t)shard];
+        for (int64_t i = 0; i < take; ++i) out[g - pos0 + i] = vg_corpus_rowid_at(c, local + i);
+        g += take;
+    }
+    return VG_OK;
+}
+
+extern "C" int vg_shards_set_scan_filter(vg_shards *s, int mode) {
+    if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
+    for (auto *p : s->sh) {
+        int rc = vg_corpus_set_scan_filter(p, mode);
+        if (rc != VG_OK) return rc;
+    }
+    return VG_OK;
+}
+
 struct Cand { uint32_t img; int64_t gpos; int shard; uint32_t local; };
 
 static inline bool cand_less(const Cand &a, const Cand &b) { return a.img != b.img ? a.img < b.img : a.gpos < b.gpos; }
@@ -206,6 +232,76 @@ static int merge_lists(const vg_shards *s, const uint64_t *keys, int len, const 
     return (int)take;
 }
 
+// ---- tie_order = reference over several shards: the same replay (vg_refslots.h), its stream assembled in GLOBAL scan
+// order from the shards' resident distances
+extern "C" int vg_shards_set_tie_order(vg_shards *s, int mode) {
+    if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
+    for (auto *p : s->sh) {
+        int rc = vg_corpus_set_tie_order(p, mode);
+        if (rc != VG_OK) return rc;
+    }
+    s->tie_order = mode;
+    return VG_OK;
+}
+
+namespace {
+struct ShardsSrc {
+    vg_shards *s;
+    std::vector<uint64_t> pairs;
+    static const int64_t kCap = 1 << 17;
+    int fetch(int64_t g0, int64_t cnt, float *out) {
+        int64_t g = g0;
+        while (g < g0 + cnt) {
+            int shard;
+            int64_t local;
+            locate(s, g, &shard, &local);
+            const int64_t take = std::min<int64_t>(s->B - g % s->B, g0 + cnt - g);
+            int rc = vg_resident_distances_fetch(s->sh[(size_t)shard], local, take, out + (g - g0));
+            if (rc != VG_OK) return rc;
+            g += take;
+        }
+        return VG_OK;
+    }
+    int below(int64_t g0, float bound, std::vector<VgRefCand> &out, bool *overflow) {
+        pairs.resize((size_t)kCap);
+        const int64_t pb = g0 / s->B, rem = g0 % s->B;
+        for (int i = 0; i < s->S; ++i) {
+            // local rows of shard i in front of global position g0: its whole blocks below block pb, + rem when pb is its own
+            const int64_t full = (pb + s->S - 1 - i) / s->S;
+            const int64_t local_from = full * s->B + ((int)(pb % s->S) == i ? rem : 0);
+            int64_t count = 0;
+            int rc = vg_resident_distances_below(s->sh[(size_t)i], local_from, bound, pairs.data(), kCap, &count);
+            if (rc != VG_OK) return rc;
+            if (count > kCap) { *overflow = true; return VG_OK; }
+            for (int64_t j = 0; j < count; ++j) {
+                const uint32_t bits = (uint32_t)pairs[(size_t)j];
+                float d;
+                memcpy(&d, &bits, 4);
+                out.push_back(VgRefCand{global_of(s, i, (int64_t)(pairs[(size_t)j] >> 32)), d});
+            }
+        }
+        return VG_OK;
+    }
+};
+}
+
+static int shards_scan_topk_reference(vg_shards *s, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist,
+                                      int *out_count) {
+    int rc = VG_OK;
+    for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_distances_resident(s->sh[(size_t)i], metric, query);   // all shards in flight
+    if (rc != VG_OK) return rc;
+    ShardsSrc src{s, {}};
+    VgRefSlots slots;
+    if ((rc = vg_ref_replay(src, s->n_rows, k, slots)) != VG_OK) return rc;
+    const int cnt = slots.finish();
+    for (int i = 0; i < cnt; ++i) {
+        out_dist[i] = slots.dist[(size_t)i];
+        out_rowids[i] = vg_shards_rowid_at(s, slots.pos[(size_t)i]);
+    }
+    *out_count = cnt;
+    return VG_OK;
+}
+
 extern "C" int vg_shards_scan_topk(vg_shards *s, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist,
                                    int *out_count) {
     if (!s || !query || !out_count) return fail(VG_ERR_INVALID, "vg_shards_scan_topk: NULL argument");
@@ -213,6 +309,7 @@ extern "C" int vg_shards_scan_topk(vg_shards *s, int metric, const void *query, 
     if (s->S == 1) return vg_scan_topk(s->sh[0], metric, query, k, out_rowids, out_dist, out_count);
     if (k <= 0 || s->n_rows == 0) return VG_OK;
     if (!out_rowids || !out_dist) return fail(VG_ERR_INVALID, "vg_shards_scan_topk: NULL output");
+    if (s->tie_order == VG_TIE_REFERENCE) return shards_scan_topk_reference(s, metric, query, k, out_rowids, out_dist, out_count);
     if (k <= VG_WAVE_KEYS) {
         // every shard in flight before the first wait: S scans run concurrently, one host thread
         std::vector<uint64_t> keys((size_t)s->S * VG_WAVE_KEYS);
@@ -246,6 +343,15 @@ extern "C" int vg_shards_scan_topk_batch(vg_shards *s, int metric, const void *q
     for (int i = 0; i < nq; ++i) out_counts[i] = 0;
     if (k <= 0 || s->n_rows == 0) return VG_OK;
     if (!out_rowids || !out_dist) return fail(VG_ERR_INVALID, "vg_shards_scan_topk_batch: NULL output");
+    if (s->tie_order == VG_TIE_REFERENCE) {                // the reference's order is defined per scan
+        const size_t qbytes = (size_t)s->dim * s->es;
+        for (int q = 0; q < nq; ++q) {
+            int rc1 = shards_scan_topk_reference(s, metric, (const uint8_t *)queries + (size_t)q * qbytes, k, out_rowids + (size_t)q * k,
+                                                 out_dist + (size_t)q * k, &out_counts[q]);
+            if (rc1 != VG_OK) return rc1;
+        }
+        return VG_OK;
+    }
     const int kk = (int)std::min<int64_t>((int64_t)k, s->n_rows);
     std::vector<uint64_t> keys((size_t)s->S * nq * kk);
     std::vector<int> counts((size_t)s->S * nq, 0);

@@ -13,7 +13,8 @@
  * extension itself links only against libc/libdl and talks to SQLite through sqlite3_api_routines.
  *
  * Deliberate deviations from the reference (documented in DESIGN.md):
- *   - result order among EQUAL distances is scan order (reference: slot-history dependent);
+ *   - result order among EQUAL distances is scan order unless tie_order=reference is set (vector_init option /
+ *     VECTORGPU_TIE_ORDER): then the reference's slot-history dependent result is reproduced rowid for rowid;
  *   - the *_stream modules emit exactly the N rows (the reference emits a spurious leading (0, 0.0) row because
  *     xFilter never advances, sqlite-vector.c:1790-1792);
  *   - the JSON query vector is freed (the reference leaks it, :1771).
@@ -68,6 +69,9 @@ typedef struct {
     int (*quantize_query)(int, const void *, int, float, float, int, void *);
     int (*corpus_minmax)(vg_shards *, float *, float *, int *);
     int (*corpus_quantize_rows)(vg_shards *, float, float, int, int64_t, int64_t, uint8_t *);
+    int (*corpus_set_tie_order)(vg_shards *, int);
+    int (*corpus_set_scan_filter)(vg_shards *, int);
+    int (*corpus_rowids)(const vg_shards *, int64_t, int64_t, int64_t *);
     char load_error[512];
 } gpu_api;
 
@@ -128,6 +132,9 @@ static int gpu_load_locked(void) {
     G.quantize_query = (int (*)(int, const void *, int, float, float, int, void *))gpu_sym("vg_quantize_query");
     G.corpus_minmax = (int (*)(vg_shards *, float *, float *, int *))gpu_sym("vg_shards_minmax");
     G.corpus_quantize_rows = (int (*)(vg_shards *, float, float, int, int64_t, int64_t, uint8_t *))gpu_sym("vg_shards_quantize_rows");
+    G.corpus_set_tie_order = (int (*)(vg_shards *, int))gpu_sym("vg_shards_set_tie_order");
+    G.corpus_set_scan_filter = (int (*)(vg_shards *, int))gpu_sym("vg_shards_set_scan_filter");
+    G.corpus_rowids = (int (*)(const vg_shards *, int64_t, int64_t, int64_t *))gpu_sym("vg_shards_rowids");
     if (G.load_error[0]) { dlclose(G.handle); G.handle = NULL; return 0; }
     G.ready = 1;
     return 1;
@@ -144,7 +151,7 @@ static const char *gpu_error(void) {
  * in the environment; a device may repeat).  Default: device 0.  More than one entry deals the rows block-cyclically
  * over the devices (gpu_shard_rows / VECTORGPU_SHARD_ROWS rows per block, default 65536) and every scan runs on all
  * of them at once (vg_shards). */
-static int corpus_open_spec(const char *spec, int64_t shard_rows, int vtype, int dim, vg_shards **out) {
+static int corpus_open_devices(const char *spec, int64_t shard_rows, int vtype, int dim, vg_shards **out) {
     int devs[64], n = 0;
     const char *e = (spec && *spec) ? spec : getenv("VECTORGPU_DEVICES");
     if (e && *e) {
@@ -184,7 +191,31 @@ typedef struct {
     uint64_t max_memory;
     char gpu_devices[64];       /* additions (ignored by the reference): where the corpus lives */
     int64_t gpu_shard_rows;
+    int tie_order;              /* -1 = default, VG_TIE_POSITION, VG_TIE_REFERENCE (option tie_order=position|reference) */
+    int scan_filter;            /* -1 = default, 0 / 1 (option scan_filter=0|1): f32 scans through the bf16 shadow copy */
 } vec_options;
+
+/* Result order among EQUAL distances.  tie_order=reference replays the reference's slot algorithm: rowids and order
+ * identical to sqlite-vector.c:2022-2069,2102-2106 (one store-mode scan + a host replay of the few rows that can enter;
+ * batch TVFs then run one such scan per query).  tie_order=position (the default) is (distance, scan position): the fused
+ * top-k scan and the matrix-core batch kernels.  Unset: the VECTORGPU_TIE_ORDER environment variable, else position. */
+static int tie_order_for(const vec_options *o) {
+    if (o->tie_order >= 0) return o->tie_order;
+    const char *e = getenv("VECTORGPU_TIE_ORDER");
+    if (e && *e) return !strcasecmp(e, "reference") ? VG_TIE_REFERENCE : VG_TIE_POSITION;
+    return VG_TIE_POSITION;
+}
+
+static int corpus_open_spec(const vec_options *o, int vtype, int dim, vg_shards **out) {
+    int rc = corpus_open_devices(o->gpu_devices, o->gpu_shard_rows, vtype, dim, out);
+    if (rc != VG_OK) return rc;
+    if ((rc = G.corpus_set_tie_order(*out, tie_order_for(o))) != VG_OK ||
+        (rc = G.corpus_set_scan_filter(*out, o->scan_filter)) != VG_OK) {
+        G.corpus_destroy(*out);
+        *out = NULL;
+    }
+    return rc;
+}
 
 typedef struct {
     char *t_name, *c_name, *pk_name;
@@ -193,14 +224,19 @@ typedef struct {
 
     /* HBM-resident state owned by this (table, column) */
     vg_shards *full;            /* raw vectors for vector_full_scan[_stream] */
-    int64_t full_data_version;  /* staleness stamps: PRAGMA data_version + sqlite3_total_changes() */
+    int64_t full_data_version;  /* staleness stamps: PRAGMA data_version + sqlite3_total_changes() + PRAGMA schema_version */
     int64_t full_changes;
+    int64_t full_schema;
+    int64_t full_table_rows;    /* COUNT(*) of the table when it was staged (NULL vectors included) and its largest key: */
+    int64_t full_max_pk;        /*   what the append-only check of stage_full() compares against */
+    int full_have_pk;
     int full_in_txn;            /* staged inside an open transaction: a ROLLBACK leaves both stamps unchanged */
     int full_validated;         /* set when stage_full() (re)validated `full` during the current vector_quantize call */
     vg_shards *quant;           /* quantized vectors for vector_quantize_scan[_stream] */
     int quant_preloaded;        /* explicit vector_quantize_preload() (kept until cleanup / re-quantize) */
     int64_t quant_data_version;
     int64_t quant_changes;
+    int64_t quant_schema;
     int quant_in_txn;
 } table_ctx;
 
@@ -434,6 +470,8 @@ static void options_default(vec_options *o) {
     o->v_distance = VG_DIST_L2;
     o->max_memory = DEFAULT_MAX_MEMORY;
     o->q_type = VG_QUANT_AUTO;
+    o->tie_order = -1;
+    o->scan_filter = -1;
 }
 
 static uint64_t parse_size(const char *s) {
@@ -479,6 +517,12 @@ static int option_apply(sqlite3_context *ctx, vec_options *o, const char *key, i
         snprintf(o->gpu_devices, sizeof(o->gpu_devices), "%s", v);
     } else if (!strncasecmp(key, "gpu_shard_rows", (size_t)klen) && klen == 14) {
         o->gpu_shard_rows = (int64_t)strtoll(v, NULL, 0);
+    } else if (!strncasecmp(key, "tie_order", (size_t)klen) && klen == 9) {
+        if (!strcasecmp(v, "reference")) o->tie_order = VG_TIE_REFERENCE;
+        else if (!strcasecmp(v, "position")) o->tie_order = VG_TIE_POSITION;
+        else { ctx_error(ctx, SQLITE_ERROR, "Invalid tie_order: '%s' (expected 'reference' or 'position').", v); return 0; }
+    } else if (!strncasecmp(key, "scan_filter", (size_t)klen) && klen == 11) {
+        o->scan_filter = strtol(v, NULL, 0) != 0;
     }
     return 1;                                                   /* unknown keys are ignored */
 }
@@ -653,40 +697,21 @@ static void fn_as_u8(sqlite3_context *c, int n, sqlite3_value **v) { vector_as_t
 
 /* ------------------------------------------------------------------------------------------------ staging into HBM */
 
-static void db_stamps(sqlite3 *db, int64_t *data_version, int64_t *changes) {
+static void db_stamps(sqlite3 *db, int64_t *data_version, int64_t *changes, int64_t *schema) {
     *data_version = read_int64(db, "PRAGMA data_version;");      /* bumps when ANOTHER connection commits */
-    *changes = (int64_t)sqlite3_total_changes(db);                /* bumps when THIS connection writes */
+    *changes = (int64_t)sqlite3_total_changes(db);                /* bumps when THIS connection writes rows */
+    *schema = read_int64(db, "PRAGMA schema_version;");          /* bumps on DROP / CREATE / ALTER (no row change is counted
+                                                                     for DROP TABLE t; CREATE TABLE t ...) */
 }
 
-/* Stage (or re-stage, if the database changed since) the raw vectors of (table, column) into HBM in the order the
- * reference scans them: "SELECT pk, col FROM tbl" (sqlite-vector.c:2077), NULL vectors skipped (:2093).
- * Short BLOBs are an error here (the reference would read past them, :2095-2098). */
-static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
-    int64_t dv, ch;
-    db_stamps(db, &dv, &ch);
-    /* rows staged inside an open transaction may be rolled back without either stamp moving (total_changes never
-     * decreases): such a copy is good for one scan only - which is what the reference does for every scan anyway */
-    if (t->full && !t->full_in_txn && t->full_data_version == dv && t->full_changes == ch) return SQLITE_OK;
-    if (!gpu_load()) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
+/* rows of the staging loop shared by the full and the append-only pass */
+static int stage_rows(sqlite3 *db, table_ctx *t, sqlite3_stmt *st, char **err) {
     const int es = elem_size(t->opt.v_type), dim = t->opt.v_dim;
     const int64_t row_bytes = (int64_t)es * dim;
-    if (t->full) G.corpus_clear(t->full);
-    else if (corpus_open_spec(t->opt.gpu_devices, t->opt.gpu_shard_rows, t->opt.v_type, dim, &t->full) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
-
-    {   /* one HBM allocation of the right size instead of geometric regrowth (COUNT(*) is an upper bound: NULLs) */
-        char *cnt = sqlite3_mprintf("SELECT COUNT(*) FROM %q;", t->t_name);
-        if (cnt) { int64_t n = read_int64(db, cnt); sqlite3_free(cnt); if (n > 0) G.corpus_reserve(t->full, n); }
-    }
-    char *sql = sqlite3_mprintf("SELECT %q, %q FROM %q;", t->pk_name, t->c_name, t->t_name);
-    if (!sql) return SQLITE_NOMEM;
-    sqlite3_stmt *st = NULL;
-    int rc = sqlite3_prepare_v2(db, sql, -1, &st, NULL);
-    sqlite3_free(sql);
-    if (rc != SQLITE_OK) { *err = sqlite3_mprintf("%s", sqlite3_errmsg(db)); return rc; }
     uint8_t *stage = (uint8_t *)sqlite3_malloc64((sqlite3_uint64)STAGE_ROWS * (sqlite3_uint64)row_bytes);
     int64_t *ids = (int64_t *)sqlite3_malloc64((sqlite3_uint64)STAGE_ROWS * sizeof(int64_t));
-    if (!stage || !ids) { sqlite3_free(stage); sqlite3_free(ids); sqlite3_finalize(st); return SQLITE_NOMEM; }
-    int fill = 0;
+    if (!stage || !ids) { sqlite3_free(stage); sqlite3_free(ids); return SQLITE_NOMEM; }
+    int fill = 0, rc;
     while (1) {
         rc = sqlite3_step(st);
         if (rc != SQLITE_ROW) break;
@@ -713,22 +738,116 @@ static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
     }
     sqlite3_free(stage);
     sqlite3_free(ids);
+    return rc;
+}
+
+/* COUNT(*) and MAX(pk) of the table as staged: the reference points of the append-only check */
+static void table_watermark(sqlite3 *db, table_ctx *t) {
+    char *sql = sqlite3_mprintf("SELECT COUNT(*), MAX(%q) FROM %q;", t->pk_name, t->t_name);
+    sqlite3_stmt *st = NULL;
+    t->full_table_rows = 0; t->full_max_pk = 0; t->full_have_pk = 0;
+    if (sql && sqlite3_prepare_v2(db, sql, -1, &st, NULL) == SQLITE_OK && sqlite3_step(st) == SQLITE_ROW) {
+        t->full_table_rows = sqlite3_column_int64(st, 0);
+        if (sqlite3_column_type(st, 1) == SQLITE_INTEGER) { t->full_max_pk = sqlite3_column_int64(st, 1); t->full_have_pk = 1; }
+    }
     sqlite3_finalize(st);
-    if (rc == SQLITE_OK) { t->full_data_version = dv; t->full_changes = ch; t->full_in_txn = !sqlite3_get_autocommit(db); }
-    else { G.corpus_destroy(t->full); t->full = NULL; }
+    sqlite3_free(sql);
+}
+
+/* Only this connection wrote since the corpus was staged (data_version and schema_version are unchanged), and
+ * sqlite3_total_changes() grew by d.  If the table now holds exactly d more rows and exactly d rows lie above the key
+ * watermark, then all d changes were INSERTs into THIS table behind every staged row (an UPDATE or DELETE anywhere, or
+ * an INSERT elsewhere, raises the change counter without raising both counts): the staged rows are still the table's
+ * rows in scan order and only the d new ones have to go to the device.  The scan order must be the key order for this
+ * (a covering index on the vector column would make "SELECT pk, col" walk the index instead): checked with the query
+ * plan.  Returns 1 and the statement that yields the new rows, else 0 (caller re-stages everything). */
+static int append_only_since_staged(sqlite3 *db, table_ctx *t, int64_t d, sqlite3_stmt **new_rows) {
+    *new_rows = NULL;
+    if (d <= 0 || !t->full_have_pk || getenv("VECTORGPU_NO_INCREMENTAL")) return 0;
+    int ok = 0;
+    char *sql = sqlite3_mprintf("SELECT (SELECT COUNT(*) FROM %q), (SELECT COUNT(*) FROM %q WHERE %q > %lld);", t->t_name, t->t_name,
+                                t->pk_name, (long long)t->full_max_pk);
+    sqlite3_stmt *st = NULL;
+    if (sql && sqlite3_prepare_v2(db, sql, -1, &st, NULL) == SQLITE_OK && sqlite3_step(st) == SQLITE_ROW)
+        ok = (sqlite3_column_int64(st, 0) - t->full_table_rows == d) && (sqlite3_column_int64(st, 1) == d);
+    sqlite3_finalize(st);
+    sqlite3_free(sql);
+    if (!ok) return 0;
+    sql = sqlite3_mprintf("EXPLAIN QUERY PLAN SELECT %q, %q FROM %q;", t->pk_name, t->c_name, t->t_name);
+    st = NULL;
+    if (sql && sqlite3_prepare_v2(db, sql, -1, &st, NULL) == SQLITE_OK) {
+        while (sqlite3_step(st) == SQLITE_ROW) {
+            const char *detail = (const char *)sqlite3_column_text(st, 3);
+            if (detail && strstr(detail, "INDEX")) ok = 0;               /* "SCAN t USING COVERING INDEX ..." */
+        }
+    } else ok = 0;
+    sqlite3_finalize(st);
+    sqlite3_free(sql);
+    if (!ok) return 0;
+    sql = sqlite3_mprintf("SELECT %q, %q FROM %q WHERE %q > %lld ORDER BY %q;", t->pk_name, t->c_name, t->t_name, t->pk_name,
+                          (long long)t->full_max_pk, t->pk_name);
+    if (!sql || sqlite3_prepare_v2(db, sql, -1, new_rows, NULL) != SQLITE_OK) { sqlite3_free(sql); *new_rows = NULL; return 0; }
+    sqlite3_free(sql);
+    return 1;
+}
+
+/* Stage (or re-stage, if the database changed since) the raw vectors of (table, column) into HBM in the order the
+ * reference scans them: "SELECT pk, col FROM tbl" (sqlite-vector.c:2077), NULL vectors skipped (:2093).
+ * Short BLOBs are an error here (the reference would read past them, :2095-2098). */
+static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
+    int64_t dv, ch, sv;
+    db_stamps(db, &dv, &ch, &sv);
+    /* rows staged inside an open transaction may be rolled back without either stamp moving (total_changes never
+     * decreases): such a copy is good for one scan only - which is what the reference does for every scan anyway */
+    if (t->full && !t->full_in_txn && t->full_data_version == dv && t->full_changes == ch && t->full_schema == sv) return SQLITE_OK;
+    if (!gpu_load()) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
+    const int dim = t->opt.v_dim;
+    sqlite3_stmt *st = NULL;
+    int rc;
+    if (t->full && !t->full_in_txn && t->full_data_version == dv && t->full_schema == sv &&
+        append_only_since_staged(db, t, ch - t->full_changes, &st)) {
+        /* row-granular freshness: the new rows are appended behind the staged ones (the device extends its cached
+         * per-row data - norms, shadow copies - for the appended rows only) */
+        rc = stage_rows(db, t, st, err);
+        sqlite3_finalize(st);
+        if (rc == SQLITE_OK) {
+            t->full_changes = ch;
+            t->full_in_txn = !sqlite3_get_autocommit(db);
+            table_watermark(db, t);
+        } else { G.corpus_destroy(t->full); t->full = NULL; }
+        return rc;
+    }
+    if (t->full) G.corpus_clear(t->full);
+    else if (corpus_open_spec(&t->opt, t->opt.v_type, dim, &t->full) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
+
+    {   /* one HBM allocation of the right size instead of geometric regrowth (COUNT(*) is an upper bound: NULLs) */
+        char *cnt = sqlite3_mprintf("SELECT COUNT(*) FROM %q;", t->t_name);
+        if (cnt) { int64_t n = read_int64(db, cnt); sqlite3_free(cnt); if (n > 0) G.corpus_reserve(t->full, n); }
+    }
+    char *sql = sqlite3_mprintf("SELECT %q, %q FROM %q;", t->pk_name, t->c_name, t->t_name);
+    if (!sql) return SQLITE_NOMEM;
+    rc = sqlite3_prepare_v2(db, sql, -1, &st, NULL);
+    sqlite3_free(sql);
+    if (rc != SQLITE_OK) { *err = sqlite3_mprintf("%s", sqlite3_errmsg(db)); return rc; }
+    rc = stage_rows(db, t, st, err);
+    sqlite3_finalize(st);
+    if (rc == SQLITE_OK) {
+        t->full_data_version = dv; t->full_changes = ch; t->full_schema = sv; t->full_in_txn = !sqlite3_get_autocommit(db);
+        table_watermark(db, t);
+    } else { G.corpus_destroy(t->full); t->full = NULL; }
     return rc;
 }
 
 /* Stage the persisted quantized records (vector0_<tbl>_<col>.data = counter x [int64 LE rowid | dim bytes],
  * sqlite-vector.c:1296-1309) into HBM; this is what vector_quantize_preload does with a malloc'd buffer (:1338-1404). */
 static int stage_quant(sqlite3 *db, table_ctx *t, int force, char **err) {
-    int64_t dv, ch;
-    db_stamps(db, &dv, &ch);
-    if (!force && t->quant && !t->quant_in_txn && t->quant_data_version == dv && t->quant_changes == ch) return SQLITE_OK;
+    int64_t dv, ch, sv;
+    db_stamps(db, &dv, &ch, &sv);
+    if (!force && t->quant && !t->quant_in_txn && t->quant_data_version == dv && t->quant_changes == ch && t->quant_schema == sv) return SQLITE_OK;
     if (!gpu_load()) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
     const int vt = (t->opt.q_type == VG_QUANT_U8) ? VG_TYPE_U8 : VG_TYPE_I8;
     if (t->quant) { G.corpus_destroy(t->quant); t->quant = NULL; }
-    if (corpus_open_spec(t->opt.gpu_devices, t->opt.gpu_shard_rows, vt, t->opt.v_dim, &t->quant) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
+    if (corpus_open_spec(&t->opt, vt, t->opt.v_dim, &t->quant) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); return SQLITE_ERROR; }
     char sql[SQL_BUF];
     sqlite3_snprintf(sizeof(sql), sql, "SELECT counter, data FROM vector0_%q_%q;", t->t_name, t->c_name);
     sqlite3_stmt *st = NULL;
@@ -745,7 +864,7 @@ static int stage_quant(sqlite3 *db, table_ctx *t, int force, char **err) {
     }
     sqlite3_finalize(st);
     if (rc == SQLITE_DONE) rc = SQLITE_OK;
-    if (rc == SQLITE_OK) { t->quant_data_version = dv; t->quant_changes = ch; t->quant_in_txn = !sqlite3_get_autocommit(db); }
+    if (rc == SQLITE_OK) { t->quant_data_version = dv; t->quant_changes = ch; t->quant_schema = sv; t->quant_in_txn = !sqlite3_get_autocommit(db); }
     else { G.corpus_destroy(t->quant); t->quant = NULL; }
     return rc;
 }
@@ -774,6 +893,17 @@ static void fn_vector_init(sqlite3_context *ctx, int argc, sqlite3_value **argv)
         if (o.v_dim != t->opt.v_dim) { ctx_error(ctx, SQLITE_ERROR, "Inconsistent vector dimension for '%s.%s': existing=%d, provided=%d.", tbl, col, t->opt.v_dim, o.v_dim); return; }
         if (o.v_type != t->opt.v_type) { ctx_error(ctx, SQLITE_ERROR, "Inconsistent vector type for '%s.%s': existing=%s, provided=%s.", tbl, col, type_name(t->opt.v_type), type_name(o.v_type)); return; }
         if (o.v_normalized != t->opt.v_normalized) { ctx_error(ctx, SQLITE_ERROR, "Inconsistent normalization flag for '%s.%s': existing=%s, provided=%s.", tbl, col, t->opt.v_normalized ? "true" : "false", o.v_normalized ? "true" : "false"); return; }
+        /* the GPU knobs (ignored by the reference) may be changed by calling vector_init again: they apply at once */
+        if (o.tie_order >= 0) t->opt.tie_order = o.tie_order;
+        if (o.scan_filter >= 0) t->opt.scan_filter = o.scan_filter;
+        if ((o.tie_order >= 0 || o.scan_filter >= 0) && G.ready) {
+            vg_shards *hs[2] = {t->full, t->quant};
+            for (int i = 0; i < 2; ++i) {
+                if (!hs[i]) continue;
+                G.corpus_set_tie_order(hs[i], tie_order_for(&t->opt));
+                G.corpus_set_scan_filter(hs[i], t->opt.scan_filter);
+            }
+        }
         return;
     }
     if (vc->count >= MAX_TABLES) { ctx_error(ctx, SQLITE_ERROR, "Cannot add table: maximum number of allowed tables reached (%d).", MAX_TABLES); return; }
@@ -1014,7 +1144,7 @@ static void quantize_common(sqlite3_context *ctx, const char *tbl, const char *c
     int was_preloaded = t->quant_preloaded;
     if (t->quant) { G.corpus_destroy(t->quant); t->quant = NULL; }   /* HBM copy is stale now */
     if (t->full && stamps_were_fresh) {       /* only our own shadow-table writes happened, and they are committed */
-        db_stamps(db, &t->full_data_version, &t->full_changes);
+        db_stamps(db, &t->full_data_version, &t->full_changes, &t->full_schema);
         t->full_in_txn = 0;
     }
     sqlite3_result_int64(ctx, (sqlite3_int64)counter);
@@ -1104,7 +1234,7 @@ typedef struct {
     int *query_no;                     /* batch TVFs: which query of the batch each output row answers */
     /* streaming: all N distances computed by ONE kernel launch, paged out row by row */
     float *all_dist;
-    vg_shards *stream_corpus;
+    int64_t *all_rowids;               /* the cursor's own snapshot: the corpus may be re-staged / destroyed while it is stepped */
     int64_t stream_pos, stream_n;
 } scan_cursor;
 
@@ -1162,6 +1292,7 @@ static int tvf_close(sqlite3_vtab_cursor *cur) {
     sqlite3_free(c->rowids);
     sqlite3_free(c->distance);
     sqlite3_free(c->all_dist);
+    sqlite3_free(c->all_rowids);
     sqlite3_free(c->query_no);
     sqlite3_free(c);
     return SQLITE_OK;
@@ -1245,13 +1376,17 @@ static int filter_common(sqlite3_vtab_cursor *cur, int argc, sqlite3_value **arg
     if (streaming) {
         int64_t n = G.corpus_rows(corpus);
         sqlite3_free(c->all_dist);
+        sqlite3_free(c->all_rowids);
         c->all_dist = (float *)sqlite3_malloc64((sqlite3_uint64)(n > 0 ? n : 1) * sizeof(float));
-        if (!c->all_dist) { rc = SQLITE_NOMEM; goto out; }
-        if (n > 0 && G.scan_distances(corpus, t->opt.v_distance, scan_query, c->all_dist) != VG_OK) {
+        c->all_rowids = (int64_t *)sqlite3_malloc64((sqlite3_uint64)(n > 0 ? n : 1) * sizeof(int64_t));
+        if (!c->all_dist || !c->all_rowids) { rc = SQLITE_NOMEM; goto out; }
+        /* distances AND rowids are copied into the cursor here (the reference's stream cursor reads its own statement,
+         * sqlite-vector.c:2277-2313): later re-staging / vector_quantize / cleanup on the table cannot touch them */
+        if (n > 0 && (G.scan_distances(corpus, t->opt.v_distance, scan_query, c->all_dist) != VG_OK ||
+                      G.corpus_rowids(corpus, 0, n, c->all_rowids) != VG_OK)) {
             rc = vtab_error(&vt->base, "%s: %s", fname, gpu_error());
             goto out;
         }
-        c->stream_corpus = corpus;
         c->stream_n = n;
         c->stream_pos = 0;
     } else {
@@ -1464,7 +1599,7 @@ static int tvf_eof(sqlite3_vtab_cursor *cur) {
 }
 
 static sqlite3_int64 cursor_rowid(scan_cursor *c) {
-    return c->streaming ? (sqlite3_int64)G.corpus_rowid_at(c->stream_corpus, c->stream_pos) : (sqlite3_int64)c->rowids[c->row_index];
+    return c->streaming ? (sqlite3_int64)c->all_rowids[c->stream_pos] : (sqlite3_int64)c->rowids[c->row_index];
 }
 
 static int tvf_column(sqlite3_vtab_cursor *cur, sqlite3_context *ctx, int col) {

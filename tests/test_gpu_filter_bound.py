@@ -1,0 +1,242 @@
+"""Adversarial inputs for the bf16 shadow-copy filter (vg_scan_filter.h, vg_batch_h.hip with an f32 corpus).
+
+The filter's "lower bound" of a row's distance rests on |s~ - s| <= c |q||x| for the dot product s~ of the bf16-ROUNDED
+query and row.  Round 1 shipped c = 2^-8 (1 + 2^-8) - one input's rounding; both are rounded, the true constant is
+2^-7 (1 + 2^-9).  Gaussian test data never noticed (the rounding errors cancel like sqrt(D)); rows whose elements all
+round the SAME way do: an exact duplicate of the query (true distance 0) was dropped.  Every case here
+
+  * is checked by a plain-numpy restatement of the kernel's bound formula to be a counter-example for the old constant
+    (so the file documents what was wrong) and to be admitted by the current one,
+  * must return the plain f32 scan's rowids and distance bits (filter off) AND match the oracle.
+
+The reference behaviour matched is distance-avx2.c:67-100,128-151 + the strict '<' slot insertion sqlite-vector.c:2102-2106.
+"""
+import numpy as np
+import pytest
+
+import datagen as dg
+from test_gpu_scan import pkg, _check_float_distances  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+OLD_C = 2.0 ** -8 * (1 + 2.0 ** -8)       # round 1 (unsound)
+NEW_C = 2.0 ** -7 + 2.0 ** -16            # (1 + u)^2 - 1, u = 2^-8
+DOWN = np.float32(1 + 2.0 ** -8 - 2.0 ** -20)    # just below a bf16 midpoint: rounds DOWN to 1.0
+UP = np.float32(1 + 2.0 ** -8 + 2.0 ** -20)      # just above it: rounds UP to 1 + 2^-7
+
+
+def bf16_round(x):
+    return dg.bf16_bits_to_f32(dg.f32_to_bf16_bits(x))
+
+
+def kernel_lower_bound(q, x, c_base, metric):
+    """vg_scan_filter.h's bound, restated in f64 (its own f32 rounding is covered by the (D + 64) 2^-21 / 2^-22 slacks)"""
+    D = q.size
+    cerr = c_base + (D + 64) * 2.0 ** -21
+    rel = (D + 64) * 2.0 ** -22
+    st = float((bf16_round(q).astype(np.float64) * bf16_round(x).astype(np.float64)).sum())
+    qq = float((q.astype(np.float64) ** 2).sum())
+    nn = float((x.astype(np.float64) ** 2).sum())
+    E = cerr * np.sqrt(qq) * np.sqrt(nn)
+    if metric == dg.DOT:
+        return -(st + E) - rel * np.sqrt(qq * nn)
+    return qq + nn - 2.0 * (st + E) - rel * (qq + nn)            # squared distance
+
+
+def true_distance(q, x, metric):
+    q64, x64 = q.astype(np.float64), x.astype(np.float64)
+    if metric == dg.DOT:
+        return -float((q64 * x64).sum())
+    return float(((q64 - x64) ** 2).sum())                        # squared
+
+
+def adversarial_case(dim, metric, n_comp):
+    """(query, target row, competitor rows): the target is the true best row, the competitors are bf16-EXACT rows (their
+    bound is tight) slightly worse than the target - with the old constant the target's bound lands above them."""
+    if metric == dg.DOT:
+        q = np.full(dim, -UP, np.float32)                         # q~ x~ = -(1 + 2^-7)^2: more negative than q x
+        target = np.full(dim, UP, np.float32)
+        comps = []
+        for j in range(n_comp):
+            c = np.ones(dim, np.float32)
+            c[:dim // 2 + 1 + (j % 3)] = np.float32(1 + 2.0 ** -7)
+            comps.append(np.roll(c, j))
+    else:
+        q = np.full(dim, DOWN, np.float32)
+        target = q.copy()                                         # distance exactly 0
+        comps = []
+        for j in range(n_comp):
+            c = np.ones(dim, np.float32)
+            c[j % dim] = np.float32(1 + 2.0 ** -7) if (j % 4 == 3) else np.float32(1.0)
+            comps.append(c)
+    return q, target, np.stack(comps)
+
+
+def check_case_is_adversarial(q, target, comps, metric, k):
+    d_t = true_distance(q, target, metric)
+    d_c = np.sort([true_distance(q, c, metric) for c in comps])
+    assert d_t < d_c[0], "the target must be the true best row"
+    thr = d_c[k - 1]                                              # the list's k-th best once k competitors are in
+    assert kernel_lower_bound(q, target, OLD_C, metric) > thr, "not a counter-example for the round-1 constant"
+    assert kernel_lower_bound(q, target, NEW_C, metric) <= d_t, "the corrected bound must stay below the true distance"
+
+
+def filler(n, dim, seed):
+    """far-away rows (never candidates) so that the corpus has every launch shape's ragged tail"""
+    return (dg.corpus(dg.F32, n, dim, seed) * np.float32(3.0) + np.float32(8.0)).astype(np.float32)
+
+
+@pytest.mark.parametrize("dim", (33, 384, 768))
+@pytest.mark.parametrize("metric", (dg.L2, dg.SQUARED_L2, dg.DOT))
+def test_filter_keeps_the_exact_duplicate_when_every_element_rounds_the_same_way(pkg, orc, dim, metric, monkeypatch):
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    k = 20
+    q, target, comps = adversarial_case(dim, metric, 3 * k)
+    check_case_is_adversarial(q, target, comps, metric, k)
+    n = 30_011
+    rows = filler(n, dim, 4100 + dim)
+    if metric == dg.DOT:
+        rows = np.abs(rows)                                       # q < 0: large positive rows have large positive (far) distances
+    pos_comp = np.arange(100, 100 + len(comps)) * 37 % n          # competitors first in scan order ...
+    rows[pos_comp] = comps
+    pos_t = n - 77                                                # ... the target late: the lists are warm when it arrives
+    rows[pos_t] = target
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    for kk in (1, k, 64):
+        c.set_scan_filter(1)
+        assert c.kernel_name(metric).startswith("scan_filter_f32")
+        ids1, d1 = c.scan_topk(metric, q, kk)
+        c.set_scan_filter(0)
+        assert not c.kernel_name(metric).startswith("scan_filter")
+        ids0, d0 = c.scan_topk(metric, q, kk)
+        assert ids0[0] == pos_t + 1
+        assert ids1.tolist() == ids0.tolist(), (dim, metric, kk)
+        assert dg.same_float_bits(d1, d0), (dim, metric, kk)
+        if metric != dg.DOT:
+            assert d1[0] == 0.0
+        want = orc.scan_distances(orc.AVX2, metric, dg.F32, q, rows)
+        _check_float_distances(d1.astype(np.float32), want[ids1 - 1], dg.F32, metric, q, rows[ids1 - 1])
+        oids, _, _ = orc.topk_ordered(want, None, 1)
+        assert oids[0] == pos_t + 1
+    c.set_scan_filter(-1)
+    c.close()
+
+
+@pytest.mark.parametrize("dim,metric", ((33, dg.L2), (64, dg.DOT), (96, dg.SQUARED_L2)))
+def test_filter_prepass_branch_on_clustered_unit_norm_rows(pkg, orc, dim, metric, monkeypatch):
+    """n >= 2^20 rows: the filter scan starts from the threshold of its plain-f32 pre-pass (vg_api.hip).  Unit-norm rows
+    clustered around a few centres (|q||x| slack large against the distance gaps), the query equal to a late row, plus the
+    same-way-rounding block from above scaled to unit norm."""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    n = (1 << 20) + 4099
+    rng = np.random.default_rng(5200 + dim)
+    centres = rng.standard_normal((7, dim)).astype(np.float32)
+    rows = centres[rng.integers(0, 7, n)] + np.float32(0.05) * rng.standard_normal((n, dim), dtype=np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True).astype(np.float32)
+    k = 20
+    q, target, comps = adversarial_case(dim, metric, 2 * k)
+    check_case_is_adversarial(q, target, comps, metric, k)
+    # far from the clusters?  not needed: the assertions below compare with the plain scan, whatever the neighbours are
+    rows[5000:5000 + len(comps)] = comps                          # inside the pre-pass prefix (first max(65536, n/64) rows)
+    pos_t = n - 1234
+    rows[pos_t] = target
+    twin = n - 99
+    queries = [q, rows[twin].copy(), rows[70000].copy(), centres[3] / np.linalg.norm(centres[3])]
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    for qi, qq in enumerate(queries):
+        qq = np.ascontiguousarray(qq, dtype=np.float32)
+        for kk in (1, k):
+            c.set_scan_filter(1)
+            ids1, d1 = c.scan_topk(metric, qq, kk)
+            c.set_scan_filter(0)
+            ids0, d0 = c.scan_topk(metric, qq, kk)
+            assert ids1.tolist() == ids0.tolist(), (dim, metric, qi, kk)
+            assert dg.same_float_bits(d1, d0), (dim, metric, qi, kk)
+        if qi == 0 and metric != dg.DOT:                          # (dot: unit-norm rows with a negative element sum rank ahead)
+            assert ids1[0] == pos_t + 1 and d1[0] == 0.0
+        want = orc.scan_distances(orc.AVX2, metric, dg.F32, qq, rows)
+        _check_float_distances(d1.astype(np.float32), want[ids1 - 1], dg.F32, metric, qq, rows[ids1 - 1])
+    c.set_scan_filter(1)
+    c.scan_topk(metric, queries[2], k)
+    evals = c.filter_exact_evals()                                # instrumentation: the counter moves and is bounded by N
+    assert 0 < evals <= n
+    c.close()
+
+
+@pytest.mark.parametrize("dim,force", ((768, "0"), (384, "1")))
+@pytest.mark.parametrize("metric", (dg.L2, dg.DOT))
+def test_batch_bf16_filter_keeps_the_exact_duplicate(pkg, orc, dim, force, metric, monkeypatch):
+    """the same rows through vg_scan_topk_batch: f32 rows of 513 .. 1024 floats always go through the bf16-filter kernel,
+    shorter rows with VG_F32_FILTER=1 (vg_batch_h.hip, type_code 2 shares the constant)."""
+    monkeypatch.setenv("VG_F32_FILTER", force)
+    k = 20
+    q, target, comps = adversarial_case(dim, metric, 3 * k)
+    check_case_is_adversarial(q, target, comps, metric, k)
+    n = 9_001
+    rows = filler(n, dim, 4300 + dim)
+    if metric == dg.DOT:
+        rows = np.abs(rows)
+    rows[40:40 + len(comps)] = comps
+    pos_t = n - 500
+    rows[pos_t] = target
+    qs = dg.corpus(dg.F32, 37, dim, 4400 + dim)
+    qs[0] = q
+    qs[20] = q
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    monkeypatch.setenv("VG_BATCH_MFMA", "1")
+    ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+    c.set_scan_filter(0)
+    for i in (0, 20):
+        assert ids[i][0] == pos_t + 1, (dim, metric, i, ids[i][:4])
+        ids0, d0 = c.scan_topk(metric, qs[i], k)
+        assert ids0[0] == pos_t + 1
+        if metric != dg.DOT:
+            assert dist[i][0] == 0.0
+        assert cnt[i] == len(d0) and np.allclose(dist[i][:cnt[i]], d0, rtol=1e-5, atol=1e-6)   # (the competitors tie: compare distances)
+    c.close()
+
+
+def _coherent_fuzz_case(rng, dim, n):
+    """rows and a query whose bf16 rounding errors all push the dot product the same way: every element is a signed power
+    of two times DOWN (rounds toward zero) with the query's sign pattern, so every product shrinks under rounding"""
+    sign = rng.choice(np.array([-1.0, 1.0], np.float32), dim)
+    e = rng.integers(-2, 3, dim)
+    u = (sign * np.exp2(e)).astype(np.float32)                    # bf16-exact direction
+    q = (u * DOWN).astype(np.float32)
+    rows = dg.corpus(dg.F32, n, dim, int(rng.integers(1 << 30))) * np.float32(0.5)      # zero-mean filler: far for L2, ~orthogonal for dot
+    m = n // 3
+    base = np.where(rng.random((m, 1)) < 0.5, np.float32(1.0), DOWN).astype(np.float32)      # bf16-exact rows and rounders
+    near = (u[None, :] * base).astype(np.float32)
+    nflip = rng.integers(0, 6, m)
+    for j in range(m):                                            # a few coordinates moved by one bf16 step
+        idx = rng.integers(0, dim, nflip[j])
+        near[j, idx] = u[idx] * rng.choice(np.array([1.0, 1 + 2.0 ** -7, 1 - 2.0 ** -8, DOWN, UP], np.float32), nflip[j])
+    pos = rng.permutation(n)[:m]
+    rows[pos] = near
+    rows[int(rng.integers(0, n))] = q
+    return q, rows
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_filter_fuzz_sign_coherent_rounding(pkg, chunk, monkeypatch):
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    rng = np.random.default_rng(7700 + chunk)
+    for _ in range(6):
+        dim = int(rng.choice([rng.integers(2, 40), rng.integers(40, 400), rng.integers(400, 1100)]))
+        n = int(rng.integers(600, 30000))
+        q, rows = _coherent_fuzz_case(rng, dim, n)
+        c = pkg.Corpus(pkg.F32, dim)
+        c.append(rows)
+        for metric in (dg.L2, dg.SQUARED_L2, dg.DOT):
+            qq = q
+            for k in (1, 20, 64):
+                c.set_scan_filter(1)
+                ids1, d1 = c.scan_topk(metric, qq, k)
+                c.set_scan_filter(0)
+                ids0, d0 = c.scan_topk(metric, qq, k)
+                assert ids1.tolist() == ids0.tolist(), (dim, n, metric, k)
+                assert dg.same_float_bits(d1, d0), (dim, n, metric, k)
+        c.close()
