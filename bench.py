@@ -136,23 +136,35 @@ def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows, seconds=10.0, all_co
     # its OWN >= 64k rows (~9 ms of kernel work per call: the Python dispatch of a call is noise next to it) out of a
     # sample made 4x larger by tiling, so the threads do not share cache lines; `cores` = the threads actually used.
     try:
-        from concurrent.futures import ThreadPoolExecutor
+        import threading
         per_thread = 65536
         big = np.tile(rows, (4, 1)) if sample_rows * 4 * dim * rows.itemsize <= (8 << 30) else rows
         nthreads = max(1, min(os.cpu_count() or 1, big.shape[0] // per_thread))
         views = [big[i * per_thread:(i + 1) * per_thread] for i in range(nthreads)]
-        with ThreadPoolExecutor(max_workers=nthreads) as ex:
-            list(ex.map(work, views))                                        # warm
-            reps2, t1 = 0, time.perf_counter()
-            while True:
-                list(ex.map(work, views))
-                reps2 += 1
-                el2 = time.perf_counter() - t1
-                if el2 > 4.0 or reps2 >= 400:
-                    break
-        out["all_cores"] = {"value": nthreads * per_thread * reps2 / el2, "unit": "vectors/s", "cores": nthreads,
-                            "note": "%d threads x %d private rows each (ctypes releases the GIL), the per-range top-k lists are not "
-                                    "merged; the host has %d logical cores" % (nthreads, per_thread, os.cpu_count() or 1)}
+        counts = [0] * nthreads
+        go, stop = threading.Event(), threading.Event()
+
+        def worker(i):                                # every thread loops on its own rows: no per-call dispatch from a pool
+            work(views[i])                            # warm
+            go.wait()
+            while not stop.is_set():
+                work(views[i])
+                counts[i] += 1
+
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(nthreads)]
+        for t in ths:
+            t.start()
+        time.sleep(0.5)
+        t1 = time.perf_counter()
+        go.set()
+        time.sleep(4.0)
+        stop.set()
+        for t in ths:
+            t.join()
+        el2 = time.perf_counter() - t1
+        out["all_cores"] = {"value": per_thread * sum(counts) / el2, "unit": "vectors/s", "cores": nthreads,
+                            "note": "%d threads, each looping over its own %d rows (ctypes releases the GIL), the per-range top-k lists "
+                                    "are not merged; the host has %d logical cores" % (nthreads, per_thread, os.cpu_count() or 1)}
     except Exception as e:
         out["all_cores"] = {"value": None, "note": "unavailable: %r" % (e,)}
     return out
@@ -531,19 +543,9 @@ def main():
             }
         except Exception as e:
             out["filter_scan"] = {"error": repr(e)}
-        # ---- configs[4] over the same corpus, configs[2] over its own
+        # ---- configs[2] over its own corpus, then configs[4] over the f32 corpus (the MFMA-bound batch last: the HBM-bound
+        # lines are not timed on a package it has just heated)
         also = {}
-        try:
-            corpus.set_scan_filter(0)
-            v5, t5, d5, m5, desc5 = WORKLOADS["c5"]
-            line = run_batched(args, pkg, torch, corpus, "c5", n_rows, d5, m5, k, desc5)
-            if not args.no_cpu_baseline:
-                line["cpu_baseline"] = batch_cpu_baseline(args, v5, t5, d5, m5, k, seconds=5.0)
-            also["c5"] = line
-        except Exception as e:
-            also["c5"] = {"error": repr(e)}
-        corpus.close()
-        corpus = None
         try:
             v3, t3, d3, m3, desc3 = WORKLOADS["c3"]
             c3 = make_shard(pkg, torch, v3, d3, n_rows, 42, local_rank)
@@ -556,6 +558,15 @@ def main():
             c3.close()
         except Exception as e:
             also["c3"] = {"error": repr(e)}
+        try:
+            corpus.set_scan_filter(0)
+            v5, t5, d5, m5, desc5 = WORKLOADS["c5"]
+            line = run_batched(args, pkg, torch, corpus, "c5", n_rows, d5, m5, k, desc5)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = batch_cpu_baseline(args, v5, t5, d5, m5, k, seconds=5.0)
+            also["c5"] = line
+        except Exception as e:
+            also["c5"] = {"error": repr(e)}
         out["also"] = also
     if rank == 0:
         print(json.dumps(out))

@@ -1,40 +1,55 @@
-// vg_scan_filter.h - single-query scan of an f32 corpus through its bf16 shadow copy (VG_SCAN_FILTER=0 turns it off).
+// vg_scan_filter.h - single-query top-k scans through a cheap LOWER BOUND of every row's distance; only the rows whose
+// bound can beat the wavefront's current k-th best are evaluated exactly (vg_scan_filter_kernel<XT, U, NT>).
 //
-// The f32 scan (vg_scan.h) is HBM-bound at ~85 % of the peak: the only way to answer faster is to read fewer bytes.
-// This kernel streams the bf16 SHADOW copy of the corpus (half the bytes; built once per appended row for the batch
-// path, vg_batch_h.hip) and computes s~ = sum q~ x~ with v_dot2c_f32_bf16.  bf16 keeps 8 bits of precision (7 stored):
-// rounding to nearest has unit roundoff u = 2^-8, and BOTH the query and the row are rounded, so every product is off by
-// a factor (1 + dq)(1 + dx), |dq|, |dx| <= u:  |s~ - s| <= (2u + u^2) sum |q_i x_i| <= 2^-7 (1 + 2^-9) |q||x|.  With the
-// f32 summation error that gives |s~ - s| <= c |q||x|, c = 2^-7 (1 + 2^-9) + (D + 64) 2^-21, and with the cached ||x|| a
-// LOWER bound of the row's distance.  (Round 1 used 2^-8 (1 + 2^-8) - one input's worth: rows whose elements all round
-// the same way, e.g. a constant 1 + 2^-8 - 2^-20, could lose an exact duplicate of the query.  tests/test_gpu_filter_bound.py.)  A row whose bound cannot beat the wavefront's current k-th best is dropped; the others -
-// k ln(N/k) per list plus a fraction of a row per query on random data - are re-evaluated by the whole wavefront on the
-// f32 rows with the single-query kernel's accumulator (Accum<T_F32, ..>), and only that distance enters the list.  The
-// answers are the f32 scan's answers bit for bit (the evaluation sums in vg_scan_kernel's order).  Rows the bound cannot judge (norm not finite or out of
-// [1e-15, 1e15], i.e. Inf / NaN / huge / tiny rows) and queries with such a norm always take the exact path.
+// f32 corpora (XT = T_F32) - fewer BYTES.  The f32 scan (vg_scan.h) is HBM-bound at ~85 % of the peak: the only way to
+// answer faster is to read fewer bytes.  The kernel streams the bf16 SHADOW copy of the corpus (half the bytes; built once
+// per appended row, vg_batch_h.hip) and computes s~ = sum q~ x~ with v_dot2_f32_bf16.  bf16 keeps 8 bits of precision
+// (7 stored): rounding to nearest has unit roundoff u = 2^-8, and BOTH the query and the row are rounded, so every product
+// is off by a factor (1 + dq)(1 + dx), |dq|, |dx| <= u:  |s~ - s| <= (2u + u^2) sum |q_i x_i| <= 2^-7 (1 + 2^-9) |q||x|.
+// With the f32 summation error: |s~ - s| <= c |q||x|, c = 2^-7 (1 + 2^-9) + (D + 64) 2^-21.  (Round 1 used
+// 2^-8 (1 + 2^-8) - one input's worth: rows whose elements all round the same way, e.g. a constant 1 + 2^-8 - 2^-20, could
+// lose an exact duplicate of the query.  tests/test_gpu_filter_bound.py.)
 //
-// Same decomposition as vg_scan_kernel: LPR lanes per row, U chunks (8 bf16 elements each) per lane, double-buffered
-// loads, one sorted list per wavefront, vg_block_publish + vg_merge_kernel.  Metrics: L2, squared L2, dot.
+// f16 / bf16 corpora (XT = T_F16 / T_BF16) - less ARITHMETIC.  Their plain scans follow the reference's f64 accumulation
+// (distance-avx2.c:166-582) and that chain, not HBM, bounds them (5.2-6.4 TB/s).  Here the kernel reads the rows
+// themselves (no shadow copy) and forms s~ in f32 - exact products of two halves, f32 sums: |s~ - s| <= c |q||x| with
+// c = (D + 64) 2^-21 - which is a handful of VALU operations per 16 bytes; the f64 chain runs for the candidates only.
+//
+// With the cached per-row norm (f32 corpora: ||x||, f16 / bf16: (float) sum x^2) the bound of the distance is
+//     L2 (squared)   |q|^2 + |x|^2 - 2 (s~ + c |q||x|)
+//     dot            -(s~ + c |q||x|)
+//     cosine         1 - (s~ + c |q||x|) / (|q||x|)
+// each widened by what the norms / the float epilogue may be off by.  A row whose bound cannot beat the wavefront's
+// current k-th best is dropped; the others - k ln(N/k) per list plus a fraction of a row per query on random data - are
+// re-evaluated by the whole wavefront with the single-query kernel's own accumulator (Accum<XT, ..>) IN ITS summation
+// order (same lanes-per-row x chunks-per-lane shape, same butterfly; f16 / bf16 rows holding Inf / NaN through the same
+// slow path), and only that distance enters the list: the answers are the plain scan's answers bit for bit.  Rows the
+// bound cannot judge (norm not finite or out of range, i.e. Inf / NaN / huge / tiny / zero rows) and queries with such a
+// norm always take the exact path.
+//
+// Same decomposition as vg_scan_kernel: LPR lanes per row, U 16-byte chunks per lane, double-buffered loads, one sorted
+// list per wavefront, vg_block_publish + vg_merge_kernel.
 #pragma once
 
 #include "vg_scan.h"
 
 struct FilterScanArgs {
-    const uint8_t *shadow;     // N x bstride bytes of bf16 (zero padded)
-    const uint8_t *rows;       // N x stride bytes of f32 (the corpus)
-    const uint8_t *query;      // the f32 query, nch * 16 bytes, zero padded (device or pinned host)
-    const float *row_norm;     // ||x|| per row
+    const uint8_t *shadow;     // what the filter streams: N x bstride bytes (f32 corpora: the bf16 shadow copy; f16 / bf16: the rows)
+    const uint8_t *rows;       // N x stride bytes: what the exact evaluation reads (the corpus)
+    const uint8_t *query;      // the query in the corpus' element type, nch * 16 bytes, zero padded (device or pinned host)
+    const float *row_norm;     // per row: ||x|| (f32 corpora) / (float) sum x^2 (f16 / bf16 corpora)
     uint64_t *cand;
     long long n_rows, stride, bstride;
-    int nch, nch_b;            // 16-byte chunks per f32 / bf16 row
-    int lpr_log2, k, root, dot, dim;
-    float cerr;                // |s~ - s| <= cerr |q||x|: 2^-7 (1 + 2^-9) for the two rounded inputs + (D + 64) 2^-21 for the f32 sums
-    float rel;                 // (D + 64) 2^-22: what the cached norms and the exact f32 evaluation themselves may be off by
+    int nch, nch_b;            // 16-byte chunks per corpus row / per streamed row
+    int lpr_log2, k, root, mode, dim;   // mode: VGF_L2 (root: 1 = L2, 0 = squared), VGF_DOT, VGF_COS
+    float cerr;                // |s~ - s| <= cerr |q||x|: (D + 64) 2^-21 for the f32 sums [+ 2^-7 (1 + 2^-9) for two bf16-rounded inputs]
+    float rel;                 // (D + 64) 2^-22: what the cached norms and the exact evaluation themselves may be off by
     int xlpr_log2, xU;         // the launch shape vg_scan_kernel would use for this corpus: the exact evaluation sums in ITS order
-    const uint64_t *init_keys; // the k best of a plain f32 scan over the first rows (64 keys) or nullptr: its k-th distance is
+    const uint64_t *init_keys; // the k best of a plain scan over the first rows (64 keys) or nullptr: its k-th distance is
                                //   an upper bound of the final k-th best - the lists do not have to warm up from +Inf
     unsigned long long *evals; // instrumentation: += exact evaluations of this launch (one atomic per workgroup)
 };
+enum { VGF_L2 = 0, VGF_DOT = 1, VGF_COS = 2 };
 
 typedef __bf16 vgf_bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -42,41 +57,124 @@ __device__ inline uint32_t vgf_pack_bf16(uint32_t lo, uint32_t hi) {           /
     return ((lo + 0x7FFFu + ((lo >> 16) & 1u)) >> 16) | ((hi + 0x7FFFu + ((hi >> 16) & 1u)) & 0xFFFF0000u);
 }
 
-template <int U, bool NT>
+// s += the 8 products of one 16-byte chunk of packed 16-bit elements (f32 sums of exact products)
+template <int FT>
+__device__ inline void vgf_dot_chunk(const uint4 &q, const uint4 &x, float &s0, float &s1) {
+    if constexpr (FT == T_BF16) {
+        s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(vgf_bf16x2, q.x), __builtin_bit_cast(vgf_bf16x2, x.x), s0, false);
+        s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(vgf_bf16x2, q.y), __builtin_bit_cast(vgf_bf16x2, x.y), s1, false);
+        s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(vgf_bf16x2, q.z), __builtin_bit_cast(vgf_bf16x2, x.z), s0, false);
+        s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(vgf_bf16x2, q.w), __builtin_bit_cast(vgf_bf16x2, x.w), s1, false);
+    } else {
+        // f16: v_dot2_f32_f16.  The instruction may treat subnormal halves as zero: the bound carries a term for that (esub).
+        s0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(vg_half2, q.x), __builtin_bit_cast(vg_half2, x.x), s0, false);
+        s1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(vg_half2, q.y), __builtin_bit_cast(vg_half2, x.y), s1, false);
+        s0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(vg_half2, q.z), __builtin_bit_cast(vg_half2, x.z), s0, false);
+        s1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(vg_half2, q.w), __builtin_bit_cast(vg_half2, x.w), s1, false);
+    }
+}
+
+template <int XT, int U, bool NT>
 __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs a) {
+    constexpr bool XF32 = (XT == T_F32);
+    constexpr int FT = XF32 ? T_BF16 : XT;                                // element type the filter multiplies
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & (VG_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     const int lpr_log2 = a.lpr_log2, lpr = 1 << lpr_log2, rpb = VG_WAVE >> lpr_log2;
     const int sub = lane & (lpr - 1), rib = lane >> lpr_log2;
     const int k = a.k;
+    const int mode = a.mode;
 
-    // the f32 query, staged once per workgroup: the exact path reads it, the bf16 chunks are built from it
+    // the query, staged once per workgroup: the exact path reads it, the filter's chunks are built from it
     uint4 *qs = reinterpret_cast<uint4 *>(smem);
     for (int c = threadIdx.x; c < a.nch; c += VG_BLOCK) qs[c] = reinterpret_cast<const uint4 *>(a.query)[c];
     __syncthreads();
     uint4 q[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int cb = sub + u * lpr;                                     // bf16 chunk = f32 chunks 2cb, 2cb+1
-        const uint4 f0 = (2 * cb < a.nch) ? qs[2 * cb] : make_uint4(0u, 0u, 0u, 0u);
-        const uint4 f1 = (2 * cb + 1 < a.nch) ? qs[2 * cb + 1] : make_uint4(0u, 0u, 0u, 0u);
-        q[u] = make_uint4(vgf_pack_bf16(f0.x, f0.y), vgf_pack_bf16(f0.z, f0.w), vgf_pack_bf16(f1.x, f1.y), vgf_pack_bf16(f1.z, f1.w));
+        const int cb = sub + u * lpr;
+        if constexpr (XF32) {                                             // bf16 chunk cb = f32 chunks 2cb, 2cb+1, rounded
+            const uint4 f0 = (2 * cb < a.nch) ? qs[2 * cb] : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 f1 = (2 * cb + 1 < a.nch) ? qs[2 * cb + 1] : make_uint4(0u, 0u, 0u, 0u);
+            q[u] = make_uint4(vgf_pack_bf16(f0.x, f0.y), vgf_pack_bf16(f0.z, f0.w), vgf_pack_bf16(f1.x, f1.y), vgf_pack_bf16(f1.z, f1.w));
+        } else {
+            q[u] = (cb < a.nch) ? qs[cb] : make_uint4(0u, 0u, 0u, 0u);
+        }
     }
-    float qq;                                                             // sum q^2 (f32), every lane
-    {
+    float qq;                                                             // sum q^2 (f32, for the bound only), every lane
+    if constexpr (XF32) {
         Accum<T_F32, A_DOT> t;
         t.init();
         for (int c = lane; c < a.nch; c += VG_WAVE) t.chunk(qs[c], qs[c]);
         qq = vg_group_sum((t.a0 + t.a1) + (t.a2 + t.a3), 6);
+    } else {
+        float t0 = 0.0f, t1 = 0.0f;
+        for (int c = lane; c < a.nch; c += VG_WAVE) { const uint4 v = qs[c]; vgf_dot_chunk<FT>(v, v, t0, t1); }
+        qq = vg_group_sum(t0 + t1, 6);
     }
     const float qn = sqrtf(qq);
     const bool q_ok = (qq >= 1.0e-30f && qq <= 1.0e30f);                  // else: every row takes the exact path
+    // f16 only: v_dot2_f32_f16 may flush subnormal halves (|v| < 2^-14) to zero.  What s~ can lose that way:
+    //   rows' subnormal elements   sum |q_i| 2^-14 <= 2^-14 |q|_1                      (esub_q, the same for every row)
+    //   the query's subnormals     sum 2^-14 |x_i| <= 2^-14 sqrt(D) |x|                 (esub_x * |x|, zero unless the query has any)
+    float esub_q = 0.0f, esub_x = 0.0f;
+    if constexpr (FT == T_F16) {
+        float l1 = 0.0f;
+        uint32_t has_sub = 0;
+        for (int c = lane; c < a.nch; c += VG_WAVE) {
+            const uint4 v = qs[c];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float lo, hi;
+                vg_unpack2<T_F16>(w[j], lo, hi);
+                l1 += fabsf(lo) + fabsf(hi);
+                has_sub |= ((w[j] & 0x7C00u) == 0u && (w[j] & 0x03FFu) != 0u) || ((w[j] & 0x7C000000u) == 0u && (w[j] & 0x03FF0000u) != 0u);
+            }
+        }
+        l1 = vg_group_sum(l1, 6);
+        esub_q = 6.2e-5f * l1 * (1.0f + 1e-4f);
+        if (__ballot(has_sub != 0) != 0) esub_x = 6.2e-5f * sqrtf((float)a.dim + 8.0f);
+    }
+
+    // ---- the exact evaluation's query statistics, in vg_scan_kernel's own shape (2^xlpr_log2 lanes per row, lane `xs` owns
+    // chunks xs + u * xlpr, u < xU): Accum<XT, ..>::query_stat's arithmetic with a run-time chunk count
+    const int xlpr = 1 << a.xlpr_log2, xs = lane & (xlpr - 1);
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    float xq_f32 = 0.0f;                                                  // f32 cosine: sum q^2 over the lane group
+    double xq_f64 = 0.0;                                                  // f16 / bf16 cosine: the same in f64
+    uint32_t xq_special = 0;                                              // f16 / bf16: the query holds Inf / NaN
+    if constexpr (XF32) {
+        if (mode == VGF_COS) {
+            Accum<T_F32, A_DOT> t;
+            t.init();
+            for (int u = 0; u < a.xU; ++u) { const int c = xs + u * xlpr; const uint4 v = (c < a.nch) ? qs[c] : zero4; t.chunk(v, v); }
+            xq_f32 = vg_group_sum((t.a0 + t.a1) + (t.a2 + t.a3), a.xlpr_log2);
+        }
+    } else {
+        uint32_t sp = 0;
+        double t = 0.0;
+        for (int u = 0; u < a.xU; ++u) {
+            const int c = xs + u * xlpr;
+            const uint4 v = (c < a.nch) ? qs[c] : zero4;
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sp |= vg_special_pair<XT>(w[j]);
+                float lo, hi;
+                vg_unpack2<XT>(w[j], lo, hi);
+                t += (double)(lo * lo); t += (double)(hi * hi);
+            }
+        }
+        xq_special = vg_group_or(sp, a.xlpr_log2);
+        if (mode == VGF_COS) xq_f64 = vg_group_sum(t, a.xlpr_log2);
+    }
 
     uint64_t mine = VG_EMPTY_KEY, thr = VG_EMPTY_KEY;
     unsigned n_exact = 0;                                                 // exact evaluations of this wavefront
     auto gate_of = [&](float t) -> float {                                // the bound must stay below this to go on
-        if (a.dot) return t + a.rel * fabsf(t) + 1e-30f;
+        if (mode != VGF_L2) return t + a.rel * fabsf(t) + 1e-30f;
         const float t2 = a.root ? t * t : t;
         return t2 * (1.0f + 2.0f * a.rel) + 1e-30f;
     };
@@ -90,28 +188,38 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
         const float t = (thr == VG_EMPTY_KEY) ? INFINITY : vg_sortable_f32((uint32_t)(thr >> 32));
         thr_gate = fminf(gate_of(t), gate_init);
     };
-    // the exact distance of one row (wave-uniform): the single-query f32 kernel's arithmetic IN ITS ORDER - lane group of
-    // 2^xlpr_log2 lanes, lane `xs` takes chunks xs + u * xlpr (u < xU), same butterfly - so the distance is bit for bit what
-    // vg_scan_kernel computes for the row (every group of the wavefront computes the same value)
-    const int xlpr = 1 << a.xlpr_log2, xs = lane & (xlpr - 1);
-    auto exact = [&](uint32_t row_u) -> float {
-        const uint4 *xp = reinterpret_cast<const uint4 *>(a.rows + (unsigned long long)row_u * (unsigned long long)a.stride);
-        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    // the exact distance of one row (wave-uniform): the single-query kernel's arithmetic IN ITS ORDER, so the distance is bit
+    // for bit what vg_scan_kernel computes for the row (every lane group of the wavefront computes the same value).
+    // (Inlined on purpose: as a real function its registers are added to the kernel's and the streaming loop spills.)
+    auto exact_with = [&](auto acc, uint32_t row_u) -> float {
+        typedef decltype(acc) A;
+        const uint8_t *rp = a.rows + (unsigned long long)row_u * (unsigned long long)a.stride;
+        const uint4 *xp = reinterpret_cast<const uint4 *>(rp);
+        acc.init();
+        for (int u = 0; u < a.xU; ++u) { const int c = xs + u * xlpr; if (c < a.nch) acc.chunk(qs[c], xp[c]); else acc.chunk(zero4, zero4); }
+        typename A::QStat st;
         float d;
-        if (a.dot) {
-            Accum<T_F32, A_DOT> acc;
-            acc.init();
-            for (int u = 0; u < a.xU; ++u) { const int c = xs + u * xlpr; if (c < a.nch) acc.chunk(qs[c], xp[c]); else acc.chunk(zero, zero); }
-            typename Accum<T_F32, A_DOT>::QStat s; s.qq = 0.0f;
-            d = acc.finish(s, a.xlpr_log2, 0);
+        if constexpr (XF32) {
+            st.qq = xq_f32;
+            d = acc.finish(st, a.xlpr_log2, a.root);
         } else {
-            Accum<T_F32, A_L2> acc;
-            acc.init();
-            for (int u = 0; u < a.xU; ++u) { const int c = xs + u * xlpr; if (c < a.nch) acc.chunk(qs[c], xp[c]); else acc.chunk(zero, zero); }
-            typename Accum<T_F32, A_L2>::QStat s; s.qq = 0.0f;
-            d = acc.finish(s, a.xlpr_log2, a.root);
+            st.qq = xq_f64; st.qspecial = xq_special;
+            if (mode == VGF_COS) d = acc.finish_cached_norm(st, a.xlpr_log2, a.row_norm[row_u]);
+            else d = acc.finish(st, a.xlpr_log2, a.root);
+            // rows (or a query) holding Inf / NaN: one lane replays the reference algorithm exactly (vg_half.h)
+            if (acc.special(st, a.xlpr_log2) && lane == 0) {
+                const uint16_t *q16 = reinterpret_cast<const uint16_t *>(qs), *r16 = reinterpret_cast<const uint16_t *>(rp);
+                if (mode == VGF_L2) d = vg_slow_distance<XT, A_L2>(q16, r16, a.dim, a.root);
+                else if (mode == VGF_DOT) d = vg_slow_distance<XT, A_DOT>(q16, r16, a.dim, a.root);
+                else d = vg_slow_distance<XT, A_COS>(q16, r16, a.dim, a.root);
+            }
         }
         return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vg_clamp(d))));
+    };
+    auto exact = [&](uint32_t row_u) -> float {
+        if (mode == VGF_L2) return exact_with(Accum<XT, A_L2>(), row_u);
+        if (mode == VGF_DOT) return exact_with(Accum<XT, A_DOT>(), row_u);
+        return exact_with(Accum<XT, XF32 ? A_COS : A_COSN>(), row_u);
     };
 
     const long long nbatch = (a.n_rows + rpb - 1) / rpb;
@@ -130,18 +238,19 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
         load(nxt, nrm_nxt, bn);
         float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(vgf_bf16x2, q[u].x), __builtin_bit_cast(vgf_bf16x2, cur[u].x), s0, false);
-            s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(vgf_bf16x2, q[u].y), __builtin_bit_cast(vgf_bf16x2, cur[u].y), s1, false);
-            s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(vgf_bf16x2, q[u].z), __builtin_bit_cast(vgf_bf16x2, cur[u].z), s0, false);
-            s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(vgf_bf16x2, q[u].w), __builtin_bit_cast(vgf_bf16x2, cur[u].w), s1, false);
-        }
+        for (int u = 0; u < U; ++u) vgf_dot_chunk<FT>(q[u], cur[u], s0, s1);
         const float st = vg_group_sum(s0 + s1, lpr_log2);
         const long long row = b * rpb + rib;
-        const float nrm = nrm_cur, E = a.cerr * qn * nrm;
-        const bool judged = q_ok && (nrm >= 1.0e-15f && nrm <= 1.0e15f);
+        // cached norm: ||x|| for f32 corpora, sum x^2 for f16 / bf16 corpora
+        const float nn = XF32 ? nrm_cur * nrm_cur : nrm_cur;
+        const float nrm = XF32 ? nrm_cur : sqrtf(nrm_cur);
+        const float E = a.cerr * qn * nrm + esub_q + esub_x * nrm;
+        const bool judged = q_ok && (XF32 ? (nrm >= 1.0e-15f && nrm <= 1.0e15f) : (nn >= 1.0e-30f && nn <= 1.0e30f));
         // lower bound of the distance (squared for L2)
-        const float lb = a.dot ? -(st + E) - a.rel * qn * nrm : (qq + nrm * nrm - 2.0f * (st + E) - a.rel * (qq + nrm * nrm));
+        float lb;
+        if (mode == VGF_L2) lb = qq + nn - 2.0f * (st + E) - a.rel * (qq + nn);
+        else if (mode == VGF_DOT) lb = -(st + E) - a.rel * qn * nrm;
+        else { const float r = (st + E) / (qn * nrm); lb = 1.0f - r - a.rel * fabsf(r) - 4.0e-6f; }   // (norms + the float epilogue)
         const bool cand = (sub == 0) && (row < a.n_rows) && (!judged || lb < thr_gate);
         unsigned long long m = __ballot(cand);
         while (m) {

@@ -349,37 +349,74 @@ def test_batch_multi_query_scan_vs_single_scans(pkg, orc, vt, monkeypatch):
 
 
 @pytest.mark.parametrize("dim", (3, 33, 100, 384, 768, 1024, 1536))
-def test_f32_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, dim, monkeypatch):
-    """f32 L2 / squared-L2 / dot top-k scans read the bf16 shadow copy as a lower-bound filter and re-evaluate the candidates
-    on the f32 rows in the plain kernel's summation order (vg_scan_filter.h): rowids and distance BITS must equal the plain
-    f32 scan's (VG_SCAN_FILTER=0), for ordinary rows, edge rows (NaN / Inf / huge / tiny / zero) and edge queries."""
-    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")         # (by default only corpora >= 3 GB take the filter scan)
+@pytest.mark.parametrize("vt", (dg.F32, dg.F16, dg.BF16))
+def test_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, vt, dim, monkeypatch):
+    """L2 / squared-L2 / dot / cosine top-k scans of f32, f16 and bf16 corpora go through a lower-bound filter (f32: the bf16
+    shadow copy, half the bytes; f16 / bf16: f32 sums instead of the reference's f64 chain) and re-evaluate the candidates
+    with the plain kernel's accumulator in its summation order (vg_scan_filter.h): rowids and distance BITS must equal the
+    plain scan's (filter off), for ordinary rows, edge rows (NaN / Inf / huge / tiny / zero / subnormal) and edge queries."""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")         # (by default only corpora >= 3 GB / 1 GB take the filter scan)
     n = 60_007
-    rows = dg.corpus(dg.F32, n, dim, 9700 + dim)
-    _, edge = dg.edge_rows(dg.F32, dim, 9800 + dim)
+    rows = dg.corpus(vt, n, dim, 9700 + dim)
+    _, edge = dg.edge_rows(vt, dim, 9800 + dim)
     rows[500:500 + len(edge)] = edge
     rows[40000] = rows[17]                                   # an exact duplicate: a tie decided by position
-    rows[30000:30050] *= np.float32(1e-4)
-    c = pkg.Corpus(pkg.F32, dim)
+    small = dg.storage_to_f64(vt, rows[30000:30050]) * 1e-4  # tiny rows (f16: down into the subnormal range)
+    rows[30000:30050] = dg.to_storage(vt, small.astype(np.float32))
+    c = pkg.Corpus(vt, dim)
     c.append(rows)
-    queries = [rows[17].copy()] + dg.edge_queries(dg.F32, dim, 9900 + dim) + [dg.query(dg.F32, dim, 9901 + i) for i in range(4)]
-    for metric in (dg.L2, dg.SQUARED_L2, dg.DOT):
-        monkeypatch.setenv("VG_SCAN_FILTER", "1")
-        assert c.kernel_name(metric).startswith("scan_filter_f32")
-        for q in queries:
+    queries = [rows[17].copy()] + dg.edge_queries(vt, dim, 9900 + dim) + [dg.query(vt, dim, 9901 + i) for i in range(4)]
+    queries.append(rows[30007].copy())                       # a tiny (subnormal) query
+    tag = dg.TYPE_NAMES[vt]
+    for metric in (dg.L2, dg.SQUARED_L2, dg.DOT, dg.COSINE):
+        c.set_scan_filter(1)
+        assert c.kernel_name(metric).startswith("scan_filter_" + tag), c.kernel_name(metric)
+        for qi, q in enumerate(queries):
             for k in (1, 20, 64):
-                monkeypatch.setenv("VG_SCAN_FILTER", "1")
+                c.set_scan_filter(1)
                 ids1, d1 = c.scan_topk(metric, q, k)
-                monkeypatch.setenv("VG_SCAN_FILTER", "0")
+                c.set_scan_filter(0)
                 ids0, d0 = c.scan_topk(metric, q, k)
-                assert ids1.tolist() == ids0.tolist(), (metric, k)
-                assert dg.same_float_bits(d1, d0), (metric, k)
-    monkeypatch.setenv("VG_SCAN_FILTER", "1")
-    more = dg.corpus(dg.F32, 300, dim, 9950)                 # appended rows extend the shadow copy and the norms
-    more[5] = queries[-1]
+                assert ids1.tolist() == ids0.tolist(), (vt, metric, qi, k)
+                assert dg.same_float_bits(d1, d0), (vt, metric, qi, k)
+    c.set_scan_filter(1)
+    more = dg.corpus(vt, 300, dim, 9950)                     # appended rows extend the shadow copy and the norms
+    more[5] = queries[-2]
     c.append(more)
-    ids1, d1 = c.scan_topk(dg.L2, queries[-1], 3)
+    ids1, d1 = c.scan_topk(dg.L2, queries[-2], 3)
     assert ids1[0] == n + 6 and d1[0] == 0.0
+    c.set_scan_filter(-1)
+    c.close()
+
+
+@pytest.mark.parametrize("vt,dim", ((dg.F16, 64), (dg.BF16, 40), (dg.F32, 48)))
+def test_filter_scan_with_its_prepass_on_clustered_rows(pkg, orc, vt, dim, monkeypatch):
+    """n >= 2^20: the filter scan starts from its plain pre-pass' threshold; clustered unit-norm rows + near-duplicates of
+    the query; every metric the filter serves; compared with the plain scan and the oracle"""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    n = (1 << 20) + 777
+    rng = np.random.default_rng(8800 + dim)
+    centres = rng.standard_normal((9, dim)).astype(np.float32)
+    x = centres[rng.integers(0, 9, n)] + np.float32(0.08) * rng.standard_normal((n, dim), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+    rows = dg.to_storage(vt, x)
+    twin = n - 4321
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    for qi, q in enumerate((rows[twin].copy(), rows[100].copy(), dg.to_storage(vt, centres[2] / np.linalg.norm(centres[2])))):
+        for metric in (dg.L2, dg.SQUARED_L2, dg.DOT, dg.COSINE):
+            c.set_scan_filter(1)
+            ids1, d1 = c.scan_topk(metric, q, 20)
+            c.set_scan_filter(0)
+            ids0, d0 = c.scan_topk(metric, q, 20)
+            assert ids1.tolist() == ids0.tolist(), (vt, metric, qi)
+            assert dg.same_float_bits(d1, d0), (vt, metric, qi)
+            want = orc.scan_distances(orc.AVX2, metric, vt, q, rows[ids1 - 1])
+            _check_float_distances(d1.astype(np.float32), want, vt, metric, q, rows[ids1 - 1])
+    c.set_scan_filter(1)
+    c.filter_exact_evals()
+    c.scan_topk(dg.COSINE, rows[100].copy(), 20)
+    assert 0 < c.filter_exact_evals() < n // 4              # the bound is selective on this data
     c.close()
 
 

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--types", type=str, default="1,2,3,4,5")
     ap.add_argument("--bytes", type=float, default=0, help="if set: rows = bytes / row size (same HBM footprint for every dim)")
+    ap.add_argument("--filter", type=int, default=-1, help="vg_corpus_set_scan_filter mode: 0 = plain scans, 1 = filter scans where served, -1 = default")
     args = ap.parse_args()
     import torch
     torch.cuda.init()
@@ -60,17 +61,21 @@ def main():
             else:
                 q = rng.integers(-128, 128, dim).astype(np.int8)
             c.set_profiling(True)
+            c.set_scan_filter(args.filter)
             line = "%-5s dim %4d rows %d :" % (names[vt], dim, n)
             for m in (1, 3, 4, 5):
                 for _ in range(2):
                     c.scan_topk(m, q, 20)
                 c.set_profiling(True)
+                c.filter_exact_evals()
                 for _ in range(args.reps):
                     c.scan_topk(m, q, 20)
-                nl, scan_ms, merge_ms = c.profile_mean_ms()
+                nl, scan_ms, merge_ms, pre_ms = c.profile_mean_ms_ex()
                 gbs = n * dim * es / (scan_ms * 1e-3) / 1e9
-                line += "  %s %.3f ms %5.0f GB/s (merge %.0f us)" % (mnames[m], scan_ms, gbs, merge_ms * 1e3)
-            print(line + "   [" + c.kernel_name(1) + "]", flush=True)
+                line += "  %s %.3f ms %5.0f GB/s" % (mnames[m], scan_ms, gbs)
+                if c.kernel_name(m).startswith("scan_filter"):
+                    line += " (filter: pre-pass %.0f us, %d exact rows/query)" % (pre_ms * 1e3, c.filter_exact_evals() // args.reps)
+            print(line + "   [" + ", ".join(c.kernel_name(m) for m in (1, 3, 4, 5)) + "]", flush=True)
             c.close()
 
 
