@@ -554,6 +554,19 @@ def main():
             line, _ = single_query_line(args, pkg, r3, c3, "c3", v3, d3, m3, k, n_rows, 1, desc3)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(v3, t3, d3, m3, k, args.cpu_sample_rows, seconds=5.0, all_cores=False)
+            # what tie_order=reference costs (the reference's rowids among equal distances, vg_reforder.hip): the same host
+            # entry point (vg_scan_topk: host query in, host rowids out) in both orders, 10 queries each
+            tie = {}
+            for name, mode in (("position", pkg.TIE_POSITION), ("reference", pkg.TIE_REFERENCE)):
+                c3.set_tie_order(mode)
+                c3.scan_topk(m3, q3[0], k)
+                t0 = time.perf_counter()
+                for i in range(10):
+                    c3.scan_topk(m3, q3[1 + i], k)
+                tie["ms_per_query_%s" % name] = (time.perf_counter() - t0) / 10 * 1e3
+            c3.set_tie_order(pkg.TIE_POSITION)
+            tie["what"] = "vg_scan_topk end to end, top-%d; reference = store-mode scan + device compaction of the rows below the bound + host slot replay" % k
+            line["tie_order"] = tie
             also["c3"] = line
             c3.close()
         except Exception as e:

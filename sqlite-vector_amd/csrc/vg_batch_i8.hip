@@ -34,7 +34,9 @@ typedef int vgi_i32x4 __attribute__((ext_vector_type(4)));
 #define VGI_QPW 32
 #define VGI_TILE 32
 #define VGI_MAX_K 32
-#define VGI_BPIPE 4
+#ifndef VGI_BPIPE
+#define VGI_BPIPE 4                     // B-operand register quads in flight (LDS reads issued this many k-steps ahead)
+#endif
 #ifndef VGI_PHASED
 #define VGI_PHASED 0                    // experiment, measured SLOWER (u8 cosine 15.0 vs 9.9 ms): the two wavefronts of a SIMD alternate, 3 tile buffers
 #endif
@@ -44,7 +46,16 @@ typedef int vgi_i32x4 __attribute__((ext_vector_type(4)));
 #ifndef VGI_DEPTH2
 #define VGI_DEPTH2 0                    // experiment, measured NEUTRAL (10.5 / 8.95 / 6.1 vs 9.9 / 9.3 / 5.5 ms): DMA two tiles ahead, counted vmcnt waits
 #endif
-#define VGI_NBUF ((VGI_PHASED || VGI_DEPTH2) ? 3 : 2)
+#ifndef VGI_ASYNC
+#define VGI_ASYNC 0                     // experiment, measured NEUTRAL TO SLOWER (profiles/r2c_int8_batch_async_ring_vs_barrier.txt: u8 cosine 10.10 vs
+                                        // 9.78 ms, dot 9.45 vs 9.24, D = 128 6.69 vs 5.87, D = 1024 12.80 vs 13.07; bit-exact tests pass): a tile ring with
+                                        // per-buffer ready / free counters in LDS instead of one workgroup barrier per tile - the barrier is NOT what a tile
+                                        // waits for
+#endif
+// tile buffers: the barrier schedule double-buffers; the async ring keeps 4 (3 for 1 KiB rows: LDS) and lets a wavefront run
+// up to two (one) tiles ahead of the slowest one; rows beyond 1 KiB (4-wavefront workgroups, 48 / 64 KiB tiles) keep the barrier
+#define VGI_IS_ASYNC(NTB) (VGI_ASYNC && (NTB) <= 32)
+#define VGI_NBUF_OF(NTB) (VGI_IS_ASYNC(NTB) ? ((NTB) <= 24 ? 4 : 3) : ((VGI_PHASED || VGI_DEPTH2) ? 3 : 2))
 
 enum { VGI_DOT = 0, VGI_COS = 1, VGI_L2 = 2 };
 
@@ -96,10 +107,13 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
     // time proportional to the row COUNT, not to the bytes.
     constexpr int TILE_BYTES = NTB * 2 * 512;
     constexpr int L = NTB * 32;                                 // padded row length the matrix core sees
+    constexpr int NBUF = VGI_NBUF_OF(NTB);
+    constexpr bool ASYNC = VGI_IS_ASYNC(NTB);
     uint8_t *tile0 = smem;
-    uint32_t *rstat_lds = reinterpret_cast<uint32_t *>(smem + VGI_NBUF * TILE_BYTES);    // [buffers][sum x: 32 | sum x^2: 32]
-    uint32_t *qstat_lds = rstat_lds + VGI_NBUF * 64;                                     // [waves][32][2]: sum q, sum q^2
+    uint32_t *rstat_lds = reinterpret_cast<uint32_t *>(smem + NBUF * TILE_BYTES);        // [buffers][sum x: 32 | sum x^2: 32]
+    uint32_t *qstat_lds = rstat_lds + NBUF * 64;                                         // [waves][32][2]: sum q, sum q^2
     uint64_t *lists = reinterpret_cast<uint64_t *>(qstat_lds + WAVES * VGI_QPW * 2);  // [4][32][k]
+    uint32_t *ring_ctr = reinterpret_cast<uint32_t *>(lists + (size_t)WAVES * VGI_QPW * a.k);   // async ring: ready[NBUF] | freed[NBUF]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -146,7 +160,8 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
         for (int s = lane; s < VGI_QPW * k; s += 64) wave_lists[s] = VG_EMPTY_KEY;
     }
     // pad columns never touched by the DMA must read as "0" of the original representation
-    for (int s = tid; s < VGI_NBUF * TILE_BYTES / 4; s += THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = IS_U8 ? 0x80808080u : 0u;
+    for (int s = tid; s < NBUF * TILE_BYTES / 4; s += THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = IS_U8 ? 0x80808080u : 0u;
+    if (ASYNC && tid < 2 * NBUF) ring_ctr[tid] = (tid == 0) ? (uint32_t)WAVES : 0u;     // tile 0 is "ready" after the prologue's barrier
     __syncthreads();
 
     // ---- tile streaming by LDS-DMA: piece p = chunk columns 2p and 2p+1 of all 32 rows; wavefront w moves pieces
@@ -347,10 +362,8 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
 #endif
     };
     // the tile boundary: margins (integer for dot / L2, float for cosine), one ballot, the rare inserts
-    auto boundary = [&](long long tile, int cur_buf) __attribute__((always_inline)) {
+    auto boundary_with = [&](long long tile, int sx, uint32_t xx) __attribute__((always_inline)) {
         const long long row_cur = tile * VGI_TILE + x;
-        const int sx = (int)rstat_lds[cur_buf * 64 + x];                  // this tile's row sums (landed with the tile)
-        const uint32_t xx = rstat_lds[cur_buf * 64 + 32 + x];
         const int cx = IS_U8 ? 128 * sx : 0;
         unsigned pend = 0;
         bool any;
@@ -394,6 +407,63 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
         }
     };
 
+    auto boundary = [&](long long tile, int cur_buf) __attribute__((always_inline)) {
+        // this tile's row sums (landed with the tile)
+        boundary_with(tile, (int)rstat_lds[cur_buf * 64 + x], rstat_lds[cur_buf * 64 + 32 + x]);
+    };
+
+    if constexpr (ASYNC) {
+        // ASYNC RING.  Tile t lives in buffer t % NBUF; the k loop of tile t issues this wavefront's DMA pieces of tile t + 2.
+        // No workgroup barrier in the loop: ready[b] counts the wavefronts whose pieces of the tile in buffer b have landed,
+        // freed[b] those that are done reading it (both only ever grow: generation g of a buffer is complete at WAVES * (g + 1)).
+        // A wavefront in its survivor path no longer stops the other seven: they run on until they need a buffer it still
+        // reads - NBUF - 2 tiles later.
+        volatile uint32_t *ready = ring_ctr, *freed = ring_ctr + NBUF;
+        auto wait_ge = [&](volatile uint32_t *p, uint32_t target) __attribute__((always_inline)) {
+            while ((uint32_t)__builtin_amdgcn_readfirstlane((int)*p) < target) __builtin_amdgcn_s_sleep(1);
+        };
+        int n_mine = (stat_mask != 0) ? 2 : 0;                           // DMA instructions this wavefront issues per tile
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) n_mine += (piece_mask[i] != 0) ? 1 : 0;
+        if (tile_first < tile_last) {
+            const long long t1 = min(tile_first + 1, tile_last - 1);
+            const uint32_t goff0 = lane_offset(tile_first), goff1 = lane_offset(t1);
+#pragma unroll
+            for (int pc = 0; pc < NPIECE; ++pc) dma_piece(tile_first, goff0, 0, pc);
+            dma_stats(tile_first, 0);
+#pragma unroll
+            for (int pc = 0; pc < NPIECE; ++pc) dma_piece(t1, goff1, 1, pc);
+            dma_stats(t1, 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                 // tiles 0 and 1 have landed; ready[0] was preset, ready[1] is signalled in iteration 0
+        for (long long tile = tile_first; tile < tile_last; ++tile) {
+            const long long ti = tile - tile_first;
+            const int b = (int)(ti % NBUF), nb = (int)((ti + 2) % NBUF);
+            const uint32_t g = (uint32_t)(ti / NBUF), g2 = (uint32_t)((ti + 2) / NBUF);
+            wait_ge(&ready[b], (uint32_t)WAVES * (g + 1u));              // every wavefront's pieces of this tile are in LDS
+            wait_ge(&freed[nb], (uint32_t)WAVES * g2);                   // nobody still reads the buffer tile t + 2 goes to
+            k_loop(b, min(tile + 2, tile_last - 1), nb);
+            const int sx = (int)rstat_lds[b * 64 + x];
+            const uint32_t xx = rstat_lds[b * 64 + 32 + x];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (the two reads above have returned)
+            if (lane == 0) atomicAdd((uint32_t *)&freed[b], 1u);         // done with buffer b - BEFORE the boundary's slow path
+            // my pieces of tile t + 1 (issued one iteration ago) have landed: everything but this k loop's own DMA issue.
+            // Signalled BEFORE the boundary as well, so that nobody waits for this wavefront's inserts.
+            switch (n_mine) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            }
+            if (lane == 0) atomicAdd((uint32_t *)&ready[(ti + 1) % NBUF], 1u);
+            boundary_with(tile, sx, xx);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
 #if VGI_PHASED
     // PHASED schedule (experiment, slower).  The workgroup's wavefronts form two groups (waves 0-3 / 4-7: one of each per SIMD).  A step is
     // one barrier interval; on even steps group 0 runs the k loop of tile s/2 while group 1 is at the boundary of the
@@ -488,6 +558,7 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
         __syncthreads();
     }
 #endif
+    }   // !ASYNC
 
     for (int s = lane; s < VGI_QPW * 64; s += 64) {
         const int qi = s >> 6, slot = s & 63;
@@ -605,7 +676,7 @@ extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k) {
     if (!NTB || k < 1 || k > VGI_MAX_K) return 0;
     if (VGI_PHASED && NTB > 32) return 0;
     const size_t waves = (size_t)VGI_WAVES_OF(NTB);
-    const size_t b = (size_t)VGI_NBUF * (NTB * 1024 + 256) + waves * VGI_QPW * 2 * 4 + waves * VGI_QPW * k * 8;
+    const size_t b = (size_t)VGI_NBUF_OF(NTB) * (NTB * 1024 + 256) + waves * VGI_QPW * 2 * 4 + waves * VGI_QPW * k * 8 + 64;   // (+ the ring counters)
     return b <= 160 * 1024 ? b : 0;
 }
 

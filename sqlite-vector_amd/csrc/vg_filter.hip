@@ -1,0 +1,178 @@
+// vg_filter.hip - host side of the filter scans (vg_scan_filter.h): which scans they serve, kernel selection, the launch with
+// its plain pre-pass.  A translation unit of its own: the kernels are instantiated per (corpus type, metric mode, chunks per
+// lane, load policy) - ~110 of them - and compile next to vg_api.hip's ~300 scan kernels instead of after them.
+#include "vg_internal.h"
+
+#include "vg_scan.h"
+#include "vg_scan_filter.h"
+
+typedef VgShape Shape;
+
+// ---- f32 through the bf16 shadow copy (vg_scan_filter.h): half the bytes per row, exact answers.
+typedef void (*filter_fn_t)(FilterScanArgs);
+
+// Is the filter scan switched on for this corpus?  vg_corpus_set_scan_filter (the extension's scan_filter= option) wins
+// over the VG_SCAN_FILTER environment switch; default on.
+static bool scan_filter_enabled(const vg_corpus *c) {
+    if (c->filter_disabled) return false;
+    if (c->scan_filter_mode >= 0) return c->scan_filter_mode != 0;
+    return env_int("VG_SCAN_FILTER", 1) != 0;
+}
+// Which scans the filter serves: f32 / f16 / bf16 corpora, L2 / squared L2 / dot / cosine (f16 / bf16 cosine with the cached
+// row norms, A_COSN - what the plain scan uses unless VG_HALF_COSN=0), and L1 on f16 / bf16 corpora.
+// Small corpora keep the plain scan: the filter scan pays a pre-pass launch plus the exact evaluations of the lists'
+// warm-up (measured at f32 D = 384: 3M rows 0.41 vs 0.70 ms, 1M rows - no pre-pass - 0.43 vs 0.26 ms, 10k rows 52 vs 34 us);
+// f32 corpora additionally pay the shadow copy (+50 % HBM): from 3 GB up; f16 / bf16 corpora (no copy): from 1 GB up.
+static bool scan_filter_serves(const vg_corpus *c, int metric) {
+    const bool half = (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16);
+    if (c->vtype != VG_TYPE_F32 && !half) return false;
+    if (metric == VG_DIST_L1 && !half) return false;         // (the f32 L1 scan already streams at the HBM ceiling: nothing to skip)
+    if (metric != VG_DIST_L2 && metric != VG_DIST_SQUARED_L2 && metric != VG_DIST_DOT && metric != VG_DIST_COSINE && metric != VG_DIST_L1) return false;
+    if (half && metric == VG_DIST_COSINE && !env_int("VG_HALF_COSN", 1)) return false;
+    if (!scan_filter_enabled(c)) return false;
+    return c->n_rows * c->stride >= (long long)env_int("VG_SCAN_FILTER_MIN_MB", half ? 1024 : 3072) * (1ll << 20);
+}
+
+template <int XT, int MODE, bool NT>
+static filter_fn_t pick_filter_u(int U) {
+    switch (U) {
+        case 1: return vg_scan_filter_kernel<XT, MODE, 1, NT>;
+        case 2: return vg_scan_filter_kernel<XT, MODE, 2, NT>;
+        case 3: return vg_scan_filter_kernel<XT, MODE, 3, NT>;
+        case 4: return vg_scan_filter_kernel<XT, MODE, 4, NT>;
+        case 6: return vg_scan_filter_kernel<XT, MODE, 6, NT>;
+    }
+    return nullptr;
+}
+template <int XT, bool NT>
+static filter_fn_t pick_filter_mode(int mode, int U) {
+    switch (mode) {
+        case VGF_L2: return pick_filter_u<XT, VGF_L2, NT>(U);
+        case VGF_DOT: return pick_filter_u<XT, VGF_DOT, NT>(U);
+        case VGF_COS: return pick_filter_u<XT, VGF_COS, NT>(U);
+        case VGF_L1:
+            if constexpr (XT != T_F32) return pick_filter_u<XT, VGF_L1, NT>(U);
+            return nullptr;
+    }
+    return nullptr;
+}
+template <bool NT>
+static filter_fn_t pick_filter(int vtype, int mode, int U) {
+    switch (vtype) {
+        case VG_TYPE_F32: return pick_filter_mode<T_F32, NT>(mode, U);
+        case VG_TYPE_F16: return pick_filter_mode<T_F16, NT>(mode, U);
+        case VG_TYPE_BF16: return pick_filter_mode<T_BF16, NT>(mode, U);
+    }
+    return nullptr;
+}
+static int filter_mode_of(int metric) {
+    return (metric == VG_DIST_DOT) ? VGF_DOT : (metric == VG_DIST_COSINE ? VGF_COS : (metric == VG_DIST_L1 ? VGF_L1 : VGF_L2));
+}
+// chunks per lane the filter kernels hold without spilling under the 128-VGPR cap of 16 wavefronts per CU (tools/kernel_regs.py)
+static int filter_u_cap(const vg_corpus *) { return 6; }
+// bytes per row the filter streams: the bf16 shadow copy of an f32 corpus, the rows themselves otherwise
+static long long filter_stream_stride(const vg_corpus *c) { return c->vtype == VG_TYPE_F32 ? vg_bf16_shadow_stride(c) : (long long)c->stride; }
+
+// Returns -1 when the shape is not served (caller takes the plain scan).
+int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream) {
+    if (!scan_filter_serves(c, metric)) return -1;
+    const bool f32 = (c->vtype == VG_TYPE_F32);
+    const long long bs = filter_stream_stride(c);
+    const int nch_b = (int)(bs / 16);
+    Shape s;
+    vg_choose_shape(nch_b, VG_TYPE_U8, A_DOT, &s, filter_u_cap(c));
+    if (s.long_rows) return -1;
+    {   // experiment override of the filter's own launch shape
+        const int fl = env_int("VG_FILTER_LPR_LOG2", -1), fu = env_int("VG_FILTER_U", -1);
+        if (fl >= 0 && fl <= 6 && fu > 0 && (nch_b + (1 << fl) - 1) / (1 << fl) <= fu && pick_filter<true>(c->vtype, filter_mode_of(metric), fu)) { s.lpr_log2 = fl; s.U = fu; }
+    }
+    Shape xs;                                            // the plain kernel's own shape: the exact evaluation sums in its order
+    vg_plain_scan_shape(c, metric, &xs);
+    if (xs.long_rows) return -1;
+    // f32: the shadow copy and the norms cost +50 % of the corpus in HBM.  A corpus they do not fit next to keeps the plain
+    // f32 scan (which served it before the filter existed) instead of failing every query.
+    int rc = vg_ensure_row_norms(c);
+    if (rc == VG_OK && f32) rc = vg_ensure_bf16_shadow(c);
+    if (rc == VG_ERR_NOMEM) {
+        (void)hipGetLastError();                         // clear the sticky allocation error
+        c->filter_disabled = true;
+        return -1;
+    }
+    if (rc != VG_OK) return rc;
+    if (!c->d_filter_evals) {
+        HIP_TRY(hipMalloc(&c->d_filter_evals, sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(c->d_filter_evals, 0, sizeof(unsigned long long), c->stream));
+    }
+    if (stream != c->stream) {                           // both passes (and the memset) ran on the corpus stream
+        if (!c->norm_ev) HIP_TRY(hipEventCreateWithFlags(&c->norm_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->norm_ev, c->stream));
+        HIP_TRY(hipStreamWaitEvent(stream, c->norm_ev, 0));
+    }
+    const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (c->n_rows * bs > (256ll << 20));
+    const int mode = filter_mode_of(metric);
+    filter_fn_t fn = nt ? pick_filter<true>(c->vtype, mode, s.U) : pick_filter<false>(c->vtype, mode, s.U);
+    if (!fn) return -1;
+    const int rpb = VG_WAVE >> s.lpr_log2;
+    const long long nbatch = (c->n_rows + rpb - 1) / rpb;
+    long long blocks = (nbatch + VG_WAVES_PER_BLOCK - 1) / VG_WAVES_PER_BLOCK;
+    blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count));
+    blocks = std::min<long long>(blocks, VG_SEL_MAX_HEADS);
+    FilterScanArgs a;
+    a.shadow = f32 ? c->d_rows_bf : c->d_rows; a.rows = c->d_rows; a.query = dev_query; a.row_norm = c->d_xnorm; a.cand = c->d_cand;
+    a.n_rows = c->n_rows; a.stride = c->stride; a.bstride = bs; a.nch = c->nch; a.nch_b = nch_b;
+    a.lpr_log2 = s.lpr_log2; a.k = k; a.root = (metric == VG_DIST_L2) ? 1 : 0; a.dim = c->dim;
+    a.mode = mode;
+    // |s~ - s| <= cerr |q||x| (vg_scan_filter.h): (D + 64) 2^-21 for the f32 sums; an f32 corpus is read through its bf16
+    // shadow copy - BOTH factors of every product rounded, unit roundoff u = 2^-8 each: + (1+u)^2 - 1 = 2^-7 + 2^-16
+    a.cerr = (float)(c->dim + 64) * 4.76837158203125e-7f + (f32 ? 0.0078125f + 1.52587890625e-5f : 0.0f);
+#ifdef VG_TEST_ROUND1_CERR     // tools/build_round1_cerr_variant.sh only: round 1's unsound constant, to show tests/test_gpu_filter_bound.py red on it
+    if (f32) a.cerr = 0.00390625f + 1.6e-5f + (float)(c->dim + 64) * 4.76837158203125e-7f;
+#endif
+    a.rel = (float)(c->dim + 64) * 2.384185791015625e-7f;
+    a.xlpr_log2 = xs.lpr_log2; a.xU = xs.U;
+    a.evals = c->d_filter_evals;
+    const size_t smem = std::max<size_t>((size_t)c->nch * 16, (size_t)VG_PUBLISH_LDS_BYTES);
+    if (c->append_pending && stream != c->stream) HIP_TRY(hipStreamWaitEvent(stream, c->append_ev, 0));
+    // Pre-pass: a plain scan of the first 1/64 of the rows.  Its k-th best distance bounds the final k-th best from
+    // above, so no wavefront has to warm its list up from +Inf (k ln(rows per wavefront / k) exact evaluations each,
+    // ~0.35 ms in all); the filter scan below still covers every row.
+    const bool prepass = env_int("VG_SCAN_FILTER_PREPASS", 1) != 0 && c->n_rows >= (1 << 20);
+    hipEvent_t *evs = vg_prof_slot(c, (uint8_t)(VG_EVF_MERGE | (prepass ? VG_EVF_PREPASS : 0)));
+    if (evs) hipEventRecord(evs[0], stream);
+    a.init_keys = nullptr;
+    if (prepass) {
+        ScanPlan pre;
+        pre.n_rows = std::max<int64_t>(65536, c->n_rows / 64);
+        pre.allow_filter = false;
+        pre.record = false;
+        const int rcp = vg_launch_plain_scan(c, metric, dev_query, k, dev_out_keys, stream, pre);
+        if (rcp != VG_OK) return rcp;
+        a.init_keys = dev_out_keys;                      // read by every workgroup before the final merge overwrites it
+        if (evs) hipEventRecord(evs[1], stream);
+    }
+    if (smem > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
+    if (evs) hipEventRecord(evs[2], stream);
+    const int rcm = vg_launch_merge_one((const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys, stream);
+    if (evs) hipEventRecord(evs[3], stream);
+    if (rcm != 0) return vg_fail(VG_ERR_HIP, "merge launch failed: %s", hipGetErrorString((hipError_t)rcm));
+    HIP_TRY(hipGetLastError());
+    return VG_OK;
+}
+
+static const char *filter_type_tag(int t) { return t == VG_TYPE_F32 ? "f32" : (t == VG_TYPE_F16 ? "f16" : "bf16"); }
+
+// "scan_filter_<type>_<metric>[_bf16]_u<U>_lpr<L>[_nt]" when the filter serves (corpus, metric); false otherwise
+bool vg_scan_filter_name(vg_corpus *c, int metric, char *out, size_t out_len) {
+    if (!scan_filter_serves(c, metric)) return false;
+    const long long bs = filter_stream_stride(c);
+    Shape fs, xs;
+    vg_choose_shape((int)(bs / 16), VG_TYPE_U8, A_DOT, &fs, filter_u_cap(c));
+    vg_plain_scan_shape(c, metric, &xs);
+    if (fs.long_rows || xs.long_rows) return false;
+    const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (c->n_rows * bs > (256ll << 20));
+    static const char *mtag[4] = {"l2", "dot", "cos", "l1"};
+    snprintf(out, out_len, "scan_filter_%s_%s%s_u%d_lpr%d%s", filter_type_tag(c->vtype), mtag[filter_mode_of(metric)],
+             c->vtype == VG_TYPE_F32 ? "_bf16" : "", fs.U, 1 << fs.lpr_log2, nt ? "_nt" : "");
+    return true;
+}

@@ -116,6 +116,22 @@ static inline int env_int(const char *name, int dflt) {
     return atoi(s);
 }
 
+// What one scan launch covers.  n_rows < 0: the whole corpus; a prefix otherwise (the filter scan's plain pre-pass).
+struct ScanPlan {
+    int64_t n_rows = -1;
+    bool allow_filter = true;      // false: the plain kernel of vg_scan.h whatever the corpus / the switches say
+    bool record = true;            // false: no entry in the profiling ring (a pre-pass is recorded by its parent launch)
+};
+
+// next slot of the profiling ring (nullptr when profiling is off)
+static inline hipEvent_t *vg_prof_slot(vg_corpus *c, uint8_t flags) {
+    if (!c->profiling) return nullptr;
+    const int slot = (int)(c->prof_launches % VG_PROF_RING);
+    c->ev_flags[(size_t)slot] = flags;
+    ++c->prof_launches;
+    return &c->ev[(size_t)slot * VG_PROF_EVS];
+}
+
 // ---- internal entry points that cross translation units
 int vg_metric_to_acc(int metric);                                  // vg_api.hip; -1 for an unknown metric
 void vg_collect_timing(vg_corpus *c);                              // vg_api.hip: event times of the last launch
@@ -123,6 +139,13 @@ int vg_ensure_row_norms(vg_corpus *c);                             // vg_api.hip
 struct VgShape { int lpr_log2; int U; bool long_rows; };           // launch shape of a scan: lanes per row, chunks per lane
 bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap);   // vg_api.hip
 int vg_launch_merge(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, int nq, hipStream_t stream);   // vg_api.hip
+// vg_api.hip <-> vg_filter.hip (the filter scans of vg_scan_filter.h are a translation unit of their own)
+int vg_launch_plain_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream,
+                         const ScanPlan &plan);                    // vg_api.hip: the plain scan + merge (the filter's pre-pass)
+int vg_launch_merge_one(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, hipStream_t stream);   // vg_api.hip
+int vg_plain_scan_shape(const vg_corpus *c, int metric, VgShape *out);   // vg_api.hip: launch shape of the plain kernel
+int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream);   // vg_filter.hip; -1: not served
+bool vg_scan_filter_name(vg_corpus *c, int metric, char *out, size_t out_len);   // vg_filter.hip: kernel name when the filter serves the scan
 long long vg_bf16_shadow_stride(const vg_corpus *c);               // vg_batch_api.hip: row stride of the bf16 shadow copy of an f32 corpus
 int vg_ensure_bf16_shadow(vg_corpus *c);                           // vg_batch_api.hip: build / extend it (corpus stream)
 int vg_multi_queries_per_pass(const vg_corpus *c, int metric);     // vg_multi.hip: queries per pass of the multi-query scan, 0 = none

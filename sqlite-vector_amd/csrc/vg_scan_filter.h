@@ -49,7 +49,7 @@ struct FilterScanArgs {
                                //   an upper bound of the final k-th best - the lists do not have to warm up from +Inf
     unsigned long long *evals; // instrumentation: += exact evaluations of this launch (one atomic per workgroup)
 };
-enum { VGF_L2 = 0, VGF_DOT = 1, VGF_COS = 2 };
+enum { VGF_L2 = 0, VGF_DOT = 1, VGF_COS = 2, VGF_L1 = 3 /* f16 / bf16 only */ };
 
 typedef __bf16 vgf_bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -74,9 +74,31 @@ __device__ inline void vgf_dot_chunk(const uint4 &q, const uint4 &x, float &s0, 
     }
 }
 
-template <int XT, int U, bool NT>
+// s += sum |q - x| over the 8 elements of one 16-byte chunk: the reference's own f32 differences (distance-avx2.c:222-279 f16;
+// bf16 subtracts in f64, :434-489 - an f32 difference of two bf16 values is off by at most 2^-24 of itself), summed in f32
+// instead of f64.  Every term is >= 0, so the f32 sum is within (D + 64) 2^-23 of the f64 one, relatively: a lower bound of
+// the L1 distance without any cached norm.
+template <int FT>
+__device__ inline void vgf_l1_chunk(const uint4 &q, const uint4 &x, float &s0, float &s1) {
+    const uint32_t qw[4] = {q.x, q.y, q.z, q.w}, xw[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float q0, q1, x0, x1;
+        vg_unpack2<FT>(qw[j], q0, q1);
+        vg_unpack2<FT>(xw[j], x0, x1);
+        s0 += fabsf(q0 - x0);
+        s1 += fabsf(q1 - x1);
+    }
+}
+
+// MODE (VGF_*) is a template parameter: as a run-time switch every instantiation carried all the exact evaluations (three
+// sets of f64 accumulators for the half types) and the streaming loop spilled beyond 3 chunks per lane.
+template <int XT, int MODE, int U, bool NT>
 __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs a) {
     constexpr bool XF32 = (XT == T_F32);
+    constexpr bool L1M = (MODE == VGF_L1);
+    constexpr int mode = MODE;
+    static_assert(!(XF32 && L1M), "the f32 L1 scan has no filter variant");
     constexpr int FT = XF32 ? T_BF16 : XT;                                // element type the filter multiplies
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & (VG_WAVE - 1);
@@ -84,7 +106,6 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
     const int lpr_log2 = a.lpr_log2, lpr = 1 << lpr_log2, rpb = VG_WAVE >> lpr_log2;
     const int sub = lane & (lpr - 1), rib = lane >> lpr_log2;
     const int k = a.k;
-    const int mode = a.mode;
 
     // the query, staged once per workgroup: the exact path reads it, the filter's chunks are built from it
     uint4 *qs = reinterpret_cast<uint4 *>(smem);
@@ -204,22 +225,20 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
             d = acc.finish(st, a.xlpr_log2, a.root);
         } else {
             st.qq = xq_f64; st.qspecial = xq_special;
-            if (mode == VGF_COS) d = acc.finish_cached_norm(st, a.xlpr_log2, a.row_norm[row_u]);
+            if constexpr (MODE == VGF_COS) d = acc.finish_cached_norm(st, a.xlpr_log2, a.row_norm[row_u]);
             else d = acc.finish(st, a.xlpr_log2, a.root);
             // rows (or a query) holding Inf / NaN: one lane replays the reference algorithm exactly (vg_half.h)
             if (acc.special(st, a.xlpr_log2) && lane == 0) {
                 const uint16_t *q16 = reinterpret_cast<const uint16_t *>(qs), *r16 = reinterpret_cast<const uint16_t *>(rp);
-                if (mode == VGF_L2) d = vg_slow_distance<XT, A_L2>(q16, r16, a.dim, a.root);
-                else if (mode == VGF_DOT) d = vg_slow_distance<XT, A_DOT>(q16, r16, a.dim, a.root);
-                else d = vg_slow_distance<XT, A_COS>(q16, r16, a.dim, a.root);
+                constexpr int SLOW = L1M ? A_L1 : (MODE == VGF_L2 ? A_L2 : (MODE == VGF_DOT ? A_DOT : A_COS));
+                d = vg_slow_distance<XT, SLOW>(q16, r16, a.dim, a.root);
             }
         }
         return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vg_clamp(d))));
     };
     auto exact = [&](uint32_t row_u) -> float {
-        if (mode == VGF_L2) return exact_with(Accum<XT, A_L2>(), row_u);
-        if (mode == VGF_DOT) return exact_with(Accum<XT, A_DOT>(), row_u);
-        return exact_with(Accum<XT, XF32 ? A_COS : A_COSN>(), row_u);
+        constexpr int XACC = L1M ? A_L1 : (MODE == VGF_L2 ? A_L2 : (MODE == VGF_DOT ? A_DOT : (XF32 ? A_COS : A_COSN)));
+        return exact_with(Accum<XT, XACC>(), row_u);
     };
 
     const long long nbatch = (a.n_rows + rpb - 1) / rpb;
@@ -237,18 +256,29 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
         const long long bn = b + wstride;
         load(nxt, nrm_nxt, bn);
         float s0 = 0.0f, s1 = 0.0f;
+        if constexpr (L1M) {
+            // keep the query as RAW halves in registers (the compiler would hoist the widened copies out of the loop and spill)
 #pragma unroll
-        for (int u = 0; u < U; ++u) vgf_dot_chunk<FT>(q[u], cur[u], s0, s1);
+            for (int u = 0; u < U; ++u) asm volatile("" : "+v"(q[u].x), "+v"(q[u].y), "+v"(q[u].z), "+v"(q[u].w));
+#pragma unroll
+            for (int u = 0; u < U; ++u) vgf_l1_chunk<FT>(q[u], cur[u], s0, s1);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) vgf_dot_chunk<FT>(q[u], cur[u], s0, s1);
+        }
         const float st = vg_group_sum(s0 + s1, lpr_log2);
         const long long row = b * rpb + rib;
         // cached norm: ||x|| for f32 corpora, sum x^2 for f16 / bf16 corpora
         const float nn = XF32 ? nrm_cur * nrm_cur : nrm_cur;
         const float nrm = XF32 ? nrm_cur : sqrtf(nrm_cur);
         const float E = a.cerr * qn * nrm + esub_q + esub_x * nrm;
-        const bool judged = q_ok && (XF32 ? (nrm >= 1.0e-15f && nrm <= 1.0e15f) : (nn >= 1.0e-30f && nn <= 1.0e30f));
+        // (L1 needs no norm: its bound is the f32 sum itself; a NaN / Inf / overflowing sum sends the row to the exact path)
+        const bool judged = L1M ? (xq_special == 0u && st < 3.0e38f)
+                                : (q_ok && (XF32 ? (nrm >= 1.0e-15f && nrm <= 1.0e15f) : (nn >= 1.0e-30f && nn <= 1.0e30f)));
         // lower bound of the distance (squared for L2)
         float lb;
-        if (mode == VGF_L2) lb = qq + nn - 2.0f * (st + E) - a.rel * (qq + nn);
+        if (L1M) lb = st - 2.0f * a.rel * st;
+        else if (mode == VGF_L2) lb = qq + nn - 2.0f * (st + E) - a.rel * (qq + nn);
         else if (mode == VGF_DOT) lb = -(st + E) - a.rel * qn * nrm;
         else { const float r = (st + E) / (qn * nrm); lb = 1.0f - r - a.rel * fabsf(r) - 4.0e-6f; }   // (norms + the float epilogue)
         const bool cand = (sub == 0) && (row < a.n_rows) && (!judged || lb < thr_gate);

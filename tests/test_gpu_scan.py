@@ -351,7 +351,7 @@ def test_batch_multi_query_scan_vs_single_scans(pkg, orc, vt, monkeypatch):
 @pytest.mark.parametrize("dim", (3, 33, 100, 384, 768, 1024, 1536))
 @pytest.mark.parametrize("vt", (dg.F32, dg.F16, dg.BF16))
 def test_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, vt, dim, monkeypatch):
-    """L2 / squared-L2 / dot / cosine top-k scans of f32, f16 and bf16 corpora go through a lower-bound filter (f32: the bf16
+    """L2 / squared-L2 / dot / cosine (f16 / bf16: also L1) top-k scans of f32, f16 and bf16 corpora go through a lower-bound filter (f32: the bf16
     shadow copy, half the bytes; f16 / bf16: f32 sums instead of the reference's f64 chain) and re-evaluate the candidates
     with the plain kernel's accumulator in its summation order (vg_scan_filter.h): rowids and distance BITS must equal the
     plain scan's (filter off), for ordinary rows, edge rows (NaN / Inf / huge / tiny / zero / subnormal) and edge queries."""
@@ -368,7 +368,7 @@ def test_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, vt, dim, monke
     queries = [rows[17].copy()] + dg.edge_queries(vt, dim, 9900 + dim) + [dg.query(vt, dim, 9901 + i) for i in range(4)]
     queries.append(rows[30007].copy())                       # a tiny (subnormal) query
     tag = dg.TYPE_NAMES[vt]
-    for metric in (dg.L2, dg.SQUARED_L2, dg.DOT, dg.COSINE):
+    for metric in (dg.L2, dg.SQUARED_L2, dg.DOT, dg.COSINE) + ((dg.L1,) if vt != dg.F32 else ()):   # (f32 L1: plain scan only)
         c.set_scan_filter(1)
         assert c.kernel_name(metric).startswith("scan_filter_" + tag), c.kernel_name(metric)
         for qi, q in enumerate(queries):
@@ -404,7 +404,7 @@ def test_filter_scan_with_its_prepass_on_clustered_rows(pkg, orc, vt, dim, monke
     c = pkg.Corpus(vt, dim)
     c.append(rows)
     for qi, q in enumerate((rows[twin].copy(), rows[100].copy(), dg.to_storage(vt, centres[2] / np.linalg.norm(centres[2])))):
-        for metric in (dg.L2, dg.SQUARED_L2, dg.DOT, dg.COSINE):
+        for metric in (dg.L2, dg.SQUARED_L2, dg.DOT, dg.COSINE) + ((dg.L1,) if vt != dg.F32 else ()):
             c.set_scan_filter(1)
             ids1, d1 = c.scan_topk(metric, q, 20)
             c.set_scan_filter(0)

@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/../sqlite-vector_amd"
 python build.py >/dev/null
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result -DVG_TEST_ROUND1_CERR -c csrc/vg_api.hip -o build/vg_api_round1cerr.o
-objs=$(ls build/*.o | grep -v vg_api.hip.o | grep -v round1cerr)
-hipcc --offload-arch=gfx950 -shared -fPIC -o libvectorgpu_round1cerr.so build/vg_api_round1cerr.o $objs
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result -DVG_TEST_ROUND1_CERR -c csrc/vg_filter.hip -o build/vg_filter_round1cerr.o
+objs=$(python -c "import build as b; print(' '.join('build/' + u[1] for u in b.HIP_UNITS if u[1] != 'vg_filter.hip.o'))")
+hipcc --offload-arch=gfx950 -shared -fPIC -o libvectorgpu_round1cerr.so build/vg_filter_round1cerr.o $objs
 echo built libvectorgpu_round1cerr.so
