@@ -125,6 +125,7 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_rows_bf) hipFree(c->d_rows_bf);
     if (c->d_filter_evals) hipFree(c->d_filter_evals);
     if (c->d_below) hipFree(c->d_below);
+    if (c->h_ref) hipHostFree(c->h_ref);
     if (c->norm_ev) hipEventDestroy(c->norm_ev);
     if (c->d_bcand) hipFree(c->d_bcand);
     if (c->d_bkeys) hipFree(c->d_bkeys);

@@ -67,6 +67,9 @@ struct vg_corpus {
     int64_t d_dist_cap = 0;
     int64_t dist_valid_rows = 0;   // rows of d_dist the last vg_scan_distances_resident filled (0: none)
     unsigned long long *d_below = nullptr;   // vg_reforder.hip: [count | VG_BELOW_CAP (position, distance) pairs]
+    uint8_t *h_ref = nullptr;      // pinned landing zone of its small device-to-host copies (a pageable destination costs ~100 us each)
+    size_t h_ref_bytes = 0;
+    std::vector<uint64_t> ref_pairs;   // its candidate pairs on the host (kept between scans: no 1 MB clear per query)
     int tie_order = 0;             // VG_TIE_POSITION / VG_TIE_REFERENCE (vg_corpus_set_tie_order)
     uint64_t *d_sel_keys = nullptr, *d_sel_sorted = nullptr;   // k > 64 path: N keys, unsorted / sorted
     void *d_sel_temp = nullptr;

@@ -51,13 +51,26 @@ __global__ __launch_bounds__(256) void vg_below_kernel(const float *dist, long l
     }
 }
 
+#define VG_REF_PINNED_BYTES ((size_t)1 << 20)
+static int ensure_ref_pinned(vg_corpus *c) {
+    if (c->h_ref) return VG_OK;
+    HIP_TRY(hipHostMalloc(&c->h_ref, VG_REF_PINNED_BYTES));
+    c->h_ref_bytes = VG_REF_PINNED_BYTES;
+    return VG_OK;
+}
+
 extern "C" int vg_resident_distances_fetch(vg_corpus *c, int64_t pos0, int64_t n, float *out_host) {
     if (!c || !out_host) return vg_fail(VG_ERR_INVALID, "vg_resident_distances_fetch: NULL argument");
     if (n <= 0) return VG_OK;
     if (!c->d_dist || pos0 < 0 || pos0 + n > c->dist_valid_rows) return vg_fail(VG_ERR_INVALID, "vg_resident_distances_fetch: no resident distances for rows %lld..%lld", (long long)pos0, (long long)(pos0 + n));
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(out_host, c->d_dist + pos0, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    int rc = ensure_ref_pinned(c);
+    if (rc != VG_OK) return rc;
+    const size_t bytes = (size_t)n * sizeof(float);
+    void *dst = bytes <= c->h_ref_bytes ? (void *)c->h_ref : (void *)out_host;        // small copies land in pinned memory
+    HIP_TRY(hipMemcpyAsync(dst, c->d_dist + pos0, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (dst != (void *)out_host) memcpy(out_host, dst, bytes);
     return VG_OK;
 }
 
@@ -76,15 +89,17 @@ extern "C" int vg_resident_distances_below(vg_corpus *c, int64_t pos0, float bou
     hipLaunchKernelGGL(vg_below_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float *)c->d_dist, (long long)pos0, (long long)n, bound,
                        c->d_below, dcap);
     HIP_TRY(hipGetLastError());
-    // the count and the first pairs in one copy; the rest only when there are more
+    // the count and the first pairs in one copy (into pinned memory); the rest only when there are more
+    int rcp = ensure_ref_pinned(c);
+    if (rcp != VG_OK) return rcp;
     const size_t first = std::min<size_t>((size_t)dcap, 8191);
-    std::vector<unsigned long long> head(first + 1);
-    HIP_TRY(hipMemcpyAsync(head.data(), c->d_below, (first + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long *head = reinterpret_cast<unsigned long long *>(c->h_ref);
+    HIP_TRY(hipMemcpyAsync(head, c->d_below, (first + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const unsigned long long count = head[0];
     *out_count = (int64_t)count;
     const size_t have = (size_t)std::min<unsigned long long>(count, dcap);
-    memcpy(out_pairs, head.data() + 1, std::min(have, first) * sizeof(uint64_t));
+    memcpy(out_pairs, head + 1, std::min(have, first) * sizeof(uint64_t));
     if (have > first) {
         HIP_TRY(hipMemcpyAsync(out_pairs + first, c->d_below + 1 + first, (have - first) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -95,10 +110,10 @@ extern "C" int vg_resident_distances_below(vg_corpus *c, int64_t pos0, float bou
 namespace {
 struct CorpusSrc {
     vg_corpus *c;
-    std::vector<uint64_t> pairs;
+    std::vector<uint64_t> &pairs;
     int fetch(int64_t g0, int64_t cnt, float *out) { return vg_resident_distances_fetch(c, g0, cnt, out); }
     int below(int64_t g0, float bound, std::vector<VgRefCand> &out, bool *overflow) {
-        pairs.resize(VG_BELOW_CAP);
+        if (pairs.size() < (size_t)VG_BELOW_CAP) pairs.resize(VG_BELOW_CAP);      // (once per corpus)
         int64_t count = 0;
         int rc = vg_resident_distances_below(c, g0, bound, pairs.data(), VG_BELOW_CAP, &count);
         if (rc != VG_OK) return rc;
@@ -122,7 +137,7 @@ extern "C" int vg_scan_topk_reference(vg_corpus *c, int metric, const void *quer
     if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_reference: NULL output");
     int rc = vg_scan_distances_resident(c, metric, query);
     if (rc != VG_OK) return rc;
-    CorpusSrc src{c, {}};
+    CorpusSrc src{c, c->ref_pairs};
     VgRefSlots slots;
     if ((rc = vg_ref_replay(src, c->n_rows, k, slots)) != VG_OK) return rc;
     vg_collect_timing(c);
