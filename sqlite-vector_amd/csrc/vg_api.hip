@@ -566,15 +566,17 @@ extern "C" int vg_profile_mean_ms(vg_corpus *c, int *n_launches, float *scan_ms,
     return vg_profile_mean_ms_ex(c, n_launches, scan_ms, merge_ms, nullptr);
 }
 
-// Filter scan instrumentation: exact (f32) evaluations done by the filter-scan launches since the last call; resets the counter.
+// Filter scan instrumentation: rows evaluated exactly by the filter-scan launches since the last call (waits for the corpus
+// stream, so that the launches enqueued on it are counted).
 extern "C" int vg_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals) {
     if (!c || !out_evals) return vg_fail(VG_ERR_INVALID, "vg_filter_exact_evals: NULL argument");
     *out_evals = 0;
     if (!c->d_filter_evals) return VG_OK;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(out_evals, c->d_filter_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_filter_evals, 0, sizeof(unsigned long long), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const unsigned long long now = *(volatile unsigned long long *)c->d_filter_evals;
+    *out_evals = now - c->filter_evals_read;
+    c->filter_evals_read = now;
     return VG_OK;
 }
 

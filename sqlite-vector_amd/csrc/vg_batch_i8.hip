@@ -46,6 +46,9 @@ typedef int vgi_i32x4 __attribute__((ext_vector_type(4)));
 #ifndef VGI_DEPTH2
 #define VGI_DEPTH2 0                    // experiment, measured NEUTRAL (10.5 / 8.95 / 6.1 vs 9.9 / 9.3 / 5.5 ms): DMA two tiles ahead, counted vmcnt waits
 #endif
+#ifndef VGI_SKEW
+#define VGI_SKEW 0                      // with VGI_ASYNC: the two wavefronts of a SIMD run half a tile apart
+#endif
 #ifndef VGI_ASYNC
 #define VGI_ASYNC 0                     // experiment, measured NEUTRAL TO SLOWER (profiles/r2c_int8_batch_async_ring_vs_barrier.txt: u8 cosine 10.10 vs
                                         // 9.78 ms, dot 9.45 vs 9.24, D = 128 6.69 vs 5.87, D = 1024 12.80 vs 13.07; bit-exact tests pass): a tile ring with
@@ -58,6 +61,23 @@ typedef int vgi_i32x4 __attribute__((ext_vector_type(4)));
 #define VGI_NBUF_OF(NTB) (VGI_IS_ASYNC(NTB) ? ((NTB) <= 24 ? 4 : 3) : ((VGI_PHASED || VGI_DEPTH2) ? 3 : 2))
 
 enum { VGI_DOT = 0, VGI_COS = 1, VGI_L2 = 2 };
+
+#ifndef VGI_TIMING
+#define VGI_TIMING 0                    // measurement builds (tools/tools_i8_timing.py, tools/build_i8_variants.sh timing -DVGI_TIMING=1)
+#endif
+#if VGI_TIMING
+// s_memtime ticks summed over all wavefronts of the REAL pass (barrier schedule): k loop (incl. the MFMA drain) | gate math |
+// inserts | DMA wait | barrier | whole loop | wave-tiles | wave-tiles with pending registers
+__device__ unsigned long long vgi_ticks[8];
+extern "C" int vg_batch_i8_timing(unsigned long long *out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(vgi_ticks), sizeof(vgi_ticks)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vgi_ticks), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define VGI_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define VGI_TICK(var)
+#endif
 
 struct BatchArgsI8 {
     const uint8_t *rows;      // N x stride bytes, SIGNED representation (int8 corpus as is, uint8 corpus XOR 0x80)
@@ -221,6 +241,19 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
     uint32_t qq_reg[16];
     int cq_reg[16], gate_i[16];
     float thr_reg[16], gate_f[16], na_reg[16];
+#ifndef VGI_FOLD
+#define VGI_FOLD 1                      // 0: the round-1 boundary for every metric (accumulators start at 0, 3-5 VALU operations per register and tile)
+#endif
+    // (measured, profiles/r2g: dot 9.05 -> 9.01 ms - its tile then waits longer for the DMA instead -, L2 9.44 -> 9.10, D = 1024 13.6 -> 12.2;
+    //  cosine got SLOWER, 9.78 -> 10.11: the lane's loosest gate lets the per-register pass run too often - cosine keeps the round-1 boundary)
+    constexpr bool FOLD = (VGI_FOLD != 0) && !COS;
+    // FOLDED GATES: the accumulator of register r STARTS at acc_init[r] instead of 0 (integer sums: exact), so that the tile
+    // boundary needs ONE max over the 16 registers and one comparison per lane instead of 3-5 operations per register:
+    //   dot     init = -gate_i                  any pair passes  <=>  max_r acc' + cx >= 0
+    //   L2      init = -(gate_i >> 1)           any pair passes   =>  max_r acc' - ((xx - 2 cx) >> 1) >= 0     (floors: a superset)
+    //   cosine  (row norms differ per lane: no folding; tried with the lane's loosest gate as a first test - slower, see below)
+    // The exact distance test in reg_insert is unchanged (it gets the raw accumulator acc' - init back).
+    int acc_init[16];
     const bool l2_root = a.root != 0;
     auto as_float_like = [](uint32_t v) -> float { return IS_U8 ? (float)v : (float)(int32_t)v; };
     // gates are supersets of "distance <= thr" (exact test in reg_insert):
@@ -243,7 +276,9 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
             const int Gq = (Gf > -1.5e9f) ? (int)floorf(Gf) : -1500000000;  // thr = +Inf: accept everything (|qx| < 2^27)
             gate_i[r] = Gq - cq_reg[r];
         }
+        acc_init[r] = !FOLD ? 0 : (L2M ? -(gate_i[r] >> 1) : -gate_i[r]);
     };
+
     vgb_static_for<0, 16>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -258,6 +293,7 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
         if (q0 + qi >= a.nq_real) {                      // padding (an all-zero query ties every row at cosine 1.0)
             thr_reg[r] = -INFINITY;
             if (COS) gate_f[r] = 3.0e38f; else gate_i[r] = 1500000000;
+            acc_init[r] = !FOLD ? 0 : (L2M ? -(gate_i[r] >> 1) : -gate_i[r]);
         }
     });
 
@@ -326,7 +362,7 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
     auto k_loop = [&](int cur_buf, long long tile_next, int next_buf) __attribute__((always_inline)) {
         const uint32_t goff_next = lane_offset(tile_next);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0;
+        for (int r = 0; r < 16; ++r) acc[r] = acc_init[r];
 #if VGI_CHAINS == 2
         vgi_i32x16 acc2;
 #pragma unroll
@@ -362,11 +398,26 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
 #endif
     };
     // the tile boundary: margins (integer for dot / L2, float for cosine), one ballot, the rare inserts
+#if VGI_TIMING
+    unsigned long long tk_gate_end = 0, tk_pend = 0, tk_k = 0, tk_gate = 0, tk_ins = 0, tk_dma = 0, tk_bar = 0, tk_tiles = 0;
+#endif
     auto boundary_with = [&](long long tile, int sx, uint32_t xx) __attribute__((always_inline)) {
         const long long row_cur = tile * VGI_TILE + x;
         const int cx = IS_U8 ? 128 * sx : 0;
         unsigned pend = 0;
         bool any;
+        if constexpr (FOLD) {
+            int amax = acc[0];                           // max over the lane's 16 folded accumulators: 8 x v_max3
+            vgb_static_for<1, 16>([&](auto rc) { constexpr int r = decltype(rc)::value; amax = acc[r] > amax ? acc[r] : amax; });
+            const int h2 = L2M ? (((int)xx - 2 * cx) >> 1) : -cx;
+            any = __ballot(amax - h2 >= 0) != 0;
+            if (any) {
+                vgb_static_for<0, 16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    pend |= __ballot(acc[r] - h2 >= 0) ? (1u << r) : 0u;
+                });
+            }
+        } else
         if (COS) {
             const float nb = sqrtf(as_float_like(xx));
             float margin = -INFINITY;
@@ -399,10 +450,14 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
                 });
             }
         }
+#if VGI_TIMING
+        tk_gate_end = __builtin_readcyclecounter();
+        tk_pend += pend ? 1 : 0;
+#endif
         if (pend) {
             vgb_static_for<0, 16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                if (pend & (1u << r)) reg_insert(rc, acc[r], row_cur, cx, xx);
+                if (pend & (1u << r)) reg_insert(rc, acc[r] - acc_init[r], row_cur, cx, xx);     // (the raw accumulator)
             });
         }
     };
@@ -437,6 +492,11 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                                 // tiles 0 and 1 have landed; ready[0] was preset, ready[1] is signalled in iteration 0
+#if VGI_SKEW
+        // Start the second wavefront of every SIMD (waves WAVES/2 ..: the same SIMDs as waves 0 .. WAVES/2-1) half a tile late: nothing
+        // in the ring re-aligns them afterwards, so while one of a SIMD's two wavefronts is at its boundary the other is in its k loop.
+        if (wave >= WAVES / 2) wait_ge(&freed[0], (uint32_t)(WAVES / 2));
+#endif
         for (long long tile = tile_first; tile < tile_last; ++tile) {
             const long long ti = tile - tile_first;
             const int b = (int)(ti % NBUF), nb = (int)((ti + 2) % NBUF);
@@ -550,13 +610,32 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    VGI_TICK(t_loop0);
     for (long long tile = tile_first; tile < tile_last; ++tile) {
         const int cur_buf = (int)((tile - tile_first) & 1);
+        VGI_TICK(t0);
         k_loop(cur_buf, min(tile + 1, tile_last - 1), cur_buf ^ 1);      // (the last iteration re-fetches its own tile)
+#if VGI_TIMING
+        asm volatile("s_nop 0" :: "v"(acc[15]));                          // the k loop's last MFMA has retired
+#endif
+        VGI_TICK(t1);
         boundary(tile, cur_buf);
+        VGI_TICK(t3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VGI_TICK(t4);
         __syncthreads();
+#if VGI_TIMING
+        const unsigned long long t5 = __builtin_readcyclecounter();
+        tk_k += t1 - t0; tk_gate += tk_gate_end - t1; tk_ins += t3 - tk_gate_end; tk_dma += t4 - t3; tk_bar += t5 - t4; ++tk_tiles;
+#endif
     }
+#if VGI_TIMING
+    if (!PRE && lane == 0) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        atomicAdd(&vgi_ticks[0], tk_k); atomicAdd(&vgi_ticks[1], tk_gate); atomicAdd(&vgi_ticks[2], tk_ins); atomicAdd(&vgi_ticks[3], tk_dma);
+        atomicAdd(&vgi_ticks[4], tk_bar); atomicAdd(&vgi_ticks[5], t_end - t_loop0); atomicAdd(&vgi_ticks[6], tk_tiles); atomicAdd(&vgi_ticks[7], tk_pend);
+    }
+#endif
 #endif
     }   // !ASYNC
 

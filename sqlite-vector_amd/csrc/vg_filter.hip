@@ -100,8 +100,22 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     }
     if (rc != VG_OK) return rc;
     if (!c->d_filter_evals) {
-        HIP_TRY(hipMalloc(&c->d_filter_evals, sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(c->d_filter_evals, 0, sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipHostMalloc(&c->d_filter_evals, sizeof(unsigned long long)));   // pinned, device-visible
+        *c->d_filter_evals = 0;
+    }
+    {   // Selectivity guard.  The bound cannot separate rows that are (nearly) identical to each other: on such data every row
+        // is a candidate and the exact evaluations - serial per wavefront - cost more than the plain scan.  The kernels count
+        // them in pinned host memory; when the completed launches since the last look averaged more than 1/32 of the rows, the
+        // next 256 scans of this corpus take the plain kernel, then the filter is tried again.
+        const unsigned long long now = *(volatile unsigned long long *)c->d_filter_evals;
+        const long long launches = c->filter_launches - c->filter_launches_seen;
+        if (launches >= 2) {
+            if ((now - c->filter_evals_seen) / (unsigned long long)launches > (unsigned long long)(c->n_rows / 32) && !env_int("VG_SCAN_FILTER_NO_GUARD", 0))
+                c->filter_cooldown = 256;
+            c->filter_evals_seen = now;
+            c->filter_launches_seen = c->filter_launches;
+        }
+        if (c->filter_cooldown > 0) { --c->filter_cooldown; return -1; }
     }
     if (stream != c->stream) {                           // both passes (and the memset) ran on the corpus stream
         if (!c->norm_ev) HIP_TRY(hipEventCreateWithFlags(&c->norm_ev, hipEventDisableTiming));
@@ -152,6 +166,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     }
     if (smem > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
+    ++c->filter_launches;
     if (evs) hipEventRecord(evs[2], stream);
     const int rcm = vg_launch_merge_one((const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys, stream);
     if (evs) hipEventRecord(evs[3], stream);

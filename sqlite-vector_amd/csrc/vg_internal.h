@@ -95,7 +95,12 @@ struct vg_corpus {
     int64_t bf_rows = 0, bf_cap = 0;
     bool filter_disabled = false;                 // the shadow copy / norms did not fit HBM: single queries keep the plain f32 scan
     int scan_filter_mode = -1;                    // vg_corpus_set_scan_filter: -1 = default (env VG_SCAN_FILTER, else on), 0 = off, 1 = on
-    unsigned long long *d_filter_evals = nullptr; // filter scan: exact evaluations of the launches since the last read-out
+    unsigned long long *d_filter_evals = nullptr; // filter scan: exact evaluations so far - a counter in PINNED HOST memory the kernels add to
+                                                  //   (one atomic per workgroup), so the host can look at it without a copy or a wait
+    unsigned long long filter_evals_read = 0;     // its value at the last vg_filter_exact_evals read-out
+    unsigned long long filter_evals_seen = 0;     // ... and when the selectivity guard last looked
+    long long filter_launches_seen = 0, filter_launches = 0;
+    int filter_cooldown = 0;                      // > 0: the bound is not selective on this data - that many scans take the plain kernel
     int64_t i8_rows = 0, i8_cap = 0;              // orders a caller-stream scan behind a norm pass on the corpus stream
     void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
     uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;

@@ -243,3 +243,29 @@ def test_filter_fuzz_sign_coherent_rounding(pkg, chunk, monkeypatch):
                 assert ids1.tolist() == ids0.tolist(), (dim, n, metric, k)
                 assert dg.same_float_bits(d1, d0), (dim, n, metric, k)
         c.close()
+
+
+def test_selectivity_guard_on_a_corpus_of_identical_rows(pkg, orc, monkeypatch):
+    """rows that are all alike cannot be separated by any bound: every row is a candidate and the exact evaluations would cost
+    more than the plain scan.  The launch watches the kernels' evaluation counter and sends such a corpus back to the plain
+    kernel (for 256 scans, then it tries again); the answers are the plain scan's throughout."""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    n, dim = (1 << 20) + 3, 24
+    base = dg.query(dg.F32, dim, 4242)
+    rows = np.tile(base, (n, 1))
+    rows[n // 2] = base * np.float32(1.5)                              # one row that differs, so that not all distances tie
+    q = (base * np.float32(1.01)).astype(np.float32)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    c.set_scan_filter(0)
+    ids0, d0 = c.scan_topk(dg.L2, q, 20)
+    c.set_scan_filter(1)
+    c.filter_exact_evals()
+    seen = []
+    for i in range(6):
+        ids1, d1 = c.scan_topk(dg.L2, q, 20)
+        assert ids1.tolist() == ids0.tolist() and dg.same_float_bits(d1, d0)
+        seen.append(c.filter_exact_evals())
+    assert seen[0] > n // 2 and seen[1] > n // 2                      # unselective: (nearly) every row evaluated exactly ...
+    assert seen[3] == 0 and seen[4] == 0 and seen[5] == 0              # ... so the following scans take the plain kernel
+    c.close()
