@@ -574,7 +574,8 @@ extern "C" int vg_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals
     if (!c->d_filter_evals) return VG_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const unsigned long long now = *(volatile unsigned long long *)c->d_filter_evals;
+    unsigned long long now = 0;
+    HIP_TRY(hipMemcpy(&now, c->d_filter_evals, sizeof(now), hipMemcpyDeviceToHost));
     *out_evals = now - c->filter_evals_read;
     c->filter_evals_read = now;
     return VG_OK;

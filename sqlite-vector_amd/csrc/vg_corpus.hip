@@ -123,7 +123,8 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_sxx) hipFree(c->d_sxx);
     if (c->d_rows_s8) hipFree(c->d_rows_s8);
     if (c->d_rows_bf) hipFree(c->d_rows_bf);
-    if (c->d_filter_evals) hipHostFree(c->d_filter_evals);
+    if (c->d_filter_evals) hipFree(c->d_filter_evals);
+    if (c->h_filter_evals) hipHostFree(c->h_filter_evals);
     if (c->d_below) hipFree(c->d_below);
     if (c->h_ref) hipHostFree(c->h_ref);
     if (c->norm_ev) hipEventDestroy(c->norm_ev);

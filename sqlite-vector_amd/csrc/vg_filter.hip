@@ -100,14 +100,17 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     }
     if (rc != VG_OK) return rc;
     if (!c->d_filter_evals) {
-        HIP_TRY(hipHostMalloc(&c->d_filter_evals, sizeof(unsigned long long)));   // pinned, device-visible
-        *c->d_filter_evals = 0;
+        HIP_TRY(hipMalloc(&c->d_filter_evals, sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(c->d_filter_evals, 0, sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipHostMalloc(&c->h_filter_evals, sizeof(unsigned long long)));
+        *c->h_filter_evals = 0;
     }
     {   // Selectivity guard.  The bound cannot separate rows that are (nearly) identical to each other: on such data every row
         // is a candidate and the exact evaluations - serial per wavefront - cost more than the plain scan.  The kernels count
-        // them in pinned host memory; when the completed launches since the last look averaged more than 1/32 of the rows, the
-        // next 256 scans of this corpus take the plain kernel, then the filter is tried again.
-        const unsigned long long now = *(volatile unsigned long long *)c->d_filter_evals;
+        // them, a copy behind every launch mirrors the counter into pinned host memory; when the completed launches since the
+        // last look averaged more than 1/32 of the rows, the next 256 scans of this corpus take the plain kernel, then the
+        // filter is tried again.
+        const unsigned long long now = *(volatile unsigned long long *)c->h_filter_evals;
         const long long launches = c->filter_launches - c->filter_launches_seen;
         if (launches >= 2) {
             if ((now - c->filter_evals_seen) / (unsigned long long)launches > (unsigned long long)(c->n_rows / 32) && !env_int("VG_SCAN_FILTER_NO_GUARD", 0))
@@ -170,6 +173,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     if (evs) hipEventRecord(evs[2], stream);
     const int rcm = vg_launch_merge_one((const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys, stream);
     if (evs) hipEventRecord(evs[3], stream);
+    HIP_TRY(hipMemcpyAsync(c->h_filter_evals, c->d_filter_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     if (rcm != 0) return vg_fail(VG_ERR_HIP, "merge launch failed: %s", hipGetErrorString((hipError_t)rcm));
     HIP_TRY(hipGetLastError());
     return VG_OK;

@@ -95,8 +95,10 @@ struct vg_corpus {
     int64_t bf_rows = 0, bf_cap = 0;
     bool filter_disabled = false;                 // the shadow copy / norms did not fit HBM: single queries keep the plain f32 scan
     int scan_filter_mode = -1;                    // vg_corpus_set_scan_filter: -1 = default (env VG_SCAN_FILTER, else on), 0 = off, 1 = on
-    unsigned long long *d_filter_evals = nullptr; // filter scan: exact evaluations so far - a counter in PINNED HOST memory the kernels add to
-                                                  //   (one atomic per workgroup), so the host can look at it without a copy or a wait
+    unsigned long long *d_filter_evals = nullptr; // filter scan: exact evaluations so far (device counter, one atomic per workgroup) ...
+    unsigned long long *h_filter_evals = nullptr; // ... and its pinned host mirror, refreshed by an 8-byte copy behind every filter launch: the
+                                                  //   host can look at it without a wait (system-scope atomics straight into host memory were
+                                                  //   tried: 256 of them per launch serialise on the host link, +160 us per scan)
     unsigned long long filter_evals_read = 0;     // its value at the last vg_filter_exact_evals read-out
     unsigned long long filter_evals_seen = 0;     // ... and when the selectivity guard last looked
     long long filter_launches_seen = 0, filter_launches = 0;

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void vg_below_kernel(const float *dist, long l
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (base + j >= from && base + j < n && v[j] < bound) mine |= 1u << j;
         const int cnt = __popc(mine);
+        if (__ballot(mine != 0u) == 0ull) continue;          // nearly every wavefront: nothing below the bound in its 256 rows
         // wave-level slot reservation: exclusive prefix of cnt over the lanes, one atomic per wavefront
         int incl = cnt;
 #pragma unroll
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void vg_below_kernel(const float *dist, long l
     }
 }
 
-#define VG_REF_PINNED_BYTES ((size_t)1 << 20)
+#define VG_REF_PINNED_BYTES ((size_t)4 << 20)
 static int ensure_ref_pinned(vg_corpus *c) {
     if (c->h_ref) return VG_OK;
     HIP_TRY(hipHostMalloc(&c->h_ref, VG_REF_PINNED_BYTES));

@@ -62,9 +62,10 @@ struct VgRefSlots {
 };
 
 // rows of the stream the host replays before it asks the device for candidates: balances the host's work on the prefix
-// (P rows) against the expected number of candidates behind it (~ k N / P)
+// (P rows at ~2 ns each) against the expected number of candidates behind it (~ k N / P, each copied, sorted and replayed:
+// ~30 ns) - the optimum is ~4 sqrt(k N); at 10M rows, k = 20: 57k prefix rows, ~3500 candidates (one 64 KiB copy)
 static inline int64_t vg_ref_prefix_rows(int64_t n, int k) {
-    int64_t p = (int64_t)std::sqrt((double)k * (double)n);
+    int64_t p = 4 * (int64_t)std::sqrt((double)k * (double)n);
     if (p < 4096) p = 4096;
     if (p < 4 * (int64_t)k) p = 4 * (int64_t)k;
     return p < n ? p : n;

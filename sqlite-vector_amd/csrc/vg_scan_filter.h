@@ -307,8 +307,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
         __syncthreads();
         if (lane == 0 && n_exact) atomicAdd(blk, n_exact);
         __syncthreads();
-        // (the counter lives in pinned host memory: a system-scope atomic)
-        if (threadIdx.x == 0 && *blk) __hip_atomic_fetch_add(a.evals, (unsigned long long)*blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0 && *blk) atomicAdd(a.evals, (unsigned long long)*blk);
         __syncthreads();
     }
     vg_block_publish(smem, mine, k, a.cand + (long long)blockIdx.x * VG_WAVE);

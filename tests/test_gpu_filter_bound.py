@@ -25,6 +25,14 @@ DOWN = np.float32(1 + 2.0 ** -8 - 2.0 ** -20)    # just below a bf16 midpoint: r
 UP = np.float32(1 + 2.0 ** -8 + 2.0 ** -20)      # just above it: rounds UP to 1 + 2^-7
 
 
+@pytest.fixture(autouse=True)
+def _no_selectivity_guard(request, monkeypatch):
+    """these tests compare the FILTER kernel with the plain one: the selectivity guard (which sends an unselective corpus back
+    to the plain kernel) must not quietly make such a comparison vacuous; its own test switches it back on"""
+    if "guard" not in request.node.name:
+        monkeypatch.setenv("VG_SCAN_FILTER_NO_GUARD", "1")
+
+
 def bf16_round(x):
     return dg.bf16_bits_to_f32(dg.f32_to_bf16_bits(x))
 

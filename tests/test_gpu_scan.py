@@ -356,6 +356,7 @@ def test_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, vt, dim, monke
     with the plain kernel's accumulator in its summation order (vg_scan_filter.h): rowids and distance BITS must equal the
     plain scan's (filter off), for ordinary rows, edge rows (NaN / Inf / huge / tiny / zero / subnormal) and edge queries."""
     monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")         # (by default only corpora >= 3 GB / 1 GB take the filter scan)
+    monkeypatch.setenv("VG_SCAN_FILTER_NO_GUARD", "1")       # (edge queries make every row a candidate: keep the filter kernel under test)
     n = 60_007
     rows = dg.corpus(vt, n, dim, 9700 + dim)
     _, edge = dg.edge_rows(vt, dim, 9800 + dim)
@@ -394,6 +395,7 @@ def test_filter_scan_with_its_prepass_on_clustered_rows(pkg, orc, vt, dim, monke
     """n >= 2^20: the filter scan starts from its plain pre-pass' threshold; clustered unit-norm rows + near-duplicates of
     the query; every metric the filter serves; compared with the plain scan and the oracle"""
     monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    monkeypatch.setenv("VG_SCAN_FILTER_NO_GUARD", "1")
     n = (1 << 20) + 777
     rng = np.random.default_rng(8800 + dim)
     centres = rng.standard_normal((9, dim)).astype(np.float32)
