@@ -562,7 +562,7 @@ def main():
                 c3.scan_topk(m3, q3[0], k)
                 t0 = time.perf_counter()
                 for i in range(10):
-                    c3.scan_topk(m3, q3[1 + i], k)
+                    c3.scan_topk(m3, q3[(1 + i) % nq], k)
                 tie["ms_per_query_%s" % name] = (time.perf_counter() - t0) / 10 * 1e3
             c3.set_tie_order(pkg.TIE_POSITION)
             tie["what"] = "vg_scan_topk end to end, top-%d; reference = store-mode scan + device compaction of the rows below the bound + host slot replay" % k

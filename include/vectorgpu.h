@@ -85,10 +85,13 @@ int vg_corpus_append_device(vg_corpus *c, const void *dev_rows, int64_t n_rows, 
 /* ---- the hot path ---- */
 /* One query (dim elements of the corpus type, host memory) -> the k best rows.
  * out_rowids[k], out_dist[k] (float values widened to double, like vFullScanCursor.distance), *out_count <= k.
- * f32 corpora, L2 / SQUARED_L2 / DOT, k <= 64: the scan streams a bf16 shadow copy of the corpus (built on the first such
- * scan after rows were appended; + 50 % device memory) as a lower-bound filter and re-evaluates the candidates on the f32
- * rows - the same rowids and distance bits as the plain f32 scan, from half the bytes.  vg_corpus_set_scan_filter(c, 0) /
- * VG_SCAN_FILTER=0 turn it off; a corpus whose shadow copy does not fit device memory keeps the plain scan by itself. */
+ * Large f32 / f16 / bf16 corpora, k <= 64 (L2 / SQUARED_L2 / DOT / COSINE; f16 / bf16 also L1): the scan goes through a
+ * provable LOWER BOUND of every row's distance and evaluates only the candidates exactly, with the plain kernel's own
+ * arithmetic - the same rowids and distance bits as the plain scan.  f32 corpora (>= 3 GB) stream a bf16 shadow copy for it
+ * (built on the first such scan after rows were appended; + 50 % device memory; half the bytes per query), f16 / bf16 corpora
+ * (>= 1 GB) their own rows (the bound replaces the reference's f64 chain for non-candidates).  vg_corpus_set_scan_filter(c, 0)
+ * / VG_SCAN_FILTER=0 turn it off; a corpus whose shadow copy does not fit device memory, or whose rows the bound cannot tell
+ * apart (it evaluates more than 1/32 of them), keeps the plain scan by itself. */
 int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k,
                  int64_t *out_rowids, double *out_dist, int *out_count);
 
