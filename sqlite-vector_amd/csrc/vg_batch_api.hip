@@ -82,7 +82,11 @@ static bool batch_i8_eligible(const vg_corpus *c, int metric, int k) {
     return vg_batch_i8_lds_bytes(c->stride, k) != 0;
 }
 
-// row sums (+ the flipped copy for uint8), once per appended row
+// row sums + the TILE-MAJOR copy of the corpus the matrix-core kernel streams (uint8: XOR 0x80 = the signed representation the
+// instruction multiplies), once per appended row.  Tile t = rows 32t .. 32t+31 occupies 32 * stride contiguous bytes laid out
+// exactly like the kernel's LDS tile (chunk column c of the 32 rows = 512 contiguous bytes at c * 512 + row * 16), so that every
+// LDS-DMA instruction of the kernel moves 1 KiB of CONTIGUOUS memory.  Gathering 32-byte runs from 32 rows of the row-major
+// corpus instead held the DMA path at ~13 GB/s per CU - what bounded the kernel (vg_batch_i8.hip).
 static int ensure_i8_row_stats(vg_corpus *c) {
     const bool u8 = (c->vtype == VG_TYPE_U8);
     if (c->i8_cap < c->n_rows) {
@@ -95,7 +99,9 @@ static int ensure_i8_row_stats(vg_corpus *c) {
         // + one tile of slack: the batch kernel fetches the sums of a whole 32-row tile, also behind the last row
         HIP_TRY(hipMalloc(&c->d_sx, (size_t)(cap + 64) * sizeof(int32_t)));
         HIP_TRY(hipMalloc(&c->d_sxx, (size_t)(cap + 64) * sizeof(uint32_t)));
-        if (u8) HIP_TRY(hipMalloc(&c->d_rows_s8, (size_t)cap * c->stride));
+        const size_t tiled_bytes = (size_t)((cap + 31) / 32 * 32) * c->stride;               // whole tiles
+        HIP_TRY(hipMalloc(&c->d_rows_s8, tiled_bytes));
+        HIP_TRY(hipMemsetAsync(c->d_rows_s8, 0, tiled_bytes, c->stream));                  // (rows past the end: defined bytes)
         c->i8_cap = cap;
     }
     if (c->i8_rows < c->n_rows) {
@@ -169,7 +175,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     const int mode = metric == VG_DIST_DOT ? 0 : (metric == VG_DIST_COSINE ? 1 : 2), root = metric == VG_DIST_L2 ? 1 : 0;
     int rc;
     if (quantized)
-        rc = vg_batch_i8_launch(c->vtype == VG_TYPE_U8 ? c->d_rows_s8 : c->d_rows, c->n_rows, c->stride, (const uint8_t *)c->d_bq,
+        rc = vg_batch_i8_launch(c->d_rows_s8, c->n_rows, c->stride, (const uint8_t *)c->d_bq,
                                 nq_pad, nq, k, mode, root, c->vtype == VG_TYPE_U8 ? 1 : 0, c->d_sx, c->d_sxx, c->d_bcand, npart,
                                 tiles_per_part, c->d_bkeys, c->stream);
     else if (half)

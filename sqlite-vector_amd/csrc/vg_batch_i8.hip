@@ -80,7 +80,8 @@ extern "C" int vg_batch_i8_timing(unsigned long long *out8, int reset) {
 #endif
 
 struct BatchArgsI8 {
-    const uint8_t *rows;      // N x stride bytes, SIGNED representation (int8 corpus as is, uint8 corpus XOR 0x80)
+    const uint8_t *rows;      // the TILE-MAJOR copy in SIGNED representation (int8 bytes as they are, uint8 XOR 0x80): tile t = rows
+                              // 32t .. 32t+31 = 32 * stride contiguous bytes, chunk column c of the 32 rows at c * 512 + row * 16
     const uint8_t *queries;   // nq_pad x stride bytes in the corpus' own (unflipped) representation, zero padded
     const int32_t *row_sx;    // sum x per row (original representation)
     const uint32_t *row_sxx;  // sum x^2 per row
@@ -197,15 +198,16 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
         const int p = wave + i * WAVES;
+#ifdef VGI_ABLATE_HALF_DMA      // measurement build (WRONG results): only every second piece of a tile is fetched
+        piece_mask[i] = __ballot(p < npieces && (p & 1) == 0 && (2 * p + h) < chunks_per_row);
+#else
         piece_mask[i] = __ballot(p < npieces && (2 * p + h) < chunks_per_row);
+#endif
     }
     // rows past the end of the corpus (last tile only) re-read the last row: their scores are masked by the row bound
-    auto lane_offset = [&](long long tile) -> uint32_t {
-        const long long row0 = tile * VGI_TILE;
-        const long long last = a.n_rows - 1 - row0;             // >= 0: the tile exists
-        const uint32_t xr = (uint32_t)((long long)x < last ? (long long)x : last);
-        return xr * (uint32_t)a.stride + (uint32_t)h * 16u;
-    };
+    // (the tile-major copy holds whole tiles: rows past the end of the corpus read whatever the allocation holds there, their
+    //  scores are masked by the row bound)
+    auto lane_offset = [&](long long) -> uint32_t { return (uint32_t)lane * 16u; };
     // The per-row sums of a tile ride the same pipeline (two 128-byte pieces, issued by the last wavefront): read
     // with ordinary loads at the tile boundary they cost a full L2 / HBM round trip per tile - with only 8..32
     // MFMAs per tile that latency WAS the kernel time (7 ms of the 10.7 at D = 768, and independent of D).
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
     };
     auto dma_piece = [&](long long tile, uint32_t lane_goff, int buf, int i) {
         const int p = wave + i * WAVES;
-        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGI_TILE) * stride_b + (unsigned)p * 32u;
+        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGI_TILE) * stride_b + (unsigned)p * 1024u;   // 1 KiB contiguous
         const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + p * 1024);
         uint32_t keep;
         uint64_t keep_exec;
@@ -244,16 +246,21 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
 #ifndef VGI_FOLD
 #define VGI_FOLD 1                      // 0: the round-1 boundary for every metric (accumulators start at 0, 3-5 VALU operations per register and tile)
 #endif
-    // (measured, profiles/r2g: dot 9.05 -> 9.01 ms - its tile then waits longer for the DMA instead -, L2 9.44 -> 9.10, D = 1024 13.6 -> 12.2;
-    //  cosine got SLOWER, 9.78 -> 10.11: the lane's loosest gate lets the per-register pass run too often - cosine keeps the round-1 boundary)
-    constexpr bool FOLD = (VGI_FOLD != 0) && !COS;
+    // (measured, profiles/r2g: dot 9.05 -> 9.01 ms - its tile then waited longer for the DMA instead, until the tile-major copy -, L2 9.44 -> 9.10,
+    //  D = 1024 13.6 -> 12.2; a first cosine variant - the lane's LOOSEST gate as a pre-test - was slower, 9.78 -> 10.11: it fired too often)
+    constexpr bool FOLD = (VGI_FOLD != 0);
     // FOLDED GATES: the accumulator of register r STARTS at acc_init[r] instead of 0 (integer sums: exact), so that the tile
     // boundary needs ONE max over the 16 registers and one comparison per lane instead of 3-5 operations per register:
     //   dot     init = -gate_i                  any pair passes  <=>  max_r acc' + cx >= 0
     //   L2      init = -(gate_i >> 1)           any pair passes   =>  max_r acc' - ((xx - 2 cx) >> 1) >= 0     (floors: a superset)
-    //   cosine  (row norms differ per lane: no folding; tried with the lane's loosest gate as a first test - slower, see below)
+    //   cosine  init = cq + 1 (query part of q.x + 1): q.x >= G nb - 1  <=>  (q.x + 1) / G >= nb for a closed gate G > 0, so
+    //           any pair passes  <=>  max_r float(acc' + cx) * (1 / G_r) >= nb   - 3 operations per register instead of 5, the 16 results
+    //           are comparable (one max tree, one comparison with the lane's row norm); registers whose gate is still open (G <= 0:
+    //           list not full) are flagged in open_mask and always pass
     // The exact distance test in reg_insert is unchanged (it gets the raw accumulator acc' - init back).
     int acc_init[16];
+    float invg[16];                                      // cosine: (1 + 1e-6) / gate_f of a closed gate
+    uint32_t open_mask = 0;                              // cosine: registers whose gate is open (accept everything)
     const bool l2_root = a.root != 0;
     auto as_float_like = [](uint32_t v) -> float { return IS_U8 ? (float)v : (float)(int32_t)v; };
     // gates are supersets of "distance <= thr" (exact test in reg_insert):
@@ -276,7 +283,12 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
             const int Gq = (Gf > -1.5e9f) ? (int)floorf(Gf) : -1500000000;  // thr = +Inf: accept everything (|qx| < 2^27)
             gate_i[r] = Gq - cq_reg[r];
         }
-        acc_init[r] = !FOLD ? 0 : (L2M ? -(gate_i[r] >> 1) : -gate_i[r]);
+        acc_init[r] = !FOLD ? 0 : (COS ? cq_reg[r] + 1 : (L2M ? -(gate_i[r] >> 1) : -gate_i[r]));
+        if (COS) {
+            const bool closed = gate_f[r] > 1e-30f;
+            invg[r] = closed ? __fdividef(1.0f + 1e-6f, gate_f[r]) : 0.0f;
+            open_mask = closed ? (open_mask & ~(1u << r)) : (open_mask | (1u << r));
+        }
     };
 
     vgb_static_for<0, 16>([&](auto rc) {
@@ -293,7 +305,8 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
         if (q0 + qi >= a.nq_real) {                      // padding (an all-zero query ties every row at cosine 1.0)
             thr_reg[r] = -INFINITY;
             if (COS) gate_f[r] = 3.0e38f; else gate_i[r] = 1500000000;
-            acc_init[r] = !FOLD ? 0 : (L2M ? -(gate_i[r] >> 1) : -gate_i[r]);
+            acc_init[r] = !FOLD ? 0 : (COS ? cq_reg[r] + 1 : (L2M ? -(gate_i[r] >> 1) : -gate_i[r]));
+            if (COS) { invg[r] = 0.0f; open_mask &= ~(1u << r); }
         }
     });
 
@@ -406,7 +419,22 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
         const int cx = IS_U8 ? 128 * sx : 0;
         unsigned pend = 0;
         bool any;
-        if constexpr (FOLD) {
+        if constexpr (FOLD && COS) {
+            const float nb = sqrtf(as_float_like(xx));
+            float fmax = -INFINITY;
+            vgb_static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                fmax = fmaxf(fmax, as_float_like((uint32_t)(acc[r] + cx)) * invg[r]);       // (q.x + 1) / G_r
+            });
+            any = __ballot(open_mask != 0u || fmax >= nb) != 0;
+            if (any) {
+                vgb_static_for<0, 16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    const float qxf = as_float_like((uint32_t)(acc[r] - 1 + cx));
+                    pend |= __ballot(qxf + 1.0f - gate_f[r] * nb >= 0.0f) ? (1u << r) : 0u;
+                });
+            }
+        } else if constexpr (FOLD) {
             int amax = acc[0];                           // max over the lane's 16 folded accumulators: 8 x v_max3
             vgb_static_for<1, 16>([&](auto rc) { constexpr int r = decltype(rc)::value; amax = acc[r] > amax ? acc[r] : amax; });
             const int h2 = L2M ? (((int)xx - 2 * cx) >> 1) : -cx;
@@ -646,17 +674,20 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
 }
 
 #ifndef VGI_TU_PRE
-// ---- per-row sums of the ORIGINAL representation + (uint8) the XOR-0x80 copy the matrix core reads
+// ---- per-row sums of the ORIGINAL representation + the tile-major copy the matrix core reads (uint8: XOR 0x80)
 template <bool IS_U8>
 __global__ __launch_bounds__(256) void vg_i8_rowstat_kernel(const uint8_t *rows, long long row0, long long n, long long stride,
-                                                            int32_t *sx, uint32_t *sxx, uint8_t *flipped) {
+                                                            int32_t *sx, uint32_t *sxx, uint8_t *tiled) {
     const int sub = threadIdx.x & 15;
     const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const long long ngroups = ((long long)gridDim.x * blockDim.x) >> 4;
     const int nch = (int)(stride / 16);
     for (long long r = group; r < n; r += ngroups) {
         const uint4 *p = reinterpret_cast<const uint4 *>(rows + (row0 + r) * stride);
-        uint4 *o = flipped ? reinterpret_cast<uint4 *>(flipped + (row0 + r) * stride) : nullptr;
+        // chunk c of row R lives at tile (R / 32) * (32 * stride) + c * 512 + (R % 32) * 16 of the tile-major copy
+        const long long R = row0 + r;
+        uint8_t *o = tiled ? tiled + (R >> 5) * (32 * stride) + (R & 31) * 16 : nullptr;
+        const uint32_t flip = IS_U8 ? 0x80808080u : 0u;
         uint32_t s1 = 0, s2 = 0;
         for (int c = sub; c < nch; c += 16) {
             const uint4 v = p[c];
@@ -666,7 +697,7 @@ __global__ __launch_bounds__(256) void vg_i8_rowstat_kernel(const uint8_t *rows,
                 if (IS_U8) { s1 = __builtin_amdgcn_udot4(w[j], 0x01010101u, s1, false); s2 = __builtin_amdgcn_udot4(w[j], w[j], s2, false); }
                 else { s1 = (uint32_t)__builtin_amdgcn_sdot4((int)w[j], 0x01010101, (int)s1, false); s2 = (uint32_t)__builtin_amdgcn_sdot4((int)w[j], (int)w[j], (int)s2, false); }
             }
-            if (o) o[c] = make_uint4(v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u);
+            if (o) *reinterpret_cast<uint4 *>(o + (long long)c * 512) = make_uint4(v.x ^ flip, v.y ^ flip, v.z ^ flip, v.w ^ flip);
         }
         s1 += __shfl_xor(s1, 8); s1 += __shfl_xor(s1, 4); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 1);
         s2 += __shfl_xor(s2, 8); s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 2); s2 += __shfl_xor(s2, 1);
@@ -680,7 +711,7 @@ extern "C" int vg_i8_rowstat_launch(const uint8_t *dev_rows, long long row0, lon
     long long blocks = (n * 16 + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (is_u8) hipLaunchKernelGGL((vg_i8_rowstat_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, stream, dev_rows, row0, n, stride, dev_sx, dev_sxx, dev_flipped);
-    else hipLaunchKernelGGL((vg_i8_rowstat_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, stream, dev_rows, row0, n, stride, dev_sx, dev_sxx, (uint8_t *)nullptr);
+    else hipLaunchKernelGGL((vg_i8_rowstat_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, stream, dev_rows, row0, n, stride, dev_sx, dev_sxx, dev_flipped);
     return (int)hipGetLastError();
 }
 
