@@ -32,3 +32,30 @@ __device__ __forceinline__ uint64_t vgb_list_insert(uint64_t *list, int k, int l
 __device__ __forceinline__ float vgb_kth_distance(uint64_t kth) {
     return (kth == VG_EMPTY_KEY) ? INFINITY : vg_sortable_f32((uint32_t)(kth >> 32));
 }
+
+// ---- STAGED REAL PASSES (host side).  A two-pass launch starts every list of the real pass at the query's k-th best of a
+// pre-pass over 1/32 of the rows: ~k * 32 rows per query still beat that threshold in the real pass (655k slow-path entries
+// for 1024 queries x 10M rows), and each of them holds its workgroup at a tile barrier.  The real pass therefore runs in
+// STAGES over growing row ranges [0, 2P), [2P, 4P), [4P, 8P) ... (P = the pre-pass rows): the lists are merged after every
+// stage and the next one starts from the query's k-th best over ALL rows scanned so far - a stage that doubles the scanned
+// range lets ~k rows per query through, ~6k per query in all instead of 32k.  From the second stage on, partition 0 of a
+// query group seeds its lists with the merged keys (they stand for rows of EARLIER stages, which no later stage meets again),
+// so every stage writes - and every merge reads - the same npart lists per query.
+// bounds[0 .. n]: stage i scans tiles [bounds[i], bounds[i+1]); returns n.  growth_pct: VG_BATCH_STAGES (200 = doubling,
+// 0 = one real pass over everything).
+#include <cstdlib>
+static inline int vgb_stage_bounds(long long ntiles, long long pre_tiles, long long *bounds, int max_stages) {
+    const char *e = getenv("VG_BATCH_STAGES");
+    const int growth_pct = (e && *e) ? atoi(e) : 200;
+    int n = 0;
+    bounds[0] = 0;
+    if (pre_tiles > 0 && growth_pct > 100) {
+        long long b = 2 * pre_tiles;
+        while (b < ntiles && n + 2 < max_stages && ntiles - b > b / 4) {      // (no sliver at the end)
+            bounds[++n] = b;
+            b = b * growth_pct / 100;
+        }
+    }
+    bounds[++n] = ntiles;
+    return n;
+}

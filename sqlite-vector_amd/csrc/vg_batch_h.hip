@@ -86,6 +86,7 @@ struct BatchArgsH {
     long long tile_begin, tile_end;
     int part_base, npart_total;
     const uint64_t *init_keys;
+    int seed;                 // staged real passes (vg_batch_common.h): partition 0 starts its lists from init_keys
 };
 
 template <int OFF>
@@ -210,7 +211,11 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
         if (q0 + lane >= a.nq_real) t = -INFINITY;
         thr_w[lane] = t;
     }
-    for (int s = lane; s < VGH_QPW * k; s += 64) wave_lists[s] = VG_EMPTY_KEY;
+    {
+        const bool seeded = a.seed != 0 && part == 0;                  // (exact keys of rows no later stage meets again)
+        for (int s = lane; s < VGH_QPW * k; s += 64)
+            wave_lists[s] = seeded ? a.init_keys[(long long)(q0 + s / k) * 64 + s % k] : VG_EMPTY_KEY;
+    }
     for (int s = tid; s < 2 * TILE_BYTES / 4; s += THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = 0u;   // pad columns
     __syncthreads();
 
@@ -665,8 +670,8 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long
         if (denom > 0 && ntiles >= 65536) pre = ((ntiles / denom + npart - 1) / npart) * npart;      // whole partitions; < 2M rows: one pass
     }
     int rc;
-    a.npart_total = npart;                                        // both passes write (and the merges read) lists 0 .. npart-1
-    a.part_base = 0;
+    a.npart_total = npart;                                        // every pass writes (and the merges read) lists 0 .. npart-1
+    a.part_base = 0; a.seed = 0;
     if (pre > 0) {
         a.tile_begin = 0; a.tile_end = pre; a.tiles_per_part = (int)(pre / npart); a.init_keys = nullptr;
         if ((rc = launch(a, true)) != 0) return rc;
@@ -675,8 +680,18 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long
     } else {
         a.init_keys = nullptr;
     }
-    a.tile_begin = 0; a.tile_end = ntiles; a.tiles_per_part = (int)((ntiles + npart - 1) / npart);
-    if ((rc = launch(a, false)) != 0) return rc;
-    return vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream);
+    // the real pass, in stages over growing row ranges (vg_batch_common.h): the first one scans the pre-pass rows again (their
+    // lists hold bounds, not distances), every later one starts from - and partition 0 carries on - the merged lists so far
+    long long bounds[16];
+    const int nstages = vgb_stage_bounds(ntiles, pre, bounds, 16);
+    for (int s = 0; s < nstages; ++s) {
+        a.tile_begin = bounds[s]; a.tile_end = bounds[s + 1];
+        a.tiles_per_part = (int)((a.tile_end - a.tile_begin + npart - 1) / npart);
+        a.seed = (s > 0) ? 1 : 0;
+        if ((rc = launch(a, false)) != 0) return rc;
+        if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream)) != 0) return rc;
+        a.init_keys = dev_out_keys;
+    }
+    return 0;
 }
 #endif   // VGH_TU

@@ -94,6 +94,7 @@ struct BatchArgsI8 {
     long long tile_begin, tile_end;
     int part_base, npart_total;
     const uint64_t *init_keys;
+    int seed;                 // staged real passes (vg_batch_common.h): partition 0 starts its lists from init_keys
 };
 
 template <int CTRL> __device__ __forceinline__ uint64_t vgi_dpp64(uint64_t v) {
@@ -178,7 +179,9 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
     {
         const uint32_t sq = sq_part + __shfl_xor(sq_part, 32), sqq = sqq_part + __shfl_xor(sqq_part, 32);
         if (h == 0) { qs_w[2 * x] = sq; qs_w[2 * x + 1] = sqq; }
-        for (int s = lane; s < VGI_QPW * k; s += 64) wave_lists[s] = VG_EMPTY_KEY;
+        const bool seeded = a.seed != 0 && part == 0;               // (keys of rows no later stage meets again)
+        for (int s = lane; s < VGI_QPW * k; s += 64)
+            wave_lists[s] = seeded ? a.init_keys[(long long)(q0 + s / k) * 64 + s % k] : VG_EMPTY_KEY;
     }
     // pad columns never touched by the DMA must read as "0" of the original representation
     for (int s = tid; s < NBUF * TILE_BYTES / 4; s += THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = IS_U8 ? 0x80808080u : 0u;
@@ -816,15 +819,25 @@ extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_ro
         if (denom > 0 && ntiles >= 65536) pre = ((ntiles / denom + npart - 1) / npart) * npart;      // < 2M rows: one pass
     }
     int rc;
-    a.npart_total = npart; a.part_base = 0; a.init_keys = nullptr;
+    a.npart_total = npart; a.part_base = 0; a.init_keys = nullptr; a.seed = 0;
     if (pre > 0) {
         a.tile_begin = 0; a.tile_end = pre; a.tiles_per_part = (int)(pre / npart);
         if ((rc = vgi_launch_pre(&a, ntb, blocks, smem, stream)) != 0) return rc;
         if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream)) != 0) return rc;
         a.init_keys = dev_out_keys;
     }
-    a.tile_begin = 0; a.tile_end = ntiles; a.tiles_per_part = (int)((ntiles + npart - 1) / npart);
-    if ((rc = vgi_launch_real(&a, ntb, blocks, smem, stream)) != 0) return rc;
-    return vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream);
+    // the real pass, in stages over growing row ranges (vg_batch_common.h): the first one meets the pre-pass rows again (their
+    // lists hold tile minima only), every later one starts from - and partition 0 carries on - the merged lists so far
+    long long bounds[16];
+    const int nstages = vgb_stage_bounds(ntiles, pre, bounds, 16);
+    for (int s = 0; s < nstages; ++s) {
+        a.tile_begin = bounds[s]; a.tile_end = bounds[s + 1];
+        a.tiles_per_part = (int)((a.tile_end - a.tile_begin + npart - 1) / npart);
+        a.seed = (s > 0) ? 1 : 0;
+        if ((rc = vgi_launch_real(&a, ntb, blocks, smem, stream)) != 0) return rc;
+        if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream)) != 0) return rc;
+        a.init_keys = dev_out_keys;
+    }
+    return 0;
 }
 #endif   // !VGI_TU_PRE

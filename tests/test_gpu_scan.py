@@ -930,3 +930,49 @@ def test_batch_larger_than_one_slice(pkg, monkeypatch):
     b = c.scan_topk_batch(dg.DOT, qs, k)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     c.close()
+
+
+@pytest.mark.parametrize("vt", (dg.U8, dg.F16))
+def test_batch_staged_real_passes_with_ties_across_stage_boundaries(pkg, vt, monkeypatch):
+    """>= 2^16 tiles: the real pass runs in stages over growing row ranges, each one starting from (and partition 0 carrying
+    on) the merged lists of the rows before it (vg_batch_common.h).  Low-entropy rows make every list a chain of ties that
+    straddles the stage boundaries; copies of one query's best row sit in the pre-pass range, in the first stage, exactly at
+    stage boundaries and in the last stage.  Every growth setting and the single real pass must return the lists of the
+    single-query scans - rowid for rowid, bit for bit for uint8."""
+    dim, n, k, nq = 32, 2_300_000, 20, 40
+    rng = np.random.default_rng(123)
+    if vt == dg.U8:
+        rows = rng.integers(0, 3, (n, dim)).astype(np.uint8)           # 3 levels: huge tie classes
+        qs = rng.integers(0, 3, (nq, dim)).astype(np.uint8)
+        qs[5] = rng.integers(0, 256, dim).astype(np.uint8)
+        special = (rng.integers(0, 256, dim).astype(np.uint8) // 2 + 64)
+    else:
+        rows = dg.to_storage(vt, rng.integers(-1, 2, (n, dim)).astype(np.float32))
+        qs = dg.to_storage(vt, rng.integers(-1, 2, (nq, dim)).astype(np.float32))
+        special = dg.to_storage(vt, rng.standard_normal((1, dim), dtype=np.float32) * 3)[0]
+    ntiles = (n + 31) // 32
+    pre = ntiles // 32
+    spots = [3, 32 * pre - 1, 32 * pre, 64 * pre - 1, 64 * pre, 64 * pre + 1, 128 * pre - 1, 128 * pre, 256 * pre, 512 * pre - 1,
+             512 * pre, n - 2]
+    spots += [int(x) for x in rng.integers(0, n, 14)]                   # 26 copies > k: the tie class itself is cut by position
+    for s in spots:
+        rows[min(s, n - 1)] = special
+    qs[7] = special
+    c = pkg.Corpus(vt, dim, capacity=n)
+    c.append(rows)
+    for metric in (dg.DOT, dg.COSINE, dg.L2):
+        singles = [c.scan_topk(metric, qs[i], k) for i in range(nq)]
+        for growth in ("200", "0", "130", "400"):
+            monkeypatch.setenv("VG_BATCH_STAGES", growth)
+            ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+            for i in range(nq):
+                one_ids, one_dist = singles[i]
+                assert cnt[i] == k, (metric, growth, i)
+                if vt == dg.U8:
+                    assert ids[i].tolist() == one_ids.tolist(), (metric, growth, i)
+                    assert np.array_equal(dist[i], one_dist), (metric, growth, i)
+                else:
+                    _same_topk_up_to_ties(ids[i], dist[i], one_ids, one_dist)
+                    if metric != dg.COSINE:                              # small integers: both paths are exact, ties go by position
+                        assert ids[i].tolist() == one_ids.tolist(), (metric, growth, i)
+    c.close()
