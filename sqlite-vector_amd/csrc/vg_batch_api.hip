@@ -22,10 +22,10 @@ extern "C" int vg_rownorm_launch(const float *dev_rows, long long row0, long lon
 extern "C" size_t vg_batch_i8_lds_bytes(long long stride_bytes, int k);
 extern "C" int vg_batch_i8_queries_per_block(long long stride_bytes);
 extern "C" int vg_i8_rowstat_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int is_u8,
-                                    int32_t *dev_sx, uint32_t *dev_sxx, uint8_t *dev_flipped, hipStream_t stream);
+                                    uint32_t *dev_stat, uint8_t *dev_flipped, hipStream_t stream);
 extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_rows, long long stride_bytes,
                                   const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root, int is_u8,
-                                  const int32_t *dev_sx, const uint32_t *dev_sxx, uint64_t *dev_cand, int npart,
+                                  const uint32_t *dev_row_stat, uint64_t *dev_cand, int npart,
                                   int tiles_per_part, uint64_t *dev_out_keys, hipStream_t stream);
 
 // ---- f16 / bf16 batches: matrix-core filter + exact f64 re-evaluation (vg_batch_h.hip)
@@ -93,19 +93,18 @@ static int ensure_i8_row_stats(vg_corpus *c) {
         const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_sx) hipFree(c->d_sx);
-        if (c->d_sxx) hipFree(c->d_sxx);
         if (c->d_rows_s8) hipFree(c->d_rows_s8);
-        c->d_sx = nullptr; c->d_sxx = nullptr; c->d_rows_s8 = nullptr; c->i8_cap = 0; c->i8_rows = 0;
-        // + one tile of slack: the batch kernel fetches the sums of a whole 32-row tile, also behind the last row
-        HIP_TRY(hipMalloc(&c->d_sx, (size_t)(cap + 64) * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&c->d_sxx, (size_t)(cap + 64) * sizeof(uint32_t)));
+        c->d_sx = nullptr; c->d_rows_s8 = nullptr; c->i8_cap = 0; c->i8_rows = 0;
+        // (sum x, sum x^2) pairs; + slack: the batch kernel fetches the sums of four whole 32-row tiles at a time, also behind the last row
+        HIP_TRY(hipMalloc(&c->d_sx, (size_t)(cap + 256) * 2 * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(c->d_sx, 0, (size_t)(cap + 256) * 2 * sizeof(uint32_t), c->stream));
         const size_t tiled_bytes = (size_t)((cap + 31) / 32 * 32) * c->stride;               // whole tiles
         HIP_TRY(hipMalloc(&c->d_rows_s8, tiled_bytes));
         HIP_TRY(hipMemsetAsync(c->d_rows_s8, 0, tiled_bytes, c->stream));                  // (rows past the end: defined bytes)
         c->i8_cap = cap;
     }
     if (c->i8_rows < c->n_rows) {
-        int rc = vg_i8_rowstat_launch(c->d_rows, c->i8_rows, c->n_rows - c->i8_rows, c->stride, u8 ? 1 : 0, c->d_sx, c->d_sxx,
+        int rc = vg_i8_rowstat_launch(c->d_rows, c->i8_rows, c->n_rows - c->i8_rows, c->stride, u8 ? 1 : 0, c->d_sx,
                                       c->d_rows_s8, c->stream);
         if (rc != 0) return vg_fail(VG_ERR_HIP, "row-statistics pass failed: %s", hipGetErrorString((hipError_t)rc));
         c->i8_rows = c->n_rows;
@@ -176,7 +175,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     int rc;
     if (quantized)
         rc = vg_batch_i8_launch(c->d_rows_s8, c->n_rows, c->stride, (const uint8_t *)c->d_bq,
-                                nq_pad, nq, k, mode, root, c->vtype == VG_TYPE_U8 ? 1 : 0, c->d_sx, c->d_sxx, c->d_bcand, npart,
+                                nq_pad, nq, k, mode, root, c->vtype == VG_TYPE_U8 ? 1 : 0, c->d_sx, c->d_bcand, npart,
                                 tiles_per_part, c->d_bkeys, c->stream);
     else if (half)
         rc = vg_batch_h_launch(f32_filter ? c->d_rows_bf : c->d_rows, c->n_rows, fstride, c->dim,

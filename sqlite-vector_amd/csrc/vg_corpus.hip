@@ -120,7 +120,6 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_xnorm) hipFree(c->d_xnorm);
     if (c->d_sel_state) hipFree(c->d_sel_state);
     if (c->d_sx) hipFree(c->d_sx);
-    if (c->d_sxx) hipFree(c->d_sxx);
     if (c->d_rows_s8) hipFree(c->d_rows_s8);
     if (c->d_rows_bf) hipFree(c->d_rows_bf);
     if (c->d_filter_evals) hipFree(c->d_filter_evals);

@@ -88,8 +88,7 @@ struct vg_corpus {
     int64_t xnorm_rows = 0, xnorm_cap = 0;
     hipEvent_t norm_ev = nullptr;
     // quantized batches (vg_batch_i8.hip): per-row sum x / sum x^2 and, for uint8, the XOR-0x80 copy the matrix core reads
-    int32_t *d_sx = nullptr;
-    uint32_t *d_sxx = nullptr;
+    uint32_t *d_sx = nullptr;                     // per row: (sum x, sum x^2)
     uint8_t *d_rows_s8 = nullptr;
     uint8_t *d_rows_bf = nullptr;                 // f32 corpora: bf16 shadow copy for the matrix-core filter (vg_batch_h.hip)
     int64_t bf_rows = 0, bf_cap = 0;

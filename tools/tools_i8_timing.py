@@ -37,19 +37,20 @@ def main():
     rng = np.random.default_rng(44)
     qs = rng.integers(0, 256, (args.nq, args.dim)).astype(np.uint8)
     c.scan_topk_batch(args.metric, qs, 20)
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 16)()
     lib.vg_batch_i8_timing(out, 1)
     c.set_profiling(True)
     c.scan_topk_batch(args.metric, qs, 20)
     lib.vg_batch_i8_timing(out, 0)
     v = [int(x) for x in out]
-    names = ["k loop", "gate math", "inserts", "DMA wait", "barrier"]
-    tot = sum(v[:5])
-    print("dim %d metric %d nq %d: kernel ms (events) %.3f  wave-tiles %d  ticks per wave-tile %.1f" %
-          (args.dim, args.metric, args.nq, c.profile_mean_ms()[1], v[6], tot / max(v[6], 1)))
-    for n, x in zip(names, v[:5]):
-        print("  %-10s %5.1f %%   %8.1f ticks per wave-tile" % (n, 100.0 * x / tot, x / max(v[6], 1)))
-    print("  whole loop vs sum of phases: %.3f   wave-tiles with pending registers: %.2f %%" % (v[5] / max(tot, 1), 100.0 * v[7] / max(v[6], 1)))
+    tiles = max(v[6], 1)
+    print("dim %d metric %d nq %d: kernel ms (events) %.3f  wave-tiles %d  ticks per wave-tile (whole loop) %.1f" %
+          (args.dim, args.metric, args.nq, c.profile_mean_ms()[1], v[6], v[0] / tiles))
+    for n, x in zip(["first half of the k loop (+ test of the previous tile)", "mid-tile wait (DMA landed + barrier)",
+                     "slow path (exact distances, inserts)", "second half of the k loop (+ DMA issue)"], [v[3], v[1], v[2], v[4]]):
+        print("  %-58s %5.1f %%   %8.1f ticks per wave-tile" % (n, 100.0 * x / max(v[0], 1), x / tiles))
+    print("  wave-tiles that entered the slow path: %.2f %%" % (100.0 * v[7] / tiles))
+    print("  mid-tile wait per wavefront index 0..7 (ticks per tile): " + " ".join("%.0f" % (8.0 * x / tiles) for x in v[8:16]))
     c.close()
 
 
