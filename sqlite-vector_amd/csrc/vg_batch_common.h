@@ -41,12 +41,12 @@ __device__ __forceinline__ float vgb_kth_distance(uint64_t kth) {
 // range lets ~k rows per query through, ~6k per query in all instead of 32k.  From the second stage on, partition 0 of a
 // query group seeds its lists with the merged keys (they stand for rows of EARLIER stages, which no later stage meets again),
 // so every stage writes - and every merge reads - the same npart lists per query.
-// bounds[0 .. n]: stage i scans tiles [bounds[i], bounds[i+1]); returns n.  growth_pct: VG_BATCH_STAGES (200 = doubling,
+// bounds[0 .. n]: stage i scans tiles [bounds[i], bounds[i+1]); returns n.  growth_pct: VG_BATCH_STAGES (200 = doubling; default 400: three stages at 1/32 - fewer launches, the same survivors within 10 %;
 // 0 = one real pass over everything).
 #include <cstdlib>
 static inline int vgb_stage_bounds(long long ntiles, long long pre_tiles, long long *bounds, int max_stages) {
     const char *e = getenv("VG_BATCH_STAGES");
-    const int growth_pct = (e && *e) ? atoi(e) : 200;
+    const int growth_pct = (e && *e) ? atoi(e) : 400;
     int n = 0;
     bounds[0] = 0;
     if (pre_tiles > 0 && growth_pct > 100) {

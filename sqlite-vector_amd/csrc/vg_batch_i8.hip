@@ -14,11 +14,15 @@
 //     with sum x, sum x^2 per row from cached vectors (vg_i8_rowstat_kernel) and sum q, sum q^2 per query;
 //   * gates are integer margins on the raw accumulator for dot / L2 and one multiply per register for cosine; survivors get
 //     the exact distance and go through the same list insert as in vg_batch.hip;
-//   * THE SCHEDULE (rows up to 1 KiB) IS A SOFTWARE PIPELINE: a wavefront owns TWO accumulator sets and the gate math of
+//   * the schedule (rows up to 1 KiB) is a software pipeline: a wavefront owns TWO accumulator sets and the gate math of
 //     tile t runs under the MFMAs of tile t+1; tiles live in three LDS buffers, the one workgroup barrier per tile sits in
-//     the MIDDLE of the k loop (where it only orders buffer reuse), and the B-operand reads run on across tile ends - the
-//     MFMA stream of a wavefront never drains.  (The round-1 schedule - k loop, drain, gate math, barrier, first LDS reads,
-//     one after the other and in phase on all eight wavefronts - left the matrix pipe idle for 35-50 % of every tile.)
+//     the MIDDLE of the k loop (where it only orders buffer reuse), the B-operand reads run on across tile ends, the first
+//     wavefront of every SIMD issues the tile's LDS-DMA (contiguous pieces: one M0 set-up, back-to-back instructions);
+//   * what round 2 measured about this kernel (timing builds): the two wavefronts of a SIMD run in lockstep, so
+//     their non-MFMA work (DMA issue ~90-180 cycles per instruction, tests, barrier) adds to the 1536 MFMA cycles of a tile
+//     instead of hiding under them; neither issue priorities, nor a fourth buffer, nor alternating MFMA / everything-else
+//     roles with two accumulator chains per wavefront (a lone wavefront then issues an MFMA every 37 cycles, but every role
+//     switch costs ~500) changed that.  What did help: fewer survivors (staged passes), the tile-major copy, contiguous DMA;
 //   * large corpora: a pre-pass over 1/32 of the rows, then the real pass in stages over doubling row ranges, the lists
 //     merged and the thresholds refreshed in between (vg_batch_common.h).
 #include <hip/hip_runtime.h>
@@ -43,17 +47,13 @@ typedef int vgi_i32x4 __attribute__((ext_vector_type(4)));
 #ifndef VGI_BPIPE
 #define VGI_BPIPE 4                     // B-operand register quads in flight (LDS reads issued this many k-steps ahead)
 #endif
-#ifndef VGI_PRIO
-#define VGI_PRIO 0                      // issue priority of the two wavefronts of a SIMD (the arbiter prefers the older one: waves 0-3 reach the
-                                        // barrier ~450 cycles before waves 4-7).  1: first half of a tile waves 0-3 high, second half waves
-                                        // 4-7; 2: the other way round; 3: waves 4-7 always high
-#endif
 #ifndef VGI_PIPE
 #define VGI_PIPE 1                      // 0: every shape on the barrier-per-tile schedule (A/B measurements)
 #endif
-// Schedules measured and dropped in rounds 1-2 (profiles/r2b, r2c, r2d, r2g): the two wavefronts of a SIMD in
-// alternating phases, DMA two tiles ahead with counted waits, a 4-buffer ring with ready / free counters instead of the
-// barrier (also skewed by half a tile), two accumulator chains over even / odd k-steps, B reads 8 k-steps ahead.
+// Schedules measured and dropped in rounds 1-2 (profiles/r2b, r2c, r2d, r2g, r2t): the two wavefronts of a SIMD in
+// alternating phases (one chain each; two chains each over double tiles), DMA two tiles ahead with counted waits, a 4-buffer
+// ring with ready / free counters instead of the barrier (also skewed by half a tile), two accumulator chains over even / odd
+// k-steps, B reads 8 k-steps ahead, s_setprio on either wavefront of a SIMD or alternating by half tile.
 
 enum { VGI_DOT = 0, VGI_COS = 1, VGI_L2 = 2 };
 
@@ -203,21 +203,28 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
     const long long tile_last = min(tile_first + a.tiles_per_part, a.tile_end);
     const unsigned long long stride_b = (unsigned long long)a.stride;
     const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)tile0;
-    constexpr int NPIECE = (NTB + WAVES - 1) / WAVES;  // piece slots per wavefront and tile (compile time)
+#ifndef VGI_DMA_G0
+#define VGI_DMA_G0 1                    // the first wavefront of every SIMD (waves 0-3: the arbiter favours the older wavefront, they reach the
+                                        // barrier ~400 cycles early whatever they do) moves ALL pieces; 0: every wavefront its share (+2 %)
+#endif
+    constexpr int NISSUE = (VGI_DMA_G0 && WAVES == 8) ? 4 : WAVES;    // wavefronts that issue DMA
+    constexpr int NPIECE = (NTB + NISSUE - 1) / NISSUE;               // piece slots per issuing wavefront and tile (compile time)
+    // issuing wavefront w moves the CONTIGUOUS pieces w * NPIECE .. w * NPIECE + NPIECE - 1: one M0 set-up serves up to four
+    // of them (the instruction offset moves the global and the LDS address alike)
     uint64_t piece_mask[NPIECE];
-    int n_mine = 0;                                    // DMA instructions this wavefront issues per tile
+    bool all_full = wave < NISSUE;
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
-        const int p = wave + i * WAVES;
-        piece_mask[i] = __ballot(p < npieces && (2 * p + h) < chunks_per_row);
-        n_mine += piece_mask[i] != 0 ? 1 : 0;
+        const int p = wave * NPIECE + i;
+        piece_mask[i] = __ballot(wave < NISSUE && p < npieces && (2 * p + h) < chunks_per_row);
+        all_full = all_full && piece_mask[i] == ~0ull;
     }
     // (the tile-major copy holds whole tiles: rows past the end of the corpus read whatever the allocation holds there,
     //  their scores are masked by the row bound)
     const uint32_t lane_goff = (uint32_t)lane * 16u;
     auto dma_piece = [&](long long tile, int buf, int i) {
-        if (piece_mask[i] == 0) return;                           // (not issued at all: the counted waits below rely on it)
-        const int p = wave + i * WAVES;
+        if (piece_mask[i] == 0) return;
+        const int p = wave * NPIECE + i;
         const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGI_TILE) * stride_b + (unsigned)p * 1024u;   // 1 KiB contiguous
         const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + p * 1024);
         uint32_t keep;
@@ -226,7 +233,37 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
                      "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep), "=&s"(keep_exec) : "v"(lane_goff), "s"(sbase), "s"(lds_dst), "s"(piece_mask[i]) : "memory", "scc");
     };
+    // N (1 .. 4) whole pieces starting at piece slot i0, back to back
+    auto dma_run = [&](long long tile, int buf, auto i0c, auto nc) {
+        constexpr int i0 = decltype(i0c)::value, N = decltype(nc)::value;
+        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGI_TILE) * stride_b + (unsigned)(wave * NPIECE + i0) * 1024u;
+        const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + (wave * NPIECE + i0) * 1024);
+        uint32_t keep;
+        if constexpr (N == 1)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
+        else if constexpr (N == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
+        else if constexpr (N == 3)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
+    };
     auto dma_tile = [&](long long tile, int buf) {
+        if (all_full) {                                              // the common case: whole pieces, back to back in runs of <= 4
+            vgb_static_for<0, (NPIECE + 3) / 4>([&](auto rc) {
+                constexpr int i0 = 4 * decltype(rc)::value, N = NPIECE - i0 < 4 ? NPIECE - i0 : 4;
+                dma_run(tile, buf, std::integral_constant<int, i0>{}, std::integral_constant<int, N>{});
+            });
+            return;
+        }
 #pragma unroll
         for (int pc = 0; pc < NPIECE; ++pc) dma_piece(tile, buf, pc);
     };
@@ -416,15 +453,13 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
         //   k-steps 1 .. M-1   the fast test of tile t-1 (accumulator set `prev`: its last MFMA was issued one k-step ago, so
         //                      neither the MFMA drain nor the gate math ever stops the matrix pipe),
         //   k-step  M          THE tile's synchronisation: my DMA pieces of tile t+1 (issued during tile t-1) have landed,
-        //                      barrier - from here on tile t+1 is readable and nobody reads tile t-1
-        //                      any more - then the slow path of tile t-1 if a pair passed (its wavefront falls behind; the
-        //                      others wait at the next barrier),
-        //   k-steps M+1 ..     the DMA of tile t+2 into the buffer of tile t-1; the
-        //                      two wavefronts of a SIMD (w, w+4) issue theirs at different k-steps - an LDS-DMA instruction
-        //                      holds its wavefront for ~180 cycles, the other one's MFMAs fill them,
+        //                      barrier - from here on tile t+1 is readable and nobody reads tile t-1 any more - then the slow
+        //                      path of tile t-1 if a pair passed (its wavefront falls behind; the others wait at the next
+        //                      barrier),
+        //   k-step  M+1        the DMA of tile t+2 into the buffer of tile t-1 (by the wavefronts that issue DMA: VGI_DMA_G0),
         //   the last BP steps  the first B reads of tile t+1: the read pipeline runs on across the tile end.
         constexpr int M = NTB / 2;
-        static_assert(BP <= NTB - M && 2 * NPIECE <= NTB - M - 1, "pipeline shape");
+        static_assert(BP <= NTB - M && 2 <= NTB - M - 1, "pipeline shape");
         const int grp = wave >= WAVES / 2 ? 1 : 0;
         if (T > 0) {
             dma_tile(tile_first, 0);
@@ -441,9 +476,6 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
             const uint32_t lane_stat = lds_rstat0 + (uint32_t)(x * 8);
             vgb_static_for<0, BP>([&](auto tc) { vgi_lds_read128<1024 * decltype(tc)::value>(bq[decltype(tc)::value], lane_b); });
             VGI_TICK(t_loop0);
-#if VGI_PRIO == 3
-            if (grp == 1) __builtin_amdgcn_s_setprio(2);
-#endif
             int bcur = 0;                                                    // buffer of tile t
             // `car` = the row sums of the tile under test: read (inline asm, like the B operand) just before a step's
             // synchronisation, used by the next step
@@ -457,15 +489,10 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
                 const uint32_t pxx = car[1];
                 const int pcx = IS_U8 ? 128 * psx : 0;
                 // the row sums of tiles t+2 .. t+5 go with tile t+2's pieces when t+2 starts a group of four
-                const bool stat_turn = ((ti + 2) & 3) == 0 && wave == (((ti + 2) >> 2) & (WAVES - 1));
+                const bool stat_turn = ((ti + 2) & 3) == 0 && wave == (((ti + 2) >> 2) & (NISSUE - 1));
                 int jm_i = -0x7FFFFFFF;
                 float jm_f = -INFINITY;
                 VGI_TICK(tstep0);
-#if VGI_PRIO == 1
-                if (grp == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-#elif VGI_PRIO == 2
-                if (grp == 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-#endif
 #pragma unroll
                 for (int r = 0; r < 16; ++r) cur[r] = cinit[r];
                 vgb_static_for<0, NTB>([&](auto tc) {
@@ -473,11 +500,6 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
                     vgi_wait_lds<BP - 1>(bq[t % BP]);
                     cur = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[t], bq[t % BP], cur, 0, 0, 0);
                     if constexpr (t == M) {
-#if VGI_PRIO == 1
-                        if (grp == 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-#elif VGI_PRIO == 2
-                        if (grp == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
-#endif
                         const bool any = judge_any(jm_i, jm_f, pcx, pxx) && prev_valid;
                         VGI_TICK(ts0);
                         // this tile's row sums for the next step; then every LDS read in flight has returned (the slow path may
@@ -499,27 +521,16 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
                     else vgi_lds_read128<1024 * (t + BP - NTB)>(bq[t % BP], base_next);
                     if constexpr (t >= 1 && t < M) {
                         vgb_static_for<0, 8>([&](auto ic) {
-#ifndef VGI_ABLATE_JUDGE                                               // (measurement builds, WRONG results: nothing is tested)
                             if constexpr (1 + decltype(ic)::value * (M - 1) / 8 == t) {
                                 judge_item(ic, prev, pcx, jm_i, jm_f);
                                 // (pinned to this k-step: left alone, the optimizer sinks the whole test next to its use)
                                 if constexpr (COS) asm volatile("" : "+v"(jm_f)); else asm volatile("" : "+v"(jm_i));
                             }
-#endif
                         });
                     }
-#ifndef VGI_ABLATE_DMA                                                 // (measurement builds, WRONG results: no tile after the second is fetched)
-                    if constexpr (t > M) {
-                        // DMA slot s = 2 i + group of piece i: k-step M + 1 + s (NTB - M - 1) / (2 NPIECE)
-                        vgb_static_for<0, 2 * NPIECE>([&](auto sc) {
-                            constexpr int sl = decltype(sc)::value;
-                            if constexpr (M + 1 + sl * (NTB - M - 1) / (2 * NPIECE) == t) {
-                                if ((sl & 1) == grp) dma_piece(tile_dma, bdma, sl >> 1);
-                            }
-                        });
-                    }
+                    if constexpr (t == M + 1) { if (grp == 0) dma_tile(tile_dma, bdma); }
+                    if constexpr (t == M + 1 + (NTB - M - 1) / 2) { if (grp == 1 && NISSUE == WAVES) dma_tile(tile_dma, bdma); }
                     if constexpr (t == NTB - 1) { if (stat_turn) dma_stat_group(tile + 2, ((ti + 2) >> 2) & 1); }
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                 });
 #if VGI_TIMING

@@ -14,11 +14,14 @@ for v in "" "$@"; do
   echo "== lib ${v:-default}"
   VG_LIB_PATH="$lp" timeout 300 python tools/r2k_stage_sweep.py --types u8,u8s --stages 200 --nq 1024 2>&1 | grep -v amdgpu.ids
 done
-if [ -f "$L/libvectorgpu_timing.so" ]; then
+for tl in timing locktiming g0timing; do
+if [ -f "$L/libvectorgpu_$tl.so" ]; then
+echo "== $tl"
 for spec in "768 4" "768 3"; do
   set -- $spec
-  VG_LIB_PATH="$L/libvectorgpu_timing.so" timeout 300 python tools/tools_i8_timing.py --dim $1 --metric $2 2>&1 | grep -v amdgpu.ids
+  VG_LIB_PATH="$L/libvectorgpu_$tl.so" timeout 300 python tools/tools_i8_timing.py --dim $1 --metric $2 2>&1 | grep -v amdgpu.ids
 done
 fi
+done
 } > "$OUT/variants.txt" 2>&1
 cat "$OUT/variants.txt"

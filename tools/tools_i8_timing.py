@@ -46,11 +46,11 @@ def main():
     tiles = max(v[6], 1)
     print("dim %d metric %d nq %d: kernel ms (events) %.3f  wave-tiles %d  ticks per wave-tile (whole loop) %.1f" %
           (args.dim, args.metric, args.nq, c.profile_mean_ms()[1], v[6], v[0] / tiles))
-    for n, x in zip(["first half of the k loop (+ test of the previous tile)", "mid-tile wait (DMA landed + barrier)",
-                     "slow path (exact distances, inserts)", "second half of the k loop (+ DMA issue)"], [v[3], v[1], v[2], v[4]]):
+    for n, x in zip(["MFMA role (k loop of a double tile, two chains)", "X role: DMA issue", "X role: tests + slow paths (+ DMA wait)",
+                     "barrier"], [v[3], v[4], v[2], v[1]]):
         print("  %-58s %5.1f %%   %8.1f ticks per wave-tile" % (n, 100.0 * x / max(v[0], 1), x / tiles))
-    print("  wave-tiles that entered the slow path: %.2f %%" % (100.0 * v[7] / tiles))
-    print("  mid-tile wait per wavefront index 0..7 (ticks per tile): " + " ".join("%.0f" % (8.0 * x / tiles) for x in v[8:16]))
+    print("  double tiles with a slow path: %.2f %% of the wave-tiles" % (100.0 * v[7] / tiles))
+    print("  barrier wait per wavefront index 0..7 (ticks per tile): " + " ".join("%.0f" % (8.0 * x / tiles) for x in v[8:16]))
     c.close()
 
 

@@ -25,4 +25,9 @@ for f in glob.glob(out + "/p*/*/*counter_collection.csv"):
 for k, d in tot.items():
     print(k)
     for c in sorted(d): print("   %-28s %.4g" % (c, d[c]))
+    if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_WAVE_CYCLES"):
+        # GRBM_GUI_ACTIVE counts per XCD (8), the SQ_* counters per wavefront / SIMD: 1024 SIMDs x active cycles = 128 x GRBM_GUI_ACTIVE
+        print("   -> MFMA pipe busy %.1f %% of (1024 SIMDs x active cycles); %.1f busy cycles per MFMA instruction; waiting %.0f %% / waiting to issue %.0f %% of the wavefront cycles"
+              % (100.0 * d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (128.0 * d["GRBM_GUI_ACTIVE"]), d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(d.get("SQ_INSTS_MFMA", 1), 1),
+                 100.0 * d.get("SQ_WAIT_ANY", 0) / d["SQ_WAVE_CYCLES"], 100.0 * d.get("SQ_WAIT_INST_ANY", 0) / d["SQ_WAVE_CYCLES"]))
 PY
