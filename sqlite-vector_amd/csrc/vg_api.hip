@@ -503,7 +503,8 @@ int vg_ensure_row_norms(vg_corpus *c) {
     if (c->xnorm_cap < c->n_rows) {
         float *nb = nullptr;
         const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
-        HIP_TRY(hipMalloc(&nb, (size_t)(cap + 64) * sizeof(float)));      // + a tile of slack: the batch kernels fetch whole tiles
+        HIP_TRY(hipMalloc(&nb, (size_t)(cap + 192) * sizeof(float)));     // + slack: the batch kernels fetch the norms of four whole tiles at a time
+        HIP_TRY(hipMemsetAsync(nb, 0, (size_t)(cap + 192) * sizeof(float), c->stream));
         if (c->d_xnorm && c->xnorm_rows > 0)
             HIP_TRY(hipMemcpyAsync(nb, c->d_xnorm, (size_t)c->xnorm_rows * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
         if (c->d_xnorm) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->d_xnorm); }

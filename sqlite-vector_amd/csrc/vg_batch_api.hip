@@ -31,11 +31,12 @@ extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_ro
 // ---- f16 / bf16 batches: matrix-core filter + exact f64 re-evaluation (vg_batch_h.hip)
 extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k);
 extern "C" int vg_batch_h_queries_per_block(long long stride_bytes);
-extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long long stride_bytes, int dim, int type_code,
+extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long long n_rows, long long stride_bytes, int dim, int type_code,
                                  const uint8_t *dev_xrows, long long xstride_bytes,
                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
                                  const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
                                  uint64_t *dev_out_keys, hipStream_t stream);
+extern "C" int vg_tile_major_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, uint8_t *dev_out, hipStream_t stream);
 extern "C" int vg_f32_to_bf16_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int dim,
                                      uint8_t *dev_out, long long ostride, hipStream_t stream);
 
@@ -64,6 +65,29 @@ int vg_ensure_bf16_shadow(vg_corpus *c) {
         int rc = vg_f32_to_bf16_launch(c->d_rows, c->bf_rows, c->n_rows - c->bf_rows, c->stride, c->dim, c->d_rows_bf, bs, c->stream);
         if (rc != 0) return vg_fail(VG_ERR_HIP, "bf16 shadow pass failed: %s", hipGetErrorString((hipError_t)rc));
         c->bf_rows = c->n_rows;
+    }
+    return VG_OK;
+}
+
+// f16 / bf16 corpora: the tile-major copy the matrix-core kernel streams (+ 100 % of the corpus in HBM, made at the first batch and
+// extended per appended row; without it every LDS-DMA instruction gathers 32-byte runs from 32 rows - vg_batch_i8.hip).  A corpus
+// it does not fit next to keeps the row-major gather.
+static int ensure_half_tile_major(vg_corpus *c) {
+    if (env_int("VG_BATCH_TILE_MAJOR", 1) == 0 || c->tm_disabled) return -1;
+    if (c->tm_cap < c->n_rows) {
+        const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_rows_tm) hipFree(c->d_rows_tm);
+        c->d_rows_tm = nullptr; c->tm_cap = 0; c->tm_rows = 0;
+        const size_t bytes = (size_t)((cap + 31) / 32 * 32) * c->stride;                        // whole tiles
+        if (hipMalloc(&c->d_rows_tm, bytes) != hipSuccess) { (void)hipGetLastError(); c->d_rows_tm = nullptr; c->tm_disabled = true; return -1; }
+        HIP_TRY(hipMemsetAsync(c->d_rows_tm, 0, bytes, c->stream));                             // (rows past the end: defined bytes)
+        c->tm_cap = cap;
+    }
+    if (c->tm_rows < c->n_rows) {
+        int rc = vg_tile_major_launch(c->d_rows, c->tm_rows, c->n_rows - c->tm_rows, c->stride, c->d_rows_tm, c->stream);
+        if (rc != 0) return vg_fail(VG_ERR_HIP, "tile-major pass failed: %s", hipGetErrorString((hipError_t)rc));
+        c->tm_rows = c->n_rows;
     }
     return VG_OK;
 }
@@ -172,13 +196,20 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
         hipEventRecord(evs[0], c->stream);
     }
     const int mode = metric == VG_DIST_DOT ? 0 : (metric == VG_DIST_COSINE ? 1 : 2), root = metric == VG_DIST_L2 ? 1 : 0;
+    const uint8_t *hrows = f32_filter ? c->d_rows_bf : c->d_rows;       // what the half-precision kernel's matrix core reads
+    int hrows_tiled = 0;
+    if (half && !f32_filter) {
+        const int rct = ensure_half_tile_major(c);
+        if (rct == VG_OK) { hrows = c->d_rows_tm; hrows_tiled = 1; }
+        else if (rct != -1) return rct;
+    }
     int rc;
     if (quantized)
         rc = vg_batch_i8_launch(c->d_rows_s8, c->n_rows, c->stride, (const uint8_t *)c->d_bq,
                                 nq_pad, nq, k, mode, root, c->vtype == VG_TYPE_U8 ? 1 : 0, c->d_sx, c->d_bcand, npart,
                                 tiles_per_part, c->d_bkeys, c->stream);
     else if (half)
-        rc = vg_batch_h_launch(f32_filter ? c->d_rows_bf : c->d_rows, c->n_rows, fstride, c->dim,
+        rc = vg_batch_h_launch(hrows, hrows_tiled, c->n_rows, fstride, c->dim,
                                f32_filter ? 2 : (c->vtype == VG_TYPE_BF16 ? 1 : 0), c->d_rows, c->stride, (const uint8_t *)c->d_bq,
                                nq_pad, nq, k, mode, root, c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys, c->stream);
     else

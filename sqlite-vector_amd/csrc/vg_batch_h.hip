@@ -70,13 +70,16 @@ extern "C" int vg_batch_h_timing(unsigned long long *out8, int reset) {
 #endif
 
 struct BatchArgsH {
-    const uint8_t *rows;      // N x stride bytes (f16 / bf16 elements, zero padded to 16 bytes): what the matrix core reads
+    const uint8_t *rows;      // N x stride bytes (f16 / bf16 elements, zero padded to 16 bytes): what the matrix core reads -
+                              // row-major, or (tiled != 0) the TILE-MAJOR copy of vg_batch_i8.hip: tile t = rows 32t .. 32t+31 =
+                              // 32 * stride contiguous bytes, chunk column c of the 32 rows at c * 512 + row * 16
+    int tiled;
     const uint8_t *queries;   // nq_pad x stride bytes, zero padded (f32 corpora: unused, the A operand is converted from xqueries)
     const uint8_t *xrows;     // what the exact evaluation reads: = rows, or the f32 corpus behind a bf16 shadow copy
     const uint8_t *xqueries;  // = queries, or the f32 queries (nq_pad x xstride bytes, zero padded)
     long long xstride;
     float cerr;               // relative error bound of the filter's s~ (times |q||x|)
-    const float *row_nn;      // (float) sum x^2 per row - f32 corpora: ||x|| - readable up to the end of the last tile
+    const float *row_nn;      // (float) sum x^2 per row - f32 corpora: ||x|| - readable for four tiles past the last row
     uint64_t *cand;
     long long n_rows;
     long long stride;
@@ -130,8 +133,8 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int TILE_BYTES = NTB * 2 * 512;                           // chunk column c of the 32 rows at c * 512 + row * 16
     uint8_t *tile0 = smem;
-    float *rstat_lds = reinterpret_cast<float *>(smem + 2 * TILE_BYTES);                 // [2 buffers][32]: sum x^2
-    double *qq_lds = reinterpret_cast<double *>(rstat_lds + 2 * 32);                     // [waves][32]: sum q^2 (f64)
+    float *rstat_lds = reinterpret_cast<float *>(smem + 2 * TILE_BYTES);                 // [2 slots][4 tiles][32]: sum x^2
+    double *qq_lds = reinterpret_cast<double *>(rstat_lds + 2 * 128);                    // [waves][32]: sum q^2 (f64)
     uint32_t *qsp_lds = reinterpret_cast<uint32_t *>(qq_lds + WAVES * VGH_QPW);       // [waves][32]: query holds Inf / NaN
     float *thr_lds = reinterpret_cast<float *>(qsp_lds + WAVES * VGH_QPW);            // [waves][32]: k-th best so far
     uint64_t *lists = reinterpret_cast<uint64_t *>(thr_lds + WAVES * VGH_QPW);        // [waves][32][k]
@@ -225,25 +228,39 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
     const long long tile_last = min(tile_first + a.tiles_per_part, a.tile_end);
     const unsigned long long stride_b = (unsigned long long)a.stride;
     const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)tile0;
-    constexpr int NPIECE = (NTB + WAVES - 1) / WAVES;
-    uint64_t piece_mask[NPIECE];
-#pragma unroll
-    for (int i = 0; i < NPIECE; ++i) {
-        const int p = wave + i * WAVES;
-        piece_mask[i] = __ballot(p < npieces && (2 * p + h) < chunks_per_row);
-    }
-    auto lane_offset = [&](long long tile) -> uint32_t {            // rows past the end re-read the last row (masked later)
-        const long long row0 = tile * VGH_TILE;
+    // From the tile-major copy the first wavefront of every SIMD (waves 0-3 of an 8-wavefront workgroup: the arbiter favours the
+    // older wavefront, they reach the barrier early whatever they do) moves ALL pieces; issuing wavefront w moves the
+    // CONTIGUOUS pieces w * NPIECE .. w * NPIECE + NPIECE - 1.  From the tile-major copy a piece is 1 KiB of contiguous memory and up to four
+    // of them share one M0 set-up (the instruction offset moves the global and the LDS address alike); from a row-major
+    // corpus (the bf16 shadow of an f32 corpus, which the single-query filter scan reads by rows) every lane gathers its
+    // 16 bytes of row (l & 31) and a piece is one instruction.
+    constexpr int NISSUE_T = WAVES == 8 ? 4 : WAVES;                // issuing wavefronts on the tile-major copy ...
+    constexpr int NPIECE = (NTB + NISSUE_T - 1) / NISSUE_T;
+    // ... while a row-major gather (measured: 10.5 vs 10.0 ms from four wavefronts) stays spread over all of them
+    const int nissue = a.tiled != 0 ? NISSUE_T : WAVES, np_mine = a.tiled != 0 ? NPIECE : (NTB + WAVES - 1) / WAVES;
+    // piece p carries data if p < npieces; its second chunk column is a pad column when the chunk count is odd (lanes >= 32 off)
+    auto piece_mask_of = [&](int p) -> uint64_t {
+        if (wave >= nissue || p >= npieces) return 0ull;
+        return (2 * p + 1 < chunks_per_row) ? ~0ull : 0xFFFFFFFFull;
+    };
+    // (all of this wavefront's pieces whole, from the tile-major copy: the back-to-back path)
+    const bool all_full = wave < NISSUE_T && a.tiled != 0 && 2 * (wave * NPIECE + NPIECE) <= chunks_per_row;
+    const bool tiled = a.tiled != 0;
+    auto lane_offset = [&](long long tile) -> uint32_t {
+        if (tiled) return (uint32_t)lane * 16u;                     // (whole tiles exist in the copy; rows past the end are masked later)
+        const long long row0 = tile * VGH_TILE;                     // row-major: rows past the end re-read the last row
         const long long last = a.n_rows - 1 - row0;
         const uint32_t xr = (uint32_t)((long long)x < last ? (long long)x : last);
         return xr * (uint32_t)a.stride + (uint32_t)h * 16u;
     };
+    // the row norms ride the same pipeline, FOUR tiles (512 bytes) per instruction into a two-slot ring, the issuing
+    // wavefronts taking turns
     const uint32_t lds_rstat0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)rstat_lds;
-    const uint64_t stat_mask = __ballot(wave == WAVES - 1 && lane < 8);
+    const uint64_t stat_mask = __ballot(lane < 32);
     const uint32_t stat_goff = (uint32_t)lane * 16u;
-    auto dma_stats = [&](long long tile, int buf) {                 // the tile's 32 row norms ride the same pipeline
-        const uint8_t *b0 = reinterpret_cast<const uint8_t *>(a.row_nn + tile * VGH_TILE);
-        const uint32_t d0 = lds_rstat0 + (uint32_t)(buf * 128);
+    auto dma_stat_group = [&](long long tile4, int slot) {          // tiles tile4 .. tile4 + 3
+        const uint8_t *b0 = reinterpret_cast<const uint8_t *>(a.row_nn + tile4 * VGH_TILE);
+        const uint32_t d0 = lds_rstat0 + (uint32_t)(slot * 512);
         uint32_t keep;
         uint64_t keep_exec;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_and_b64 exec, exec, %5\n\t"
@@ -252,14 +269,47 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
                      : "=&s"(keep), "=&s"(keep_exec) : "v"(stat_goff), "s"(b0), "s"(d0), "s"(stat_mask) : "memory", "scc");
     };
     auto dma_piece = [&](long long tile, uint32_t lane_goff, int buf, int i) {
-        const int p = wave + i * WAVES;
-        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGH_TILE) * stride_b + (unsigned)p * 32u;
+        if (i >= np_mine) return;
+        const int p = wave * np_mine + i;
+        const uint64_t pmask = piece_mask_of(p);
+        if (pmask == 0) return;
+        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGH_TILE) * stride_b + (unsigned)p * (tiled ? 1024u : 32u);
         const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + p * 1024);
         uint32_t keep;
         uint64_t keep_exec;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_and_b64 exec, exec, %5\n\t"
                      "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep), "=&s"(keep_exec) : "v"(lane_goff), "s"(sbase), "s"(lds_dst), "s"(piece_mask[i]) : "memory", "scc");
+                     : "=&s"(keep), "=&s"(keep_exec) : "v"(lane_goff), "s"(sbase), "s"(lds_dst), "s"(pmask) : "memory", "scc");
+    };
+    // N (1 .. 4) whole pieces of the tile-major copy starting at piece slot i0, back to back
+    auto dma_run = [&](long long tile, uint32_t lane_goff, int buf, auto i0c, auto nc) __attribute__((always_inline)) {
+        constexpr int i0 = decltype(i0c)::value, N = decltype(nc)::value;
+        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGH_TILE) * stride_b + (unsigned)(wave * NPIECE + i0) * 1024u;
+        const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + (wave * NPIECE + i0) * 1024);
+        uint32_t keep;
+        if constexpr (N == 1)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
+        else if constexpr (N == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
+        else if constexpr (N == 3)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
+    };
+    // run r (pieces 4r .. 4r+3 of this wavefront's share) of a tile
+    constexpr int NRUN = (NPIECE + 3) / 4;
+    auto dma_share = [&](long long tile, uint32_t lane_goff, int buf, auto rc) __attribute__((always_inline)) {
+        constexpr int i0 = 4 * decltype(rc)::value, N = NPIECE - i0 < 4 ? NPIECE - i0 : 4;
+        if (all_full) dma_run(tile, lane_goff, buf, std::integral_constant<int, i0>{}, std::integral_constant<int, N>{});
+        else vgb_static_for<i0, i0 + N>([&](auto pc) { dma_piece(tile, lane_goff, buf, decltype(pc)::value); });
     };
 
     // (every lambda of this kernel is always_inline: left to its heuristics the compiler may keep one of the survivor-path
@@ -414,9 +464,8 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
 
     if (tile_first < tile_last) {
         const uint32_t goff0 = lane_offset(tile_first);
-#pragma unroll
-        for (int pc = 0; pc < NPIECE; ++pc) dma_piece(tile_first, goff0, 0, pc);
-        dma_stats(tile_first, 0);
+        vgb_static_for<0, NRUN>([&](auto rc) { dma_share(tile_first, goff0, 0, rc); });
+        if (wave == 0) dma_stat_group(tile_first, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -429,9 +478,11 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
 #endif
     for (long long tile = tile_first; tile < tile_last; ++tile) {
         VGH_TICK(t0);
-        const int cur_buf = (int)((tile - tile_first) & 1);
+        const long long ti = tile - tile_first;
+        const int cur_buf = (int)(ti & 1);
         const long long tile_next = min(tile + 1, tile_last - 1);
         const uint32_t goff_next = lane_offset(tile_next);
+        const bool stat_turn = ((ti + 1) & 3) == 0 && wave == (int)(((ti + 1) >> 2) & (NISSUE_T - 1));
         const long long row_cur = tile * VGH_TILE + x;
 
         vgh_f32x16 acc;
@@ -449,13 +500,15 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
             const vgh_i32x4 b = bq[t % BP];
             acc = vgh_mfma<FT>(areg[t], b, acc);
             if constexpr (t + BP < NTB) vgh_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
-            constexpr int NTD = (NTB + 1) / 2;                       // next tile's DMA pieces over the first half of the k loop
-            constexpr int pc_lo = (t >= NTD) ? NPIECE : (t * NPIECE + NTD - 1) / NTD;
-            constexpr int pc_hi = (t >= NTD) ? NPIECE : (t + 1 == NTD ? NPIECE : ((t + 1) * NPIECE + NTD - 1) / NTD);
-            vgb_static_for<pc_lo, pc_hi>([&](auto pcc) { dma_piece(tile_next, goff_next, cur_buf ^ 1, decltype(pcc)::value); });
-            if constexpr (t == 0) dma_stats(tile_next, cur_buf ^ 1);
+            // the next tile's DMA (runs of up to four pieces) over the first half of the k loop; every fourth tile one of
+            // the issuing wavefronts adds the row norms of the four tiles after this one
+            constexpr int NTD = (NTB + 1) / 2;
+            vgb_static_for<0, NRUN>([&](auto rc) {
+                if constexpr (decltype(rc)::value * NTD / NRUN == t) dma_share(tile_next, goff_next, cur_buf ^ 1, rc);
+            });
+            if constexpr (t == NTD) { if (stat_turn) dma_stat_group(tile + 1, (int)(((ti + 1) >> 2) & 1)); }
         });
-        float nn_row = rstat_lds[cur_buf * 32 + x];                  // landed with the tile, one barrier ago
+        float nn_row = rstat_lds[((ti >> 2) & 1) * 128 + (ti & 3) * 32 + x];      // landed with its group of four tiles
         if constexpr (XF32) nn_row = nn_row * nn_row;                // (the f32 corpus caches ||x||, not sum x^2)
 #if VGH_TIMING
         asm volatile("s_nop 0" :: "v"(acc[15]));                      // the k loop's last MFMA has retired
@@ -600,8 +653,28 @@ extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k) {
     const int NTB = vgh_ntb(stride_bytes);
     if (!NTB || k < 1 || k > VGH_MAX_K) return 0;
     const size_t waves = (size_t)VGH_WAVES_OF(NTB);
-    const size_t b = (size_t)2 * NTB * 1024 + 256 + waves * VGH_QPW * (8 + 4 + 4) + waves * VGH_QPW * k * 8;
+    const size_t b = (size_t)2 * NTB * 1024 + 1024 + waves * VGH_QPW * (8 + 4 + 4) + waves * VGH_QPW * k * 8;
     return b <= 160 * 1024 ? b : 0;
+}
+
+// rows [row0, row0 + n) of a row-major corpus -> the TILE-MAJOR copy the batch kernels stream (one 16-byte chunk per thread):
+// chunk c of row R goes to tile (R / 32) * (32 * stride) + c * 512 + (R % 32) * 16
+__global__ __launch_bounds__(256) void vg_tile_major_kernel(const uint8_t *rows, long long row0, long long n, long long stride, uint8_t *out) {
+    const int nch = (int)(stride / 16);
+    const long long total = n * nch;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long R = row0 + i / nch;
+        const int c = (int)(i % nch);
+        *reinterpret_cast<uint4 *>(out + (R >> 5) * (32 * stride) + (long long)c * 512 + (R & 31) * 16) =
+            *reinterpret_cast<const uint4 *>(rows + R * stride + 16 * c);
+    }
+}
+extern "C" int vg_tile_major_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, uint8_t *dev_out, hipStream_t stream) {
+    if (n <= 0) return 0;
+    long long blocks = (n * (stride / 16) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(vg_tile_major_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dev_rows, row0, n, stride, dev_out);
+    return (int)hipGetLastError();
 }
 
 // f32 rows -> their bf16 shadow copy (round to nearest even; zero padded to the shadow stride): 8 elements per thread
@@ -632,11 +705,12 @@ extern "C" int vg_f32_to_bf16_launch(const uint8_t *dev_rows, long long row0, lo
     return (int)hipGetLastError();
 }
 
-// type_code 0 / 1: dev_rows / dev_queries hold f16 / bf16 elements, zero padded rows of stride_bytes; dev_xrows = dev_rows.
+// type_code 0 / 1: dev_rows / dev_queries hold f16 / bf16 elements, zero padded rows of stride_bytes; dev_xrows = the row-major
+// corpus; rows_tiled: dev_rows is its tile-major copy (vg_tile_major_launch; whole tiles allocated).
 // type_code 2: an f32 corpus - dev_rows is its bf16 shadow copy (stride_bytes per row), dev_xrows / dev_queries the f32 rows /
 // queries (xstride_bytes per row).  dev_row_nn: (float) sum x^2 per row (f32: ||x||), readable for 32 floats past the last
 // whole tile.  Returns 0, -1 if the shape is not served, a hipError_t otherwise.  dev_cand sized like the f32 kernel's.
-extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long long stride_bytes, int dim, int type_code,
+extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long long n_rows, long long stride_bytes, int dim, int type_code,
                                  const uint8_t *dev_xrows, long long xstride_bytes,
                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
                                  const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
@@ -645,7 +719,7 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, long long n_rows, long
     if (!smem || nq_pad % vg_batch_h_queries_per_block(stride_bytes) != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
     if (mode < VGH_DOT || mode > VGH_L2 || !dev_row_nn) return -1;
     BatchArgsH a;
-    a.rows = dev_rows; a.queries = dev_queries; a.row_nn = dev_row_nn; a.cand = dev_cand;
+    a.rows = dev_rows; a.tiled = rows_tiled; a.queries = dev_queries; a.row_nn = dev_row_nn; a.cand = dev_cand;
     a.xrows = dev_xrows; a.xqueries = dev_queries; a.xstride = xstride_bytes;
     a.cerr = (float)(dim + 64) * 4.76837158203125e-7f + (type_code == 2 ? 0.0078125f + 1.52587890625e-5f : 0.0f);   // (D+64) 2^-21 [+ 2u + u^2, u = 2^-8: query AND row are rounded to bf16]
     a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;

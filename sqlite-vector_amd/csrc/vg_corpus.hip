@@ -121,6 +121,7 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_sel_state) hipFree(c->d_sel_state);
     if (c->d_sx) hipFree(c->d_sx);
     if (c->d_rows_s8) hipFree(c->d_rows_s8);
+    if (c->d_rows_tm) hipFree(c->d_rows_tm);
     if (c->d_rows_bf) hipFree(c->d_rows_bf);
     if (c->d_filter_evals) hipFree(c->d_filter_evals);
     if (c->h_filter_evals) hipHostFree(c->h_filter_evals);
@@ -140,6 +141,7 @@ extern "C" int vg_corpus_clear(vg_corpus *c) {
     c->dist_valid_rows = 0;
     c->xnorm_rows = 0;
     c->i8_rows = 0;
+    c->tm_rows = 0;
     c->bf_rows = 0;
     c->rowids.clear();
     return VG_OK;

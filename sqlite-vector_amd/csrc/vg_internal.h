@@ -90,6 +90,9 @@ struct vg_corpus {
     // quantized batches (vg_batch_i8.hip): per-row sum x / sum x^2 and, for uint8, the XOR-0x80 copy the matrix core reads
     uint32_t *d_sx = nullptr;                     // per row: (sum x, sum x^2)
     uint8_t *d_rows_s8 = nullptr;
+    uint8_t *d_rows_tm = nullptr;                 // f16 / bf16 corpora: the tile-major copy the batched matrix-core kernel streams
+    int64_t tm_rows = 0, tm_cap = 0;
+    bool tm_disabled = false;                     // (it did not fit: the kernel gathers from the row-major corpus)
     uint8_t *d_rows_bf = nullptr;                 // f32 corpora: bf16 shadow copy for the matrix-core filter (vg_batch_h.hip)
     int64_t bf_rows = 0, bf_cap = 0;
     bool filter_disabled = false;                 // the shadow copy / norms did not fit HBM: single queries keep the plain f32 scan

@@ -976,3 +976,24 @@ def test_batch_staged_real_passes_with_ties_across_stage_boundaries(pkg, vt, mon
                     if metric != dg.COSINE:                              # small integers: both paths are exact, ties go by position
                         assert ids[i].tolist() == one_ids.tolist(), (metric, growth, i)
     c.close()
+
+
+@pytest.mark.parametrize("vt", [dg.F16, dg.BF16])
+def test_batch_half_tile_major_copy_equals_row_major_gather(pkg, vt, monkeypatch):
+    """f16 / bf16 batches stream a tile-major copy of the corpus (contiguous 1 KiB LDS-DMA pieces); VG_BATCH_TILE_MAJOR=0
+    keeps the row-major gather.  Same lists either way, also after rows are appended behind a ragged last tile."""
+    k, nq = 10, 70
+    for dim in (24, 384, 500, 768):
+        rows = dg.corpus(vt, 5000, dim, 4400 + dim)
+        qs = dg.corpus(vt, nq, dim, 4401 + dim)
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("VG_BATCH_TILE_MAJOR", mode)
+            c = pkg.Corpus(vt, dim)
+            c.append(rows[:3333])                                # (not a multiple of 32)
+            first = c.scan_topk_batch(dg.DOT, qs, k)
+            c.append(rows[3333:])
+            out[mode] = (first, [c.scan_topk_batch(m, qs, k) for m in (dg.DOT, dg.COSINE, dg.L2)])
+            c.close()
+        for a, b in zip([out["1"][0]] + out["1"][1], [out["0"][0]] + out["0"][1]):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), dim
