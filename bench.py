@@ -224,6 +224,7 @@ def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc
     n_launch, kern_ms, _ = corpus.profile_mean_ms()
     flops = 2.0 * nq * n_rows * dim
     tf = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    run_batched.last_result = last.get("res")
     if rank != 0:
         return None
     return {
@@ -578,6 +579,30 @@ def main():
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = batch_cpu_baseline(args, v5, t5, d5, m5, k, seconds=5.0)
             also["c5"] = line
+            # the same batches through the bf16 filter (VG_F32_FILTER=1, the shadow copy the filter scan above has made): the
+            # GEMM at the bf16 rate over HALF the bytes, every survivor re-evaluated with the f32 single-scan arithmetic.
+            # Priced on the bf16 MFMA peak and reported next to the f32 MFMA line, never as its roofline.
+            try:
+                plain_res = run_batched.last_result
+                os.environ["VG_F32_FILTER"] = "1"
+                fl = run_batched(args, pkg, torch, corpus, "c5f", n_rows, d5, m5, k, WORKLOADS["c5f"][4])
+                fres = run_batched.last_result
+                same_ids = bool(np.array_equal(np.asarray(fres[0]), np.asarray(plain_res[0])))
+                d_f, d_p = np.asarray(fres[1], dtype=np.float64), np.asarray(plain_res[1], dtype=np.float64)
+                line["filter_batch"] = {
+                    "what": "the same batches through vg_batch_h_kernel over the bf16 shadow copy (matrix cores as a lower-bound "
+                            "filter) + exact f32 re-evaluation of the survivors: the f32 single scans' distances",
+                    "value": fl["value"], "unit": "vectors/s", "ms_per_step": fl["ms_per_step"], "dtype_streamed": "bf16",
+                    "kernel": fl["roofline"]["kernel"], "kernel_ms": fl["roofline"]["kernel_ms"],
+                    "achieved_TFLOPs_of_the_QxNxD_product": fl["roofline"]["achieved"], "peak_bf16_TFLOPs": F16_MFMA_PEAK_TF,
+                    "frac_of_bf16_peak": fl["roofline"]["frac"], "speedup_over_f32_mfma_kernel": line["ms_per_step"] / fl["ms_per_step"],
+                    "last_batch_same_rowids_as_f32_mfma_kernel": same_ids,
+                    "last_batch_max_rel_distance_difference": float(np.max(np.abs(d_f - d_p) / np.maximum(np.abs(d_p), 1e-30))) if d_f.shape == d_p.shape else None,
+                }
+            except Exception as e:
+                line["filter_batch"] = {"error": repr(e)}
+            finally:
+                os.environ.pop("VG_F32_FILTER", None)
         except Exception as e:
             also["c5"] = {"error": repr(e)}
         out["also"] = also
