@@ -524,23 +524,26 @@ def main():
             fn_launch, fscan_ms, fmerge_ms, fpre_ms = corpus.profile_mean_ms_ex()
             evals = corpus.filter_exact_evals()
             fname = corpus.kernel_name(metric)
-            streamed = n_rows * (((dim * 2 + 15) // 16) * 16 + 4)        # bf16 shadow row + one cached f32 norm per row
+            q8 = "_q8_" in fname
+            # per row: the int8 shadow row + (scale, residual norm, cached f32 norm) | the bf16 shadow row + the cached f32 norm
+            per_row = (((dim + 15) // 16) * 16 + 12) if q8 else (((dim * 2 + 15) // 16) * 16 + 4)
+            streamed = n_rows * per_row
             ftraffic, fsource = pmc_traffic(fname, n_rows)
             same = (list(runner.last["pos"]) == list(plain_last["pos"]) and
                     np.array_equal(np.asarray(runner.last["dist"]), np.asarray(plain_last["dist"])))
             out["filter_scan"] = {
-                "what": "the same %d queries through vg_scan_filter_kernel: bf16 shadow copy as a lower-bound filter + exact f32 "
-                        "re-evaluation of the candidates (same rowids and distance bits as the plain scan)" % args.steps,
+                "what": "the same %d queries through vg_scan_filter_kernel: %s shadow copy as a lower-bound filter + exact f32 "
+                        "re-evaluation of the candidates (same rowids and distance bits as the plain scan)" % (args.steps, "int8" if q8 else "bf16"),
                 "value": n_rows * args.steps / felapsed, "unit": "vectors/s", "ms_per_step": felapsed / args.steps * 1e3,
                 "p50_query_latency_ms": float(np.median(flat) * 1e3),
                 "kernel": fname, "kernel_ms": fscan_ms, "prepass_ms": fpre_ms, "merge_kernel_ms": fmerge_ms, "launches_timed": fn_launch,
-                "dtype_streamed": "bf16", "streamed_bytes_per_launch": streamed,
+                "dtype_streamed": "int8" if q8 else "bf16", "streamed_bytes_per_launch": streamed,
                 "achieved_on_streamed_GBs": streamed / (fscan_ms * 1e-3) / 1e9 if fscan_ms > 0 else 0.0,
                 "frac_on_streamed": streamed / (fscan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fscan_ms > 0 else 0.0,
                 "traffic": ftraffic, "traffic_source": fsource,
                 "exact_f32_evaluations_per_query": evals / float(args.warmup + args.steps),
                 "last_query_same_answer_as_plain_scan": bool(same),
-                "extra_hbm_bytes": n_rows * (((dim * 2 + 15) // 16) * 16 + 4),
+                "extra_hbm_bytes": n_rows * per_row,
             }
         except Exception as e:
             out["filter_scan"] = {"error": repr(e)}

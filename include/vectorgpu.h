@@ -136,7 +136,10 @@ int64_t vg_corpus_rowid_at(const vg_corpus *c, int64_t position);
  * f32 corpora, k <= 32, rows <= 512 floats, metric DOT / COSINE / L2 / SQUARED_L2: one pass over the corpus on the
  * matrix cores (Q x C^T tiles feed per-query candidate lists; L2 survivors are re-evaluated with the direct formula);
  * rows of 513 .. 1024 floats: a bf16 shadow copy of the corpus feeds the matrix cores as a filter, every candidate is
- * re-evaluated on the f32 rows with the single scan's arithmetic.
+ * re-evaluated on the f32 rows with the single scan's arithmetic - and so do shorter rows of a corpus the filter scan serves
+ * (switched on, >= 3 GB: the shadow copy those scans make; the GEMM at the bf16 rate over half the bytes, the distances are
+ * the single scans' distances; a selectivity guard falls back to the f32 matrix-core kernel on data the bound does not
+ * separate; environment VG_F32_FILTER=0 / 1 forces it off / on).
  * uint8 / int8 corpora, k <= 32, rows <= 2048 bytes, same metrics: the integer matrix cores, results identical to
  * nq vg_scan_topk calls.  f16 / bf16 corpora, k <= 32, rows <= 1024 elements, same metrics: the matrix cores filter,
  * every candidate is re-evaluated with the single scan's f64 arithmetic.  Other shapes on f32 / uint8 / int8 corpora
@@ -204,6 +207,8 @@ const char *vg_scan_kernel_name(vg_corpus *c, int metric);
 /* filter scan: f32 rows evaluated exactly by the filter-scan launches since the last call (then reset) - how selective the
  * bf16 bound is on the data at hand */
 int vg_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals);
+/* the same for f32 batches through the bf16 filter (vg_scan_topk_batch): (query, row) pairs evaluated exactly since the last call */
+int vg_batch_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals);
 
 /* rows sent to a device by every vg_corpus_append* / vg_shards_append* call of this process so far */
 long long vg_stat_rows_appended(void);

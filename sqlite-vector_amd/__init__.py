@@ -103,6 +103,7 @@ def lib():
         "vg_scan_kernel_name": (C.c_char_p, [vp, i32]),
         "vg_profile_mean_ms_ex": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "vg_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
+        "vg_batch_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
         "vg_corpus_set_scan_filter": (i32, [vp, i32]),
         "vg_corpus_set_tie_order": (i32, [vp, i32]),
         "vg_corpus_tie_order": (i32, [vp]),
@@ -257,6 +258,11 @@ class Corpus:
     def filter_exact_evals(self):
         v = C.c_ulonglong(0)
         _check(lib().vg_filter_exact_evals(self.h, C.byref(v)))
+        return v.value
+
+    def batch_filter_exact_evals(self):
+        v = C.c_ulonglong(0)
+        _check(lib().vg_batch_filter_exact_evals(self.h, C.byref(v)))
         return v.value
 
     def set_scan_filter(self, mode):

@@ -35,20 +35,27 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
                                  const uint8_t *dev_xrows, long long xstride_bytes,
                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
                                  const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
-                                 uint64_t *dev_out_keys, hipStream_t stream);
+                                 uint64_t *dev_out_keys, unsigned long long *dev_evals, hipStream_t stream);
 extern "C" int vg_tile_major_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, uint8_t *dev_out, hipStream_t stream);
 extern "C" int vg_f32_to_bf16_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int dim,
                                      uint8_t *dev_out, long long ostride, hipStream_t stream);
 
 // f32 corpora with rows of 513 .. 1024 floats have no f32 matrix-core kernel (A does not fit the register file, the tiles not
 // the LDS): they run through the half-precision kernel with a bf16 SHADOW copy as the filter's input and the f32 rows for the
-// exact evaluation.  VG_F32_FILTER=1 sends shorter rows the same way (5x the f32 MFMA kernel at D = 384: the filter runs at
-// the bf16 rate, the survivors carry the single-query kernel's f32 arithmetic).
+// exact evaluation.  Shorter rows go the same way (5x the f32 MFMA kernel at D = 384: the filter runs at the bf16 rate over
+// half the bytes, the survivors carry the single-query kernel's f32 arithmetic) when the corpus has - or by the filter scan's
+// own rule (vg_filter.hip: switched on, >= 3 GB) is about to have - that shadow copy; VG_F32_FILTER=1 / 0 forces it on / off.
+// A selectivity guard like the filter scan's watches the exact evaluations (see scan_topk_batch_mfma).
 long long vg_bf16_shadow_stride(const vg_corpus *c) { return (((long long)c->dim * 2 + 15) / 16) * 16; }
 static long long bf16_shadow_stride(const vg_corpus *c) { return vg_bf16_shadow_stride(c); }
+static bool batch_f32_filter_short_rows(const vg_corpus *c) {
+    const int sw = env_int("VG_F32_FILTER", -1);
+    if (sw >= 0) return sw != 0;
+    return vg_scan_filter_policy(c) && c->bfilter_cooldown == 0;
+}
 static bool batch_f32_filter_eligible(const vg_corpus *c, int metric, int k) {
     if (env_int("VG_BATCH_MFMA", 1) == 0 || c->vtype != VG_TYPE_F32 || metric == VG_DIST_L1) return false;
-    if (c->dim <= 512 && env_int("VG_F32_FILTER", 0) == 0) return false;
+    if (c->dim <= 512 && !batch_f32_filter_short_rows(c)) return false;
     return vg_batch_h_lds_bytes(bf16_shadow_stride(c), k) != 0;
 }
 int vg_ensure_bf16_shadow(vg_corpus *c) {
@@ -147,8 +154,17 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
                                 int *out_counts) {
     const bool quantized = (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8);
     // f32 through the half-precision kernel (bf16 shadow copy): rows the f32 matrix-core kernel does not serve, or on request
-    const bool f32_filter = (c->vtype == VG_TYPE_F32) && batch_f32_filter_eligible(c, metric, k) &&
-                            (vg_batch_lds_bytes(c->stride, k) == 0 || env_int("VG_F32_FILTER", 0) != 0);
+    bool f32_filter = (c->vtype == VG_TYPE_F32) && batch_f32_filter_eligible(c, metric, k) &&
+                      (vg_batch_lds_bytes(c->stride, k) == 0 || batch_f32_filter_short_rows(c));
+    const bool f32_mfma_serves = (c->vtype == VG_TYPE_F32) && vg_batch_lds_bytes(c->stride, k) != 0;
+    if (c->vtype == VG_TYPE_F32 && c->bfilter_cooldown > 0 && env_int("VG_F32_FILTER", -1) < 0) --c->bfilter_cooldown;
+    if (f32_filter && f32_mfma_serves) {
+        // the shadow copy (+ 50 % of the corpus) and the norms must fit; a corpus they do not fit next to keeps the f32 kernel
+        int rcs = vg_ensure_row_norms(c);
+        if (rcs == VG_OK) rcs = vg_ensure_bf16_shadow(c);
+        if (rcs == VG_ERR_NOMEM) { (void)hipGetLastError(); c->filter_disabled = true; f32_filter = false; }
+        else if (rcs != VG_OK) return rcs;
+    }
     const bool half = (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) || f32_filter;
     const long long fstride = f32_filter ? bf16_shadow_stride(c) : c->stride;       // row stride of what the matrix core reads
     const int QPB = quantized ? vg_batch_i8_queries_per_block(c->stride) : (half ? vg_batch_h_queries_per_block(fstride) : 128);
@@ -208,10 +224,19 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
         rc = vg_batch_i8_launch(c->d_rows_s8, c->n_rows, c->stride, (const uint8_t *)c->d_bq,
                                 nq_pad, nq, k, mode, root, c->vtype == VG_TYPE_U8 ? 1 : 0, c->d_sx, c->d_bcand, npart,
                                 tiles_per_part, c->d_bkeys, c->stream);
-    else if (half)
+    else if (half) {
+        unsigned long long *dev_evals = nullptr;
+        if (f32_filter) {                                  // the guard's counter (vg_filter.hip: slot [1] of the corpus' pair)
+            const int rce = vg_ensure_filter_counters(c);
+            if (rce != VG_OK) return rce;
+            dev_evals = c->d_filter_evals + 1;
+        }
         rc = vg_batch_h_launch(hrows, hrows_tiled, c->n_rows, fstride, c->dim,
                                f32_filter ? 2 : (c->vtype == VG_TYPE_BF16 ? 1 : 0), c->d_rows, c->stride, (const uint8_t *)c->d_bq,
-                               nq_pad, nq, k, mode, root, c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys, c->stream);
+                               nq_pad, nq, k, mode, root, c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys, dev_evals, c->stream);
+        if (rc == 0 && dev_evals)
+            HIP_TRY(hipMemcpyAsync(c->h_filter_evals + 1, dev_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    }
     else
         rc = vg_batch_launch((const float *)c->d_rows, c->n_rows, c->stride, (const float *)c->d_bq, nq_pad, nq, k, mode, root,
                              metric == VG_DIST_DOT ? nullptr : c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys,
@@ -223,6 +248,16 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     HIP_TRY(hipMemcpyAsync(keys.data(), c->d_bkeys, (size_t)nq * 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     vg_collect_timing(c);
+    if (f32_filter && f32_mfma_serves) {
+        // Selectivity guard.  An exact evaluation occupies a whole wavefront (and stalls its workgroup at the tile barrier):
+        // the filter pays while few pairs need one.  On data it cannot separate (rows nearly identical to each other) nearly
+        // every pair does; when a batch averaged more than one evaluation per 256 pairs the next 64 batches of this corpus
+        // take the f32 matrix-core kernel, then the filter is tried again.  (Rows of 513+ floats have no such kernel: no guard.)
+        const unsigned long long now = c->h_filter_evals[1];
+        const unsigned long long pairs = (unsigned long long)nq * (unsigned long long)c->n_rows;
+        if ((now - c->bfilter_evals_seen) > pairs / 256 && env_int("VG_F32_FILTER", -1) < 0) c->bfilter_cooldown = 64;
+        c->bfilter_evals_seen = now;
+    }
     for (int i = 0; i < nq; ++i) {
         int cnt = 0;
         for (int j = 0; j < k; ++j) {
@@ -308,6 +343,19 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
         int rc = vg_scan_topk_keys(c, metric, q + (size_t)i * c->dim * c->es, k, out_keys + (size_t)i * k, out_counts + i);
         if (rc != VG_OK) return rc;
     }
+    return VG_OK;
+}
+
+extern "C" int vg_batch_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals) {
+    if (!c || !out_evals) return vg_fail(VG_ERR_INVALID, "vg_batch_filter_exact_evals: NULL argument");
+    *out_evals = 0;
+    if (!c->d_filter_evals) return VG_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long now = 0;
+    HIP_TRY(hipMemcpy(&now, c->d_filter_evals + 1, sizeof(now), hipMemcpyDeviceToHost));
+    *out_evals = now - c->bfilter_evals_read;
+    c->bfilter_evals_read = now;
     return VG_OK;
 }
 

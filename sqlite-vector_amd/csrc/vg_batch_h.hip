@@ -90,6 +90,7 @@ struct BatchArgsH {
     int part_base, npart_total;
     const uint64_t *init_keys;
     int seed;                 // staged real passes (vg_batch_common.h): partition 0 starts its lists from init_keys
+    unsigned long long *evals;   // exact evaluations of the real passes (one atomic per wavefront; the host's selectivity guard), or NULL
 };
 
 template <int OFF>
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
         return vg_clamp(d);
     };
     bool bound_changed = false;
+    unsigned n_exact = 0;                                // exact evaluations of this wavefront (wave-uniform)
 #if VGH_TIMING
     unsigned long long tk_cnt = 0, tk_regs = 0, tk_entries = 0, tk_exact = 0, tk_offer = 0, tk_phase = 0, tk_pairs = 0;
 #endif
@@ -443,6 +445,7 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
             const uint32_t row_u = (uint32_t)__builtin_amdgcn_readlane((int)row, src);
             const float nn_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nn_row), src));
             const float thr_u = thr_w[qi_u];
+            ++n_exact;
             // every lane holds the same value (butterfly sums): say so, or the branch below counts as divergent
             VGH_TICK(te0);
             const float de = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, exact_distance(qi_u, row_u, nn_u))));
@@ -572,6 +575,7 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
         const int qi = s >> 6, slot = s & 63;
         a.cand[((long long)(q0 + qi) * a.npart_total + a.part_base + part) * 64 + slot] = (slot < k) ? wave_lists[qi * k + slot] : VG_EMPTY_KEY;
     }
+    if (!BOUND && a.evals && lane == 0 && n_exact) atomicAdd(a.evals, (unsigned long long)n_exact);
 }
 
 // ---- host side
@@ -710,11 +714,12 @@ extern "C" int vg_f32_to_bf16_launch(const uint8_t *dev_rows, long long row0, lo
 // type_code 2: an f32 corpus - dev_rows is its bf16 shadow copy (stride_bytes per row), dev_xrows / dev_queries the f32 rows /
 // queries (xstride_bytes per row).  dev_row_nn: (float) sum x^2 per row (f32: ||x||), readable for 32 floats past the last
 // whole tile.  Returns 0, -1 if the shape is not served, a hipError_t otherwise.  dev_cand sized like the f32 kernel's.
+// dev_evals (or NULL): incremented by the number of exact evaluations of the real passes.
 extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long long n_rows, long long stride_bytes, int dim, int type_code,
                                  const uint8_t *dev_xrows, long long xstride_bytes,
                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
                                  const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
-                                 uint64_t *dev_out_keys, hipStream_t stream) {
+                                 uint64_t *dev_out_keys, unsigned long long *dev_evals, hipStream_t stream) {
     const size_t smem = vg_batch_h_lds_bytes(stride_bytes, k);
     if (!smem || nq_pad % vg_batch_h_queries_per_block(stride_bytes) != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
     if (mode < VGH_DOT || mode > VGH_L2 || !dev_row_nn) return -1;
@@ -723,7 +728,7 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
     a.xrows = dev_xrows; a.xqueries = dev_queries; a.xstride = xstride_bytes;
     a.cerr = (float)(dim + 64) * 4.76837158203125e-7f + (type_code == 2 ? 0.0078125f + 1.52587890625e-5f : 0.0f);   // (D+64) 2^-21 [+ 2u + u^2, u = 2^-8: query AND row are rounded to bf16]
     a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;
-    a.mode = mode; a.root = root; a.dim = dim;
+    a.mode = mode; a.root = root; a.dim = dim; a.evals = dev_evals;
     const int ntb = vgh_ntb(stride_bytes);
     const int G = nq_pad / vg_batch_h_queries_per_block(stride_bytes);
     const int blocks = G * ((npart + 7) / 8) * 8;

@@ -123,6 +123,8 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_rows_s8) hipFree(c->d_rows_s8);
     if (c->d_rows_tm) hipFree(c->d_rows_tm);
     if (c->d_rows_bf) hipFree(c->d_rows_bf);
+    if (c->d_rows_q8) hipFree(c->d_rows_q8);
+    if (c->d_q8stat) hipFree(c->d_q8stat);
     if (c->d_filter_evals) hipFree(c->d_filter_evals);
     if (c->h_filter_evals) hipHostFree(c->h_filter_evals);
     if (c->d_below) hipFree(c->d_below);
@@ -143,6 +145,7 @@ extern "C" int vg_corpus_clear(vg_corpus *c) {
     c->i8_rows = 0;
     c->tm_rows = 0;
     c->bf_rows = 0;
+    c->q8_rows = 0;
     c->rowids.clear();
     return VG_OK;
 }

@@ -18,6 +18,19 @@ static bool scan_filter_enabled(const vg_corpus *c) {
     if (c->scan_filter_mode >= 0) return c->scan_filter_mode != 0;
     return env_int("VG_SCAN_FILTER", 1) != 0;
 }
+// (vg_batch_api.hip: f32 batches follow the same switch and the same size threshold - they read the shadow copy these scans make)
+bool vg_scan_filter_policy(const vg_corpus *c) {
+    return scan_filter_enabled(c) && c->n_rows * c->stride >= (long long)env_int("VG_SCAN_FILTER_MIN_MB", 3072) * (1ll << 20);
+}
+// exact-evaluation counters on the device ([0] filter scans, [1] filtered batches) + their pinned host mirror
+int vg_ensure_filter_counters(vg_corpus *c) {
+    if (c->d_filter_evals) return VG_OK;
+    HIP_TRY(hipMalloc(&c->d_filter_evals, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->d_filter_evals, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipHostMalloc(&c->h_filter_evals, 2 * sizeof(unsigned long long)));
+    c->h_filter_evals[0] = c->h_filter_evals[1] = 0;
+    return VG_OK;
+}
 // Which scans the filter serves: f32 / f16 / bf16 corpora, L2 / squared L2 / dot / cosine (f16 / bf16 cosine with the cached
 // row norms, A_COSN - what the plain scan uses unless VG_HALF_COSN=0), and L1 on f16 / bf16 corpora.
 // Small corpora keep the plain scan: the filter scan pays a pre-pass launch plus the exact evaluations of the lists'
@@ -33,37 +46,119 @@ static bool scan_filter_serves(const vg_corpus *c, int metric) {
     return c->n_rows * c->stride >= (long long)env_int("VG_SCAN_FILTER_MIN_MB", half ? 1024 : 3072) * (1ll << 20);
 }
 
-template <int XT, int MODE, bool NT>
+template <int XT, int MODE, bool NT, bool Q8>
 static filter_fn_t pick_filter_u(int U) {
     switch (U) {
-        case 1: return vg_scan_filter_kernel<XT, MODE, 1, NT>;
-        case 2: return vg_scan_filter_kernel<XT, MODE, 2, NT>;
-        case 3: return vg_scan_filter_kernel<XT, MODE, 3, NT>;
-        case 4: return vg_scan_filter_kernel<XT, MODE, 4, NT>;
-        case 6: return vg_scan_filter_kernel<XT, MODE, 6, NT>;
+        case 1: return vg_scan_filter_kernel<XT, MODE, 1, NT, Q8>;
+        case 2: return vg_scan_filter_kernel<XT, MODE, 2, NT, Q8>;
+        case 3: return vg_scan_filter_kernel<XT, MODE, 3, NT, Q8>;
+        case 4: return vg_scan_filter_kernel<XT, MODE, 4, NT, Q8>;
+        case 6: return vg_scan_filter_kernel<XT, MODE, 6, NT, Q8>;
     }
     return nullptr;
 }
-template <int XT, bool NT>
+template <int XT, bool NT, bool Q8>
 static filter_fn_t pick_filter_mode(int mode, int U) {
     switch (mode) {
-        case VGF_L2: return pick_filter_u<XT, VGF_L2, NT>(U);
-        case VGF_DOT: return pick_filter_u<XT, VGF_DOT, NT>(U);
-        case VGF_COS: return pick_filter_u<XT, VGF_COS, NT>(U);
+        case VGF_L2: return pick_filter_u<XT, VGF_L2, NT, Q8>(U);
+        case VGF_DOT: return pick_filter_u<XT, VGF_DOT, NT, Q8>(U);
+        case VGF_COS: return pick_filter_u<XT, VGF_COS, NT, Q8>(U);
         case VGF_L1:
-            if constexpr (XT != T_F32) return pick_filter_u<XT, VGF_L1, NT>(U);
+            if constexpr (XT != T_F32) return pick_filter_u<XT, VGF_L1, NT, false>(U);
             return nullptr;
     }
     return nullptr;
 }
 template <bool NT>
-static filter_fn_t pick_filter(int vtype, int mode, int U) {
+static filter_fn_t pick_filter(int vtype, int mode, int U, bool q8 = false) {
     switch (vtype) {
-        case VG_TYPE_F32: return pick_filter_mode<T_F32, NT>(mode, U);
-        case VG_TYPE_F16: return pick_filter_mode<T_F16, NT>(mode, U);
-        case VG_TYPE_BF16: return pick_filter_mode<T_BF16, NT>(mode, U);
+        case VG_TYPE_F32: return q8 ? pick_filter_mode<T_F32, NT, true>(mode, U) : pick_filter_mode<T_F32, NT, false>(mode, U);
+        case VG_TYPE_F16: return pick_filter_mode<T_F16, NT, false>(mode, U);
+        case VG_TYPE_BF16: return pick_filter_mode<T_BF16, NT, false>(mode, U);
     }
     return nullptr;
+}
+
+// ---- the int8 shadow copy of an f32 corpus (vg_scan_filter.h, Q8): 16 lanes per row.  Row r becomes ostride bytes of int8
+// (zero padded) and stat[r] = (sx, ||ex||): sx = max|x| / 127, ex = x - sx * xi formed and summed in f64 (the product of a
+// float and a 7-bit integer is exact there), its norm rounded up.  Rows with Inf / NaN elements get sx = NaN (never judged).
+__global__ __launch_bounds__(256) void vg_f32_to_q8_kernel(const uint8_t *rows, long long row0, long long n, long long stride, int dim,
+                                                           uint8_t *out, long long ostride, float2 *stat) {
+    const int l16 = threadIdx.x & 15;
+    const long long groups = ((long long)gridDim.x * blockDim.x) >> 4;
+    const long long n_pad = ((n + 3) / 4) * 4;                            // whole wavefronts stay together (DPP reductions)
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < n_pad; i += groups) {
+        const bool live = i < n;
+        const long long r = row0 + (live ? i : n - 1);
+        const float *src = reinterpret_cast<const float *>(rows + r * stride);
+        float mx = 0.0f;
+        uint32_t bad = 0;
+        for (int e = 4 * l16; e < dim; e += 64) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (e + j < dim) { const float v = src[e + j]; mx = fmaxf(mx, fabsf(v)); bad |= !(fabsf(v) <= 3.0e38f); }
+        }
+        mx = fmaxf(mx, vg_dpp<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(mx));
+        mx = fmaxf(mx, vg_dpp<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(mx));
+        mx = fmaxf(mx, vg_dpp<VG_DPP_ROW_HALF_MIRROR>(mx));
+        mx = fmaxf(mx, vg_dpp<VG_DPP_ROW_MIRROR>(mx));
+        bad = vg_group_or(bad, 4);
+        const float sx = (mx > 0.0f) ? mx / 127.0f : 0.0f;
+        const float inv = (mx > 0.0f) ? 1.0f / sx : 0.0f;
+        double e2 = 0.0;
+        for (int e = 4 * l16; e < (int)ostride; e += 64) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (e + j < dim && !bad) {
+                    const float v = src[e + j];
+                    const int xi = vgf_q8(v, inv);
+                    const double res = (double)v - (double)sx * (double)xi;
+                    e2 += res * res;
+                    w |= (uint32_t)(xi & 255) << (8 * j);
+                }
+            }
+            if (live) *reinterpret_cast<uint32_t *>(out + r * ostride + e) = w;
+        }
+        e2 = vg_group_sum(e2, 4);
+        if (live && l16 == 0) {
+            float ex = (float)sqrt(e2);
+            ex = ex * (1.0f + 4.0e-7f) + 1.0e-37f;                        // rounded up (f64 sum, one sqrt, one conversion)
+            stat[r] = bad ? make_float2(__builtin_nanf(""), 0.0f) : make_float2(sx, e2 > 0.0 ? ex : 0.0f);
+        }
+    }
+}
+
+static long long q8_shadow_stride(const vg_corpus *c) { return (((long long)c->dim + 15) / 16) * 16; }
+// which shadow copy the f32 filter scans stream: the int8 one (a quarter of the corpus' bytes, + 26 % HBM) unless
+// VG_SCAN_FILTER_SHADOW=bf16 (half the bytes, + 50 % HBM - the copy the batched filter kernel reads)
+static bool filter_uses_q8(const vg_corpus *c) {
+    if (c->vtype != VG_TYPE_F32) return false;
+    const char *e = getenv("VG_SCAN_FILTER_SHADOW");
+    return !(e && (e[0] == 'b' || e[0] == 'B'));
+}
+int vg_ensure_q8_shadow(vg_corpus *c) {
+    const long long qs = q8_shadow_stride(c);
+    if (c->q8_cap < c->n_rows) {
+        const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_rows_q8) hipFree(c->d_rows_q8);
+        if (c->d_q8stat) hipFree(c->d_q8stat);
+        c->d_rows_q8 = nullptr; c->d_q8stat = nullptr; c->q8_cap = 0; c->q8_rows = 0;
+        HIP_TRY(hipMalloc(&c->d_rows_q8, (size_t)cap * qs));
+        HIP_TRY(hipMalloc(&c->d_q8stat, (size_t)cap * sizeof(float2)));
+        c->q8_cap = cap;
+    }
+    if (c->q8_rows < c->n_rows) {
+        const long long n = c->n_rows - c->q8_rows;
+        const long long blocks = std::min<long long>((n * 16 + 255) / 256, 256 * 32);
+        hipLaunchKernelGGL(vg_f32_to_q8_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_rows, (long long)c->q8_rows, n,
+                           (long long)c->stride, c->dim, c->d_rows_q8, qs, reinterpret_cast<float2 *>(c->d_q8stat));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return vg_fail(VG_ERR_HIP, "int8 shadow pass failed: %s", hipGetErrorString(e));
+        c->q8_rows = c->n_rows;
+    }
+    return VG_OK;
 }
 static int filter_mode_of(int metric) {
     return (metric == VG_DIST_DOT) ? VGF_DOT : (metric == VG_DIST_COSINE ? VGF_COS : (metric == VG_DIST_L1 ? VGF_L1 : VGF_L2));
@@ -71,12 +166,15 @@ static int filter_mode_of(int metric) {
 // chunks per lane the filter kernels hold without spilling under the 128-VGPR cap of 16 wavefronts per CU (tools/kernel_regs.py)
 static int filter_u_cap(const vg_corpus *) { return 6; }
 // bytes per row the filter streams: the bf16 shadow copy of an f32 corpus, the rows themselves otherwise
-static long long filter_stream_stride(const vg_corpus *c) { return c->vtype == VG_TYPE_F32 ? vg_bf16_shadow_stride(c) : (long long)c->stride; }
+static long long filter_stream_stride(const vg_corpus *c) {
+    if (c->vtype != VG_TYPE_F32) return (long long)c->stride;
+    return filter_uses_q8(c) ? q8_shadow_stride(c) : vg_bf16_shadow_stride(c);
+}
 
 // Returns -1 when the shape is not served (caller takes the plain scan).
 int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream) {
     if (!scan_filter_serves(c, metric)) return -1;
-    const bool f32 = (c->vtype == VG_TYPE_F32);
+    const bool f32 = (c->vtype == VG_TYPE_F32), q8 = filter_uses_q8(c);
     const long long bs = filter_stream_stride(c);
     const int nch_b = (int)(bs / 16);
     Shape s;
@@ -84,7 +182,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     if (s.long_rows) return -1;
     {   // experiment override of the filter's own launch shape
         const int fl = env_int("VG_FILTER_LPR_LOG2", -1), fu = env_int("VG_FILTER_U", -1);
-        if (fl >= 0 && fl <= 6 && fu > 0 && (nch_b + (1 << fl) - 1) / (1 << fl) <= fu && pick_filter<true>(c->vtype, filter_mode_of(metric), fu)) { s.lpr_log2 = fl; s.U = fu; }
+        if (fl >= 0 && fl <= 6 && fu > 0 && (nch_b + (1 << fl) - 1) / (1 << fl) <= fu && pick_filter<true>(c->vtype, filter_mode_of(metric), fu, q8)) { s.lpr_log2 = fl; s.U = fu; }
     }
     Shape xs;                                            // the plain kernel's own shape: the exact evaluation sums in its order
     vg_plain_scan_shape(c, metric, &xs);
@@ -92,19 +190,14 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     // f32: the shadow copy and the norms cost +50 % of the corpus in HBM.  A corpus they do not fit next to keeps the plain
     // f32 scan (which served it before the filter existed) instead of failing every query.
     int rc = vg_ensure_row_norms(c);
-    if (rc == VG_OK && f32) rc = vg_ensure_bf16_shadow(c);
+    if (rc == VG_OK && f32) rc = q8 ? vg_ensure_q8_shadow(c) : vg_ensure_bf16_shadow(c);
     if (rc == VG_ERR_NOMEM) {
         (void)hipGetLastError();                         // clear the sticky allocation error
         c->filter_disabled = true;
         return -1;
     }
     if (rc != VG_OK) return rc;
-    if (!c->d_filter_evals) {
-        HIP_TRY(hipMalloc(&c->d_filter_evals, sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(c->d_filter_evals, 0, sizeof(unsigned long long), c->stream));
-        HIP_TRY(hipHostMalloc(&c->h_filter_evals, sizeof(unsigned long long)));
-        *c->h_filter_evals = 0;
-    }
+    if ((rc = vg_ensure_filter_counters(c)) != VG_OK) return rc;
     {   // Selectivity guard.  The bound cannot separate rows that are (nearly) identical to each other: on such data every row
         // is a candidate and the exact evaluations - serial per wavefront - cost more than the plain scan.  The kernels count
         // them, a copy behind every launch mirrors the counter into pinned host memory; when the completed launches since the
@@ -127,7 +220,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     }
     const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (c->n_rows * bs > (256ll << 20));
     const int mode = filter_mode_of(metric);
-    filter_fn_t fn = nt ? pick_filter<true>(c->vtype, mode, s.U) : pick_filter<false>(c->vtype, mode, s.U);
+    filter_fn_t fn = nt ? pick_filter<true>(c->vtype, mode, s.U, q8) : pick_filter<false>(c->vtype, mode, s.U, q8);
     if (!fn) return -1;
     const int rpb = VG_WAVE >> s.lpr_log2;
     const long long nbatch = (c->n_rows + rpb - 1) / rpb;
@@ -135,7 +228,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count));
     blocks = std::min<long long>(blocks, VG_SEL_MAX_HEADS);
     FilterScanArgs a;
-    a.shadow = f32 ? c->d_rows_bf : c->d_rows; a.rows = c->d_rows; a.query = dev_query; a.row_norm = c->d_xnorm; a.cand = c->d_cand;
+    a.shadow = f32 ? (q8 ? c->d_rows_q8 : c->d_rows_bf) : c->d_rows; a.q8stat = reinterpret_cast<const float2 *>(c->d_q8stat); a.rows = c->d_rows; a.query = dev_query; a.row_norm = c->d_xnorm; a.cand = c->d_cand;
     a.n_rows = c->n_rows; a.stride = c->stride; a.bstride = bs; a.nch = c->nch; a.nch_b = nch_b;
     a.lpr_log2 = s.lpr_log2; a.k = k; a.root = (metric == VG_DIST_L2) ? 1 : 0; a.dim = c->dim;
     a.mode = mode;
@@ -159,7 +252,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     a.init_keys = nullptr;
     if (prepass) {
         ScanPlan pre;
-        pre.n_rows = std::max<int64_t>(65536, c->n_rows / 64);
+        pre.n_rows = std::max<int64_t>(65536, c->n_rows / std::max(1, env_int("VG_SCAN_FILTER_PREPASS_DIV", 64)));
         pre.allow_filter = false;
         pre.record = false;
         const int rcp = vg_launch_plain_scan(c, metric, dev_query, k, dev_out_keys, stream, pre);
@@ -192,6 +285,6 @@ bool vg_scan_filter_name(vg_corpus *c, int metric, char *out, size_t out_len) {
     const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (c->n_rows * bs > (256ll << 20));
     static const char *mtag[4] = {"l2", "dot", "cos", "l1"};
     snprintf(out, out_len, "scan_filter_%s_%s%s_u%d_lpr%d%s", filter_type_tag(c->vtype), mtag[filter_mode_of(metric)],
-             c->vtype == VG_TYPE_F32 ? "_bf16" : "", fs.U, 1 << fs.lpr_log2, nt ? "_nt" : "");
+             c->vtype == VG_TYPE_F32 ? (filter_uses_q8(c) ? "_q8" : "_bf16") : "", fs.U, 1 << fs.lpr_log2, nt ? "_nt" : "");
     return true;
 }

@@ -95,6 +95,9 @@ struct vg_corpus {
     bool tm_disabled = false;                     // (it did not fit: the kernel gathers from the row-major corpus)
     uint8_t *d_rows_bf = nullptr;                 // f32 corpora: bf16 shadow copy for the matrix-core filter (vg_batch_h.hip)
     int64_t bf_rows = 0, bf_cap = 0;
+    uint8_t *d_rows_q8 = nullptr;                 // f32 corpora: int8 shadow copy for the single-query filter scan (vg_filter.hip) ...
+    void *d_q8stat = nullptr;                     // ... and per row (scale, residual norm) as float2
+    int64_t q8_rows = 0, q8_cap = 0;
     bool filter_disabled = false;                 // the shadow copy / norms did not fit HBM: single queries keep the plain f32 scan
     int scan_filter_mode = -1;                    // vg_corpus_set_scan_filter: -1 = default (env VG_SCAN_FILTER, else on), 0 = off, 1 = on
     unsigned long long *d_filter_evals = nullptr; // filter scan: exact evaluations so far (device counter, one atomic per workgroup) ...
@@ -105,6 +108,10 @@ struct vg_corpus {
     unsigned long long filter_evals_seen = 0;     // ... and when the selectivity guard last looked
     long long filter_launches_seen = 0, filter_launches = 0;
     int filter_cooldown = 0;                      // > 0: the bound is not selective on this data - that many scans take the plain kernel
+    // f32 batches through the bf16 filter (vg_batch_api.hip): counter [1] of d_filter_evals, the same kind of guard
+    unsigned long long bfilter_evals_seen = 0, bfilter_evals_read = 0;
+    long long bfilter_pairs = 0;                  // (query, row) pairs of the filtered batches since the guard last looked
+    int bfilter_cooldown = 0;                     // > 0: that many batches take the f32 matrix-core kernel
     int64_t i8_rows = 0, i8_cap = 0;              // orders a caller-stream scan behind a norm pass on the corpus stream
     void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
     uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;
@@ -157,6 +164,8 @@ int vg_launch_plain_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int
 int vg_launch_merge_one(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, hipStream_t stream);   // vg_api.hip
 int vg_plain_scan_shape(const vg_corpus *c, int metric, VgShape *out);   // vg_api.hip: launch shape of the plain kernel
 int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream);   // vg_filter.hip; -1: not served
+bool vg_scan_filter_policy(const vg_corpus *c);      // vg_filter.hip: filter switched on for this corpus and the corpus large enough for the shadow copy to pay
+int vg_ensure_filter_counters(vg_corpus *c);         // vg_filter.hip: d_filter_evals[2] + pinned mirror
 bool vg_scan_filter_name(vg_corpus *c, int metric, char *out, size_t out_len);   // vg_filter.hip: kernel name when the filter serves the scan
 long long vg_bf16_shadow_stride(const vg_corpus *c);               // vg_batch_api.hip: row stride of the bf16 shadow copy of an f32 corpus
 int vg_ensure_bf16_shadow(vg_corpus *c);                           // vg_batch_api.hip: build / extend it (corpus stream)

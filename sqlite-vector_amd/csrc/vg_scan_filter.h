@@ -10,6 +10,14 @@
 // 2^-8 (1 + 2^-8) - one input's worth: rows whose elements all round the same way, e.g. a constant 1 + 2^-8 - 2^-20, could
 // lose an exact duplicate of the query.  tests/test_gpu_filter_bound.py.)
 //
+// f32 corpora, Q8 = true - a QUARTER of the bytes.  The shadow copy is int8: per row x = sx * xi + ex with integers
+// xi in [-127, 127], sx = max|x| / 127 and ex the exact residual (vg_f32_to_q8_kernel stores sx and ||ex||, computed in f64
+// and rounded up, next to the row); the query is split the same way in this kernel (q = sq * qi + eq).  Then
+//     q.x = sq sx (qi.xi) + sq (qi.ex) + eq.x      |q.x - sq sx (qi.xi)| <= sq ||qi|| ||ex|| + ||eq|| ||x||   (Cauchy-Schwarz)
+// with qi.xi an exact integer (v_dot4_i32_i8).  No rounding argument is involved: whatever integers the quantizer picked,
+// the residuals are what is left.  The bound adapts to the data (||ex|| ~ sx sqrt(D / 12)): on N(0,1) rows of 384 floats
+// ~5.6 against the bf16 copy's 3.0 - about twice the candidates for half the bytes.
+//
 // f16 / bf16 corpora (XT = T_F16 / T_BF16) - less ARITHMETIC.  Their plain scans follow the reference's f64 accumulation
 // (distance-avx2.c:166-582) and that chain, not HBM, bounds them (5.2-6.4 TB/s).  Here the kernel reads the rows
 // themselves (no shadow copy) and forms s~ in f32 - exact products of two halves, f32 sums: |s~ - s| <= c |q||x| with
@@ -38,6 +46,7 @@ struct FilterScanArgs {
     const uint8_t *rows;       // N x stride bytes: what the exact evaluation reads (the corpus)
     const uint8_t *query;      // the query in the corpus' element type, nch * 16 bytes, zero padded (device or pinned host)
     const float *row_norm;     // per row: ||x|| (f32 corpora) / (float) sum x^2 (f16 / bf16 corpora)
+    const float2 *q8stat;      // int8 shadow copy only: per row (sx, ||ex|| rounded up); sx = NaN for rows the filter must not judge
     uint64_t *cand;
     long long n_rows, stride, bstride;
     int nch, nch_b;            // 16-byte chunks per corpus row / per streamed row
@@ -74,6 +83,24 @@ __device__ inline void vgf_dot_chunk(const uint4 &q, const uint4 &x, float &s0, 
     }
 }
 
+// the 16 products of one 16-byte chunk of int8 elements, exact
+__device__ inline void vgf_dot_chunk_i8(const uint4 &q, const uint4 &x, int &i0, int &i1) {
+    i0 = __builtin_amdgcn_sdot4((int)q.x, (int)x.x, i0, false);
+    i1 = __builtin_amdgcn_sdot4((int)q.y, (int)x.y, i1, false);
+    i0 = __builtin_amdgcn_sdot4((int)q.z, (int)x.z, i0, false);
+    i1 = __builtin_amdgcn_sdot4((int)q.w, (int)x.w, i1, false);
+}
+// the int8 image of one f32 element under scale s (inv = 1 / s up to rounding; any integer in [-127, 127] is a valid choice -
+// the residual is defined against whatever comes out of here)
+__device__ inline int vgf_q8(float v, float inv) {
+    const float t = rintf(v * inv);
+    return (int)fminf(fmaxf(t, -127.0f), 127.0f);
+}
+__device__ inline uint32_t vgf_q8_pack4(const uint4 &f, float inv) {
+    return (uint32_t)(vgf_q8(__uint_as_float(f.x), inv) & 255) | ((uint32_t)(vgf_q8(__uint_as_float(f.y), inv) & 255) << 8) |
+           ((uint32_t)(vgf_q8(__uint_as_float(f.z), inv) & 255) << 16) | ((uint32_t)(vgf_q8(__uint_as_float(f.w), inv) & 255) << 24);
+}
+
 // s += sum |q - x| over the 8 elements of one 16-byte chunk: the reference's own f32 differences (distance-avx2.c:222-279 f16;
 // bf16 subtracts in f64, :434-489 - an f32 difference of two bf16 values is off by at most 2^-24 of itself), summed in f32
 // instead of f64.  Every term is >= 0, so the f32 sum is within (D + 64) 2^-23 of the f64 one, relatively: a lower bound of
@@ -93,12 +120,13 @@ __device__ inline void vgf_l1_chunk(const uint4 &q, const uint4 &x, float &s0, f
 
 // MODE (VGF_*) is a template parameter: as a run-time switch every instantiation carried all the exact evaluations (three
 // sets of f64 accumulators for the half types) and the streaming loop spilled beyond 3 chunks per lane.
-template <int XT, int MODE, int U, bool NT>
+template <int XT, int MODE, int U, bool NT, bool Q8 = false>
 __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs a) {
     constexpr bool XF32 = (XT == T_F32);
     constexpr bool L1M = (MODE == VGF_L1);
     constexpr int mode = MODE;
     static_assert(!(XF32 && L1M), "the f32 L1 scan has no filter variant");
+    static_assert(!Q8 || XF32, "the int8 shadow copy belongs to f32 corpora");
     constexpr int FT = XF32 ? T_BF16 : XT;                                // element type the filter multiplies
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & (VG_WAVE - 1);
@@ -111,11 +139,56 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
     uint4 *qs = reinterpret_cast<uint4 *>(smem);
     for (int c = threadIdx.x; c < a.nch; c += VG_BLOCK) qs[c] = reinterpret_cast<const uint4 *>(a.query)[c];
     __syncthreads();
+    // int8 shadow: the query's own split q = sq * qi + eq (sq = max|q| / 127)
+    float q8_sq = 0.0f, q8_sqi = 0.0f, q8_eqn = 0.0f;                     // sq | sq ||qi|| | ||eq||, the last two rounded up
+    bool q8_ok = true;
+    float q8_inv = 0.0f;
+    if constexpr (Q8) {
+        float mx = 0.0f;
+        uint32_t bad = 0;
+        for (int c = lane; c < a.nch; c += VG_WAVE) {
+            const uint4 v = qs[c];
+            const float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mx = fmaxf(mx, fabsf(f[j])); bad |= !(fabsf(f[j]) <= 3.0e38f); }
+        }
+        mx = fmaxf(mx, vg_dpp<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(mx));
+        mx = fmaxf(mx, vg_dpp<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(mx));
+        mx = fmaxf(mx, vg_dpp<VG_DPP_ROW_HALF_MIRROR>(mx));
+        mx = fmaxf(mx, vg_dpp<VG_DPP_ROW_MIRROR>(mx));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        q8_ok = (__ballot(bad != 0) == 0) && mx >= 1.0e-30f && mx <= 1.0e30f;
+        q8_sq = q8_ok ? mx / 127.0f : 1.0f;
+        q8_inv = 1.0f / q8_sq;
+        uint32_t i2 = 0;
+        float e2 = 0.0f;
+        for (int c = lane; c < a.nch; c += VG_WAVE) {
+            const uint4 v = qs[c];
+            const float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int qi = vgf_q8(f[j], q8_inv);
+                const float e = fmaf(-q8_sq, (float)qi, f[j]);           // one rounding
+                i2 += (uint32_t)(qi * qi);
+                e2 = fmaf(e, e, e2);
+            }
+        }
+        i2 = vg_group_sum(i2, 6);
+        e2 = vg_group_sum(e2, 6);
+        q8_sqi = q8_sq * sqrtf((float)i2) * (1.0f + 1.0e-5f);
+        q8_eqn = sqrtf(e2) * (1.0f + 1.0e-4f);                           // (f32 sum of D squares, each off by 2^-23 of itself at most)
+    }
     uint4 q[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int cb = sub + u * lpr;
-        if constexpr (XF32) {                                             // bf16 chunk cb = f32 chunks 2cb, 2cb+1, rounded
+        if constexpr (Q8) {                                               // int8 chunk cb = f32 chunks 4cb .. 4cb+3
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (4 * cb + j < a.nch) ? vgf_q8_pack4(qs[4 * cb + j], q8_inv) : 0u;
+            q[u] = make_uint4(w[0], w[1], w[2], w[3]);
+        } else if constexpr (XF32) {                                      // bf16 chunk cb = f32 chunks 2cb, 2cb+1, rounded
             const uint4 f0 = (2 * cb < a.nch) ? qs[2 * cb] : make_uint4(0u, 0u, 0u, 0u);
             const uint4 f1 = (2 * cb + 1 < a.nch) ? qs[2 * cb + 1] : make_uint4(0u, 0u, 0u, 0u);
             q[u] = make_uint4(vgf_pack_bf16(f0.x, f0.y), vgf_pack_bf16(f0.z, f0.w), vgf_pack_bf16(f1.x, f1.y), vgf_pack_bf16(f1.z, f1.w));
@@ -135,7 +208,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
         qq = vg_group_sum(t0 + t1, 6);
     }
     const float qn = sqrtf(qq);
-    const bool q_ok = (qq >= 1.0e-30f && qq <= 1.0e30f);                  // else: every row takes the exact path
+    const bool q_ok = (qq >= 1.0e-30f && qq <= 1.0e30f) && q8_ok;         // else: every row takes the exact path
     // f16 only: v_dot2_f32_f16 may flush subnormal halves (|v| < 2^-14) to zero.  What s~ can lose that way:
     //   rows' subnormal elements   sum |q_i| 2^-14 <= 2^-14 |q|_1                      (esub_q, the same for every row)
     //   the query's subnormals     sum 2^-14 |x_i| <= 2^-14 sqrt(D) |x|                 (esub_x * |x|, zero unless the query has any)
@@ -246,17 +319,24 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
     long long b = (long long)blockIdx.x * VG_WAVES_PER_BLOCK + wave;
     uint4 cur[U], nxt[U];
     float nrm_cur = 0.0f, nrm_nxt = 0.0f;
-    auto load = [&](uint4 (&dst)[U], float &nrm, long long batch) {
+    float2 q8_cur = make_float2(0.0f, 0.0f), q8_nxt = make_float2(0.0f, 0.0f);
+    auto load = [&](uint4 (&dst)[U], float &nrm, float2 &q8s, long long batch) {
         vg_load_batch<U, NT>(dst, a.shadow, batch * rpb + rib, (batch < nbatch) ? a.n_rows : 0, a.bstride, sub, lpr, a.nch_b);
         const long long r0 = batch * rpb + rib;
         nrm = (batch < nbatch && r0 < a.n_rows) ? a.row_norm[r0] : 0.0f;
+        if constexpr (Q8) q8s = (batch < nbatch && r0 < a.n_rows) ? a.q8stat[r0] : make_float2(0.0f, 0.0f);
     };
-    load(cur, nrm_cur, b);
+    load(cur, nrm_cur, q8_cur, b);
     while (b < nbatch) {
         const long long bn = b + wstride;
-        load(nxt, nrm_nxt, bn);
+        load(nxt, nrm_nxt, q8_nxt, bn);
         float s0 = 0.0f, s1 = 0.0f;
-        if constexpr (L1M) {
+        if constexpr (Q8) {
+            int i0 = 0, i1 = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) vgf_dot_chunk_i8(q[u], cur[u], i0, i1);
+            s0 = (float)(int)vg_group_sum((uint32_t)(i0 + i1), lpr_log2) * (q8_sq * q8_cur.x);     // sq sx (qi.xi)
+        } else if constexpr (L1M) {
             // keep the query as RAW halves in registers (the compiler would hoist the widened copies out of the loop and spill)
 #pragma unroll
             for (int u = 0; u < U; ++u) asm volatile("" : "+v"(q[u].x), "+v"(q[u].y), "+v"(q[u].z), "+v"(q[u].w));
@@ -266,15 +346,18 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
 #pragma unroll
             for (int u = 0; u < U; ++u) vgf_dot_chunk<FT>(q[u], cur[u], s0, s1);
         }
-        const float st = vg_group_sum(s0 + s1, lpr_log2);
+        const float st = Q8 ? s0 : vg_group_sum(s0 + s1, lpr_log2);
         const long long row = b * rpb + rib;
         // cached norm: ||x|| for f32 corpora, sum x^2 for f16 / bf16 corpora
         const float nn = XF32 ? nrm_cur * nrm_cur : nrm_cur;
         const float nrm = XF32 ? nrm_cur : sqrtf(nrm_cur);
-        const float E = a.cerr * qn * nrm + esub_q + esub_x * nrm;
+        // int8 shadow: sq ||qi|| ||ex|| + ||eq|| ||x|| (the cached norm is within rel of ||x||) + the three roundings of st
+        const float E = Q8 ? q8_sqi * q8_cur.y + q8_eqn * nrm * (1.0f + a.rel) + 4.0e-7f * fabsf(st)
+                           : a.cerr * qn * nrm + esub_q + esub_x * nrm;
         // (L1 needs no norm: its bound is the f32 sum itself; a NaN / Inf / overflowing sum sends the row to the exact path)
         const bool judged = L1M ? (xq_special == 0u && st < 3.0e38f)
-                                : (q_ok && (XF32 ? (nrm >= 1.0e-15f && nrm <= 1.0e15f) : (nn >= 1.0e-30f && nn <= 1.0e30f)));
+                                : (q_ok && (XF32 ? (nrm >= 1.0e-15f && nrm <= 1.0e15f) : (nn >= 1.0e-30f && nn <= 1.0e30f)) &&
+                                   (!Q8 || (q8_cur.x > 0.0f && q8_cur.x <= 3.0e38f)));       // (sx = NaN: Inf / NaN elements)
         // lower bound of the distance (squared for L2)
         float lb;
         if (L1M) lb = st - 2.0f * a.rel * st;
@@ -298,6 +381,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
         nrm_cur = nrm_nxt;
+        q8_cur = q8_nxt;
         b = bn;
     }
     __syncthreads();                                   // everyone is done with the query staging area

@@ -25,6 +25,14 @@ DOWN = np.float32(1 + 2.0 ** -8 - 2.0 ** -20)    # just below a bf16 midpoint: r
 UP = np.float32(1 + 2.0 ** -8 + 2.0 ** -20)      # just above it: rounds UP to 1 + 2^-7
 
 
+@pytest.fixture(autouse=True, params=("bf16", "int8"))
+def shadow(request, monkeypatch):
+    """every case of this file runs through BOTH shadow copies of an f32 corpus: bf16 (half the bytes, rounding-error bound) and
+    int8 (a quarter of the bytes, residual-norm bound - vg_scan_filter.h, Q8).  Whatever the data, the answers are the plain scan's."""
+    monkeypatch.setenv("VG_SCAN_FILTER_SHADOW", request.param)
+    return request.param
+
+
 @pytest.fixture(autouse=True)
 def _no_selectivity_guard(request, monkeypatch):
     """these tests compare the FILTER kernel with the plain one: the selectivity guard (which sends an unselective corpus back
@@ -96,7 +104,7 @@ def filler(n, dim, seed):
 
 @pytest.mark.parametrize("dim", (33, 384))
 @pytest.mark.parametrize("metric", (dg.L2, dg.SQUARED_L2, dg.DOT))
-def test_filter_keeps_the_exact_duplicate_when_every_element_rounds_the_same_way(pkg, orc, dim, metric, monkeypatch):
+def test_filter_keeps_the_exact_duplicate_when_every_element_rounds_the_same_way(pkg, orc, dim, metric, shadow, monkeypatch):
     """no pre-pass here (n < 2^20): every wavefront tightens its OWN list, so the competitors are dense - every 4th row -
     and each of the ~4096 wavefronts has met far more than k of them when the target arrives near the end of the scan"""
     monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
@@ -118,7 +126,7 @@ def test_filter_keeps_the_exact_duplicate_when_every_element_rounds_the_same_way
     assert oids[0] == pos_t + 1
     for kk in (1, k, 64):
         c.set_scan_filter(1)
-        assert c.kernel_name(metric).startswith("scan_filter_f32")
+        assert c.kernel_name(metric).startswith("scan_filter_f32") and ("_q8_" in c.kernel_name(metric)) == (shadow == "int8")
         ids1, d1 = c.scan_topk(metric, q, kk)
         c.set_scan_filter(0)
         assert not c.kernel_name(metric).startswith("scan_filter")
@@ -277,3 +285,111 @@ def test_selectivity_guard_on_a_corpus_of_identical_rows(pkg, orc, monkeypatch):
     assert seen[0] > n // 2 and seen[1] > n // 2                      # unselective: (nearly) every row evaluated exactly ...
     assert seen[3] == 0 and seen[4] == 0 and seen[5] == 0              # ... so the following scans take the plain kernel
     c.close()
+
+
+# ---------------------------------------------------------------------------------------------- the int8 shadow copy
+def q8_split(v):
+    """the kernel's split of a vector: v = s * vi + e, s = max|v| / 127 (vg_f32_to_q8_kernel / the query's part of the filter kernel)"""
+    v64 = v.astype(np.float64)
+    s = float(np.float32(np.abs(v).max()) / np.float32(127.0))
+    vi = np.clip(np.rint(v64 / s), -127, 127)
+    return s, vi, v64 - s * vi
+
+
+def q8_lower_bound(q, x, metric):
+    """vg_scan_filter.h's int8 bound restated in f64: |q.x - sq sx (qi.xi)| <= sq |qi| |ex| + |eq| |x|"""
+    sq, qi, eq = q8_split(q)
+    sx, xi, ex = q8_split(x)
+    st = sq * sx * float((qi * xi).sum())
+    E = sq * np.linalg.norm(qi) * np.linalg.norm(ex) + np.linalg.norm(eq) * np.linalg.norm(x.astype(np.float64))
+    qq, nn = float((q.astype(np.float64) ** 2).sum()), float((x.astype(np.float64) ** 2).sum())
+    if metric == dg.DOT:
+        return -(st + E)
+    return qq + nn - 2.0 * (st + E)
+
+
+def q8_adversarial_case(dim, n_comp, seed):
+    """every element of the target sits just below a quantization MIDPOINT (s (m + 0.5)): all residuals are +s/2, coherent -
+    the worst case for an error estimate that assumed they cancel; query == target.  Competitors are grid-exact rows
+    (residual 0: their bound is tight) a little worse than the target."""
+    rng = np.random.default_rng(seed)
+    s = 1.0 / 127.0
+    m = rng.integers(10, 100, dim).astype(np.float64)
+    target = (s * (m + 0.499)).astype(np.float32)
+    target[0] = np.float32(1.0)                                    # sets the scale: max = 127 s
+    m[0] = 127.0
+    comps = []
+    for j in range(n_comp):
+        c = (s * m).astype(np.float32)
+        c[1 + (j % (dim - 1))] += np.float32(s * (j % 3))
+        comps.append(c)
+    return target.copy(), target, np.stack(comps)
+
+
+@pytest.mark.parametrize("dim", (17, 384, 1000))
+@pytest.mark.parametrize("metric", (dg.L2, dg.SQUARED_L2, dg.COSINE))
+def test_int8_shadow_keeps_the_exact_duplicate_with_coherent_residuals(pkg, orc, dim, metric, shadow, monkeypatch):
+    """the int8 counterpart of the rounding cases above: residuals of the same sign in every element of the query and of the
+    true best row.  The restated bound must admit the target (<= its true distance 0) although the ESTIMATE s~ alone would put
+    it behind the grid-exact competitors; the scan must return the plain scan's rows and bits."""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    k = 20
+    q, target, comps = q8_adversarial_case(dim, 3 * k, 6100 + dim)
+    sq, qi, eq = q8_split(q)
+    sx, xi, ex = q8_split(target)
+    st = sq * sx * float((qi * xi).sum())
+    naive = float((q.astype(np.float64) ** 2).sum() + (target.astype(np.float64) ** 2).sum() - 2.0 * st)   # estimate without the error term
+    d_c = np.sort([true_distance(q, c, dg.L2) for c in comps])
+    assert naive > d_c[k - 1] > 0.0, "the estimate alone must rank the target behind k competitors"
+    assert q8_lower_bound(q, target, dg.L2) <= 0.0, "the bound must admit the exact duplicate"
+    n = 200_003
+    rows = filler(n, dim, 6200 + dim)
+    pos_comp = np.arange(0, n - 1000, 4)
+    rows[pos_comp] = comps[np.arange(len(pos_comp)) % len(comps)]
+    pos_t = n - 77
+    rows[pos_t] = target
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    want = orc.scan_distances(orc.AVX2, metric, dg.F32, q, rows)
+    for kk in (1, k, 64):
+        c.set_scan_filter(1)
+        ids1, d1 = c.scan_topk(metric, q, kk)
+        c.set_scan_filter(0)
+        ids0, d0 = c.scan_topk(metric, q, kk)
+        assert ids0[0] == pos_t + 1 and d0[0] == 0.0
+        assert ids1.tolist() == ids0.tolist(), (dim, metric, kk)
+        assert dg.same_float_bits(d1, d0), (dim, metric, kk)
+        _check_float_distances(d1.astype(np.float32), want[ids1 - 1], dg.F32, metric, q, rows[ids1 - 1])
+    c.close()
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_int8_shadow_fuzz_outliers_and_scales(pkg, chunk, shadow, monkeypatch):
+    """rows whose scale is set by ONE outlier (everything else quantizes to a handful of levels - large residuals), rows of very
+    different magnitudes, near-duplicates of the query, zero / Inf / NaN rows: the filter's answers are the plain scan's"""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    rng = np.random.default_rng(8800 + chunk)
+    for _ in range(5):
+        dim = int(rng.choice([rng.integers(2, 40), rng.integers(40, 400), rng.integers(400, 1100)]))
+        n = int(rng.integers(600, 30000))
+        rows = rng.standard_normal((n, dim)).astype(np.float32)
+        rows *= np.exp2(rng.integers(-20, 20, (n, 1))).astype(np.float32)            # magnitudes over 12 decades
+        out = rng.random(n) < 0.3
+        rows[out, rng.integers(0, dim)] *= np.float32(300.0)                        # one outlier sets the row's scale
+        q = rows[int(rng.integers(0, n))].copy()
+        dup = rng.permutation(n)[:50]
+        rows[dup] = q * (1 + rng.standard_normal((50, 1)).astype(np.float32) * np.float32(1e-3))
+        rows[int(rng.integers(0, n))] = 0.0
+        rows[int(rng.integers(0, n)), 0] = np.float32(np.inf)
+        rows[int(rng.integers(0, n)), dim - 1] = np.float32(np.nan)
+        c = pkg.Corpus(pkg.F32, dim)
+        c.append(rows)
+        for metric in (dg.L2, dg.DOT, dg.COSINE):
+            for k in (1, 20, 64):
+                c.set_scan_filter(1)
+                ids1, d1 = c.scan_topk(metric, q, k)
+                c.set_scan_filter(0)
+                ids0, d0 = c.scan_topk(metric, q, k)
+                assert ids1.tolist() == ids0.tolist(), (dim, n, metric, k)
+                assert dg.same_float_bits(d1, d0), (dim, n, metric, k)
+        c.close()

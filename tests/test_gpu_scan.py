@@ -480,6 +480,57 @@ def test_batch_f32_long_rows_through_the_bf16_filter(pkg, orc, metric, monkeypat
         c.close()
 
 
+@pytest.mark.gpu
+def test_batch_f32_filter_default_policy_and_selectivity_guard(pkg, monkeypatch):
+    """f32 batches of a corpus the filter scan serves (switched on, large enough - here VG_SCAN_FILTER_MIN_MB=0) go through
+    the bf16-filter kernel by default: same lists as the f32 matrix-core kernel; scan_filter=0 / VG_F32_FILTER=0 keep the f32
+    kernel; on rows the bound cannot separate (copies of one row) the guard sends the next batches back to the f32 kernel."""
+    monkeypatch.delenv("VG_F32_FILTER", raising=False)
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    monkeypatch.setenv("VG_BATCH_MFMA", "1")
+    # (large enough for the two-pass launch: with lists warming up from +Inf in 256 partitions a small corpus has most of its
+    # pairs evaluated exactly - which is why the default needs the filter scan's size threshold)
+    n, dim, nq, k = 2_200_003, 64, 70, 20
+    rows = np.random.default_rng(9901).standard_normal((n, dim), dtype=np.float32)
+    qs = dg.corpus(dg.F32, nq, dim, 9902)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    for metric in (dg.DOT, dg.L2, dg.COSINE):
+        c.set_scan_filter(-1)
+        c.batch_filter_exact_evals()
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        evals = c.batch_filter_exact_evals()
+        assert 0 < evals < nq * n // 256, (metric, evals)          # the filtered path ran and was selective
+        c.set_scan_filter(0)                                       # the per-corpus switch: f32 matrix-core kernel
+        ids0, dist0, cnt0 = c.scan_topk_batch(metric, qs, k)
+        assert c.batch_filter_exact_evals() == 0
+        monkeypatch.setenv("VG_F32_FILTER", "0")                   # the environment switch does the same
+        c.set_scan_filter(-1)
+        ids1, dist1, cnt1 = c.scan_topk_batch(metric, qs, k)
+        assert c.batch_filter_exact_evals() == 0
+        monkeypatch.delenv("VG_F32_FILTER")
+        assert np.array_equal(cnt, cnt0) and np.array_equal(cnt, cnt1)
+        for i in range(nq):
+            _same_topk_up_to_ties(ids[i], dist[i], ids0[i], dist0[i], rtol=1e-5)
+            _same_topk_up_to_ties(ids1[i], dist1[i], ids0[i], dist0[i], rtol=1e-5)
+        one_ids, one_dist = c.scan_topk(metric, qs[3], k)          # the filtered batch carries the single scan's arithmetic
+        _same_topk_up_to_ties(ids[3], dist[3], one_ids, one_dist, rtol=1e-6)
+    c.close()
+    # copies of one row: every (query, row) pair has the same bound - nothing can be excluded
+    del rows
+    same = np.tile(dg.corpus(dg.F32, 1, dim, 9903), (20000, 1))
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(same)
+    ids, dist, cnt = c.scan_topk_batch(dg.L2, qs, k)
+    first = c.batch_filter_exact_evals()
+    assert first > nq * 20000 // 256                               # ... the guard sees it ...
+    ids2, dist2, cnt2 = c.scan_topk_batch(dg.L2, qs, k)
+    assert c.batch_filter_exact_evals() == 0                       # ... and this batch took the f32 matrix-core kernel
+    assert np.array_equal(ids, ids2) and np.allclose(dist, dist2, rtol=1e-5)
+    assert ids[0].tolist() == list(range(1, k + 1))                # ties resolve by scan position on both paths
+    c.close()
+
+
 def _same_topk_up_to_ties(ids, dist, ids0, dist0, rtol=1e-6):
     """two result lists of one query agree: same distances (summation order only) and the same rows except where
     neighbouring distances tie within that tolerance"""

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--types", default="f32,f16,bf16")
+    ap.add_argument("--data", default="clustered,near,gaussian")
     args = ap.parse_args()
     import torch
     torch.cuda.init()
@@ -26,8 +28,13 @@ def main():
     pkg = g.load_package()
     n, dim = args.rows, args.dim
     mnames = {1: "l2", 3: "cos", 4: "dot", 5: "l1"}
-    for data in ("clustered unit-norm (1000 centres, noise 0.3)", "near-duplicates (20000 distinct rows + 1e-3 noise)"):
+    shadow = os.environ.get("VG_SCAN_FILTER_SHADOW", "int8 (default)")
+    for data in ("clustered unit-norm (1000 centres, noise 0.3)", "near-duplicates (20000 distinct rows + 1e-3 noise)", "gaussian N(0,1)"):
+        if data.split()[0].split("-")[0] not in args.data.split(","):
+            continue
         for tname, vt, tdt in (("f32", pkg.F32, torch.float32), ("f16", pkg.F16, torch.float16), ("bf16", pkg.BF16, torch.bfloat16)):
+            if tname not in args.types.split(","):
+                continue
             gen = torch.Generator(device="cuda")
             gen.manual_seed(7)
             ncent = 1000 if data.startswith("clustered") else 20000
@@ -40,8 +47,11 @@ def main():
             for r0 in range(0, n, 1_000_000):
                 nr = min(1_000_000, n - r0)
                 idx = torch.randint(0, ncent, (nr,), generator=gen, device="cuda")
-                x = cent[idx] + noise / (dim ** 0.5) * torch.randn((nr, dim), generator=gen, device="cuda")
-                x /= x.norm(dim=1, keepdim=True)
+                if data.startswith("gaussian"):
+                    x = torch.randn((nr, dim), generator=gen, device="cuda")
+                else:
+                    x = cent[idx] + noise / (dim ** 0.5) * torch.randn((nr, dim), generator=gen, device="cuda")
+                    x /= x.norm(dim=1, keepdim=True)
                 t = x.to(tdt).contiguous()
                 torch.cuda.synchronize()
                 c.append_device(t.data_ptr(), nr, dim * es)
@@ -49,7 +59,7 @@ def main():
                     keep = t[:64].clone()
                 del t, x
             qs = keep.view(torch.uint8).cpu().numpy().view({4: np.float32, 2: np.uint16}[es]).reshape(64, dim)
-            line = "%-52s %-4s %dx%d:" % (data, tname, n, dim)
+            line = "%-52s %-4s %dx%d%s:" % (data, tname, n, dim, (" [shadow " + shadow + "]") if vt == pkg.F32 else "")
             for m in (1, 3, 4) + ((5,) if vt != pkg.F32 else ()):
                 res = {}
                 for mode in (1, 0):
