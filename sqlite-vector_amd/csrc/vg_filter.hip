@@ -73,30 +73,41 @@ template <bool NT>
 static filter_fn_t pick_filter(int vtype, int mode, int U, bool q8 = false) {
     switch (vtype) {
         case VG_TYPE_F32: return q8 ? pick_filter_mode<T_F32, NT, true>(mode, U) : pick_filter_mode<T_F32, NT, false>(mode, U);
-        case VG_TYPE_F16: return pick_filter_mode<T_F16, NT, false>(mode, U);
-        case VG_TYPE_BF16: return pick_filter_mode<T_BF16, NT, false>(mode, U);
+        case VG_TYPE_F16: return q8 ? pick_filter_mode<T_F16, NT, true>(mode, U) : pick_filter_mode<T_F16, NT, false>(mode, U);
+        case VG_TYPE_BF16: return q8 ? pick_filter_mode<T_BF16, NT, true>(mode, U) : pick_filter_mode<T_BF16, NT, false>(mode, U);
     }
     return nullptr;
 }
 
-// ---- the int8 shadow copy of an f32 corpus (vg_scan_filter.h, Q8): 16 lanes per row.  Row r becomes ostride bytes of int8
+// ---- the int8 shadow copy of a corpus (vg_scan_filter.h, Q8): 16 lanes per row.  Row r becomes ostride bytes of int8
 // (zero padded) and stat[r] = (sx, ||ex||): sx = max|x| / 127, ex = x - sx * xi formed and summed in f64 (the product of a
-// float and a 7-bit integer is exact there), its norm rounded up.  Rows with Inf / NaN elements get sx = NaN (never judged).
-__global__ __launch_bounds__(256) void vg_f32_to_q8_kernel(const uint8_t *rows, long long row0, long long n, long long stride, int dim,
-                                                           uint8_t *out, long long ostride, float2 *stat) {
+// float and a 7-bit integer is exact there; f16 / bf16 elements widen to f32 exactly), its norm rounded up.  Rows with
+// Inf / NaN elements get sx = NaN (never judged).
+template <int XT> __device__ inline float vgq_elem(const uint8_t *row, int e) {
+    if constexpr (XT == T_F32) return reinterpret_cast<const float *>(row)[e];
+    else {
+        float lo, hi;
+        vg_unpack2<XT>(reinterpret_cast<const uint32_t *>(row)[e >> 1], lo, hi);
+        return (e & 1) ? hi : lo;
+    }
+}
+template <int XT>
+__global__ __launch_bounds__(256) void vg_to_q8_kernel(const uint8_t *rows, long long row0, long long n, long long stride, int dim,
+                                                       uint8_t *out, long long ostride, float2 *stat) {
     const int l16 = threadIdx.x & 15;
     const long long groups = ((long long)gridDim.x * blockDim.x) >> 4;
     const long long n_pad = ((n + 3) / 4) * 4;                            // whole wavefronts stay together (DPP reductions)
+    const int dim2 = (dim + 1) & ~1;                                      // (halves come in pairs; the pad element of an odd row is zero)
     for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < n_pad; i += groups) {
         const bool live = i < n;
         const long long r = row0 + (live ? i : n - 1);
-        const float *src = reinterpret_cast<const float *>(rows + r * stride);
+        const uint8_t *src = rows + r * stride;
         float mx = 0.0f;
         uint32_t bad = 0;
-        for (int e = 4 * l16; e < dim; e += 64) {
+        for (int e = 4 * l16; e < dim2; e += 64) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (e + j < dim) { const float v = src[e + j]; mx = fmaxf(mx, fabsf(v)); bad |= !(fabsf(v) <= 3.0e38f); }
+                if (e + j < dim) { const float v = vgq_elem<XT>(src, e + j); mx = fmaxf(mx, fabsf(v)); bad |= !(fabsf(v) <= 3.0e38f); }
         }
         mx = fmaxf(mx, vg_dpp<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(mx));
         mx = fmaxf(mx, vg_dpp<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(mx));
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(256) void vg_f32_to_q8_kernel(const uint8_t *rows, 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (e + j < dim && !bad) {
-                    const float v = src[e + j];
+                    const float v = vgq_elem<XT>(src, e + j);
                     const int xi = vgf_q8(v, inv);
                     const double res = (double)v - (double)sx * (double)xi;
                     e2 += res * res;
@@ -130,12 +141,15 @@ __global__ __launch_bounds__(256) void vg_f32_to_q8_kernel(const uint8_t *rows, 
 }
 
 static long long q8_shadow_stride(const vg_corpus *c) { return (((long long)c->dim + 15) / 16) * 16; }
-// which shadow copy the f32 filter scans stream: the int8 one (a quarter of the corpus' bytes, + 26 % HBM) unless
-// VG_SCAN_FILTER_SHADOW=bf16 (half the bytes, + 50 % HBM - the copy the batched filter kernel reads)
-static bool filter_uses_q8(const vg_corpus *c) {
-    if (c->vtype != VG_TYPE_F32) return false;
+// What the filter scans stream.  Default: the int8 shadow copy - a quarter of an f32 corpus' bytes (+ 26 % HBM), half of an
+// f16 / bf16 corpus' (+ 52 %).  VG_SCAN_FILTER_SHADOW=bf16 (or "rows"): f32 corpora through the bf16 shadow copy (half the
+// bytes, + 50 % HBM - the copy the batched filter kernel reads), f16 / bf16 corpora through their own rows (no copy).
+// L1 (f16 / bf16 only) has no dot-product bound: always the rows.
+static bool filter_uses_q8(const vg_corpus *c, int metric) {
+    if (c->vtype != VG_TYPE_F32 && c->vtype != VG_TYPE_F16 && c->vtype != VG_TYPE_BF16) return false;
+    if (metric == VG_DIST_L1 || c->q8_disabled) return false;
     const char *e = getenv("VG_SCAN_FILTER_SHADOW");
-    return !(e && (e[0] == 'b' || e[0] == 'B'));
+    return !(e && (e[0] == 'b' || e[0] == 'B' || e[0] == 'r' || e[0] == 'R'));
 }
 int vg_ensure_q8_shadow(vg_corpus *c) {
     const long long qs = q8_shadow_stride(c);
@@ -152,7 +166,8 @@ int vg_ensure_q8_shadow(vg_corpus *c) {
     if (c->q8_rows < c->n_rows) {
         const long long n = c->n_rows - c->q8_rows;
         const long long blocks = std::min<long long>((n * 16 + 255) / 256, 256 * 32);
-        hipLaunchKernelGGL(vg_f32_to_q8_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_rows, (long long)c->q8_rows, n,
+        auto kern = c->vtype == VG_TYPE_F32 ? vg_to_q8_kernel<T_F32> : (c->vtype == VG_TYPE_F16 ? vg_to_q8_kernel<T_F16> : vg_to_q8_kernel<T_BF16>);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_rows, (long long)c->q8_rows, n,
                            (long long)c->stride, c->dim, c->d_rows_q8, qs, reinterpret_cast<float2 *>(c->d_q8stat));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return vg_fail(VG_ERR_HIP, "int8 shadow pass failed: %s", hipGetErrorString(e));
@@ -166,16 +181,31 @@ static int filter_mode_of(int metric) {
 // chunks per lane the filter kernels hold without spilling under the 128-VGPR cap of 16 wavefronts per CU (tools/kernel_regs.py)
 static int filter_u_cap(const vg_corpus *) { return 6; }
 // bytes per row the filter streams: the bf16 shadow copy of an f32 corpus, the rows themselves otherwise
-static long long filter_stream_stride(const vg_corpus *c) {
-    if (c->vtype != VG_TYPE_F32) return (long long)c->stride;
-    return filter_uses_q8(c) ? q8_shadow_stride(c) : vg_bf16_shadow_stride(c);
+static long long filter_stream_stride(const vg_corpus *c, int metric) {
+    if (filter_uses_q8(c, metric)) return q8_shadow_stride(c);
+    return c->vtype == VG_TYPE_F32 ? vg_bf16_shadow_stride(c) : (long long)c->stride;
 }
 
 // Returns -1 when the shape is not served (caller takes the plain scan).
 int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream) {
     if (!scan_filter_serves(c, metric)) return -1;
-    const bool f32 = (c->vtype == VG_TYPE_F32), q8 = filter_uses_q8(c);
-    const long long bs = filter_stream_stride(c);
+    const bool f32 = (c->vtype == VG_TYPE_F32);
+    // The shadow copy and the norms cost HBM next to the corpus (see filter_uses_q8).  An f32 corpus they do not fit next to
+    // keeps the plain f32 scan (which served it before the filter existed) instead of failing every query; an f16 / bf16
+    // corpus falls back to filtering over its own rows.
+    int rc = vg_ensure_row_norms(c);
+    bool q8 = filter_uses_q8(c, metric);
+    if (rc == VG_OK && q8) {
+        rc = vg_ensure_q8_shadow(c);
+        if (rc == VG_ERR_NOMEM && !f32) { (void)hipGetLastError(); c->q8_disabled = true; q8 = false; rc = VG_OK; }
+    } else if (rc == VG_OK && f32) rc = vg_ensure_bf16_shadow(c);
+    if (rc == VG_ERR_NOMEM) {
+        (void)hipGetLastError();                         // clear the sticky allocation error
+        c->filter_disabled = true;
+        return -1;
+    }
+    if (rc != VG_OK) return rc;
+    const long long bs = filter_stream_stride(c, metric);
     const int nch_b = (int)(bs / 16);
     Shape s;
     vg_choose_shape(nch_b, VG_TYPE_U8, A_DOT, &s, filter_u_cap(c));
@@ -187,16 +217,6 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     Shape xs;                                            // the plain kernel's own shape: the exact evaluation sums in its order
     vg_plain_scan_shape(c, metric, &xs);
     if (xs.long_rows) return -1;
-    // f32: the shadow copy and the norms cost +50 % of the corpus in HBM.  A corpus they do not fit next to keeps the plain
-    // f32 scan (which served it before the filter existed) instead of failing every query.
-    int rc = vg_ensure_row_norms(c);
-    if (rc == VG_OK && f32) rc = q8 ? vg_ensure_q8_shadow(c) : vg_ensure_bf16_shadow(c);
-    if (rc == VG_ERR_NOMEM) {
-        (void)hipGetLastError();                         // clear the sticky allocation error
-        c->filter_disabled = true;
-        return -1;
-    }
-    if (rc != VG_OK) return rc;
     if ((rc = vg_ensure_filter_counters(c)) != VG_OK) return rc;
     {   // Selectivity guard.  The bound cannot separate rows that are (nearly) identical to each other: on such data every row
         // is a candidate and the exact evaluations - serial per wavefront - cost more than the plain scan.  The kernels count
@@ -228,7 +248,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count));
     blocks = std::min<long long>(blocks, VG_SEL_MAX_HEADS);
     FilterScanArgs a;
-    a.shadow = f32 ? (q8 ? c->d_rows_q8 : c->d_rows_bf) : c->d_rows; a.q8stat = reinterpret_cast<const float2 *>(c->d_q8stat); a.rows = c->d_rows; a.query = dev_query; a.row_norm = c->d_xnorm; a.cand = c->d_cand;
+    a.shadow = q8 ? c->d_rows_q8 : (f32 ? c->d_rows_bf : c->d_rows); a.q8stat = reinterpret_cast<const float2 *>(c->d_q8stat); a.rows = c->d_rows; a.query = dev_query; a.row_norm = c->d_xnorm; a.cand = c->d_cand;
     a.n_rows = c->n_rows; a.stride = c->stride; a.bstride = bs; a.nch = c->nch; a.nch_b = nch_b;
     a.lpr_log2 = s.lpr_log2; a.k = k; a.root = (metric == VG_DIST_L2) ? 1 : 0; a.dim = c->dim;
     a.mode = mode;
@@ -241,7 +261,8 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     a.rel = (float)(c->dim + 64) * 2.384185791015625e-7f;
     a.xlpr_log2 = xs.lpr_log2; a.xU = xs.U;
     a.evals = c->d_filter_evals;
-    const size_t smem = std::max<size_t>((size_t)c->nch * 16, (size_t)VG_PUBLISH_LDS_BYTES);
+    // the staged query; behind it, for an int8 shadow of f16 / bf16 rows, its exact f32 copy (16 * nch_b floats)
+    const size_t smem = std::max<size_t>((size_t)c->nch * 16 + ((q8 && !f32) ? (size_t)nch_b * 64 : 0), (size_t)VG_PUBLISH_LDS_BYTES);
     if (c->append_pending && stream != c->stream) HIP_TRY(hipStreamWaitEvent(stream, c->append_ev, 0));
     // Pre-pass: a plain scan of the first 1/64 of the rows.  Its k-th best distance bounds the final k-th best from
     // above, so no wavefront has to warm its list up from +Inf (k ln(rows per wavefront / k) exact evaluations each,
@@ -252,7 +273,8 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     a.init_keys = nullptr;
     if (prepass) {
         ScanPlan pre;
-        pre.n_rows = std::max<int64_t>(65536, c->n_rows / std::max(1, env_int("VG_SCAN_FILTER_PREPASS_DIV", 64)));
+        // (1/128 of the rows: 38 us instead of 60 at 10M x 384 for ~2x the exact evaluations of the 0.6 ms pass - measured, profiles/r2y)
+        pre.n_rows = std::max<int64_t>(65536, c->n_rows / std::max(1, env_int("VG_SCAN_FILTER_PREPASS_DIV", 128)));
         pre.allow_filter = false;
         pre.record = false;
         const int rcp = vg_launch_plain_scan(c, metric, dev_query, k, dev_out_keys, stream, pre);
@@ -277,7 +299,7 @@ static const char *filter_type_tag(int t) { return t == VG_TYPE_F32 ? "f32" : (t
 // "scan_filter_<type>_<metric>[_bf16]_u<U>_lpr<L>[_nt]" when the filter serves (corpus, metric); false otherwise
 bool vg_scan_filter_name(vg_corpus *c, int metric, char *out, size_t out_len) {
     if (!scan_filter_serves(c, metric)) return false;
-    const long long bs = filter_stream_stride(c);
+    const long long bs = filter_stream_stride(c, metric);
     Shape fs, xs;
     vg_choose_shape((int)(bs / 16), VG_TYPE_U8, A_DOT, &fs, filter_u_cap(c));
     vg_plain_scan_shape(c, metric, &xs);
@@ -285,6 +307,6 @@ bool vg_scan_filter_name(vg_corpus *c, int metric, char *out, size_t out_len) {
     const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (c->n_rows * bs > (256ll << 20));
     static const char *mtag[4] = {"l2", "dot", "cos", "l1"};
     snprintf(out, out_len, "scan_filter_%s_%s%s_u%d_lpr%d%s", filter_type_tag(c->vtype), mtag[filter_mode_of(metric)],
-             c->vtype == VG_TYPE_F32 ? (filter_uses_q8(c) ? "_q8" : "_bf16") : "", fs.U, 1 << fs.lpr_log2, nt ? "_nt" : "");
+             filter_uses_q8(c, metric) ? "_q8" : (c->vtype == VG_TYPE_F32 ? "_bf16" : ""), fs.U, 1 << fs.lpr_log2, nt ? "_nt" : "");
     return true;
 }

@@ -98,6 +98,7 @@ struct vg_corpus {
     uint8_t *d_rows_q8 = nullptr;                 // f32 corpora: int8 shadow copy for the single-query filter scan (vg_filter.hip) ...
     void *d_q8stat = nullptr;                     // ... and per row (scale, residual norm) as float2
     int64_t q8_rows = 0, q8_cap = 0;
+    bool q8_disabled = false;                     // (it did not fit next to an f16 / bf16 corpus: the filter scans read the rows themselves)
     bool filter_disabled = false;                 // the shadow copy / norms did not fit HBM: single queries keep the plain f32 scan
     int scan_filter_mode = -1;                    // vg_corpus_set_scan_filter: -1 = default (env VG_SCAN_FILTER, else on), 0 = off, 1 = on
     unsigned long long *d_filter_evals = nullptr; // filter scan: exact evaluations so far (device counter, one atomic per workgroup) ...

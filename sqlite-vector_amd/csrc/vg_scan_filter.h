@@ -10,7 +10,7 @@
 // 2^-8 (1 + 2^-8) - one input's worth: rows whose elements all round the same way, e.g. a constant 1 + 2^-8 - 2^-20, could
 // lose an exact duplicate of the query.  tests/test_gpu_filter_bound.py.)
 //
-// f32 corpora, Q8 = true - a QUARTER of the bytes.  The shadow copy is int8: per row x = sx * xi + ex with integers
+// Q8 = true - an int8 shadow copy: a QUARTER of an f32 corpus' bytes, HALF of an f16 / bf16 corpus'.  The shadow copy is int8: per row x = sx * xi + ex with integers
 // xi in [-127, 127], sx = max|x| / 127 and ex the exact residual (vg_f32_to_q8_kernel stores sx and ||ex||, computed in f64
 // and rounded up, next to the row); the query is split the same way in this kernel (q = sq * qi + eq).  Then
 //     q.x = sq sx (qi.xi) + sq (qi.ex) + eq.x      |q.x - sq sx (qi.xi)| <= sq ||qi|| ||ex|| + ||eq|| ||x||   (Cauchy-Schwarz)
@@ -96,11 +96,6 @@ __device__ inline int vgf_q8(float v, float inv) {
     const float t = rintf(v * inv);
     return (int)fminf(fmaxf(t, -127.0f), 127.0f);
 }
-__device__ inline uint32_t vgf_q8_pack4(const uint4 &f, float inv) {
-    return (uint32_t)(vgf_q8(__uint_as_float(f.x), inv) & 255) | ((uint32_t)(vgf_q8(__uint_as_float(f.y), inv) & 255) << 8) |
-           ((uint32_t)(vgf_q8(__uint_as_float(f.z), inv) & 255) << 16) | ((uint32_t)(vgf_q8(__uint_as_float(f.w), inv) & 255) << 24);
-}
-
 // s += sum |q - x| over the 8 elements of one 16-byte chunk: the reference's own f32 differences (distance-avx2.c:222-279 f16;
 // bf16 subtracts in f64, :434-489 - an f32 difference of two bf16 values is off by at most 2^-24 of itself), summed in f32
 // instead of f64.  Every term is >= 0, so the f32 sum is within (D + 64) 2^-23 of the f64 one, relatively: a lower bound of
@@ -126,7 +121,6 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
     constexpr bool L1M = (MODE == VGF_L1);
     constexpr int mode = MODE;
     static_assert(!(XF32 && L1M), "the f32 L1 scan has no filter variant");
-    static_assert(!Q8 || XF32, "the int8 shadow copy belongs to f32 corpora");
     constexpr int FT = XF32 ? T_BF16 : XT;                                // element type the filter multiplies
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & (VG_WAVE - 1);
@@ -139,19 +133,28 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
     uint4 *qs = reinterpret_cast<uint4 *>(smem);
     for (int c = threadIdx.x; c < a.nch; c += VG_BLOCK) qs[c] = reinterpret_cast<const uint4 *>(a.query)[c];
     __syncthreads();
-    // int8 shadow: the query's own split q = sq * qi + eq (sq = max|q| / 127)
+    // int8 shadow: the query's own split q = sq * qi + eq (sq = max|q| / 127), from the query widened to f32 (f32 corpora: the
+    // staged query itself; f16 / bf16: an exact f32 copy staged behind it)
     float q8_sq = 0.0f, q8_sqi = 0.0f, q8_eqn = 0.0f;                     // sq | sq ||qi|| | ||eq||, the last two rounded up
     bool q8_ok = true;
-    float q8_inv = 0.0f;
+    float q8_inv = 0.0f, q8_qq = 0.0f;
+    const float *qf = reinterpret_cast<const float *>(smem);              // 16 * nch_b floats, zero padded
     if constexpr (Q8) {
+        const int nqf = 16 * a.nch_b;
+        if constexpr (!XF32) {
+            float *wq = reinterpret_cast<float *>(smem + (size_t)a.nch * 16);
+            for (int e2 = threadIdx.x; e2 < nqf / 2; e2 += VG_BLOCK) {
+                float lo = 0.0f, hi = 0.0f;
+                if (e2 < a.nch * 4) vg_unpack2<XT>(reinterpret_cast<const uint32_t *>(smem)[e2], lo, hi);
+                wq[2 * e2] = lo; wq[2 * e2 + 1] = hi;
+            }
+            __syncthreads();
+            qf = wq;
+        }
+        const int nq_have = XF32 ? a.nch * 4 : nqf;                       // floats actually staged (f32: the corpus stride may end before 16 * nch_b)
         float mx = 0.0f;
         uint32_t bad = 0;
-        for (int c = lane; c < a.nch; c += VG_WAVE) {
-            const uint4 v = qs[c];
-            const float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { mx = fmaxf(mx, fabsf(f[j])); bad |= !(fabsf(f[j]) <= 3.0e38f); }
-        }
+        for (int e = lane; e < nq_have; e += VG_WAVE) { const float f = qf[e]; mx = fmaxf(mx, fabsf(f)); bad |= !(fabsf(f) <= 3.0e38f); }
         mx = fmaxf(mx, vg_dpp<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(mx));
         mx = fmaxf(mx, vg_dpp<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(mx));
         mx = fmaxf(mx, vg_dpp<VG_DPP_ROW_HALF_MIRROR>(mx));
@@ -162,31 +165,37 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
         q8_sq = q8_ok ? mx / 127.0f : 1.0f;
         q8_inv = 1.0f / q8_sq;
         uint32_t i2 = 0;
-        float e2 = 0.0f;
-        for (int c = lane; c < a.nch; c += VG_WAVE) {
-            const uint4 v = qs[c];
-            const float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int qi = vgf_q8(f[j], q8_inv);
-                const float e = fmaf(-q8_sq, (float)qi, f[j]);           // one rounding
-                i2 += (uint32_t)(qi * qi);
-                e2 = fmaf(e, e, e2);
-            }
+        float e2s = 0.0f, q2s = 0.0f;
+        for (int e = lane; e < nq_have; e += VG_WAVE) {
+            const float f = qf[e];
+            const int qi = vgf_q8(f, q8_inv);
+            const float r = fmaf(-q8_sq, (float)qi, f);                  // one rounding
+            i2 += (uint32_t)(qi * qi);
+            e2s = fmaf(r, r, e2s);
+            q2s = fmaf(f, f, q2s);
         }
         i2 = vg_group_sum(i2, 6);
-        e2 = vg_group_sum(e2, 6);
+        e2s = vg_group_sum(e2s, 6);
+        q8_qq = vg_group_sum(q2s, 6);
         q8_sqi = q8_sq * sqrtf((float)i2) * (1.0f + 1.0e-5f);
-        q8_eqn = sqrtf(e2) * (1.0f + 1.0e-4f);                           // (f32 sum of D squares, each off by 2^-23 of itself at most)
+        q8_eqn = sqrtf(e2s) * (1.0f + 1.0e-4f);                          // (f32 sum of D squares, each off by 2^-23 of itself at most)
     }
     uint4 q[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int cb = sub + u * lpr;
-        if constexpr (Q8) {                                               // int8 chunk cb = f32 chunks 4cb .. 4cb+3
+        if constexpr (Q8) {                                               // int8 chunk cb = the query's elements 16cb .. 16cb+15
+            const int have = XF32 ? a.nch * 4 : 16 * a.nch_b;
             uint32_t w[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = (4 * cb + j < a.nch) ? vgf_q8_pack4(qs[4 * cb + j], q8_inv) : 0u;
+            for (int j = 0; j < 4; ++j) {
+                w[j] = 0u;
+#pragma unroll
+                for (int b4 = 0; b4 < 4; ++b4) {
+                    const int e = 16 * cb + 4 * j + b4;
+                    if (cb < a.nch_b && e < have) w[j] |= (uint32_t)(vgf_q8(qf[e], q8_inv) & 255) << (8 * b4);
+                }
+            }
             q[u] = make_uint4(w[0], w[1], w[2], w[3]);
         } else if constexpr (XF32) {                                      // bf16 chunk cb = f32 chunks 2cb, 2cb+1, rounded
             const uint4 f0 = (2 * cb < a.nch) ? qs[2 * cb] : make_uint4(0u, 0u, 0u, 0u);
@@ -207,13 +216,14 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
         for (int c = lane; c < a.nch; c += VG_WAVE) { const uint4 v = qs[c]; vgf_dot_chunk<FT>(v, v, t0, t1); }
         qq = vg_group_sum(t0 + t1, 6);
     }
+    if constexpr (Q8 && !XF32) qq = q8_qq;                                // (exact products of the widened halves, no flushed subnormals)
     const float qn = sqrtf(qq);
     const bool q_ok = (qq >= 1.0e-30f && qq <= 1.0e30f) && q8_ok;         // else: every row takes the exact path
     // f16 only: v_dot2_f32_f16 may flush subnormal halves (|v| < 2^-14) to zero.  What s~ can lose that way:
     //   rows' subnormal elements   sum |q_i| 2^-14 <= 2^-14 |q|_1                      (esub_q, the same for every row)
     //   the query's subnormals     sum 2^-14 |x_i| <= 2^-14 sqrt(D) |x|                 (esub_x * |x|, zero unless the query has any)
     float esub_q = 0.0f, esub_x = 0.0f;
-    if constexpr (FT == T_F16) {
+    if constexpr (FT == T_F16 && !Q8) {
         float l1 = 0.0f;
         uint32_t has_sub = 0;
         for (int c = lane; c < a.nch; c += VG_WAVE) {

@@ -363,33 +363,38 @@ def test_int8_shadow_keeps_the_exact_duplicate_with_coherent_residuals(pkg, orc,
     c.close()
 
 
-@pytest.mark.parametrize("chunk", range(3))
-def test_int8_shadow_fuzz_outliers_and_scales(pkg, chunk, shadow, monkeypatch):
+@pytest.mark.parametrize("vt", (dg.F32, dg.F16, dg.BF16))
+@pytest.mark.parametrize("chunk", range(2))
+def test_int8_shadow_fuzz_outliers_and_scales(pkg, chunk, vt, shadow, monkeypatch):
     """rows whose scale is set by ONE outlier (everything else quantizes to a handful of levels - large residuals), rows of very
-    different magnitudes, near-duplicates of the query, zero / Inf / NaN rows: the filter's answers are the plain scan's"""
+    different magnitudes, near-duplicates of the query, zero / Inf / NaN rows, f32 / f16 / bf16 corpora: the filter's answers are
+    the plain scan's"""
     monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
-    rng = np.random.default_rng(8800 + chunk)
-    for _ in range(5):
+    rng = np.random.default_rng(8800 + chunk + 10 * vt)
+    for _ in range(4):
         dim = int(rng.choice([rng.integers(2, 40), rng.integers(40, 400), rng.integers(400, 1100)]))
         n = int(rng.integers(600, 30000))
-        rows = rng.standard_normal((n, dim)).astype(np.float32)
-        rows *= np.exp2(rng.integers(-20, 20, (n, 1))).astype(np.float32)            # magnitudes over 12 decades
+        x = rng.standard_normal((n, dim)).astype(np.float32)
+        span = 6 if vt == dg.F16 else 20
+        x *= np.exp2(rng.integers(-span, span, (n, 1))).astype(np.float32)           # magnitudes over many decades
         out = rng.random(n) < 0.3
-        rows[out, rng.integers(0, dim)] *= np.float32(300.0)                        # one outlier sets the row's scale
-        q = rows[int(rng.integers(0, n))].copy()
+        x[out, rng.integers(0, dim)] *= np.float32(300.0)                           # one outlier sets the row's scale
+        q = x[int(rng.integers(0, n))].copy()
         dup = rng.permutation(n)[:50]
-        rows[dup] = q * (1 + rng.standard_normal((50, 1)).astype(np.float32) * np.float32(1e-3))
-        rows[int(rng.integers(0, n))] = 0.0
-        rows[int(rng.integers(0, n)), 0] = np.float32(np.inf)
-        rows[int(rng.integers(0, n)), dim - 1] = np.float32(np.nan)
-        c = pkg.Corpus(pkg.F32, dim)
+        x[dup] = q * (1 + rng.standard_normal((50, 1)).astype(np.float32) * np.float32(1e-3))
+        x[int(rng.integers(0, n))] = 0.0
+        x[int(rng.integers(0, n)), 0] = np.float32(np.inf)
+        x[int(rng.integers(0, n)), dim - 1] = np.float32(np.nan)
+        rows = dg.to_storage(vt, x)
+        qs = dg.to_storage(vt, q[None, :])[0]
+        c = pkg.Corpus(vt, dim)
         c.append(rows)
         for metric in (dg.L2, dg.DOT, dg.COSINE):
             for k in (1, 20, 64):
                 c.set_scan_filter(1)
-                ids1, d1 = c.scan_topk(metric, q, k)
+                ids1, d1 = c.scan_topk(metric, qs, k)
                 c.set_scan_filter(0)
-                ids0, d0 = c.scan_topk(metric, q, k)
-                assert ids1.tolist() == ids0.tolist(), (dim, n, metric, k)
-                assert dg.same_float_bits(d1, d0), (dim, n, metric, k)
+                ids0, d0 = c.scan_topk(metric, qs, k)
+                assert ids1.tolist() == ids0.tolist(), (vt, dim, n, metric, k)
+                assert dg.same_float_bits(d1, d0), (vt, dim, n, metric, k)
         c.close()

@@ -348,15 +348,18 @@ def test_batch_multi_query_scan_vs_single_scans(pkg, orc, vt, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("shadow", ("int8", "bf16"))
 @pytest.mark.parametrize("dim", (3, 33, 100, 384, 768, 1024, 1536))
 @pytest.mark.parametrize("vt", (dg.F32, dg.F16, dg.BF16))
-def test_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, vt, dim, monkeypatch):
-    """L2 / squared-L2 / dot / cosine (f16 / bf16: also L1) top-k scans of f32, f16 and bf16 corpora go through a lower-bound filter (f32: the bf16
-    shadow copy, half the bytes; f16 / bf16: f32 sums instead of the reference's f64 chain) and re-evaluate the candidates
+def test_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, vt, dim, shadow, monkeypatch):
+    """L2 / squared-L2 / dot / cosine (f16 / bf16: also L1) top-k scans of f32, f16 and bf16 corpora go through a lower-bound filter
+    (shadow = int8: an int8 shadow copy with a residual-norm bound, a quarter / half of the bytes; shadow = bf16: f32 corpora through the bf16
+    shadow copy, half the bytes; f16 / bf16: their own rows with f32 sums instead of the reference's f64 chain) and re-evaluate the candidates
     with the plain kernel's accumulator in its summation order (vg_scan_filter.h): rowids and distance BITS must equal the
     plain scan's (filter off), for ordinary rows, edge rows (NaN / Inf / huge / tiny / zero / subnormal) and edge queries."""
     monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")         # (by default only corpora >= 3 GB / 1 GB take the filter scan)
     monkeypatch.setenv("VG_SCAN_FILTER_NO_GUARD", "1")       # (edge queries make every row a candidate: keep the filter kernel under test)
+    monkeypatch.setenv("VG_SCAN_FILTER_SHADOW", shadow)
     n = 60_007
     rows = dg.corpus(vt, n, dim, 9700 + dim)
     _, edge = dg.edge_rows(vt, dim, 9800 + dim)
@@ -372,6 +375,7 @@ def test_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, vt, dim, monke
     for metric in (dg.L2, dg.SQUARED_L2, dg.DOT, dg.COSINE) + ((dg.L1,) if vt != dg.F32 else ()):   # (f32 L1: plain scan only)
         c.set_scan_filter(1)
         assert c.kernel_name(metric).startswith("scan_filter_" + tag), c.kernel_name(metric)
+        assert ("_q8_" in c.kernel_name(metric)) == (shadow == "int8" and metric != dg.L1), c.kernel_name(metric)
         for qi, q in enumerate(queries):
             for k in (1, 20, 64):
                 c.set_scan_filter(1)
@@ -390,12 +394,14 @@ def test_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, vt, dim, monke
     c.close()
 
 
+@pytest.mark.parametrize("shadow", ("int8", "bf16"))
 @pytest.mark.parametrize("vt,dim", ((dg.F16, 64), (dg.BF16, 40), (dg.F32, 48)))
-def test_filter_scan_with_its_prepass_on_clustered_rows(pkg, orc, vt, dim, monkeypatch):
+def test_filter_scan_with_its_prepass_on_clustered_rows(pkg, orc, vt, dim, shadow, monkeypatch):
     """n >= 2^20: the filter scan starts from its plain pre-pass' threshold; clustered unit-norm rows + near-duplicates of
     the query; every metric the filter serves; compared with the plain scan and the oracle"""
     monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
     monkeypatch.setenv("VG_SCAN_FILTER_NO_GUARD", "1")
+    monkeypatch.setenv("VG_SCAN_FILTER_SHADOW", shadow)
     n = (1 << 20) + 777
     rng = np.random.default_rng(8800 + dim)
     centres = rng.standard_normal((9, dim)).astype(np.float32)

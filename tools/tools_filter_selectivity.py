@@ -59,7 +59,7 @@ def main():
                     keep = t[:64].clone()
                 del t, x
             qs = keep.view(torch.uint8).cpu().numpy().view({4: np.float32, 2: np.uint16}[es]).reshape(64, dim)
-            line = "%-52s %-4s %dx%d%s:" % (data, tname, n, dim, (" [shadow " + shadow + "]") if vt == pkg.F32 else "")
+            line = "%-52s %-4s %dx%d%s:" % (data, tname, n, dim, " [shadow " + shadow + "]")
             for m in (1, 3, 4) + ((5,) if vt != pkg.F32 else ()):
                 res = {}
                 for mode in (1, 0):
