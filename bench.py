@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=1024, help="queries per batch (workload c5)")
     ap.add_argument("--no-also", action="store_true", help="default workload: skip the filter_scan / c3 / c5 sub-results")
+    ap.add_argument("--also", default="filter,c3,c5", help="default workload: which sub-results to append (filter,c3,c5)")
     return ap.parse_args()
 
 
@@ -513,7 +514,8 @@ def main():
         except Exception as e:                                        # the checker is optional on a bare box
             out["cpu_baseline"] = {"value": None, "unit": "vectors/s", "cores": 0, "kind": "port", "sample": "unavailable: %r" % (e,)}
 
-    if n_gpus == 1 and args.workload == "c2" and not args.no_also:
+    also_set = set() if args.no_also else set(x for x in args.also.split(",") if x)
+    if n_gpus == 1 and args.workload == "c2" and "filter" in also_set:
         # ---- the same queries through the filter scan (the product's default path for this corpus)
         try:
             corpus.set_scan_filter(1)
@@ -547,67 +549,72 @@ def main():
             }
         except Exception as e:
             out["filter_scan"] = {"error": repr(e)}
+    if n_gpus == 1 and args.workload == "c2" and (also_set & {"c3", "c5"}):
         # ---- configs[2] over its own corpus, then configs[4] over the f32 corpus (the MFMA-bound batch last: the HBM-bound
         # lines are not timed on a package it has just heated)
         also = {}
-        try:
-            v3, t3, d3, m3, desc3 = WORKLOADS["c3"]
-            c3 = make_shard(pkg, torch, v3, d3, n_rows, 42, local_rank)
-            q3 = np.random.default_rng(43).integers(0, 256, (nq, d3), dtype=np.uint8)
-            r3 = SingleQueryRunner(pkg, torch, None, shard, c3, v3, d3, m3, k, n_rows, 1, q3)
-            line, _ = single_query_line(args, pkg, r3, c3, "c3", v3, d3, m3, k, n_rows, 1, desc3)
-            if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(v3, t3, d3, m3, k, args.cpu_sample_rows, seconds=5.0, all_cores=False)
-            # what tie_order=reference costs (the reference's rowids among equal distances, vg_reforder.hip): the same host
-            # entry point (vg_scan_topk: host query in, host rowids out) in both orders, 10 queries each
-            tie = {}
-            for name, mode in (("position", pkg.TIE_POSITION), ("reference", pkg.TIE_REFERENCE)):
-                c3.set_tie_order(mode)
-                c3.scan_topk(m3, q3[0], k)
-                t0 = time.perf_counter()
-                for i in range(10):
-                    c3.scan_topk(m3, q3[(1 + i) % nq], k)
-                tie["ms_per_query_%s" % name] = (time.perf_counter() - t0) / 10 * 1e3
-            c3.set_tie_order(pkg.TIE_POSITION)
-            tie["what"] = "vg_scan_topk end to end, top-%d; reference = store-mode scan + device compaction of the rows below the bound + host slot replay" % k
-            line["tie_order"] = tie
-            also["c3"] = line
-            c3.close()
-        except Exception as e:
-            also["c3"] = {"error": repr(e)}
-        try:
-            corpus.set_scan_filter(0)
-            v5, t5, d5, m5, desc5 = WORKLOADS["c5"]
-            line = run_batched(args, pkg, torch, corpus, "c5", n_rows, d5, m5, k, desc5)
-            if not args.no_cpu_baseline:
-                line["cpu_baseline"] = batch_cpu_baseline(args, v5, t5, d5, m5, k, seconds=5.0)
-            also["c5"] = line
-            # the same batches through the bf16 filter (VG_F32_FILTER=1, the shadow copy the filter scan above has made): the
-            # GEMM at the bf16 rate over HALF the bytes, every survivor re-evaluated with the f32 single-scan arithmetic.
-            # Priced on the bf16 MFMA peak and reported next to the f32 MFMA line, never as its roofline.
+        if "c3" in also_set:
             try:
-                plain_res = run_batched.last_result
-                os.environ["VG_F32_FILTER"] = "1"
-                fl = run_batched(args, pkg, torch, corpus, "c5f", n_rows, d5, m5, k, WORKLOADS["c5f"][4])
-                fres = run_batched.last_result
-                same_ids = bool(np.array_equal(np.asarray(fres[0]), np.asarray(plain_res[0])))
-                d_f, d_p = np.asarray(fres[1], dtype=np.float64), np.asarray(plain_res[1], dtype=np.float64)
-                line["filter_batch"] = {
-                    "what": "the same batches through vg_batch_h_kernel over the bf16 shadow copy (matrix cores as a lower-bound "
-                            "filter) + exact f32 re-evaluation of the survivors: the f32 single scans' distances",
-                    "value": fl["value"], "unit": "vectors/s", "ms_per_step": fl["ms_per_step"], "dtype_streamed": "bf16",
-                    "kernel": fl["roofline"]["kernel"], "kernel_ms": fl["roofline"]["kernel_ms"],
-                    "achieved_TFLOPs_of_the_QxNxD_product": fl["roofline"]["achieved"], "peak_bf16_TFLOPs": F16_MFMA_PEAK_TF,
-                    "frac_of_bf16_peak": fl["roofline"]["frac"], "speedup_over_f32_mfma_kernel": line["ms_per_step"] / fl["ms_per_step"],
-                    "last_batch_same_rowids_as_f32_mfma_kernel": same_ids,
-                    "last_batch_max_rel_distance_difference": float(np.max(np.abs(d_f - d_p) / np.maximum(np.abs(d_p), 1e-30))) if d_f.shape == d_p.shape else None,
-                }
+                v3, t3, d3, m3, desc3 = WORKLOADS["c3"]
+                c3 = make_shard(pkg, torch, v3, d3, n_rows, 42, local_rank)
+                q3 = np.random.default_rng(43).integers(0, 256, (nq, d3), dtype=np.uint8)
+                r3 = SingleQueryRunner(pkg, torch, None, shard, c3, v3, d3, m3, k, n_rows, 1, q3)
+                line, _ = single_query_line(args, pkg, r3, c3, "c3", v3, d3, m3, k, n_rows, 1, desc3)
+                if not args.no_cpu_baseline:
+                    line["cpu_baseline"] = cpu_baseline(v3, t3, d3, m3, k, args.cpu_sample_rows, seconds=5.0, all_cores=False)
+                # what tie_order=reference costs (the reference's rowids among equal distances, vg_reforder.hip): the same host
+                # entry point (vg_scan_topk: host query in, host rowids out) in both orders, 10 queries each
+                tie = {}
+                for name, mode in (("position", pkg.TIE_POSITION), ("reference", pkg.TIE_REFERENCE)):
+                    c3.set_tie_order(mode)
+                    c3.scan_topk(m3, q3[0], k)
+                    t0 = time.perf_counter()
+                    for i in range(10):
+                        c3.scan_topk(m3, q3[(1 + i) % nq], k)
+                    tie["ms_per_query_%s" % name] = (time.perf_counter() - t0) / 10 * 1e3
+                c3.set_tie_order(pkg.TIE_POSITION)
+                tie["what"] = "vg_scan_topk end to end, top-%d; reference = store-mode scan + device compaction of the rows below the bound + host slot replay" % k
+                line["tie_order"] = tie
+                also["c3"] = line
+                c3.close()
             except Exception as e:
-                line["filter_batch"] = {"error": repr(e)}
-            finally:
-                os.environ.pop("VG_F32_FILTER", None)
-        except Exception as e:
-            also["c5"] = {"error": repr(e)}
+                also["c3"] = {"error": repr(e)}
+        if "c5" in also_set:
+            try:
+                corpus.set_scan_filter(0)
+                v5, t5, d5, m5, desc5 = WORKLOADS["c5"]
+                line = run_batched(args, pkg, torch, corpus, "c5", n_rows, d5, m5, k, desc5)
+                if not args.no_cpu_baseline:
+                    line["cpu_baseline"] = batch_cpu_baseline(args, v5, t5, d5, m5, k, seconds=5.0)
+                also["c5"] = line
+                # the same batches through the bf16 filter (VG_F32_FILTER=1, the shadow copy the filter scan above has made): the
+                # GEMM at the bf16 rate over HALF the bytes, every survivor re-evaluated with the f32 single-scan arithmetic.
+                # Priced on the bf16 MFMA peak and reported next to the f32 MFMA line, never as its roofline.
+                try:
+                    plain_res = run_batched.last_result
+                    os.environ["VG_F32_FILTER"] = "1"
+                    fl = run_batched(args, pkg, torch, corpus, "c5f", n_rows, d5, m5, k, WORKLOADS["c5f"][4])
+                    fres = run_batched.last_result
+                    same_ids = bool(np.array_equal(np.asarray(fres[0]), np.asarray(plain_res[0])))
+                    d_f, d_p = np.asarray(fres[1], dtype=np.float64), np.asarray(plain_res[1], dtype=np.float64)
+                    line["filter_batch"] = {
+                        "what": "the same batches through vg_batch_h_kernel over the bf16 shadow copy (matrix cores as a lower-bound "
+                                "filter) + exact f32 re-evaluation of the survivors: the f32 single scans' distances",
+                        "value": fl["value"], "unit": "vectors/s", "ms_per_step": fl["ms_per_step"], "dtype_streamed": "bf16",
+                        "kernel": fl["roofline"]["kernel"], "kernel_ms": fl["roofline"]["kernel_ms"],
+                        "achieved_TFLOPs_of_the_QxNxD_product": fl["roofline"]["achieved"], "peak_bf16_TFLOPs": F16_MFMA_PEAK_TF,
+                        "frac_of_bf16_peak": fl["roofline"]["frac"], "speedup_over_f32_mfma_kernel": line["ms_per_step"] / fl["ms_per_step"],
+                        "last_batch_same_rowids_as_f32_mfma_kernel": same_ids,
+                        "last_batch_rowid_slots_that_differ": "%d of %d (near-ties: the two kernels' distances differ by summation order)" % (
+                            int(np.sum(np.asarray(fres[0]) != np.asarray(plain_res[0]))), int(np.asarray(fres[0]).size)),
+                        "last_batch_max_rel_distance_difference": float(np.max(np.abs(d_f - d_p) / np.maximum(np.abs(d_p), 1e-30))) if d_f.shape == d_p.shape else None,
+                    }
+                except Exception as e:
+                    line["filter_batch"] = {"error": repr(e)}
+                finally:
+                    os.environ.pop("VG_F32_FILTER", None)
+            except Exception as e:
+                also["c5"] = {"error": repr(e)}
         out["also"] = also
     if rank == 0:
         print(json.dumps(out))

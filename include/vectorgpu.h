@@ -78,6 +78,15 @@ int vg_corpus_append(vg_corpus *c, const void *host_rows, int64_t n_rows, int64_
 /* the reference's persisted/preloaded quantized format: n records of [int64 LE rowid][dim bytes], stride 8+dim
  * (sqlite-vector.c:1296-1309, 2127-2147).  Corpus type must be U8 or I8.  De-interleaved on the GPU. */
 int vg_corpus_append_records(vg_corpus *c, const void *host_records, int64_t n_records);
+/* Row maintenance - what keeps a resident corpus equal to the table after UPDATE / DELETE without re-reading the table (the
+ * reference re-reads it for every scan, sqlite-vector.c:2077-2107).  vg_corpus_find_rowid: scan position of a rowid (-1: not
+ * held; -2: the rowids were not appended in ascending order, no lookup).  vg_corpus_patch_rows: overwrite the rows at
+ * `positions` with host_rows[i].  vg_corpus_delete_rows: take the rows at `positions` (strictly ascending) out and close the
+ * gaps on the device - scan order, hence every tie-break, stays that of a fresh staging.  Per-row derived data (norms, shadow
+ * copies) is re-made from the first touched row on by the next scan that needs it. */
+int64_t vg_corpus_find_rowid(const vg_corpus *c, int64_t rowid);
+int     vg_corpus_patch_rows(vg_corpus *c, const int64_t *positions, int64_t n, const void *host_rows, int64_t row_stride_bytes);
+int     vg_corpus_delete_rows(vg_corpus *c, const int64_t *positions, int64_t n);
 /* rows already in device memory (same device), e.g. produced by another kernel / a torch tensor */
 int vg_corpus_append_device(vg_corpus *c, const void *dev_rows, int64_t n_rows, int64_t row_stride_bytes,
                             const int64_t *host_rowids);
@@ -87,9 +96,11 @@ int vg_corpus_append_device(vg_corpus *c, const void *dev_rows, int64_t n_rows, 
  * out_rowids[k], out_dist[k] (float values widened to double, like vFullScanCursor.distance), *out_count <= k.
  * Large f32 / f16 / bf16 corpora, k <= 64 (L2 / SQUARED_L2 / DOT / COSINE; f16 / bf16 also L1): the scan goes through a
  * provable LOWER BOUND of every row's distance and evaluates only the candidates exactly, with the plain kernel's own
- * arithmetic - the same rowids and distance bits as the plain scan.  f32 corpora (>= 3 GB) stream a bf16 shadow copy for it
- * (built on the first such scan after rows were appended; + 50 % device memory; half the bytes per query), f16 / bf16 corpora
- * (>= 1 GB) their own rows (the bound replaces the reference's f64 chain for non-candidates).  vg_corpus_set_scan_filter(c, 0)
+ * arithmetic - the same rowids and distance bits as the plain scan.  From 2^20 rows and 512 MB it streams an int8 shadow copy
+ * (per row: int8 elements + scale + residual norm; built on the first such scan after rows were appended or patched; + 26 %
+ * device memory for f32, + 52 % for f16 / bf16; a quarter resp. half of the bytes per query); L1 (f16 / bf16) streams the rows
+ * themselves (the bound replaces the reference's f64 chain for non-candidates).  VG_SCAN_FILTER_SHADOW=bf16: f32 corpora
+ * (>= 3 GB) through a bf16 shadow copy (+ 50 %), f16 / bf16 (>= 1 GB) through their own rows.  vg_corpus_set_scan_filter(c, 0)
  * / VG_SCAN_FILTER=0 turn it off; a corpus whose shadow copy does not fit device memory, or whose rows the bound cannot tell
  * apart (it evaluates more than 1/32 of them), keeps the plain scan by itself. */
 int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k,
@@ -183,6 +194,9 @@ int     vg_shards_append(vg_shards *s, const void *host_rows, int64_t n_rows, in
 int     vg_shards_append_records(vg_shards *s, const void *host_records, int64_t n_records);
 int64_t vg_shards_rowid_at(const vg_shards *s, int64_t position);
 int     vg_shards_rowids(const vg_shards *s, int64_t pos0, int64_t n, int64_t *out);   /* rowids of positions [pos0, pos0 + n) */
+int64_t vg_shards_find_rowid(const vg_shards *s, int64_t rowid);                       /* single-shard handles only (else -2 / VG_ERR_UNSUPPORTED): */
+int     vg_shards_patch_rows(vg_shards *s, const int64_t *positions, int64_t n, const void *host_rows, int64_t row_stride_bytes);
+int     vg_shards_delete_rows(vg_shards *s, const int64_t *positions, int64_t n);
 int     vg_shards_set_scan_filter(vg_shards *s, int mode);                             /* vg_corpus_set_scan_filter on every shard */
 int     vg_shards_scan_topk(vg_shards *s, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist, int *out_count);
 int     vg_shards_scan_topk_batch(vg_shards *s, int metric, const void *queries, int nq, int k,

@@ -102,6 +102,12 @@ def lib():
         "vg_profile_mean_ms": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "vg_scan_kernel_name": (C.c_char_p, [vp, i32]),
         "vg_profile_mean_ms_ex": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+        "vg_corpus_find_rowid": (i64, [vp, i64]),
+        "vg_corpus_patch_rows": (i32, [vp, vp, i64, vp, i64]),
+        "vg_corpus_delete_rows": (i32, [vp, vp, i64]),
+        "vg_shards_find_rowid": (i64, [vp, i64]),
+        "vg_shards_patch_rows": (i32, [vp, vp, i64, vp, i64]),
+        "vg_shards_delete_rows": (i32, [vp, vp, i64]),
         "vg_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
         "vg_batch_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
         "vg_corpus_set_scan_filter": (i32, [vp, i32]),
@@ -259,6 +265,18 @@ class Corpus:
         v = C.c_ulonglong(0)
         _check(lib().vg_filter_exact_evals(self.h, C.byref(v)))
         return v.value
+
+    def find_rowid(self, rowid):
+        return int(lib().vg_corpus_find_rowid(self.h, rowid))
+
+    def patch_rows(self, positions, rows):
+        positions = np.ascontiguousarray(positions, dtype=np.int64)
+        rows = np.ascontiguousarray(rows)
+        _check(lib().vg_corpus_patch_rows(self.h, _ptr(positions), positions.shape[0], _ptr(rows), rows.strides[0]))
+
+    def delete_rows(self, positions):
+        positions = np.ascontiguousarray(positions, dtype=np.int64)
+        _check(lib().vg_corpus_delete_rows(self.h, _ptr(positions), positions.shape[0]))
 
     def batch_filter_exact_evals(self):
         v = C.c_ulonglong(0)

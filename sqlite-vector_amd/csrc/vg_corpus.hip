@@ -147,6 +147,7 @@ extern "C" int vg_corpus_clear(vg_corpus *c) {
     c->bf_rows = 0;
     c->q8_rows = 0;
     c->rowids.clear();
+    c->rowids_ascending = true;
     return VG_OK;
 }
 
@@ -190,6 +191,13 @@ extern "C" int vg_corpus_reserve(vg_corpus *c, int64_t capacity_rows) {
 }
 
 static void note_rowids(vg_corpus *c, const int64_t *rowids, int64_t n) {
+    if (rowids && c->rowids_ascending) {                       // (vg_corpus_find_rowid searches by bisection)
+        int64_t prev = c->rowids.empty() ? (c->n_rows > 0 ? c->rowid_base + c->n_rows - 1 : INT64_MIN) : c->rowids.back();
+        for (int64_t i = 0; i < n; ++i) {
+            if (rowids[i] <= prev && !(i == 0 && prev == INT64_MIN)) { c->rowids_ascending = false; break; }
+            prev = rowids[i];
+        }
+    }
     if (rowids) {
         if (c->rowids.empty() && c->n_rows > 0) {
             c->rowids.resize((size_t)c->n_rows);
@@ -329,6 +337,139 @@ extern "C" int vg_corpus_append_device(vg_corpus *c, const void *dev_rows, int64
     g_rows_appended += n_rows;
     note_rowids(c, host_rowids, n_rows);
     c->n_rows += n_rows;
+    return VG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ row maintenance
+// The reference re-reads the table for every scan (sqlite-vector.c:2077-2107), so an UPDATE or DELETE is visible to the next
+// query for free.  A corpus resident in HBM needs the equivalent: overwrite single rows in place, take rows out and close the
+// gaps - without a pass over the table.  Everything derived per row (norms, shadow copies, tile-major copies, row sums) is
+// re-made from the first touched row on, by the passes that extend it after an append.
+
+static void invalidate_derived_from(vg_corpus *c, int64_t pos) {
+    c->xnorm_rows = std::min(c->xnorm_rows, pos);
+    c->i8_rows = std::min(c->i8_rows, pos);
+    c->tm_rows = std::min(c->tm_rows, pos);
+    c->bf_rows = std::min(c->bf_rows, pos);
+    c->q8_rows = std::min(c->q8_rows, pos);
+    c->dist_valid_rows = 0;
+}
+
+// position of `rowid`, -1 if the corpus does not hold it, -2 if its rowids are not ascending (no lookup: the caller re-stages)
+extern "C" int64_t vg_corpus_find_rowid(const vg_corpus *c, int64_t rowid) {
+    if (!c) return -1;
+    if (c->rowids.empty()) {
+        const int64_t p = rowid - c->rowid_base;
+        return (p >= 0 && p < c->n_rows) ? p : -1;
+    }
+    if (!c->rowids_ascending) return -2;
+    auto it = std::lower_bound(c->rowids.begin(), c->rowids.end(), rowid);
+    return (it != c->rowids.end() && *it == rowid) ? (int64_t)(it - c->rowids.begin()) : -1;
+}
+
+// rows at `positions` (any order) are overwritten with host_rows[i]
+extern "C" int vg_corpus_patch_rows(vg_corpus *c, const int64_t *positions, int64_t n, const void *host_rows, int64_t row_stride_bytes) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    if (n == 0) return VG_OK;
+    const int64_t row_bytes = (int64_t)c->dim * c->es;
+    if (!positions || !host_rows || n < 0 || row_stride_bytes < row_bytes) return vg_fail(VG_ERR_INVALID, "vg_corpus_patch_rows: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (row_stride_bytes > VG_PIN_BYTES) return vg_fail(VG_ERR_UNSUPPORTED, "row stride %lld exceeds the staging buffer", (long long)row_stride_bytes);
+    int64_t first = c->n_rows;
+    for (int64_t i = 0; i < n; ++i) {
+        if (positions[i] < 0 || positions[i] >= c->n_rows) return vg_fail(VG_ERR_INVALID, "vg_corpus_patch_rows: position %lld out of range", (long long)positions[i]);
+        first = std::min(first, positions[i]);
+    }
+    const int64_t piece_rows = std::max<int64_t>(1, VG_PIN_BYTES / row_stride_bytes);
+    for (int64_t r0 = 0; r0 < n; r0 += piece_rows) {
+        const int64_t nr = std::min(piece_rows, n - r0);
+        const size_t bytes = (size_t)((nr - 1) * row_stride_bytes + row_bytes);
+        uint8_t *pin;
+        int slot;
+        int rc = pin_acquire(c, &pin, &slot);
+        if (rc != VG_OK) return rc;
+        memcpy(pin, (const uint8_t *)host_rows + r0 * row_stride_bytes, bytes);
+        HIP_TRY(hipMemcpyAsync(c->d_stage, pin, bytes, hipMemcpyHostToDevice, c->stream));
+        for (int64_t i = 0; i < nr; ++i)                    // one padded row each (the pad bytes must stay zero)
+            hipLaunchKernelGGL(vg_repack_kernel, dim3((unsigned)((c->nch + 255) / 256)), dim3(256), 0, c->stream,
+                               (const uint8_t *)c->d_stage + i * row_stride_bytes, (long long)row_stride_bytes, 0, (int)row_bytes,
+                               c->d_rows + positions[r0 + i] * c->stride, (long long)c->stride, c->nch, 1ll);
+        HIP_TRY(hipEventRecord(c->pin_ev[slot], c->stream));
+        c->pin_busy[slot] = true;
+    }
+    HIP_TRY(hipEventRecord(c->append_ev, c->stream));
+    c->append_pending = true;
+    HIP_TRY(hipGetLastError());
+    invalidate_derived_from(c, first);
+    return VG_OK;
+}
+
+// rows at `positions` (strictly ascending) leave the corpus; the rows behind them move up, scan order is kept
+extern "C" int vg_corpus_delete_rows(vg_corpus *c, const int64_t *positions, int64_t n) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    if (n == 0) return VG_OK;
+    if (!positions || n < 0 || n > c->n_rows) return vg_fail(VG_ERR_INVALID, "vg_corpus_delete_rows: bad argument");
+    for (int64_t i = 0; i < n; ++i)
+        if (positions[i] < 0 || positions[i] >= c->n_rows || (i > 0 && positions[i] <= positions[i - 1]))
+            return vg_fail(VG_ERR_INVALID, "vg_corpus_delete_rows: positions must be ascending and inside the corpus");
+    HIP_TRY(hipSetDevice(c->device));
+    // segment j (rows between deletion j-1 and deletion j) moves down by j rows.  Source and destination overlap when a segment is
+    // longer than its shift: such a move goes through a bounce buffer chunk by chunk (ascending, so a chunk's destination has
+    // been consumed already); a shift of at least the chunk size copies directly in shift-sized pieces.
+    const int64_t tail_rows = c->n_rows - positions[0];
+    size_t tmp_bytes = (size_t)std::min<int64_t>(tail_rows * c->stride, 256ll << 20);
+    uint8_t *tmp = nullptr;
+    if (hipMalloc(&tmp, tmp_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        tmp = nullptr;
+        uint8_t *pin; int slot;                                  // (allocates the 16 MiB device staging area on first use)
+        int rc = pin_acquire(c, &pin, &slot);
+        if (rc != VG_OK) return rc;
+        tmp_bytes = (size_t)VG_PIN_BYTES;
+    }
+    uint8_t *bounce = tmp ? tmp : c->d_stage;
+    const int64_t bounce_rows = std::max<int64_t>(1, (int64_t)(tmp_bytes / (size_t)c->stride));
+    hipError_t e = hipSuccess;
+    for (int64_t j = 1; j <= n && e == hipSuccess; ++j) {
+        const int64_t from = positions[j - 1] + 1, to = (j < n) ? positions[j] : c->n_rows, shift = j;
+        int64_t r = from;
+        while (r < to && e == hipSuccess) {
+            if (shift >= bounce_rows || to - r <= shift) {       // no overlap inside one piece of at most `shift` rows
+                const int64_t m = std::min(shift, to - r);
+                e = hipMemcpyAsync(c->d_rows + (r - shift) * c->stride, c->d_rows + r * c->stride, (size_t)(m * c->stride), hipMemcpyDeviceToDevice, c->stream);
+                r += m;
+            } else {
+                const int64_t m = std::min(bounce_rows, to - r);
+                e = hipMemcpyAsync(bounce, c->d_rows + r * c->stride, (size_t)(m * c->stride), hipMemcpyDeviceToDevice, c->stream);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(c->d_rows + (r - shift) * c->stride, bounce, (size_t)(m * c->stride), hipMemcpyDeviceToDevice, c->stream);
+                r += m;
+            }
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (tmp) hipFree(tmp);
+    if (e != hipSuccess) return vg_fail(VG_ERR_HIP, "row compaction failed: %s", hipGetErrorString(e));
+    if (!c->rowids.empty()) {
+        size_t w = (size_t)positions[0];
+        int64_t next = 0;
+        for (size_t r = (size_t)positions[0]; r < (size_t)c->n_rows; ++r) {
+            if (next < n && (int64_t)r == positions[next]) { ++next; continue; }
+            c->rowids[w++] = c->rowids[r];
+        }
+        c->rowids.resize(w);
+    } else {                                                     // implicit rowids stop being base + position
+        std::vector<int64_t> ids;
+        ids.reserve((size_t)(c->n_rows - n));
+        int64_t next = 0;
+        for (int64_t r = 0; r < c->n_rows; ++r) {
+            if (next < n && r == positions[next]) { ++next; continue; }
+            ids.push_back(c->rowid_base + r);
+        }
+        c->rowids.swap(ids);
+    }
+    c->n_rows -= n;
+    invalidate_derived_from(c, positions[0]);
     return VG_OK;
 }
 

@@ -36,6 +36,8 @@ int vg_ensure_filter_counters(vg_corpus *c) {
 // Small corpora keep the plain scan: the filter scan pays a pre-pass launch plus the exact evaluations of the lists'
 // warm-up (measured at f32 D = 384: 3M rows 0.41 vs 0.70 ms, 1M rows - no pre-pass - 0.43 vs 0.26 ms, 10k rows 52 vs 34 us);
 // f32 corpora additionally pay the shadow copy (+50 % HBM): from 3 GB up; f16 / bf16 corpora (no copy): from 1 GB up.
+// (Those figures are for VG_SCAN_FILTER_SHADOW=bf16 / rows; the default int8 shadow copy has its own rule below.)
+static bool filter_uses_q8(const vg_corpus *c, int metric);
 static bool scan_filter_serves(const vg_corpus *c, int metric) {
     const bool half = (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16);
     if (c->vtype != VG_TYPE_F32 && !half) return false;
@@ -43,6 +45,11 @@ static bool scan_filter_serves(const vg_corpus *c, int metric) {
     if (metric != VG_DIST_L2 && metric != VG_DIST_SQUARED_L2 && metric != VG_DIST_DOT && metric != VG_DIST_COSINE && metric != VG_DIST_L1) return false;
     if (half && metric == VG_DIST_COSINE && !env_int("VG_HALF_COSN", 1)) return false;
     if (!scan_filter_enabled(c)) return false;
+    // int8 shadow copy (measured, profiles/r3a_int8_filter_size_threshold.txt, D = 384): from 2^20 rows - where the pre-pass
+    // starts - the filter wins at every size tried (1.2M rows: 0.09 + 0.035 ms against 0.27 f32 / 0.17 f16); below, without a
+    // pre-pass, it only ties.  In bytes: a quarter / half of the stream has to buy back ~45 us of pre-pass and second launch.
+    if (filter_uses_q8(c, metric) && env_int("VG_SCAN_FILTER_MIN_MB", -1) < 0)
+        return c->n_rows >= (1 << 20) && c->n_rows * c->stride >= (512ll << 20);
     return c->n_rows * c->stride >= (long long)env_int("VG_SCAN_FILTER_MIN_MB", half ? 1024 : 3072) * (1ll << 20);
 }
 

@@ -55,6 +55,7 @@ struct vg_corpus {
     int64_t cap_rows = 0;
     uint8_t *d_rows = nullptr;
     std::vector<int64_t> rowids;   // empty => implicit rowid_base + position
+    bool rowids_ascending = true;  // every appended rowid was larger than the one before it (a rowid table in key order)
     int64_t rowid_base = 1;
 
     hipStream_t stream = nullptr;

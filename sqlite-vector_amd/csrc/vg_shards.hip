@@ -199,6 +199,26 @@ extern "C" int vg_shards_rowids(const vg_shards *s, int64_t pos0, int64_t n, int
     return VG_OK;
 }
 
+// Row maintenance (vg_corpus_patch_rows / _delete_rows / _find_rowid).  A deletion shifts every later row by one position, i.e.
+// across the block-cyclic deal of several shards: only single-shard handles are served, the caller re-stages otherwise.
+extern "C" int64_t vg_shards_find_rowid(const vg_shards *s, int64_t rowid) {
+    if (!s) return -1;
+    if (s->S != 1) return -2;
+    return vg_corpus_find_rowid(s->sh[0], rowid);
+}
+extern "C" int vg_shards_patch_rows(vg_shards *s, const int64_t *positions, int64_t n, const void *host_rows, int64_t row_stride_bytes) {
+    if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
+    if (s->S != 1) return fail(VG_ERR_UNSUPPORTED, "row maintenance needs a single-shard corpus");
+    return vg_corpus_patch_rows(s->sh[0], positions, n, host_rows, row_stride_bytes);
+}
+extern "C" int vg_shards_delete_rows(vg_shards *s, const int64_t *positions, int64_t n) {
+    if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
+    if (s->S != 1) return fail(VG_ERR_UNSUPPORTED, "row maintenance needs a single-shard corpus");
+    int rc = vg_corpus_delete_rows(s->sh[0], positions, n);
+    if (rc == VG_OK) s->n_rows = vg_corpus_rows(s->sh[0]);
+    return rc;
+}
+
 extern "C" int vg_shards_set_scan_filter(vg_shards *s, int mode) {
     if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
     for (auto *p : s->sh) {

@@ -72,6 +72,9 @@ typedef struct {
     int (*corpus_set_tie_order)(vg_shards *, int);
     int (*corpus_set_scan_filter)(vg_shards *, int);
     int (*corpus_rowids)(const vg_shards *, int64_t, int64_t, int64_t *);
+    int64_t (*corpus_find_rowid)(const vg_shards *, int64_t);
+    int (*corpus_patch_rows)(vg_shards *, const int64_t *, int64_t, const void *, int64_t);
+    int (*corpus_delete_rows)(vg_shards *, const int64_t *, int64_t);
     char load_error[512];
 } gpu_api;
 
@@ -135,6 +138,9 @@ static int gpu_load_locked(void) {
     G.corpus_set_tie_order = (int (*)(vg_shards *, int))gpu_sym("vg_shards_set_tie_order");
     G.corpus_set_scan_filter = (int (*)(vg_shards *, int))gpu_sym("vg_shards_set_scan_filter");
     G.corpus_rowids = (int (*)(const vg_shards *, int64_t, int64_t, int64_t *))gpu_sym("vg_shards_rowids");
+    G.corpus_find_rowid = (int64_t (*)(const vg_shards *, int64_t))gpu_sym("vg_shards_find_rowid");
+    G.corpus_patch_rows = (int (*)(vg_shards *, const int64_t *, int64_t, const void *, int64_t))gpu_sym("vg_shards_patch_rows");
+    G.corpus_delete_rows = (int (*)(vg_shards *, const int64_t *, int64_t))gpu_sym("vg_shards_delete_rows");
     if (G.load_error[0]) { dlclose(G.handle); G.handle = NULL; return 0; }
     G.ready = 1;
     return 1;
@@ -192,7 +198,9 @@ typedef struct {
     char gpu_devices[64];       /* additions (ignored by the reference): where the corpus lives */
     int64_t gpu_shard_rows;
     int tie_order;              /* -1 = default, VG_TIE_POSITION, VG_TIE_REFERENCE (option tie_order=position|reference) */
-    int scan_filter;            /* -1 = default, 0 / 1 (option scan_filter=0|1): f32 scans through the bf16 shadow copy */
+    int scan_filter;            /* -1 = default, 0 / 1 (option scan_filter=0|1): f32 / f16 / bf16 scans through a shadow-copy filter */
+    int track_changes;          /* -1 = default (VECTORGPU_TRACK_CHANGES, else off), 0 / 1 (option track_changes=0|1): row-granular
+                                   freshness for UPDATE / DELETE through sqlite3_update_hook - see on_row_change() */
 } vec_options;
 
 /* Result order among EQUAL distances.  tie_order=reference replays the reference's slot algorithm: rowids and order
@@ -232,6 +240,10 @@ typedef struct {
     int full_have_pk;
     int full_in_txn;            /* staged inside an open transaction: a ROLLBACK leaves both stamps unchanged */
     int full_validated;         /* set when stage_full() (re)validated `full` during the current vector_quantize call */
+    /* change tracking (track_changes=1): rowids of this table touched since `full` was last brought up to date */
+    int64_t *touched;
+    int n_touched, cap_touched, touched_overflow;
+    int64_t hook_seen;          /* vec_context.hook_events at that moment; -1: `full` was staged without the hook in place */
     vg_shards *quant;           /* quantized vectors for vector_quantize_scan[_stream] */
     int quant_preloaded;        /* explicit vector_quantize_preload() (kept until cleanup / re-quantize) */
     int64_t quant_data_version;
@@ -243,6 +255,8 @@ typedef struct {
 typedef struct {
     table_ctx tables[MAX_TABLES];
     int count;
+    int hook_installed;         /* sqlite3_update_hook(db, on_row_change, this) was called for this connection */
+    int64_t hook_events;        /* row changes it has reported so far (every table, every attached database) */
 } vec_context;
 
 static int elem_size(int t) {
@@ -335,6 +349,7 @@ static void context_free(void *p) {
         sqlite3_free(c->tables[i].t_name);
         sqlite3_free(c->tables[i].c_name);
         sqlite3_free(c->tables[i].pk_name);
+        sqlite3_free(c->tables[i].touched);
     }
     sqlite3_free(c);
 }
@@ -346,6 +361,60 @@ static table_ctx *context_lookup(vec_context *c, const char *tbl, const char *co
         if (t->t_name && t->c_name && !strcasecmp(t->t_name, tbl) && !strcasecmp(t->c_name, col)) return t;
     }
     return NULL;
+}
+
+/* ------------------------------------------------------------------------------------------------ change tracking
+ * The reference reads the table for every scan, so an UPDATE or DELETE costs it nothing extra.  A corpus resident in HBM has
+ * to learn WHICH rows changed; SQLite tells exactly that to sqlite3_update_hook().  With track_changes=1 (vector_init option,
+ * or VECTORGPU_TRACK_CHANGES=1) the extension installs the hook on the connection and logs the rowids it reports for a staged
+ * table; the next scan re-reads only those rows and patches / removes / appends them on the device (stage_full).
+ * Opt-in, because a connection has ONE update hook: installing ours replaces the application's (and theirs would replace
+ * ours - which the event count below notices: the scan then falls back to the stamp logic).  The log only says where to look:
+ * what a touched row IS now is read from the table, so rolled-back statements and re-inserted keys need no special case. */
+#define TRACK_MAX_TOUCHED 65536
+#define TRACK_MAX_DELETES 4096
+
+static void on_row_change(void *p, int op, const char *dbname, const char *tbl, sqlite3_int64 rowid) {
+    vec_context *vc = (vec_context *)p;
+    (void)op;
+    vc->hook_events++;                                          /* every report counts: compared with sqlite3_total_changes() */
+    if (!tbl || !dbname || strcasecmp(dbname, "main")) return;
+    for (int i = 0; i < vc->count; ++i) {
+        table_ctx *t = &vc->tables[i];
+        if (!t->full || t->hook_seen < 0 || t->touched_overflow || strcasecmp(t->t_name, tbl)) continue;
+        if (t->n_touched > 0 && t->touched[t->n_touched - 1] == rowid) continue;
+        if (t->n_touched == t->cap_touched) {
+            int cap = t->cap_touched ? t->cap_touched * 2 : 256;
+            int64_t *nb = (cap <= TRACK_MAX_TOUCHED) ? (int64_t *)sqlite3_realloc64(t->touched, (sqlite3_uint64)cap * sizeof(int64_t)) : NULL;
+            if (!nb) { t->touched_overflow = 1; continue; }
+            t->touched = nb; t->cap_touched = cap;
+        }
+        t->touched[t->n_touched++] = rowid;
+    }
+}
+
+static int track_wanted(const vec_options *o) {
+    if (o->track_changes >= 0) return o->track_changes;
+    const char *e = getenv("VECTORGPU_TRACK_CHANGES");
+    return e && *e && strcmp(e, "0") != 0;
+}
+
+static void track_install(sqlite3 *db, vec_context *vc) {
+    if (vc->hook_installed) return;
+    sqlite3_update_hook(db, on_row_change, vc);
+    vc->hook_installed = 1;
+}
+
+/* `full` is up to date as of now: start a new log */
+static void track_reset(vec_context *vc, table_ctx *t) {
+    t->n_touched = 0;
+    t->touched_overflow = 0;
+    t->hook_seen = (vc && vc->hook_installed && track_wanted(&t->opt)) ? vc->hook_events : -1;
+}
+
+static int cmp_i64(const void *a, const void *b) {
+    const int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+    return (x > y) - (x < y);
 }
 
 /* ------------------------------------------------------------------------------------------------ small SQL helpers */
@@ -472,6 +541,7 @@ static void options_default(vec_options *o) {
     o->q_type = VG_QUANT_AUTO;
     o->tie_order = -1;
     o->scan_filter = -1;
+    o->track_changes = -1;
 }
 
 static uint64_t parse_size(const char *s) {
@@ -523,6 +593,8 @@ static int option_apply(sqlite3_context *ctx, vec_options *o, const char *key, i
         else { ctx_error(ctx, SQLITE_ERROR, "Invalid tie_order: '%s' (expected 'reference' or 'position').", v); return 0; }
     } else if (!strncasecmp(key, "scan_filter", (size_t)klen) && klen == 11) {
         o->scan_filter = strtol(v, NULL, 0) != 0;
+    } else if (!strncasecmp(key, "track_changes", (size_t)klen) && klen == 13) {
+        o->track_changes = strtol(v, NULL, 0) != 0;
     }
     return 1;                                                   /* unknown keys are ignored */
 }
@@ -791,10 +863,73 @@ static int append_only_since_staged(sqlite3 *db, table_ctx *t, int64_t d, sqlite
     return 1;
 }
 
+/* Bring `full` up to date from the change log (see on_row_change): every touched rowid is looked up in the table NOW and in
+ * the corpus; present in both = patch, in the corpus only = remove, in the table only = append (possible only behind every
+ * staged row).  Then COUNT(col) must equal the corpus' row count - what the hook cannot see (rows removed by ON CONFLICT
+ * REPLACE, a key UPDATE's old rowid) shows up there.  Returns 1 when `full` is current, 0 when the caller has to re-stage
+ * (nothing is left half-applied that a re-stage would not overwrite), -1 with *err on a hard error. */
+static int apply_tracked_changes(sqlite3 *db, table_ctx *t, char **err) {
+    const int es = elem_size(t->opt.v_type), dim = t->opt.v_dim;
+    const int64_t row_bytes = (int64_t)es * dim;
+    if (t->n_touched == 0) return 1;
+    qsort(t->touched, (size_t)t->n_touched, sizeof(int64_t), cmp_i64);
+    int n = 0;
+    for (int i = 0; i < t->n_touched; ++i) if (n == 0 || t->touched[n - 1] != t->touched[i]) t->touched[n++] = t->touched[i];
+    int result = 0, npatch = 0, ndel = 0, napp = 0;
+    int64_t *ppos = (int64_t *)sqlite3_malloc64((sqlite3_uint64)n * sizeof(int64_t));
+    int64_t *dpos = (int64_t *)sqlite3_malloc64((sqlite3_uint64)n * sizeof(int64_t));
+    int64_t *aids = (int64_t *)sqlite3_malloc64((sqlite3_uint64)n * sizeof(int64_t));
+    uint8_t *pdata = (uint8_t *)sqlite3_malloc64((sqlite3_uint64)n * (sqlite3_uint64)row_bytes);
+    uint8_t *adata = (uint8_t *)sqlite3_malloc64((sqlite3_uint64)n * (sqlite3_uint64)row_bytes);
+    sqlite3_stmt *st = NULL;
+    char *sql = sqlite3_mprintf("SELECT %q FROM %q WHERE %q = ?1;", t->c_name, t->t_name, t->pk_name);
+    if (!ppos || !dpos || !aids || !pdata || !adata || !sql || sqlite3_prepare_v2(db, sql, -1, &st, NULL) != SQLITE_OK) goto done;
+    {
+        const int64_t rows0 = G.corpus_rows(t->full);
+        int64_t last_id = rows0 > 0 ? G.corpus_rowid_at(t->full, rows0 - 1) : INT64_MIN;
+        for (int i = 0; i < n; ++i) {
+            const int64_t r = t->touched[i];
+            const int64_t pos = G.corpus_find_rowid(t->full, r);
+            if (pos == -2) goto done;                            /* several shards, or rowids not in key order */
+            sqlite3_reset(st);
+            sqlite3_bind_int64(st, 1, r);
+            const void *blob = NULL;
+            int rc = sqlite3_step(st);
+            if (rc == SQLITE_ROW && sqlite3_column_type(st, 0) != SQLITE_NULL) {
+                blob = sqlite3_column_blob(st, 0);
+                if (blob && sqlite3_column_bytes(st, 0) < row_bytes) goto done;      /* (the full pass reports the short BLOB) */
+            } else if (rc != SQLITE_ROW && rc != SQLITE_DONE) goto done;
+            if (pos >= 0 && blob) { ppos[npatch] = pos; memcpy(pdata + (int64_t)npatch * row_bytes, blob, (size_t)row_bytes); ++npatch; }
+            else if (pos >= 0) { dpos[ndel++] = pos; }
+            else if (blob) {
+                if (r <= last_id) goto done;                     /* a new row in the middle of the scan order */
+                aids[napp] = r; memcpy(adata + (int64_t)napp * row_bytes, blob, (size_t)row_bytes); ++napp;
+                last_id = r;
+            }
+        }
+    }
+    if (ndel > TRACK_MAX_DELETES) goto done;
+    /* positions are pre-deletion indices: patches first, then the removals (ascending: rowids ascend with positions), then appends */
+    if (npatch && G.corpus_patch_rows(t->full, ppos, npatch, pdata, row_bytes) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); result = -1; goto done; }
+    if (ndel && G.corpus_delete_rows(t->full, dpos, ndel) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); result = -1; goto done; }
+    if (napp && G.corpus_append(t->full, adata, napp, row_bytes, aids) != VG_OK) { *err = sqlite3_mprintf("%s", gpu_error()); result = -1; goto done; }
+    {
+        char *cnt = sqlite3_mprintf("SELECT COUNT(%q) FROM %q;", t->c_name, t->t_name);
+        const int64_t have = cnt ? read_int64(db, cnt) : -1;
+        sqlite3_free(cnt);
+        result = (have == G.corpus_rows(t->full)) ? 1 : 0;
+    }
+done:
+    sqlite3_finalize(st);
+    sqlite3_free(sql);
+    sqlite3_free(ppos); sqlite3_free(dpos); sqlite3_free(aids); sqlite3_free(pdata); sqlite3_free(adata);
+    return result;
+}
+
 /* Stage (or re-stage, if the database changed since) the raw vectors of (table, column) into HBM in the order the
  * reference scans them: "SELECT pk, col FROM tbl" (sqlite-vector.c:2077), NULL vectors skipped (:2093).
  * Short BLOBs are an error here (the reference would read past them, :2095-2098). */
-static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
+static int stage_full(sqlite3 *db, vec_context *vc, table_ctx *t, char **err) {
     int64_t dv, ch, sv;
     db_stamps(db, &dv, &ch, &sv);
     /* rows staged inside an open transaction may be rolled back without either stamp moving (total_changes never
@@ -804,6 +939,23 @@ static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
     const int dim = t->opt.v_dim;
     sqlite3_stmt *st = NULL;
     int rc;
+    /* row-granular freshness, any statement (track_changes=1): only this connection wrote (data_version, schema_version
+     * unchanged) and the update hook reported exactly as many row changes as sqlite3_total_changes() counted - none escaped
+     * it (WITHOUT ROWID tables, the truncate optimisation of DELETE without WHERE, a hook replaced by the application) */
+    if (t->full && !t->full_in_txn && t->full_data_version == dv && t->full_schema == sv && vc && vc->hook_installed &&
+        t->hook_seen >= 0 && !t->touched_overflow && track_wanted(&t->opt) && !getenv("VECTORGPU_NO_INCREMENTAL") &&
+        vc->hook_events - t->hook_seen == ch - t->full_changes) {
+        const int had = t->n_touched;
+        const int r = apply_tracked_changes(db, t, err);
+        if (r < 0) { G.corpus_destroy(t->full); t->full = NULL; return SQLITE_ERROR; }
+        if (r > 0) {
+            t->full_changes = ch;
+            t->full_in_txn = !sqlite3_get_autocommit(db);
+            if (had) table_watermark(db, t);
+            track_reset(vc, t);
+            return SQLITE_OK;
+        }
+    }
     if (t->full && !t->full_in_txn && t->full_data_version == dv && t->full_schema == sv &&
         append_only_since_staged(db, t, ch - t->full_changes, &st)) {
         /* row-granular freshness: the new rows are appended behind the staged ones (the device extends its cached
@@ -814,6 +966,7 @@ static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
             t->full_changes = ch;
             t->full_in_txn = !sqlite3_get_autocommit(db);
             table_watermark(db, t);
+            track_reset(vc, t);
         } else { G.corpus_destroy(t->full); t->full = NULL; }
         return rc;
     }
@@ -834,6 +987,7 @@ static int stage_full(sqlite3 *db, table_ctx *t, char **err) {
     if (rc == SQLITE_OK) {
         t->full_data_version = dv; t->full_changes = ch; t->full_schema = sv; t->full_in_txn = !sqlite3_get_autocommit(db);
         table_watermark(db, t);
+        track_reset(vc, t);
     } else { G.corpus_destroy(t->full); t->full = NULL; }
     return rc;
 }
@@ -896,6 +1050,8 @@ static void fn_vector_init(sqlite3_context *ctx, int argc, sqlite3_value **argv)
         /* the GPU knobs (ignored by the reference) may be changed by calling vector_init again: they apply at once */
         if (o.tie_order >= 0) t->opt.tie_order = o.tie_order;
         if (o.scan_filter >= 0) t->opt.scan_filter = o.scan_filter;
+        if (o.track_changes >= 0) t->opt.track_changes = o.track_changes;
+        if (track_wanted(&t->opt)) track_install(db, vc);
         if ((o.tie_order >= 0 || o.scan_filter >= 0) && G.ready) {
             vg_shards *hs[2] = {t->full, t->quant};
             for (int i = 0; i < 2; ++i) {
@@ -925,8 +1081,10 @@ static void fn_vector_init(sqlite3_context *ctx, int argc, sqlite3_value **argv)
         return;
     }
     t->opt = o;
+    t->hook_seen = -1;
     vc->count++;
     meta_load(db, t);
+    if (track_wanted(&t->opt)) track_install(db, vc);
 }
 
 /* ------------------------------------------------------------------------------------------------ quantization */
@@ -957,7 +1115,7 @@ static int rebuild_quantization_gpu(sqlite3_context *ctx, table_ctx *t, int qtyp
     sqlite3 *db = sqlite3_context_db_handle(ctx);
     if (!gpu_load() || G.device_count() <= 0) return -1;
     char *err = NULL;
-    int rc = stage_full(db, t, &err);
+    int rc = stage_full(db, (vec_context *)sqlite3_user_data(ctx), t, &err);
     if (rc != SQLITE_OK) {
         ctx_error(ctx, rc, "%s", err ? err : "staging failed");
         sqlite3_free(err);
@@ -1146,6 +1304,7 @@ static void quantize_common(sqlite3_context *ctx, const char *tbl, const char *c
     if (t->full && stamps_were_fresh) {       /* only our own shadow-table writes happened, and they are committed */
         db_stamps(db, &t->full_data_version, &t->full_changes, &t->full_schema);
         t->full_in_txn = 0;
+        if (t->hook_seen >= 0) t->hook_seen = ((vec_context *)sqlite3_user_data(ctx))->hook_events;   /* (the shadow-table rows were reported too) */
     }
     sqlite3_result_int64(ctx, (sqlite3_int64)counter);
     if (was_preloaded) do_preload(ctx, tbl, col);
@@ -1368,7 +1527,7 @@ static int filter_common(sqlite3_vtab_cursor *cur, int argc, sqlite3_value **arg
         scan_query = qquant;
         corpus = t->quant;
     } else {
-        rc = stage_full(vt->db, t, &err);
+        rc = stage_full(vt->db, vt->ctx, t, &err);
         if (rc != SQLITE_OK) { rc = vtab_error(&vt->base, "%s: %s", fname, err ? err : "staging failed"); goto out; }
         corpus = t->full;
     }
@@ -1543,7 +1702,7 @@ static int batch_filter_common(sqlite3_vtab_cursor *cur, int argc, sqlite3_value
         scan_queries = qquant;
         corpus = t->quant;
     } else {
-        rc = stage_full(vt->db, t, &err);
+        rc = stage_full(vt->db, vt->ctx, t, &err);
         if (rc != SQLITE_OK) { rc = vtab_error(&vt->base, "%s: %s", fname, err ? err : "staging failed"); goto out; }
         corpus = t->full;
     }

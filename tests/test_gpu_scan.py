@@ -1054,3 +1054,59 @@ def test_batch_half_tile_major_copy_equals_row_major_gather(pkg, vt, monkeypatch
             c.close()
         for a, b in zip([out["1"][0]] + out["1"][1], [out["0"][0]] + out["0"][1]):
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), dim
+
+
+@pytest.mark.parametrize("vt,dim", ((dg.F32, 100), (dg.U8, 768), (dg.F16, 384), (dg.I8, 33)))
+def test_patch_and_delete_rows_equal_a_fresh_corpus(pkg, orc, vt, dim, monkeypatch):
+    """vg_corpus_patch_rows / vg_corpus_delete_rows / vg_corpus_find_rowid (what the extension applies after UPDATE / DELETE):
+    after any mix of them the corpus answers like one staged from scratch with the surviving rows - single scans (plain and
+    through the filter with its shadow copies and norms), batches (tile-major copies, row sums), rowids, scan-position ties."""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    n = 50_003
+    rows = dg.corpus(vt, n, dim, 7300 + dim)
+    ids = np.arange(10, 10 + 3 * n, 3, dtype=np.int64)                 # ascending, not contiguous
+    c = pkg.Corpus(vt, dim)
+    c.append(rows[:30000], ids[:30000])
+    c.append(rows[30000:], ids[30000:])
+    q = dg.query(vt, dim, 7400 + dim)
+    qs = dg.corpus(vt, 40, dim, 7500 + dim)
+    metric = dg.L2
+    c.scan_topk(metric, q, 20)                                         # derived data exists before the edits
+    c.scan_topk_batch(dg.DOT, qs, 20)
+    assert c.find_rowid(int(ids[12345])) == 12345 and c.find_rowid(11) == -1 and c.find_rowid(5) == -1
+    rng = np.random.default_rng(7600 + dim)
+    keep = np.ones(n, bool)
+    cur_rows, cur_ids = rows.copy(), ids.copy()
+    for step in range(4):
+        # patches: some rows become copies of the query (new best rows, ties among themselves) or fresh random rows
+        pos = rng.permutation(len(cur_ids))[:300]
+        new = dg.corpus(vt, 300, dim, 7700 + dim + step)
+        new[:5] = q
+        c.patch_rows(pos, new)
+        cur_rows[pos] = new
+        # deletions: a run at the front, singles, a run at the very end
+        m = len(cur_ids)
+        dele = np.unique(np.concatenate([np.arange(0, 7), rng.permutation(m)[:200], np.arange(m - 3, m)])).astype(np.int64)
+        c.delete_rows(dele)
+        mask = np.ones(m, bool)
+        mask[dele] = False
+        cur_rows, cur_ids = cur_rows[mask], cur_ids[mask]
+        assert c.rows == len(cur_ids)
+        fresh = pkg.Corpus(vt, dim)
+        fresh.append(cur_rows, cur_ids)
+        for mt in (dg.L2, dg.COSINE, dg.DOT):
+            for filt in (1, 0):
+                c.set_scan_filter(filt); fresh.set_scan_filter(filt)
+                a_ids, a_d = c.scan_topk(mt, q, 20)
+                b_ids, b_d = fresh.scan_topk(mt, q, 20)
+                assert a_ids.tolist() == b_ids.tolist() and dg.same_float_bits(a_d, b_d), (vt, step, mt, filt)
+            ai, ad, ac = c.scan_topk_batch(mt, qs, 20)
+            bi, bd, bc = fresh.scan_topk_batch(mt, qs, 20)
+            assert np.array_equal(ai, bi) and np.array_equal(ac, bc) and dg.same_float_bits(ad, bd), (vt, step, mt)
+        assert c.find_rowid(int(cur_ids[len(cur_ids) // 2])) == len(cur_ids) // 2
+        fresh.close()
+    more = dg.corpus(vt, 100, dim, 7900 + dim)                         # appends keep working behind the edits
+    c.append(more, np.arange(10**7, 10**7 + 100, dtype=np.int64))
+    a_ids, _ = c.scan_topk(metric, more[7].copy(), 1)
+    assert a_ids[0] == 10**7 + 7
+    c.close()

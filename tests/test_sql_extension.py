@@ -364,6 +364,94 @@ def test_incremental_staging_appends_only_the_new_rows(ext_path, orc):
 
 
 @pytest.mark.gpu
+def test_tracked_changes_patch_delete_and_append_without_a_restage(ext_path, orc):
+    """track_changes=1: the update hook tells WHICH rows an UPDATE / DELETE / INSERT touched; the next scan re-reads only those
+    rows and patches / removes / appends them in HBM (the reference re-reads the whole table every scan, sqlite-vector.c:2077-2107).
+    A write to another table costs nothing.  Statements the hook cannot account for (DELETE without WHERE: truncate optimisation;
+    a key UPDATE; REPLACE removing a row through a UNIQUE conflict; a row inserted below the staged keys) fall back to the re-stage.  Results always equal a scan of the table as it is."""
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    n, dim = 120_000, 8
+    rows = dg.corpus(dg.F32, n + 200, dim, 177)
+    q = dg.query(dg.F32, dim, 178)
+    db = connect(ext_path)
+    db.execute("CREATE TABLE t (id INTEGER PRIMARY KEY, v BLOB, tag TEXT UNIQUE)")
+    db.executemany("INSERT INTO t(id, v, tag) VALUES (?, ?, ?)", [(i + 1, rows[i].tobytes(), "r%d" % (i + 1)) for i in range(n)])
+    db.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2,track_changes=1')" % dim)
+    db.execute("CREATE TABLE other (x)")
+
+    def scan(k=10):
+        return db.execute("SELECT rowid, distance FROM vector_full_scan('t','v',?,?)", (q.tobytes(), k)).fetchall()
+
+    def expect(k=10):
+        cur = db.execute("SELECT id, v FROM t WHERE v IS NOT NULL ORDER BY id").fetchall()
+        ids = np.array([r[0] for r in cur], dtype=np.int64)
+        m = np.frombuffer(b"".join(r[1] for r in cur), dtype=np.float32).reshape(len(cur), dim)
+        d = orc.scan_distances(orc.AVX2, dg.L2, dg.F32, q, m)
+        oids, odist, _ = orc.topk_ordered(d, ids, k)
+        return oids.tolist()
+
+    appended = pkg.lib().vg_stat_rows_appended
+
+    def check(staged_rows, k=10):
+        base = appended()
+        got = scan(k)
+        assert [x[0] for x in got] == expect(k)
+        assert appended() - base == staged_rows, (appended() - base, staged_rows)
+        return got
+
+    scan()
+    # an unrelated table: nothing is staged at all
+    db.execute("INSERT INTO other VALUES (1)")
+    check(0)
+    # UPDATE of a staged row to the query itself: patched in place
+    db.execute("UPDATE t SET v = ? WHERE id = 777", (q.tobytes(),))
+    got = check(0)
+    assert got[0] == (777, 0.0)
+    # DELETE of single rows (the best one among them), UPDATE and INSERT in the same round
+    db.execute("DELETE FROM t WHERE id IN (777, 5, 119999)")
+    db.execute("UPDATE t SET v = ? WHERE id = 60000", (q.tobytes(),))
+    db.execute("INSERT INTO t(id, v, tag) VALUES (?, ?, 'new1')", (n + 1, (q * np.float32(1.0001)).astype(np.float32).tobytes()))
+    db.execute("INSERT INTO t(v, tag) VALUES (?, 'new2')", (rows[n + 1].tobytes(),))
+    got = check(2)                                                 # only the two new rows travel as an append
+    assert got[0][0] == 60000 and got[1][0] == n + 1
+    # a vector set to NULL leaves the corpus, a NULL one set to a vector can only be appended when it lies behind every staged key
+    db.execute("UPDATE t SET v = NULL WHERE id = 60000")
+    got = check(0)
+    assert got[0][0] == n + 1
+    # a run of deletions + rollback of some of them: the log only says where to look, the table decides
+    db.execute("BEGIN")
+    db.execute("DELETE FROM t WHERE id BETWEEN 1000 AND 1100")
+    db.execute("ROLLBACK")
+    db.execute("DELETE FROM t WHERE id BETWEEN 2000 AND 2050")
+    check(0)
+    # inside an open transaction the patched copy is good for one scan (a ROLLBACK moves no stamp): re-staged afterwards
+    db.execute("BEGIN")
+    db.execute("UPDATE t SET v = ? WHERE id = 10", (q.tobytes(),))
+    assert scan()[0][0] == 10
+    db.execute("ROLLBACK")
+    assert [x[0] for x in scan()] == expect()
+    # what the hook does not see: REPLACE removing another row through the UNIQUE tag; a key UPDATE; DELETE without WHERE
+    live = db.execute("SELECT COUNT(v) FROM t").fetchone()[0]
+    db.execute("INSERT OR REPLACE INTO t(id, v, tag) VALUES (?, ?, 'r42')", (n + 50, rows[n + 50].tobytes()))   # removes id 42
+    base = appended(); got = scan(); assert [x[0] for x in got] == expect()
+    assert appended() - base >= live - 1                           # noticed by the COUNT check: re-staged
+    db.execute("UPDATE t SET id = ? WHERE id = 43", (n + 60,))
+    assert [x[0] for x in scan()] == expect()
+    db.execute("INSERT INTO t(id, v, tag) VALUES (43, ?, 'mid')", (q.tobytes(),))       # a new row in the middle of the key order
+    got = scan()
+    assert got[0] == (43, 0.0) and [x[0] for x in got] == expect()
+    db.execute("DELETE FROM t")
+    assert scan() == []
+    db.executemany("INSERT INTO t(id, v, tag) VALUES (?, ?, ?)", [(i + 1, rows[i].tobytes(), "s%d" % i) for i in range(500)])
+    assert [x[0] for x in scan()] == expect()
+    db.execute("UPDATE t SET v = ? WHERE id = 100", (q.tobytes(),))
+    got = check(0)
+    assert got[0] == (100, 0.0)
+    db.close()
+
+
+@pytest.mark.gpu
 def test_dropped_and_recreated_table_is_restaged(ext_path):
     """DROP TABLE t; CREATE TABLE t ... moves neither data_version nor total_changes: PRAGMA schema_version is stamped too"""
     db = connect(ext_path)

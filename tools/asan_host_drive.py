@@ -37,3 +37,15 @@ for vt in dg.ALL_TYPES:
         except sqlite3.Error as e: pass
     d.close()
 print("asan run done")
+# change tracking: the update hook runs for every row change of the connection (no corpus is staged without the GPU engine)
+d = connect()
+d.execute("CREATE TABLE t (id INTEGER PRIMARY KEY, v BLOB)"); d.execute("CREATE TABLE o (x)")
+d.execute("SELECT vector_init('t','v','type=FLOAT32,dimension=4,track_changes=1')")
+d.execute("SELECT vector_init('t','v','type=FLOAT32,dimension=4,track_changes=0,scan_filter=1')")
+d.execute("SELECT vector_init('t','v','type=FLOAT32,dimension=4,track_changes=1')")
+d.executemany("INSERT INTO t VALUES (?,?)", [(i + 1, np.zeros(4, np.float32).tobytes()) for i in range(3000)])
+d.execute("UPDATE t SET v = NULL WHERE id % 7 = 0"); d.execute("DELETE FROM t WHERE id < 100"); d.execute("INSERT INTO o VALUES (1)"); d.execute("DELETE FROM t")
+try: d.execute("SELECT * FROM vector_full_scan('t','v',?,3)", (np.zeros(4, np.float32).tobytes(),)).fetchall()
+except sqlite3.Error as e: print("scan without the engine:", e)
+d.close()
+print("asan run done (tracking)")
