@@ -441,6 +441,50 @@ def single_query_line(args, pkg, runner, corpus, workload, vt, dim, metric, k, n
     return out, prepass_ms
 
 
+def filter_scan_object(args, pkg, corpus, runner, metric, vt, dim, n_rows, plain_last):
+    """the SAME queries over the SAME corpus through the lower-bound filter scan (the product's default path for a corpus of this
+    size): priced on the bytes it streams, never under the line's dtype / roofline.frac"""
+    try:
+        corpus.set_scan_filter(1)
+        if n_rows < (1 << 20):
+            os.environ.setdefault("VG_SCAN_FILTER_MIN_MB", "0")    # (a reduced --rows run: the filter regardless of the size rule)
+        runner.step(0)                                             # builds the shadow copy + norms (not timed)
+        corpus.filter_exact_evals()
+        felapsed, flat = runner.run(args.warmup, args.steps)
+        fn_launch, fscan_ms, fmerge_ms, fpre_ms = corpus.profile_mean_ms_ex()
+        evals = corpus.filter_exact_evals()
+        fname = corpus.kernel_name(metric)
+        es = pkg.TYPE_SIZE[vt]
+        if "_n4_" in fname:        # uint8 / int8: the high-nibble shadow row + (sum x^2, sum of low nibbles, their centred norm)
+            kind, per_row = "high nibbles (4 bit)", ((dim + 31) // 32) * 16 + 16
+        elif "_q8_" in fname:      # the int8 shadow row + (scale, residual norm, cached f32 norm)
+            kind, per_row = "int8", ((dim + 15) // 16) * 16 + 12
+        elif vt == pkg.F32:        # the bf16 shadow row + the cached f32 norm
+            kind, per_row = "bf16", ((dim * 2 + 15) // 16) * 16 + 4
+        else:
+            kind, per_row = "rows", ((dim * es + 15) // 16) * 16 + 4
+        streamed = n_rows * per_row
+        ftraffic, fsource = pmc_traffic(fname, n_rows)
+        same = (list(runner.last["pos"]) == list(plain_last["pos"]) and
+                np.array_equal(np.asarray(runner.last["dist"]), np.asarray(plain_last["dist"])))
+        return {
+            "what": "the same %d queries through the filter scan: %s shadow copy as a lower-bound filter + exact re-evaluation of the "
+                    "candidates with the plain kernel's arithmetic (same rowids and distance bits as the plain scan)" % (args.steps, kind),
+            "value": n_rows * args.steps / felapsed, "unit": "vectors/s", "ms_per_step": felapsed / args.steps * 1e3,
+            "p50_query_latency_ms": float(np.median(flat) * 1e3),
+            "kernel": fname, "kernel_ms": fscan_ms, "prepass_ms": fpre_ms, "merge_kernel_ms": fmerge_ms, "launches_timed": fn_launch,
+            "dtype_streamed": kind, "streamed_bytes_per_launch": streamed,
+            "achieved_on_streamed_GBs": streamed / (fscan_ms * 1e-3) / 1e9 if fscan_ms > 0 else 0.0,
+            "frac_on_streamed": streamed / (fscan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fscan_ms > 0 else 0.0,
+            "traffic": ftraffic, "traffic_source": fsource,
+            "exact_evaluations_per_query": evals / float(args.warmup + args.steps),
+            "last_query_same_answer_as_plain_scan": bool(same),
+            "extra_hbm_bytes": n_rows * per_row,
+        }
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     args = parse()
     import torch
@@ -517,38 +561,7 @@ def main():
     also_set = set() if args.no_also else set(x for x in args.also.split(",") if x)
     if n_gpus == 1 and args.workload == "c2" and "filter" in also_set:
         # ---- the same queries through the filter scan (the product's default path for this corpus)
-        try:
-            corpus.set_scan_filter(1)
-            os.environ.setdefault("VG_SCAN_FILTER_MIN_MB", "0" if n_rows * dim * 4 < (3 << 30) else "3072")
-            runner.step(0)                                             # builds the shadow copy + norms (not timed)
-            corpus.filter_exact_evals()
-            felapsed, flat = runner.run(args.warmup, args.steps)
-            fn_launch, fscan_ms, fmerge_ms, fpre_ms = corpus.profile_mean_ms_ex()
-            evals = corpus.filter_exact_evals()
-            fname = corpus.kernel_name(metric)
-            q8 = "_q8_" in fname
-            # per row: the int8 shadow row + (scale, residual norm, cached f32 norm) | the bf16 shadow row + the cached f32 norm
-            per_row = (((dim + 15) // 16) * 16 + 12) if q8 else (((dim * 2 + 15) // 16) * 16 + 4)
-            streamed = n_rows * per_row
-            ftraffic, fsource = pmc_traffic(fname, n_rows)
-            same = (list(runner.last["pos"]) == list(plain_last["pos"]) and
-                    np.array_equal(np.asarray(runner.last["dist"]), np.asarray(plain_last["dist"])))
-            out["filter_scan"] = {
-                "what": "the same %d queries through vg_scan_filter_kernel: %s shadow copy as a lower-bound filter + exact f32 "
-                        "re-evaluation of the candidates (same rowids and distance bits as the plain scan)" % (args.steps, "int8" if q8 else "bf16"),
-                "value": n_rows * args.steps / felapsed, "unit": "vectors/s", "ms_per_step": felapsed / args.steps * 1e3,
-                "p50_query_latency_ms": float(np.median(flat) * 1e3),
-                "kernel": fname, "kernel_ms": fscan_ms, "prepass_ms": fpre_ms, "merge_kernel_ms": fmerge_ms, "launches_timed": fn_launch,
-                "dtype_streamed": "int8" if q8 else "bf16", "streamed_bytes_per_launch": streamed,
-                "achieved_on_streamed_GBs": streamed / (fscan_ms * 1e-3) / 1e9 if fscan_ms > 0 else 0.0,
-                "frac_on_streamed": streamed / (fscan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fscan_ms > 0 else 0.0,
-                "traffic": ftraffic, "traffic_source": fsource,
-                "exact_f32_evaluations_per_query": evals / float(args.warmup + args.steps),
-                "last_query_same_answer_as_plain_scan": bool(same),
-                "extra_hbm_bytes": n_rows * per_row,
-            }
-        except Exception as e:
-            out["filter_scan"] = {"error": repr(e)}
+        out["filter_scan"] = filter_scan_object(args, pkg, corpus, runner, metric, vt, dim, n_rows, plain_last)
     if n_gpus == 1 and args.workload == "c2" and (also_set & {"c3", "c5"}):
         # ---- configs[2] over its own corpus, then configs[4] over the f32 corpus (the MFMA-bound batch last: the HBM-bound
         # lines are not timed on a package it has just heated)
@@ -558,6 +571,7 @@ def main():
                 v3, t3, d3, m3, desc3 = WORKLOADS["c3"]
                 c3 = make_shard(pkg, torch, v3, d3, n_rows, 42, local_rank)
                 q3 = np.random.default_rng(43).integers(0, 256, (nq, d3), dtype=np.uint8)
+                c3.set_scan_filter(0)              # the line: the plain kernel on SURVEY 8(d)'s 7.68 GB; the nibble filter on its own below
                 r3 = SingleQueryRunner(pkg, torch, None, shard, c3, v3, d3, m3, k, n_rows, 1, q3)
                 line, _ = single_query_line(args, pkg, r3, c3, "c3", v3, d3, m3, k, n_rows, 1, desc3)
                 if not args.no_cpu_baseline:

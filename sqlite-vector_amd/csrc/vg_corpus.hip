@@ -123,6 +123,8 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_rows_s8) hipFree(c->d_rows_s8);
     if (c->d_rows_tm) hipFree(c->d_rows_tm);
     if (c->d_rows_bf) hipFree(c->d_rows_bf);
+    if (c->d_rows_n4) hipFree(c->d_rows_n4);
+    if (c->d_n4stat) hipFree(c->d_n4stat);
     if (c->d_rows_q8) hipFree(c->d_rows_q8);
     if (c->d_q8stat) hipFree(c->d_q8stat);
     if (c->d_filter_evals) hipFree(c->d_filter_evals);
@@ -146,6 +148,7 @@ extern "C" int vg_corpus_clear(vg_corpus *c) {
     c->tm_rows = 0;
     c->bf_rows = 0;
     c->q8_rows = 0;
+    c->n4_rows = 0;
     c->rowids.clear();
     c->rowids_ascending = true;
     return VG_OK;
@@ -352,6 +355,7 @@ static void invalidate_derived_from(vg_corpus *c, int64_t pos) {
     c->tm_rows = std::min(c->tm_rows, pos);
     c->bf_rows = std::min(c->bf_rows, pos);
     c->q8_rows = std::min(c->q8_rows, pos);
+    c->n4_rows = std::min(c->n4_rows, pos);
     c->dist_valid_rows = 0;
 }
 

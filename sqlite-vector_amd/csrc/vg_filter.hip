@@ -5,6 +5,7 @@
 
 #include "vg_scan.h"
 #include "vg_scan_filter.h"
+#include "vg_scan_filter_n4.h"
 
 typedef VgShape Shape;
 
@@ -38,7 +39,24 @@ int vg_ensure_filter_counters(vg_corpus *c) {
 // f32 corpora additionally pay the shadow copy (+50 % HBM): from 3 GB up; f16 / bf16 corpora (no copy): from 1 GB up.
 // (Those figures are for VG_SCAN_FILTER_SHADOW=bf16 / rows; the default int8 shadow copy has its own rule below.)
 static bool filter_uses_q8(const vg_corpus *c, int metric);
+// uint8 / int8 corpora: the nibble filter (vg_scan_filter_n4.h) - half the bytes.  Its bound assumes sums below 2^31 (the plain
+// kernel's arithmetic is modular like the reference's): rows of at most 16384 elements.  Sizes (D = 768, measured): see below.
+static bool scan_filter_serves_n4(const vg_corpus *c, int metric) {
+    if (c->vtype != VG_TYPE_U8 && c->vtype != VG_TYPE_I8) return false;
+    if (metric != VG_DIST_L2 && metric != VG_DIST_SQUARED_L2 && metric != VG_DIST_DOT && metric != VG_DIST_COSINE) return false;
+    if (c->dim > 16384 || c->n4_disabled || !scan_filter_enabled(c)) return false;
+    // OPT-IN (vg_corpus_set_scan_filter(c, 1) / the extension's scan_filter=1, or VG_SCAN_FILTER_N4=1): a 4-bit residual is coarse,
+    // and by Cauchy-Schwarz its bound is sqrt(D) looser than its typical size.  Measured at 10M x 768 (profiles/r3d): bytes
+    // quantized from clustered unit-norm embeddings - the neighbours are much closer than a random pair - 0.61 ms against 1.13
+    // (10k exact rows per query); independent random bytes (the synthetic C3 corpus) - distances concentrate, the slack is
+    // ~3 standard deviations of them - every 20th row is a candidate and the guard sends the scans back to the plain kernel.
+    // Paying + 52 % device memory for that has to be the user's call.
+    if (c->scan_filter_mode != 1 && !env_int("VG_SCAN_FILTER_N4", 0)) return false;
+    if (env_int("VG_SCAN_FILTER_MIN_MB", -1) >= 0) return c->n_rows * c->stride >= (long long)env_int("VG_SCAN_FILTER_MIN_MB", 0) * (1ll << 20);
+    return c->n_rows >= (1 << 20) && c->n_rows * c->stride >= (768ll << 20);
+}
 static bool scan_filter_serves(const vg_corpus *c, int metric) {
+    if (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8) return scan_filter_serves_n4(c, metric);
     const bool half = (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16);
     if (c->vtype != VG_TYPE_F32 && !half) return false;
     if (metric == VG_DIST_L1 && !half) return false;         // (the f32 L1 scan already streams at the HBM ceiling: nothing to skip)
@@ -147,6 +165,48 @@ __global__ __launch_bounds__(256) void vg_to_q8_kernel(const uint8_t *rows, long
     }
 }
 
+template <int XT, int MODE, bool NT>
+static filter_fn_t pick_n4_u(int U) {
+    switch (U) {
+        case 1: return vg_scan_filter_n4_kernel<XT, MODE, 1, NT>;
+        case 2: return vg_scan_filter_n4_kernel<XT, MODE, 2, NT>;
+        case 3: return vg_scan_filter_n4_kernel<XT, MODE, 3, NT>;
+        case 4: return vg_scan_filter_n4_kernel<XT, MODE, 4, NT>;
+        case 6: return vg_scan_filter_n4_kernel<XT, MODE, 6, NT>;
+    }
+    return nullptr;
+}
+template <bool NT>
+static filter_fn_t pick_n4(int vtype, int mode, int U) {
+    if (vtype == VG_TYPE_U8) return mode == VGF_L2 ? pick_n4_u<T_U8, VGF_L2, NT>(U) : (mode == VGF_DOT ? pick_n4_u<T_U8, VGF_DOT, NT>(U) : pick_n4_u<T_U8, VGF_COS, NT>(U));
+    return mode == VGF_L2 ? pick_n4_u<T_I8, VGF_L2, NT>(U) : (mode == VGF_DOT ? pick_n4_u<T_I8, VGF_DOT, NT>(U) : pick_n4_u<T_I8, VGF_COS, NT>(U));
+}
+static long long n4_shadow_stride(const vg_corpus *c) { return (((long long)c->dim + 31) / 32) * 16; }
+int vg_ensure_n4_shadow(vg_corpus *c) {
+    const long long ns = n4_shadow_stride(c);
+    if (c->n4_cap < c->n_rows) {
+        const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_rows_n4) hipFree(c->d_rows_n4);
+        if (c->d_n4stat) hipFree(c->d_n4stat);
+        c->d_rows_n4 = nullptr; c->d_n4stat = nullptr; c->n4_cap = 0; c->n4_rows = 0;
+        HIP_TRY(hipMalloc(&c->d_rows_n4, (size_t)cap * ns));
+        HIP_TRY(hipMalloc(&c->d_n4stat, (size_t)cap * sizeof(VgN4Stat)));
+        c->n4_cap = cap;
+    }
+    if (c->n4_rows < c->n_rows) {
+        const long long n = c->n_rows - c->n4_rows;
+        const long long blocks = std::min<long long>((n * 16 + 255) / 256, 256 * 32);
+        auto kern = c->vtype == VG_TYPE_U8 ? vg_to_n4_kernel<T_U8> : vg_to_n4_kernel<T_I8>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_rows, (long long)c->n4_rows, n,
+                           (long long)c->stride, c->dim, c->d_rows_n4, ns, reinterpret_cast<VgN4Stat *>(c->d_n4stat));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return vg_fail(VG_ERR_HIP, "nibble shadow pass failed: %s", hipGetErrorString(e));
+        c->n4_rows = c->n_rows;
+    }
+    return VG_OK;
+}
+
 static long long q8_shadow_stride(const vg_corpus *c) { return (((long long)c->dim + 15) / 16) * 16; }
 // What the filter scans stream.  Default: the int8 shadow copy - a quarter of an f32 corpus' bytes (+ 26 % HBM), half of an
 // f16 / bf16 corpus' (+ 52 %).  VG_SCAN_FILTER_SHADOW=bf16 (or "rows"): f32 corpora through the bf16 shadow copy (half the
@@ -189,6 +249,7 @@ static int filter_mode_of(int metric) {
 static int filter_u_cap(const vg_corpus *) { return 6; }
 // bytes per row the filter streams: the bf16 shadow copy of an f32 corpus, the rows themselves otherwise
 static long long filter_stream_stride(const vg_corpus *c, int metric) {
+    if (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8) return n4_shadow_stride(c);
     if (filter_uses_q8(c, metric)) return q8_shadow_stride(c);
     return c->vtype == VG_TYPE_F32 ? vg_bf16_shadow_stride(c) : (long long)c->stride;
 }
@@ -200,9 +261,13 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     // The shadow copy and the norms cost HBM next to the corpus (see filter_uses_q8).  An f32 corpus they do not fit next to
     // keeps the plain f32 scan (which served it before the filter existed) instead of failing every query; an f16 / bf16
     // corpus falls back to filtering over its own rows.
-    int rc = vg_ensure_row_norms(c);
+    const bool n4 = (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8);
+    int rc = n4 ? VG_OK : vg_ensure_row_norms(c);
     bool q8 = filter_uses_q8(c, metric);
-    if (rc == VG_OK && q8) {
+    if (n4) {
+        rc = vg_ensure_n4_shadow(c);
+        if (rc == VG_ERR_NOMEM) { (void)hipGetLastError(); c->n4_disabled = true; return -1; }
+    } else if (rc == VG_OK && q8) {
         rc = vg_ensure_q8_shadow(c);
         if (rc == VG_ERR_NOMEM && !f32) { (void)hipGetLastError(); c->q8_disabled = true; q8 = false; rc = VG_OK; }
     } else if (rc == VG_OK && f32) rc = vg_ensure_bf16_shadow(c);
@@ -219,7 +284,8 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     if (s.long_rows) return -1;
     {   // experiment override of the filter's own launch shape
         const int fl = env_int("VG_FILTER_LPR_LOG2", -1), fu = env_int("VG_FILTER_U", -1);
-        if (fl >= 0 && fl <= 6 && fu > 0 && (nch_b + (1 << fl) - 1) / (1 << fl) <= fu && pick_filter<true>(c->vtype, filter_mode_of(metric), fu, q8)) { s.lpr_log2 = fl; s.U = fu; }
+        if (fl >= 0 && fl <= 6 && fu > 0 && (nch_b + (1 << fl) - 1) / (1 << fl) <= fu &&
+            (n4 ? pick_n4<true>(c->vtype, filter_mode_of(metric), fu) : pick_filter<true>(c->vtype, filter_mode_of(metric), fu, q8))) { s.lpr_log2 = fl; s.U = fu; }
     }
     Shape xs;                                            // the plain kernel's own shape: the exact evaluation sums in its order
     vg_plain_scan_shape(c, metric, &xs);
@@ -247,7 +313,8 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     }
     const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (c->n_rows * bs > (256ll << 20));
     const int mode = filter_mode_of(metric);
-    filter_fn_t fn = nt ? pick_filter<true>(c->vtype, mode, s.U, q8) : pick_filter<false>(c->vtype, mode, s.U, q8);
+    filter_fn_t fn = n4 ? (nt ? pick_n4<true>(c->vtype, mode, s.U) : pick_n4<false>(c->vtype, mode, s.U))
+                        : (nt ? pick_filter<true>(c->vtype, mode, s.U, q8) : pick_filter<false>(c->vtype, mode, s.U, q8));
     if (!fn) return -1;
     const int rpb = VG_WAVE >> s.lpr_log2;
     const long long nbatch = (c->n_rows + rpb - 1) / rpb;
@@ -255,7 +322,8 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count));
     blocks = std::min<long long>(blocks, VG_SEL_MAX_HEADS);
     FilterScanArgs a;
-    a.shadow = q8 ? c->d_rows_q8 : (f32 ? c->d_rows_bf : c->d_rows); a.q8stat = reinterpret_cast<const float2 *>(c->d_q8stat); a.rows = c->d_rows; a.query = dev_query; a.row_norm = c->d_xnorm; a.cand = c->d_cand;
+    a.shadow = n4 ? c->d_rows_n4 : (q8 ? c->d_rows_q8 : (f32 ? c->d_rows_bf : c->d_rows));
+    a.q8stat = reinterpret_cast<const float2 *>(n4 ? c->d_n4stat : c->d_q8stat); a.rows = c->d_rows; a.query = dev_query; a.row_norm = c->d_xnorm; a.cand = c->d_cand;
     a.n_rows = c->n_rows; a.stride = c->stride; a.bstride = bs; a.nch = c->nch; a.nch_b = nch_b;
     a.lpr_log2 = s.lpr_log2; a.k = k; a.root = (metric == VG_DIST_L2) ? 1 : 0; a.dim = c->dim;
     a.mode = mode;
@@ -301,7 +369,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     return VG_OK;
 }
 
-static const char *filter_type_tag(int t) { return t == VG_TYPE_F32 ? "f32" : (t == VG_TYPE_F16 ? "f16" : "bf16"); }
+static const char *filter_type_tag(int t) { return t == VG_TYPE_F32 ? "f32" : (t == VG_TYPE_F16 ? "f16" : (t == VG_TYPE_BF16 ? "bf16" : (t == VG_TYPE_U8 ? "u8" : "i8"))); }
 
 // "scan_filter_<type>_<metric>[_bf16]_u<U>_lpr<L>[_nt]" when the filter serves (corpus, metric); false otherwise
 bool vg_scan_filter_name(vg_corpus *c, int metric, char *out, size_t out_len) {
@@ -314,6 +382,7 @@ bool vg_scan_filter_name(vg_corpus *c, int metric, char *out, size_t out_len) {
     const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (c->n_rows * bs > (256ll << 20));
     static const char *mtag[4] = {"l2", "dot", "cos", "l1"};
     snprintf(out, out_len, "scan_filter_%s_%s%s_u%d_lpr%d%s", filter_type_tag(c->vtype), mtag[filter_mode_of(metric)],
-             filter_uses_q8(c, metric) ? "_q8" : (c->vtype == VG_TYPE_F32 ? "_bf16" : ""), fs.U, 1 << fs.lpr_log2, nt ? "_nt" : "");
+             (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8) ? "_n4" : (filter_uses_q8(c, metric) ? "_q8" : (c->vtype == VG_TYPE_F32 ? "_bf16" : "")),
+             fs.U, 1 << fs.lpr_log2, nt ? "_nt" : "");
     return true;
 }

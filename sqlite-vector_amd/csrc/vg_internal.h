@@ -99,6 +99,10 @@ struct vg_corpus {
     uint8_t *d_rows_q8 = nullptr;                 // f32 corpora: int8 shadow copy for the single-query filter scan (vg_filter.hip) ...
     void *d_q8stat = nullptr;                     // ... and per row (scale, residual norm) as float2
     int64_t q8_rows = 0, q8_cap = 0;
+    uint8_t *d_rows_n4 = nullptr;                 // uint8 / int8 corpora: high-nibble shadow copy for the filter scan (vg_scan_filter_n4.h) ...
+    void *d_n4stat = nullptr;                     // ... and per row (sum x^2, sum of low nibbles, their centred norm), 16 bytes
+    int64_t n4_rows = 0, n4_cap = 0;
+    bool n4_disabled = false;
     bool q8_disabled = false;                     // (it did not fit next to an f16 / bf16 corpus: the filter scans read the rows themselves)
     bool filter_disabled = false;                 // the shadow copy / norms did not fit HBM: single queries keep the plain f32 scan
     int scan_filter_mode = -1;                    // vg_corpus_set_scan_filter: -1 = default (env VG_SCAN_FILTER, else on), 0 = off, 1 = on

@@ -398,3 +398,116 @@ def test_int8_shadow_fuzz_outliers_and_scales(pkg, chunk, vt, shadow, monkeypatc
                 assert ids1.tolist() == ids0.tolist(), (vt, dim, n, metric, k)
                 assert dg.same_float_bits(d1, d0), (vt, dim, n, metric, k)
         c.close()
+
+
+# ---------------------------------------------------------------------------------------------- the nibble filter (uint8 / int8)
+def n4_bounds(q, x):
+    """vg_scan_filter_n4.h's interval for q.x, restated exactly (integers / f64): A + mq Ls +- ||q'|| ||l'||"""
+    q64, x64 = q.astype(np.float64), x.astype(np.float64)
+    h = np.floor(x64 / 16.0)
+    lo = x64 - 16.0 * h
+    A = float((q64 * 16.0 * h).sum())
+    mq = q64.mean()
+    est = A + mq * lo.sum()
+    cs = np.linalg.norm(q64 - mq) * np.linalg.norm(lo - 7.5)
+    return est - cs, est + cs
+
+
+@pytest.mark.parametrize("vt", (dg.U8, dg.I8))
+def test_nibble_bound_restated_holds_for_structured_bytes(vt):
+    """(CPU arithmetic only) the interval contains q.x for random, constant, extreme and nibble-structured vectors"""
+    rng = np.random.default_rng(31 + vt)
+    lo_v, hi_v = (0, 255) if vt == dg.U8 else (-128, 127)
+    for dim in (1, 7, 32, 100, 768):
+        cases = [rng.integers(lo_v, hi_v + 1, dim) for _ in range(40)]
+        cases += [np.full(dim, lo_v), np.full(dim, hi_v), np.full(dim, 15), np.full(dim, 16), np.arange(dim) % 16,
+                  (np.arange(dim) % 2) * 15 + 16 * rng.integers(0, 4, dim), rng.integers(0, 2, dim) * 15]
+        cases = [np.clip(c, lo_v, hi_v).astype(np.int64) for c in cases]
+        for q in cases:
+            for x in cases:
+                lb, ub = n4_bounds(q, x)
+                true = float((q * x).sum())
+                assert lb - 1e-6 * (1 + abs(true)) <= true <= ub + 1e-6 * (1 + abs(true)), (vt, dim)
+
+
+@pytest.mark.parametrize("vt", (dg.U8, dg.I8))
+@pytest.mark.parametrize("dim", (3, 33, 384, 768, 1536))
+def test_nibble_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, vt, dim, monkeypatch):
+    """uint8 / int8 top-k scans through the high-nibble shadow copy: rowids and distance bits equal the plain scan's and the
+    oracle's - random bytes, low-entropy bytes (many exact ties), rows whose LOW nibbles are all 15 or all 0 (the part the
+    shadow copy drops, coherent with a query of the same structure), constant rows, the extremes, zero rows and a zero query,
+    exact duplicates of the query early and late in the scan, rows appended after the first scan."""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    monkeypatch.setenv("VG_SCAN_FILTER_NO_GUARD", "1")
+    n = 70_003
+    rng = np.random.default_rng(6600 + dim + vt)
+    rows = dg.corpus(vt, n, dim, 6700 + dim)
+    rows[1000:3000] = dg.corpus(vt, 2000, dim, 6701, low_entropy=True)
+    lo_v, hi_v = (0, 255) if vt == dg.U8 else (-128, 127)
+    npd = rows.dtype
+    base = rng.integers(0, 8, (400, dim)) * 16 + (lo_v if vt == dg.I8 else 0)
+    rows[5000:5200] = (base[:200] + 15).astype(np.int64).clip(lo_v, hi_v).astype(npd)      # low nibbles all 15
+    rows[5200:5400] = base[200:].astype(np.int64).clip(lo_v, hi_v).astype(npd)            # low nibbles all 0
+    rows[6000] = lo_v; rows[6001] = hi_v; rows[6002] = 0; rows[6003] = 15; rows[6004] = 16
+    q_struct = (base[7] + 15).clip(lo_v, hi_v).astype(npd)
+    rows[100] = q_struct; rows[n - 50] = q_struct
+    queries = [dg.query(vt, dim, 6800 + i) for i in range(3)] + [q_struct, np.zeros(dim, npd), np.full(dim, hi_v, npd),
+                                                               np.full(dim, lo_v, npd), dg.query(vt, dim, 6810, low_entropy=True)]
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    tag = dg.TYPE_NAMES[vt]
+    for metric in (dg.L2, dg.SQUARED_L2, dg.DOT, dg.COSINE):
+        c.set_scan_filter(1)
+        assert c.kernel_name(metric).startswith("scan_filter_%s" % tag) and "_n4_" in c.kernel_name(metric), c.kernel_name(metric)
+        for qi, q in enumerate(queries):
+            want = orc.scan_distances(orc.AVX2, metric, vt, q, rows)
+            for k in (1, 20, 64):
+                c.set_scan_filter(1)
+                ids1, d1 = c.scan_topk(metric, q, k)
+                c.set_scan_filter(0)
+                ids0, d0 = c.scan_topk(metric, q, k)
+                assert ids1.tolist() == ids0.tolist(), (vt, dim, metric, qi, k)
+                assert dg.same_float_bits(d1, d0), (vt, dim, metric, qi, k)
+            assert dg.same_float_bits(d1.astype(np.float32), want[ids1 - 1]), (vt, dim, metric, qi)
+    c.set_scan_filter(1)
+    assert not c.kernel_name(dg.L1).startswith("scan_filter")     # (no bound for L1: the plain kernel)
+    more = dg.corpus(vt, 500, dim, 6900 + dim)
+    more[17] = queries[0]
+    c.append(more)                                                   # the shadow copy and the row statistics are extended
+    ids1, d1 = c.scan_topk(dg.L2, queries[0], 3)
+    assert ids1[0] == n + 18 and d1[0] == 0.0
+    c.close()
+
+
+@pytest.mark.parametrize("vt,dim", ((dg.U8, 64), (dg.I8, 48)))
+def test_nibble_filter_with_its_prepass_on_clustered_bytes(pkg, orc, vt, dim, monkeypatch):
+    """n >= 2^20: the pre-pass threshold; bytes quantized from clustered unit-norm embeddings (values crowd a few levels: the
+    high nibbles of whole clusters coincide), near-duplicates of the query"""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    n = (1 << 20) + 911
+    rng = np.random.default_rng(7100 + dim)
+    centres = rng.standard_normal((11, dim)).astype(np.float32)
+    x = centres[rng.integers(0, 11, n)] + np.float32(0.05) * rng.standard_normal((n, dim), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+    lo, hi = x.min(), x.max()
+    if vt == dg.U8:
+        rows = np.clip(np.rint((x - lo) * (255.0 / (hi - lo))), 0, 255).astype(np.uint8)
+    else:
+        rows = np.clip(np.rint(x * (127.0 / max(abs(lo), abs(hi)))), -128, 127).astype(np.int8)
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    for qi, q in enumerate((rows[n - 4321].copy(), rows[100].copy(), rows[500000].copy())):
+        for metric in (dg.L2, dg.DOT, dg.COSINE):
+            c.set_scan_filter(1)
+            ids1, d1 = c.scan_topk(metric, q, 20)
+            c.set_scan_filter(0)
+            ids0, d0 = c.scan_topk(metric, q, 20)
+            assert ids1.tolist() == ids0.tolist(), (vt, metric, qi)
+            assert dg.same_float_bits(d1, d0), (vt, metric, qi)
+            want = orc.scan_distances(orc.AVX2, metric, vt, q, rows[ids1 - 1])
+            assert dg.same_float_bits(d1.astype(np.float32), want), (vt, metric, qi)
+    c.set_scan_filter(1)
+    c.filter_exact_evals()
+    c.scan_topk(dg.COSINE, rows[100].copy(), 20)
+    assert 0 < c.filter_exact_evals() < n // 4
+    c.close()

@@ -32,7 +32,8 @@ def main():
     for data in ("clustered unit-norm (1000 centres, noise 0.3)", "near-duplicates (20000 distinct rows + 1e-3 noise)", "gaussian N(0,1)"):
         if data.split()[0].split("-")[0] not in args.data.split(","):
             continue
-        for tname, vt, tdt in (("f32", pkg.F32, torch.float32), ("f16", pkg.F16, torch.float16), ("bf16", pkg.BF16, torch.bfloat16)):
+        for tname, vt, tdt in (("f32", pkg.F32, torch.float32), ("f16", pkg.F16, torch.float16), ("bf16", pkg.BF16, torch.bfloat16),
+                               ("u8", pkg.U8, torch.uint8), ("i8", pkg.I8, torch.int8)):
             if tname not in args.types.split(","):
                 continue
             gen = torch.Generator(device="cuda")
@@ -52,15 +53,21 @@ def main():
                 else:
                     x = cent[idx] + noise / (dim ** 0.5) * torch.randn((nr, dim), generator=gen, device="cuda")
                     x /= x.norm(dim=1, keepdim=True)
+                if vt in (pkg.U8, pkg.I8):      # quantized like vector_quantize would: one scale for the table (+- 4.5 sigma of an element)
+                    sig = 1.0 if data.startswith("gaussian") else 1.0 / dim ** 0.5
+                    if vt == pkg.U8:
+                        x = torch.clamp(torch.round((x + 4.5 * sig) * (255.0 / (9.0 * sig))), 0, 255)
+                    else:
+                        x = torch.clamp(torch.round(x * (127.0 / (4.5 * sig))), -128, 127)
                 t = x.to(tdt).contiguous()
                 torch.cuda.synchronize()
                 c.append_device(t.data_ptr(), nr, dim * es)
                 if keep is None:
                     keep = t[:64].clone()
                 del t, x
-            qs = keep.view(torch.uint8).cpu().numpy().view({4: np.float32, 2: np.uint16}[es]).reshape(64, dim)
+            qs = keep.view(torch.uint8).cpu().numpy().view({4: np.float32, 2: np.uint16, 1: np.uint8}[es]).reshape(64, dim)
             line = "%-52s %-4s %dx%d%s:" % (data, tname, n, dim, " [shadow " + shadow + "]")
-            for m in (1, 3, 4) + ((5,) if vt != pkg.F32 else ()):
+            for m in (1, 3, 4) + ((5,) if vt in (pkg.F16, pkg.BF16) else ()):
                 res = {}
                 for mode in (1, 0):
                     c.set_scan_filter(mode)
