@@ -294,12 +294,12 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     {   // Selectivity guard.  The bound cannot separate rows that are (nearly) identical to each other: on such data every row
         // is a candidate and the exact evaluations - serial per wavefront - cost more than the plain scan.  The kernels count
         // them, a copy behind every launch mirrors the counter into pinned host memory; when the completed launches since the
-        // last look averaged more than 1/32 of the rows, the next 256 scans of this corpus take the plain kernel, then the
+        // last look averaged more than 1/16 of the rows (an exact evaluation is cheap since up to 64 / xlpr of them run at once: ~0.2 ns each chip-wide), the next 256 scans of this corpus take the plain kernel, then the
         // filter is tried again.
         const unsigned long long now = *(volatile unsigned long long *)c->h_filter_evals;
         const long long launches = c->filter_launches - c->filter_launches_seen;
         if (launches >= 2) {
-            if ((now - c->filter_evals_seen) / (unsigned long long)launches > (unsigned long long)(c->n_rows / 32) && !env_int("VG_SCAN_FILTER_NO_GUARD", 0))
+            if ((now - c->filter_evals_seen) / (unsigned long long)launches > (unsigned long long)(c->n_rows / 16) && !env_int("VG_SCAN_FILTER_NO_GUARD", 0))
                 c->filter_cooldown = 256;
             c->filter_evals_seen = now;
             c->filter_launches_seen = c->filter_launches;

@@ -292,8 +292,8 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
         const float t = (thr == VG_EMPTY_KEY) ? INFINITY : vg_sortable_f32((uint32_t)(thr >> 32));
         thr_gate = fminf(gate_of(t), gate_init);
     };
-    // the exact distance of one row (wave-uniform): the single-query kernel's arithmetic IN ITS ORDER, so the distance is bit
-    // for bit what vg_scan_kernel computes for the row (every lane group of the wavefront computes the same value).
+    // the exact distance of one row PER LANE GROUP (row_u is uniform within the 2^xlpr_log2 lanes of a group): the single-query
+    // kernel's arithmetic IN ITS ORDER, so the distance is bit for bit what vg_scan_kernel computes for the row.
     // (Inlined on purpose: as a real function its registers are added to the kernel's and the streaming loop spills.)
     auto exact_with = [&](auto acc, uint32_t row_u) -> float {
         typedef decltype(acc) A;
@@ -311,13 +311,13 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
             if constexpr (MODE == VGF_COS) d = acc.finish_cached_norm(st, a.xlpr_log2, a.row_norm[row_u]);
             else d = acc.finish(st, a.xlpr_log2, a.root);
             // rows (or a query) holding Inf / NaN: one lane replays the reference algorithm exactly (vg_half.h)
-            if (acc.special(st, a.xlpr_log2) && lane == 0) {
+            if (acc.special(st, a.xlpr_log2) && xs == 0) {               // (the group's first lane: the one the caller reads)
                 const uint16_t *q16 = reinterpret_cast<const uint16_t *>(qs), *r16 = reinterpret_cast<const uint16_t *>(rp);
                 constexpr int SLOW = L1M ? A_L1 : (MODE == VGF_L2 ? A_L2 : (MODE == VGF_DOT ? A_DOT : A_COS));
                 d = vg_slow_distance<XT, SLOW>(q16, r16, a.dim, a.root);
             }
         }
-        return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vg_clamp(d))));
+        return vg_clamp(d);
     };
     auto exact = [&](uint32_t row_u) -> float {
         constexpr int XACC = L1M ? A_L1 : (MODE == VGF_L2 ? A_L2 : (MODE == VGF_DOT ? A_DOT : (XF32 ? A_COS : A_COSN)));
@@ -377,15 +377,28 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
         const bool cand = (sub == 0) && (row < a.n_rows) && (!judged || lb < thr_gate);
         unsigned long long m = __ballot(cand);
         while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const uint32_t row_u = (uint32_t)__builtin_amdgcn_readlane((int)row, src);
-            const float de = exact(row_u);
-            ++n_exact;
-            const uint64_t key = vg_make_key(de, row_u);
-            if (de < INFINITY && key < thr) {                             // NaN / +Inf never enter (sqlite-vector.c:2102)
-                vg_list_insert(mine, thr, key, lane, k);
-                refresh_gate();
+            // Up to 64 / xlpr candidates at once: the exact evaluation runs in the plain kernel's shape - xlpr lanes per row - so
+            // the wavefront's other lane groups, which used to compute the SAME row redundantly, each take a candidate of their
+            // own (group g the g-th).  A dependent row fetch per candidate was what made unselective data expensive.
+            const int ngrp = VG_WAVE >> a.xlpr_log2, gid = lane >> a.xlpr_log2;
+            int mysrc = __ffsll((long long)m) - 1, ntake = 0;
+            for (; ntake < ngrp && m; ++ntake) {
+                const int s1 = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (gid == ntake) mysrc = s1;
+            }
+            const uint32_t row_g = (uint32_t)__shfl((int)(uint32_t)row, mysrc);
+            const float d_g = exact(row_g);
+            for (int i = 0; i < ntake; ++i) {
+                const int leader = i << a.xlpr_log2;
+                const float de = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d_g), leader));
+                const uint32_t row_u = (uint32_t)__builtin_amdgcn_readlane((int)row_g, leader);
+                ++n_exact;
+                const uint64_t key = vg_make_key(de, row_u);
+                if (de < INFINITY && key < thr) {    // NaN / +Inf never enter (sqlite-vector.c:2102)
+                    vg_list_insert(mine, thr, key, lane, k);
+                    refresh_gate();
+                }
             }
         }
 #pragma unroll

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_n4_kernel(FilterScanA
         const float t = (thr == VG_EMPTY_KEY) ? INFINITY : vg_sortable_f32((uint32_t)(thr >> 32));
         thr_gate = fminf(gate_of(t), gate_init);
     };
-    // the exact distance of one row (wave-uniform): the plain kernel's integer accumulator and float epilogue
+    // the exact distance of one row per lane group (row_u uniform within a group): the plain kernel's integer accumulator and float epilogue
     auto exact = [&](uint32_t row_u) -> float {
         constexpr int XACC = (MODE == VGF_L2) ? A_L2 : (MODE == VGF_DOT ? A_DOT : A_COS);
         const uint4 *xp = reinterpret_cast<const uint4 *>(a.rows + (unsigned long long)row_u * (unsigned long long)a.stride);
@@ -96,8 +96,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_n4_kernel(FilterScanA
         for (int u = 0; u < a.xU; ++u) { const int c = xs + u * xlpr; if (c < a.nch) acc.chunk(qs[c], xp[c]); }
         typename Accum<XT, XACC>::QStat st;
         st.qq = q2;
-        const float d = acc.finish(st, a.xlpr_log2, a.root);
-        return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vg_clamp(d))));
+        return vg_clamp(acc.finish(st, a.xlpr_log2, a.root));
     };
 
     const VgN4Stat *stats = reinterpret_cast<const VgN4Stat *>(a.q8stat);
@@ -144,15 +143,28 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_n4_kernel(FilterScanA
         const bool cand = (sub == 0) && (row < a.n_rows) && (!judged || lb < thr_gate);
         unsigned long long m = __ballot(cand);
         while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const uint32_t row_u = (uint32_t)__builtin_amdgcn_readlane((int)row, src);
-            const float de = exact(row_u);
-            ++n_exact;
-            const uint64_t key = vg_make_key(de, row_u);
-            if (de < INFINITY && key < thr) {
-                vg_list_insert(mine, thr, key, lane, k);
-                refresh_gate();
+            // Up to 64 / xlpr candidates at once: the exact evaluation runs in the plain kernel's shape - xlpr lanes per row - so
+            // the wavefront's other lane groups, which used to compute the SAME row redundantly, each take a candidate of their
+            // own (group g the g-th).  A dependent row fetch per candidate was what made unselective data expensive.
+            const int ngrp = VG_WAVE >> a.xlpr_log2, gid = lane >> a.xlpr_log2;
+            int mysrc = __ffsll((long long)m) - 1, ntake = 0;
+            for (; ntake < ngrp && m; ++ntake) {
+                const int s1 = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (gid == ntake) mysrc = s1;
+            }
+            const uint32_t row_g = (uint32_t)__shfl((int)(uint32_t)row, mysrc);
+            const float d_g = exact(row_g);
+            for (int i = 0; i < ntake; ++i) {
+                const int leader = i << a.xlpr_log2;
+                const float de = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d_g), leader));
+                const uint32_t row_u = (uint32_t)__builtin_amdgcn_readlane((int)row_g, leader);
+                ++n_exact;
+                const uint64_t key = vg_make_key(de, row_u);
+                if (de < INFINITY && key < thr) {    // NaN / +Inf never enter (sqlite-vector.c:2102)
+                    vg_list_insert(mine, thr, key, lane, k);
+                    refresh_gate();
+                }
             }
         }
 #pragma unroll
