@@ -102,7 +102,9 @@ int vg_corpus_append_device(vg_corpus *c, const void *dev_rows, int64_t n_rows, 
  * themselves (the bound replaces the reference's f64 chain for non-candidates).  VG_SCAN_FILTER_SHADOW=bf16: f32 corpora
  * (>= 3 GB) through a bf16 shadow copy (+ 50 %), f16 / bf16 (>= 1 GB) through their own rows.  vg_corpus_set_scan_filter(c, 0)
  * / VG_SCAN_FILTER=0 turn it off; a corpus whose shadow copy does not fit device memory, or whose rows the bound cannot tell
- * apart (it evaluates more than 1/16 of them), keeps the plain scan by itself. */
+ * apart (it evaluates more than 1/8 of them), keeps the plain scan by itself.  uint8 / int8 corpora (2^20 rows, 768 MB): a
+ * high-nibble shadow copy (+ 52 %, half the bytes), used only if a probe over a 2M-row prefix finds the data selective under it
+ * (vg_corpus_set_scan_filter(c, 1): without the probe). */
 int vg_scan_topk(vg_corpus *c, int metric, const void *query, int k,
                  int64_t *out_rowids, double *out_dist, int *out_count);
 

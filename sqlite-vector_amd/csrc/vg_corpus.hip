@@ -149,6 +149,7 @@ extern "C" int vg_corpus_clear(vg_corpus *c) {
     c->bf_rows = 0;
     c->q8_rows = 0;
     c->n4_rows = 0;
+    c->n4_probe = 0;
     c->rowids.clear();
     c->rowids_ascending = true;
     return VG_OK;

@@ -41,17 +41,23 @@ int vg_ensure_filter_counters(vg_corpus *c) {
 static bool filter_uses_q8(const vg_corpus *c, int metric);
 // uint8 / int8 corpora: the nibble filter (vg_scan_filter_n4.h) - half the bytes.  Its bound assumes sums below 2^31 (the plain
 // kernel's arithmetic is modular like the reference's): rows of at most 16384 elements.  Sizes (D = 768, measured): see below.
+static bool n4_explicit(const vg_corpus *c) { return c->scan_filter_mode == 1 || env_int("VG_SCAN_FILTER_N4", -1) == 1; }
 static bool scan_filter_serves_n4(const vg_corpus *c, int metric) {
     if (c->vtype != VG_TYPE_U8 && c->vtype != VG_TYPE_I8) return false;
     if (metric != VG_DIST_L2 && metric != VG_DIST_SQUARED_L2 && metric != VG_DIST_DOT && metric != VG_DIST_COSINE) return false;
     if (c->dim > 16384 || c->n4_disabled || !scan_filter_enabled(c)) return false;
-    // OPT-IN (vg_corpus_set_scan_filter(c, 1) / the extension's scan_filter=1, or VG_SCAN_FILTER_N4=1): a 4-bit residual is coarse,
-    // and by Cauchy-Schwarz its bound is sqrt(D) looser than its typical size.  Measured at 10M x 768 (profiles/r3d): bytes
-    // quantized from clustered unit-norm embeddings - the neighbours are much closer than a random pair - 0.61 ms against 1.13
-    // (10k exact rows per query); independent random bytes (the synthetic C3 corpus) - distances concentrate, the slack is
-    // ~3 standard deviations of them - every 20th row is a candidate and the guard sends the scans back to the plain kernel.
-    // Paying + 52 % device memory for that has to be the user's call.
-    if (c->scan_filter_mode != 1 && !env_int("VG_SCAN_FILTER_N4", 0)) return false;
+    // A 4-bit residual is coarse, and by Cauchy-Schwarz its bound is sqrt(D) looser than its typical size.  Measured at
+    // 10M x 768 (profiles/r3d): bytes quantized from clustered unit-norm embeddings - the neighbours are much closer than a
+    // random pair - 0.61 ms against 1.13 (10k exact rows per query); independent random bytes (the synthetic C3 corpus) -
+    // distances concentrate, the slack is ~3 standard deviations of them - most rows are candidates.  So the corpus is PROBED
+    // before + 52 % device memory is spent on it (n4_probe, see vg_launch_scan_filter): the first eligible scan runs the filter
+    // over a 2M-row prefix only and counts; a selective prefix switches the filter on, an unselective one leaves the corpus
+    // with the plain kernel (probed again once it has doubled).  vg_corpus_set_scan_filter(c, 1) / the extension's
+    // scan_filter=1 / VG_SCAN_FILTER_N4=1 switch it on without a probe (the guard still watches), VG_SCAN_FILTER_N4=0 off.
+    if (!n4_explicit(c)) {
+        if (env_int("VG_SCAN_FILTER_N4", -1) == 0) return false;
+        if (c->n4_probe == 2 && c->n_rows < 2 * c->n4_probe_rows) return false;
+    }
     if (env_int("VG_SCAN_FILTER_MIN_MB", -1) >= 0) return c->n_rows * c->stride >= (long long)env_int("VG_SCAN_FILTER_MIN_MB", 0) * (1ll << 20);
     return c->n_rows >= (1 << 20) && c->n_rows * c->stride >= (768ll << 20);
 }
@@ -182,10 +188,12 @@ static filter_fn_t pick_n4(int vtype, int mode, int U) {
     return mode == VGF_L2 ? pick_n4_u<T_I8, VGF_L2, NT>(U) : (mode == VGF_DOT ? pick_n4_u<T_I8, VGF_DOT, NT>(U) : pick_n4_u<T_I8, VGF_COS, NT>(U));
 }
 static long long n4_shadow_stride(const vg_corpus *c) { return (((long long)c->dim + 31) / 32) * 16; }
-int vg_ensure_n4_shadow(vg_corpus *c) {
+int vg_ensure_n4_shadow(vg_corpus *c, int64_t upto_rows) {
     const long long ns = n4_shadow_stride(c);
-    if (c->n4_cap < c->n_rows) {
-        const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
+    upto_rows = std::min<int64_t>(upto_rows, c->n_rows);
+    if (c->n4_cap < upto_rows) {
+        // (a probe asks for a prefix only: it gets a prefix-sized allocation, not the corpus' + 52 %)
+        const int64_t cap = (upto_rows < c->n_rows) ? upto_rows : std::max<int64_t>(c->cap_rows, c->n_rows);
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_rows_n4) hipFree(c->d_rows_n4);
         if (c->d_n4stat) hipFree(c->d_n4stat);
@@ -194,15 +202,16 @@ int vg_ensure_n4_shadow(vg_corpus *c) {
         HIP_TRY(hipMalloc(&c->d_n4stat, (size_t)cap * sizeof(VgN4Stat)));
         c->n4_cap = cap;
     }
-    if (c->n4_rows < c->n_rows) {
-        const long long n = c->n_rows - c->n4_rows;
+    upto_rows = std::min<int64_t>(upto_rows, c->n_rows);
+    if (c->n4_rows < upto_rows) {
+        const long long n = upto_rows - c->n4_rows;
         const long long blocks = std::min<long long>((n * 16 + 255) / 256, 256 * 32);
         auto kern = c->vtype == VG_TYPE_U8 ? vg_to_n4_kernel<T_U8> : vg_to_n4_kernel<T_I8>;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_rows, (long long)c->n4_rows, n,
                            (long long)c->stride, c->dim, c->d_rows_n4, ns, reinterpret_cast<VgN4Stat *>(c->d_n4stat));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return vg_fail(VG_ERR_HIP, "nibble shadow pass failed: %s", hipGetErrorString(e));
-        c->n4_rows = c->n_rows;
+        c->n4_rows = upto_rows;
     }
     return VG_OK;
 }
@@ -262,10 +271,14 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     // keeps the plain f32 scan (which served it before the filter existed) instead of failing every query; an f16 / bf16
     // corpus falls back to filtering over its own rows.
     const bool n4 = (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8);
+    // uint8 / int8, not switched on explicitly: this scan PROBES (filter over a prefix, count the candidates, decide, then answer
+    // through whichever kernel the decision names - see scan_filter_serves_n4)
+    const bool probing = n4 && !n4_explicit(c) && c->n4_probe != 1;
+    const int64_t scan_rows = probing ? std::min<int64_t>(c->n_rows, 1ll << 21) : c->n_rows;
     int rc = n4 ? VG_OK : vg_ensure_row_norms(c);
     bool q8 = filter_uses_q8(c, metric);
     if (n4) {
-        rc = vg_ensure_n4_shadow(c);
+        rc = vg_ensure_n4_shadow(c, scan_rows);
         if (rc == VG_ERR_NOMEM) { (void)hipGetLastError(); c->n4_disabled = true; return -1; }
     } else if (rc == VG_OK && q8) {
         rc = vg_ensure_q8_shadow(c);
@@ -294,37 +307,43 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     {   // Selectivity guard.  The bound cannot separate rows that are (nearly) identical to each other: on such data every row
         // is a candidate and the exact evaluations - serial per wavefront - cost more than the plain scan.  The kernels count
         // them, a copy behind every launch mirrors the counter into pinned host memory; when the completed launches since the
-        // last look averaged more than 1/16 of the rows (an exact evaluation is cheap since up to 64 / xlpr of them run at once: ~0.2 ns each chip-wide), the next 256 scans of this corpus take the plain kernel, then the
+        // last look averaged more than 1/8 of the rows (an exact evaluation is cheap since up to 64 / xlpr of them run at once -
+        // ~0.2 ns each chip-wide - and the filter pass itself takes a quarter to a half of the plain scan's time), the next 256 scans of this corpus take the plain kernel, then the
         // filter is tried again.
         const unsigned long long now = *(volatile unsigned long long *)c->h_filter_evals;
         const long long launches = c->filter_launches - c->filter_launches_seen;
         if (launches >= 2) {
-            if ((now - c->filter_evals_seen) / (unsigned long long)launches > (unsigned long long)(c->n_rows / 16) && !env_int("VG_SCAN_FILTER_NO_GUARD", 0))
+            if ((now - c->filter_evals_seen) / (unsigned long long)launches > (unsigned long long)(c->n_rows / 8) && !env_int("VG_SCAN_FILTER_NO_GUARD", 0))
                 c->filter_cooldown = 256;
             c->filter_evals_seen = now;
             c->filter_launches_seen = c->filter_launches;
         }
-        if (c->filter_cooldown > 0) { --c->filter_cooldown; return -1; }
+        if (c->filter_cooldown > 0 && !probing) { --c->filter_cooldown; return -1; }
+    }
+    unsigned long long evals_before = 0;
+    if (probing) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(&evals_before, c->d_filter_evals, sizeof(evals_before), hipMemcpyDeviceToHost));
     }
     if (stream != c->stream) {                           // both passes (and the memset) ran on the corpus stream
         if (!c->norm_ev) HIP_TRY(hipEventCreateWithFlags(&c->norm_ev, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(c->norm_ev, c->stream));
         HIP_TRY(hipStreamWaitEvent(stream, c->norm_ev, 0));
     }
-    const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (c->n_rows * bs > (256ll << 20));
+    const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (scan_rows * bs > (256ll << 20));
     const int mode = filter_mode_of(metric);
     filter_fn_t fn = n4 ? (nt ? pick_n4<true>(c->vtype, mode, s.U) : pick_n4<false>(c->vtype, mode, s.U))
                         : (nt ? pick_filter<true>(c->vtype, mode, s.U, q8) : pick_filter<false>(c->vtype, mode, s.U, q8));
     if (!fn) return -1;
     const int rpb = VG_WAVE >> s.lpr_log2;
-    const long long nbatch = (c->n_rows + rpb - 1) / rpb;
+    const long long nbatch = (scan_rows + rpb - 1) / rpb;
     long long blocks = (nbatch + VG_WAVES_PER_BLOCK - 1) / VG_WAVES_PER_BLOCK;
     blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count));
     blocks = std::min<long long>(blocks, VG_SEL_MAX_HEADS);
     FilterScanArgs a;
     a.shadow = n4 ? c->d_rows_n4 : (q8 ? c->d_rows_q8 : (f32 ? c->d_rows_bf : c->d_rows));
     a.q8stat = reinterpret_cast<const float2 *>(n4 ? c->d_n4stat : c->d_q8stat); a.rows = c->d_rows; a.query = dev_query; a.row_norm = c->d_xnorm; a.cand = c->d_cand;
-    a.n_rows = c->n_rows; a.stride = c->stride; a.bstride = bs; a.nch = c->nch; a.nch_b = nch_b;
+    a.n_rows = scan_rows; a.stride = c->stride; a.bstride = bs; a.nch = c->nch; a.nch_b = nch_b;
     a.lpr_log2 = s.lpr_log2; a.k = k; a.root = (metric == VG_DIST_L2) ? 1 : 0; a.dim = c->dim;
     a.mode = mode;
     // |s~ - s| <= cerr |q||x| (vg_scan_filter.h): (D + 64) 2^-21 for the f32 sums; an f32 corpus is read through its bf16
@@ -342,14 +361,14 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     // Pre-pass: a plain scan of the first 1/64 of the rows.  Its k-th best distance bounds the final k-th best from
     // above, so no wavefront has to warm its list up from +Inf (k ln(rows per wavefront / k) exact evaluations each,
     // ~0.35 ms in all); the filter scan below still covers every row.
-    const bool prepass = env_int("VG_SCAN_FILTER_PREPASS", 1) != 0 && c->n_rows >= (1 << 20);
-    hipEvent_t *evs = vg_prof_slot(c, (uint8_t)(VG_EVF_MERGE | (prepass ? VG_EVF_PREPASS : 0)));
+    const bool prepass = env_int("VG_SCAN_FILTER_PREPASS", 1) != 0 && scan_rows >= (1 << 20);
+    hipEvent_t *evs = probing ? nullptr : vg_prof_slot(c, (uint8_t)(VG_EVF_MERGE | (prepass ? VG_EVF_PREPASS : 0)));
     if (evs) hipEventRecord(evs[0], stream);
     a.init_keys = nullptr;
     if (prepass) {
         ScanPlan pre;
         // (1/128 of the rows: 38 us instead of 60 at 10M x 384 for ~2x the exact evaluations of the 0.6 ms pass - measured, profiles/r2y)
-        pre.n_rows = std::max<int64_t>(65536, c->n_rows / std::max(1, env_int("VG_SCAN_FILTER_PREPASS_DIV", 128)));
+        pre.n_rows = std::max<int64_t>(65536, scan_rows / std::max(1, env_int("VG_SCAN_FILTER_PREPASS_DIV", 128)));
         pre.allow_filter = false;
         pre.record = false;
         const int rcp = vg_launch_plain_scan(c, metric, dev_query, k, dev_out_keys, stream, pre);
@@ -366,6 +385,23 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     HIP_TRY(hipMemcpyAsync(c->h_filter_evals, c->d_filter_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     if (rcm != 0) return vg_fail(VG_ERR_HIP, "merge launch failed: %s", hipGetErrorString((hipError_t)rcm));
     HIP_TRY(hipGetLastError());
+    if (probing) {
+        // the probe's own answer (the prefix' top k) is discarded: count what it evaluated exactly and decide.  1 candidate per
+        // 8 prefix rows - the guard's own limit - is inside the filter's break-even (~1 in 5 at 0.2 ns per evaluation).
+        HIP_TRY(hipStreamSynchronize(stream));
+        unsigned long long evals_after = 0;
+        HIP_TRY(hipMemcpy(&evals_after, c->d_filter_evals, sizeof(evals_after), hipMemcpyDeviceToHost));
+        const bool selective = (evals_after - evals_before) * 8ull < (unsigned long long)scan_rows;
+        c->n4_probe = selective ? 1 : 2;
+        c->n4_probe_rows = c->n_rows;
+        c->filter_evals_seen = evals_after;              // (the guard's averages start after the probe)
+        c->filter_launches_seen = c->filter_launches;
+        if (!selective) {                                // nothing is kept of an unselective corpus' prefix copy
+            hipFree(c->d_rows_n4); hipFree(c->d_n4stat);
+            c->d_rows_n4 = nullptr; c->d_n4stat = nullptr; c->n4_rows = 0; c->n4_cap = 0;
+        }
+        return vg_launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream);   // 1: the filter over every row; 2: -1 (plain scan)
+    }
     return VG_OK;
 }
 

@@ -103,6 +103,8 @@ struct vg_corpus {
     void *d_n4stat = nullptr;                     // ... and per row (sum x^2, sum of low nibbles, their centred norm), 16 bytes
     int64_t n4_rows = 0, n4_cap = 0;
     bool n4_disabled = false;
+    int n4_probe = 0;                             // 0 = not probed yet, 1 = selective on this data (filter on), 2 = not selective (plain kernel)
+    int64_t n4_probe_rows = 0;                    // n_rows at that probe (an unselective corpus is probed again once it has doubled)
     bool q8_disabled = false;                     // (it did not fit next to an f16 / bf16 corpus: the filter scans read the rows themselves)
     bool filter_disabled = false;                 // the shadow copy / norms did not fit HBM: single queries keep the plain f32 scan
     int scan_filter_mode = -1;                    // vg_corpus_set_scan_filter: -1 = default (env VG_SCAN_FILTER, else on), 0 = off, 1 = on

@@ -511,3 +511,41 @@ def test_nibble_filter_with_its_prepass_on_clustered_bytes(pkg, orc, vt, dim, mo
     c.scan_topk(dg.COSINE, rows[100].copy(), 20)
     assert 0 < c.filter_exact_evals() < n // 4
     c.close()
+
+
+def test_nibble_filter_probes_the_corpus_before_it_spends_memory_on_it(pkg, orc, monkeypatch):
+    """default mode (no explicit scan_filter=1): the first eligible scan of a uint8 corpus runs the nibble filter over a prefix
+    and counts the candidates.  Bytes quantized from clustered embeddings are selective -> the filter serves the following scans;
+    independent random bytes are not -> the corpus keeps the plain kernel and no shadow copy.  Answers equal the plain scan's
+    throughout (the probing scan included)."""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    monkeypatch.delenv("VG_SCAN_FILTER_N4", raising=False)
+    n, dim = (1 << 20) + 333, 64
+    rng = np.random.default_rng(7300)
+    centres = rng.standard_normal((400, dim)).astype(np.float32)       # (a cluster's rows are all candidates of a query inside it: 0.25 % each)
+    x = centres[rng.integers(0, 400, n)] + np.float32(0.05) * rng.standard_normal((n, dim), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True).astype(np.float32)
+    clustered = np.clip(np.rint((x - x.min()) * (255.0 / (x.max() - x.min()))), 0, 255).astype(np.uint8)
+    # independent bytes quantized from N(0,1) values (+- 4.5 sigma over 0 .. 255) at 768 elements: the distances concentrate, the
+    # slack is ~3 of their standard deviations and most rows are candidates (profiles/r3d, r3f); uniform bytes or short rows do
+    # not concentrate that much and pass the probe
+    random_bytes = np.clip(np.rint(rng.standard_normal((n, 768), dtype=np.float32) * np.float32(28.3) + np.float32(127.5)), 0, 255).astype(np.uint8)
+    for name, rows, want_filter in (("clustered", clustered, True), ("random", random_bytes, False)):
+        dim = rows.shape[1]
+        c = pkg.Corpus(pkg.U8, dim)
+        c.append(rows)
+        qs = [rows[n - 77].copy(), rows[5].copy(), rows[400000].copy(), rows[9].copy()]
+        c.set_scan_filter(0)
+        plain = [c.scan_topk(dg.L2, q, 20) for q in qs]
+        c.set_scan_filter(-1)                                      # default: probe, then decide
+        c.filter_exact_evals()
+        got = [c.scan_topk(dg.L2, q, 20) for q in qs]
+        for (a_ids, a_d), (b_ids, b_d) in zip(got, plain):
+            assert a_ids.tolist() == b_ids.tolist() and dg.same_float_bits(a_d, b_d), name
+        probe_and_first = c.filter_exact_evals()
+        assert probe_and_first > 0, name                           # the probe evaluated something either way
+        c.scan_topk(dg.L2, qs[1], 20)
+        later = c.filter_exact_evals()
+        assert (later > 0) == want_filter, (name, later)
+        assert c.kernel_name(dg.L2).startswith("scan_filter_u8") == want_filter, (name, c.kernel_name(dg.L2))
+        c.close()
