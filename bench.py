@@ -589,6 +589,28 @@ def main():
                 c3.set_tie_order(pkg.TIE_POSITION)
                 tie["what"] = "vg_scan_topk end to end, top-%d; reference = store-mode scan + device compaction of the rows below the bound + host slot replay" % k
                 line["tie_order"] = tie
+                if "filter" in also_set:
+                    # what the product does with this corpus by default: the high-nibble filter is PROBED (a 2M-row prefix) and kept
+                    # only if the data is selective under it - independent random bytes are not
+                    try:
+                        c3.set_scan_filter(-1)
+                        c3.filter_exact_evals()
+                        c3.scan_topk(m3, q3[0], k)                   # the probing scan
+                        probe_evals = c3.filter_exact_evals()
+                        for i in range(3):
+                            c3.scan_topk(m3, q3[1 + i], k)
+                        line["nibble_filter_probe"] = {
+                            "candidates_in_the_probed_prefix": probe_evals, "prefix_rows": min(n_rows, 1 << 21),
+                            "kernel_after_the_probe": c3.kernel_name(m3),
+                            "filter_in_use": bool(c3.kernel_name(m3).startswith("scan_filter")),
+                        }
+                        if line["nibble_filter_probe"]["filter_in_use"]:
+                            c3.set_scan_filter(0)
+                            r3.run(args.warmup, args.steps)           # (the plain answers of the same query sequence)
+                            plain3 = dict(r3.last)
+                            line["filter_scan"] = filter_scan_object(args, pkg, c3, r3, m3, v3, d3, n_rows, plain3)
+                    except Exception as e:
+                        line["nibble_filter_probe"] = {"error": repr(e)}
                 also["c3"] = line
                 c3.close()
             except Exception as e:

@@ -315,6 +315,12 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
         if (launches >= 2) {
             if ((now - c->filter_evals_seen) / (unsigned long long)launches > (unsigned long long)(c->n_rows / 8) && !env_int("VG_SCAN_FILTER_NO_GUARD", 0))
                 c->filter_cooldown = 256;
+            // the pre-pass' share of the rows follows the same average: many candidates (a loose bound on this data) are worth a
+            // tighter start threshold - a longer pre-pass; few are not (measured, profiles/r3m: nibble filter on the C3 bytes,
+            // 295k candidates per query at 1/128, 0.90 ms -> 83k at 1/16, 0.80 ms; int8 filter on C2, 6k candidates: 1/128 best)
+            const unsigned long long avg = (now - c->filter_evals_seen) / (unsigned long long)launches;
+            if (avg > (unsigned long long)(c->n_rows / 128)) c->filter_prepass_div = std::max(16, c->filter_prepass_div / 2);
+            else if (avg < (unsigned long long)(c->n_rows / 1024)) c->filter_prepass_div = std::min(128, c->filter_prepass_div * 2);
             c->filter_evals_seen = now;
             c->filter_launches_seen = c->filter_launches;
         }
@@ -368,7 +374,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     if (prepass) {
         ScanPlan pre;
         // (1/128 of the rows: 38 us instead of 60 at 10M x 384 for ~2x the exact evaluations of the 0.6 ms pass - measured, profiles/r2y)
-        pre.n_rows = std::max<int64_t>(65536, scan_rows / std::max(1, env_int("VG_SCAN_FILTER_PREPASS_DIV", 128)));
+        pre.n_rows = std::max<int64_t>(65536, scan_rows / std::max(1, env_int("VG_SCAN_FILTER_PREPASS_DIV", c->filter_prepass_div)));
         pre.allow_filter = false;
         pre.record = false;
         const int rcp = vg_launch_plain_scan(c, metric, dev_query, k, dev_out_keys, stream, pre);

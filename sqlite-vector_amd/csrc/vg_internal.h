@@ -116,6 +116,7 @@ struct vg_corpus {
     unsigned long long filter_evals_seen = 0;     // ... and when the selectivity guard last looked
     long long filter_launches_seen = 0, filter_launches = 0;
     int filter_cooldown = 0;                      // > 0: the bound is not selective on this data - that many scans take the plain kernel
+    int filter_prepass_div = 128;                 // the filter scan's pre-pass covers 1 / this of the rows (16 .. 128, follows the candidate rate)
     // f32 batches through the bf16 filter (vg_batch_api.hip): counter [1] of d_filter_evals, the same kind of guard
     unsigned long long bfilter_evals_seen = 0, bfilter_evals_read = 0;
     long long bfilter_pairs = 0;                  // (query, row) pairs of the filtered batches since the guard last looked
