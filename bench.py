@@ -4,20 +4,23 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b|c5h|c5f] [--no-also]
 
 Default line (BASELINE.json configs[1]): 10M x 384 f32, L2, top-20, single query, corpus resident in HBM, answered by
-the PLAIN f32 scan kernel (vg_scan_kernel; the bf16 shadow-copy filter is switched off for this corpus), so that
+the PLAIN f32 scan kernel (vg_scan_kernel; the shadow-copy filter is switched off for this corpus), so that
 `roofline` is SURVEY 8(d)'s figure: algorithmic bytes N*D*4 = 15.36 GB per launch / the kernel's mean duration from HIP
 events recorded around it on its own stream inside the timed region, against the 8 TB/s HBM3E peak.
 A "step" is ONE complete query: upload the query, scan the whole shard, reduce to k candidates, bring the k keys back
 and decode them - what vector_full_scan's xFilter costs once the corpus is staged.
 
-The same run appends (N = 1, default workload only; --no-also skips them):
-  filter_scan  the SAME queries over the SAME corpus through the product's default path for corpora >= 3 GB: the bf16
-               shadow-copy filter + exact f32 re-evaluation (vg_scan_filter.h).  It answers the f32 question with the
-               f32 scan's rowids and distance bits but STREAMS bf16: its rate is priced on the bytes it streams
-               (dtype_streamed / frac_on_streamed) and is never reported under dtype f32 / roofline.frac.
-  also.c3      10M x 768 uint8 cosine top-20 (configs[2]): own roofline (7.68 GB per launch) and cpu_baseline
+The same run appends (N = 1, default workload only; --no-also skips them, --also filter,c3,c5 picks):
+  filter_scan  the SAME queries over the SAME corpus through the product's default path for a corpus of this size: the lower-bound
+               filter over an int8 shadow copy + exact f32 re-evaluation of the candidates (vg_scan_filter.h).  It answers the
+               f32 question with the f32 scan's rowids and distance bits but STREAMS int8: its rate is priced on the bytes it
+               streams (dtype_streamed / frac_on_streamed) and is never reported under dtype f32 / roofline.frac.
+  also.c3      10M x 768 uint8 cosine top-20 (configs[2]): own roofline (7.68 GB per launch, the PLAIN kernel) and cpu_baseline;
+               tie_order (what the reference's result order costs); nibble_filter_probe + filter_scan (what the product does by
+               default: the high-nibble filter, probed on a prefix, same answers, half the bytes)
   also.c5      1024 queries x 10M x 384 f32 dot top-20 (configs[4]): own roofline (7.864 TFLOP per launch against the
-               157.3 TF f32 MFMA peak) and cpu_baseline
+               157.3 TF f32 MFMA peak, the f32 matrix-core kernel) and cpu_baseline; filter_batch (the product's default for a
+               corpus of this size: bf16 matrix-core filter + exact f32 re-evaluation, priced on the bf16 peak)
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): configs[3] - the corpus row-sharded over the ranks,
 12.5M x 384 f32 rows per rank (8 ranks = the stated 100M rows; weak scaling: every rank count uses that shard size),
