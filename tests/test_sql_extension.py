@@ -225,6 +225,20 @@ def test_vector_full_scan_vs_reference_golden(ext_path, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", mg.SQL_SCAN_CASES + mg.SQL_QUANT_CASES, ids=["filtered-" + c[0] for c in mg.SQL_SCAN_CASES + mg.SQL_QUANT_CASES])
+def test_golden_cases_through_the_filter_scans(ext_path, case, monkeypatch):
+    """the same golden cases with the lower-bound filter scans forced on for tables of every size (by default they start at 2^20
+    rows): int8 shadow copy for f32 / f16 / bf16 tables, high nibbles for the quantized scans - answers unchanged"""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    monkeypatch.setenv("VG_SCAN_FILTER_N4", "1")
+    monkeypatch.setenv("VG_SCAN_FILTER_NO_GUARD", "1")
+    if case in mg.SQL_QUANT_CASES:
+        test_vector_quantize_scan_vs_reference_golden(ext_path, case)
+    else:
+        test_vector_full_scan_vs_reference_golden(ext_path, case)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", mg.SQL_QUANT_CASES, ids=[c[0] for c in mg.SQL_QUANT_CASES])
 def test_vector_quantize_scan_vs_reference_golden(ext_path, case):
     name, vt, qopt, n, dim, k, seed, nonneg = case
