@@ -412,6 +412,17 @@ static void track_reset(vec_context *vc, table_ctx *t) {
     t->hook_seen = (vc && vc->hook_installed && track_wanted(&t->opt)) ? vc->hook_events : -1;
 }
 
+/* room for `need` rows of row_bytes each (geometric growth); 0 on allocation failure */
+static int rows_grow(uint8_t **buf, int64_t *cap, int64_t need, int64_t row_bytes) {
+    if (need <= *cap) return 1;
+    int64_t ncap = *cap ? *cap * 2 : 64;
+    if (ncap < need) ncap = need;
+    uint8_t *nb = (uint8_t *)sqlite3_realloc64(*buf, (sqlite3_uint64)ncap * (sqlite3_uint64)row_bytes);
+    if (!nb) return 0;
+    *buf = nb; *cap = ncap;
+    return 1;
+}
+
 static int cmp_i64(const void *a, const void *b) {
     const int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
     return (x > y) - (x < y);
@@ -879,11 +890,11 @@ static int apply_tracked_changes(sqlite3 *db, table_ctx *t, char **err) {
     int64_t *ppos = (int64_t *)sqlite3_malloc64((sqlite3_uint64)n * sizeof(int64_t));
     int64_t *dpos = (int64_t *)sqlite3_malloc64((sqlite3_uint64)n * sizeof(int64_t));
     int64_t *aids = (int64_t *)sqlite3_malloc64((sqlite3_uint64)n * sizeof(int64_t));
-    uint8_t *pdata = (uint8_t *)sqlite3_malloc64((sqlite3_uint64)n * (sqlite3_uint64)row_bytes);
-    uint8_t *adata = (uint8_t *)sqlite3_malloc64((sqlite3_uint64)n * (sqlite3_uint64)row_bytes);
+    uint8_t *pdata = NULL, *adata = NULL;                       /* the touched rows' vectors: grown as they are met, not n rows up front */
+    int64_t pcap = 0, acap = 0;
     sqlite3_stmt *st = NULL;
     char *sql = sqlite3_mprintf("SELECT %q FROM %q WHERE %q = ?1;", t->c_name, t->t_name, t->pk_name);
-    if (!ppos || !dpos || !aids || !pdata || !adata || !sql || sqlite3_prepare_v2(db, sql, -1, &st, NULL) != SQLITE_OK) goto done;
+    if (!ppos || !dpos || !aids || !sql || sqlite3_prepare_v2(db, sql, -1, &st, NULL) != SQLITE_OK) goto done;
     {
         const int64_t rows0 = G.corpus_rows(t->full);
         int64_t last_id = rows0 > 0 ? G.corpus_rowid_at(t->full, rows0 - 1) : INT64_MIN;
@@ -899,10 +910,13 @@ static int apply_tracked_changes(sqlite3 *db, table_ctx *t, char **err) {
                 blob = sqlite3_column_blob(st, 0);
                 if (blob && sqlite3_column_bytes(st, 0) < row_bytes) goto done;      /* (the full pass reports the short BLOB) */
             } else if (rc != SQLITE_ROW && rc != SQLITE_DONE) goto done;
-            if (pos >= 0 && blob) { ppos[npatch] = pos; memcpy(pdata + (int64_t)npatch * row_bytes, blob, (size_t)row_bytes); ++npatch; }
-            else if (pos >= 0) { dpos[ndel++] = pos; }
+            if (pos >= 0 && blob) {
+                if (!rows_grow(&pdata, &pcap, npatch + 1, row_bytes)) goto done;
+                ppos[npatch] = pos; memcpy(pdata + (int64_t)npatch * row_bytes, blob, (size_t)row_bytes); ++npatch;
+            } else if (pos >= 0) { dpos[ndel++] = pos; }
             else if (blob) {
                 if (r <= last_id) goto done;                     /* a new row in the middle of the scan order */
+                if (!rows_grow(&adata, &acap, napp + 1, row_bytes)) goto done;
                 aids[napp] = r; memcpy(adata + (int64_t)napp * row_bytes, blob, (size_t)row_bytes); ++napp;
                 last_id = r;
             }
