@@ -581,7 +581,7 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
 // ---- host side
 // The kernel instantiations are split over three translation units compiled from this file (build.py): the real-pass
 // kernels for f16 here (with the host entry points), for bf16 with -DVGH_TU=1, for f32 corpora with -DVGH_TU=3, the
-// bound-pass kernels with -DVGH_TU=2
+// bound-pass kernels with -DVGH_TU=2 (f16), 4 (bf16), 5 (f32 corpora) - one unit for all three was the build's critical path
 // (-DVGH_TU_ALL: everything in this one unit - the measurement builds of tools/build_half_variants.sh).
 #ifndef VGH_TU
 #define VGH_TU 0
@@ -589,7 +589,9 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(B
 extern "C" int vgh_launch_real_f16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);
 extern "C" int vgh_launch_real_bf16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);
 extern "C" int vgh_launch_real_f32(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);   // -DVGH_TU=3
-extern "C" int vgh_launch_bound(const BatchArgsH *a, int type_code, int ntb, int blocks, size_t smem, hipStream_t stream);   // 0 f16, 1 bf16, 2 f32
+extern "C" int vgh_launch_bound_f16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);    // -DVGH_TU=2
+extern "C" int vgh_launch_bound_bf16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);   // -DVGH_TU=4
+extern "C" int vgh_launch_bound_f32(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);    // -DVGH_TU=5
 
 template <int VT, int NTB, int MODE, bool BOUND>
 static int launch_h(const BatchArgsH &a, int blocks, size_t smem, hipStream_t stream) {
@@ -621,9 +623,18 @@ extern "C" int vgh_launch_real_bf16(const BatchArgsH *a, int ntb, int blocks, si
 }
 #endif
 #if VGH_TU == 2 || defined(VGH_TU_ALL)
-extern "C" int vgh_launch_bound(const BatchArgsH *a, int type_code, int ntb, int blocks, size_t smem, hipStream_t stream) {
-    if (type_code == 2) return launch_h_ntb<T_F32, true>(*a, ntb, blocks, smem, stream);
-    return type_code == 1 ? launch_h_ntb<T_BF16, true>(*a, ntb, blocks, smem, stream) : launch_h_ntb<T_F16, true>(*a, ntb, blocks, smem, stream);
+extern "C" int vgh_launch_bound_f16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_F16, true>(*a, ntb, blocks, smem, stream);
+}
+#endif
+#if VGH_TU == 4 || defined(VGH_TU_ALL)
+extern "C" int vgh_launch_bound_bf16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_BF16, true>(*a, ntb, blocks, smem, stream);
+}
+#endif
+#if VGH_TU == 5 || defined(VGH_TU_ALL)
+extern "C" int vgh_launch_bound_f32(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_F32, true>(*a, ntb, blocks, smem, stream);
 }
 #endif
 #if VGH_TU == 3 || defined(VGH_TU_ALL)
@@ -734,7 +745,8 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
     const int blocks = G * ((npart + 7) / 8) * 8;
     const long long ntiles = (n_rows + VGH_TILE - 1) / VGH_TILE;
     auto launch = [&](const BatchArgsH &b, bool bound) -> int {
-        if (bound) return vgh_launch_bound(&b, type_code, ntb, blocks, smem, stream);
+        if (bound) return type_code == 2 ? vgh_launch_bound_f32(&b, ntb, blocks, smem, stream)
+                                         : (type_code == 1 ? vgh_launch_bound_bf16(&b, ntb, blocks, smem, stream) : vgh_launch_bound_f16(&b, ntb, blocks, smem, stream));
         if (type_code == 2) return vgh_launch_real_f32(&b, ntb, blocks, smem, stream);
         return type_code == 1 ? vgh_launch_real_bf16(&b, ntb, blocks, smem, stream) : vgh_launch_real_f16(&b, ntb, blocks, smem, stream);
     };
