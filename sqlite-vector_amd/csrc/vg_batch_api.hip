@@ -316,8 +316,11 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     if (k <= 0 || c->n_rows == 0) return VG_OK;
     if (!out_keys) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch_keys: NULL output");
     HIP_TRY(hipSetDevice(c->device));
-    if (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k) || batch_h_eligible(c, metric, k) ||
-        batch_f32_filter_eligible(c, metric, k)) {
+    // A handful of queries over a corpus the filter scans serve: single scans (0.7 ms each at 10M x 384, whatever the type) beat one
+    // 128- / 256-query-wide matrix pass (~2.9 ms however few of its query slots are used) up to three queries; they tie at four.
+    const bool few = nq <= env_int("VG_BATCH_MIN_QUERIES", 4) - 1 && vg_scan_filter_would_serve(c, metric, k);
+    if (!few && (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k) || batch_h_eligible(c, metric, k) ||
+                 batch_f32_filter_eligible(c, metric, k))) {
         // very large batches go through in slices: the per-(query, partition) candidate lists are nq x ~128 x 512 B
         const int slice = std::max(256, env_int("VG_BATCH_SLICE", 4096));
         int rc = VG_OK;
@@ -332,7 +335,7 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     }
     // shapes the matrix-core kernels do not serve (f16 / bf16, L1, k > 32, rows > 512 floats / 1 KiB): the multi-query
     // scan (vg_scan_multi_kernel: 4 - or 2 for f16 / bf16 - queries share every row load of the HBM-bound pass) ...
-    if (k <= 64 && nq >= 2 && env_int("VG_MULTI_SCAN", 1)) {
+    if (!few && k <= 64 && nq >= 2 && env_int("VG_MULTI_SCAN", 1)) {
         int rc = scan_topk_batch_multi(c, metric, queries, nq, k, out_keys, out_counts);
         if (rc != -1) return rc;
         for (int i = 0; i < nq; ++i) out_counts[i] = 0;

@@ -23,6 +23,9 @@ static bool scan_filter_enabled(const vg_corpus *c) {
 bool vg_scan_filter_policy(const vg_corpus *c) {
     return scan_filter_enabled(c) && c->n_rows * c->stride >= (long long)env_int("VG_SCAN_FILTER_MIN_MB", 3072) * (1ll << 20);
 }
+// Would a single top-k scan of this corpus go through a filter scan right now?  (vg_batch_api.hip: a handful of queries are then
+// cheaper as single scans than as one 128- / 256-query-wide matrix pass.)
+bool vg_scan_filter_would_serve(const vg_corpus *c, int metric, int k);
 // exact-evaluation counters on the device ([0] filter scans, [1] filtered batches) + their pinned host mirror
 int vg_ensure_filter_counters(vg_corpus *c) {
     if (c->d_filter_evals) return VG_OK;
@@ -409,6 +412,12 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
         return vg_launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream);   // 1: the filter over every row; 2: -1 (plain scan)
     }
     return VG_OK;
+}
+
+bool vg_scan_filter_would_serve(const vg_corpus *c, int metric, int k) {
+    if (k > VG_MAX_FUSED_K || c->filter_cooldown > 0 || !scan_filter_serves(c, metric)) return false;
+    if ((c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8) && !n4_explicit(c) && c->n4_probe != 1) return false;   // (not probed yet / not selective)
+    return true;
 }
 
 static const char *filter_type_tag(int t) { return t == VG_TYPE_F32 ? "f32" : (t == VG_TYPE_F16 ? "f16" : (t == VG_TYPE_BF16 ? "bf16" : (t == VG_TYPE_U8 ? "u8" : "i8"))); }

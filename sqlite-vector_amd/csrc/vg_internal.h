@@ -173,6 +173,7 @@ int vg_launch_plain_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int
 int vg_launch_merge_one(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, hipStream_t stream);   // vg_api.hip
 int vg_plain_scan_shape(const vg_corpus *c, int metric, VgShape *out);   // vg_api.hip: launch shape of the plain kernel
 int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream);   // vg_filter.hip; -1: not served
+bool vg_scan_filter_would_serve(const vg_corpus *c, int metric, int k);   // vg_filter.hip: a single scan would take a filter scan right now
 bool vg_scan_filter_policy(const vg_corpus *c);      // vg_filter.hip: filter switched on for this corpus and the corpus large enough for the shadow copy to pay
 int vg_ensure_filter_counters(vg_corpus *c);         // vg_filter.hip: d_filter_evals[2] + pinned mirror
 bool vg_scan_filter_name(vg_corpus *c, int metric, char *out, size_t out_len);   // vg_filter.hip: kernel name when the filter serves the scan

@@ -521,6 +521,14 @@ def test_batch_f32_filter_default_policy_and_selectivity_guard(pkg, monkeypatch)
             _same_topk_up_to_ties(ids1[i], dist1[i], ids0[i], dist0[i], rtol=1e-5)
         one_ids, one_dist = c.scan_topk(metric, qs[3], k)          # the filtered batch carries the single scan's arithmetic
         _same_topk_up_to_ties(ids[3], dist[3], one_ids, one_dist, rtol=1e-6)
+    # a handful of queries: single filter scans instead of one 256-query-wide matrix pass - the single scans' answers bit for bit
+    c.set_scan_filter(-1)
+    c.batch_filter_exact_evals(); c.filter_exact_evals()
+    ids2, dist2, cnt2 = c.scan_topk_batch(dg.L2, qs[:3], k)
+    assert c.batch_filter_exact_evals() == 0 and c.filter_exact_evals() > 0
+    for i in range(3):
+        one_ids, one_dist = c.scan_topk(dg.L2, qs[i], k)
+        assert ids2[i].tolist() == one_ids.tolist() and dg.same_float_bits(dist2[i], one_dist)
     c.close()
     # copies of one row: every (query, row) pair has the same bound - nothing can be excluded
     del rows
