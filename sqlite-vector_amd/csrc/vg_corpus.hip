@@ -236,6 +236,26 @@ __global__ void vg_repack_kernel(const uint8_t *src, long long src_stride, int s
     *reinterpret_cast<uint4 *>(dst + r * dst_stride + (long long)ch * 16) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// the same for rows that go to scattered places (vg_corpus_patch_rows): source row r lands at row positions[r], padded with zeros
+__global__ void vg_scatter_rows_kernel(const uint8_t *src, long long src_stride, int row_bytes, const long long *positions,
+                                       uint8_t *dst, long long dst_stride, int nch, long long n_rows) {
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * nch) return;
+    const long long r = t / nch;
+    const int ch = (int)(t - r * nch);
+    const uint8_t *s = src + r * src_stride + (long long)ch * 16;
+    const int remain = row_bytes - ch * 16;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (remain >= 16 && ((reinterpret_cast<uintptr_t>(s) & 3) == 0)) {
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(s);
+        w[0] = s4[0]; w[1] = s4[1]; w[2] = s4[2]; w[3] = s4[3];
+    } else {
+        const int nb = remain < 16 ? remain : 16;
+        for (int j = 0; j < nb; ++j) w[j >> 2] |= (uint32_t)s[j] << ((j & 3) * 8);
+    }
+    *reinterpret_cast<uint4 *>(dst + positions[r] * dst_stride + (long long)ch * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // Host -> HBM staging pipeline: two pinned bounce buffers.  The caller's rows are memcpy'd into a pinned buffer and
 // the H2D copy (plus, when the layouts differ, the de-interleave kernel) is only ENQUEUED on the corpus stream, so
 // the call returns while the transfer runs and the caller's next sqlite3_step() batch overlaps with it.  A buffer is
@@ -372,7 +392,7 @@ extern "C" int64_t vg_corpus_find_rowid(const vg_corpus *c, int64_t rowid) {
     return (it != c->rowids.end() && *it == rowid) ? (int64_t)(it - c->rowids.begin()) : -1;
 }
 
-// rows at `positions` (any order) are overwritten with host_rows[i]
+// rows at `positions` (any order, all DISTINCT) are overwritten with host_rows[i]
 extern "C" int vg_corpus_patch_rows(vg_corpus *c, const int64_t *positions, int64_t n, const void *host_rows, int64_t row_stride_bytes) {
     if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
     if (n == 0) return VG_OK;
@@ -385,20 +405,23 @@ extern "C" int vg_corpus_patch_rows(vg_corpus *c, const int64_t *positions, int6
         if (positions[i] < 0 || positions[i] >= c->n_rows) return vg_fail(VG_ERR_INVALID, "vg_corpus_patch_rows: position %lld out of range", (long long)positions[i]);
         first = std::min(first, positions[i]);
     }
-    const int64_t piece_rows = std::max<int64_t>(1, VG_PIN_BYTES / row_stride_bytes);
+    // rows and their positions travel together in one pinned piece; one kernel scatters the piece's rows to their places
+    const int64_t piece_rows = std::max<int64_t>(1, (VG_PIN_BYTES - 8) / (row_stride_bytes + 8));
     for (int64_t r0 = 0; r0 < n; r0 += piece_rows) {
         const int64_t nr = std::min(piece_rows, n - r0);
         const size_t bytes = (size_t)((nr - 1) * row_stride_bytes + row_bytes);
+        const size_t pos_off = (bytes + 7) & ~(size_t)7;
         uint8_t *pin;
         int slot;
         int rc = pin_acquire(c, &pin, &slot);
         if (rc != VG_OK) return rc;
         memcpy(pin, (const uint8_t *)host_rows + r0 * row_stride_bytes, bytes);
-        HIP_TRY(hipMemcpyAsync(c->d_stage, pin, bytes, hipMemcpyHostToDevice, c->stream));
-        for (int64_t i = 0; i < nr; ++i)                    // one padded row each (the pad bytes must stay zero)
-            hipLaunchKernelGGL(vg_repack_kernel, dim3((unsigned)((c->nch + 255) / 256)), dim3(256), 0, c->stream,
-                               (const uint8_t *)c->d_stage + i * row_stride_bytes, (long long)row_stride_bytes, 0, (int)row_bytes,
-                               c->d_rows + positions[r0 + i] * c->stride, (long long)c->stride, c->nch, 1ll);
+        memcpy(pin + pos_off, positions + r0, (size_t)nr * sizeof(int64_t));
+        HIP_TRY(hipMemcpyAsync(c->d_stage, pin, pos_off + (size_t)nr * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        const long long total = nr * c->nch;
+        hipLaunchKernelGGL(vg_scatter_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                           (const uint8_t *)c->d_stage, (long long)row_stride_bytes, (int)row_bytes,
+                           reinterpret_cast<const long long *>(c->d_stage + pos_off), c->d_rows, (long long)c->stride, c->nch, (long long)nr);
         HIP_TRY(hipEventRecord(c->pin_ev[slot], c->stream));
         c->pin_busy[slot] = true;
     }
