@@ -71,18 +71,23 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU shard (default: 10M on one GPU, 12.5M per rank on several = config C4's shard)")
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["stage"])
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=1024, help="queries per batch (workload c5)")
     ap.add_argument("--no-also", action="store_true", help="default workload: skip the filter_scan / c3 / c5 sub-results")
-    ap.add_argument("--also", default="filter,c3,c5", help="default workload: which sub-results to append (filter,c3,c5)")
+    ap.add_argument("--also", default="filter,c3,c5,matrix,c4", help="default workload: which sub-results to append (filter,c3,c5,matrix,c4)")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="no GPU work: every rank fabricates its candidate keys and runs the N-rank exchange + merge + timing plumbing "
+                         "over gloo (what tests/test_bench_launch.py drives on a CPU-only box)")
     return ap.parse_args()
 
 
 def make_shard(pkg, torch, vt, dim, n_rows, seed, device):
-    """synthetic shard generated on the device in blocks and handed to the C-ABI as a raw device pointer"""
+    """synthetic shard generated on the device in blocks and handed to the C-ABI as a raw device pointer.
+    f32 / f16 / bf16: N(0,1); uint8: SURVEY 8(d)'s C3 data - an f32 U[0,1) source quantized with the reference's formula
+    (offset = min = 0, scale = 255 / (max - min) = 255, sqlite-vector.c:517-548): (uint8)(v * 255 + 0.5); int8: N(0,1) * 40 rounded"""
     corpus = pkg.Corpus(vt, dim, device=device, capacity=n_rows)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
@@ -92,10 +97,12 @@ def make_shard(pkg, torch, vt, dim, n_rows, seed, device):
         nr = min(block, n_rows - r0)
         if vt == pkg.F32:
             t = torch.randn((nr, dim), generator=gen, device="cuda", dtype=torch.float32)
-        elif vt == pkg.F16:
-            t = torch.randn((nr, dim), generator=gen, device="cuda", dtype=torch.float32).to(torch.float16)
+        elif vt in (pkg.F16, pkg.BF16):
+            t = torch.randn((nr, dim), generator=gen, device="cuda", dtype=torch.float32).to(torch.float16 if vt == pkg.F16 else torch.bfloat16)
+        elif vt == pkg.U8:
+            t = torch.rand((nr, dim), generator=gen, device="cuda", dtype=torch.float32).mul_(255.0).add_(0.5).floor_().clamp_(0, 255).to(torch.uint8)
         else:
-            t = torch.randint(0, 256, (nr, dim), generator=gen, device="cuda", dtype=torch.uint8)
+            t = torch.randn((nr, dim), generator=gen, device="cuda", dtype=torch.float32).mul_(40.0).round_().clamp_(-128, 127).to(torch.int8)
         torch.cuda.synchronize()
         corpus.append_device(t.data_ptr(), nr, dim * es)
         del t
@@ -110,9 +117,9 @@ def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows, seconds=10.0, all_co
     if vt == 1:
         rows = rng.standard_normal((sample_rows, dim), dtype=np.float32)
         q = rng.standard_normal(dim, dtype=np.float32)
-    else:
-        rows = rng.integers(0, 256, (sample_rows, dim), dtype=np.uint8)
-        q = rng.integers(0, 256, dim, dtype=np.uint8)
+    else:                                        # f32 U[0,1) quantized with the reference's formula
+        rows = quantize_unit_uniform_np(rng.random((sample_rows, dim), dtype=np.float32))
+        q = quantize_unit_uniform_np(rng.random(dim, dtype=np.float32))
     kind, runner = "port", None
     if orc.have_ref():
         ref = orc.RefKernels("avx2")
@@ -136,14 +143,15 @@ def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows, seconds=10.0, all_co
                      (reps, sample_rows, dim, np.dtype(np_dtype).name, k, label, os.cpu_count())}
     if not all_cores:
         return out
-    # The same single-threaded reference loop run embarrassingly parallel over row ranges.  Every thread gets
-    # its OWN >= 64k rows (~9 ms of kernel work per call: the Python dispatch of a call is noise next to it) out of a
-    # sample made 4x larger by tiling, so the threads do not share cache lines; `cores` = the threads actually used.
+    # The same single-threaded reference loop run embarrassingly parallel over row ranges, one thread per LOGICAL
+    # core of the host.  Every thread loops over its OWN rows (a sample tiled up so that no two threads stream the same
+    # memory; >= 8k rows = ~1 ms of kernel work per call: the Python dispatch of a call is noise next to it).
     try:
         import threading
-        per_thread = 65536
-        big = np.tile(rows, (4, 1)) if sample_rows * 4 * dim * rows.itemsize <= (8 << 30) else rows
-        nthreads = max(1, min(os.cpu_count() or 1, big.shape[0] // per_thread))
+        nthreads = max(1, os.cpu_count() or 1)
+        per_thread = max(8192, min(65536, (6 << 30) // max(1, nthreads * dim * rows.itemsize)))
+        need = nthreads * per_thread
+        big = np.tile(rows, ((need + sample_rows - 1) // sample_rows, 1))[:need] if need > sample_rows else rows
         views = [big[i * per_thread:(i + 1) * per_thread] for i in range(nthreads)]
         counts = [0] * nthreads
         go, stop = threading.Event(), threading.Event()
@@ -167,14 +175,15 @@ def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows, seconds=10.0, all_co
             t.join()
         el2 = time.perf_counter() - t1
         out["all_cores"] = {"value": per_thread * sum(counts) / el2, "unit": "vectors/s", "cores": nthreads,
-                            "note": "%d threads, each looping over its own %d rows (ctypes releases the GIL), the per-range top-k lists "
-                                    "are not merged; the host has %d logical cores" % (nthreads, per_thread, os.cpu_count() or 1)}
+                            "note": "%d threads = every logical core, each looping over its own %d rows (ctypes releases the GIL), "
+                                    "the per-range top-k lists are not merged: a generous upper bound for a row-split of the "
+                                    "reference's single-threaded loop" % (nthreads, per_thread)}
     except Exception as e:
         out["all_cores"] = {"value": None, "note": "unavailable: %r" % (e,)}
     return out
 
 
-def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc, dist=None, shard=None, n_gpus=1, rank=0):
+def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc, dist=None, shard=None, n_gpus=1, rank=0, share=False):
     """config #5: each step = one batch of queries through the batched scan (host queries in, host (position,
     distance) lists out).  The dominant kernel is MFMA-bound: flops = 2 * Q * N * D per launch.
     N > 1: every rank scans its own row-range shard with the same batch, ONE all_gather of nq x k keys per rank
@@ -195,7 +204,8 @@ def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc
     peak = I8_MFMA_PEAK_TOPS if quantized else (F16_MFMA_PEAK_TF if (half or filt) else F32_MFMA_PEAK_TF)
     use_dist = dist is not None
     offsets = [i * n_rows for i in range(n_gpus)]
-    gathered = torch.empty((n_gpus, nq, k), dtype=torch.int64, device="cuda") if use_dist else None
+    xdev = "cpu" if share else "cuda"                       # (share: ranks on one device exchange over gloo, host tensors)
+    gathered = torch.empty((n_gpus, nq, k), dtype=torch.int64, device=xdev) if use_dist else None
     last = {}
 
     def step(i):
@@ -203,7 +213,7 @@ def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc
             last["res"] = corpus.scan_topk_batch(metric, batches[i % 2], k)
             return
         keys, _ = corpus.scan_topk_batch_keys(metric, batches[i % 2], k)
-        local = torch.from_numpy(keys.view(np.int64)).cuda()
+        local = torch.from_numpy(keys.view(np.int64)).to(xdev)
         res = shard.gather_and_merge_batch(pkg, dist, local, gathered, offsets, k, dst=0)
         if res is not None:
             last["res"] = res
@@ -222,7 +232,7 @@ def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_launch, kern_ms, _ = corpus.profile_mean_ms()
@@ -336,8 +346,9 @@ class SingleQueryRunner:
     """one resident shard + the per-step plumbing of a single-query scan (query upload -> scan + candidate reduction ->
     [RCCL gather] -> k keys to the host -> merge); run() times K steps the way the contract prescribes"""
 
-    def __init__(self, pkg, torch, dist, shard, corpus, vt, dim, metric, k, n_rows, n_gpus, queries):
+    def __init__(self, pkg, torch, dist, shard, corpus, vt, dim, metric, k, n_rows, n_gpus, queries, share=False):
         self.pkg, self.torch, self.dist, self.shard, self.corpus = pkg, torch, dist, shard, corpus
+        self.share = share                            # ranks share a device: the exchange runs over gloo on host tensors
         self.metric, self.k, self.n_rows, self.n_gpus = metric, k, n_rows, n_gpus
         es = pkg.TYPE_SIZE[vt]
         nq = queries.shape[0]
@@ -353,7 +364,8 @@ class SingleQueryRunner:
         self.h_queries = h.pin_memory()
         self.d_keys = torch.empty(64, dtype=torch.int64, device="cuda")
         self.h_keys = torch.empty((n_gpus, 64), dtype=torch.int64).pin_memory()
-        self.d_all = torch.empty((n_gpus, 64), dtype=torch.int64, device="cuda") if dist is not None else None
+        self.d_all = torch.empty((n_gpus, 64), dtype=torch.int64, device="cpu" if share else "cuda") if dist is not None else None
+        self.h_local = torch.empty(64, dtype=torch.int64).pin_memory() if share else None
         self.offsets = [i * n_rows for i in range(n_gpus)]
         self.last = {}
 
@@ -361,7 +373,13 @@ class SingleQueryRunner:
         pkg, stream = self.pkg, self.stream
         self.d_query.copy_(self.h_queries[i], non_blocking=True)
         self.corpus.scan_topk_device(self.metric, self.d_query.data_ptr(), self.k, self.d_keys.data_ptr(), stream.cuda_stream)
-        if self.dist is not None:
+        if self.dist is not None and self.share:
+            self.h_local.copy_(self.d_keys, non_blocking=True)
+            stream.synchronize()
+            res = self.shard.gather_and_merge(pkg, self.dist, self.h_local, self.d_all, self.offsets, self.k, dst=0)
+            if res is not None:
+                self.last["pos"], self.last["dist"] = res
+        elif self.dist is not None:
             # the path's only exchange: 64 keys per rank, one RCCL all_gather, rank 0 merges (shard.py)
             res = self.shard.gather_and_merge(pkg, self.dist, self.d_keys, self.d_all, self.offsets, self.k, dst=0,
                                               host_buf=self.h_keys, sync=stream.synchronize)
@@ -394,18 +412,38 @@ class SingleQueryRunner:
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if self.share else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, lat
 
 
+KERNEL_SOURCES = ("vg_scan.h", "vg_accum.h", "vg_half.h", "vg_device.h", "vg_lists.h", "vg_scan_filter.h", "vg_scan_filter_n4.h",
+                  "vg_api.hip", "vg_filter.hip")
+
+
+def kernel_source_hash():
+    """sha256 over the sources the single-query scan kernels are compiled from (what a PMC pass has to be re-run for)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "sqlite-vector_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_name, n_rows):
-    """HBM bytes per launch measured by the PMC pass committed under profiles/ (same kernel, same N), or (None, None)"""
+    """HBM bytes per launch measured by the PMC pass committed under profiles/ (same kernel, same N) - only when that pass was
+    made on THESE kernel sources (pmc_traffic.json records the source hash of its build; tools/measure.sh refreshes it).
+    Returns (bytes or None, source / reason)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            ent = json.load(f).get("%s@%d" % (kernel_name, n_rows))
+            tab = json.load(f)
+        ent = tab.get("%s@%d" % (kernel_name, n_rows))
         if ent:
+            have, now = ent.get("kernel_source_hash"), kernel_source_hash()
+            if have != now:
+                return None, "stale: profiles/pmc_traffic.json entry was measured on kernel sources %s, this build is %s - re-run tools/measure.sh pmc" % (have, now)
             return ent["bytes_per_launch"], ent["source"]
     except Exception:
         pass
@@ -488,34 +526,125 @@ def filter_scan_object(args, pkg, corpus, runner, metric, vt, dim, n_rows, plain
         return {"error": repr(e)}
 
 
-def main():
-    args = parse()
+def self_launch(args):
+    """`python bench.py --gpus N` with no rank environment: start the N ranks ourselves (one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1) and hand their exit code back.  Fails loudly - before anything is
+    launched - when fewer than N devices are visible (VG_BENCH_SHARE_DEVICES=1: the ranks share the visible devices round
+    robin and exchange over gloo instead of RCCL - a functional check of the N-rank path on a smaller box, not a measurement)."""
+    import socket
+    import subprocess
+    if not args.selftest_launch:
+        import __graft_entry__ as g
+        have = g.load_package().device_count()
+        if have < args.gpus and os.environ.get("VG_BENCH_SHARE_DEVICES") != "1":
+            print("bench.py: --gpus %d but only %d HIP device(s) visible; refusing to report an n_gpus=%d line from fewer devices"
+                  % (args.gpus, have, args.gpus), file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def selftest_launch(args, rank, world):
+    """The N-rank plumbing without a device: rendezvous, the per-step exchange + merge of shard.py on fabricated candidate
+    keys, barrier-bracketed timing, MAX over ranks, one JSON line from rank 0 with n_gpus = N.  Measures nothing."""
     import torch
     import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # VG_BENCH_FORCE_DIST=1 runs the collective path even with one rank (RCCL smoke test on a 1-GPU box)
-    use_dist = world > 1 or (os.environ.get("VG_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
-    torch.cuda.set_device(local_rank)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    n_gpus = world if world > 1 else 1
-    if args.gpus != n_gpus and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
-
     import __graft_entry__ as g
     pkg = g.load_package()
+    shard = load_shard_module()
+    dist.init_process_group(backend="gloo")
+    k, n_rows = args.k, 1000
+    rng = np.random.default_rng(7 + rank)
+    d = np.sort(rng.random(64).astype(np.float32))
+    bits = d.view(np.uint32).astype(np.uint64)
+    keys = ((bits ^ np.uint64(0x80000000)) << np.uint64(32)) | np.arange(64, dtype=np.uint64)
+    keys[k:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    local = torch.from_numpy(keys.view(np.int64).copy())
+    gathered = torch.empty((world, 64), dtype=torch.int64)
+    offsets = [i * n_rows for i in range(world)]
+    res = None
+    for _ in range(args.warmup):
+        res = shard.gather_and_merge(pkg, dist, local, gathered, offsets, k)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = shard.gather_and_merge(pkg, dist, local, gathered, offsets, k)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        assert res is not None and len(res[0]) == k and np.all(np.diff(res[1]) >= 0)
+        print(json.dumps({"metric": "selftest: N-rank launch + candidate exchange + merge (no scan, no device)", "value": None,
+                          "unit": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": float(t.item()) / args.steps * 1e3, "data": "fabricated candidate keys",
+                          "config": {"workload": "selftest-launch", "backend": "gloo"}}))
+    dist.destroy_process_group()
+    return 0
+
+
+def load_shard_module():
     import importlib.util
     spec = importlib.util.spec_from_file_location("vg_shard", os.path.join(ROOT, "sqlite-vector_amd", "shard.py"))
     shard = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(shard)
+    return shard
+
+
+def main():
+    args = parse()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    if "RANK" not in os.environ and args.gpus > 1:
+        return self_launch(args)                 # N ranks of this same script; their rank 0 prints the line
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but launched with WORLD_SIZE=%d: the two must agree (no line is printed)" % (args.gpus, world),
+                  file=sys.stderr)
+        return 2
+    if args.selftest_launch:
+        return selftest_launch(args, rank, world)
+    import torch
+    import torch.distributed as dist
+
+    # VG_BENCH_FORCE_DIST=1 runs the collective path even with one rank (RCCL smoke test on a 1-GPU box)
+    use_dist = world > 1 or (os.environ.get("VG_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    n_dev = torch.cuda.device_count()
+    share = os.environ.get("VG_BENCH_SHARE_DEVICES") == "1" and n_dev < world
+    if n_dev < world and not share:
+        if rank == 0:
+            print("bench.py: %d ranks but only %d HIP device(s) visible" % (world, n_dev), file=sys.stderr)
+        return 2
+    device_index = local_rank % max(1, n_dev)
+    torch.cuda.set_device(device_index)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if share:
+            dist.init_process_group(backend="gloo")          # RCCL refuses two ranks on one device: functional check only
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+    n_gpus = world
+
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    shard = load_shard_module()
     if args.workload == "c1":
         if not args.rows:
             args.rows = 10_000
         return bench_sql(args, pkg, torch)
+    if args.workload == "stage":
+        return bench_stage(args, pkg, torch)
     vt, np_dtype, dim, metric, desc = WORKLOADS[args.workload]
     if args.workload == "c5f":
         os.environ["VG_F32_FILTER"] = "1"
@@ -528,34 +657,47 @@ def main():
             n_rows * n_gpus / 1e6, n_gpus, n_rows / 1e6)
     elif n_rows != 10_000_000:
         desc = desc.replace("10M", "%gM" % (n_rows / 1e6))
+    the_dist = dist if use_dist else None
 
-    corpus = make_shard(pkg, torch, vt, dim, n_rows, 42 + rank, local_rank)
+    corpus = make_shard(pkg, torch, vt, dim, n_rows, 42 + rank, device_index)
     corpus.set_rowid_base(1 + rank * n_rows)
     corpus.set_profiling(True)
     if args.workload in ("c5", "c3b", "c5h", "c5f"):
-        out = run_batched(args, pkg, torch, corpus, args.workload, n_rows, dim, metric, k, desc, dist if use_dist else None, shard,
-                          n_gpus, rank)
+        out = run_batched(args, pkg, torch, corpus, args.workload, n_rows, dim, metric, k, desc, the_dist, shard, n_gpus, rank,
+                          share=share)
         if out is not None:
-            if n_gpus == 1 and not args.no_cpu_baseline:
+            if not args.no_cpu_baseline:
                 out["cpu_baseline"] = batch_cpu_baseline(args, vt, np_dtype, dim, metric, k)
             print(json.dumps(out))
         corpus.close()
         if use_dist:
+            dist.barrier()
             dist.destroy_process_group()
-        return
+        return 0
 
     # queries: a different one every step, pre-generated on the host
     rng = np.random.default_rng(43)
     nq = args.steps + args.warmup
-    queries = rng.standard_normal((nq, dim), dtype=np.float32) if vt == pkg.F32 else rng.integers(0, 256, (nq, dim), dtype=np.uint8)
+    queries = rng.standard_normal((nq, dim), dtype=np.float32) if vt == pkg.F32 else c3_queries(nq, dim)
 
-    # THE line: the plain scan kernel on SURVEY 8(d)'s basis.  The bf16 shadow-copy filter is switched off for this corpus
-    # (it is the product's default for f32 corpora >= 3 GB and is reported on its own below).
+    # THE line: the plain scan kernel on SURVEY 8(d)'s basis.  The shadow-copy filter is switched off for this corpus
+    # (it is the product's default for f32 corpora of this size and is reported on its own below).
     corpus.set_scan_filter(0)
-    runner = SingleQueryRunner(pkg, torch, dist if use_dist else None, shard, corpus, vt, dim, metric, k, n_rows, n_gpus, queries)
+    runner = SingleQueryRunner(pkg, torch, the_dist, shard, corpus, vt, dim, metric, k, n_rows, n_gpus, queries, share=share)
     out, _ = single_query_line(args, pkg, runner, corpus, args.workload, vt, dim, metric, k, n_rows, n_gpus, desc)
+    if use_dist:
+        # every rank's own dominant-kernel time (HIP events on its stream): the line's roofline is rank 0's, the others ride along
+        mine = torch.tensor([out["roofline"]["kernel_ms"]], dtype=torch.float64, device="cpu" if share else "cuda")
+        allk = [torch.zeros_like(mine) for _ in range(n_gpus)]
+        dist.all_gather(allk, mine)
+        per = [float(t.item()) for t in allk]
+        ab = out["roofline"]["algorithmic_bytes_per_launch"]
+        out["roofline"]["per_rank"] = [{"rank": i, "kernel_ms": ms, "achieved": ab / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                                        "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0} for i, ms in enumerate(per)]
+        if share:
+            out["config"]["note"] = "VG_BENCH_SHARE_DEVICES=1: %d ranks share %d device(s), exchange over gloo - a functional check, not a measurement" % (n_gpus, n_dev)
     plain_last = dict(runner.last)
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(vt, np_dtype, dim, metric, k, args.cpu_sample_rows)
         except Exception as e:                                        # the checker is optional on a bare box
@@ -565,102 +707,256 @@ def main():
     if n_gpus == 1 and args.workload == "c2" and "filter" in also_set:
         # ---- the same queries through the filter scan (the product's default path for this corpus)
         out["filter_scan"] = filter_scan_object(args, pkg, corpus, runner, metric, vt, dim, n_rows, plain_last)
-    if n_gpus == 1 and args.workload == "c2" and (also_set & {"c3", "c5"}):
-        # ---- configs[2] over its own corpus, then configs[4] over the f32 corpus (the MFMA-bound batch last: the HBM-bound
-        # lines are not timed on a package it has just heated)
+    if n_gpus == 1 and args.workload == "c2" and (also_set & {"c3", "c5", "matrix", "c4"}):
+        # ---- configs[2] over its own corpus, then configs[4] over the f32 corpus (the MFMA-bound batch after the HBM-bound
+        # lines: they are not timed on a package it has just heated), then the plain-kernel matrix and 100M x 384 on this device
         also = {}
         if "c3" in also_set:
-            try:
-                v3, t3, d3, m3, desc3 = WORKLOADS["c3"]
-                c3 = make_shard(pkg, torch, v3, d3, n_rows, 42, local_rank)
-                q3 = np.random.default_rng(43).integers(0, 256, (nq, d3), dtype=np.uint8)
-                c3.set_scan_filter(0)              # the line: the plain kernel on SURVEY 8(d)'s 7.68 GB; the nibble filter on its own below
-                r3 = SingleQueryRunner(pkg, torch, None, shard, c3, v3, d3, m3, k, n_rows, 1, q3)
-                line, _ = single_query_line(args, pkg, r3, c3, "c3", v3, d3, m3, k, n_rows, 1, desc3)
-                if not args.no_cpu_baseline:
-                    line["cpu_baseline"] = cpu_baseline(v3, t3, d3, m3, k, args.cpu_sample_rows, seconds=5.0, all_cores=False)
-                # what tie_order=reference costs (the reference's rowids among equal distances, vg_reforder.hip): the same host
-                # entry point (vg_scan_topk: host query in, host rowids out) in both orders, 10 queries each
-                tie = {}
-                for name, mode in (("position", pkg.TIE_POSITION), ("reference", pkg.TIE_REFERENCE)):
-                    c3.set_tie_order(mode)
-                    c3.scan_topk(m3, q3[0], k)
-                    t0 = time.perf_counter()
-                    for i in range(10):
-                        c3.scan_topk(m3, q3[(1 + i) % nq], k)
-                    tie["ms_per_query_%s" % name] = (time.perf_counter() - t0) / 10 * 1e3
-                c3.set_tie_order(pkg.TIE_POSITION)
-                tie["what"] = "vg_scan_topk end to end, top-%d; reference = store-mode scan + device compaction of the rows below the bound + host slot replay" % k
-                line["tie_order"] = tie
-                if "filter" in also_set:
-                    # what the product does with this corpus by default: the high-nibble filter is PROBED (a 2M-row prefix) and kept
-                    # only if the data is selective under it - independent random bytes are not
-                    try:
-                        c3.set_scan_filter(-1)
-                        c3.filter_exact_evals()
-                        c3.scan_topk(m3, q3[0], k)                   # the probing scan
-                        probe_evals = c3.filter_exact_evals()
-                        for i in range(3):
-                            c3.scan_topk(m3, q3[1 + i], k)
-                        line["nibble_filter_probe"] = {
-                            "candidates_in_the_probed_prefix": probe_evals, "prefix_rows": min(n_rows, 1 << 21),
-                            "kernel_after_the_probe": c3.kernel_name(m3),
-                            "filter_in_use": bool(c3.kernel_name(m3).startswith("scan_filter")),
-                        }
-                        if line["nibble_filter_probe"]["filter_in_use"]:
-                            c3.set_scan_filter(0)
-                            r3.run(args.warmup, args.steps)           # (the plain answers of the same query sequence)
-                            plain3 = dict(r3.last)
-                            line["filter_scan"] = filter_scan_object(args, pkg, c3, r3, m3, v3, d3, n_rows, plain3)
-                    except Exception as e:
-                        line["nibble_filter_probe"] = {"error": repr(e)}
-                also["c3"] = line
-                c3.close()
-            except Exception as e:
-                also["c3"] = {"error": repr(e)}
+            also["c3"] = also_c3(args, pkg, torch, shard, also_set, n_rows, k, nq, device_index)
         if "c5" in also_set:
-            try:
-                corpus.set_scan_filter(0)
-                v5, t5, d5, m5, desc5 = WORKLOADS["c5"]
-                line = run_batched(args, pkg, torch, corpus, "c5", n_rows, d5, m5, k, desc5)
-                if not args.no_cpu_baseline:
-                    line["cpu_baseline"] = batch_cpu_baseline(args, v5, t5, d5, m5, k, seconds=5.0)
-                also["c5"] = line
-                # the same batches through the bf16 filter (VG_F32_FILTER=1, the shadow copy the filter scan above has made): the
-                # GEMM at the bf16 rate over HALF the bytes, every survivor re-evaluated with the f32 single-scan arithmetic.
-                # Priced on the bf16 MFMA peak and reported next to the f32 MFMA line, never as its roofline.
-                try:
-                    plain_res = run_batched.last_result
-                    os.environ["VG_F32_FILTER"] = "1"
-                    fl = run_batched(args, pkg, torch, corpus, "c5f", n_rows, d5, m5, k, WORKLOADS["c5f"][4])
-                    fres = run_batched.last_result
-                    same_ids = bool(np.array_equal(np.asarray(fres[0]), np.asarray(plain_res[0])))
-                    d_f, d_p = np.asarray(fres[1], dtype=np.float64), np.asarray(plain_res[1], dtype=np.float64)
-                    line["filter_batch"] = {
-                        "what": "the same batches through vg_batch_h_kernel over the bf16 shadow copy (matrix cores as a lower-bound "
-                                "filter) + exact f32 re-evaluation of the survivors: the f32 single scans' distances",
-                        "value": fl["value"], "unit": "vectors/s", "ms_per_step": fl["ms_per_step"], "dtype_streamed": "bf16",
-                        "kernel": fl["roofline"]["kernel"], "kernel_ms": fl["roofline"]["kernel_ms"],
-                        "achieved_TFLOPs_of_the_QxNxD_product": fl["roofline"]["achieved"], "peak_bf16_TFLOPs": F16_MFMA_PEAK_TF,
-                        "frac_of_bf16_peak": fl["roofline"]["frac"], "speedup_over_f32_mfma_kernel": line["ms_per_step"] / fl["ms_per_step"],
-                        "last_batch_same_rowids_as_f32_mfma_kernel": same_ids,
-                        "last_batch_rowid_slots_that_differ": "%d of %d (near-ties: the two kernels' distances differ by summation order)" % (
-                            int(np.sum(np.asarray(fres[0]) != np.asarray(plain_res[0]))), int(np.asarray(fres[0]).size)),
-                        "last_batch_max_rel_distance_difference": float(np.max(np.abs(d_f - d_p) / np.maximum(np.abs(d_p), 1e-30))) if d_f.shape == d_p.shape else None,
-                    }
-                except Exception as e:
-                    line["filter_batch"] = {"error": repr(e)}
-                finally:
-                    os.environ.pop("VG_F32_FILTER", None)
-            except Exception as e:
-                also["c5"] = {"error": repr(e)}
+            also["c5"] = also_c5(args, pkg, torch, corpus, n_rows, k)
+        corpus.close()
+        corpus = None
+        torch.cuda.empty_cache()
+        if "matrix" in also_set:
+            also["kernel_matrix"] = also_kernel_matrix(args, pkg, torch, shard, n_rows, k, device_index)
+        if "c4" in also_set:
+            also["c4_one_gpu"] = also_c4_one_gpu(args, pkg, torch, shard, k, device_index)
         out["also"] = also
     if rank == 0:
         print(json.dumps(out))
     if corpus is not None:
         corpus.close()
     if use_dist:
+        dist.barrier()                 # (rank 0 was timing the CPU baseline meanwhile)
         dist.destroy_process_group()
+    return 0
+
+
+def c3_queries(nq, dim):
+    """queries of config C3: f32 U[0,1) quantized like the corpus"""
+    return quantize_unit_uniform_np(np.random.default_rng(43).random((nq, dim), dtype=np.float32))
+
+
+def quantize_unit_uniform_np(v):
+    """the reference's uint8 quantizer (sqlite-vector.c:517-548) with the parameters a U[0,1) source gets: offset = min = 0,
+    scale = 255 / (max - min) = 255: (uint8)(v * 255 + 0.5)"""
+    return np.clip(np.floor(v * np.float32(255.0) + np.float32(0.5)), 0, 255).astype(np.uint8)
+
+
+def also_c3(args, pkg, torch, shard, also_set, n_rows, k, nq, device_index):
+    try:
+        v3, t3, d3, m3, desc3 = WORKLOADS["c3"]
+        c3 = make_shard(pkg, torch, v3, d3, n_rows, 42, device_index)
+        q3 = c3_queries(nq, d3)
+        c3.set_scan_filter(0)              # the line: the plain kernel on SURVEY 8(d)'s 7.68 GB; the nibble filter on its own below
+        c3.set_tie_order(pkg.TIE_POSITION)
+        r3 = SingleQueryRunner(pkg, torch, None, shard, c3, v3, d3, m3, k, n_rows, 1, q3)
+        line, _ = single_query_line(args, pkg, r3, c3, "c3", v3, d3, m3, k, n_rows, 1, desc3)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(v3, t3, d3, m3, k, args.cpu_sample_rows, seconds=5.0, all_cores=False)
+        # what the reference's result order costs (its rowids among equal distances; the default of the SQL surface for
+        # quantized scans): the same host entry point (vg_scan_topk: host query in, host rowids out) in both orders
+        tie = {}
+        for name, mode in (("position", pkg.TIE_POSITION), ("reference", pkg.TIE_REFERENCE)):
+            c3.set_tie_order(mode)
+            c3.scan_topk(m3, q3[0], k)
+            t0 = time.perf_counter()
+            for i in range(20):
+                c3.scan_topk(m3, q3[(1 + i) % nq], k)
+            tie["ms_per_query_%s" % name] = (time.perf_counter() - t0) / 20 * 1e3
+        tie["reference_over_position"] = tie["ms_per_query_reference"] / tie["ms_per_query_position"]
+        if hasattr(c3, "tie_stats"):
+            tie["reference_path_counters"] = c3.tie_stats()
+        c3.set_tie_order(pkg.TIE_POSITION)
+        tie["what"] = ("vg_scan_topk end to end, top-%d, 20 queries each; reference = the same scan with one more list slot, the "
+                       "reference's slot algorithm replayed on the host only for queries whose k+1 best distances hold a tie" % k)
+        line["tie_order"] = tie
+        if "filter" in also_set:
+            # what the product does with this corpus by default: the high-nibble filter is PROBED (a 2M-row prefix) and kept
+            # only if the data is selective under it - independent random bytes are not (DESIGN 3f)
+            try:
+                c3.set_scan_filter(-1)
+                c3.filter_exact_evals()
+                c3.scan_topk(m3, q3[0], k)                   # the probing scan
+                probe_evals = c3.filter_exact_evals()
+                for i in range(3):
+                    c3.scan_topk(m3, q3[1 + i], k)
+                line["nibble_filter_probe"] = {
+                    "candidates_in_the_probed_prefix": probe_evals, "prefix_rows": min(n_rows, 1 << 21),
+                    "kernel_after_the_probe": c3.kernel_name(m3),
+                    "filter_in_use": bool(c3.kernel_name(m3).startswith("scan_filter")),
+                }
+                if line["nibble_filter_probe"]["filter_in_use"]:
+                    c3.set_scan_filter(0)
+                    r3.run(args.warmup, args.steps)           # (the plain answers of the same query sequence)
+                    plain3 = dict(r3.last)
+                    line["filter_scan"] = filter_scan_object(args, pkg, c3, r3, m3, v3, d3, n_rows, plain3)
+            except Exception as e:
+                line["nibble_filter_probe"] = {"error": repr(e)}
+        c3.close()
+        return line
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def also_c5(args, pkg, torch, corpus, n_rows, k):
+    try:
+        corpus.set_scan_filter(0)
+        v5, t5, d5, m5, desc5 = WORKLOADS["c5"]
+        line = run_batched(args, pkg, torch, corpus, "c5", n_rows, d5, m5, k, desc5)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = batch_cpu_baseline(args, v5, t5, d5, m5, k, seconds=5.0)
+        # the same batches through the bf16 filter (VG_F32_FILTER=1, the shadow copy the filter scan above has made): the
+        # GEMM at the bf16 rate over HALF the bytes, every survivor re-evaluated with the f32 single-scan arithmetic.
+        # Priced on the bf16 MFMA peak and reported next to the f32 MFMA line, never as its roofline.
+        try:
+            plain_res = run_batched.last_result
+            os.environ["VG_F32_FILTER"] = "1"
+            fl = run_batched(args, pkg, torch, corpus, "c5f", n_rows, d5, m5, k, WORKLOADS["c5f"][4])
+            fres = run_batched.last_result
+            same_ids = bool(np.array_equal(np.asarray(fres[0]), np.asarray(plain_res[0])))
+            d_f, d_p = np.asarray(fres[1], dtype=np.float64), np.asarray(plain_res[1], dtype=np.float64)
+            line["filter_batch"] = {
+                "what": "the same batches through vg_batch_h_kernel over the bf16 shadow copy (matrix cores as a lower-bound "
+                        "filter) + exact f32 re-evaluation of the survivors: the f32 single scans' distances",
+                "value": fl["value"], "unit": "vectors/s", "ms_per_step": fl["ms_per_step"], "dtype_streamed": "bf16",
+                "kernel": fl["roofline"]["kernel"], "kernel_ms": fl["roofline"]["kernel_ms"],
+                "achieved_TFLOPs_of_the_QxNxD_product": fl["roofline"]["achieved"], "peak_bf16_TFLOPs": F16_MFMA_PEAK_TF,
+                "frac_of_bf16_peak": fl["roofline"]["frac"], "speedup_over_f32_mfma_kernel": line["ms_per_step"] / fl["ms_per_step"],
+                "last_batch_same_rowids_as_f32_mfma_kernel": same_ids,
+                "last_batch_rowid_slots_that_differ": "%d of %d (near-ties: the two kernels' distances differ by summation order; "
+                                                      "tests/test_gpu_fullsize.py checks both against the reference's own kernel)" % (
+                    int(np.sum(np.asarray(fres[0]) != np.asarray(plain_res[0]))), int(np.asarray(fres[0]).size)),
+                "last_batch_max_rel_distance_difference": float(np.max(np.abs(d_f - d_p) / np.maximum(np.abs(d_p), 1e-30))) if d_f.shape == d_p.shape else None,
+            }
+        except Exception as e:
+            line["filter_batch"] = {"error": repr(e)}
+        finally:
+            os.environ.pop("VG_F32_FILTER", None)
+        return line
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+MATRIX_TYPES = {2: ("f16", np.float16), 3: ("bf16", None), 5: ("i8", np.int8)}
+
+
+def also_kernel_matrix(args, pkg, torch, shard, n_rows, k, device_index):
+    """the element types the driver's lines never touch - f16, bf16, int8 - through their PLAIN scan kernels (filter off), L2 and
+    cosine, 10M x 384, priced like the headline: N x D x elem bytes per launch / the kernel's mean HIP-event time / 8 TB/s"""
+    out = {"what": "plain scan kernels (scan_filter=0), %d x 384, top-%d, %d timed single queries each: algorithmic bytes N*D*elem / "
+                   "mean kernel time (HIP events on the launch stream) / %.0f GB/s" % (n_rows, k, args.steps, HBM_PEAK_GBS), "rows": []}
+    dim = 384
+    for vt, (tag, _) in MATRIX_TYPES.items():
+        try:
+            c = make_shard(pkg, torch, vt, dim, n_rows, 60 + vt, device_index)
+            c.set_scan_filter(0)
+            c.set_tie_order(pkg.TIE_POSITION)
+            c.set_profiling(True)
+            nq = args.steps + args.warmup
+            qf = np.random.default_rng(61).standard_normal((nq, dim), dtype=np.float32)
+            if vt == 2:
+                q = qf.astype(np.float16)
+            elif vt == 3:
+                q = torch.from_numpy(qf).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+            else:
+                q = np.clip(np.rint(qf * 40.0), -128, 127).astype(np.int8)
+            for metric, mname in ((1, "l2"), (3, "cosine")):
+                r = SingleQueryRunner(pkg, torch, None, shard, c, vt, dim, metric, k, n_rows, 1, q)
+                elapsed, _ = r.run(args.warmup, args.steps)
+                n_launch, scan_ms, merge_ms, _ = c.profile_mean_ms_ex()
+                ab = n_rows * dim * pkg.TYPE_SIZE[vt]
+                ach = ab / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+                out["rows"].append({"dtype": tag, "metric": mname, "kernel": c.kernel_name(metric), "kernel_ms": scan_ms,
+                                    "ms_per_step": elapsed / args.steps * 1e3, "launches_timed": n_launch,
+                                    "algorithmic_bytes_per_launch": ab, "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS})
+            c.close()
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["rows"].append({"dtype": tag, "error": repr(e)})
+    return out
+
+
+def also_c4_one_gpu(args, pkg, torch, shard, k, device_index):
+    """north_star's target sentence, literally: single-query f32 L2 over 100M x 384 - resident on ONE device (153.6 GB of its
+    288 GB), the plain kernel, 10 timed queries"""
+    try:
+        n = 100_000_000
+        free, _ = torch.cuda.mem_get_info()
+        if free < n * 384 * 4 + (8 << 30):
+            return {"skipped": "needs %.1f GB of free device memory, %.1f GB free" % (n * 1536 / 1e9 + 8.6, free / 1e9)}
+        vt, _, dim, metric, _ = WORKLOADS["c2"]
+        c = make_shard(pkg, torch, vt, dim, n, 42, device_index)
+        c.set_scan_filter(0)
+        c.set_profiling(True)
+        steps, warmup = 10, 2
+        q = np.random.default_rng(43).standard_normal((steps + warmup, dim), dtype=np.float32)
+        r = SingleQueryRunner(pkg, torch, None, shard, c, vt, dim, metric, k, n, 1, q)
+        a2 = argparse.Namespace(**vars(args))
+        a2.steps, a2.warmup = steps, warmup
+        line, _ = single_query_line(a2, pkg, r, c, "c2", vt, dim, metric, k, n, 1,
+                                    "100Mx384 f32 L2 top-20 single-query, the whole corpus resident on ONE MI355X (plain kernel)")
+        c.close()
+        torch.cuda.empty_cache()
+        return line
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def bench_stage(args, pkg, torch):
+    """--workload stage: the two passes in front of the scans, each priced on its own bytes.
+       staging   host rows -> HBM through vg_corpus_append (pinned double buffer + H2D [+ the de-interleave kernel for the
+                 reference's [rowid | vector] record format]): bound by the host link, GB/s of row bytes
+       quantize  vector_quantize on the resident f32 corpus: vg_corpus_minmax (reads N*D*4 B) and vg_corpus_quantize_rows' kernel
+                 (reads N*D*4 B, writes N*D B) against the 8 TB/s HBM peak; the int8 shadow copy of the filter scans
+                 (vg_to_q8_kernel: reads N*D*4, writes N*(D+8)) likewise"""
+    n = args.rows if args.rows else 4_000_000
+    dim = 384
+    rng = np.random.default_rng(5)
+    host = rng.random((1 << 20, dim), dtype=np.float32)
+    out = {"metric": "staging + quantization throughput", "unit": "GB/s", "n_gpus": 1, "data": "synthetic", "dtype": "f32",
+           "config": {"workload": "stage: %d x %d f32 rows staged from host memory, then quantized on the device" % (n, dim),
+                      "backend": pkg.backend_name()}}
+    c = pkg.Corpus(pkg.F32, dim, capacity=n)
+    c.append(host[:4096])                                   # warm: pinned buffers, stream
+    c.clear() if hasattr(c, "clear") else None
+    t0 = time.perf_counter()
+    done = 0
+    while done < n:
+        take = min(host.shape[0], n - done)
+        c.append(host[:take])
+        done += take
+    c.rows                                                   # (appends are enqueued: the timing ends behind a synchronising call)
+    c.minmax()
+    t_stage_plus = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    lo, hi, neg = c.minmax()
+    t_minmax_call = time.perf_counter() - t1
+    stage_s = t_stage_plus - t_minmax_call
+    out["staging"] = {"rows": n, "bytes": n * dim * 4, "seconds": stage_s, "achieved": n * dim * 4 / stage_s / 1e9, "unit": "GB/s",
+                      "bound": "host link (PCIe): vg_corpus_append copies into a pinned bounce buffer and enqueues the H2D copy",
+                      "note": "host memcpy into the pinned buffer + H2D, overlapped; 1 host thread"}
+    times = c.stage_kernel_ms() if hasattr(c, "stage_kernel_ms") else None
+    # device passes: HIP-event times from the library
+    res = {}
+    if hasattr(c, "quant_pass_ms"):
+        mm_ms = c.quant_pass_ms("minmax")
+        scale = 255.0 / (hi - lo) if hi > lo else 1.0
+        c.quantize_rows(scale, lo, pkg.QUANT_U8, 0, min(n, 1 << 20))
+        q_ms, q_rows = c.quant_pass_ms("quantize"), min(n, 1 << 20)
+        res["minmax"] = {"kernel": "vg_minmax_kernel", "kernel_ms": mm_ms, "bytes": n * dim * 4,
+                         "achieved": n * dim * 4 / (mm_ms * 1e-3) / 1e9 if mm_ms > 0 else 0.0}
+        res["quantize"] = {"kernel": "vg_quantize_kernel", "kernel_ms": q_ms, "rows": q_rows, "bytes": q_rows * dim * 5,
+                           "achieved": q_rows * dim * 5 / (q_ms * 1e-3) / 1e9 if q_ms > 0 else 0.0}
+        for v in res.values():
+            v.update({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": v["achieved"] / HBM_PEAK_GBS})
+    out["quantize"] = res
+    out["value"] = out["staging"]["achieved"]
+    out["higher_is_better"] = True
+    c.close()
+    print(json.dumps(out))
+    return 0
 
 
 def batch_cpu_baseline(args, vt, np_dtype, dim, metric, k, seconds=10.0):
@@ -675,4 +971,4 @@ def batch_cpu_baseline(args, vt, np_dtype, dim, metric, k, seconds=10.0):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

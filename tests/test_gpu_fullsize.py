@@ -152,7 +152,7 @@ def test_c5_batched_10m(env, metric):
     kernel (itself checked against the reference arithmetic above and in test_gpu_scan.py): same rowids, distances
     within 1e-5.  At this size the batch runs as pre-pass + main pass (thresholds from the first 1/64 of the corpus)."""
     pkg, torch = env
-    dim, k, nq = 384, 20, 256
+    dim, k, nq = 384, 20, 1024                                           # config C5's own batch size
     c, _ = _build(pkg, torch, pkg.F32, dim, 42)
     qs = np.random.default_rng(44).standard_normal((nq, dim), dtype=np.float32)
     ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
@@ -171,7 +171,7 @@ def test_c5_batched_10m(env, metric):
         if metric == dg.DOT:
             scale = float(np.abs(qs[i]).sum()) * 4.0                           # ~ sum |q_i x_i| for N(0,1) rows
         assert np.all(np.abs(dist[i] - one_dist) <= 1e-5 * (np.abs(one_dist) + scale)), i
-    assert swapped <= 3, swapped
+    assert swapped <= 8, swapped                                         # (rowid parity with the REFERENCE's kernel: test_gpu_reference_parity.py)
     c.close()
 
 
