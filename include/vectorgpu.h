@@ -242,6 +242,10 @@ int vg_corpus_set_tie_order(vg_corpus *c, int mode);
 int vg_corpus_tie_order(const vg_corpus *c);
 int vg_shards_set_tie_order(vg_shards *s, int mode);
 int vg_scan_topk_reference(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist, int *out_count);
+/* counters of the reference-order scans of this corpus so far: [0] scans, [1] scans whose k + 1 best distances held a tie (the others
+ * cost what a tie_order = position scan costs), [2] of those, answered by the fused replay (prefix pass + the candidates the scan
+ * emitted: no second pass over the corpus), [3] answered by the store-mode replay (k >= 64, long rows, small corpora, overflow) */
+int vg_corpus_tie_stats(const vg_corpus *c, unsigned long long *out4);
 /* building blocks (what vg_shards composes over several devices): all N distances of a query left in device memory
  * (enqueued, no wait); rows [pos0, pos0 + n) of them; every row >= pos0 whose distance is < bound as
  * (position << 32 | float bits) pairs in any order - *out_count may exceed cap, then only cap pairs were written. */

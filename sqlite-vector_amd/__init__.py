@@ -113,6 +113,7 @@ def lib():
         "vg_corpus_set_scan_filter": (i32, [vp, i32]),
         "vg_corpus_set_tie_order": (i32, [vp, i32]),
         "vg_corpus_tie_order": (i32, [vp]),
+        "vg_corpus_tie_stats": (i32, [vp, vp]),
         "vg_shards_set_tie_order": (i32, [vp, i32]),
         "vg_shards_set_scan_filter": (i32, [vp, i32]),
         "vg_shards_rowids": (i32, [vp, i64, i64, vp]),
@@ -289,6 +290,12 @@ class Corpus:
     def set_tie_order(self, mode):
         """TIE_POSITION (default) or TIE_REFERENCE: the reference's slot-history result among equal distances"""
         _check(lib().vg_corpus_set_tie_order(self.h, mode))
+
+    def tie_stats(self):
+        """reference-order scans so far: {scans, with_a_tie_among_the_k_plus_1_best, fused_replays, store_mode_replays}"""
+        out = np.zeros(4, dtype=np.uint64)
+        _check(lib().vg_corpus_tie_stats(self.h, _ptr(out)))
+        return dict(zip(("scans", "with_a_tie_among_the_k_plus_1_best", "fused_replays", "store_mode_replays"), (int(x) for x in out)))
 
 
 class Shards:

@@ -10,6 +10,7 @@
 // ------------------------------------------------------------------------------------------------ kernel selection
 
 typedef void (*scan_fn_t)(ScanArgs);
+scan_fn_t vg_pick_scan_kernel_ex(int vtype, int acc, int U);      // vg_scan_ex.hip
 
 typedef VgShape Shape;
 
@@ -201,8 +202,9 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     int acc = vg_metric_to_acc(metric);
     if (acc < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
     const int64_t n_rows = (plan.n_rows >= 0) ? std::min<int64_t>(plan.n_rows, c->n_rows) : c->n_rows;
+    if (plan.ref_emit) c->ref_prefix_rows = -1;              // (set by whichever launch below really emits)
     if (plan.allow_filter && plan.n_rows < 0 && !dev_out_dist && k <= VG_MAX_FUSED_K) {
-        int rcf = vg_launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream);
+        int rcf = vg_launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream, plan.ref_emit);
         if (rcf != -1) return rcf;
     }
     Shape s;
@@ -219,7 +221,12 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
             HIP_TRY(hipStreamWaitEvent(stream, c->norm_ev, 0));
         }
     }
-    scan_fn_t fn = pick_kernel(c->vtype, acc, s, use_nt_loads(c, n_rows));
+    // tie_order = reference: the prefix pass (this kernel over the first P rows: top-k + store) runs in front of an emitting scan; its
+    // k-th best is every list's start threshold and the line below which an accepted row is emitted.  Both are EX kernels (vg_scan_ex.hip).
+    const bool emitting = plan.ref_emit && !dev_out_dist && !s.long_rows && plan.n_rows < 0 && k <= VG_MAX_FUSED_K &&
+                          n_rows >= VG_REF_EMIT_MIN_ROWS;
+    const bool prefix_pass = plan.store_prefix && !dev_out_dist && !s.long_rows && k > 0;
+    scan_fn_t fn = (emitting || prefix_pass) ? vg_pick_scan_kernel_ex(c->vtype, acc, s.U) : pick_kernel(c->vtype, acc, s, use_nt_loads(c, n_rows));
     if (!fn) return vg_fail(VG_ERR_UNSUPPORTED, "no scan kernel for type %s", type_tag(c->vtype));
 
     const int rpb = VG_WAVE >> s.lpr_log2;
@@ -230,7 +237,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count * bpc));
     blocks = std::min<long long>(blocks, VG_SEL_MAX_HEADS);          // the final rank-select handles <= 256 lists
 
-    ScanArgs a;
+    ScanArgs a{};
     a.rows = c->d_rows;
     a.query = dev_query;
     a.cand = c->d_cand;
@@ -243,6 +250,12 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     a.root = (metric == VG_DIST_L2) ? 1 : 0;
     a.dim = c->dim;
     a.row_nn = (acc == A_COSN) ? c->d_xnorm : nullptr;
+    a.init_keys = nullptr;
+    a.emit = nullptr;
+    a.emit_cap = 0;
+    a.emit_reset = plan.emit_reset;
+    if (prefix_pass) a.out_dist = plan.store_prefix;       // top-k + store (EX kernel, k > 0)
+    else a.emit_reset = nullptr;
     size_t qbytes = (size_t)c->nch * 16;
     if (s.long_rows) {
         const size_t slice = (size_t)VG_WAVE * VG_LONG_U;               // the long kernel pads the query to whole slices
@@ -258,8 +271,26 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     // host appends are only enqueued on the corpus stream: a scan on ANOTHER stream must wait for them
     if (c->append_pending && stream != c->stream) HIP_TRY(hipStreamWaitEvent(stream, c->append_ev, 0));
 
-    hipEvent_t *evs = plan.record ? vg_prof_slot(c, (uint8_t)(dev_out_dist == nullptr ? VG_EVF_MERGE : 0)) : nullptr;
+    hipEvent_t *evs = plan.record ? vg_prof_slot(c, (uint8_t)((dev_out_dist == nullptr ? VG_EVF_MERGE : 0) | (emitting ? VG_EVF_PREPASS : 0))) : nullptr;
     if (evs) hipEventRecord(evs[0], stream);
+    if (emitting) {
+        const int64_t P = vg_ref_prefix_for(n_rows);
+        int rcb = vg_ensure_ref_buffers(c, P);
+        if (rcb != VG_OK) return rcb;
+        ScanPlan pre;
+        pre.n_rows = P;
+        pre.allow_filter = false;
+        pre.record = false;
+        pre.store_prefix = c->d_ref_prefix;
+        pre.emit_reset = c->d_below;
+        int rcp = launch_scan(c, metric, dev_query, k, dev_out_keys, nullptr, stream, pre);
+        if (rcp != VG_OK) return rcp;
+        a.init_keys = dev_out_keys;                  // read by every workgroup before the final merge overwrites it
+        a.emit = c->d_below;
+        a.emit_cap = VG_BELOW_CAP;
+        c->ref_prefix_rows = P;
+        if (evs) hipEventRecord(evs[1], stream);
+    }
     if (smem > 64 * 1024)          // very long rows: the query alone needs more than the default dynamic-LDS window
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
@@ -419,7 +450,7 @@ static int scan_topk_large_k(vg_corpus *c, int metric, const void *query, int k,
 
 // fused path (k <= 64), split in two so that a caller can put several shards in flight before waiting for any:
 // enqueue = stage the query + launch scan and merge (+ copy the 64 keys back); collect = wait + hand out the keys
-extern "C" int vg_scan_topk_enqueue(vg_corpus *c, int metric, const void *query, int k) {
+int vg_scan_topk_enqueue_plan(vg_corpus *c, int metric, const void *query, int k, bool ref_emit) {
     if (!c || !query) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_enqueue: NULL argument");
     if (k < 1 || k > VG_MAX_FUSED_K) return vg_fail(VG_ERR_UNSUPPORTED, "vg_scan_topk_enqueue: k must be in 1..%d", VG_MAX_FUSED_K);
     if (vg_metric_to_acc(metric) < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
@@ -427,20 +458,25 @@ extern "C" int vg_scan_topk_enqueue(vg_corpus *c, int metric, const void *query,
     if (c->n_rows == 0) return VG_OK;
     HIP_TRY(hipSetDevice(c->device));
     stage_query(c, query);
+    ScanPlan plan;
+    plan.ref_emit = ref_emit;
     int rc;
     if (host_direct(c)) {
         // small corpus: the two staging copies cost more than the scan.  h_query / h_keys are pinned, device-mapped
         // host buffers: the kernels read the query and write the k winners straight across the host link.
-        rc = launch_scan(c, metric, c->h_query, k, c->h_keys, nullptr, c->stream);
+        rc = launch_scan(c, metric, c->h_query, k, c->h_keys, nullptr, c->stream, plan);
         if (rc != VG_OK) return rc;
     } else {
         HIP_TRY(hipMemcpyAsync(c->d_query, c->h_query, (size_t)c->stride, hipMemcpyHostToDevice, c->stream));
-        rc = launch_scan(c, metric, c->d_query, k, c->d_keys, nullptr, c->stream);
+        rc = launch_scan(c, metric, c->d_query, k, c->d_keys, nullptr, c->stream, plan);
         if (rc != VG_OK) return rc;
         HIP_TRY(hipMemcpyAsync(c->h_keys, c->d_keys, VG_WAVE * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     }
     c->enqueued = true;
     return VG_OK;
+}
+extern "C" int vg_scan_topk_enqueue(vg_corpus *c, int metric, const void *query, int k) {
+    return vg_scan_topk_enqueue_plan(c, metric, query, k, false);
 }
 
 extern "C" int vg_scan_topk_collect(vg_corpus *c, uint64_t *out_keys64) {

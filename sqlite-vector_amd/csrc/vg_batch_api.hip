@@ -369,12 +369,32 @@ extern "C" int vg_scan_topk_batch(vg_corpus *c, int metric, const void *queries,
     for (int i = 0; i < nq; ++i) out_counts[i] = 0;
     if (k <= 0 || c->n_rows == 0) return VG_OK;
     if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_batch: NULL output");
-    if (c->tie_order == VG_TIE_REFERENCE) {                // the reference's order is defined per scan: one replayed scan per query
+    if (c->tie_order == VG_TIE_REFERENCE) {
+        // The reference's order differs from (distance, position) only where equal distances meet among a query's k + 1 best
+        // (vg_scan_topk_reference): the batch runs as it is - matrix cores included - with one more list slot, and only the
+        // queries whose lists hold a tie are answered again, one by one, through the replaying scan.
         const size_t qbytes = (size_t)c->dim * c->es;
+        const int k1 = k + 1;
+        std::vector<uint64_t> keys1((size_t)nq * k1);
+        std::vector<int> cnt1((size_t)nq, 0);
+        int rcb = (k1 <= 64) ? vg_scan_topk_batch_keys(c, metric, queries, nq, k1, keys1.data(), cnt1.data()) : VG_ERR_UNSUPPORTED;
+        if (rcb != VG_OK && rcb != VG_ERR_UNSUPPORTED) return rcb;
         for (int i = 0; i < nq; ++i) {
-            int rc1 = vg_scan_topk_reference(c, metric, (const uint8_t *)queries + (size_t)i * qbytes, k, out_rowids + (size_t)i * k,
-                                             out_dist + (size_t)i * k, &out_counts[i]);
-            if (rc1 != VG_OK) return rc1;
+            bool tie = (rcb != VG_OK);
+            const uint64_t *kq = &keys1[(size_t)i * k1];
+            for (int j = 1; j < cnt1[(size_t)i] && !tie; ++j) tie = (kq[j] >> 32) == (kq[j - 1] >> 32);
+            if (tie) {
+                int rc1 = vg_scan_topk_reference(c, metric, (const uint8_t *)queries + (size_t)i * qbytes, k, out_rowids + (size_t)i * k,
+                                                 out_dist + (size_t)i * k, &out_counts[i]);
+                if (rc1 != VG_OK) return rc1;
+                continue;
+            }
+            const int take = std::min(cnt1[(size_t)i], k);
+            for (int j = 0; j < take; ++j) {
+                out_dist[(size_t)i * k + j] = (double)vg_key_distance(kq[j]);
+                out_rowids[(size_t)i * k + j] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(kq[j]));
+            }
+            out_counts[i] = take;
         }
         return VG_OK;
     }

@@ -130,6 +130,7 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_filter_evals) hipFree(c->d_filter_evals);
     if (c->h_filter_evals) hipHostFree(c->h_filter_evals);
     if (c->d_below) hipFree(c->d_below);
+    if (c->d_ref_prefix) hipFree(c->d_ref_prefix);
     if (c->h_ref) hipHostFree(c->h_ref);
     if (c->norm_ev) hipEventDestroy(c->norm_ev);
     if (c->d_bcand) hipFree(c->d_bcand);

@@ -34,6 +34,14 @@ struct ScanArgs {
     int dim;                   // elements per row (for the special-value slow paths)
     const float *row_nn;       // A_COSN: (float) sum x^2 per row (vg_half_rownorm_kernel); nullptr otherwise
     int store_lds_off;         // store mode: byte offset in dynamic LDS of the per-wavefront staging areas
+    // ---- tie_order = reference support (vg_reforder.hip), all optional
+                               //   out_dist != nullptr with k > 0: top-k mode that ALSO writes every row's distance (the replay's prefix pass)
+    const uint64_t *init_keys; // the k best of a scan over the rows in front (64 keys) or nullptr: key k-1 is every list's start threshold
+    unsigned long long *emit;  // [count | emit_cap pairs]: every row a list accepts whose distance is strictly below init_keys' k-th
+                               //   distance is appended as (position << 32 | float bits) - a superset of the rows that can enter the
+                               //   reference's k slots (it is below the k-th best of SOME earlier rows, hence possibly of all of them)
+    unsigned emit_cap;
+    unsigned long long *emit_reset;   // zeroed by this launch's first thread (the prefix pass resets the counter of the pass behind it)
 };
 
 // ------------------------------------------------------------------------------------------ keys
@@ -78,12 +86,23 @@ __device__ inline uint64_t vg_wave_shr1(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-__device__ inline void vg_list_insert(uint64_t &mine, uint64_t &thr, uint64_t c, int lane, int k) {
+// thr_cap: a start threshold from elsewhere (the k-th best of rows scanned by an earlier pass) keeps bounding thr while the list
+// itself holds fewer than k keys
+__device__ inline void vg_list_insert(uint64_t &mine, uint64_t &thr, uint64_t c, int lane, int k, uint64_t thr_cap = VG_EMPTY_KEY) {
     const uint64_t prev = vg_wave_shr1(mine);        // lane 0 sees 0, which is never > c
     const bool gt = mine > c;
     const bool pgt = prev > c;
     mine = gt ? (pgt ? prev : c) : mine;
-    thr = vg_readlane64(mine, k - 1);
+    const uint64_t kth = vg_readlane64(mine, k - 1);
+    thr = kth < thr_cap ? kth : thr_cap;
+}
+
+// tie_order = reference: one (position, distance) pair appended to the candidate stream (wave-uniform arguments, one lane writes)
+__device__ inline void vg_emit_pair(unsigned long long *emit, unsigned cap, uint64_t key, int lane) {
+    if (lane == 0) {
+        const unsigned long long slot = atomicAdd(emit, 1ull);
+        if (slot < cap) emit[1 + slot] = ((key & 0xFFFFFFFFull) << 32) | (unsigned long long)__float_as_uint(vg_sortable_f32((uint32_t)(key >> 32)));
+    }
 }
 
 // Offer one candidate per lane (valid lanes only).  Expected cost ~0 once thr has tightened.
@@ -95,6 +114,47 @@ __device__ inline void vg_list_offer(uint64_t key, bool valid, uint64_t &mine, u
         uint64_t c = vg_readlane64(key, src);
         if (c < thr) vg_list_insert(mine, thr, c, lane, k);
     }
+}
+// The same with a start threshold and the reference-order candidate stream (vg_reforder.hip).  The three values involved are
+// needed only when a list accepts a key - about once per wavefront and scan - so they live in LDS, not in the scalar registers the
+// streaming loop is short of (every scan kernel sits at the 106-SGPR limit; holding them there spilled SGPRs into VGPR lanes).
+struct VgListExtras {
+    uint64_t thr_cap;            // key: the k-th best of the rows an earlier pass scanned (EMPTY: none) - bounds thr while a list is short
+    uint64_t emit_below;         // accepted keys below this are emitted (0: nothing is)
+    unsigned long long *emit;    // [count | emit_cap pairs] or nullptr
+    unsigned long long emit_cap;
+};
+__device__ inline uint64_t vg_uniform64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+// ex points into LDS (filled before the workgroup's first barrier)
+__device__ inline void vg_list_offer_ex(uint64_t key, bool valid, uint64_t &mine, uint64_t &thr, int lane, int k, const VgListExtras *ex) {
+    unsigned long long m = __ballot(valid && key < thr);
+    while (m) {
+        int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        uint64_t c = vg_readlane64(key, src);
+        if (c < thr) {
+            vg_list_insert(mine, thr, c, lane, k, vg_uniform64(ex->thr_cap));
+            if (c < vg_uniform64(ex->emit_below))
+                vg_emit_pair(reinterpret_cast<unsigned long long *>(vg_uniform64((uint64_t)ex->emit)), (unsigned)ex->emit_cap, c, lane);
+        }
+    }
+}
+// fills the LDS block from a launch's arguments (one thread; the caller's next barrier publishes it) and returns the start threshold
+__device__ inline uint64_t vg_list_extras_init(VgListExtras *ex, const uint64_t *init_keys, int k, unsigned long long *emit, unsigned emit_cap) {
+    uint64_t thr_cap = VG_EMPTY_KEY, emit_below = emit ? VG_EMPTY_KEY : 0ull;    // no pass in front: everything a list accepts can enter the slots
+    if (init_keys) {
+        const uint64_t kk = init_keys[k - 1];
+        if (kk != VG_EMPTY_KEY) {                            // <= its distance enters a list, < is emitted
+            thr_cap = kk | 0xFFFFFFFFull;
+            if (emit) emit_below = kk & 0xFFFFFFFF00000000ull;
+        }
+    }
+    if (threadIdx.x == 0) { ex->thr_cap = thr_cap; ex->emit_below = emit_below; ex->emit = emit; ex->emit_cap = emit_cap; }
+    return thr_cap;
 }
 
 // Butterfly sum over the 2^lpr_log2 lanes that share a row; every lane of the group ends with the (bitwise

@@ -267,7 +267,8 @@ static long long filter_stream_stride(const vg_corpus *c, int metric) {
 }
 
 // Returns -1 when the shape is not served (caller takes the plain scan).
-int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream) {
+int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream,
+                          bool ref_emit) {
     if (!scan_filter_serves(c, metric)) return -1;
     const bool f32 = (c->vtype == VG_TYPE_F32);
     // The shadow copy and the norms cost HBM next to the corpus (see filter_uses_q8).  An f32 corpus they do not fit next to
@@ -349,7 +350,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     long long blocks = (nbatch + VG_WAVES_PER_BLOCK - 1) / VG_WAVES_PER_BLOCK;
     blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count));
     blocks = std::min<long long>(blocks, VG_SEL_MAX_HEADS);
-    FilterScanArgs a;
+    FilterScanArgs a{};
     a.shadow = n4 ? c->d_rows_n4 : (q8 ? c->d_rows_q8 : (f32 ? c->d_rows_bf : c->d_rows));
     a.q8stat = reinterpret_cast<const float2 *>(n4 ? c->d_n4stat : c->d_q8stat); a.rows = c->d_rows; a.query = dev_query; a.row_norm = c->d_xnorm; a.cand = c->d_cand;
     a.n_rows = scan_rows; a.stride = c->stride; a.bstride = bs; a.nch = c->nch; a.nch_b = nch_b;
@@ -370,16 +371,32 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     // Pre-pass: a plain scan of the first 1/64 of the rows.  Its k-th best distance bounds the final k-th best from
     // above, so no wavefront has to warm its list up from +Inf (k ln(rows per wavefront / k) exact evaluations each,
     // ~0.35 ms in all); the filter scan below still covers every row.
-    const bool prepass = env_int("VG_SCAN_FILTER_PREPASS", 1) != 0 && scan_rows >= (1 << 20);
+    // tie_order = reference (ref_emit): the pre-pass doubles as the replay's prefix pass (it also stores its rows' distances) and the
+    // filter kernel emits the later rows that can enter the reference's slots - a probing launch never does (its answer is discarded)
+    const bool emitting = ref_emit && !probing && scan_rows >= VG_REF_EMIT_MIN_ROWS;
+    const bool prepass = (env_int("VG_SCAN_FILTER_PREPASS", 1) != 0 && scan_rows >= (1 << 20)) || emitting;
     hipEvent_t *evs = probing ? nullptr : vg_prof_slot(c, (uint8_t)(VG_EVF_MERGE | (prepass ? VG_EVF_PREPASS : 0)));
     if (evs) hipEventRecord(evs[0], stream);
     a.init_keys = nullptr;
+    a.emit = nullptr;
+    a.emit_cap = 0;
     if (prepass) {
         ScanPlan pre;
         // (1/128 of the rows: 38 us instead of 60 at 10M x 384 for ~2x the exact evaluations of the 0.6 ms pass - measured, profiles/r2y)
         pre.n_rows = std::max<int64_t>(65536, scan_rows / std::max(1, env_int("VG_SCAN_FILTER_PREPASS_DIV", c->filter_prepass_div)));
+        if (scan_rows < (1 << 20)) pre.n_rows = vg_ref_prefix_for(scan_rows);      // (a pre-pass only because of the replay)
         pre.allow_filter = false;
         pre.record = false;
+        if (emitting) {
+            pre.n_rows = std::min<int64_t>(pre.n_rows, VG_REF_PREFIX_MAX);
+            const int rcb = vg_ensure_ref_buffers(c, pre.n_rows);
+            if (rcb != VG_OK) return rcb;
+            pre.store_prefix = c->d_ref_prefix;
+            pre.emit_reset = c->d_below;
+            a.emit = c->d_below;
+            a.emit_cap = VG_BELOW_CAP;
+            c->ref_prefix_rows = pre.n_rows;
+        }
         const int rcp = vg_launch_plain_scan(c, metric, dev_query, k, dev_out_keys, stream, pre);
         if (rcp != VG_OK) return rcp;
         a.init_keys = dev_out_keys;                      // read by every workgroup before the final merge overwrites it

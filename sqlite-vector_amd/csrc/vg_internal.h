@@ -72,6 +72,13 @@ struct vg_corpus {
     size_t h_ref_bytes = 0;
     std::vector<uint64_t> ref_pairs;   // its candidate pairs on the host (kept between scans: no 1 MB clear per query)
     int tie_order = 0;             // VG_TIE_POSITION / VG_TIE_REFERENCE (vg_corpus_set_tie_order)
+    // tie_order = reference, the fused form (vg_reforder.hip): a top-k scan with one more list slot; only when its k+1 best distances
+    // hold a tie does the host replay the reference's slots - over the prefix pass' distances + the candidate stream the scan emitted
+    float *d_ref_prefix = nullptr; // distances of the first ref_prefix_rows rows (written by the prefix pass: top-k + store)
+    int64_t ref_prefix_cap = 0;
+    int64_t ref_prefix_rows = -1;  // rows the LAST emitting launch stored (-1: that launch could not emit - long rows / a small corpus)
+    int ref_hot = 0;               // > 0: ties were seen recently - plain-kernel scans pay the prefix pass up front instead of a second scan
+    unsigned long long ref_stats[4] = {0, 0, 0, 0};   // reference-order scans | with a tie among the k+1 best | answered by the fused replay | by the store-mode replay
     uint64_t *d_sel_keys = nullptr, *d_sel_sorted = nullptr;   // k > 64 path: N keys, unsorted / sorted
     void *d_sel_temp = nullptr;
     uint32_t *d_sel_state = nullptr;   // radix-select state + histogram (vg_select.hip)
@@ -149,7 +156,24 @@ struct ScanPlan {
     int64_t n_rows = -1;
     bool allow_filter = true;      // false: the plain kernel of vg_scan.h whatever the corpus / the switches say
     bool record = true;            // false: no entry in the profiling ring (a pre-pass is recorded by its parent launch)
+    // tie_order = reference (vg_reforder.hip).  ref_emit: a whole-corpus top-k scan that also leaves behind what a host replay of the
+    // reference's slot algorithm needs - the distances of the first c->ref_prefix_rows rows (c->d_ref_prefix, written by a prefix pass
+    // that runs in front: top-k + store) and every later row that can enter the slots (c->d_below, emitted by the lists).
+    bool ref_emit = false;
+    float *store_prefix = nullptr;            // (the prefix pass itself) top-k mode that also stores every row's distance here ...
+    unsigned long long *emit_reset = nullptr; // ... and zeroes the candidate counter of the pass behind it
 };
+#define VG_BELOW_CAP (1 << 17)        // candidate pairs the device buffer holds (more: the store-mode replay takes over)
+#define VG_REF_EMIT_MIN_ROWS (1 << 17) // below this a reference-order scan with a tie simply replays a store-mode scan (cheap at that size)
+#define VG_REF_PREFIX_MAX (1 << 20)   // rows of the prefix pass whose distances travel to the host on a tie (4 MB of pinned memory)
+#define VG_REF_PINNED_BYTES (((size_t)VG_REF_PREFIX_MAX * 4) + ((size_t)VG_BELOW_CAP + 1) * 8)
+static inline int64_t vg_ref_prefix_for(int64_t n_rows) {
+    int64_t p = n_rows / 128;
+    if (p < 16384) p = 16384;
+    if (p > VG_REF_PREFIX_MAX) p = VG_REF_PREFIX_MAX;
+    return p;
+}
+int vg_ensure_ref_buffers(vg_corpus *c, int64_t prefix_rows);       // vg_reforder.hip: d_ref_prefix / d_below / h_ref
 
 // next slot of the profiling ring (nullptr when profiling is off)
 static inline hipEvent_t *vg_prof_slot(vg_corpus *c, uint8_t flags) {
@@ -172,7 +196,9 @@ int vg_launch_plain_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int
                          const ScanPlan &plan);                    // vg_api.hip: the plain scan + merge (the filter's pre-pass)
 int vg_launch_merge_one(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, hipStream_t stream);   // vg_api.hip
 int vg_plain_scan_shape(const vg_corpus *c, int metric, VgShape *out);   // vg_api.hip: launch shape of the plain kernel
-int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream);   // vg_filter.hip; -1: not served
+int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream,
+                          bool ref_emit = false);   // vg_filter.hip; -1: not served
+int vg_scan_topk_enqueue_plan(vg_corpus *c, int metric, const void *query, int k, bool ref_emit);   // vg_api.hip: vg_scan_topk_enqueue with the reference-order extras
 bool vg_scan_filter_would_serve(const vg_corpus *c, int metric, int k);   // vg_filter.hip: a single scan would take a filter scan right now
 bool vg_scan_filter_policy(const vg_corpus *c);      // vg_filter.hip: filter switched on for this corpus and the corpus large enough for the shadow copy to pay
 int vg_ensure_filter_counters(vg_corpus *c);         // vg_filter.hip: d_filter_evals[2] + pinned mirror

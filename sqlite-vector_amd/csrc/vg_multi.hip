@@ -78,7 +78,7 @@ int vg_launch_scan_multi(vg_corpus *c, int metric, const uint8_t *dev_queries, i
     blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count));
     blocks = std::min<long long>(blocks, VG_SEL_MAX_HEADS);
     if (c->append_pending && stream != c->stream) HIP_TRY(hipStreamWaitEvent(stream, c->append_ev, 0));
-    ScanArgs a;
+    ScanArgs a{};
     a.rows = c->d_rows; a.query = dev_queries; a.cand = dev_cand; a.out_dist = nullptr; a.n_rows = c->n_rows;
     a.stride = c->stride; a.nch = c->nch; a.lpr_log2 = s.lpr_log2; a.k = k; a.root = (metric == VG_DIST_L2) ? 1 : 0;
     a.dim = c->dim; a.row_nn = nullptr; a.store_lds_off = 0;

@@ -9,7 +9,6 @@
 #include "vg_internal.h"
 #include "vg_refslots.h"
 
-#define VG_BELOW_CAP (1 << 17)          // candidate pairs the device buffer holds (more: the host replays a stretch itself)
 
 // out[0] = number of rows with dist < bound in [from, n) (may exceed cap), out[1 + i] = (position << 32) | float bits
 __global__ __launch_bounds__(256) void vg_below_kernel(const float *dist, long long from, long long n, float bound,
@@ -52,7 +51,6 @@ __global__ __launch_bounds__(256) void vg_below_kernel(const float *dist, long l
     }
 }
 
-#define VG_REF_PINNED_BYTES ((size_t)4 << 20)
 static int ensure_ref_pinned(vg_corpus *c) {
     if (c->h_ref) return VG_OK;
     HIP_TRY(hipHostMalloc(&c->h_ref, VG_REF_PINNED_BYTES));
@@ -130,12 +128,9 @@ struct CorpusSrc {
 };
 }
 
-extern "C" int vg_scan_topk_reference(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist,
-                                      int *out_count) {
-    if (!c || !query || !out_count) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_reference: NULL argument");
-    *out_count = 0;
-    if (k <= 0 || c->n_rows == 0) return VG_OK;
-    if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_reference: NULL output");
+// the store-mode replay (round 2's form): one scan that writes all N distances, host replay of a prefix, device compaction of the
+// later rows below the bound.  Still what serves k >= 64, long rows, small corpora with a tie and candidate-buffer overflows.
+static int reference_store_mode_replay(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist, int *out_count) {
     int rc = vg_scan_distances_resident(c, metric, query);
     if (rc != VG_OK) return rc;
     CorpusSrc src{c, c->ref_pairs};
@@ -148,6 +143,122 @@ extern "C" int vg_scan_topk_reference(vg_corpus *c, int metric, const void *quer
         out_rowids[i] = vg_corpus_rowid_at(c, slots.pos[(size_t)i]);
     }
     *out_count = cnt;
+    ++c->ref_stats[3];
+    return VG_OK;
+}
+
+int vg_ensure_ref_buffers(vg_corpus *c, int64_t prefix_rows) {
+    if (c->ref_prefix_cap < prefix_rows) {
+        if (c->d_ref_prefix) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->d_ref_prefix); c->d_ref_prefix = nullptr; c->ref_prefix_cap = 0; }
+        HIP_TRY(hipMalloc(&c->d_ref_prefix, (size_t)prefix_rows * sizeof(float)));
+        c->ref_prefix_cap = prefix_rows;
+    }
+    if (!c->d_below) HIP_TRY(hipMalloc(&c->d_below, (size_t)(VG_BELOW_CAP + 1) * sizeof(unsigned long long)));
+    return ensure_ref_pinned(c);
+}
+
+// The reference's slots replayed over what the last emitting launch left on the device: the prefix pass' distances (rows 0 .. P-1, all
+// of them) and the candidate stream (every later row that can enter the slots; a superset, in any order).  1 = the stream overflowed.
+static int replay_emitted(vg_corpus *c, int k, VgRefSlots &slots) {
+    const int64_t P = c->ref_prefix_rows;
+    float *prefix = reinterpret_cast<float *>(c->h_ref);
+    unsigned long long *head = reinterpret_cast<unsigned long long *>(c->h_ref + (size_t)VG_REF_PREFIX_MAX * 4);
+    const size_t first = 8191;
+    HIP_TRY(hipMemcpyAsync(prefix, c->d_ref_prefix, (size_t)P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(head, c->d_below, (first + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const unsigned long long count = head[0];
+    if (count > (unsigned long long)VG_BELOW_CAP) return 1;
+    if (count > first) {
+        HIP_TRY(hipMemcpyAsync(head + 1 + first, c->d_below + 1 + first, (size_t)(count - first) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    slots.init(k);
+    // the prefix: nearly every row is no candidate once the slots are warm - look at 16 rows at a time (a min the compiler vectorises)
+    int64_t i = 0;
+    for (; i + 16 <= P; i += 16) {
+        float m = prefix[i];
+        for (int j = 1; j < 16; ++j) m = prefix[i + j] < m ? prefix[i + j] : m;     // (NaN never wins: it cannot enter either)
+        if (!((double)m < slots.cur_max) && !(prefix[i] != prefix[i])) continue;     // (a leading NaN would hide the rest: take the slow way)
+        for (int j = 0; j < 16; ++j) slots.offer(prefix[i + j], i + j);
+    }
+    for (; i < P; ++i) slots.offer(prefix[i], i);
+    // the rows behind it, in scan order (position is the high word of a pair)
+    unsigned long long *pairs = head + 1;
+    std::sort(pairs, pairs + count);
+    for (unsigned long long j = 0; j < count; ++j) {
+        const int64_t pos = (int64_t)(pairs[j] >> 32);
+        if (pos < P) continue;                              // (the main pass covers the prefix rows again)
+        const uint32_t bits = (uint32_t)pairs[j];
+        float d;
+        memcpy(&d, &bits, 4);
+        slots.offer(d, pos);
+    }
+    return VG_OK;
+}
+
+// tie_order = reference.  The reference's result differs from (distance, position) order only when equal distances meet among the
+// k+1 best: with k+1 pairwise distinct distances its k slots end up holding exactly the k smallest, and its exchange sort of
+// distinct values is the ascending order.  So: the ordinary top-k scan with ONE MORE list slot; no tie among those k+1 -> done, the
+// same cost as tie_order = position.  A tie -> the slots are replayed on the host over the rows that can enter them at all
+// (replay_emitted), which the scan left behind at no cost: no second pass over the corpus, no N-distance store.
+extern "C" int vg_scan_topk_reference(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist,
+                                      int *out_count) {
+    if (!c || !query || !out_count) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_reference: NULL argument");
+    *out_count = 0;
+    if (k <= 0 || c->n_rows == 0) return VG_OK;
+    if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_reference: NULL output");
+    if (vg_metric_to_acc(metric) < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
+    ++c->ref_stats[0];
+    if (k + 1 > 64 || env_int("VG_REF_STORE_MODE", 0)) return reference_store_mode_replay(c, metric, query, k, out_rowids, out_dist, out_count);
+    const int k1 = k + 1;
+    const bool can_emit = c->n_rows >= VG_REF_EMIT_MIN_ROWS;
+    // scans through a filter kernel have a pre-pass anyway (emitting is free); plain-kernel scans pay for one only while ties are around
+    bool emit = can_emit && (c->ref_hot > 0 || vg_scan_filter_would_serve(c, metric, k1) || env_int("VG_REF_ALWAYS_EMIT", 0));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        uint64_t keys[64];
+        int rc = vg_scan_topk_enqueue_plan(c, metric, query, k1, emit);
+        if (rc == VG_OK) rc = vg_scan_topk_collect(c, keys);
+        if (rc != VG_OK) return rc;
+        int cnt = 0;
+        while (cnt < k1 && keys[cnt] != VG_KEY_EMPTY) ++cnt;
+        bool tie = false;
+        for (int i = 1; i < cnt; ++i) tie |= (keys[i] >> 32) == (keys[i - 1] >> 32);
+        if (!tie) {
+            const int take = std::min(cnt, k);
+            for (int i = 0; i < take; ++i) {
+                out_dist[i] = (double)vg_key_distance(keys[i]);
+                out_rowids[i] = vg_corpus_rowid_at(c, (int64_t)vg_key_position(keys[i]));
+            }
+            *out_count = take;
+            if (c->ref_hot > 0) --c->ref_hot;
+            return VG_OK;
+        }
+        if (attempt == 0) ++c->ref_stats[1];
+        c->ref_hot = 64;
+        if (emit && c->ref_prefix_rows > 0) {
+            VgRefSlots slots;
+            rc = replay_emitted(c, k, slots);
+            if (rc == 1) break;                             // too many candidates (heavy ties / descending distances): store mode
+            if (rc != VG_OK) return rc;
+            const int n = slots.finish();
+            for (int i = 0; i < n; ++i) {
+                out_dist[i] = slots.dist[(size_t)i];
+                out_rowids[i] = vg_corpus_rowid_at(c, slots.pos[(size_t)i]);
+            }
+            *out_count = n;
+            ++c->ref_stats[2];
+            return VG_OK;
+        }
+        if (emit || !can_emit) break;                       // this corpus cannot emit (long rows, small): store mode
+        emit = true;                                        // a tie and nothing emitted: scan again, emitting
+    }
+    return reference_store_mode_replay(c, metric, query, k, out_rowids, out_dist, out_count);
+}
+
+extern "C" int vg_corpus_tie_stats(const vg_corpus *c, unsigned long long *out4) {
+    if (!c || !out4) return vg_fail(VG_ERR_INVALID, "vg_corpus_tie_stats: NULL argument");
+    for (int i = 0; i < 4; ++i) out4[i] = c->ref_stats[i];
     return VG_OK;
 }
 

@@ -62,9 +62,14 @@ __device__ inline void vg_load_batch(uint4 (&dst)[U], const uint8_t *rows, long 
 #endif
 #define VG_STORE_FLOATS 1024          // store mode: distances parked in LDS per wavefront between bursts of stores
 
-template <int VT, int ACC, int U, bool NT>
+// EX = true: the variants tie_order = reference needs (vg_reforder.hip) - a start threshold from a pass over the rows in front
+// (init_keys), the candidate stream (emit) and "top-k + store" (out_dist != nullptr with k > 0: the replay's prefix pass).  They are
+// instantiations of their own (vg_scan_ex.hip) because the plain kernels sit AT the 128-VGPR / 106-SGPR limit of 16 wavefronts per
+// CU: the few registers the extras take spilled f32 U = 8 and f16 U = 6, shapes the plain scans use.
+template <int VT, int ACC, int U, bool NT, bool EX = false>
 __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ VgListExtras ex;
     const int lane = threadIdx.x & (VG_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     const int lpr_log2 = a.lpr_log2;
@@ -76,6 +81,15 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
     // ---- query: global -> LDS (once per workgroup) -> VGPRs
     uint4 *qs = reinterpret_cast<uint4 *>(smem);
     for (int c = threadIdx.x; c < a.nch; c += VG_BLOCK) qs[c] = reinterpret_cast<const uint4 *>(a.query)[c];
+    // ---- candidate list (top-k mode).  tie_order = reference (vg_reforder.hip): a start threshold from the pass over the rows in
+    // front and the candidate stream - kept in LDS (`ex`), published by the same barrier as the query
+    const int k = a.k;
+    uint64_t mine = VG_EMPTY_KEY;
+    uint64_t thr = VG_EMPTY_KEY;
+    if constexpr (EX) {
+        if (k > 0) thr = vg_list_extras_init(&ex, a.init_keys, k, a.emit, a.emit_cap);
+        if (a.emit_reset && blockIdx.x == 0 && threadIdx.x == 0) *a.emit_reset = 0ull;
+    }
     __syncthreads();
     uint4 q[U];
 #pragma unroll
@@ -84,11 +98,8 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
         q[u] = (c < a.nch) ? qs[c] : make_uint4(0u, 0u, 0u, 0u);
     }
     const typename Accum<VT, ACC>::QStat qstat = Accum<VT, ACC>::template query_stat<U>(q, lpr_log2);
-
-    // ---- candidate list (top-k mode)
-    uint64_t mine = VG_EMPTY_KEY, thr = VG_EMPTY_KEY;
-    const int k = a.k;
-    const bool store_mode = (a.out_dist != nullptr);
+    const bool store_mode = EX ? ((a.out_dist != nullptr) && k == 0) : (a.out_dist != nullptr);
+    const bool store_too = EX && (a.out_dist != nullptr) && k != 0; // the reference replay's prefix pass: top-k + every distance
 
     // ---- loop over row batches, one batch prefetched.  Top-k mode: grid-stride (batch b, b + W, ...).  Store mode:
     // each wavefront owns a CONTIGUOUS run of batches, parks VG_STORE_FLOATS distances in LDS and writes them out in
@@ -163,6 +174,9 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
                 in_line = 0;
                 line_row0 = (bcur + wstride) * rpb;
             }
+        } else if constexpr (EX) {
+            if (store_too && owner) a.out_dist[row] = d;
+            vg_list_offer_ex(vg_make_key(d, (uint32_t)row), owner && (d < INFINITY), mine, thr, lane, k, &ex);
         } else {
             // NaN and +Inf never enter (strict '<' against INFINITY-initialised slots, sqlite-vector.c:1809,2102)
             vg_list_offer(vg_make_key(d, (uint32_t)row), owner && (d < INFINITY), mine, thr, lane, k);

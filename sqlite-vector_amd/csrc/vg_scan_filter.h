@@ -57,6 +57,8 @@ struct FilterScanArgs {
     const uint64_t *init_keys; // the k best of a plain scan over the first rows (64 keys) or nullptr: its k-th distance is
                                //   an upper bound of the final k-th best - the lists do not have to warm up from +Inf
     unsigned long long *evals; // instrumentation: += exact evaluations of this launch (one atomic per workgroup)
+    unsigned long long *emit;  // tie_order = reference (vg_reforder.hip): [count | emit_cap pairs] - every row a list accepts whose distance
+    unsigned emit_cap;         //   is strictly below init_keys' k-th distance, as (position << 32 | float bits); nullptr = off
 };
 enum { VGF_L2 = 0, VGF_DOT = 1, VGF_COS = 2, VGF_L1 = 3 /* f16 / bf16 only */ };
 
@@ -283,9 +285,10 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
         return t2 * (1.0f + 2.0f * a.rel) + 1e-30f;
     };
     float gate_init = INFINITY;
+    uint64_t emit_below = VG_EMPTY_KEY;                                   // (no pass in front: every accepted row may enter the slots)
     if (a.init_keys) {
         const uint64_t kk = a.init_keys[k - 1];
-        if (kk != VG_EMPTY_KEY) gate_init = gate_of(vg_sortable_f32((uint32_t)(kk >> 32)));
+        if (kk != VG_EMPTY_KEY) { gate_init = gate_of(vg_sortable_f32((uint32_t)(kk >> 32))); emit_below = kk & 0xFFFFFFFF00000000ull; }
     }
     float thr_gate = gate_init;
     auto refresh_gate = [&]() {
@@ -398,6 +401,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
                 if (de < INFINITY && key < thr) {    // NaN / +Inf never enter (sqlite-vector.c:2102)
                     vg_list_insert(mine, thr, key, lane, k);
                     refresh_gate();
+                    if (a.emit && key < emit_below) vg_emit_pair(a.emit, a.emit_cap, key, lane);
                 }
             }
         }

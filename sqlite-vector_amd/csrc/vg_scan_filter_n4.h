@@ -78,9 +78,10 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_n4_kernel(FilterScanA
         return t2 * (1.0f + 2.0f * a.rel) + 1e-30f;
     };
     float gate_init = INFINITY;
+    uint64_t emit_below = VG_EMPTY_KEY;                                   // (no pass in front: every accepted row may enter the slots)
     if (a.init_keys) {
         const uint64_t kk = a.init_keys[k - 1];
-        if (kk != VG_EMPTY_KEY) gate_init = gate_of(vg_sortable_f32((uint32_t)(kk >> 32)));
+        if (kk != VG_EMPTY_KEY) { gate_init = gate_of(vg_sortable_f32((uint32_t)(kk >> 32))); emit_below = kk & 0xFFFFFFFF00000000ull; }
     }
     float thr_gate = gate_init;
     auto refresh_gate = [&]() {
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_n4_kernel(FilterScanA
                 if (de < INFINITY && key < thr) {    // NaN / +Inf never enter (sqlite-vector.c:2102)
                     vg_list_insert(mine, thr, key, lane, k);
                     refresh_gate();
+                    if (a.emit && key < emit_below) vg_emit_pair(a.emit, a.emit_cap, key, lane);
                 }
             }
         }

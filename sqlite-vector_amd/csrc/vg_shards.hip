@@ -232,9 +232,12 @@ struct Cand { uint32_t img; int64_t gpos; int shard; uint32_t local; };
 
 static inline bool cand_less(const Cand &a, const Cand &b) { return a.img != b.img ? a.img < b.img : a.gpos < b.gpos; }
 
-// merge per-shard ascending key lists (list i = shard i, `len` keys each, `counts[i]` valid) into the global top-k
+// merge per-shard ascending key lists (list i = shard i, `len` keys each, `counts[i]` valid) into the global top-k.
+// ref_k >= 0: the lists were taken with one more slot than asked for (tie_order = reference, see vg_scan_topk_reference): when the
+// best ref_k + 1 distances are pairwise distinct the reference's own result IS the first ref_k in ascending order and that is what
+// comes back; when they hold a tie nothing is written and -1 comes back (the caller replays the reference's slots).
 static int merge_lists(const vg_shards *s, const uint64_t *keys, int len, const int *counts, int k, int64_t *out_rowids,
-                       double *out_dist) {
+                       double *out_dist, int ref_k = -1) {
     std::vector<Cand> all;
     for (int i = 0; i < s->S; ++i)
         for (int j = 0; j < counts[i]; ++j) {
@@ -243,8 +246,12 @@ static int merge_lists(const vg_shards *s, const uint64_t *keys, int len, const 
             const uint32_t local = vg_key_position(key);
             all.push_back(Cand{(uint32_t)(key >> 32), global_of(s, i, (int64_t)local), i, local});
         }
-    const size_t take = std::min<size_t>((size_t)k, all.size());
+    size_t take = std::min<size_t>((size_t)k, all.size());
     std::partial_sort(all.begin(), all.begin() + (long)take, all.end(), cand_less);
+    if (ref_k >= 0) {
+        for (size_t i = 1; i < take; ++i) if (all[i].img == all[i - 1].img) return -1;
+        take = std::min<size_t>(take, (size_t)ref_k);
+    }
     for (size_t i = 0; i < take; ++i) {
         out_dist[i] = (double)vg_key_distance((uint64_t)all[i].img << 32);
         out_rowids[i] = vg_corpus_rowid_at(s->sh[(size_t)all[i].shard], (int64_t)all[i].local);
@@ -329,19 +336,24 @@ extern "C" int vg_shards_scan_topk(vg_shards *s, int metric, const void *query, 
     if (s->S == 1) return vg_scan_topk(s->sh[0], metric, query, k, out_rowids, out_dist, out_count);
     if (k <= 0 || s->n_rows == 0) return VG_OK;
     if (!out_rowids || !out_dist) return fail(VG_ERR_INVALID, "vg_shards_scan_topk: NULL output");
-    if (s->tie_order == VG_TIE_REFERENCE) return shards_scan_topk_reference(s, metric, query, k, out_rowids, out_dist, out_count);
+    const bool ref = s->tie_order == VG_TIE_REFERENCE;
+    if (ref && k + 1 > VG_WAVE_KEYS) return shards_scan_topk_reference(s, metric, query, k, out_rowids, out_dist, out_count);
     if (k <= VG_WAVE_KEYS) {
-        // every shard in flight before the first wait: S scans run concurrently, one host thread
+        // every shard in flight before the first wait: S scans run concurrently, one host thread.  tie_order = reference: one more
+        // list slot; only a tie among the k + 1 best sends the query to the replay (vg_scan_topk_reference explains why)
+        const int kk = ref ? k + 1 : k;
         std::vector<uint64_t> keys((size_t)s->S * VG_WAVE_KEYS);
         std::vector<int> counts((size_t)s->S, VG_WAVE_KEYS);
         int rc = VG_OK;
-        for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue(s->sh[(size_t)i], metric, query, k);
+        for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue(s->sh[(size_t)i], metric, query, kk);
         for (int i = 0; i < s->S; ++i) {
             int rc2 = vg_scan_topk_collect(s->sh[(size_t)i], &keys[(size_t)i * VG_WAVE_KEYS]);
             if (rc == VG_OK) rc = rc2;
         }
         if (rc != VG_OK) return rc;
-        *out_count = merge_lists(s, keys.data(), VG_WAVE_KEYS, counts.data(), k, out_rowids, out_dist);
+        const int got = merge_lists(s, keys.data(), VG_WAVE_KEYS, counts.data(), kk, out_rowids, out_dist, ref ? k : -1);
+        if (got < 0) return shards_scan_topk_reference(s, metric, query, k, out_rowids, out_dist, out_count);
+        *out_count = got;
         return VG_OK;
     }
     const int kk = (int)std::min<int64_t>((int64_t)k, s->n_rows);
@@ -363,16 +375,9 @@ extern "C" int vg_shards_scan_topk_batch(vg_shards *s, int metric, const void *q
     for (int i = 0; i < nq; ++i) out_counts[i] = 0;
     if (k <= 0 || s->n_rows == 0) return VG_OK;
     if (!out_rowids || !out_dist) return fail(VG_ERR_INVALID, "vg_shards_scan_topk_batch: NULL output");
-    if (s->tie_order == VG_TIE_REFERENCE) {                // the reference's order is defined per scan
-        const size_t qbytes = (size_t)s->dim * s->es;
-        for (int q = 0; q < nq; ++q) {
-            int rc1 = shards_scan_topk_reference(s, metric, (const uint8_t *)queries + (size_t)q * qbytes, k, out_rowids + (size_t)q * k,
-                                                 out_dist + (size_t)q * k, &out_counts[q]);
-            if (rc1 != VG_OK) return rc1;
-        }
-        return VG_OK;
-    }
-    const int kk = (int)std::min<int64_t>((int64_t)k, s->n_rows);
+    const bool ref = s->tie_order == VG_TIE_REFERENCE;      // (one more list slot; only the queries with a tie are replayed one by one)
+    const size_t qbytes = (size_t)s->dim * s->es;
+    const int kk = (int)std::min<int64_t>((int64_t)k + (ref ? 1 : 0), s->n_rows);
     std::vector<uint64_t> keys((size_t)s->S * nq * kk);
     std::vector<int> counts((size_t)s->S * nq, 0);
     int rc = for_each_shard(s, [&](int i) {
@@ -386,7 +391,13 @@ extern "C" int vg_shards_scan_topk_batch(vg_shards *s, int metric, const void *q
             memcpy(&qkeys[(size_t)i * kk], &keys[((size_t)i * nq + q) * kk], (size_t)kk * sizeof(uint64_t));
             qcounts[(size_t)i] = counts[(size_t)i * nq + q];
         }
-        out_counts[q] = merge_lists(s, qkeys.data(), kk, qcounts.data(), kk, out_rowids + (size_t)q * k, out_dist + (size_t)q * k);
+        int got = merge_lists(s, qkeys.data(), kk, qcounts.data(), kk, out_rowids + (size_t)q * k, out_dist + (size_t)q * k, ref ? k : -1);
+        if (got < 0) {
+            int rc1 = shards_scan_topk_reference(s, metric, (const uint8_t *)queries + (size_t)q * qbytes, k, out_rowids + (size_t)q * k,
+                                                 out_dist + (size_t)q * k, &got);
+            if (rc1 != VG_OK) return rc1;
+        }
+        out_counts[q] = got;
     }
     return VG_OK;
 }

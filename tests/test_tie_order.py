@@ -142,3 +142,80 @@ def test_reference_tie_order_when_candidates_overflow_the_device_buffer(pkg, orc
         want_ids, want_d = orc.topk_reference(c.scan_distances(dg.L1, q), None, k)
         assert got_ids.tolist() == want_ids.tolist() and np.array_equal(got_d, want_d)
     c.close()
+
+
+@pytest.mark.gpu
+def test_fused_reference_order_costs_a_replay_only_when_the_k_plus_1_best_hold_a_tie(pkg, orc):
+    """the round-3 form of tie_order = reference: the ordinary top-k scan with one more list slot.  Distinct distances among the
+    k + 1 best -> no replay at all (counters), and the answer is the (distance, position) answer = the reference's.  A tie -> the
+    fused replay (prefix pass + the candidates the scan emitted), not a second pass over the corpus."""
+    n, dim, k = 300_000, 32, 20
+    rows = dg.corpus(dg.U8, n, dim, 901)
+    q = dg.query(dg.U8, dim, 902)
+    c = pkg.Corpus(dg.U8, dim)
+    c.append(rows)
+    c.set_tie_order(pkg.TIE_REFERENCE)
+    dist = c.scan_distances(dg.COSINE, q)
+    top = np.sort(dist)[:k + 1]
+    assert len(np.unique(top)) == k + 1                                     # (random bytes, cosine: no tie up there)
+    before = c.tie_stats()
+    ids, d = c.scan_topk(dg.COSINE, q, k)
+    after = c.tie_stats()
+    want_ids, want_d = orc.topk_reference(dist, None, k)
+    assert ids.tolist() == want_ids.tolist() and np.array_equal(d, want_d)
+    assert after["scans"] == before["scans"] + 1 and after["with_a_tie_among_the_k_plus_1_best"] == before["with_a_tie_among_the_k_plus_1_best"]
+    # plant exact copies of the best rows: ties among the k + 1 best, resolved by the fused replay
+    rows2 = rows.copy()
+    best = (want_ids[:3] - 1).tolist()
+    rows2[[1000, 150_000, 299_999]] = rows[best]
+    rows2[[7, 8]] = rows[best[0]]
+    c2 = pkg.Corpus(dg.U8, dim)
+    c2.append(rows2)
+    c2.set_tie_order(pkg.TIE_REFERENCE)
+    for metric in (dg.COSINE, dg.L2, dg.DOT, dg.L1):
+        dist2 = c2.scan_distances(metric, q)
+        for kk in (1, 5, 20, 63):
+            ids2, d2 = c2.scan_topk(metric, q, kk)
+            w_ids, w_d = orc.topk_reference(dist2, None, kk)
+            assert ids2.tolist() == w_ids.tolist() and np.array_equal(d2, w_d), (metric, kk)
+    st = c2.tie_stats()
+    assert st["fused_replays"] >= 4 and st["store_mode_replays"] == 0, st
+    c.close()
+    c2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vt", (dg.F32, dg.F16, dg.U8))
+def test_reference_order_through_the_filter_scans(pkg, orc, vt, monkeypatch):
+    """the filter kernels (int8 shadow copy for f32 / f16, high nibbles for uint8) emit the replay's candidates themselves and
+    their pre-pass doubles as its prefix pass: tie-heavy corpora answered in the reference's order, no store-mode scan"""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    n, dim, k = 400_000, 64, 20
+    rng = np.random.default_rng(77 + vt)
+    rows = dg.corpus(vt, n, dim, 910 + vt)
+    q = rows[12345].copy()
+    # duplicates of the query's row and of a near row, spread over the scan: ties at distance 0 and at the next distance
+    near = rows[54321].copy()
+    rows[[5, 99_999, 250_000, 399_998]] = q
+    rows[[6, 100_001, 300_000]] = near
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    c.set_scan_filter(1)
+    c.set_tie_order(pkg.TIE_REFERENCE)
+    for metric in (dg.L2, dg.COSINE, dg.DOT):
+        ids0, _ = c.scan_topk(metric, q, k)                                 # (builds the shadow copy)
+        assert c.kernel_name(metric).startswith("scan_filter"), c.kernel_name(metric)
+        dist = c.scan_distances(metric, q)
+        for kk in (3, 20, 40):
+            ids, d = c.scan_topk(metric, q, kk)
+            w_ids, w_d = orc.topk_reference(dist, None, kk)
+            assert ids.tolist() == w_ids.tolist() and np.array_equal(d, w_d), (vt, metric, kk)
+    st = c.tie_stats()
+    assert st["fused_replays"] >= 3 and st["store_mode_replays"] == 0, st
+    # batches: the matrix-core pass with one more slot, only tie queries are answered again one by one
+    qs = np.stack([q, rows[777], near, rows[31]])
+    bi, bd, bc = c.scan_topk_batch(dg.L2, qs, k)
+    for j in range(len(qs)):
+        w_ids, w_d = orc.topk_reference(c.scan_distances(dg.L2, qs[j]), None, k)
+        assert bi[j][:bc[j]].tolist() == w_ids.tolist() and np.array_equal(bd[j][:bc[j]], w_d), (vt, j)
+    c.close()
