@@ -13,8 +13,9 @@
  * extension itself links only against libc/libdl and talks to SQLite through sqlite3_api_routines.
  *
  * Deliberate deviations from the reference (documented in DESIGN.md):
- *   - result order among EQUAL distances is scan order unless tie_order=reference is set (vector_init option /
- *     VECTORGPU_TIE_ORDER): then the reference's slot-history dependent result is reproduced rowid for rowid;
+ *   - result order among EQUAL distances: the reference's own slot-history dependent result, rowid for rowid, for integer
+ *     element types (quantized scans, INT8 / UINT8 columns) by default; (distance, scan position) for float columns
+ *     (vector_init option tie_order=reference|position / VECTORGPU_TIE_ORDER, see tie_order_for());
  *   - the *_stream modules emit exactly the N rows (the reference emits a spurious leading (0, 0.0) row because
  *     xFilter never advances, sqlite-vector.c:1790-1792);
  *   - the JSON query vector is freed (the reference leaks it, :1771).
@@ -203,21 +204,24 @@ typedef struct {
                                    freshness for UPDATE / DELETE through sqlite3_update_hook - see on_row_change() */
 } vec_options;
 
-/* Result order among EQUAL distances.  tie_order=reference replays the reference's slot algorithm: rowids and order
- * identical to sqlite-vector.c:2022-2069,2102-2106 (one store-mode scan + a host replay of the few rows that can enter;
- * batch TVFs then run one such scan per query).  tie_order=position (the default) is (distance, scan position): the fused
- * top-k scan and the matrix-core batch kernels.  Unset: the VECTORGPU_TIE_ORDER environment variable, else position. */
-static int tie_order_for(const vec_options *o) {
+/* Result order among EQUAL distances.  tie_order=reference is the reference's own result, rowid for rowid - its slot algorithm
+ * (sqlite-vector.c:2022-2069, 2102-2106) is history dependent among ties.  It costs what tie_order=position costs unless the k + 1
+ * best distances of a query hold a tie (then a host replay over the few rows that can enter the slots, vg_reforder.hip), so it is
+ * the DEFAULT wherever ties are routine: integer element types - every vector_quantize_scan, and full scans of INT8 / UINT8
+ * columns (north_star: "bit-exact rowid/top-k ordering for int8/uint8").  Float columns default to (distance, scan position):
+ * their distances differ from the reference's in the last bits anyway (f32 <= 1e-5), exact ties are duplicates.
+ * Explicit: the tie_order= option, else the VECTORGPU_TIE_ORDER environment variable. */
+static int tie_order_for(const vec_options *o, int vtype) {
     if (o->tie_order >= 0) return o->tie_order;
     const char *e = getenv("VECTORGPU_TIE_ORDER");
     if (e && *e) return !strcasecmp(e, "reference") ? VG_TIE_REFERENCE : VG_TIE_POSITION;
-    return VG_TIE_POSITION;
+    return (vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8) ? VG_TIE_REFERENCE : VG_TIE_POSITION;
 }
 
 static int corpus_open_spec(const vec_options *o, int vtype, int dim, vg_shards **out) {
     int rc = corpus_open_devices(o->gpu_devices, o->gpu_shard_rows, vtype, dim, out);
     if (rc != VG_OK) return rc;
-    if ((rc = G.corpus_set_tie_order(*out, tie_order_for(o))) != VG_OK ||
+    if ((rc = G.corpus_set_tie_order(*out, tie_order_for(o, vtype))) != VG_OK ||
         (rc = G.corpus_set_scan_filter(*out, o->scan_filter)) != VG_OK) {
         G.corpus_destroy(*out);
         *out = NULL;
@@ -1070,7 +1074,8 @@ static void fn_vector_init(sqlite3_context *ctx, int argc, sqlite3_value **argv)
             vg_shards *hs[2] = {t->full, t->quant};
             for (int i = 0; i < 2; ++i) {
                 if (!hs[i]) continue;
-                G.corpus_set_tie_order(hs[i], tie_order_for(&t->opt));
+                /* t->quant always holds uint8 / int8 records; t->full the column's own type */
+                G.corpus_set_tie_order(hs[i], tie_order_for(&t->opt, i == 1 ? VG_TYPE_U8 : t->opt.v_type));
                 G.corpus_set_scan_filter(hs[i], t->opt.scan_filter);
             }
         }

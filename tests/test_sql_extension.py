@@ -187,9 +187,13 @@ def _check_vs_golden(got, want_ids, want_dist_bits, exact):
         assert dg.same_float_bits(dist, want)
     else:
         assert np.allclose(dist, want, rtol=1e-5, atol=1e-6)
-    # default tie order (distance, scan position): rowids must match wherever the distance is unique in the result and
-    # below the last distance (a row tying with the LAST one may be left out of the result on either side) - checked
-    # unconditionally; tie_order=reference is held to ALL rowids (test_reference_tie_order_matches_golden_rowids)
+    if exact:
+        # integer element types (bit-exact distances): the DEFAULT result order is the reference's own (tie_order=reference,
+        # vector_ext.c tie_order_for) - EVERY rowid of the reference extension's output, in its order, ties included
+        assert ids == [int(x) for x in want_ids]
+        return
+    # float columns default to (distance, scan position): rowids must match wherever the distance is unique in the result and
+    # below the last distance (a row tying with the LAST one may be left out of the result on either side)
     uniq = [i for i in range(len(want)) if np.sum(want == want[i]) == 1 and want[i] < want[-1]]
     assert [ids[i] for i in uniq] == [int(want_ids[i]) for i in uniq]
 
@@ -264,15 +268,18 @@ def test_vector_quantize_scan_vs_reference_golden(ext_path, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [c for c in mg.SQL_SCAN_CASES if c[1] in (dg.U8, dg.I8)] + list(mg.SQL_QUANT_CASES),
                          ids=[c[0] for c in mg.SQL_SCAN_CASES if c[1] in (dg.U8, dg.I8)] + [c[0] for c in mg.SQL_QUANT_CASES])
-@pytest.mark.parametrize("how", ("option", "env", "reinit", "shards"))
+@pytest.mark.parametrize("how", ("default", "default-shards", "option", "env", "reinit", "shards", "store-mode"))
 def test_reference_tie_order_matches_golden_rowids(ext_path, case, how, monkeypatch):
-    """tie_order=reference (vector_init option, VECTORGPU_TIE_ORDER, or a later vector_init call; one device or several
-    shards): integer distances are bit-exact, so EVERY rowid of the reference's own result must come back in its order -
-    ties included (the low-entropy cases tie constantly).  Golden = the reference extension's output."""
+    """the reference's own result order - the DEFAULT for integer element types, or asked for (vector_init option,
+    VECTORGPU_TIE_ORDER, a later vector_init call); one device or several shards; through the fused form or (VG_REF_STORE_MODE)
+    round 2's store-mode replay: integer distances are bit-exact, so EVERY rowid of the reference's own result must come back
+    in its order - ties included (the low-entropy cases tie constantly).  Golden = the reference extension's output."""
     sql = np.load(os.path.join(HERE, "golden", "sql.npz"))
     extra = ",tie_order=reference" if how in ("option", "shards") else ""
-    if how == "shards":
+    if how in ("shards", "default-shards"):
         extra += ",gpu_devices=0+0+0,gpu_shard_rows=257"
+    if how == "store-mode":
+        monkeypatch.setenv("VG_REF_STORE_MODE", "1")
     if how == "env":
         monkeypatch.setenv("VECTORGPU_TIE_ORDER", "reference")
     db = connect(ext_path)
@@ -292,7 +299,8 @@ def test_reference_tie_order_matches_golden_rowids(ext_path, case, how, monkeypa
         db.execute("SELECT vector_quantize('t','v',?)", ("qtype=%s" % qopt,)) if qopt else db.execute("SELECT vector_quantize('t','v')")
         db.execute("SELECT vector_quantize_preload('t','v')")
         fn = "vector_quantize_scan"
-    if how == "reinit":                                      # staged in the default order first, then switched
+    if how == "reinit":                                      # staged in (distance, position) order first, then switched
+        db.execute("SELECT vector_init('t','v',?)", ("type=%s,dimension=%d,tie_order=position" % (TYPE_OPT[vt], dim),))
         db.execute("SELECT rowid FROM %s('t','v',?,?)" % fn, (q.tobytes(), k)).fetchall()
         db.execute("SELECT vector_init('t','v',?)", ("type=%s,dimension=%d,tie_order=reference" % (TYPE_OPT[vt], dim),))
     got = db.execute("SELECT rowid, distance FROM %s('t','v',?,?)" % fn, (q.tobytes(), k)).fetchall()
@@ -300,7 +308,7 @@ def test_reference_tie_order_matches_golden_rowids(ext_path, case, how, monkeypa
     want = sql["avx2/%s/dist" % name].view(np.float32)
     assert [g[0] for g in got] == [int(x) for x in want_ids], (name, how)
     assert dg.same_float_bits(np.array([g[1] for g in got], dtype=np.float32), want)
-    # the batch TVF in this mode is one replayed scan per query: same rows
+    # the batch TVF in this mode: the batch kernels with one more list slot, tie queries answered again one by one - same rows
     gb = db.execute("SELECT id, distance FROM %s_batch('t','v',?,?) WHERE query = 1" % fn, ((q.tobytes() * 2), k)).fetchall()
     assert [g[0] for g in gb] == [int(x) for x in want_ids]
 
