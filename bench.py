@@ -905,55 +905,86 @@ def also_c4_one_gpu(args, pkg, torch, shard, k, device_index):
 
 
 def bench_stage(args, pkg, torch):
-    """--workload stage: the two passes in front of the scans, each priced on its own bytes.
-       staging   host rows -> HBM through vg_corpus_append (pinned double buffer + H2D [+ the de-interleave kernel for the
-                 reference's [rowid | vector] record format]): bound by the host link, GB/s of row bytes
-       quantize  vector_quantize on the resident f32 corpus: vg_corpus_minmax (reads N*D*4 B) and vg_corpus_quantize_rows' kernel
-                 (reads N*D*4 B, writes N*D B) against the 8 TB/s HBM peak; the int8 shadow copy of the filter scans
-                 (vg_to_q8_kernel: reads N*D*4, writes N*(D+8)) likewise"""
+    """--workload stage: the passes in front of the scans, each priced on its own bytes.
+       staging    host rows -> HBM through vg_corpus_append (pinned double buffer + H2D) and through vg_corpus_append_records (the
+                  reference's persisted [int64 rowid | vector] records, de-interleaved on the device): bound by the host link
+       minmax     vector_quantize pass 1 over the resident f32 corpus: reads N*D*4 bytes              } kernel time from HIP events
+       quantize   vector_quantize pass 2: reads N*D*4, writes N*D (the D2H of the result is not in it) } on the corpus stream, against
+       q8_shadow  the filter scans' int8 shadow copy: reads N*D*4, writes N*(D+8)                      } the 8 TB/s HBM peak"""
     n = args.rows if args.rows else 4_000_000
     dim = 384
     rng = np.random.default_rng(5)
     host = rng.random((1 << 20, dim), dtype=np.float32)
-    out = {"metric": "staging + quantization throughput", "unit": "GB/s", "n_gpus": 1, "data": "synthetic", "dtype": "f32",
+    out = {"metric": "staging + quantization throughput", "unit": "GB/s", "n_gpus": 1, "steps": 1, "warmup": 0, "data": "synthetic",
+           "dtype": "f32", "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "config": {"workload": "stage: %d x %d f32 rows staged from host memory, then quantized on the device" % (n, dim),
                       "backend": pkg.backend_name()}}
     c = pkg.Corpus(pkg.F32, dim, capacity=n)
     c.append(host[:4096])                                   # warm: pinned buffers, stream
-    c.clear() if hasattr(c, "clear") else None
+    c.minmax()
+    c.clear()
     t0 = time.perf_counter()
     done = 0
     while done < n:
         take = min(host.shape[0], n - done)
         c.append(host[:take])
         done += take
-    c.rows                                                   # (appends are enqueued: the timing ends behind a synchronising call)
-    c.minmax()
-    t_stage_plus = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    lo, hi, neg = c.minmax()
-    t_minmax_call = time.perf_counter() - t1
-    stage_s = t_stage_plus - t_minmax_call
+    lo, hi, neg = c.minmax()                                # (appends are only enqueued: this waits for them on the same stream)
+    mm_ms, mm_rows = c.pass_ms("minmax")
+    stage_s = time.perf_counter() - t0 - mm_ms * 1e-3
     out["staging"] = {"rows": n, "bytes": n * dim * 4, "seconds": stage_s, "achieved": n * dim * 4 / stage_s / 1e9, "unit": "GB/s",
-                      "bound": "host link (PCIe): vg_corpus_append copies into a pinned bounce buffer and enqueues the H2D copy",
-                      "note": "host memcpy into the pinned buffer + H2D, overlapped; 1 host thread"}
-    times = c.stage_kernel_ms() if hasattr(c, "stage_kernel_ms") else None
-    # device passes: HIP-event times from the library
+                      "bound": "host link", "note": "vg_corpus_append: host memcpy into a pinned bounce buffer + enqueued H2D, overlapped; 1 host thread"}
+    # the reference's persisted record format: [int64 LE rowid | dim bytes], stride 8 + dim, de-interleaved by vg_repack_kernel
+    try:
+        nrec, dq = 2_000_000, 768
+        rec = np.zeros((1 << 19, 8 + dq), dtype=np.uint8)
+        rec[:, 8:] = rng.integers(0, 256, (1 << 19, dq), dtype=np.uint8)
+        rec[:, :8] = np.arange(1, (1 << 19) + 1, dtype="<i8").view(np.uint8).reshape(-1, 8)
+        cq = pkg.Corpus(pkg.U8, dq, capacity=nrec)
+        cq.append_records(rec[:1024], 1024)
+        cq.minmax()
+        cq.clear()
+        t1 = time.perf_counter()
+        done = 0
+        while done < nrec:
+            take = min(rec.shape[0], nrec - done)
+            cq.append_records(rec[:take], take)
+            done += take
+        cq.minmax()
+        qmm_ms, _ = cq.pass_ms("minmax")
+        rs = time.perf_counter() - t1 - qmm_ms * 1e-3
+        out["staging_records"] = {"rows": nrec, "bytes": nrec * (8 + dq), "seconds": rs, "achieved": nrec * (8 + dq) / rs / 1e9,
+                                  "unit": "GB/s", "bound": "host link",
+                                  "note": "vg_corpus_append_records: [rowid | vector] records of vector0_<t>_<c>, de-interleaved on the device"}
+        cq.close()
+    except Exception as e:
+        out["staging_records"] = {"error": repr(e)}
     res = {}
-    if hasattr(c, "quant_pass_ms"):
-        mm_ms = c.quant_pass_ms("minmax")
-        scale = 255.0 / (hi - lo) if hi > lo else 1.0
-        c.quantize_rows(scale, lo, pkg.QUANT_U8, 0, min(n, 1 << 20))
-        q_ms, q_rows = c.quant_pass_ms("quantize"), min(n, 1 << 20)
-        res["minmax"] = {"kernel": "vg_minmax_kernel", "kernel_ms": mm_ms, "bytes": n * dim * 4,
-                         "achieved": n * dim * 4 / (mm_ms * 1e-3) / 1e9 if mm_ms > 0 else 0.0}
-        res["quantize"] = {"kernel": "vg_quantize_kernel", "kernel_ms": q_ms, "rows": q_rows, "bytes": q_rows * dim * 5,
-                           "achieved": q_rows * dim * 5 / (q_ms * 1e-3) / 1e9 if q_ms > 0 else 0.0}
-        for v in res.values():
-            v.update({"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": v["achieved"] / HBM_PEAK_GBS})
+
+    def priced(kernel, ms, nbytes, rows):
+        ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"kernel": kernel, "kernel_ms": ms, "rows": rows, "bytes": nbytes, "bound": "hbm", "achieved": ach,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+
+    res["minmax"] = priced("vg_minmax_kernel<f32>", mm_ms, mm_rows * dim * 4, mm_rows)
+    scale = 255.0 / (hi - lo) if hi > lo else 1.0
+    c.quantize_rows(scale, lo, pkg.QUANT_U8, 0, n)
+    q_ms, q_rows = c.pass_ms("quantize")
+    res["quantize"] = priced("vg_quantize_kernel<f32>", q_ms, q_rows * dim * 5, q_rows)
+    try:
+        os.environ["VG_SCAN_FILTER_MIN_MB"] = "0"
+        c.set_scan_filter(1)
+        c.set_profiling(True)
+        c.scan_topk(1, host[0], args.k)                      # the first filter scan builds the shadow copy
+        s_ms, s_rows = c.pass_ms("q8_shadow")
+        res["q8_shadow"] = priced("vg_to_q8_reg_kernel<f32>", s_ms, s_rows * (dim * 4 + dim + 8), s_rows)
+    except Exception as e:
+        res["q8_shadow"] = {"error": repr(e)}
+    finally:
+        os.environ.pop("VG_SCAN_FILTER_MIN_MB", None)
     out["quantize"] = res
     out["value"] = out["staging"]["achieved"]
-    out["higher_is_better"] = True
+    out["roofline"] = dict(res["quantize"])
     c.close()
     print(json.dumps(out))
     return 0

@@ -200,6 +200,12 @@ int64_t vg_shards_find_rowid(const vg_shards *s, int64_t rowid);                
 int     vg_shards_patch_rows(vg_shards *s, const int64_t *positions, int64_t n, const void *host_rows, int64_t row_stride_bytes);
 int     vg_shards_delete_rows(vg_shards *s, const int64_t *positions, int64_t n);
 int     vg_shards_set_scan_filter(vg_shards *s, int mode);                             /* vg_corpus_set_scan_filter on every shard */
+/* How the S x 64 candidate keys of a top-k scan reach the host: 0 = every shard copies its own 64 keys back (default), 1 = ONE grouped
+ * ncclAllGather over RCCL / xGMI on the scan streams + one copy from the first device (librccl.so is dlopen'ed on first use; devices
+ * must be distinct; any failure falls back to 0 for the handle).  Default from VECTORGPU_SHARD_GATHER=host|rccl.  Same keys, same
+ * merge, same result either way.  vg_shards_gather_stats: queries served by [0] the host gather, [1] RCCL; returns 1 while RCCL serves. */
+int     vg_shards_set_gather(vg_shards *s, int mode);
+int     vg_shards_gather_stats(vg_shards *s, unsigned long long *out2);
 int     vg_shards_scan_topk(vg_shards *s, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist, int *out_count);
 int     vg_shards_scan_topk_batch(vg_shards *s, int metric, const void *queries, int nq, int k,
                                   int64_t *out_rowids, double *out_dist, int *out_counts);
@@ -226,6 +232,9 @@ int vg_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals);
 /* the same for f32 batches through the bf16 filter (vg_scan_topk_batch): (query, row) pairs evaluated exactly since the last call */
 int vg_batch_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals);
 
+/* kernel milliseconds (HIP events on the corpus stream) and rows of the corpus' last vg_corpus_minmax (which = 0) /
+ * vg_corpus_quantize_rows (1) pass, and - while profiling is on - of the last int8 shadow-copy pass of the filter scans (2) */
+int vg_corpus_pass_ms(const vg_corpus *c, int which, float *out_ms, long long *out_rows);
 /* rows sent to a device by every vg_corpus_append* / vg_shards_append* call of this process so far */
 long long vg_stat_rows_appended(void);
 

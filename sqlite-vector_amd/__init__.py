@@ -114,8 +114,11 @@ def lib():
         "vg_corpus_set_tie_order": (i32, [vp, i32]),
         "vg_corpus_tie_order": (i32, [vp]),
         "vg_corpus_tie_stats": (i32, [vp, vp]),
+        "vg_corpus_pass_ms": (i32, [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_longlong)]),
         "vg_shards_set_tie_order": (i32, [vp, i32]),
         "vg_shards_set_scan_filter": (i32, [vp, i32]),
+        "vg_shards_set_gather": (i32, [vp, i32]),
+        "vg_shards_gather_stats": (i32, [vp, vp]),
         "vg_shards_rowids": (i32, [vp, i64, i64, vp]),
         "vg_scan_topk_reference": (i32, [vp, i32, vp, i32, vp, vp, C.POINTER(i32)]),
         "vg_stat_rows_appended": (C.c_longlong, []),
@@ -291,6 +294,15 @@ class Corpus:
         """TIE_POSITION (default) or TIE_REFERENCE: the reference's slot-history result among equal distances"""
         _check(lib().vg_corpus_set_tie_order(self.h, mode))
 
+    def pass_ms(self, which):
+        """(kernel ms, rows) of the last "minmax" / "quantize" / "q8_shadow" pass over this corpus"""
+        ms, rows = C.c_float(0), C.c_longlong(0)
+        _check(lib().vg_corpus_pass_ms(self.h, {"minmax": 0, "quantize": 1, "q8_shadow": 2}[which], C.byref(ms), C.byref(rows)))
+        return ms.value, rows.value
+
+    def clear(self):
+        _check(lib().vg_corpus_clear(self.h))
+
     def tie_stats(self):
         """reference-order scans so far: {scans, with_a_tie_among_the_k_plus_1_best, fused_replays, store_mode_replays}"""
         out = np.zeros(4, dtype=np.uint64)
@@ -349,6 +361,15 @@ class Shards:
 
     def set_scan_filter(self, mode):
         _check(lib().vg_shards_set_scan_filter(self.h, mode))
+
+    def set_gather(self, mode):
+        """candidate gather: "host" (every shard copies its 64 keys back) or "rccl" (one grouped ncclAllGather over xGMI)"""
+        _check(lib().vg_shards_set_gather(self.h, {"host": 0, "rccl": 1}[mode]))
+
+    def gather_stats(self):
+        out = np.zeros(2, dtype=np.uint64)
+        serving = lib().vg_shards_gather_stats(self.h, _ptr(out))
+        return {"host": int(out[0]), "rccl": int(out[1]), "rccl_serving": bool(serving)}
 
     def scan_topk(self, metric, query, k):
         query = np.ascontiguousarray(query)

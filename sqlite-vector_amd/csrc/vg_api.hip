@@ -478,6 +478,22 @@ int vg_scan_topk_enqueue_plan(vg_corpus *c, int metric, const void *query, int k
 extern "C" int vg_scan_topk_enqueue(vg_corpus *c, int metric, const void *query, int k) {
     return vg_scan_topk_enqueue_plan(c, metric, query, k, false);
 }
+// the same, but the 64 keys stay in c->d_keys on the device (no host-direct path, no copy back): what a device-side gather of the
+// shards' candidates reads (vg_shards.hip, RCCL form).  An empty corpus leaves 64 EMPTY keys there.
+int vg_scan_topk_enqueue_dev(vg_corpus *c, int metric, const void *query, int k) {
+    if (!c || !query) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_enqueue_dev: NULL argument");
+    if (k < 1 || k > VG_MAX_FUSED_K) return vg_fail(VG_ERR_UNSUPPORTED, "vg_scan_topk_enqueue_dev: k must be in 1..%d", VG_MAX_FUSED_K);
+    if (vg_metric_to_acc(metric) < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
+    HIP_TRY(hipSetDevice(c->device));
+    c->enqueued = false;
+    if (c->n_rows == 0) {
+        HIP_TRY(hipMemsetAsync(c->d_keys, 0xFF, VG_WAVE * sizeof(uint64_t), c->stream));
+        return VG_OK;
+    }
+    stage_query(c, query);
+    HIP_TRY(hipMemcpyAsync(c->d_query, c->h_query, (size_t)c->stride, hipMemcpyHostToDevice, c->stream));
+    return launch_scan(c, metric, c->d_query, k, c->d_keys, nullptr, c->stream);
+}
 
 extern "C" int vg_scan_topk_collect(vg_corpus *c, uint64_t *out_keys64) {
     if (!c || !out_keys64) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_collect: NULL argument");

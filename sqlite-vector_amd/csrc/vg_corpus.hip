@@ -638,15 +638,30 @@ extern "C" int vg_corpus_minmax(vg_corpus *c, float *out_min, float *out_max, in
     if (c->n_rows > 0) {
         uint32_t *d3 = nullptr;
         HIP_TRY(hipMalloc(&d3, sizeof(h)));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        HIP_TRY(hipMemcpyAsync(d3, h, sizeof(h), hipMemcpyHostToDevice, c->stream));     // (so that the events bracket the kernel alone)
+        hipEventRecord(e0, c->stream);
         int rc = vg_quant_minmax_launch(c->d_rows, c->n_rows, c->stride, c->dim, c->vtype, d3, c->stream);
+        hipEventRecord(e1, c->stream);
         hipError_t e = (rc == 0) ? hipMemcpyAsync(h, d3, sizeof(h), hipMemcpyDeviceToHost, c->stream) : (hipError_t)rc;
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) { hipEventElapsedTime(&c->pass_ms[0], e0, e1); c->pass_rows[0] = c->n_rows; }
+        hipEventDestroy(e0); hipEventDestroy(e1);
         hipFree(d3);
         if (e != hipSuccess) return vg_fail(VG_ERR_HIP, "min/max pass failed: %s", hipGetErrorString(e));
     }
     *out_min = vg_sortable_f32(h[0]);
     *out_max = vg_sortable_f32(h[1]);
     *out_any_negative = (int)h[2];
+    return VG_OK;
+}
+
+// kernel milliseconds + rows of the last minmax (0) / quantize (1) / int8-shadow (2) pass of this corpus
+extern "C" int vg_corpus_pass_ms(const vg_corpus *c, int which, float *out_ms, long long *out_rows) {
+    if (!c || which < 0 || which > 2 || !out_ms || !out_rows) return vg_fail(VG_ERR_INVALID, "vg_corpus_pass_ms: bad argument");
+    *out_ms = c->pass_ms[which];
+    *out_rows = c->pass_rows[which];
     return VG_OK;
 }
 
@@ -660,15 +675,24 @@ extern "C" int vg_corpus_quantize_rows(vg_corpus *c, float scale, float offset, 
     const int64_t piece = std::max<int64_t>(1, (256ll << 20) / c->dim);
     uint8_t *d_out = nullptr;
     HIP_TRY(hipMalloc(&d_out, (size_t)(std::min(piece, n_rows) * c->dim)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    c->pass_ms[1] = 0.f; c->pass_rows[1] = 0;
     for (int64_t r = 0; r < n_rows; r += piece) {
         const int64_t nr = std::min(piece, n_rows - r);
+        hipEventRecord(e0, c->stream);
         int rc = vg_quant_quantize_launch(c->d_rows, row0 + r, nr, c->stride, c->dim, c->vtype, scale, offset,
                                           qtype == VG_QUANT_U8 ? 1 : 0, d_out, c->stream);
+        hipEventRecord(e1, c->stream);
         hipError_t e = (rc == 0) ? hipMemcpyAsync(out_host + r * c->dim, d_out, (size_t)(nr * c->dim), hipMemcpyDeviceToHost, c->stream)
                                  : (hipError_t)rc;
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { hipFree(d_out); return vg_fail(VG_ERR_HIP, "quantize pass failed: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d_out); return vg_fail(VG_ERR_HIP, "quantize pass failed: %s", hipGetErrorString(e)); }
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        c->pass_ms[1] += ms; c->pass_rows[1] += nr;
     }
+    hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(d_out);
     return VG_OK;
 }

@@ -174,6 +174,90 @@ __global__ __launch_bounds__(256) void vg_to_q8_kernel(const uint8_t *rows, long
     }
 }
 
+// The same pass with the row held in REGISTERS between the two sweeps (max |x|, then quantize + residual): lane l of a row's 16 keeps
+// the 16-byte chunks l, l + 16, ... (U of them), so every corpus byte is fetched once - the kernel above reads each row twice
+// (rocprofv3 FETCH_SIZE 30.6 GB for a 15.36 GB corpus).  Rows of up to 16 U chunks (f32: 64 U elements, f16 / bf16: 128 U).
+template <int XT, int U>
+__global__ __launch_bounds__(256) void vg_to_q8_reg_kernel(const uint8_t *rows, long long row0, long long n, long long stride, int dim,
+                                                           int nch, uint8_t *out, long long ostride, float2 *stat) {
+    constexpr int N = (XT == T_F32) ? 4 : 8;                               // elements per 16-byte chunk
+    const int l16 = threadIdx.x & 15;
+    const long long groups = ((long long)gridDim.x * blockDim.x) >> 4;
+    const long long n_pad = ((n + 3) / 4) * 4;                            // whole wavefronts stay together (DPP reductions)
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < n_pad; i += groups) {
+        const bool live = i < n;
+        const long long r = row0 + (live ? i : n - 1);
+        const uint8_t *src = rows + r * stride;
+        float v[U][N];
+        float mx = 0.0f;
+        uint32_t bad = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = l16 + 16 * u;
+            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+            if (c < nch) raw = vg_load16<true>(src + (long long)c * 16);
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (XT == T_F32) v[u][j] = __uint_as_float(w[j]);
+                else vg_unpack2<XT>(w[j], v[u][2 * j], v[u][2 * j + 1]);
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                if (c * N + j < dim) { mx = fmaxf(mx, fabsf(v[u][j])); bad |= !(fabsf(v[u][j]) <= 3.0e38f); }
+        }
+        mx = fmaxf(mx, vg_dpp<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(mx));
+        mx = fmaxf(mx, vg_dpp<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(mx));
+        mx = fmaxf(mx, vg_dpp<VG_DPP_ROW_HALF_MIRROR>(mx));
+        mx = fmaxf(mx, vg_dpp<VG_DPP_ROW_MIRROR>(mx));
+        bad = vg_group_or(bad, 4);
+        const float sx = (mx > 0.0f) ? mx / 127.0f : 0.0f;
+        const float inv = (mx > 0.0f) ? 1.0f / sx : 0.0f;
+        double e2 = 0.0;
+        uint8_t *o = out + r * ostride;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = l16 + 16 * u;
+            uint32_t w[N / 4];
+#pragma unroll
+            for (int j4 = 0; j4 < N / 4; ++j4) {
+                w[j4] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = c * N + 4 * j4 + j;
+                    if (e < dim && !bad) {
+                        const float x = v[u][4 * j4 + j];
+                        const int xi = vgf_q8(x, inv);
+                        const double res = (double)x - (double)sx * (double)xi;
+                        e2 += res * res;
+                        w[j4] |= (uint32_t)(xi & 255) << (8 * j);
+                    }
+                }
+            }
+            if (live && c * N < (int)ostride) {
+                if constexpr (N == 4) *reinterpret_cast<uint32_t *>(o + c * 4) = w[0];
+                else *reinterpret_cast<uint2 *>(o + c * 8) = make_uint2(w[0], w[1]);
+            }
+        }
+        // the shadow row's zero padding behind the chunks the corpus row has
+        if (live) for (int e = N * nch + 4 * l16; e < (int)ostride; e += 64) *reinterpret_cast<uint32_t *>(o + e) = 0u;
+        e2 = vg_group_sum(e2, 4);
+        if (live && l16 == 0) {
+            float ex = (float)sqrt(e2);
+            ex = ex * (1.0f + 4.0e-7f) + 1.0e-37f;                        // rounded up (f64 sum, one sqrt, one conversion)
+            stat[r] = bad ? make_float2(__builtin_nanf(""), 0.0f) : make_float2(sx, e2 > 0.0 ? ex : 0.0f);
+        }
+    }
+}
+typedef void (*to_q8_fn_t)(const uint8_t *, long long, long long, long long, int, int, uint8_t *, long long, float2 *);
+template <int XT> static to_q8_fn_t pick_to_q8_reg(int nch) {
+    if (nch <= 32) return vg_to_q8_reg_kernel<XT, 2>;
+    if (nch <= 64) return vg_to_q8_reg_kernel<XT, 4>;
+    if (nch <= 96) return vg_to_q8_reg_kernel<XT, 6>;
+    if (nch <= 128) return vg_to_q8_reg_kernel<XT, 8>;
+    return nullptr;
+}
+
 template <int XT, int MODE, bool NT>
 static filter_fn_t pick_n4_u(int U) {
     switch (U) {
@@ -245,9 +329,26 @@ int vg_ensure_q8_shadow(vg_corpus *c) {
     if (c->q8_rows < c->n_rows) {
         const long long n = c->n_rows - c->q8_rows;
         const long long blocks = std::min<long long>((n * 16 + 255) / 256, 256 * 32);
-        auto kern = c->vtype == VG_TYPE_F32 ? vg_to_q8_kernel<T_F32> : (c->vtype == VG_TYPE_F16 ? vg_to_q8_kernel<T_F16> : vg_to_q8_kernel<T_BF16>);
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_rows, (long long)c->q8_rows, n,
-                           (long long)c->stride, c->dim, c->d_rows_q8, qs, reinterpret_cast<float2 *>(c->d_q8stat));
+        // rows of up to 128 chunks: the single-read kernel (the row lives in registers between its two sweeps)
+        to_q8_fn_t reg = env_int("VG_Q8_TWO_READS", 0) ? nullptr
+                       : (c->vtype == VG_TYPE_F32 ? pick_to_q8_reg<T_F32>(c->nch) : (c->vtype == VG_TYPE_F16 ? pick_to_q8_reg<T_F16>(c->nch) : pick_to_q8_reg<T_BF16>(c->nch)));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, c->stream); }
+        if (reg) {
+            hipLaunchKernelGGL(reg, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_rows, (long long)c->q8_rows, n,
+                               (long long)c->stride, c->dim, c->nch, c->d_rows_q8, qs, reinterpret_cast<float2 *>(c->d_q8stat));
+        } else {
+            auto kern = c->vtype == VG_TYPE_F32 ? vg_to_q8_kernel<T_F32> : (c->vtype == VG_TYPE_F16 ? vg_to_q8_kernel<T_F16> : vg_to_q8_kernel<T_BF16>);
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_rows, (long long)c->q8_rows, n,
+                               (long long)c->stride, c->dim, c->d_rows_q8, qs, reinterpret_cast<float2 *>(c->d_q8stat));
+        }
+        if (e0) {                                            // (profiling runs only: what bench.py --workload stage reports)
+            hipEventRecord(e1, c->stream);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&c->pass_ms[2], e0, e1);
+            c->pass_rows[2] = n;
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return vg_fail(VG_ERR_HIP, "int8 shadow pass failed: %s", hipGetErrorString(e));
         c->q8_rows = c->n_rows;

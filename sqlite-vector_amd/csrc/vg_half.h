@@ -48,6 +48,25 @@ template <int VT> __device__ inline void vg_unpack2(uint32_t w, float &lo, float
 
 // ============================================================================================ fast path
 
+// f16: v_fma_mix_f32 reads its f16 operands straight out of the packed dword (op_sel picks the half, op_sel_hi marks a source as
+// f16) and produces the f32 result with ONE rounding - (float)q - (float)x as fma(q, 1.0, -x), (float)q * (float)x as fma(q, x, 0)
+// - bit for bit what the two conversions + the f32 operation compute, in one VALU instruction instead of three (the unpacking was
+// 40 % of the f16 kernels' instruction stream; they are bound by it, not by HBM).  f16 denormal inputs are honoured by the mix
+// instructions (unlike v_mad_mix); the f32 result follows the kernel's f32 denormal mode like v_sub_f32 / v_mul_f32 do.
+#ifndef VG_HALF_FMA_MIX
+#define VG_HALF_FMA_MIX 1
+#endif
+__device__ inline void vg_f16_diff2(uint32_t qw, uint32_t xw, float &d0, float &d1) {
+    asm("v_fma_mix_f32 %0, %2, 1.0, -%3 op_sel_hi:[1,0,1]\n\t"
+        "v_fma_mix_f32 %1, %2, 1.0, -%3 op_sel:[1,0,1] op_sel_hi:[1,0,1]"
+        : "=&v"(d0), "=v"(d1) : "v"(qw), "v"(xw));
+}
+__device__ inline void vg_f16_prod2(uint32_t qw, uint32_t xw, float &p0, float &p1) {
+    asm("v_fma_mix_f32 %0, %2, %3, 0 op_sel_hi:[1,1,0]\n\t"
+        "v_fma_mix_f32 %1, %2, %3, 0 op_sel:[1,1,0] op_sel_hi:[1,1,0]"
+        : "=&v"(p0), "=v"(p1) : "v"(qw), "v"(xw));
+}
+
 template <int VT, int ACC> struct AccumHalf {
     // four independent f64 accumulators per lane: a single chain of dependent v_fma_f64 / v_add_f64 (8 per chunk)
     // left the kernel latency-bound at ~5 TB/s
@@ -60,6 +79,21 @@ template <int VT, int ACC> struct AccumHalf {
 
     __device__ inline void pair(uint32_t qw, uint32_t xw, double &s0, double &s1, double &m0, double &m1) {
         flag |= vg_special_pair<VT>(xw);
+        if constexpr (VT == T_F16 && VG_HALF_FMA_MIX != 0 && ACC != A_COS) {
+            float e0, e1;
+            if (ACC == A_L2) {                  // f32 subtract, square in f64 (distance-avx2.c:186-205)
+                vg_f16_diff2(qw, xw, e0, e1);
+                const double d0 = (double)e0, d1 = (double)e1;
+                s0 = fma(d0, d0, s0); s1 = fma(d1, d1, s1);
+            } else if (ACC == A_L1) {
+                vg_f16_diff2(qw, xw, e0, e1);
+                s0 += (double)fabsf(e0); s1 += (double)fabsf(e1);
+            } else {                            // A_DOT / A_COSN: exact f32 products
+                vg_f16_prod2(qw, xw, e0, e1);
+                s0 += (double)e0; s1 += (double)e1;
+            }
+            return;
+        }
         float q0, q1, x0, x1;
         vg_unpack2<VT>(qw, q0, q1);
         vg_unpack2<VT>(xw, x0, x1);

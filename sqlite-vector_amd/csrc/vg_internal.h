@@ -143,6 +143,10 @@ struct vg_corpus {
     long long prof_launches = 0;           // launches recorded since profiling was (re)enabled
     float last_scan_ms = 0.f, last_merge_ms = 0.f, last_prepass_ms = 0.f;
     char kernel_name[64] = {0};
+    // kernel milliseconds / rows of the last minmax [0], quantize [1] and int8-shadow [2] pass (HIP events on the corpus stream;
+    // the first two always, the shadow pass while profiling is on) - bench.py --workload stage prices them against the HBM peak
+    float pass_ms[3] = {0.f, 0.f, 0.f};
+    long long pass_rows[3] = {0, 0, 0};
 };
 
 static inline int env_int(const char *name, int dflt) {

@@ -15,30 +15,66 @@
 #include "vg_device.h"
 #include "vg_half.h"
 
-__device__ inline float vgq_elem(int vtype, const uint8_t *row, int i) {
-    switch (vtype) {
-        case T_F32: return reinterpret_cast<const float *>(row)[i];
-        case T_F16: return vg_h2f(reinterpret_cast<const uint16_t *>(row)[i]);
-        case T_BF16: return vg_b2f(reinterpret_cast<const uint16_t *>(row)[i]);
-        case T_U8: return (float)row[i];
-        default: return (float)reinterpret_cast<const int8_t *>(row)[i];
-    }
+// Both passes share one decomposition (the scan kernels' own): 16 lanes per row, lane l owns the 16-byte chunks l, l + 16, ... of
+// the row - every load is a full 16 bytes of a 256-byte run, no index division anywhere (round 2's first draft did a 64-bit
+// divide + modulo per ELEMENT).  The zero padding behind `dim` elements is masked out: it must not become a minimum.
+typedef uint32_t vgq_u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline uint4 vgq_load16(const uint4 *p) {        // every corpus byte is read once per pass: keep it out of the caches
+    const vgq_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const vgq_u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
+template <int VT> struct VgqChunk {                         // elements of one 16-byte chunk, widened the way the reference does
+    static constexpr int N = (VT == T_F32) ? 4 : (VT == T_F16 || VT == T_BF16) ? 8 : 16;
+    __device__ static inline void widen(const uint4 &v, float (&out)[N]) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if constexpr (VT == T_F32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = __uint_as_float(w[j]);
+        } else if constexpr (VT == T_F16 || VT == T_BF16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (VT == T_F16) { out[2 * j] = vg_h2f((uint16_t)(w[j] & 0xFFFFu)); out[2 * j + 1] = vg_h2f((uint16_t)(w[j] >> 16)); }
+                else { out[2 * j] = vg_b2f((uint16_t)(w[j] & 0xFFFFu)); out[2 * j + 1] = vg_b2f((uint16_t)(w[j] >> 16)); }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t byte = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                out[j] = (VT == T_U8) ? (float)byte : (float)(int)(int8_t)byte;
+            }
+        }
+    }
+};
 
 // out[0] = sortable(min), out[1] = sortable(max), out[2] = any negative.  Pre-set by the host to
 // sortable(FLT_MAX), sortable(-FLT_MAX), 0 (the reference's initial values, :1197-1198).
-__global__ __launch_bounds__(256) void vg_minmax_kernel(const uint8_t *rows, long long n_rows, long long stride, int dim,
-                                                         int vtype, uint32_t *out) {
-    const long long total = n_rows * (long long)dim;
+template <int VT>
+__global__ __launch_bounds__(256) void vg_minmax_kernel(const uint8_t *rows, long long n_rows, long long stride, int dim, int nch,
+                                                         uint32_t *out) {
+    constexpr int N = VgqChunk<VT>::N;
+    const int l16 = threadIdx.x & 15;
+    const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long long ngroups = ((long long)gridDim.x * blockDim.x) >> 4;
     float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
     int neg = 0;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const long long r = e / dim;
-        const int i = (int)(e - r * dim);
-        const float v = vgq_elem(vtype, rows + r * stride, i);
-        if (v < lo) lo = v;
-        if (v > hi) hi = v;
-        if (v < 0.0f) neg = 1;
+    const int full = dim / N;                                // chunks without padding
+    for (long long r = group; r < n_rows; r += ngroups) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(rows + r * stride);
+#pragma unroll 4
+        for (int c = l16; c < nch; c += 16) {
+            const uint4 v = vgq_load16(p + c);
+            float e[N];
+            VgqChunk<VT>::widen(v, e);
+            const int live = (c < full) ? N : (dim - c * N);              // (<= 0 for a chunk that is padding only)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (j < live) {
+                    if (e[j] < lo) lo = e[j];
+                    if (e[j] > hi) hi = e[j];
+                    if (e[j] < 0.0f) neg = 1;
+                }
+            }
+        }
     }
     for (int off = 32; off >= 1; off >>= 1) {
         const float l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
@@ -59,36 +95,73 @@ __device__ inline int vgq_trunc_x86(float r) {           // cvttss2si semantics
     return (int)r;
 }
 
-__global__ __launch_bounds__(256) void vg_quantize_kernel(const uint8_t *rows, long long row0, long long n_rows,
-                                                           long long stride, int dim, int vtype, float scale, float offset,
-                                                           int qtype_u8, uint8_t *out) {
-    const long long total = n_rows * (long long)dim;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const long long r = e / dim;
-        const int i = (int)(e - r * dim);
-        const float v = vgq_elem(vtype, rows + (row0 + r) * stride, i);
-        const float s = (v - offset) * scale;                              // two roundings, no contraction
-        const float rr = s + 0.5f * (1.0f - 2.0f * (s < 0.0f ? 1.0f : 0.0f));
-        uint8_t q;
-        if (vtype == T_F32) {                                              // sqlite-vector.c:517-548, :626-656
-            const int ir = vgq_trunc_x86(rr);
-            if (qtype_u8) q = (uint8_t)(ir > 255 ? 255 : (ir < 0 ? 0 : ir));
-            else q = (uint8_t)(int8_t)(ir > 127 ? 127 : (ir < -128 ? -128 : ir));
-        } else if (qtype_u8) {                                             // q_round_u8, :495-504
-            if (!isfinite(s)) q = (s > 0.0f) ? 255u : 0u;
-            else if (rr >= 255.0f) q = 255u;
-            else if (rr <= 0.0f) q = 0u;
-            else q = (uint8_t)(int)rr;
-        } else {                                                           // q_round_s8, :506-515
-            int8_t t;
-            if (!isfinite(s)) t = (s > 0.0f) ? 127 : (s < 0.0f ? -128 : 0);
-            else if (rr >= 127.0f) t = 127;
-            else if (rr <= -128.0f) t = -128;
-            else t = (int8_t)(int)rr;
-            q = (uint8_t)t;
-        }
-        out[e] = q;
+// one element: s = (v - offset) * scale (two roundings, no contraction), round half away from zero, clamp
+template <int VT>
+__device__ inline uint32_t vgq_one(float v, float scale, float offset, int qtype_u8) {
+    const float s = (v - offset) * scale;
+    const float rr = s + 0.5f * (1.0f - 2.0f * (s < 0.0f ? 1.0f : 0.0f));
+    if constexpr (VT == T_F32) {                                          // sqlite-vector.c:517-548, :626-656
+        const int ir = vgq_trunc_x86(rr);
+        if (qtype_u8) return (uint32_t)(ir > 255 ? 255 : (ir < 0 ? 0 : ir));
+        return (uint32_t)(uint8_t)(int8_t)(ir > 127 ? 127 : (ir < -128 ? -128 : ir));
+    } else if (qtype_u8) {                                                // q_round_u8, :495-504
+        if (!isfinite(s)) return (s > 0.0f) ? 255u : 0u;
+        if (rr >= 255.0f) return 255u;
+        if (rr <= 0.0f) return 0u;
+        return (uint32_t)(uint8_t)(int)rr;
+    } else {                                                              // q_round_s8, :506-515
+        int8_t t;
+        if (!isfinite(s)) t = (s > 0.0f) ? 127 : (s < 0.0f ? -128 : 0);
+        else if (rr >= 127.0f) t = 127;
+        else if (rr <= -128.0f) t = -128;
+        else t = (int8_t)(int)rr;
+        return (uint32_t)(uint8_t)t;
     }
+}
+
+// rows [row0, row0 + n_rows) -> n_rows x dim tightly packed bytes.  A chunk's N output bytes go out as one 4- / 8- / 16-byte
+// store when the packed row length keeps them aligned (dim a multiple of N), byte by byte otherwise.
+template <int VT>
+__global__ __launch_bounds__(256) void vg_quantize_kernel(const uint8_t *rows, long long row0, long long n_rows, long long stride,
+                                                           int dim, int nch, float scale, float offset, int qtype_u8, uint8_t *out) {
+    constexpr int N = VgqChunk<VT>::N;
+    const int l16 = threadIdx.x & 15;
+    const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long long ngroups = ((long long)gridDim.x * blockDim.x) >> 4;
+    const bool packed_ok = (dim % N) == 0;
+    const int full = dim / N;
+    for (long long r = group; r < n_rows; r += ngroups) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(rows + (row0 + r) * stride);
+        uint8_t *o = out + r * (long long)dim;
+#pragma unroll 4
+        for (int c = l16; c < nch; c += 16) {
+            if (c * N >= dim) continue;
+            const uint4 v = vgq_load16(p + c);
+            float e[N];
+            VgqChunk<VT>::widen(v, e);
+            uint32_t q[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) q[j] = vgq_one<VT>(e[j], scale, offset, qtype_u8);
+            if (packed_ok && c < full) {
+                uint32_t w[N / 4];
+#pragma unroll
+                for (int j = 0; j < N / 4; ++j) w[j] = q[4 * j] | (q[4 * j + 1] << 8) | (q[4 * j + 2] << 16) | (q[4 * j + 3] << 24);
+                if constexpr (N == 4) *reinterpret_cast<uint32_t *>(o + c * 4) = w[0];
+                else if constexpr (N == 8) *reinterpret_cast<uint2 *>(o + c * 8) = make_uint2(w[0], w[1]);
+                else *reinterpret_cast<uint4 *>(o + c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) if (c * N + j < dim) o[c * N + j] = (uint8_t)q[j];
+            }
+        }
+    }
+}
+
+static inline unsigned vgq_blocks(long long n_rows) {
+    long long blocks = (n_rows * 16 + 255) / 256;            // 16 lanes per row
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
 }
 
 extern "C" int vg_quant_minmax_launch(const uint8_t *rows, long long n_rows, long long stride, int dim, int vtype,
@@ -96,22 +169,31 @@ extern "C" int vg_quant_minmax_launch(const uint8_t *rows, long long n_rows, lon
     const uint32_t init[3] = {vg_f32_sortable(3.402823466e+38f), vg_f32_sortable(-3.402823466e+38f), 0u};
     hipError_t e = hipMemcpyAsync(dev_out3, init, sizeof(init), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return (int)e;
-    const long long total = n_rows * (long long)dim;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(vg_minmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rows, n_rows, stride, dim, vtype, dev_out3);
+    const int nch = (int)(stride / 16);
+    const dim3 g(vgq_blocks(n_rows)), b(256);
+    switch (vtype) {
+        case T_F32: hipLaunchKernelGGL(vg_minmax_kernel<T_F32>, g, b, 0, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
+        case T_F16: hipLaunchKernelGGL(vg_minmax_kernel<T_F16>, g, b, 0, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
+        case T_BF16: hipLaunchKernelGGL(vg_minmax_kernel<T_BF16>, g, b, 0, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
+        case T_U8: hipLaunchKernelGGL(vg_minmax_kernel<T_U8>, g, b, 0, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
+        default: hipLaunchKernelGGL(vg_minmax_kernel<T_I8>, g, b, 0, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
+    }
     return (int)hipGetLastError();
 }
 
 extern "C" int vg_quant_quantize_launch(const uint8_t *rows, long long row0, long long n_rows, long long stride, int dim,
                                         int vtype, float scale, float offset, int qtype_u8, uint8_t *dev_out,
                                         hipStream_t stream) {
-    const long long total = n_rows * (long long)dim;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(vg_quantize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, rows, row0, n_rows, stride, dim,
-                       vtype, scale, offset, qtype_u8, dev_out);
+    const int nch = (int)(stride / 16);
+    const dim3 g(vgq_blocks(n_rows)), b(256);
+#define VGQ_LAUNCH(T) hipLaunchKernelGGL(vg_quantize_kernel<T>, g, b, 0, stream, rows, row0, n_rows, stride, dim, nch, scale, offset, qtype_u8, dev_out)
+    switch (vtype) {
+        case T_F32: VGQ_LAUNCH(T_F32); break;
+        case T_F16: VGQ_LAUNCH(T_F16); break;
+        case T_BF16: VGQ_LAUNCH(T_BF16); break;
+        case T_U8: VGQ_LAUNCH(T_U8); break;
+        default: VGQ_LAUNCH(T_I8); break;
+    }
+#undef VGQ_LAUNCH
     return (int)hipGetLastError();
 }

@@ -9,10 +9,21 @@
 // Rows can be appended as they stream out of sqlite3_step() without knowing the final count (a contiguous
 // row-range split would need it), and every device gets work as soon as B * S rows exist.
 //
-// No collective is involved: the devices never talk to each other, the host gathers S x k keys (<= 512 B per
-// shard).  The one-process-per-GPU variant of the same exchange (torch.distributed / RCCL) is shard.py.
-#include "../../include/vectorgpu.h"
+// The exchange step - S x 64 candidate keys, 512 B per shard - has two forms, chosen per handle (vg_shards_set_gather, the
+// VECTORGPU_SHARD_GATHER environment variable: host | rccl):
+//   host  (default) every shard copies its 64 keys to pinned host memory behind its scan, one host thread waits for the S streams;
+//   rccl            north_star's "RCCL gather of per-shard candidates over xGMI": one communicator per device of this process
+//                   (ncclCommInitAll), ONE grouped ncclAllGather of 64 keys per shard on the scan streams, then a single 512 B x S
+//                   copy from the first device.  librccl.so is dlopen'ed on first use (the library has no link-time dependency
+//                   on it); the devices of a handle must be distinct (RCCL refuses two ranks on one device) - otherwise, or if
+//                   the library / a call fails, the handle stays with the host gather.
+// Both produce the same S x 64 keys, so the merge - and the result - is identical bit for bit; which one is faster is a
+// measurement (tools/shards_gather_bench.py): the payload is latency-bound either way.  The one-process-per-GPU variant of the
+// same exchange (torch.distributed / RCCL) is shard.py.
+#include "vg_internal.h"
 #include "vg_refslots.h"
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -33,12 +44,59 @@ struct vg_shards {
     int64_t rowid_base = 1;
     int tie_order = VG_TIE_POSITION;
     std::vector<vg_corpus *> sh;
+    std::vector<int> devices;
+    // ---- the RCCL form of the candidate gather (see the file header)
+    int gather_mode = 0;                       // 0 = host, 1 = rccl
+    std::vector<void *> comms;                 // ncclComm_t per shard (empty until first use)
+    std::vector<uint64_t *> d_gather;          // per shard: S x 64 keys (the all-gather's receive buffer)
+    uint64_t *h_gather = nullptr;              // pinned: S x 64 keys
+    bool rccl_failed = false;
+    unsigned long long gather_calls[2] = {0, 0};
 };
+
+// ---- librccl.so, resolved at run time
+namespace {
+typedef int (*nccl_comm_init_all_t)(void **, int, const int *);
+typedef int (*nccl_all_gather_t)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*nccl_group_t)(void);
+typedef int (*nccl_comm_destroy_t)(void *);
+typedef const char *(*nccl_error_string_t)(int);
+struct RcclApi {
+    void *lib = nullptr;
+    nccl_comm_init_all_t comm_init_all = nullptr;
+    nccl_all_gather_t all_gather = nullptr;
+    nccl_group_t group_start = nullptr, group_end = nullptr;
+    nccl_comm_destroy_t comm_destroy = nullptr;
+    nccl_error_string_t error_string = nullptr;
+    bool tried = false;
+};
+RcclApi g_rccl;
+const int kNcclUint64 = 5;                      // ncclUint64 (rccl.h ncclDataType_t)
+bool rccl_load() {
+    if (g_rccl.tried) return g_rccl.lib != nullptr;
+    g_rccl.tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) if ((g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!g_rccl.lib) return false;
+    g_rccl.comm_init_all = (nccl_comm_init_all_t)dlsym(g_rccl.lib, "ncclCommInitAll");
+    g_rccl.all_gather = (nccl_all_gather_t)dlsym(g_rccl.lib, "ncclAllGather");
+    g_rccl.group_start = (nccl_group_t)dlsym(g_rccl.lib, "ncclGroupStart");
+    g_rccl.group_end = (nccl_group_t)dlsym(g_rccl.lib, "ncclGroupEnd");
+    g_rccl.comm_destroy = (nccl_comm_destroy_t)dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.error_string = (nccl_error_string_t)dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.comm_init_all || !g_rccl.all_gather || !g_rccl.group_start || !g_rccl.group_end || !g_rccl.comm_destroy) {
+        dlclose(g_rccl.lib);
+        g_rccl.lib = nullptr;
+    }
+    return g_rccl.lib != nullptr;
+}
+}
 
 static int fail(int code, const char *msg) {
     vg_set_last_error_(msg);
     return code;
 }
+int vg_scan_topk_enqueue_dev(vg_corpus *c, int metric, const void *query, int k);    // vg_api.hip: keys stay in c->d_keys
 
 static inline void locate(const vg_shards *s, int64_t g, int *shard, int64_t *local) {
     const int64_t b = g / s->B;
@@ -78,8 +136,13 @@ extern "C" int vg_shards_create(const int *devices, int n_devices, int vtype, in
     s->B = block_rows > 0 ? block_rows : 65536;
     s->vtype = vtype;
     s->dim = dim;
+    {
+        const char *g = getenv("VECTORGPU_SHARD_GATHER");
+        s->gather_mode = (g && (g[0] == 'r' || g[0] == 'R')) ? 1 : 0;
+    }
     for (int i = 0; i < n_devices; ++i) {
         vg_corpus *c = nullptr;
+        s->devices.push_back(devices ? devices[i] : i);
         int rc = vg_corpus_create(devices ? devices[i] : i, vtype, dim, 0, &c);
         if (rc != VG_OK) {
             for (auto *p : s->sh) vg_corpus_destroy(p);
@@ -93,10 +156,82 @@ extern "C" int vg_shards_create(const int *devices, int n_devices, int vtype, in
     return VG_OK;
 }
 
+static void rccl_release(vg_shards *s) {
+    for (size_t i = 0; i < s->comms.size(); ++i) if (s->comms[i] && g_rccl.comm_destroy) g_rccl.comm_destroy(s->comms[i]);
+    s->comms.clear();
+    for (size_t i = 0; i < s->d_gather.size(); ++i)
+        if (s->d_gather[i]) { hipSetDevice(s->devices[i]); hipFree(s->d_gather[i]); }
+    s->d_gather.clear();
+    if (s->h_gather) { hipHostFree(s->h_gather); s->h_gather = nullptr; }
+}
+
 extern "C" void vg_shards_destroy(vg_shards *s) {
     if (!s) return;
+    rccl_release(s);
     for (auto *p : s->sh) vg_corpus_destroy(p);
     delete s;
+}
+
+// communicators + receive buffers on first use; false (and the handle falls back to the host gather for good) when RCCL cannot
+// serve this handle
+static bool rccl_ready(vg_shards *s) {
+    if (s->rccl_failed) return false;
+    if (!s->comms.empty()) return true;
+    bool distinct = true;
+    for (int i = 0; i < s->S; ++i) for (int j = 0; j < i; ++j) distinct &= s->devices[(size_t)i] != s->devices[(size_t)j];
+    if (!distinct || !rccl_load()) { s->rccl_failed = true; return false; }
+    s->comms.assign((size_t)s->S, nullptr);
+    if (g_rccl.comm_init_all(s->comms.data(), s->S, s->devices.data()) != 0) { s->comms.clear(); s->rccl_failed = true; return false; }
+    s->d_gather.assign((size_t)s->S, nullptr);
+    bool ok = true;
+    for (int i = 0; i < s->S && ok; ++i) {
+        ok = hipSetDevice(s->devices[(size_t)i]) == hipSuccess &&
+             hipMalloc(&s->d_gather[(size_t)i], (size_t)s->S * VG_WAVE_KEYS * sizeof(uint64_t)) == hipSuccess;
+    }
+    ok = ok && hipHostMalloc(&s->h_gather, (size_t)s->S * VG_WAVE_KEYS * sizeof(uint64_t)) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); rccl_release(s); s->rccl_failed = true; return false; }
+    return true;
+}
+
+// The RCCL form of "scan every shard, bring the S x 64 candidate keys to the host": scans enqueued on the shards' streams with the
+// keys left on their devices, one grouped all-gather on those streams, one copy from the first device.  VG_OK, or an error after
+// which the caller repeats the query through the host gather.
+static int rccl_scan_and_gather(vg_shards *s, int metric, const void *query, int kk, uint64_t *out_keys) {
+    int rc = VG_OK;
+    for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue_dev(s->sh[(size_t)i], metric, query, kk);
+    if (rc != VG_OK) return rc;
+    int nrc = g_rccl.group_start();
+    for (int i = 0; i < s->S && nrc == 0; ++i) {
+        vg_corpus *c = s->sh[(size_t)i];
+        nrc = g_rccl.all_gather(c->d_keys, s->d_gather[(size_t)i], VG_WAVE_KEYS, kNcclUint64, s->comms[(size_t)i], c->stream);
+    }
+    const int erc = g_rccl.group_end();
+    if (nrc != 0 || erc != 0) {
+        for (int i = 0; i < s->S; ++i) { hipSetDevice(s->devices[(size_t)i]); hipStreamSynchronize(s->sh[(size_t)i]->stream); s->sh[(size_t)i]->enqueued = false; }
+        return fail(VG_ERR_HIP, (g_rccl.error_string ? g_rccl.error_string(nrc ? nrc : erc) : "RCCL all-gather failed"));
+    }
+    vg_corpus *c0 = s->sh[0];
+    HIP_TRY(hipSetDevice(s->devices[0]));
+    HIP_TRY(hipMemcpyAsync(s->h_gather, s->d_gather[0], (size_t)s->S * VG_WAVE_KEYS * sizeof(uint64_t), hipMemcpyDeviceToHost, c0->stream));
+    HIP_TRY(hipStreamSynchronize(c0->stream));                 // (every shard's keys arrived on device 0: all scans are done)
+    for (int i = 0; i < s->S; ++i) { s->sh[(size_t)i]->enqueued = false; vg_collect_timing(s->sh[(size_t)i]); }
+    memcpy(out_keys, s->h_gather, (size_t)s->S * VG_WAVE_KEYS * sizeof(uint64_t));
+    ++s->gather_calls[1];
+    return VG_OK;
+}
+
+extern "C" int vg_shards_set_gather(vg_shards *s, int mode) {
+    if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
+    if (mode != 0 && mode != 1) return fail(VG_ERR_INVALID, "vg_shards_set_gather: 0 = host, 1 = rccl");
+    s->gather_mode = mode;
+    if (mode == 1) s->rccl_failed = false;                     // (asked again explicitly: try again)
+    return VG_OK;
+}
+// [0] queries answered through the host gather, [1] through the RCCL all-gather; returns the mode in effect (1 only when RCCL serves)
+extern "C" int vg_shards_gather_stats(vg_shards *s, unsigned long long *out2) {
+    if (!s) return 0;
+    if (out2) { out2[0] = s->gather_calls[0]; out2[1] = s->gather_calls[1]; }
+    return (s->gather_mode == 1 && !s->rccl_failed) ? 1 : 0;
 }
 
 extern "C" int vg_shards_clear(vg_shards *s) {
@@ -333,7 +468,7 @@ extern "C" int vg_shards_scan_topk(vg_shards *s, int metric, const void *query, 
                                    int *out_count) {
     if (!s || !query || !out_count) return fail(VG_ERR_INVALID, "vg_shards_scan_topk: NULL argument");
     *out_count = 0;
-    if (s->S == 1) return vg_scan_topk(s->sh[0], metric, query, k, out_rowids, out_dist, out_count);
+    if (s->S == 1 && s->gather_mode == 0) return vg_scan_topk(s->sh[0], metric, query, k, out_rowids, out_dist, out_count);
     if (k <= 0 || s->n_rows == 0) return VG_OK;
     if (!out_rowids || !out_dist) return fail(VG_ERR_INVALID, "vg_shards_scan_topk: NULL output");
     const bool ref = s->tie_order == VG_TIE_REFERENCE;
@@ -344,13 +479,21 @@ extern "C" int vg_shards_scan_topk(vg_shards *s, int metric, const void *query, 
         const int kk = ref ? k + 1 : k;
         std::vector<uint64_t> keys((size_t)s->S * VG_WAVE_KEYS);
         std::vector<int> counts((size_t)s->S, VG_WAVE_KEYS);
-        int rc = VG_OK;
-        for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue(s->sh[(size_t)i], metric, query, kk);
-        for (int i = 0; i < s->S; ++i) {
-            int rc2 = vg_scan_topk_collect(s->sh[(size_t)i], &keys[(size_t)i * VG_WAVE_KEYS]);
-            if (rc == VG_OK) rc = rc2;
+        int rc = -1;
+        if (s->gather_mode == 1 && rccl_ready(s)) {
+            rc = rccl_scan_and_gather(s, metric, query, kk, keys.data());
+            if (rc != VG_OK) s->rccl_failed = true;            // (the host gather serves this query and the ones after it)
         }
-        if (rc != VG_OK) return rc;
+        if (rc != VG_OK) {
+            rc = VG_OK;
+            for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue(s->sh[(size_t)i], metric, query, kk);
+            for (int i = 0; i < s->S; ++i) {
+                int rc2 = vg_scan_topk_collect(s->sh[(size_t)i], &keys[(size_t)i * VG_WAVE_KEYS]);
+                if (rc == VG_OK) rc = rc2;
+            }
+            if (rc != VG_OK) return rc;
+            ++s->gather_calls[0];
+        }
         const int got = merge_lists(s, keys.data(), VG_WAVE_KEYS, counts.data(), kk, out_rowids, out_dist, ref ? k : -1);
         if (got < 0) return shards_scan_topk_reference(s, metric, query, k, out_rowids, out_dist, out_count);
         *out_count = got;

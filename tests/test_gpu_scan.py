@@ -1118,3 +1118,39 @@ def test_patch_and_delete_rows_equal_a_fresh_corpus(pkg, orc, vt, dim, monkeypat
     a_ids, _ = c.scan_topk(metric, more[7].copy(), 1)
     assert a_ids[0] == 10**7 + 7
     c.close()
+
+
+def test_shards_rccl_candidate_gather_equals_the_host_gather(pkg, orc):
+    """vg_shards' two forms of the candidate exchange (include/vectorgpu.h vg_shards_set_gather): the host gather and ONE grouped
+    ncclAllGather over RCCL on the scan streams.  Same keys, same merge: results bit-identical.  This box has one device, so the
+    RCCL communicator has one rank (devices must be distinct) - the multi-rank form of the same call runs when a handle spans
+    several devices; logical shards on one device silently keep the host gather."""
+    n, dim, k = 300_000, 64, 20
+    rows = dg.corpus(dg.U8, n, dim, 4242)
+    qs = [dg.query(dg.U8, dim, 4300 + i) for i in range(4)]
+    one = pkg.Shards(dg.U8, dim, [0])
+    one.append(rows)
+    want = [one.scan_topk(dg.COSINE, q, k) for q in qs]
+    assert one.gather_stats() == {"host": 0, "rccl": 0, "rccl_serving": False}          # (a single shard forwards to its corpus)
+    one.set_gather("rccl")
+    for q, (w_ids, w_d) in zip(qs, want):
+        ids, d = one.scan_topk(dg.COSINE, q, k)
+        assert ids.tolist() == w_ids.tolist() and np.array_equal(d, w_d)
+    st = one.gather_stats()
+    assert st["rccl"] == len(qs) and st["rccl_serving"], st
+    # tie_order = reference rides on the same gather (one more key per shard)
+    one.set_tie_order(pkg.TIE_REFERENCE)
+    ids, d = one.scan_topk(dg.L2, qs[0], k)
+    r_ids, r_d = orc.topk_reference(orc.scan_distances(orc.AVX2, dg.L2, dg.U8, qs[0], rows), None, k)
+    assert ids.tolist() == r_ids.tolist() and np.array_equal(d, r_d)
+    one.close()
+    # three logical shards on ONE device: RCCL cannot serve (ranks must sit on distinct devices) - the handle keeps the host gather
+    three = pkg.Shards(dg.U8, dim, [0, 0, 0], block_rows=4099)
+    three.append(rows)
+    three.set_gather("rccl")
+    for q, (w_ids, w_d) in zip(qs, want):
+        ids, d = three.scan_topk(dg.COSINE, q, k)
+        assert ids.tolist() == w_ids.tolist() and np.array_equal(d, w_d)
+    st = three.gather_stats()
+    assert st["host"] == len(qs) and st["rccl"] == 0 and not st["rccl_serving"], st
+    three.close()

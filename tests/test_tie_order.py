@@ -217,5 +217,9 @@ def test_reference_order_through_the_filter_scans(pkg, orc, vt, monkeypatch):
     bi, bd, bc = c.scan_topk_batch(dg.L2, qs, k)
     for j in range(len(qs)):
         w_ids, w_d = orc.topk_reference(c.scan_distances(dg.L2, qs[j]), None, k)
-        assert bi[j][:bc[j]].tolist() == w_ids.tolist() and np.array_equal(bd[j][:bc[j]], w_d), (vt, j)
+        assert bi[j][:bc[j]].tolist() == w_ids.tolist(), (vt, j)
+        if vt == dg.U8:
+            assert np.array_equal(bd[j][:bc[j]], w_d), (vt, j)
+        else:                     # (a query without a tie keeps the matrix-core kernel's distances: another summation order)
+            assert np.allclose(bd[j][:bc[j]], w_d, rtol=1e-5, atol=1e-6), (vt, j)
     c.close()

@@ -30,6 +30,10 @@ PROBE(k_pk_mul_f32, "v_pk_mul_f32 %0, %2, %2\nv_pk_mul_f32 %1, %2, %2\nv_pk_mul_
 PROBE(k_mul_f64, "v_mul_f64 %0, %4, %4\nv_mul_f64 %1, %4, %4\nv_mul_f64 %2, %4, %4\nv_mul_f64 %3, %4, %4\n", "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3) : "v"((double)seed))
 PROBE(k_dot2_f32_f16, "v_dot2_f32_f16 %0, %4, %4, %0\nv_dot2_f32_f16 %1, %4, %4, %1\nv_dot2_f32_f16 %2, %4, %4, %2\nv_dot2_f32_f16 %3, %4, %4, %3\n", "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(u0))
 
+PROBE(k_fma_mix_sub, "v_fma_mix_f32 %0, %4, 1.0, -%5 op_sel_hi:[1,0,1]\nv_fma_mix_f32 %1, %4, 1.0, -%5 op_sel:[1,0,1] op_sel_hi:[1,0,1]\nv_fma_mix_f32 %2, %5, 1.0, -%4 op_sel_hi:[1,0,1]\nv_fma_mix_f32 %3, %5, 1.0, -%4 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n", "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : "v"(u0), "v"(u0 + 7u))
+PROBE(k_cvt_f32_f16_sdwa, "v_cvt_f32_f16_sdwa %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\nv_cvt_f32_f16_sdwa %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\nv_cvt_f32_f16_sdwa %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\nv_cvt_f32_f16_sdwa %3, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n", "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : "v"(u0))
+PROBE(k_sub_f32, "v_sub_f32 %0, %4, %5\nv_sub_f32 %1, %4, %5\nv_sub_f32 %2, %4, %5\nv_sub_f32 %3, %4, %5\n", "=v"(f0), "=v"(f1), "=v"(f2), "=v"(f3) : "v"(seed), "v"(seed))
+
 template <typename K>
 static void run(const char *name, K kern, int insts_per_rep, int waves) {
     unsigned long long *d, h[2];
@@ -54,6 +58,9 @@ int main() {
         run("v_mul_f64", k_mul_f64, 4, waves);
         run("v_fma_f64", k_fma_f64, 4, waves);
         run("v_dot2_f32_f16", k_dot2_f32_f16, 4, waves);
+        run("v_fma_mix_f32", k_fma_mix_sub, 4, waves);
+        run("v_cvt_f32_f16 sdwa", k_cvt_f32_f16_sdwa, 4, waves);
+        run("v_sub_f32", k_sub_f32, 4, waves);
     }
     return 0;
 }
