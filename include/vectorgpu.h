@@ -267,8 +267,11 @@ int vg_resident_distances_below(vg_corpus *c, int64_t pos0, float bound, uint64_
 int vg_reference_topk_replay(const float *dist, int64_t n, int k, int64_t below_cap, int64_t *out_pos, double *out_dist);
 
 /* ---- per-corpus switches ---- */
-/* single f32 queries through the bf16 shadow copy: 0 = off (plain f32 scans, no shadow copy is built), 1 = on where it
- * serves, -1 = default (environment VG_SCAN_FILTER, else on).  The extension maps vector_init's scan_filter= option here. */
+/* The lower-bound filter scans of single top-k queries (see vg_scan_topk): 0 = off (plain scans, no shadow copy is built),
+ * -1 = default (environment VG_SCAN_FILTER, else on): f32 / f16 / bf16 corpora from 2^20 rows and 512 MB through an int8 shadow
+ * copy (+ 26 % / + 52 % device memory), uint8 / int8 corpora through a high-nibble copy (+ 52 %) only after a probe of a 2M-row
+ * prefix found the data selective under it; 1 = on where it serves WITHOUT that probe (uint8 / int8: the + 52 % is spent at
+ * once).  The extension maps vector_init's scan_filter= option here - for the raw-vector corpus and the quantized one alike. */
 int vg_corpus_set_scan_filter(vg_corpus *c, int mode);
 
 #ifdef __cplusplus

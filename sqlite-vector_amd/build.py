@@ -85,7 +85,7 @@ def build_extension(force=False, verbose=False):
     src = os.path.join(EXT, "vector_ext.c")
     if not os.path.exists(src):
         return None
-    deps = [src, os.path.join(ROOT, "include", "vectorgpu.h")]
+    deps = [src, os.path.join(ROOT, "include", "vectorgpu.h")] + [os.path.join(EXT, f) for f in os.listdir(EXT) if f.endswith(".inc")]
     if not force and not _newer(VEC, deps):
         return VEC
     inc = sqlite_include_dir()
@@ -94,7 +94,7 @@ def build_extension(force=False, verbose=False):
             return VEC            # prebuilt artefact travelled here (GPU box): keep it
         raise RuntimeError("sqlite3ext.h not found: cannot build the SQLite extension host")
     cmd = ["gcc", "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-missing-field-initializers",
-           "-I" + inc, "-I" + os.path.join(ROOT, "include"), "-o", VEC, src, "-ldl", "-lm", "-lpthread"]
+           "-I" + inc, "-I" + os.path.join(ROOT, "include"), "-I" + EXT, "-o", VEC, src, "-ldl", "-lm", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -76,6 +76,44 @@ int vg_ensure_bf16_shadow(vg_corpus *c) {
     return VG_OK;
 }
 
+// f32 corpora through the bf16 filter: the shadow copy the BATCH kernel streams is tile-major (vg_f32_to_bf16_tm_kernel) - the
+// row-major bf16 copy above is what the single-query bf16 filter scan reads (VG_SCAN_FILTER_SHADOW=bf16; the default single-query
+// filter streams the int8 copy, so by default only this one exists).  Same + 50 % of the corpus; tm_rows / tm_cap are shared with
+// the f16 / bf16 corpora's tile-major copy (a corpus has one element type).  -1: switched off / no memory (row-major gather).
+extern "C" int vg_f32_to_bf16_tm_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int dim,
+                                        uint8_t *dev_out, long long ostride, hipStream_t stream);
+static int ensure_bf16_tile_major(vg_corpus *c) {
+    if (env_int("VG_BATCH_TILE_MAJOR", 1) == 0 || c->tm_disabled) return -1;
+    const long long bs = bf16_shadow_stride(c);
+    if (c->tm_cap < c->n_rows) {
+        const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_rows_tm) hipFree(c->d_rows_tm);
+        c->d_rows_tm = nullptr; c->tm_cap = 0; c->tm_rows = 0;
+        const size_t bytes = (size_t)((cap + 31) / 32 * 32) * bs;                               // whole tiles
+        if (hipMalloc(&c->d_rows_tm, bytes) != hipSuccess) { (void)hipGetLastError(); c->d_rows_tm = nullptr; c->tm_disabled = true; return -1; }
+        HIP_TRY(hipMemsetAsync(c->d_rows_tm, 0, bytes, c->stream));                             // (rows past the end: defined bytes)
+        c->tm_cap = cap;
+    }
+    if (c->tm_rows < c->n_rows) {
+        int rc = vg_f32_to_bf16_tm_launch(c->d_rows, c->tm_rows, c->n_rows - c->tm_rows, c->stride, c->dim, c->d_rows_tm, bs, c->stream);
+        if (rc != 0) return vg_fail(VG_ERR_HIP, "tile-major bf16 shadow pass failed: %s", hipGetErrorString((hipError_t)rc));
+        c->tm_rows = c->n_rows;
+    }
+    return VG_OK;
+}
+
+// what the batched bf16 filter streams for an f32 corpus: the tile-major shadow copy, else (switched off / no room) the row-major one
+static int ensure_f32_batch_shadow(vg_corpus *c, const uint8_t **rows, int *tiled) {
+    const int rct = ensure_bf16_tile_major(c);
+    if (rct == VG_OK) { *rows = c->d_rows_tm; *tiled = 1; return VG_OK; }
+    if (rct != -1) return rct;
+    const int rc = vg_ensure_bf16_shadow(c);
+    if (rc != VG_OK) return rc;
+    *rows = c->d_rows_bf; *tiled = 0;
+    return VG_OK;
+}
+
 // f16 / bf16 corpora: the tile-major copy the matrix-core kernel streams (+ 100 % of the corpus in HBM, made at the first batch and
 // extended per appended row; without it every LDS-DMA instruction gathers 32-byte runs from 32 rows - vg_batch_i8.hip).  A corpus
 // it does not fit next to keeps the row-major gather.
@@ -158,10 +196,12 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
                       (vg_batch_lds_bytes(c->stride, k) == 0 || batch_f32_filter_short_rows(c));
     const bool f32_mfma_serves = (c->vtype == VG_TYPE_F32) && vg_batch_lds_bytes(c->stride, k) != 0;
     if (c->vtype == VG_TYPE_F32 && c->bfilter_cooldown > 0 && env_int("VG_F32_FILTER", -1) < 0) --c->bfilter_cooldown;
+    const uint8_t *f32_shadow = nullptr;                   // f32 through the bf16 filter: the shadow copy its matrix core reads
+    int f32_shadow_tiled = 0;
     if (f32_filter && f32_mfma_serves) {
         // the shadow copy (+ 50 % of the corpus) and the norms must fit; a corpus they do not fit next to keeps the f32 kernel
         int rcs = vg_ensure_row_norms(c);
-        if (rcs == VG_OK) rcs = vg_ensure_bf16_shadow(c);
+        if (rcs == VG_OK) rcs = ensure_f32_batch_shadow(c, &f32_shadow, &f32_shadow_tiled);
         if (rcs == VG_ERR_NOMEM) { (void)hipGetLastError(); c->filter_disabled = true; f32_filter = false; }
         else if (rcs != VG_OK) return rcs;
     }
@@ -200,7 +240,10 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     } else if (half || metric != VG_DIST_DOT) {            // f16 / bf16: every metric's filter needs sum x^2 per row
         int rcn = vg_ensure_row_norms(c);
         if (rcn != VG_OK) return rcn;
-        if (f32_filter && (rcn = vg_ensure_bf16_shadow(c)) != VG_OK) return rcn;
+    }
+    if (f32_filter && !f32_shadow) {
+        const int rcn = ensure_f32_batch_shadow(c, &f32_shadow, &f32_shadow_tiled);
+        if (rcn != VG_OK) return rcn;
     }
 
     hipEvent_t *evs = nullptr;
@@ -212,8 +255,8 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
         hipEventRecord(evs[0], c->stream);
     }
     const int mode = metric == VG_DIST_DOT ? 0 : (metric == VG_DIST_COSINE ? 1 : 2), root = metric == VG_DIST_L2 ? 1 : 0;
-    const uint8_t *hrows = f32_filter ? c->d_rows_bf : c->d_rows;       // what the half-precision kernel's matrix core reads
-    int hrows_tiled = 0;
+    const uint8_t *hrows = f32_filter ? f32_shadow : c->d_rows;         // what the half-precision kernel's matrix core reads
+    int hrows_tiled = f32_filter ? f32_shadow_tiled : 0;
     if (half && !f32_filter) {
         const int rct = ensure_half_tile_major(c);
         if (rct == VG_OK) { hrows = c->d_rows_tm; hrows_tiled = 1; }

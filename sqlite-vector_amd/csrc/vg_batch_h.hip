@@ -720,6 +720,42 @@ extern "C" int vg_f32_to_bf16_launch(const uint8_t *dev_rows, long long row0, lo
     return (int)hipGetLastError();
 }
 
+// f32 rows -> the TILE-MAJOR bf16 shadow copy in one pass (what vg_tile_major_kernel makes of an f16 / bf16 corpus): tile t = rows
+// 32t .. 32t+31, chunk column g of the 32 rows = one 512-byte run.  The batched filter streams this copy with 1 KiB-contiguous
+// LDS-DMA pieces instead of gathering 32-byte runs from 32 shadow rows (round 2: 1.3x the shadow copy's bytes in HBM traffic).
+__global__ __launch_bounds__(256) void vg_f32_to_bf16_tm_kernel(const uint8_t *rows, long long row0, long long n, long long stride,
+                                                                int dim, uint8_t *out, long long ostride) {
+    const int groups = (int)(ostride / 16);
+    const long long tiles = ((row0 + n + 31) >> 5) - (row0 >> 5);         // tiles the rows [row0, row0 + n) touch
+    const long long total = tiles * 32 * groups;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // consecutive threads take consecutive ROWS of one group column: their 16-byte stores are one contiguous 512-byte run
+        const long long tile_rel = i / (32ll * groups);
+        const int within = (int)(i - tile_rel * 32ll * groups);
+        const int g = within >> 5, rr = within & 31;
+        const long long R = (row0 & ~31ll) + tile_rel * 32 + rr;
+        if (R < row0 || R >= row0 + n) continue;
+        const float *src = reinterpret_cast<const float *>(rows + R * stride) + 8 * g;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = 8 * g + 2 * j;
+            const uint32_t lo = (e < dim) ? __float_as_uint(src[2 * j]) : 0u, hi = (e + 1 < dim) ? __float_as_uint(src[2 * j + 1]) : 0u;
+            w[j] = ((lo + 0x7FFFu + ((lo >> 16) & 1u)) >> 16) | ((hi + 0x7FFFu + ((hi >> 16) & 1u)) & 0xFFFF0000u);
+        }
+        *reinterpret_cast<uint4 *>(out + (R >> 5) * (32 * ostride) + (long long)g * 512 + (R & 31) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+extern "C" int vg_f32_to_bf16_tm_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int dim,
+                                        uint8_t *dev_out, long long ostride, hipStream_t stream) {
+    if (n <= 0) return 0;
+    const long long tiles = ((row0 + n + 31) >> 5) - (row0 >> 5);
+    long long blocks = (tiles * 32 * (ostride / 16) + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(vg_f32_to_bf16_tm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dev_rows, row0, n, stride, dim, dev_out, ostride);
+    return (int)hipGetLastError();
+}
+
 // type_code 0 / 1: dev_rows / dev_queries hold f16 / bf16 elements, zero padded rows of stride_bytes; dev_xrows = the row-major
 // corpus; rows_tiled: dev_rows is its tile-major copy (vg_tile_major_launch; whole tiles allocated).
 // type_code 2: an f32 corpus - dev_rows is its bf16 shadow copy (stride_bytes per row), dev_xrows / dev_queries the f32 rows /

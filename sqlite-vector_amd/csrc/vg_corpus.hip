@@ -210,6 +210,9 @@ static void note_rowids(vg_corpus *c, const int64_t *rowids, int64_t n) {
         }
         c->rowids.insert(c->rowids.end(), rowids, rowids + n);
     } else if (!c->rowids.empty()) {
+        // implicit rowids behind explicit ones: base + position may fall below the last explicit rowid - then the map is no longer
+        // ascending and vg_corpus_find_rowid must not bisect it
+        if (n > 0 && c->rowid_base + c->n_rows <= c->rowids.back()) c->rowids_ascending = false;
         for (int64_t i = 0; i < n; ++i) c->rowids.push_back(c->rowid_base + c->n_rows + i);
     }
 }

@@ -29,10 +29,11 @@ bool vg_scan_filter_would_serve(const vg_corpus *c, int metric, int k);
 // exact-evaluation counters on the device ([0] filter scans, [1] filtered batches) + their pinned host mirror
 int vg_ensure_filter_counters(vg_corpus *c) {
     if (c->d_filter_evals) return VG_OK;
-    HIP_TRY(hipMalloc(&c->d_filter_evals, 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(c->d_filter_evals, 0, 2 * sizeof(unsigned long long), c->stream));
-    HIP_TRY(hipHostMalloc(&c->h_filter_evals, 2 * sizeof(unsigned long long)));
-    c->h_filter_evals[0] = c->h_filter_evals[1] = 0;
+    // [0] filter scans' exact evaluations, [1] filtered batches', [2] filter-scan launches finished (bumped by the kernels)
+    HIP_TRY(hipMalloc(&c->d_filter_evals, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->d_filter_evals, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipHostMalloc(&c->h_filter_evals, 4 * sizeof(unsigned long long)));
+    c->h_filter_evals[0] = c->h_filter_evals[1] = c->h_filter_evals[2] = c->h_filter_evals[3] = 0;
     return VG_OK;
 }
 // Which scans the filter serves: f32 / f16 / bf16 corpora, L2 / squared L2 / dot / cosine (f16 / bf16 cosine with the cached
@@ -285,8 +286,14 @@ int vg_ensure_n4_shadow(vg_corpus *c, int64_t upto_rows) {
         if (c->d_rows_n4) hipFree(c->d_rows_n4);
         if (c->d_n4stat) hipFree(c->d_n4stat);
         c->d_rows_n4 = nullptr; c->d_n4stat = nullptr; c->n4_cap = 0; c->n4_rows = 0;
-        HIP_TRY(hipMalloc(&c->d_rows_n4, (size_t)cap * ns));
-        HIP_TRY(hipMalloc(&c->d_n4stat, (size_t)cap * sizeof(VgN4Stat)));
+        // both or neither: a failed second allocation must not leave the first one pinned while the corpus falls back to the plain scan
+        if (hipMalloc(&c->d_rows_n4, (size_t)cap * ns) != hipSuccess || hipMalloc(&c->d_n4stat, (size_t)cap * sizeof(VgN4Stat)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->d_rows_n4) hipFree(c->d_rows_n4);
+            if (c->d_n4stat) hipFree(c->d_n4stat);
+            c->d_rows_n4 = nullptr; c->d_n4stat = nullptr;
+            return vg_fail(VG_ERR_NOMEM, "no device memory for the high-nibble shadow copy (%lld rows)", (long long)cap);
+        }
         c->n4_cap = cap;
     }
     upto_rows = std::min<int64_t>(upto_rows, c->n_rows);
@@ -322,8 +329,13 @@ int vg_ensure_q8_shadow(vg_corpus *c) {
         if (c->d_rows_q8) hipFree(c->d_rows_q8);
         if (c->d_q8stat) hipFree(c->d_q8stat);
         c->d_rows_q8 = nullptr; c->d_q8stat = nullptr; c->q8_cap = 0; c->q8_rows = 0;
-        HIP_TRY(hipMalloc(&c->d_rows_q8, (size_t)cap * qs));
-        HIP_TRY(hipMalloc(&c->d_q8stat, (size_t)cap * sizeof(float2)));
+        if (hipMalloc(&c->d_rows_q8, (size_t)cap * qs) != hipSuccess || hipMalloc(&c->d_q8stat, (size_t)cap * sizeof(float2)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->d_rows_q8) hipFree(c->d_rows_q8);
+            if (c->d_q8stat) hipFree(c->d_q8stat);
+            c->d_rows_q8 = nullptr; c->d_q8stat = nullptr;
+            return vg_fail(VG_ERR_NOMEM, "no device memory for the int8 shadow copy (%lld rows)", (long long)cap);
+        }
         c->q8_cap = cap;
     }
     if (c->q8_rows < c->n_rows) {
@@ -415,8 +427,11 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
         // last look averaged more than 1/8 of the rows (an exact evaluation is cheap since up to 64 / xlpr of them run at once -
         // ~0.2 ns each chip-wide - and the filter pass itself takes a quarter to a half of the plain scan's time), the next 256 scans of this corpus take the plain kernel, then the
         // filter is tried again.
+        // (the mirror holds the counter as of the last launch whose copy has LANDED and, in word [2], how many filter launches had
+        // finished by then: averaging over launches still in flight would bias the figure low)
         const unsigned long long now = *(volatile unsigned long long *)c->h_filter_evals;
-        const long long launches = c->filter_launches - c->filter_launches_seen;
+        const long long landed = (long long)*(volatile unsigned long long *)(c->h_filter_evals + 2);
+        const long long launches = std::min<long long>(c->filter_launches, landed) - c->filter_launches_seen;
         if (launches >= 2) {
             if ((now - c->filter_evals_seen) / (unsigned long long)launches > (unsigned long long)(c->n_rows / 8) && !env_int("VG_SCAN_FILTER_NO_GUARD", 0))
                 c->filter_cooldown = 256;
@@ -427,7 +442,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
             if (avg > (unsigned long long)(c->n_rows / 128)) c->filter_prepass_div = std::max(16, c->filter_prepass_div / 2);
             else if (avg < (unsigned long long)(c->n_rows / 1024)) c->filter_prepass_div = std::min(128, c->filter_prepass_div * 2);
             c->filter_evals_seen = now;
-            c->filter_launches_seen = c->filter_launches;
+            c->filter_launches_seen += launches;
         }
         if (c->filter_cooldown > 0 && !probing) { --c->filter_cooldown; return -1; }
     }
@@ -509,7 +524,8 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     if (evs) hipEventRecord(evs[2], stream);
     const int rcm = vg_launch_merge_one((const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys, stream);
     if (evs) hipEventRecord(evs[3], stream);
-    HIP_TRY(hipMemcpyAsync(c->h_filter_evals, c->d_filter_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    // counter [0] and the number of finished filter launches [2] (bumped by the kernel itself) travel in ONE copy: consistent
+    HIP_TRY(hipMemcpyAsync(c->h_filter_evals, c->d_filter_evals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     if (rcm != 0) return vg_fail(VG_ERR_HIP, "merge launch failed: %s", hipGetErrorString((hipError_t)rcm));
     HIP_TRY(hipGetLastError());
     if (probing) {

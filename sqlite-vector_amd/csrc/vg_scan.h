@@ -60,6 +60,9 @@ __device__ inline void vg_load_batch(uint4 (&dst)[U], const uint8_t *rows, long 
 #ifndef VG_HALF_LAUNDER
 #define VG_HALF_LAUNDER 1
 #endif
+#ifndef VG_BF16_HOIST_Q
+#define VG_BF16_HOIST_Q 1
+#endif
 #define VG_STORE_FLOATS 1024          // store mode: distances parked in LDS per wavefront between bursts of stores
 
 // EX = true: the variants tie_order = reference needs (vg_reforder.hip) - a start threshold from a pass over the rows in front
@@ -141,7 +144,9 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
         if constexpr (VT == T_F16 || VT == T_BF16) {
             // keep the query as RAW halves in registers: without this the compiler hoists the widened (f32 / f64)
             // copies out of the loop - up to 48 more VGPRs per lane, which is what capped U (bytes in flight)
-            if (VG_HALF_LAUNDER) {
+            // (bf16 with U <= 3 - its dot / cosine shapes - has the registers: there the hoisted f32 copies of the query save two
+            // unpack operations per element pair, VG_BF16_HOIST_Q)
+            if (VG_HALF_LAUNDER && !(VG_BF16_HOIST_Q && VT == T_BF16 && U <= 3)) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) asm volatile("" : "+v"(q[u].x), "+v"(q[u].y), "+v"(q[u].z), "+v"(q[u].w));
             }

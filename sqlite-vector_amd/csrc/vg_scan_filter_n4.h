@@ -182,6 +182,7 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_n4_kernel(FilterScanA
         if (lane == 0 && n_exact) atomicAdd(blk, n_exact);
         __syncthreads();
         if (threadIdx.x == 0 && *blk) atomicAdd(a.evals, (unsigned long long)*blk);
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(a.evals + 2, 1ull);      // (launches finished: what the host's guard averages over)
         __syncthreads();
     }
     vg_block_publish(smem, mine, k, a.cand + (long long)blockIdx.x * VG_WAVE);
