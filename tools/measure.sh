@@ -10,6 +10,9 @@
 #          dist       the N-rank path on this 1-GPU box: 1 rank over RCCL (forced), 2 ranks sharing the device over gloo
 #          others     the other workloads' lines (c1, c3b, c5h, stage)
 #          matrix     tools_kernel_matrix.py: plain kernels + default path, all five types
+#          stage      bench.py --workload stage (staging GB/s, minmax / quantize / int8-shadow kernels against the HBM peak)
+#          shards     tools/shards_gather_bench.py: vg_shards' candidate gather, host vs RCCL, per query
+#          probe      tools/valu_probe.hip: issue cost of the VALU instructions the f16 / bf16 kernels are made of
 # Everything lands in gpurun_out/<tag>/; copy what is worth keeping into profiles/ (tools/summarize_profiles.py --keep does).
 tag=${1:?tag}; shift
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
@@ -20,7 +23,7 @@ cd "$REPO"
 for step in "$@"; do
   echo "==== $step"
   case "$step" in
-    tests)    timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > "$OUT/pytest_gpu.txt"; cat "$OUT/pytest_gpu.txt" ;;
+    tests)    timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -15 > "$OUT/pytest_gpu.txt"; cat "$OUT/pytest_gpu.txt" ;;
     newtests) timeout 1500 python -m pytest $VG_TESTS -m gpu -x -q 2>&1 | tail -40 > "$OUT/pytest_new.txt"; cat "$OUT/pytest_new.txt" ;;
     bench)    ( time timeout 900 python bench.py $VG_BENCH_ARGS ) > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; tail -3 "$OUT/bench_default.err"; cut -c1-600 "$OUT/bench_default.json" ;;
     stats)    cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -o run -- python "$REPO/bench.py" --steps 20 --warmup 5 --no-cpu-baseline $VG_BENCH_ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof_stats.err"; cd "$REPO"
@@ -33,6 +36,9 @@ for step in "$@"; do
     others)   for w in c1 c3b c5h stage; do timeout 600 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1; done > "$OUT/bench_lines_other_workloads.jsonl"; cut -c1-400 "$OUT/bench_lines_other_workloads.jsonl" ;;
     matrix)   ( echo "# default path"; python tools/tools_kernel_matrix.py --rows 10000000 --dims 384 --types 1,2,3 --filter -1
                 echo "# filter off (plain kernels)"; python tools/tools_kernel_matrix.py --rows 10000000 --dims 384 --types 1,2,3,4,5 --filter 0 ) 2>&1 | grep -v amdgpu.ids > "$OUT/kernel_matrix.txt"; cut -c1-300 "$OUT/kernel_matrix.txt" ;;
+    stage)    timeout 600 python bench.py --workload stage 2> "$OUT/bench_stage.err" | tail -1 > "$OUT/bench_stage.json"; cut -c1-2500 "$OUT/bench_stage.json" ;;
+    shards)   timeout 600 python tools/shards_gather_bench.py 2> "$OUT/shards_gather.err" | grep '^{' > "$OUT/shards_gather.json"; cat "$OUT/shards_gather.json" ;;
+    probe)    hipcc --offload-arch=gfx950 -O3 tools/valu_probe.hip -o /tmp/valu_probe 2>/dev/null && /tmp/valu_probe > "$OUT/valu_probe.txt" 2>&1; grep "waves/CU  4" "$OUT/valu_probe.txt" ;;
     *)        echo "unknown step $step" ;;
   esac
 done
