@@ -1,34 +1,42 @@
 #!/usr/bin/env python3
 """bench.py - vectors scanned / second for the sqlite-vector hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b|c5h|c5f] [--no-also]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b|c5h|c5f|stage] [--no-also]
 
 Default line (BASELINE.json configs[1]): 10M x 384 f32, L2, top-20, single query, corpus resident in HBM, answered by
 the PLAIN f32 scan kernel (vg_scan_kernel; the shadow-copy filter is switched off for this corpus), so that
 `roofline` is SURVEY 8(d)'s figure: algorithmic bytes N*D*4 = 15.36 GB per launch / the kernel's mean duration from HIP
-events recorded around it on its own stream inside the timed region, against the 8 TB/s HBM3E peak.
+events recorded around it on its own stream inside the timed region, against the 8 TB/s HBM3E peak.  `roofline.traffic` is the
+PMC FETCH_SIZE figure of profiles/pmc_traffic.json - emitted only while that file's kernel-source hash matches this build.
 A "step" is ONE complete query: upload the query, scan the whole shard, reduce to k candidates, bring the k keys back
 and decode them - what vector_full_scan's xFilter costs once the corpus is staged.
 
-The same run appends (N = 1, default workload only; --no-also skips them, --also filter,c3,c5 picks):
+The same run appends (N = 1, default workload only; --no-also skips them, --also filter,c3,c5,matrix,c4 picks):
   filter_scan  the SAME queries over the SAME corpus through the product's default path for a corpus of this size: the lower-bound
                filter over an int8 shadow copy + exact f32 re-evaluation of the candidates (vg_scan_filter.h).  It answers the
                f32 question with the f32 scan's rowids and distance bits but STREAMS int8: its rate is priced on the bytes it
                streams (dtype_streamed / frac_on_streamed) and is never reported under dtype f32 / roofline.frac.
-  also.c3      10M x 768 uint8 cosine top-20 (configs[2]): own roofline (7.68 GB per launch, the PLAIN kernel) and cpu_baseline;
-               tie_order (what the reference's result order costs); nibble_filter_probe + filter_scan (what the product does by
-               default: the high-nibble filter, probed on a prefix, same answers, half the bytes)
+  also.c3      10M x 768 uint8 cosine top-20 (configs[2]; bytes = an f32 U[0,1) source quantized with the reference's formula):
+               own roofline (7.68 GB per launch, the PLAIN kernel) and cpu_baseline; tie_order (the reference's result order -
+               the SQL surface's default for integer types - next to (distance, position) order, with the replay counters);
+               nibble_filter_probe + filter_scan (the high-nibble filter, probed on a prefix, same answers, half the bytes)
   also.c5      1024 queries x 10M x 384 f32 dot top-20 (configs[4]): own roofline (7.864 TFLOP per launch against the
                157.3 TF f32 MFMA peak, the f32 matrix-core kernel) and cpu_baseline; filter_batch (the product's default for a
                corpus of this size: bf16 matrix-core filter + exact f32 re-evaluation, priced on the bf16 peak)
+  also.kernel_matrix   f16 / bf16 / int8 x L2 / cosine at 10M x 384 through their PLAIN kernels: frac of the HBM peak each
+  also.c4_one_gpu      north_star's target sentence: 100M x 384 f32 L2 resident on ONE device, the plain kernel
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): configs[3] - the corpus row-sharded over the ranks,
-12.5M x 384 f32 rows per rank (8 ranks = the stated 100M rows; weak scaling: every rank count uses that shard size),
-each step = local scan -> all_gather of the per-shard candidate keys over RCCL/xGMI -> rank 0 merges.
-value = rows scanned by ALL ranks / max-over-ranks time.
+N > 1: configs[3] - the corpus row-sharded over the ranks, 12.5M x 384 f32 rows per rank (8 ranks = the stated 100M rows; weak
+scaling: every rank count uses that shard size), each step = local scan -> all_gather of the per-shard candidate keys over
+RCCL/xGMI -> rank 0 merges.  value = rows scanned by ALL ranks / max-over-ranks time; roofline.per_rank lists every rank's kernel.
+`python bench.py --gpus N` WITHOUT a rank environment starts the N ranks itself (torch.distributed.run, 127.0.0.1) and refuses,
+non-zero and without printing a line, when fewer than N devices are visible or when a launcher's WORLD_SIZE disagrees with --gpus.
+(VG_BENCH_SHARE_DEVICES=1: the ranks share the visible devices and exchange over gloo - a functional check of the N-rank path on a
+smaller box; --selftest-launch: the launch + exchange + merge plumbing with fabricated keys, no device - tests/test_bench_launch.py.)
 
-cpu_baseline = the reference's own kernel + top-k loop (oracle/_ref/libref_avx2.so, built from /root/reference by
-oracle/Makefile) on ONE host core - the reference is single-threaded - over a bounded sample, timed in this run.
+cpu_baseline (rank 0, every N) = the reference's own kernel + top-k loop (oracle/_ref/libref_avx2.so, built from /root/reference
+by oracle/Makefile) on ONE host core - the reference is single-threaded - over a bounded sample, timed in this run; all_cores =
+the same loop on every logical core of the host, one thread each over its own rows (a generous upper bound).
 """
 import argparse
 import json

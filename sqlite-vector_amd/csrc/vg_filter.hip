@@ -543,7 +543,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
             hipFree(c->d_rows_n4); hipFree(c->d_n4stat);
             c->d_rows_n4 = nullptr; c->d_n4stat = nullptr; c->n4_rows = 0; c->n4_cap = 0;
         }
-        return vg_launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream);   // 1: the filter over every row; 2: -1 (plain scan)
+        return vg_launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream, ref_emit);   // 1: the filter over every row; 2: -1 (plain scan)
     }
     return VG_OK;
 }

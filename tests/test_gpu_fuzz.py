@@ -82,3 +82,62 @@ def test_random_batches_vs_single_scans(pkg, chunk):
                 assert np.all(np.abs(dist[i][:cnt[i]] - one_dist) <= 1e-5 * (np.abs(one_dist) + scale) + 1e-6), tag
                 assert len(set(ids[i][:cnt[i]].tolist()) ^ set(one_ids.tolist())) <= 2, tag
         c.close()
+
+
+def _tie_cases(seed, count):
+    """(type, metric, dim, rows, k, value levels, planted duplicates, filter scans forced, shards, seed): corpora whose distances tie
+    at every density from "never" to "constantly", on both sides of the sizes where the reference-order scan changes its form
+    (store-mode replay below 2^17 rows, fused replay above; k + 1 > 64: store mode again)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        vt = int(rng.choice([dg.U8, dg.I8, dg.F32, dg.F16]))
+        metric = int(rng.choice(dg.ALL_METRICS))
+        dim = int(rng.choice([rng.integers(1, 12), rng.integers(12, 100), rng.integers(100, 400)], p=[0.4, 0.4, 0.2]))
+        n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 20000), rng.integers(131072, 400000)], p=[0.3, 0.35, 0.35]))
+        k = int(rng.choice([1, 2, 5, 20, 40, 63, 64, 100]))
+        levels = int(rng.choice([2, 4, 16, 256]))
+        dups = int(rng.choice([0, 0, 3, 40]))
+        filt = bool(rng.integers(0, 2)) and n >= 131072 and metric != dg.L1
+        shards = int(rng.choice([1, 1, 3]))
+        out.append((vt, metric, dim, n, k, levels, dups, filt, shards, int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_reference_order_fuzz(pkg, orc, chunk, monkeypatch):
+    """tie_order = reference on random tie-heavy shapes, every path it can take (plain / filter kernels, one corpus / shards, the
+    fused replay / the store-mode replay / no replay at all): rowids AND order must be the reference's slot algorithm's
+    (orc.topk_reference, pinned to the reference extension) over the GPU's own distances.  VG_FUZZ_CASES scales the sweep."""
+    import os
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    per_chunk = max(1, int(os.environ.get("VG_FUZZ_CASES", "48")) // 4)
+    for vt, metric, dim, n, k, levels, dups, filt, shards, seed in _tie_cases(3000 + chunk, per_chunk):
+        rng = np.random.default_rng(seed)
+        if vt == dg.U8:
+            rows = rng.integers(0, levels, (n, dim)).astype(np.uint8)
+        elif vt == dg.I8:
+            rows = rng.integers(-(levels // 2), levels // 2 + 1, (n, dim)).astype(np.int8)
+        else:
+            rows = dg.to_storage(vt, (rng.integers(0, levels, (n, dim)) - levels // 2).astype(np.float32) / 2.0)
+        q = rows[int(rng.integers(0, n))].copy()
+        for _ in range(dups):                                               # exact copies: ties at distance 0 and elsewhere
+            rows[int(rng.integers(0, n))] = rows[int(rng.integers(0, n))]
+        tag = (vt, metric, dim, n, k, levels, dups, filt, shards, seed)
+        if shards == 1:
+            c = pkg.Corpus(vt, dim)
+            c.append(rows)
+        else:
+            c = pkg.Shards(vt, dim, [0] * shards, block_rows=int(rng.choice([257, 4099, 65536])))
+            c.append(rows)
+        c.set_scan_filter(1 if filt else 0)
+        c.set_tie_order(pkg.TIE_REFERENCE)
+        dist = c.scan_distances(metric, q)
+        want_ids, want_d = orc.topk_reference(dist, None, k)
+        ids, d = c.scan_topk(metric, q, k)
+        assert ids.tolist() == want_ids.tolist() and np.array_equal(d, want_d), tag
+        c.set_tie_order(pkg.TIE_POSITION)
+        oids, od, _ = orc.topk_ordered(dist, None, k)
+        ids, d = c.scan_topk(metric, q, k)
+        assert ids.tolist() == oids.tolist() and np.array_equal(d, od), tag
+        c.close()
