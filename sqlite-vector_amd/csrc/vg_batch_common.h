@@ -41,12 +41,19 @@ __device__ __forceinline__ float vgb_kth_distance(uint64_t kth) {
 // range lets ~k rows per query through, ~6k per query in all instead of 32k.  From the second stage on, partition 0 of a
 // query group seeds its lists with the merged keys (they stand for rows of EARLIER stages, which no later stage meets again),
 // so every stage writes - and every merge reads - the same npart lists per query.
-// bounds[0 .. n]: stage i scans tiles [bounds[i], bounds[i+1]); returns n.  growth_pct: VG_BATCH_STAGES (200 = doubling; default 400: three stages at 1/32 - fewer launches, the same survivors within 10 %;
-// 0 = one real pass over everything).
+// bounds[0 .. n]: stage i scans tiles [bounds[i], bounds[i+1]); returns n.  growth_pct: VG_BATCH_STAGES (200 = doubling,
+// 0 = one real pass over everything), else the caller's default.
+// Round 3 re-measured both knobs on the kernels as they are now (tile-major copies, tile-minimum pre-pass, staged passes;
+// tools/batch_knob_sweep.py, profiles/r4h_batch_knob_sweeps.jsonl): the pre-pass wants to be SMALL - 1/512 of the rows instead of
+// 1/32 - because the staged passes do the warming-up more cheaply than a longer pre-pass does: 1024 x 10M, f32 through the bf16
+// filter 10.54 -> 8.95 ms, f16 dot 9.92 -> 8.68, bf16 cosine 10.03 -> 8.43, uint8 cosine 9.01 -> 7.61, uint8 dot 7.61 -> 6.57,
+// int8 L2 7.70 -> 6.61; 256 queries 3.12 -> 2.72 (f32) / 2.70 -> 2.24 (uint8).  Growth: doubling for the half-precision kernel
+// with several query groups (its exact evaluations are the expensive part), x4 otherwise (fewer launches).
 #include <cstdlib>
-static inline int vgb_stage_bounds(long long ntiles, long long pre_tiles, long long *bounds, int max_stages) {
+#define VGB_PREPASS_DENOM_DEFAULT 512
+static inline int vgb_stage_bounds(long long ntiles, long long pre_tiles, long long *bounds, int max_stages, int default_growth_pct = 400) {
     const char *e = getenv("VG_BATCH_STAGES");
-    const int growth_pct = (e && *e) ? atoi(e) : 400;
+    const int growth_pct = (e && *e) ? atoi(e) : default_growth_pct;
     int n = 0;
     bounds[0] = 0;
     if (pre_tiles > 0 && growth_pct > 100) {

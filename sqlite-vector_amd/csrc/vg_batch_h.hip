@@ -786,14 +786,14 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
         if (type_code == 2) return vgh_launch_real_f32(&b, ntb, blocks, smem, stream);
         return type_code == 1 ? vgh_launch_real_bf16(&b, ntb, blocks, smem, stream) : vgh_launch_real_f16(&b, ntb, blocks, smem, stream);
     };
-    // Large corpora: a BOUND pre-pass over the first 1/32 of the rows gives every query an upper bound of its final
+    // Large corpora: a BOUND pre-pass over the first 1/512 of the rows (round 3; 1/32 before) gives every query an upper bound of its final
     // k-th best distance (no exact evaluations - with thresholds starting at +Inf they were a quarter of the whole
     // time); the real pass then scans EVERY row starting from those thresholds.  (1/16 .. 1/32 measured best: 11.7 ms
     // at 1024 x 10M x 384; 1/64 12.2, 1/8 12.4, 1/4 13.9.)
     long long pre = 0;
     {
         const char *e = getenv("VG_BATCH_PREPASS");
-        const int denom = (e && *e) ? atoi(e) : 32;
+        const int denom = (e && *e) ? atoi(e) : VGB_PREPASS_DENOM_DEFAULT;     // (vg_batch_common.h: re-measured in round 3)
         if (denom > 0 && ntiles >= 65536) pre = ((ntiles / denom + npart - 1) / npart) * npart;      // whole partitions; < 2M rows: one pass
     }
     int rc;
@@ -810,7 +810,7 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
     // the real pass, in stages over growing row ranges (vg_batch_common.h): the first one scans the pre-pass rows again (their
     // lists hold bounds, not distances), every later one starts from - and partition 0 carries on - the merged lists so far
     long long bounds[16];
-    const int nstages = vgb_stage_bounds(ntiles, pre, bounds, 16);
+    const int nstages = vgb_stage_bounds(ntiles, pre, bounds, 16, G >= 2 ? 200 : 400);     // (several query groups: doubling)
     for (int s = 0; s < nstages; ++s) {
         a.tile_begin = bounds[s]; a.tile_end = bounds[s + 1];
         a.tiles_per_part = (int)((a.tile_end - a.tile_begin + npart - 1) / npart);

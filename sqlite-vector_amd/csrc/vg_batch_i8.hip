@@ -736,12 +736,12 @@ extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_ro
     const int G = nq_pad / vg_batch_i8_queries_per_block(stride_bytes);
     const int blocks = G * ((npart + 7) / 8) * 8;
     const long long ntiles = (n_rows + VGI_TILE - 1) / VGI_TILE;
-    // Large corpora: the PRE pass over the first 1/32 of the rows (one insert per query and tile) hands every query a
+    // Large corpora: the PRE pass over the first 1/512 of the rows (round 3; 1/32 before - one insert per query and tile) hands every query a
     // start threshold; the real pass scans every row from there.  Both write lists 0 .. npart-1 of the candidate buffer.
     long long pre = 0;
     {
         const char *e = getenv("VG_BATCH_PREPASS");
-        const int denom = (e && *e) ? atoi(e) : 32;
+        const int denom = (e && *e) ? atoi(e) : VGB_PREPASS_DENOM_DEFAULT;     // (vg_batch_common.h: re-measured in round 3)
         if (denom > 0 && ntiles >= 65536) pre = ((ntiles / denom + npart - 1) / npart) * npart;      // < 2M rows: one pass
     }
     int rc;
