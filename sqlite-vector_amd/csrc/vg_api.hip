@@ -29,8 +29,20 @@ static int max_chunks_per_lane(int vtype, int acc) {
     return 8;
 }
 
+// preference among shapes that waste the same share of lane slots (higher is better).  Round 1 preferred 6 chunks per lane; round 3
+// re-measured (profiles/r4k_launch_shape_sweep_c2_c3.txt, r4j_c4_one_gpu_launch_shapes.txt): for f32 / uint8 / int8 rows TWICE the
+// lanes per row with 3 chunks each - 512 contiguous bytes of a row per load instruction instead of 256 - streams faster at every
+// size: 10M x 384 f32 0.863 -> 0.875 of the peak, 12.5M 0.854 -> 0.870, 100M 0.827 -> 0.858, 10M x 768 uint8 0.809 -> 0.813.
+// (Not beyond 32 lanes per row - two crossbar steps in the butterfly - and not for f16 / bf16, whose kernels are bound by their
+// arithmetic: 16 x 3 measured slower than 8 x 6 there, profiles/r4b_kernel_matrix_half_shapes.txt.)
+static int shape_pref(int vtype, int l2, int U) {
+    static const int pref[9] = {0, 1, 2, 4, 5, 0, 6, 0, 3};
+    const bool wide = (vtype == VG_TYPE_F32 || vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8) && !env_int("VG_SHAPE_PREF_ROUND1", 0);
+    if (wide && U == 3 && l2 <= 5) return 7;
+    return pref[U];
+}
+
 bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap) {
-    static const int pref[9] = {0, 1, 2, 4, 5, 0, 6, 0, 3};   // preference rank by U (higher is better)
     const int max_u = std::min(max_chunks_per_lane(vtype, acc), u_cap);
     double best_eff = -1.0; int best_flag = -1, best_pref = -1; Shape best = {0, 0, false};
     for (int l2 = 0; l2 <= 6; ++l2) {
@@ -41,9 +53,10 @@ bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap) {
         if (!U) continue;
         double eff = (double)nch / ((double)lpr * U);
         int flag = (lpr >= 8 || lpr >= nch) ? 1 : 0;
+        const int pr = shape_pref(vtype, l2, U);
         bool better = eff > best_eff + 1e-9 ||
-                      (fabs(eff - best_eff) <= 1e-9 && (flag > best_flag || (flag == best_flag && pref[U] > best_pref)));
-        if (better) { best_eff = eff; best_flag = flag; best_pref = pref[U]; best.lpr_log2 = l2; best.U = U; }
+                      (fabs(eff - best_eff) <= 1e-9 && (flag > best_flag || (flag == best_flag && pr > best_pref)));
+        if (better) { best_eff = eff; best_flag = flag; best_pref = pr; best.lpr_log2 = l2; best.U = U; }
     }
     if (best.U == 0 || env_int("VG_FORCE_LONG", 0)) { best.lpr_log2 = 6; best.U = VG_LONG_U; best.long_rows = true; }
     int fl = env_int("VG_LPR_LOG2", -1), fu = env_int("VG_U", -1);   // experiment overrides
