@@ -33,12 +33,15 @@ static int max_chunks_per_lane(int vtype, int acc) {
 // re-measured (profiles/r4k_launch_shape_sweep_c2_c3.txt, r4j_c4_one_gpu_launch_shapes.txt): for f32 / uint8 / int8 rows TWICE the
 // lanes per row with 3 chunks each - 512 contiguous bytes of a row per load instruction instead of 256 - streams faster at every
 // size: 10M x 384 f32 0.863 -> 0.875 of the peak, 12.5M 0.854 -> 0.870, 100M 0.827 -> 0.858, 10M x 768 uint8 0.809 -> 0.813.
-// (Not beyond 32 lanes per row - two crossbar steps in the butterfly - and not for f16 / bf16, whose kernels are bound by their
-// arithmetic: 16 x 3 measured slower than 8 x 6 there, profiles/r4b_kernel_matrix_half_shapes.txt.)
+// 64 lanes x 3 beats 32 x 6 as well (2.6M x 768 f32: 6.72 -> 6.92 TB/s, the two crossbar steps of its butterfly notwithstanding),
+// while 4 chunks per lane are NOT improved by 2 at twice the lanes (f32 128 / 256 / 512, uint8 512 / 1024: equal or slower).
+// Not for f16 / bf16, whose kernels are bound by their arithmetic: 16 x 3 measured slower than 8 x 6 there
+// (profiles/r4b_kernel_matrix_half_shapes.txt).
 static int shape_pref(int vtype, int l2, int U) {
     static const int pref[9] = {0, 1, 2, 4, 5, 0, 6, 0, 3};
     const bool wide = (vtype == VG_TYPE_F32 || vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8) && !env_int("VG_SHAPE_PREF_ROUND1", 0);
-    if (wide && U == 3 && l2 <= 5) return 7;
+    (void)l2;
+    if (wide && U == 3) return 7;
     return pref[U];
 }
 
