@@ -776,6 +776,21 @@ def also_c3(args, pkg, torch, shard, also_set, n_rows, k, nq, device_index):
         tie["reference_over_position"] = tie["ms_per_query_reference"] / tie["ms_per_query_position"]
         if hasattr(c3, "tie_stats"):
             tie["reference_path_counters"] = c3.tie_stats()
+        # ... and what a query WITH a tie costs: the same corpus under L1 - integer sums, so equal distances among the 21 best are
+        # routine - where most queries go through the fused replay (prefix pass + the candidates the scan emitted + host replay)
+        before = c3.tie_stats() if hasattr(c3, "tie_stats") else None
+        for name, mode in (("position", pkg.TIE_POSITION), ("reference", pkg.TIE_REFERENCE)):
+            c3.set_tie_order(mode)
+            for i in range(12):                  # (untimed: the first tie also loads the emitting kernels' code object, ~ms, once per process)
+                c3.scan_topk(5, q3[(30 + i) % nq], k)
+            t0 = time.perf_counter()
+            for i in range(20):
+                c3.scan_topk(5, q3[(2 + i) % nq], k)
+            tie["l1_ms_per_query_%s" % name] = (time.perf_counter() - t0) / 20 * 1e3
+        tie["l1_reference_over_position"] = tie["l1_ms_per_query_reference"] / tie["l1_ms_per_query_position"]
+        if before is not None:
+            after = c3.tie_stats()
+            tie["l1_reference_path_counters"] = {kk: after[kk] - before[kk] for kk in after}
         c3.set_tie_order(pkg.TIE_POSITION)
         tie["what"] = ("vg_scan_topk end to end, top-%d, 20 queries each; reference = the same scan with one more list slot, the "
                        "reference's slot algorithm replayed on the host only for queries whose k+1 best distances hold a tie" % k)
