@@ -25,7 +25,7 @@ static const int kAllowedU[] = {1, 2, 3, 4, 6, 8};
 // bf16 dot / cosine, which spill beyond U = 3 (measured 2.4 TB/s at U = 6).
 static int max_chunks_per_lane(int vtype, int acc) {
     if (vtype == VG_TYPE_F16) return 6;
-    if (vtype == VG_TYPE_BF16) return (acc == A_L2 || acc == A_L1) ? 6 : 3;
+    if (vtype == VG_TYPE_BF16) return 3;      // (dot / cosine spill beyond 3; L2 / L1 fit 6 but measured 3 % faster at 3: profiles/r4p_half_shape_ab.txt)
     return 8;
 }
 
