@@ -21,8 +21,8 @@ out = sys.argv[1]
 
 # rocprofv3 kernel name (prefix) -> bench.py's kernel name @ rows, for the kernels bench.py attaches `traffic` to
 KNOWN = {
-    "vg_scan_kernel<1, 0, 6, true, false>": "scan_f32_l2_u6_lpr16_nt",
-    "vg_scan_kernel<4, 1, 6, true, false>": "scan_u8_cos_u6_lpr8_nt",
+    "vg_scan_kernel<1, 0, 3, true, false>": "scan_f32_l2_u3_lpr32_nt",
+    "vg_scan_kernel<4, 1, 3, true, false>": "scan_u8_cos_u3_lpr16_nt",
     "vg_scan_filter_kernel<1, 0, 3, true, true>": "scan_filter_f32_l2_q8_u3_lpr8_nt",
     "vg_scan_filter_n4_kernel<4, 2, 3, true>": "scan_filter_u8_cos_n4_u3_lpr8_nt",
 }
