@@ -37,17 +37,32 @@ static int max_chunks_per_lane(int vtype, int acc) {
 // while 4 chunks per lane are NOT improved by 2 at twice the lanes (f32 128 / 256 / 512, uint8 512 / 1024: equal or slower).
 // Not for f16 / bf16, whose kernels are bound by their arithmetic: 16 x 3 measured slower than 8 x 6 there
 // (profiles/r4b_kernel_matrix_half_shapes.txt).
-static int shape_pref(int vtype, int l2, int U) {
+static int shape_pref(int vtype, int l2, int U, bool ragged) {
     static const int pref[9] = {0, 1, 2, 4, 5, 0, 6, 0, 3};
     const bool wide = (vtype == VG_TYPE_F32 || vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8) && !env_int("VG_SHAPE_PREF_ROUND1", 0);
-    (void)l2;
     if (wide && U == 3) return 7;
+    // rows no shape covers exactly (e.g. 100 floats = 25 chunks): 2 chunks per lane at twice the lanes beat 4 (longer contiguous
+    // runs over rows that are not line-aligned): 15M x 100 f32 5.3 -> 6.1-6.6 TB/s (profiles/r4q_short_rows_shape_ab.txt)
+    if (wide && ragged && U == 2 && l2 <= 4) return 6;      // (not across 32+ lanes: 7.5M x 200 f32 cosine 6.6 -> 6.0 TB/s with the crossbar step)
     return pref[U];
 }
 
 bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap) {
     const int max_u = std::min(max_chunks_per_lane(vtype, acc), u_cap);
-    double best_eff = -1.0; int best_flag = -1, best_pref = -1; Shape best = {0, 0, false};
+    const bool round1 = env_int("VG_SHAPE_PREF_ROUND1", 0) != 0;
+    // Short rows (3 .. 8 chunks): with ONE chunk per lane a batch is one load + a whole epilogue (butterfly, conversions, sqrt /
+    // divide, key, ballot) for 64 / lanes-per-row rows - half the lanes per row with 2 chunks each amortise it over twice the rows.
+    // Measured (same file): f32 32 floats 5.1-5.9 -> 6.0-6.2 TB/s on every metric; uint8 64 / 100 / 128 bytes L2 and cosine + 8-14 %,
+    // but dot / L1 (light epilogues) - 9-15 %: so for integer rows only where the epilogue is heavy.
+    const bool short_rows = !round1 && nch >= 3 && nch <= 8 &&
+                            (vtype == VG_TYPE_F32 || ((vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8) && (acc == A_L2 || acc == A_COS)));
+    double best_eff = -1.0;
+    for (int l2 = 0; l2 <= 6; ++l2) {                        // (the best cover any shape reaches: "ragged" rows have none at 1.0)
+        const int lpr = 1 << l2, need = (nch + lpr - 1) / lpr;
+        for (int a : kAllowedU) if (a >= need && a <= max_u) { best_eff = std::max(best_eff, (double)nch / ((double)lpr * a)); break; }
+    }
+    const bool ragged = best_eff < 0.999;
+    best_eff = -1.0; int best_flag = -1, best_pref = -1; Shape best = {0, 0, false};
     for (int l2 = 0; l2 <= 6; ++l2) {
         int lpr = 1 << l2;
         int need = (nch + lpr - 1) / lpr;
@@ -55,8 +70,8 @@ bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap) {
         for (int a : kAllowedU) if (a >= need && a <= max_u) { U = a; break; }
         if (!U) continue;
         double eff = (double)nch / ((double)lpr * U);
-        int flag = (lpr >= 8 || lpr >= nch) ? 1 : 0;
-        const int pr = shape_pref(vtype, l2, U);
+        int flag = (lpr >= 8 || lpr >= nch || (short_rows && U == 2)) ? 1 : 0;
+        const int pr = shape_pref(vtype, l2, U, ragged);
         bool better = eff > best_eff + 1e-9 ||
                       (fabs(eff - best_eff) <= 1e-9 && (flag > best_flag || (flag == best_flag && pr > best_pref)));
         if (better) { best_eff = eff; best_flag = flag; best_pref = pr; best.lpr_log2 = l2; best.U = U; }
