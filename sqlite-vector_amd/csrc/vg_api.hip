@@ -267,6 +267,9 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     long long blocks = (nbatch + VG_WAVES_PER_BLOCK - 1) / VG_WAVES_PER_BLOCK;
     blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count * bpc));
     blocks = std::min<long long>(blocks, VG_SEL_MAX_HEADS);          // the final rank-select handles <= 256 lists
+    // small corpora: at least two batches per wavefront - the merge kernel's time grows with the number of per-CU lists (6.6 us for
+    // 32, 14 us for 256) and is most of a 10k-row query; round 3's wider shapes halved the rows per batch, i.e. doubled the lists
+    blocks = std::min<long long>(blocks, std::max<long long>(32, nbatch / (2 * VG_WAVES_PER_BLOCK)));
 
     ScanArgs a{};
     a.rows = c->d_rows;

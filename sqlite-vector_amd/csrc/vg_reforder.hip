@@ -235,7 +235,8 @@ extern "C" int vg_scan_topk_reference(vg_corpus *c, int metric, const void *quer
             return VG_OK;
         }
         if (attempt == 0) ++c->ref_stats[1];
-        c->ref_hot = 64;
+        c->ref_hot = 16;        // (break-even: a plain-kernel scan pays ~85 us for prefix pass + emitting kernel, a tie without them a
+                                // second ~1.2 ms scan - emitting pays from one tie in ~14 queries on)
         if (emit && c->ref_prefix_rows > 0) {
             VgRefSlots slots;
             rc = replay_emitted(c, k, slots);
