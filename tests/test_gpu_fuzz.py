@@ -27,9 +27,15 @@ def _cases(seed, count):
     return out
 
 
+def _scale():
+    """VG_FUZZ_SCALE=10 runs every sweep of this file ten times as wide (new seeds): the occasional long soak"""
+    import os
+    return max(1, int(os.environ.get("VG_FUZZ_SCALE", "1")))
+
+
 @pytest.mark.parametrize("chunk", range(6))
 def test_random_shapes_vs_oracle(pkg, orc, chunk):
-    for vt, metric, dim, n, k, low, seed in _cases(1000 + chunk, 25):
+    for vt, metric, dim, n, k, low, seed in _cases(1000 + chunk, 25 * _scale()):
         rows = dg.corpus(vt, n, dim, seed, low_entropy=low)
         q = dg.query(vt, dim, seed + 1, low_entropy=low)
         want = orc.scan_distances(orc.AVX2, metric, vt, q, rows)
@@ -54,7 +60,7 @@ def test_random_batches_vs_single_scans(pkg, chunk):
     """batched scans (matrix-core kernels and their fallbacks) against the single-query kernel on random shapes:
     quantized types bit for bit, f16 / bf16 within 1e-6, f32 within 1e-5 with the same rowids unless two candidates differ by less than that."""
     rng = np.random.default_rng(2000 + chunk)
-    for _ in range(20):
+    for _ in range(20 * _scale()):
         vt = int(rng.choice([dg.F32, dg.U8, dg.I8, dg.F16, dg.BF16]))
         metric = int(rng.choice(dg.ALL_METRICS))
         dim = int(rng.integers(1, 513)) if vt == dg.F32 else (int(rng.integers(1, 2200)) if vt in (dg.U8, dg.I8) else int(rng.integers(1, 1100)))
@@ -111,7 +117,7 @@ def test_reference_order_fuzz(pkg, orc, chunk, monkeypatch):
     (orc.topk_reference, pinned to the reference extension) over the GPU's own distances.  VG_FUZZ_CASES scales the sweep."""
     import os
     monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
-    per_chunk = max(1, int(os.environ.get("VG_FUZZ_CASES", "48")) // 4)
+    per_chunk = max(1, int(os.environ.get("VG_FUZZ_CASES", str(48 * _scale()))) // 4)
     for vt, metric, dim, n, k, levels, dups, filt, shards, seed in _tie_cases(3000 + chunk, per_chunk):
         rng = np.random.default_rng(seed)
         if vt == dg.U8:
