@@ -274,7 +274,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     ScanArgs a{};
     a.rows = c->d_rows;
     a.query = dev_query;
-    a.cand = c->d_cand;
+    a.cand = plan.lists_out ? plan.lists_out : c->d_cand;
     a.out_dist = dev_out_dist;
     a.n_rows = n_rows;
     a.stride = c->stride;
@@ -329,7 +329,9 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
     if (evs) hipEventRecord(evs[2], stream);
-    if (!dev_out_dist) {
+    if (plan.lists_out) {                                   // the caller's kernel reads the lists itself: no merge launch
+        if (plan.n_lists_out) *plan.n_lists_out = (int)blocks;
+    } else if (!dev_out_dist) {
         hipLaunchKernelGGL(vg_merge_kernel, dim3(1), dim3(VG_MERGE_THREADS), 0, stream,
                            (const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys);
     }

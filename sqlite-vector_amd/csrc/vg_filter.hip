@@ -494,6 +494,8 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     hipEvent_t *evs = probing ? nullptr : vg_prof_slot(c, (uint8_t)(VG_EVF_MERGE | (prepass ? VG_EVF_PREPASS : 0)));
     if (evs) hipEventRecord(evs[0], stream);
     a.init_keys = nullptr;
+    a.init_lists = nullptr;
+    a.n_init_lists = 0;
     a.emit = nullptr;
     a.emit_cap = 0;
     if (prepass) {
@@ -513,19 +515,43 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
             a.emit_cap = VG_BELOW_CAP;
             c->ref_prefix_rows = pre.n_rows;
         }
+        // The pre-pass' per-CU lists go to the filter kernel UNMERGED (every workgroup takes the k-th smallest list head itself,
+        // vg_kth_head): one launch less on the query's critical path (~12 us of a 0.68 ms query).  VG_SCAN_FILTER_PREMERGE=1: round 2's
+        // form (merge launch, init_keys) - also what serves a staged query too long to leave the head scratch free.
+        int n_pre_lists = 0;
+        const bool unmerged = !env_int("VG_SCAN_FILTER_PREMERGE", 0) &&
+                              smem >= (size_t)VG_PUBLISH_LDS_BYTES &&
+                              (size_t)c->nch * 16 + ((q8 && !f32) ? (size_t)nch_b * 64 : 0) + 64 <= (size_t)VG_PUBLISH_LDS_BYTES - VG_KTH_HEAD_SCRATCH_BYTES - 16;
+        if (unmerged) {
+            if (!c->d_cand_pre) HIP_TRY(hipMalloc(&c->d_cand_pre, (size_t)VG_SEL_MAX_HEADS * VG_WAVE * sizeof(uint64_t)));
+            pre.lists_out = c->d_cand_pre;
+            pre.n_lists_out = &n_pre_lists;
+        }
         const int rcp = vg_launch_plain_scan(c, metric, dev_query, k, dev_out_keys, stream, pre);
         if (rcp != VG_OK) return rcp;
-        a.init_keys = dev_out_keys;                      // read by every workgroup before the final merge overwrites it
+        if (unmerged) { a.init_lists = c->d_cand_pre; a.n_init_lists = n_pre_lists; }
+        else a.init_keys = dev_out_keys;                 // read by every workgroup before the final merge overwrites it
         if (evs) hipEventRecord(evs[1], stream);
     }
     if (smem > 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
     ++c->filter_launches;
     if (evs) hipEventRecord(evs[2], stream);
+    // counter [0] and the number of finished filter launches [2] (bumped by the kernel itself) travel in ONE copy - on a side stream
+    // behind the filter kernel, so that the final merge and the caller's key read-back do not queue up behind it
+    bool mirrored = false;
+    if (!probing && !env_int("VG_SCAN_FILTER_MIRROR_INLINE", 0)) {
+        if (!c->aux_stream) {
+            if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->aux_stream = nullptr; }
+            else if (hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); hipStreamDestroy(c->aux_stream); c->aux_stream = nullptr; }
+        }
+        if (c->aux_stream && hipEventRecord(c->aux_ev, stream) == hipSuccess && hipStreamWaitEvent(c->aux_stream, c->aux_ev, 0) == hipSuccess)
+            mirrored = hipMemcpyAsync(c->h_filter_evals, c->d_filter_evals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->aux_stream) == hipSuccess;
+        if (!mirrored) (void)hipGetLastError();
+    }
     const int rcm = vg_launch_merge_one((const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys, stream);
     if (evs) hipEventRecord(evs[3], stream);
-    // counter [0] and the number of finished filter launches [2] (bumped by the kernel itself) travel in ONE copy: consistent
-    HIP_TRY(hipMemcpyAsync(c->h_filter_evals, c->d_filter_evals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    if (!mirrored) HIP_TRY(hipMemcpyAsync(c->h_filter_evals, c->d_filter_evals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     if (rcm != 0) return vg_fail(VG_ERR_HIP, "merge launch failed: %s", hipGetErrorString((hipError_t)rcm));
     HIP_TRY(hipGetLastError());
     if (probing) {

@@ -62,6 +62,9 @@ struct vg_corpus {
     uint8_t *d_query = nullptr;    // nch*16 bytes
     uint8_t *h_query = nullptr;    // pinned
     uint64_t *d_cand = nullptr;    // max_blocks * 64 keys
+    uint64_t *d_cand_pre = nullptr; // the same size: a filter scan's pre-pass lists, read unmerged by the filter kernel
+    hipStream_t aux_stream = nullptr;   // side stream + event: the exact-evaluation counter's host mirror travels off the scan's critical path
+    hipEvent_t aux_ev = nullptr;
     uint64_t *d_keys = nullptr;    // 64 keys
     uint64_t *h_keys = nullptr;    // pinned, 64 keys
     float *d_dist = nullptr;       // lazily sized to n_rows (stream scans / large k / tie_order = reference)
@@ -166,6 +169,9 @@ struct ScanPlan {
     bool ref_emit = false;
     float *store_prefix = nullptr;            // (the prefix pass itself) top-k mode that also stores every row's distance here ...
     unsigned long long *emit_reset = nullptr; // ... and zeroes the candidate counter of the pass behind it
+    // a pre-pass whose per-CU lists are consumed UNMERGED by the kernel behind it (vg_kth_head): lists go to lists_out, no merge launch
+    uint64_t *lists_out = nullptr;
+    int *n_lists_out = nullptr;
 };
 #define VG_BELOW_CAP (1 << 17)        // candidate pairs the device buffer holds (more: the store-mode replay takes over)
 #define VG_REF_EMIT_MIN_ROWS (1 << 17) // below this a reference-order scan with a tie simply replays a store-mode scan (cheap at that size)

@@ -22,6 +22,31 @@
 // scratch bytes needed in LDS by vg_select_lists (heads + survivors + 2 words)
 #define VG_SEL_SCRATCH_BYTES ((VG_SEL_MAX_HEADS + VG_SURV_CAP) * 8 + 16)
 
+// The k-th smallest of the first ceil(k / L) keys of L sorted lists: an upper bound of the k-th smallest key overall (those k keys
+// are all <= it) and a tight one - step 1 of vg_select_lists on its own.  Used by the filter kernels to take their start threshold
+// straight from a pre-pass' per-CU lists (2 us in every workgroup) instead of waiting for a merge LAUNCH (11-15 us) to reduce them.
+// Every thread of the workgroup calls (two barriers); scratch: (VG_SEL_MAX_HEADS + 1) * 8 bytes of LDS.  EMPTY: fewer than k keys.
+#define VG_KTH_HEAD_SCRATCH_BYTES ((VG_SEL_MAX_HEADS + 1) * 8)
+__device__ inline uint64_t vg_kth_head(const uint64_t *lists, int L, int k, uint8_t *scratch) {
+    uint64_t *heads = reinterpret_cast<uint64_t *>(scratch);
+    uint64_t *tau_slot = heads + VG_SEL_MAX_HEADS;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int m = (k + L - 1) / L;
+    const int H = L * m;
+    for (int h = tid; h < H; h += nthr) heads[h] = lists[(long long)(h / m) * VG_WAVE + (h % m)];
+    if (tid == 0) *tau_slot = VG_EMPTY_KEY;
+    __syncthreads();
+    for (int h = tid; h < H; h += nthr) {
+        const uint64_t mykey = heads[h];
+        if (mykey == VG_EMPTY_KEY) continue;
+        int rank = 0;
+        for (int j = 0; j < H; ++j) rank += (heads[j] < mykey) ? 1 : 0;
+        if (rank == k - 1) *tau_slot = mykey;
+    }
+    __syncthreads();
+    return *tau_slot;
+}
+
 // lists : L lists of 64 slots each (ascending, VG_EMPTY_KEY padded; only slots < k are looked at); LDS or global
 // out   : 64 slots, receives the k smallest ascending, VG_EMPTY_KEY padded
 // scratch: VG_SEL_SCRATCH_BYTES of LDS, 16-byte aligned.  All threads of the workgroup must call (barriers inside).

@@ -56,6 +56,8 @@ struct FilterScanArgs {
     int xlpr_log2, xU;         // the launch shape vg_scan_kernel would use for this corpus: the exact evaluation sums in ITS order
     const uint64_t *init_keys; // the k best of a plain scan over the first rows (64 keys) or nullptr: its k-th distance is
                                //   an upper bound of the final k-th best - the lists do not have to warm up from +Inf
+    const uint64_t *init_lists; // ... or that scan's per-CU candidate lists BEFORE their merge (n_init_lists x 64 keys): every workgroup takes
+    int n_init_lists;           //   the k-th smallest list head itself (vg_kth_head) - one launch less in front of this kernel
     unsigned long long *evals; // instrumentation: += exact evaluations of this launch (one atomic per workgroup)
     unsigned long long *emit;  // tie_order = reference (vg_reforder.hip): [count | emit_cap pairs] - every row a list accepts whose distance
     unsigned emit_cap;         //   is strictly below init_keys' k-th distance, as (position << 32 | float bits); nullptr = off
@@ -286,8 +288,10 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
     };
     float gate_init = INFINITY;
     uint64_t emit_below = VG_EMPTY_KEY;                                   // (no pass in front: every accepted row may enter the slots)
-    if (a.init_keys) {
-        const uint64_t kk = a.init_keys[k - 1];
+    if (a.init_lists || a.init_keys) {
+        // (the tail of the publish area is free until the publish; the host launches this form only when the staged query ends below it)
+        const uint64_t kk = a.init_lists ? vg_kth_head(a.init_lists, a.n_init_lists, k, smem + VG_PUBLISH_LDS_BYTES - VG_KTH_HEAD_SCRATCH_BYTES - 16)
+                                         : a.init_keys[k - 1];
         if (kk != VG_EMPTY_KEY) { gate_init = gate_of(vg_sortable_f32((uint32_t)(kk >> 32))); emit_below = kk & 0xFFFFFFFF00000000ull; }
     }
     float thr_gate = gate_init;

@@ -79,8 +79,10 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_n4_kernel(FilterScanA
     };
     float gate_init = INFINITY;
     uint64_t emit_below = VG_EMPTY_KEY;                                   // (no pass in front: every accepted row may enter the slots)
-    if (a.init_keys) {
-        const uint64_t kk = a.init_keys[k - 1];
+    if (a.init_lists || a.init_keys) {
+        // (the tail of the publish area is free until the publish; the host launches this form only when the staged query ends below it)
+        const uint64_t kk = a.init_lists ? vg_kth_head(a.init_lists, a.n_init_lists, k, smem + VG_PUBLISH_LDS_BYTES - VG_KTH_HEAD_SCRATCH_BYTES - 16)
+                                         : a.init_keys[k - 1];
         if (kk != VG_EMPTY_KEY) { gate_init = gate_of(vg_sortable_f32((uint32_t)(kk >> 32))); emit_below = kk & 0xFFFFFFFF00000000ull; }
     }
     float thr_gate = gate_init;
