@@ -106,8 +106,6 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_rows) hipFree(c->d_rows);
     if (c->d_query) hipFree(c->d_query);
     if (c->h_query) hipHostFree(c->h_query);
-    if (c->aux_stream) { hipStreamSynchronize(c->aux_stream); hipStreamDestroy(c->aux_stream); }
-    if (c->aux_ev) hipEventDestroy(c->aux_ev);
     if (c->d_cand) hipFree(c->d_cand);
     if (c->d_cand_pre) hipFree(c->d_cand_pre);
     if (c->d_keys) hipFree(c->d_keys);

@@ -516,7 +516,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
             c->ref_prefix_rows = pre.n_rows;
         }
         // The pre-pass' per-CU lists go to the filter kernel UNMERGED (every workgroup takes the k-th smallest list head itself,
-        // vg_kth_head): one launch less on the query's critical path (~12 us of a 0.68 ms query).  VG_SCAN_FILTER_PREMERGE=1: round 2's
+        // vg_kth_head): one launch less on the query's critical path (pre-pass 37 -> 26 us, the filter kernel + 4 us: 0.684 -> 0.676 ms per query).  VG_SCAN_FILTER_PREMERGE=1: round 2's
         // form (merge launch, init_keys) - also what serves a staged query too long to leave the head scratch free.
         int n_pre_lists = 0;
         const bool unmerged = !env_int("VG_SCAN_FILTER_PREMERGE", 0) &&
@@ -537,21 +537,12 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
     ++c->filter_launches;
     if (evs) hipEventRecord(evs[2], stream);
-    // counter [0] and the number of finished filter launches [2] (bumped by the kernel itself) travel in ONE copy - on a side stream
-    // behind the filter kernel, so that the final merge and the caller's key read-back do not queue up behind it
-    bool mirrored = false;
-    if (!probing && !env_int("VG_SCAN_FILTER_MIRROR_INLINE", 0)) {
-        if (!c->aux_stream) {
-            if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->aux_stream = nullptr; }
-            else if (hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); hipStreamDestroy(c->aux_stream); c->aux_stream = nullptr; }
-        }
-        if (c->aux_stream && hipEventRecord(c->aux_ev, stream) == hipSuccess && hipStreamWaitEvent(c->aux_stream, c->aux_ev, 0) == hipSuccess)
-            mirrored = hipMemcpyAsync(c->h_filter_evals, c->d_filter_evals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->aux_stream) == hipSuccess;
-        if (!mirrored) (void)hipGetLastError();
-    }
     const int rcm = vg_launch_merge_one((const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys, stream);
     if (evs) hipEventRecord(evs[3], stream);
-    if (!mirrored) HIP_TRY(hipMemcpyAsync(c->h_filter_evals, c->d_filter_evals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    // counter [0] and the number of finished filter launches [2] (bumped by the kernel itself) travel in ONE copy: consistent.
+    // (Sending it down a side stream behind the filter kernel was measured: the event record + wait cost more than the copy
+    // holds up the key read-back - 0.684 against 0.676 ms per query, profiles/r4v_filter_floor_ab.txt.)
+    HIP_TRY(hipMemcpyAsync(c->h_filter_evals, c->d_filter_evals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     if (rcm != 0) return vg_fail(VG_ERR_HIP, "merge launch failed: %s", hipGetErrorString((hipError_t)rcm));
     HIP_TRY(hipGetLastError());
     if (probing) {

@@ -63,8 +63,6 @@ struct vg_corpus {
     uint8_t *h_query = nullptr;    // pinned
     uint64_t *d_cand = nullptr;    // max_blocks * 64 keys
     uint64_t *d_cand_pre = nullptr; // the same size: a filter scan's pre-pass lists, read unmerged by the filter kernel
-    hipStream_t aux_stream = nullptr;   // side stream + event: the exact-evaluation counter's host mirror travels off the scan's critical path
-    hipEvent_t aux_ev = nullptr;
     uint64_t *d_keys = nullptr;    // 64 keys
     uint64_t *h_keys = nullptr;    // pinned, 64 keys
     float *d_dist = nullptr;       // lazily sized to n_rows (stream scans / large k / tie_order = reference)
