@@ -21,8 +21,9 @@
  *   - the JSON query vector is freed (the reference leaks it, :1771).
  *
  * Layout: this file holds the includes, the registration and the entry point; the rest lives in vext_*.inc by concern
- * (gpulib, context, tracking, sqlutil, convert, staging, quantize, tvf, batch, cursor).  vext_convert.inc / vext_sqlutil.inc say
- * which of their functions restate reference host code for error-text compatibility.
+ * (gpulib, context, tracking, sqlutil, convert, staging, quantize, tvf, batch, cursor).  The JSON and option-string parsers
+ * (vext_convert.inc / vext_sqlutil.inc) implement the reference's user-visible contract - what is accepted, every error
+ * text - in this repository's own structure; a differential test against the reference extension pins that contract.
  */
 #define _GNU_SOURCE            /* dladdr, strcasestr */
 #include "sqlite3ext.h"

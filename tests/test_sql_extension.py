@@ -82,7 +82,10 @@ def test_conversions_and_errors_match_reference(ext_path, orc):
         pytest.skip("reference extension not built")
     db, rdb = connect(ext_path), connect(ref_path)
     for fn in ("f32", "f16", "bf16", "i8", "u8"):
-        for js in ("[1, 2, 3]", "[0.5,-0.25 , 100]", "[1e-8, 65504, 70000, 3.14159]", "[ 7 ]", "[1,2,3,]", "[]"):
+        # (the malformed ones pin what the parser ACCEPTS as much as its messages: blanks, trailing commas, what may follow a number)
+        for js in ("[1, 2, 3]", "[0.5,-0.25 , 100]", "[1e-8, 65504, 70000, 3.14159]", "[ 7 ]", "[1,2,3,]", "[]",
+                   "[   ", "[", "[ ]", " [1,2", "1,2]", "[1 2]", "[a]", "[1,,2]", "[300]", "[-1]", "[1e400]", "[ 1 , 2 , ]", "[1,2,", "[1,2, ",
+                   "[1;2]", "", "[1,2]]", "[nan, inf]", "[1,2 ", "[,1]", "[-129, 5]", "[0x10]", "  [ 7 ]  "):
             try:
                 a = db.execute("SELECT vector_as_%s(?)" % fn, (js,)).fetchone()[0]
                 ea = None
@@ -129,6 +132,43 @@ def test_conversions_and_errors_match_reference(ext_path, orc):
             except sqlite3.Error as e:
                 errs.append(str(e))
         assert errs[0] == errs[1], (sql, errs)
+
+
+OPTION_STRINGS = [
+    "type=FLOAT32,dimension=3", "t=FLOAT32,d=3", "TYPE = float16 , DIM = 7", "dimension=3", "type=FLOAT32",
+    "dimension=3,type=FLOAT32,junk,=5,foo=bar", "type=FLOAT32,dimension=3,distance=cosine", "type=FLOAT32,dimension=3,dist=L1",
+    "type=FLOAT32,dimension=3,distance=", "type=FLOAT32,,dimension=3", "type=FLOAT32,dimension=0x10",
+    "type=FLOAT32,dimension=3,max_memory=64KBx", "type=FLOAT32,dimension=3,max_memory=1.5 gb", "type=FLOAT32,dimension=3,normalized=2",
+    "type=FLOAT32,dimension=3,n=1", "type=BFLOAT16,dimension=4,qtype=INT8", "type=FLOAT32,dimension=3,qtype=uint4",
+    "type=FLOAT32,dimension=3,q=UINT8", "type==FLOAT32,dimension=3", "  type=FLOAT32  ,  dimension = 3  ",
+    "type=FLOAT32,dimension=3,typ=INT8", "type=FLOAT32;dimension=3", "dimensionx=3,type=FLOAT32", "type=FLOAT32,dimension=-1",
+    "type=FLOAT32,dimension=abc", "type=FLOAT32,dimension=3,=", "type=FLOAT32,dimension=3,x=,y=2"]
+
+
+def test_option_strings_parse_like_the_reference(ext_path, orc):
+    """Which keys the option parser recognises (the reference matches its keys by PREFIX, in a fixed order), what it skips,
+    and what it rejects: vector_init with each string on both extensions, then three re-inits whose refusal messages name
+    the type / dimension / normalized flag the first call stored (sqlite-vector.c:938-1056, :1377-1401)."""
+    ref_path = orc.ref_extension_path("cpu")
+    if not ref_path:
+        pytest.skip("reference extension not built")
+
+    def probe(path, opts):
+        d = connect(path)
+        d.execute("CREATE TABLE t (id INTEGER PRIMARY KEY, v BLOB)")
+        out = []
+        for o in (opts, "type=FLOAT32,dimension=99991", "type=INT8,dimension=3", "type=FLOAT32,dimension=3,normalized=1"):
+            try:
+                d.execute("SELECT vector_init('t','v',?)", (o,)).fetchall()
+                out.append(None)
+            except sqlite3.Error as e:
+                out.append(str(e))
+                if o is opts:
+                    break
+        return out
+
+    for opts in OPTION_STRINGS:
+        assert probe(ext_path, opts) == probe(ref_path, opts), opts
 
 
 @pytest.mark.parametrize("case", mg.SQL_QUANT_CASES, ids=[c[0] for c in mg.SQL_QUANT_CASES])
