@@ -35,11 +35,15 @@ static int max_chunks_per_lane(int vtype, int acc) {
 // size: 10M x 384 f32 0.863 -> 0.875 of the peak, 12.5M 0.854 -> 0.870, 100M 0.827 -> 0.858, 10M x 768 uint8 0.809 -> 0.813.
 // 64 lanes x 3 beats 32 x 6 as well (2.6M x 768 f32: 6.72 -> 6.92 TB/s, the two crossbar steps of its butterfly notwithstanding),
 // while 4 chunks per lane are NOT improved by 2 at twice the lanes (f32 128 / 256 / 512, uint8 512 / 1024: equal or slower).
-// Not for f16 / bf16, whose kernels are bound by their arithmetic: 16 x 3 measured slower than 8 x 6 there
-// (profiles/r4b_kernel_matrix_half_shapes.txt).
+// f16 too since the batch loads are unconditional (vg_load_batch): while a branch around every load cost the prefetch its overlap,
+// 8 x 6 - more bytes per wait - hid that best and 16 x 3 measured slower (profiles/r4b_kernel_matrix_half_shapes.txt); with the
+// prefetch really in flight behind the arithmetic 16 x 3 wins on every metric (10M x 384 f16: L2 6.91 -> 6.91, cosine 6.53 -> 6.85,
+// dot 6.54 -> 7.01, L1 6.90 -> 6.97 TB/s; 5M x 768: 6.34-6.54 -> 6.65-6.77, profiles/r5c_shape_sweep_unconditional_loads.txt).
+// bf16 takes at most 3 chunks per lane anyway (max_chunks_per_lane).
 static int shape_pref(int vtype, int l2, int U, bool ragged) {
     static const int pref[9] = {0, 1, 2, 4, 5, 0, 6, 0, 3};
-    const bool wide = (vtype == VG_TYPE_F32 || vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8) && !env_int("VG_SHAPE_PREF_ROUND1", 0);
+    const bool wide = (vtype == VG_TYPE_F32 || vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8 || (vtype == VG_TYPE_F16 && !env_int("VG_SHAPE_F16_ROUND3", 0))) &&
+                      !env_int("VG_SHAPE_PREF_ROUND1", 0);
     if (wide && U == 3) return 7;
     // rows no shape covers exactly (e.g. 100 floats = 25 chunks): 2 chunks per lane at twice the lanes beat 4 (longer contiguous
     // runs over rows that are not line-aligned): 15M x 100 f32 5.3 -> 6.1-6.6 TB/s (profiles/r4q_short_rows_shape_ab.txt)
@@ -197,15 +201,19 @@ extern "C" const char *vg_scan_kernel_name(vg_corpus *c, int metric) {
 // (vg_lists.h).  out_keys receives k keys ascending, VG_EMPTY_KEY padded to 64.
 #define VG_MERGE_THREADS 1024
 __global__ __launch_bounds__(VG_MERGE_THREADS) void vg_merge_kernel(const uint64_t *cand, int nlists, int k,
-                                                                    uint64_t *out_keys) {
+                                                                    uint64_t *out_keys, const unsigned long long *mirror_src,
+                                                                    unsigned long long *mirror_dst) {
     __shared__ __attribute__((aligned(16))) uint8_t scratch[VG_SEL_SCRATCH_BYTES];
+    // (filter scans) the counters the kernel in front finished with, copied to their pinned mirror: saves the copy command
+    if (mirror_dst && blockIdx.x == 0 && threadIdx.x < 3) mirror_dst[threadIdx.x] = mirror_src[threadIdx.x];
     // one workgroup per query (gridDim.x = 1 for the single-query scan, NQ for vg_scan_multi_kernel)
     vg_select_lists(cand + (long long)blockIdx.x * nlists * VG_WAVE, nlists, k, out_keys + (long long)blockIdx.x * VG_WAVE, scratch);
 }
 
 // merge launch shared with vg_multi.hip: one workgroup per query
 int vg_launch_merge(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, int nq, hipStream_t stream) {
-    hipLaunchKernelGGL(vg_merge_kernel, dim3((unsigned)nq), dim3(VG_MERGE_THREADS), 0, stream, dev_cand, nlists, k, dev_out_keys);
+    hipLaunchKernelGGL(vg_merge_kernel, dim3((unsigned)nq), dim3(VG_MERGE_THREADS), 0, stream, dev_cand, nlists, k, dev_out_keys,
+                       (const unsigned long long *)nullptr, (unsigned long long *)nullptr);
     return (int)hipGetLastError();
 }
 
@@ -218,8 +226,9 @@ int vg_launch_plain_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int
                          const ScanPlan &plan) {
     return launch_scan(c, metric, dev_query, k, dev_out_keys, nullptr, stream, plan);
 }
-int vg_launch_merge_one(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, hipStream_t stream) {
-    hipLaunchKernelGGL(vg_merge_kernel, dim3(1), dim3(VG_MERGE_THREADS), 0, stream, dev_cand, nlists, k, dev_out_keys);
+int vg_launch_merge_one(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, hipStream_t stream,
+                        const unsigned long long *mirror_src, unsigned long long *mirror_dst) {
+    hipLaunchKernelGGL(vg_merge_kernel, dim3(1), dim3(VG_MERGE_THREADS), 0, stream, dev_cand, nlists, k, dev_out_keys, mirror_src, mirror_dst);
     return (int)hipGetLastError();
 }
 int vg_plain_scan_shape(const vg_corpus *c, int metric, VgShape *out) {
@@ -235,7 +244,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     const int64_t n_rows = (plan.n_rows >= 0) ? std::min<int64_t>(plan.n_rows, c->n_rows) : c->n_rows;
     if (plan.ref_emit) c->ref_prefix_rows = -1;              // (set by whichever launch below really emits)
     if (plan.allow_filter && plan.n_rows < 0 && !dev_out_dist && k <= VG_MAX_FUSED_K) {
-        int rcf = vg_launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream, plan.ref_emit);
+        int rcf = vg_launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream, plan.ref_emit, plan.final_out);
         if (rcf != -1) return rcf;
     }
     Shape s;
@@ -333,7 +342,8 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
         if (plan.n_lists_out) *plan.n_lists_out = (int)blocks;
     } else if (!dev_out_dist) {
         hipLaunchKernelGGL(vg_merge_kernel, dim3(1), dim3(VG_MERGE_THREADS), 0, stream,
-                           (const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys);
+                           (const uint64_t *)c->d_cand, (int)blocks, k, plan.final_out ? plan.final_out : dev_out_keys,
+                           (const unsigned long long *)nullptr, (unsigned long long *)nullptr);
     }
     if (evs) hipEventRecord(evs[3], stream);
     HIP_TRY(hipGetLastError());
@@ -503,10 +513,14 @@ int vg_scan_topk_enqueue_plan(vg_corpus *c, int metric, const void *query, int k
         rc = launch_scan(c, metric, c->h_query, k, c->h_keys, nullptr, c->stream, plan);
         if (rc != VG_OK) return rc;
     } else {
+        // the query is staged into HBM (every workgroup reads it); the k winners are written by the final merge's one workgroup
+        // straight into the pinned h_keys (VG_KEYS_DIRECT=0: into d_keys + a copy command, the form measured against it)
+        const bool keys_direct = env_int("VG_KEYS_DIRECT", 1) != 0;
         HIP_TRY(hipMemcpyAsync(c->d_query, c->h_query, (size_t)c->stride, hipMemcpyHostToDevice, c->stream));
+        if (keys_direct) plan.final_out = c->h_keys;
         rc = launch_scan(c, metric, c->d_query, k, c->d_keys, nullptr, c->stream, plan);
         if (rc != VG_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(c->h_keys, c->d_keys, VG_WAVE * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+        if (!keys_direct) HIP_TRY(hipMemcpyAsync(c->h_keys, c->d_keys, VG_WAVE * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     }
     c->enqueued = true;
     return VG_OK;

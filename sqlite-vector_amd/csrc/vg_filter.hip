@@ -381,7 +381,7 @@ static long long filter_stream_stride(const vg_corpus *c, int metric) {
 
 // Returns -1 when the shape is not served (caller takes the plain scan).
 int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream,
-                          bool ref_emit) {
+                          bool ref_emit, uint64_t *final_out) {
     if (!scan_filter_serves(c, metric)) return -1;
     const bool f32 = (c->vtype == VG_TYPE_F32);
     // The shadow copy and the norms cost HBM next to the corpus (see filter_uses_q8).  An f32 corpus they do not fit next to
@@ -537,12 +537,15 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(VG_BLOCK), smem, stream, a);
     ++c->filter_launches;
     if (evs) hipEventRecord(evs[2], stream);
-    const int rcm = vg_launch_merge_one((const uint64_t *)c->d_cand, (int)blocks, k, dev_out_keys, stream);
+    // counter [0] and the number of finished filter launches [2] (bumped by the kernel itself) travel together: consistent.  The
+    // merge's workgroup copies them into the pinned mirror on its way (VG_SCAN_FILTER_MIRROR_COPY=1: a copy command behind the
+    // merge, the earlier form; sending that down a side stream behind the filter kernel was measured too: the event record + wait
+    // cost more than the copy holds up the key read-back - 0.684 against 0.676 ms per query, profiles/r4v_filter_floor_ab.txt).
+    const bool mirror_in_merge = !probing && env_int("VG_SCAN_FILTER_MIRROR_COPY", 0) == 0;
+    const int rcm = vg_launch_merge_one((const uint64_t *)c->d_cand, (int)blocks, k, (final_out && !probing) ? final_out : dev_out_keys, stream,
+                                        mirror_in_merge ? c->d_filter_evals : nullptr, mirror_in_merge ? c->h_filter_evals : nullptr);
     if (evs) hipEventRecord(evs[3], stream);
-    // counter [0] and the number of finished filter launches [2] (bumped by the kernel itself) travel in ONE copy: consistent.
-    // (Sending it down a side stream behind the filter kernel was measured: the event record + wait cost more than the copy
-    // holds up the key read-back - 0.684 against 0.676 ms per query, profiles/r4v_filter_floor_ab.txt.)
-    HIP_TRY(hipMemcpyAsync(c->h_filter_evals, c->d_filter_evals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    if (!mirror_in_merge) HIP_TRY(hipMemcpyAsync(c->h_filter_evals, c->d_filter_evals, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     if (rcm != 0) return vg_fail(VG_ERR_HIP, "merge launch failed: %s", hipGetErrorString((hipError_t)rcm));
     HIP_TRY(hipGetLastError());
     if (probing) {
@@ -560,7 +563,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
             hipFree(c->d_rows_n4); hipFree(c->d_n4stat);
             c->d_rows_n4 = nullptr; c->d_n4stat = nullptr; c->n4_rows = 0; c->n4_cap = 0;
         }
-        return vg_launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream, ref_emit);   // 1: the filter over every row; 2: -1 (plain scan)
+        return vg_launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream, ref_emit, final_out);   // 1: the filter over every row; 2: -1 (plain scan)
     }
     return VG_OK;
 }

@@ -67,6 +67,17 @@ __device__ inline void vg_f16_prod2(uint32_t qw, uint32_t xw, float &p0, float &
         : "=&v"(p0), "=v"(p1) : "v"(qw), "v"(xw));
 }
 
+// Which rows hold an Inf / NaN element is read off the row's f64 total instead of being tested element pair by element pair (three
+// VALU operations per pair, a quarter to a third of the fast path's instruction stream): every such element makes the total
+// non-finite - x = NaN poisons its term; x = +-Inf gives q - x = -+Inf (or NaN) for L2 / L1 and q * x = +-Inf, or NaN for q = 0,
+// for the products - and opposite infinities meet as NaN, so nothing cancels back to a finite value.  The converse only costs
+// time: a row of finite bf16 values whose f32 product overflows also takes the slow path, which is the reference's algorithm
+// itself.  (f64 never overflows on finite 16-bit inputs: |term| < 2^256.)
+#ifndef VG_HALF_FLAG_FROM_SUM
+#define VG_HALF_FLAG_FROM_SUM 1
+#endif
+__device__ inline uint32_t vg_f64_nonfinite(double s) { return ((uint32_t)__double2hiint(s) & 0x7FF00000u) == 0x7FF00000u ? 1u : 0u; }
+
 template <int VT, int ACC> struct AccumHalf {
     // four independent f64 accumulators per lane: a single chain of dependent v_fma_f64 / v_add_f64 (8 per chunk)
     // left the kernel latency-bound at ~5 TB/s
@@ -78,7 +89,7 @@ template <int VT, int ACC> struct AccumHalf {
     __device__ inline void init() { a0 = a1 = a2 = a3 = 0.0; n0 = n1 = n2 = n3 = 0.0; flag = 0; }
 
     __device__ inline void pair(uint32_t qw, uint32_t xw, double &s0, double &s1, double &m0, double &m1) {
-        flag |= vg_special_pair<VT>(xw);
+        if constexpr (VG_HALF_FLAG_FROM_SUM == 0) flag |= vg_special_pair<VT>(xw);
         if constexpr (VT == T_F16 && VG_HALF_FMA_MIX != 0 && ACC != A_COS) {
             float e0, e1;
             if (ACC == A_L2) {                  // f32 subtract, square in f64 (distance-avx2.c:186-205)
@@ -141,11 +152,15 @@ template <int VT, int ACC> struct AccumHalf {
 
     __device__ static inline void merge_qstat(QStat &into, const QStat &part) { into.qq += part.qq; into.qspecial |= part.qspecial; }
 
-    // true for every lane of the group if any lane saw a special element (or the query has one)
-    __device__ inline bool special(const QStat &qs, int lpr_log2) const { return (vg_group_or(flag, lpr_log2) | qs.qspecial) != 0; }
+    // true for every lane of the group if the row (as seen by finish(), which must have run) or the query has a special element
+    __device__ inline bool special(const QStat &qs, int lpr_log2) const {
+        if constexpr (VG_HALF_FLAG_FROM_SUM != 0) return (flag | qs.qspecial) != 0;       // (finish() left the same total in every lane)
+        return (vg_group_or(flag, lpr_log2) | qs.qspecial) != 0;
+    }
 
     __device__ inline float finish(const QStat &qs, int lpr_log2, int root) {
         const double s = vg_group_sum((a0 + a1) + (a2 + a3), lpr_log2);
+        if constexpr (VG_HALF_FLAG_FROM_SUM != 0) flag = vg_f64_nonfinite(s);
         if (ACC == A_L2) return root ? (float)sqrt(s) : (float)s;                 // distance-avx2.c:217, :421
         if (ACC == A_L1) return (float)s;
         if (ACC == A_DOT) return (float)(-s);
@@ -155,6 +170,7 @@ template <int VT, int ACC> struct AccumHalf {
     // A_COSN: the row's (float) sum x^2 comes from the corpus' cached vector (same f64 accumulation, done once per row)
     __device__ inline float finish_cached_norm(const QStat &qs, int lpr_log2, float nn_row) {
         const double s = vg_group_sum((a0 + a1) + (a2 + a3), lpr_log2);
+        if constexpr (VG_HALF_FLAG_FROM_SUM != 0) flag = vg_f64_nonfinite(s);
         return cosine_epilogue(qs, (float)s, nn_row);
     }
     __device__ static inline float cosine_epilogue(const QStat &qs, float dot, float nnf) {

@@ -170,6 +170,10 @@ struct ScanPlan {
     // a pre-pass whose per-CU lists are consumed UNMERGED by the kernel behind it (vg_kth_head): lists go to lists_out, no merge launch
     uint64_t *lists_out = nullptr;
     int *n_lists_out = nullptr;
+    // where the LAST merge of the launch leaves the k winners, if not in dev_out_keys: the corpus' pinned, device-mapped h_keys -
+    // the one workgroup of the merge writes its 512 bytes straight across the host link and the copy command behind it goes away
+    // (anything in front that reads dev_out_keys on the device - a pre-pass' threshold keys - still finds them in device memory)
+    uint64_t *final_out = nullptr;
 };
 #define VG_BELOW_CAP (1 << 17)        // candidate pairs the device buffer holds (more: the store-mode replay takes over)
 #define VG_REF_EMIT_MIN_ROWS (1 << 17) // below this a reference-order scan with a tie simply replays a store-mode scan (cheap at that size)
@@ -202,10 +206,12 @@ int vg_launch_merge(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_o
 // vg_api.hip <-> vg_filter.hip (the filter scans of vg_scan_filter.h are a translation unit of their own)
 int vg_launch_plain_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream,
                          const ScanPlan &plan);                    // vg_api.hip: the plain scan + merge (the filter's pre-pass)
-int vg_launch_merge_one(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, hipStream_t stream);   // vg_api.hip
+// vg_api.hip; mirror_*: three counter words the merge's workgroup copies on its way (the filter scans' pinned counter mirror)
+int vg_launch_merge_one(const uint64_t *dev_cand, int nlists, int k, uint64_t *dev_out_keys, hipStream_t stream,
+                        const unsigned long long *mirror_src = nullptr, unsigned long long *mirror_dst = nullptr);
 int vg_plain_scan_shape(const vg_corpus *c, int metric, VgShape *out);   // vg_api.hip: launch shape of the plain kernel
 int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, int k, uint64_t *dev_out_keys, hipStream_t stream,
-                          bool ref_emit = false);   // vg_filter.hip; -1: not served
+                          bool ref_emit = false, uint64_t *final_out = nullptr);   // vg_filter.hip; -1: not served
 int vg_scan_topk_enqueue_plan(vg_corpus *c, int metric, const void *query, int k, bool ref_emit);   // vg_api.hip: vg_scan_topk_enqueue with the reference-order extras
 bool vg_scan_filter_would_serve(const vg_corpus *c, int metric, int k);   // vg_filter.hip: a single scan would take a filter scan right now
 bool vg_scan_filter_policy(const vg_corpus *c);      // vg_filter.hip: filter switched on for this corpus and the corpus large enough for the shadow copy to pay

@@ -44,6 +44,17 @@ __device__ inline uint4 vg_load16(const uint8_t *p) {
     return *reinterpret_cast<const uint4 *>(p);
 }
 
+// 16 zero bytes in device memory: where a lane that has nothing to load (a row behind the last one, a chunk behind the row's last
+// one) points its load.  The loads of a batch are UNCONDITIONAL - only the address is selected: a load under `if (valid)` becomes a
+// branch around the instruction, the compiler's wait-count bookkeeping must then assume that none of the prefetch loads were
+// issued, and the wait in front of the CURRENT batch's arithmetic turns into vmcnt(0) - the wavefront sat out the full latency
+// of the prefetch it had just issued before touching data that had long arrived (f16 U = 6, bf16 / uint8 U = 3: every shape
+// whose loop the compiler unrolls into two register sets).  VG_LOAD_PREDICATED=1: the earlier form, for A/B runs.
+#ifndef VG_LOAD_PREDICATED
+#define VG_LOAD_PREDICATED 0
+#endif
+static __device__ __attribute__((aligned(16))) uint32_t vg_zero_chunk[4] = {0u, 0u, 0u, 0u};      // (not const: a constant-address-space pointer would turn the selected loads into flat loads)
+
 template <int U, bool NT>
 __device__ inline void vg_load_batch(uint4 (&dst)[U], const uint8_t *rows, long long row, long long n_rows,
                                      long long stride, int sub, int lpr, int nch) {
@@ -51,9 +62,14 @@ __device__ inline void vg_load_batch(uint4 (&dst)[U], const uint8_t *rows, long 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int c = sub + u * lpr;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < n_rows && c < nch) v = vg_load16<NT>(p + (long long)u * lpr * 16);
-        dst[u] = v;
+        if (VG_LOAD_PREDICATED) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (row < n_rows && c < nch) v = vg_load16<NT>(p + (long long)u * lpr * 16);
+            dst[u] = v;
+        } else {
+            const uint8_t *src = (row < n_rows && c < nch) ? p + (long long)u * lpr * 16 : reinterpret_cast<const uint8_t *>(vg_zero_chunk);
+            dst[u] = vg_load16<NT>(src);
+        }
     }
 }
 
@@ -136,7 +152,8 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
     auto load = [&](uint4 (&dst)[U], float &nn_dst, long long batch) {
         vg_load_batch<U, NT>(dst, a.rows, batch * rpb + rib, (batch < b_end) ? a.n_rows : 0, a.stride, sub, lpr, a.nch);
         // A_COSN: the row's squared norm rides along with the batch prefetch (one dword per row from the cached vector)
-        if constexpr (ACC == A_COSN) { const long long r0 = batch * rpb + rib; nn_dst = (batch < b_end && r0 < a.n_rows) ? a.row_nn[r0] : 0.0f; }
+        // (unconditional for the same reason as the chunk loads: row 0's norm stands in, the row's result is never used)
+        if constexpr (ACC == A_COSN) { const long long r0 = batch * rpb + rib; nn_dst = a.row_nn[(batch < b_end && r0 < a.n_rows) ? r0 : 0]; }
     };
     auto process = [&](uint4 (&cur)[U], float nn_cur, long long bcur) {
         Accum<VT, ACC> acc;
@@ -267,9 +284,14 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_long_kernel(ScanArgs a) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = s * slice + u * VG_WAVE + lane;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (row < a.n_rows && c < a.nch) v = vg_load16<NT>(a.rows + row * a.stride + (long long)c * 16);
-            dst[u] = v;
+            if (VG_LOAD_PREDICATED) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (row < a.n_rows && c < a.nch) v = vg_load16<NT>(a.rows + row * a.stride + (long long)c * 16);
+                dst[u] = v;
+            } else {                                                // (unconditional, address selected: see vg_load_batch)
+                dst[u] = vg_load16<NT>((row < a.n_rows && c < a.nch) ? a.rows + row * a.stride + (long long)c * 16
+                                                                     : reinterpret_cast<const uint8_t *>(vg_zero_chunk));
+            }
         }
     };
     uint4 cur[U], nxt[U];

@@ -339,9 +339,14 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
     float2 q8_cur = make_float2(0.0f, 0.0f), q8_nxt = make_float2(0.0f, 0.0f);
     auto load = [&](uint4 (&dst)[U], float &nrm, float2 &q8s, long long batch) {
         vg_load_batch<U, NT>(dst, a.shadow, batch * rpb + rib, (batch < nbatch) ? a.n_rows : 0, a.bstride, sub, lpr, a.nch_b);
+        // (per-row values: loaded unconditionally from a clamped index, then zeroed - a load under a branch costs the prefetch its
+        // overlap, see vg_load_batch)
         const long long r0 = batch * rpb + rib;
-        nrm = (batch < nbatch && r0 < a.n_rows) ? a.row_norm[r0] : 0.0f;
-        if constexpr (Q8) q8s = (batch < nbatch && r0 < a.n_rows) ? a.q8stat[r0] : make_float2(0.0f, 0.0f);
+        const bool live = batch < nbatch && r0 < a.n_rows;
+        const long long ri = live ? r0 : 0;
+        const float nv = a.row_norm[ri];
+        nrm = live ? nv : 0.0f;
+        if constexpr (Q8) { const float2 qv = a.q8stat[ri]; q8s = live ? qv : make_float2(0.0f, 0.0f); }
     };
     load(cur, nrm_cur, q8_cur, b);
     while (b < nbatch) {

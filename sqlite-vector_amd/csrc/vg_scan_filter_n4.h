@@ -110,8 +110,10 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_n4_kernel(FilterScanA
     uint4 st_cur = zero4, st_nxt = zero4;
     auto load = [&](uint4 (&dst)[U], uint4 &rs, long long batch) {
         vg_load_batch<U, NT>(dst, a.shadow, batch * rpb + rib, (batch < nbatch) ? a.n_rows : 0, a.bstride, sub, lpr, a.nch_b);
-        const long long r0 = batch * rpb + rib;
-        rs = (batch < nbatch && r0 < a.n_rows) ? *reinterpret_cast<const uint4 *>(stats + r0) : zero4;
+        const long long r0 = batch * rpb + rib;                       // (unconditional load, clamped index: see vg_load_batch)
+        const bool live = batch < nbatch && r0 < a.n_rows;
+        const uint4 rv = *reinterpret_cast<const uint4 *>(stats + (live ? r0 : 0));
+        rs = live ? rv : zero4;
     };
     load(cur, st_cur, b);
     while (b < nbatch) {
