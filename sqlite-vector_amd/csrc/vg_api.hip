@@ -25,7 +25,9 @@ static const int kAllowedU[] = {1, 2, 3, 4, 6, 8};
 // bf16 dot / cosine, which spill beyond U = 3 (measured 2.4 TB/s at U = 6).
 static int max_chunks_per_lane(int vtype, int acc) {
     if (vtype == VG_TYPE_F16) return 6;
-    if (vtype == VG_TYPE_BF16) return 3;      // (dot / cosine spill beyond 3; L2 / L1 fit 6 but measured 3 % faster at 3: profiles/r4p_half_shape_ab.txt)
+    // bf16: dot / cosine spill beyond 3.  L2 / L1 fit 6; with the unconditional batch loads L2 measures 2 % faster at 8 lanes x 6
+    // (10M x 384: 6.55 / 6.69 against 6.43 / 6.57 TB/s in two alternating passes), L1 2 % slower (profiles/r5d_shape_ab_f32_half.txt)
+    if (vtype == VG_TYPE_BF16) return (acc == A_L2 && !env_int("VG_SHAPE_BF16_L2_U3", 0)) ? 6 : 3;
     return 8;
 }
 

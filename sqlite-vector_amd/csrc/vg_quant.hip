@@ -17,11 +17,24 @@
 
 // Both passes share one decomposition (the scan kernels' own): 16 lanes per row, lane l owns the 16-byte chunks l, l + 16, ... of
 // the row - every load is a full 16 bytes of a 256-byte run, no index division anywhere (round 2's first draft did a 64-bit
-// divide + modulo per ELEMENT).  The zero padding behind `dim` elements is masked out: it must not become a minimum.
+// divide + modulo per ELEMENT).  A lane first issues the loads of G of its chunks - unconditionally, a chunk behind the row's
+// last one reads 16 zero bytes instead (a load under a branch is waited for on the spot: the first form of these kernels had ONE
+// load in flight per wavefront and ran at 0.59 / 0.73 of the HBM peak) - and then works through them.  G = chunks per lane of the
+// row, up to 8 (rows of up to 128 chunks in one go, longer ones in rounds of 128).  The zero padding behind `dim` elements is
+// masked out: it must not become a minimum.
 typedef uint32_t vgq_u32x4 __attribute__((ext_vector_type(4)));
-__device__ inline uint4 vgq_load16(const uint4 *p) {        // every corpus byte is read once per pass: keep it out of the caches
+static __device__ __attribute__((aligned(16))) uint32_t vgq_zero_chunk[4] = {0u, 0u, 0u, 0u};
+__device__ inline uint4 vgq_load16(const uint8_t *p) {      // every corpus byte is read once per pass: keep it out of the caches
     const vgq_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const vgq_u32x4 *>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <int G>
+__device__ inline void vgq_load_part(uint4 (&buf)[G], const uint8_t *row, int c0, int l16, int nch) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int c = c0 + g * 16 + l16;
+        buf[g] = vgq_load16(c < nch ? row + (long long)c * 16 : reinterpret_cast<const uint8_t *>(vgq_zero_chunk));
+    }
 }
 template <int VT> struct VgqChunk {                         // elements of one 16-byte chunk, widened the way the reference does
     static constexpr int N = (VT == T_F32) ? 4 : (VT == T_F16 || VT == T_BF16) ? 8 : 16;
@@ -48,45 +61,52 @@ template <int VT> struct VgqChunk {                         // elements of one 1
 
 // out[0] = sortable(min), out[1] = sortable(max), out[2] = any negative.  Pre-set by the host to
 // sortable(FLT_MAX), sortable(-FLT_MAX), 0 (the reference's initial values, :1197-1198).
-template <int VT>
+template <int VT, int G>
 __global__ __launch_bounds__(256) void vg_minmax_kernel(const uint8_t *rows, long long n_rows, long long stride, int dim, int nch,
                                                          uint32_t *out) {
     constexpr int N = VgqChunk<VT>::N;
     const int l16 = threadIdx.x & 15;
     const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const long long ngroups = ((long long)gridDim.x * blockDim.x) >> 4;
-    float lo = 3.402823466e+38f, hi = -3.402823466e+38f;
-    int neg = 0;
+    float lo = 3.402823466e+38f, hi = -3.402823466e+38f;     // ("any negative element" is min < 0: NaN never wins a comparison, -0 is not < 0)
     const int full = dim / N;                                // chunks without padding
     for (long long r = group; r < n_rows; r += ngroups) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(rows + r * stride);
-#pragma unroll 4
-        for (int c = l16; c < nch; c += 16) {
-            const uint4 v = vgq_load16(p + c);
-            float e[N];
-            VgqChunk<VT>::widen(v, e);
-            const int live = (c < full) ? N : (dim - c * N);              // (<= 0 for a chunk that is padding only)
+        const uint8_t *p = rows + r * stride;
+        for (int c0 = 0; c0 < nch; c0 += 16 * G) {
+            uint4 buf[G];
+            vgq_load_part<G>(buf, p, c0, l16, nch);
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                if (j < live) {
-                    if (e[j] < lo) lo = e[j];
-                    if (e[j] > hi) hi = e[j];
-                    if (e[j] < 0.0f) neg = 1;
+            for (int g = 0; g < G; ++g) {
+                const int c = c0 + g * 16 + l16;
+                float e[N];
+                VgqChunk<VT>::widen(buf[g], e);
+                if (c < full) {                                               // a chunk of elements only
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        if (e[j] < lo) lo = e[j];
+                        if (e[j] > hi) hi = e[j];
+                    }
+                } else {                                                      // the row's last chunk (or nothing: live <= 0)
+                    const int live = dim - c * N;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        const bool in = j < live;
+                        if (in && e[j] < lo) lo = e[j];
+                        if (in && e[j] > hi) hi = e[j];
+                    }
                 }
             }
         }
     }
     for (int off = 32; off >= 1; off >>= 1) {
         const float l2 = __shfl_xor(lo, off), h2 = __shfl_xor(hi, off);
-        const int n2 = __shfl_xor(neg, off);
         if (l2 < lo) lo = l2;
         if (h2 > hi) hi = h2;
-        neg |= n2;
     }
     if ((threadIdx.x & 63) == 0) {
         atomicMin(&out[0], vg_f32_sortable(lo));
         atomicMax(&out[1], vg_f32_sortable(hi));
-        if (neg) atomicOr(&out[2], 1u);
+        if (lo < 0.0f) atomicOr(&out[2], 1u);
     }
 }
 
@@ -121,7 +141,7 @@ __device__ inline uint32_t vgq_one(float v, float scale, float offset, int qtype
 
 // rows [row0, row0 + n_rows) -> n_rows x dim tightly packed bytes.  A chunk's N output bytes go out as one 4- / 8- / 16-byte
 // store when the packed row length keeps them aligned (dim a multiple of N), byte by byte otherwise.
-template <int VT>
+template <int VT, int G>
 __global__ __launch_bounds__(256) void vg_quantize_kernel(const uint8_t *rows, long long row0, long long n_rows, long long stride,
                                                            int dim, int nch, float scale, float offset, int qtype_u8, uint8_t *out) {
     constexpr int N = VgqChunk<VT>::N;
@@ -131,27 +151,30 @@ __global__ __launch_bounds__(256) void vg_quantize_kernel(const uint8_t *rows, l
     const bool packed_ok = (dim % N) == 0;
     const int full = dim / N;
     for (long long r = group; r < n_rows; r += ngroups) {
-        const uint4 *p = reinterpret_cast<const uint4 *>(rows + (row0 + r) * stride);
+        const uint8_t *p = rows + (row0 + r) * stride;
         uint8_t *o = out + r * (long long)dim;
-#pragma unroll 4
-        for (int c = l16; c < nch; c += 16) {
-            if (c * N >= dim) continue;
-            const uint4 v = vgq_load16(p + c);
-            float e[N];
-            VgqChunk<VT>::widen(v, e);
-            uint32_t q[N];
+        for (int c0 = 0; c0 < nch; c0 += 16 * G) {
+            uint4 buf[G];
+            vgq_load_part<G>(buf, p, c0, l16, nch);
 #pragma unroll
-            for (int j = 0; j < N; ++j) q[j] = vgq_one<VT>(e[j], scale, offset, qtype_u8);
-            if (packed_ok && c < full) {
-                uint32_t w[N / 4];
+            for (int g = 0; g < G; ++g) {
+                const int c = c0 + g * 16 + l16;
+                float e[N];
+                VgqChunk<VT>::widen(buf[g], e);
+                uint32_t q[N];
 #pragma unroll
-                for (int j = 0; j < N / 4; ++j) w[j] = q[4 * j] | (q[4 * j + 1] << 8) | (q[4 * j + 2] << 16) | (q[4 * j + 3] << 24);
-                if constexpr (N == 4) *reinterpret_cast<uint32_t *>(o + c * 4) = w[0];
-                else if constexpr (N == 8) *reinterpret_cast<uint2 *>(o + c * 8) = make_uint2(w[0], w[1]);
-                else *reinterpret_cast<uint4 *>(o + c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
-            } else {
+                for (int j = 0; j < N; ++j) q[j] = vgq_one<VT>(e[j], scale, offset, qtype_u8);
+                if (packed_ok && c < full) {
+                    uint32_t w[N / 4];
 #pragma unroll
-                for (int j = 0; j < N; ++j) if (c * N + j < dim) o[c * N + j] = (uint8_t)q[j];
+                    for (int j = 0; j < N / 4; ++j) w[j] = q[4 * j] | (q[4 * j + 1] << 8) | (q[4 * j + 2] << 16) | (q[4 * j + 3] << 24);
+                    if constexpr (N == 4) *reinterpret_cast<uint32_t *>(o + c * 4) = w[0];
+                    else if constexpr (N == 8) *reinterpret_cast<uint2 *>(o + c * 8) = make_uint2(w[0], w[1]);
+                    else *reinterpret_cast<uint4 *>(o + c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+                } else if (c * N < dim) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) if (c * N + j < dim) o[c * N + j] = (uint8_t)q[j];
+                }
             }
         }
     }
@@ -164,19 +187,51 @@ static inline unsigned vgq_blocks(long long n_rows) {
     return (unsigned)blocks;
 }
 
+// chunks per lane of one row (16 lanes per row), rounded up to an instantiated G; rows beyond 128 chunks go round by round at 8
+static inline int vgq_pick_g(int nch) {
+    const int need = (nch + 15) / 16;
+    static const int gs[] = {1, 2, 3, 4, 6, 8};
+    for (int g : gs) if (g >= need) return g;
+    return 8;
+}
+template <int VT> static void vgq_minmax_go(int G, dim3 g, dim3 b, hipStream_t stream, const uint8_t *rows, long long n_rows, long long stride,
+                                            int dim, int nch, uint32_t *out) {
+    switch (G) {
+        case 1: hipLaunchKernelGGL((vg_minmax_kernel<VT, 1>), g, b, 0, stream, rows, n_rows, stride, dim, nch, out); break;
+        case 2: hipLaunchKernelGGL((vg_minmax_kernel<VT, 2>), g, b, 0, stream, rows, n_rows, stride, dim, nch, out); break;
+        case 3: hipLaunchKernelGGL((vg_minmax_kernel<VT, 3>), g, b, 0, stream, rows, n_rows, stride, dim, nch, out); break;
+        case 4: hipLaunchKernelGGL((vg_minmax_kernel<VT, 4>), g, b, 0, stream, rows, n_rows, stride, dim, nch, out); break;
+        case 6: hipLaunchKernelGGL((vg_minmax_kernel<VT, 6>), g, b, 0, stream, rows, n_rows, stride, dim, nch, out); break;
+        default: hipLaunchKernelGGL((vg_minmax_kernel<VT, 8>), g, b, 0, stream, rows, n_rows, stride, dim, nch, out); break;
+    }
+}
+template <int VT> static void vgq_quantize_go(int G, dim3 g, dim3 b, hipStream_t stream, const uint8_t *rows, long long row0, long long n_rows,
+                                              long long stride, int dim, int nch, float scale, float offset, int qtype_u8, uint8_t *out) {
+#define VGQ_LAUNCH(GG) hipLaunchKernelGGL((vg_quantize_kernel<VT, GG>), g, b, 0, stream, rows, row0, n_rows, stride, dim, nch, scale, offset, qtype_u8, out)
+    switch (G) {
+        case 1: VGQ_LAUNCH(1); break;
+        case 2: VGQ_LAUNCH(2); break;
+        case 3: VGQ_LAUNCH(3); break;
+        case 4: VGQ_LAUNCH(4); break;
+        case 6: VGQ_LAUNCH(6); break;
+        default: VGQ_LAUNCH(8); break;
+    }
+#undef VGQ_LAUNCH
+}
+
 extern "C" int vg_quant_minmax_launch(const uint8_t *rows, long long n_rows, long long stride, int dim, int vtype,
                                       uint32_t *dev_out3, hipStream_t stream) {
     const uint32_t init[3] = {vg_f32_sortable(3.402823466e+38f), vg_f32_sortable(-3.402823466e+38f), 0u};
     hipError_t e = hipMemcpyAsync(dev_out3, init, sizeof(init), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return (int)e;
-    const int nch = (int)(stride / 16);
+    const int nch = (int)(stride / 16), G = vgq_pick_g(nch);
     const dim3 g(vgq_blocks(n_rows)), b(256);
     switch (vtype) {
-        case T_F32: hipLaunchKernelGGL(vg_minmax_kernel<T_F32>, g, b, 0, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
-        case T_F16: hipLaunchKernelGGL(vg_minmax_kernel<T_F16>, g, b, 0, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
-        case T_BF16: hipLaunchKernelGGL(vg_minmax_kernel<T_BF16>, g, b, 0, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
-        case T_U8: hipLaunchKernelGGL(vg_minmax_kernel<T_U8>, g, b, 0, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
-        default: hipLaunchKernelGGL(vg_minmax_kernel<T_I8>, g, b, 0, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
+        case T_F32: vgq_minmax_go<T_F32>(G, g, b, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
+        case T_F16: vgq_minmax_go<T_F16>(G, g, b, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
+        case T_BF16: vgq_minmax_go<T_BF16>(G, g, b, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
+        case T_U8: vgq_minmax_go<T_U8>(G, g, b, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
+        default: vgq_minmax_go<T_I8>(G, g, b, stream, rows, n_rows, stride, dim, nch, dev_out3); break;
     }
     return (int)hipGetLastError();
 }
@@ -184,16 +239,14 @@ extern "C" int vg_quant_minmax_launch(const uint8_t *rows, long long n_rows, lon
 extern "C" int vg_quant_quantize_launch(const uint8_t *rows, long long row0, long long n_rows, long long stride, int dim,
                                         int vtype, float scale, float offset, int qtype_u8, uint8_t *dev_out,
                                         hipStream_t stream) {
-    const int nch = (int)(stride / 16);
+    const int nch = (int)(stride / 16), G = vgq_pick_g(nch);
     const dim3 g(vgq_blocks(n_rows)), b(256);
-#define VGQ_LAUNCH(T) hipLaunchKernelGGL(vg_quantize_kernel<T>, g, b, 0, stream, rows, row0, n_rows, stride, dim, nch, scale, offset, qtype_u8, dev_out)
     switch (vtype) {
-        case T_F32: VGQ_LAUNCH(T_F32); break;
-        case T_F16: VGQ_LAUNCH(T_F16); break;
-        case T_BF16: VGQ_LAUNCH(T_BF16); break;
-        case T_U8: VGQ_LAUNCH(T_U8); break;
-        default: VGQ_LAUNCH(T_I8); break;
+        case T_F32: vgq_quantize_go<T_F32>(G, g, b, stream, rows, row0, n_rows, stride, dim, nch, scale, offset, qtype_u8, dev_out); break;
+        case T_F16: vgq_quantize_go<T_F16>(G, g, b, stream, rows, row0, n_rows, stride, dim, nch, scale, offset, qtype_u8, dev_out); break;
+        case T_BF16: vgq_quantize_go<T_BF16>(G, g, b, stream, rows, row0, n_rows, stride, dim, nch, scale, offset, qtype_u8, dev_out); break;
+        case T_U8: vgq_quantize_go<T_U8>(G, g, b, stream, rows, row0, n_rows, stride, dim, nch, scale, offset, qtype_u8, dev_out); break;
+        default: vgq_quantize_go<T_I8>(G, g, b, stream, rows, row0, n_rows, stride, dim, nch, scale, offset, qtype_u8, dev_out); break;
     }
-#undef VGQ_LAUNCH
     return (int)hipGetLastError();
 }

@@ -714,12 +714,14 @@ def test_long_row_kernel_forced_on_ordinary_rows(pkg, orc, monkeypatch):
 
 # ------------------------------------------------------------------------------------------------- GPU quantization
 
+@pytest.mark.parametrize("dim", [77, 200, 384, 700, 2100])
 @pytest.mark.parametrize("vt", dg.ALL_TYPES)
-def test_gpu_minmax_and_quantize_bit_exact(pkg, orc, vt):
+def test_gpu_minmax_and_quantize_bit_exact(pkg, orc, vt, dim):
     """vector_quantize's two passes as kernels over the staged corpus: min / max / any-negative and every quantized
     byte must equal the pinned oracle (= the reference's host arithmetic, sqlite-vector.c:495-757, :1210-1268),
-    including NaN / Inf / huge elements."""
-    n, dim = 1500, 77
+    including NaN / Inf / huge elements.  (The dims walk the kernels' chunks-per-lane instantiations, 1 .. 8, and rows longer than
+    one round of 128 chunks; all of them end in a partly filled chunk for some type.)"""
+    n = 1500 if dim == 77 else 1001
     rows = dg.corpus(vt, n, dim, 61)
     if vt == dg.F32:
         rows[3, 5] = np.float32(np.nan); rows[4, 6] = np.float32(3e9); rows[5, 7] = np.float32(-np.inf); rows[6, 8] = np.float32(-3e9)
@@ -748,6 +750,30 @@ def test_gpu_minmax_and_quantize_bit_exact(pkg, orc, vt):
         part = c.quantize_rows(sc, off, qtype, row0=700, n_rows=300)
         assert np.array_equal(part, want[700:1000])
     c.close()
+
+
+@pytest.mark.parametrize("dim", [5, 77, 390, 1030])
+@pytest.mark.parametrize("vt", dg.ALL_TYPES)
+def test_gpu_minmax_ignores_the_row_padding(pkg, vt, dim):
+    """rows are padded with zero bytes to a multiple of 16 (and lanes without a chunk read zeros): none of that may become the
+    minimum of a corpus whose elements are all >= 3, or the maximum of one whose elements are all <= -3"""
+    rng = np.random.default_rng(dim)
+    n = 257
+    for sign in (1, -1):
+        if vt == dg.U8 and sign < 0:
+            continue
+        if vt in (dg.F32, dg.F16, dg.BF16):
+            rows = dg.to_storage(vt, (sign * (np.abs(rng.standard_normal((n, dim), dtype=np.float32)) + 3.0)).astype(np.float32))
+        elif vt == dg.U8:
+            rows = rng.integers(3, 256, (n, dim)).astype(np.uint8)
+        else:
+            rows = (sign * rng.integers(3, 128, (n, dim))).astype(np.int8)
+        c = pkg.Corpus(vt, dim)
+        c.append(rows)
+        lo, hi, neg = c.minmax()
+        f = dg.storage_to_f64(vt, rows)
+        assert lo == float(f.min()) and hi == float(f.max()) and neg == (sign < 0), (dg.TYPE_NAMES[vt], dim, sign, lo, hi, f.min(), f.max())
+        c.close()
 
 
 def test_device_appends_and_cross_stream_scan(pkg, orc):

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--bytes", type=float, default=7.68e9)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--cases", type=str, default="2:384,3:384,4:384,4:768,2:768,3:768,1:384")
+    ap.add_argument("--repeat", type=int, default=1, help="walk the shape list this many times (A/B/A/B against drift)")
     args = ap.parse_args()
     import torch
     torch.cuda.init()
@@ -55,7 +56,7 @@ def main():
             for U in (1, 2, 3, 4, 6, 8):
                 if (1 << l2) * U == nch or ((1 << l2) * U > nch and (1 << l2) * U * 3 <= nch * 4 and U <= 6 and l2 >= 2):
                     shapes.append((l2, U))
-        for l2, U in shapes:
+        for l2, U in shapes * args.repeat:
             if l2 < 0:
                 os.environ.pop("VG_LPR_LOG2", None); os.environ.pop("VG_U", None)
             else:
