@@ -93,3 +93,40 @@ def test_bf16_two_sided_rounding_constant():
         rb = dg.bf16_bits_to_f32(dg.f32_to_bf16_bits(b)).astype(np.float64)
         t = float((a.astype(np.float64) * b.astype(np.float64)).sum())
         assert abs(t - float((ra * rb).sum())) <= (2.0 ** -7 + 2.0 ** -16) * float(np.linalg.norm(a.astype(np.float64)) * np.linalg.norm(b.astype(np.float64)))
+
+
+@pytest.mark.parametrize("vt", [dg.F16, dg.BF16])
+def test_a_special_element_always_shows_in_the_f64_total(vt):
+    """vg_half.h's fast path no longer tests every element pair for Inf / NaN: it reads "this row needs the exact slow path" off the
+    row's f64 total.  The claim behind that - every Inf / NaN element of the ROW makes the total non-finite, whatever the (finite)
+    query holds, for each of the fast path's four accumulations - restated in numpy with the fast path's own arithmetic (f32
+    difference / product for f16, f64 difference for bf16, f64 accumulation), incl. query zeros under an Inf (Inf * 0 = NaN),
+    opposite infinities (Inf - Inf = NaN) and several specials per row.  The converse costs time only (finite bf16 rows whose f32
+    product overflows take the slow path, which is the reference's own algorithm) and is shown to occur."""
+    rng = np.random.default_rng(7)
+    specials = [np.inf, -np.inf, np.nan]
+    old = np.seterr(all="ignore")
+    try:
+        for trial in range(400):
+            dim = int(rng.integers(1, 70))
+            q = dg.storage_to_f64(vt, dg.to_storage(vt, rng.standard_normal((1, dim), dtype=np.float32) * float(np.exp2(rng.integers(-8, 8)))))[0]
+            x = dg.storage_to_f64(vt, dg.to_storage(vt, rng.standard_normal((1, dim), dtype=np.float32)))[0]
+            if trial % 3 == 0:
+                q[rng.integers(0, dim, max(1, dim // 2))] = 0.0
+            for _ in range(int(rng.integers(1, 4))):
+                x[rng.integers(0, dim)] = specials[int(rng.integers(0, 3))]
+            q32, x32 = q.astype(np.float32), x.astype(np.float32)
+            if vt == dg.F16:
+                d = (q32 - x32).astype(np.float64)            # f32 subtract (distance-avx2.c:186-205)
+            else:
+                d = q - x                                       # f64 subtract (:383-409)
+            totals = {"l2": np.sum(d * d), "l1": np.sum(np.abs(d)), "dot": np.sum((q32 * x32).astype(np.float64))}
+            for name, t in totals.items():
+                assert not np.isfinite(t), (dg.TYPE_NAMES[vt], name, q, x, t)
+        # finite inputs: f64 cannot overflow on 16-bit elements (|term| < 2^256), so a finite row is flagged only through an
+        # overflowing f32 PRODUCT - possible for bf16 (3e38 * 3e38), impossible for f16 (65504^2 < 2^32)
+        big = np.float32(3.0e38)
+        assert not np.isfinite(np.float64(big * big)) and np.isfinite(np.float64(big) - np.float64(-big)) and np.isfinite((np.float64(big) * 2) ** 2)
+        assert np.isfinite(np.float32(65504.0) * np.float32(65504.0))
+    finally:
+        np.seterr(**old)
