@@ -1,1 +1,1 @@
-bash tools/measure.sh r5g bench
+bash tools/measure.sh r5h bench
