@@ -189,23 +189,34 @@ __global__ __launch_bounds__(256) void vg_to_q8_reg_kernel(const uint8_t *rows, 
         const bool live = i < n;
         const long long r = row0 + (live ? i : n - 1);
         const uint8_t *src = rows + r * stride;
+        // all of the lane's chunks are requested before the first one is touched - unconditionally, a chunk behind the row's last one
+        // reads 16 zero bytes (vg_load_batch's reasoning: a load under a branch is waited for on the spot, and this kernel's first
+        // form had ONE load in flight per wavefront) - and the elements behind `dim` are zeroed by a select, not skipped by a branch
+        uint4 raw[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = l16 + 16 * u;
+            raw[u] = vg_load16<true>(c < nch ? src + (long long)c * 16 : reinterpret_cast<const uint8_t *>(vg_zero_chunk));
+        }
         float v[U][N];
         float mx = 0.0f;
         uint32_t bad = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int c = l16 + 16 * u;
-            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-            if (c < nch) raw = vg_load16<true>(src + (long long)c * 16);
-            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+            const uint32_t w[4] = {raw[u].x, raw[u].y, raw[u].z, raw[u].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr (XT == T_F32) v[u][j] = __uint_as_float(w[j]);
                 else vg_unpack2<XT>(w[j], v[u][2 * j], v[u][2 * j + 1]);
             }
 #pragma unroll
-            for (int j = 0; j < N; ++j)
-                if (c * N + j < dim) { mx = fmaxf(mx, fabsf(v[u][j])); bad |= !(fabsf(v[u][j]) <= 3.0e38f); }
+            for (int j = 0; j < N; ++j) {
+                v[u][j] = (c * N + j < dim) ? v[u][j] : 0.0f;
+                const float av = fabsf(v[u][j]);
+                mx = fmaxf(mx, av);
+                bad |= !(av <= 3.0e38f) ? 1u : 0u;
+            }
         }
         mx = fmaxf(mx, vg_dpp<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(mx));
         mx = fmaxf(mx, vg_dpp<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(mx));
@@ -224,16 +235,14 @@ __global__ __launch_bounds__(256) void vg_to_q8_reg_kernel(const uint8_t *rows, 
             for (int j4 = 0; j4 < N / 4; ++j4) {
                 w[j4] = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int e = c * N + 4 * j4 + j;
-                    if (e < dim && !bad) {
-                        const float x = v[u][4 * j4 + j];
-                        const int xi = vgf_q8(x, inv);
-                        const double res = (double)x - (double)sx * (double)xi;
-                        e2 += res * res;
-                        w[j4] |= (uint32_t)(xi & 255) << (8 * j);
-                    }
+                for (int j = 0; j < 4; ++j) {                       // (an element behind `dim` is 0 here: image 0, residual 0)
+                    const float x = v[u][4 * j4 + j];
+                    const int xi = vgf_q8(x, inv);
+                    const double res = (double)x - (double)sx * (double)xi;
+                    e2 += res * res;
+                    w[j4] |= (uint32_t)(xi & 255) << (8 * j);
                 }
+                if (bad) w[j4] = 0;                                 // (a row the filter must not judge: zero image, NaN scale below)
             }
             if (live && c * N < (int)ostride) {
                 if constexpr (N == 4) *reinterpret_cast<uint32_t *>(o + c * 4) = w[0];
