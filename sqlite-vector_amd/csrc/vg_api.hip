@@ -58,10 +58,13 @@ bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap) {
     const bool round1 = env_int("VG_SHAPE_PREF_ROUND1", 0) != 0;
     // Short rows (3 .. 8 chunks): with ONE chunk per lane a batch is one load + a whole epilogue (butterfly, conversions, sqrt /
     // divide, key, ballot) for 64 / lanes-per-row rows - half the lanes per row with 2 chunks each amortise it over twice the rows.
-    // Measured (same file): f32 32 floats 5.1-5.9 -> 6.0-6.2 TB/s on every metric; uint8 64 / 100 / 128 bytes L2 and cosine + 8-14 %,
-    // but dot / L1 (light epilogues) - 9-15 %: so for integer rows only where the epilogue is heavy.
+    // f32 (32 floats: 5.9 -> 6.2 TB/s on every metric) and - re-measured with the unconditional batch loads,
+    // profiles/r5k_shape_sweep_short_rows.txt - f16 / bf16, whose f64 epilogue is the heaviest (64 halves: L2 4.8 -> 5.9, cosine 4.4 -> 5.8,
+    // dot 5.7 -> 6.1 TB/s).  NOT uint8 / int8 any more: the rule had been adopted for their L2 / cosine while the prefetch did not
+    // overlap; with it in flight one chunk per lane wins on every metric (64 bytes L2 5.4 -> 6.0, 100 bytes 4.3 -> 5.0, 128 bytes 5.4 -> 6.1).
     const bool short_rows = !round1 && nch >= 3 && nch <= 8 &&
-                            (vtype == VG_TYPE_F32 || ((vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8) && (acc == A_L2 || acc == A_COS)));
+                            (vtype == VG_TYPE_F32 || vtype == VG_TYPE_F16 || vtype == VG_TYPE_BF16 ||
+                             (env_int("VG_SHAPE_INT_SHORT_ROUND3", 0) && (vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8) && (acc == A_L2 || acc == A_COS)));
     double best_eff = -1.0;
     for (int l2 = 0; l2 <= 6; ++l2) {                        // (the best cover any shape reaches: "ragged" rows have none at 1.0)
         const int lpr = 1 << l2, need = (nch + lpr - 1) / lpr;

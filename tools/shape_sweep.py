@@ -40,15 +40,17 @@ def main():
                 t = torch.randn((nr, dim), device="cuda", dtype=torch.float16)
             elif vt == 3:
                 t = torch.randn((nr, dim), device="cuda", dtype=torch.bfloat16)
-            else:
+            elif vt == 4:
                 t = torch.randint(0, 256, (nr, dim), device="cuda", dtype=torch.uint8)
+            else:
+                t = torch.randint(-128, 128, (nr, dim), device="cuda", dtype=torch.int8)
             torch.cuda.synchronize()
             c.append_device(t.data_ptr(), nr, dim * es)
             del t
         rng = np.random.default_rng(1)
         q32 = rng.standard_normal(dim, dtype=np.float32)
         q = {1: q32, 2: q32.astype(np.float16).view(np.uint16), 3: (q32.view(np.uint32) >> 16).astype(np.uint16),
-             4: rng.integers(0, 256, dim).astype(np.uint8)}[vt]
+             4: rng.integers(0, 256, dim).astype(np.uint8), 5: rng.integers(-128, 128, dim).astype(np.int8)}[vt]
         c.set_scan_filter(0)
         nch = (dim * es + 15) // 16
         shapes = [(-1, -1)]
