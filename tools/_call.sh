@@ -1,1 +1,1 @@
-bash tools/measure.sh r5n tests stats pmc bench others matrix stage dist shards
+bash tools/measure.sh r5o bench
