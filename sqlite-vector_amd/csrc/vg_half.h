@@ -83,7 +83,8 @@ template <int VT, int ACC> struct AccumHalf {
     // left the kernel latency-bound at ~5 TB/s
     double a0, a1, a2, a3;  // L2: sum d^2 | L1: sum |d| | DOT/COS: sum q*x
     double n0, n1, n2, n3;  // COS: sum x*x
-    uint32_t flag;          // nonzero once an Inf/NaN element was seen in this lane's part of the row
+    uint32_t flag;          // set by finish(): the row's f64 total is non-finite, i.e. the row takes the exact slow path (the per-pair
+                            // test of VG_HALF_FLAG_FROM_SUM=0 builds: nonzero once this lane saw an Inf / NaN element)
     struct QStat { double qq; uint32_t qspecial; };
 
     __device__ inline void init() { a0 = a1 = a2 = a3 = 0.0; n0 = n1 = n2 = n3 = 0.0; flag = 0; }
