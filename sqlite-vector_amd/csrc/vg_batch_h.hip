@@ -38,6 +38,9 @@ typedef int vgh_i32x4 __attribute__((ext_vector_type(4)));
 #endif
 #define VGH_WAVES_LONG 4                // ... and for rows up to 2 KiB: A alone is up to 256 registers, one wavefront per SIMD
 #define VGH_WAVES_OF(NTB) ((NTB) <= 32 ? VGH_WAVES : VGH_WAVES_LONG)
+#ifndef VGH_MIN_BLOCKS
+#define VGH_MIN_BLOCKS 1                // workgroups per CU the register budget is cut for (2 with -DVGH_WAVES=4: two half-size workgroups per CU, an experiment)
+#endif
 #define VGH_QPW 32
 #define VGH_TILE 32
 #define VGH_MAX_K 32
@@ -120,7 +123,7 @@ __device__ __forceinline__ vgh_f32x16 vgh_mfma(const vgh_i32x4 &a, const vgh_i32
 // BOUND of its distance (the filter's own estimate plus its error bound); the k-th smallest bound of a query is then an
 // upper bound of its final k-th best distance - the start threshold of the real pass, which scans every row.
 template <int VT, int NTB, int MODE, bool BOUND>
-__global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), 1) void vg_batch_h_kernel(BatchArgsH a) {
+__global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), VGH_MIN_BLOCKS) void vg_batch_h_kernel(BatchArgsH a) {
     constexpr int WAVES = VGH_WAVES_OF(NTB), THREADS = 64 * WAVES, QPB = WAVES * VGH_QPW;
     constexpr int XU = ((NTB <= 32) ? 1 : 2) * (VT == T_F32 ? 2 : 1);    // 16-byte chunks per lane in the exact evaluation
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);

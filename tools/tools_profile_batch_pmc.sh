@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 T=${1:-u8}; D=${2:-768}; M=${3:-3}; OUT=${4:-gpurun_out/pmc_batch}
 mkdir -p $OUT
-CMD="python tools/tools_batch_bench.py --type $T --dim $D --nq 1024 --metric $M --reps 1"
+CMD="python /root/repo/tools/tools_batch_bench.py --type $T --dim $D --nq 1024 --metric $M --reps 1"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM" \
