@@ -224,6 +224,9 @@ int vg_profile_mean_ms(vg_corpus *c, int *n_launches, float *scan_ms, float *mer
 /* the same, with the filter scan's plain-f32 pre-pass (its scan + merge, run before the filter kernel) reported on its
  * own: scan_ms is ONE kernel - the dominant one - whichever path served the scan */
 int vg_profile_mean_ms_ex(vg_corpus *c, int *n_launches, float *scan_ms, float *merge_ms, float *prepass_ms);
+/* the launch shape the plain scan kernel would run a row of `dim` elements of `vtype` with under `metric`: lanes sharing a row,
+ * 16-byte chunks per lane, and whether the row takes the long-row kernel instead (pure host logic - no device, no corpus) */
+int vg_plan_scan_shape(int vtype, int dim, int metric, int *lanes_per_row, int *chunks_per_lane, int *long_rows);
 /* name of the scan kernel variant chosen for (metric) on this corpus, e.g. "scan_f32_l2_u6_lpr16" */
 const char *vg_scan_kernel_name(vg_corpus *c, int metric);
 /* filter scan: f32 rows evaluated exactly by the filter-scan launches since the last call (then reset) - how selective the

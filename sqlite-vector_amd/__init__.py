@@ -101,6 +101,7 @@ def lib():
         "vg_last_kernel_ms": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "vg_profile_mean_ms": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "vg_scan_kernel_name": (C.c_char_p, [vp, i32]),
+        "vg_plan_scan_shape": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
         "vg_profile_mean_ms_ex": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "vg_corpus_find_rowid": (i64, [vp, i64]),
         "vg_corpus_patch_rows": (i32, [vp, vp, i64, vp, i64]),
@@ -151,6 +152,13 @@ def device_count():
 
 def backend_name():
     return lib().vg_backend_name().decode()
+
+
+def plan_scan_shape(vtype, dim, metric):
+    """(lanes per row, 16-byte chunks per lane, long-row kernel?) the plain scan would launch with - host logic only, no device"""
+    lpr, u, lng = C.c_int(0), C.c_int(0), C.c_int(0)
+    _check(lib().vg_plan_scan_shape(vtype, dim, metric, C.byref(lpr), C.byref(u), C.byref(lng)))
+    return lpr.value, u.value, bool(lng.value)
 
 
 class Corpus:

@@ -92,6 +92,17 @@ bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap) {
     return true;
 }
 static bool choose_shape(int nch, int vtype, int acc, Shape *out) { return vg_choose_shape(nch, vtype, acc, out, 8); }
+int vg_metric_to_acc(int metric);
+extern "C" int vg_plan_scan_shape(int vtype, int dim, int metric, int *lanes_per_row, int *chunks_per_lane, int *long_rows) {
+    const int acc = vg_metric_to_acc(metric);
+    if (vtype < VG_TYPE_F32 || vtype > VG_TYPE_I8 || dim < 1 || acc < 0) return vg_fail(VG_ERR_INVALID, "vg_plan_scan_shape: bad type / dim / metric");
+    Shape s;
+    choose_shape((int)(((long long)dim * vg_elem_size(vtype) + 15) / 16), vtype, acc, &s);
+    if (lanes_per_row) *lanes_per_row = 1 << s.lpr_log2;
+    if (chunks_per_lane) *chunks_per_lane = s.U;
+    if (long_rows) *long_rows = s.long_rows ? 1 : 0;
+    return VG_OK;
+}
 
 template <int VT, int ACC, bool NT>
 static scan_fn_t pick_u(int U) {

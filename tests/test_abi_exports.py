@@ -79,3 +79,50 @@ def test_merge_keys_host_helper(pkg):
     assert abs(lib.vg_key_distance(C.c_uint64(key(0.25, 7))) - 0.25) == 0 and lib.vg_key_position(C.c_uint64(key(0.25, 7))) == 7
     pos, dist = pkg.merge_keys(lists, None, 10)
     assert len(pos) == 5
+
+
+def test_launch_shape_rules(pkg, monkeypatch):
+    """vg_plan_scan_shape (pure host logic): the (lanes per row x 16-byte chunks per lane) decomposition the plain scan kernels are
+    launched with, pinned for the BASELINE configurations and for every rule DESIGN.md section 3 states with a measurement behind it -
+    so that a change to one rule cannot silently move another shape."""
+    for name in ("VG_LPR_LOG2", "VG_U", "VG_SHAPE_PREF_ROUND1", "VG_SHAPE_F16_ROUND3", "VG_SHAPE_BF16_L2_U3", "VG_SHAPE_INT_SHORT_ROUND3", "VG_FORCE_LONG"):
+        monkeypatch.delenv(name, raising=False)
+    F32, F16, BF16, U8, I8 = pkg.F32, pkg.F16, pkg.BF16, pkg.U8, pkg.I8
+    L2, COS, DOT, L1 = pkg.L2, pkg.COSINE, pkg.DOT, pkg.L1
+    want = {
+        # the BASELINE configurations: 3 chunks per lane, twice the lanes (512 contiguous bytes of a row per load instruction)
+        (F32, 384, L2): (32, 3), (F32, 384, DOT): (32, 3), (U8, 768, COS): (16, 3), (I8, 768, L2): (16, 3), (U8, 384, L2): (8, 3),
+        (F32, 768, L2): (64, 3),
+        # f16 follows the same rule since the batch loads are unconditional; bf16: at most 3 chunks per lane, except L2
+        (F16, 384, L2): (16, 3), (F16, 384, COS): (16, 3), (F16, 768, DOT): (32, 3),
+        (BF16, 384, COS): (16, 3), (BF16, 384, DOT): (16, 3), (BF16, 384, L1): (16, 3), (BF16, 384, L2): (8, 6), (BF16, 768, COS): (32, 3),
+        # 4 chunks per lane are not traded for 2 at twice the lanes
+        (F32, 128, L2): (8, 4), (F32, 256, L2): (16, 4), (F32, 512, L2): (32, 4), (F32, 1024, L2): (64, 4), (U8, 512, L2): (8, 4),
+        (U8, 1024, COS): (16, 4), (F16, 256, L2): (8, 4), (F16, 512, COS): (16, 4), (F16, 1024, L2): (32, 4),
+        # short rows (3 .. 8 chunks): 2 chunks per lane for the float types, one for uint8 / int8
+        (F32, 32, L2): (4, 2), (F32, 32, COS): (4, 2), (F16, 64, L2): (4, 2), (F16, 64, DOT): (4, 2), (BF16, 64, COS): (4, 2),
+        (U8, 64, L2): (4, 1), (U8, 64, COS): (4, 1), (U8, 64, DOT): (4, 1), (I8, 128, L2): (8, 1), (U8, 128, COS): (8, 1), (U8, 100, L2): (8, 1),
+        (U8, 256, L2): (8, 2), (F16, 128, L2): (8, 2),
+        # rows no shape covers exactly: 2 chunks per lane over 4, up to 16 lanes per row
+        (F32, 100, L2): (16, 2), (F32, 100, COS): (16, 2), (F16, 200, L2): (16, 2), (F32, 200, L2): (16, 4),
+    }
+    got = {key: pkg.plan_scan_shape(*key)[:2] for key in want}
+    assert got == want, {k: (got[k], want[k]) for k in want if got[k] != want[k]}
+    # every shape covers its row, wastes less than half of its lane slots, and very long rows take the long-row kernel
+    for vt in (F32, F16, BF16, U8, I8):
+        es = pkg.TYPE_SIZE[vt]
+        for dim in list(range(1, 200)) + [255, 256, 300, 384, 512, 700, 768, 1000, 1024, 1536, 2048]:
+            for metric in (L2, COS, DOT, L1):
+                lpr, u, long_rows = pkg.plan_scan_shape(vt, dim, metric)
+                nch = (dim * es + 15) // 16
+                if long_rows:
+                    assert nch > 64
+                    continue
+                assert lpr * u >= nch and lpr in (1, 2, 4, 8, 16, 32, 64) and u in (1, 2, 3, 4, 6, 8), (vt, dim, metric, lpr, u)
+                assert lpr * u < 2 * nch or nch == 1, (vt, dim, metric, lpr, u)
+    assert pkg.plan_scan_shape(F32, 4096, L2)[2] and pkg.plan_scan_shape(F16, 4096, L2)[2]
+    with pytest.raises(pkg.VectorGpuError):
+        pkg.plan_scan_shape(9, 384, L2)
+    # the experiment override reaches the same function
+    monkeypatch.setenv("VG_LPR_LOG2", "4"); monkeypatch.setenv("VG_U", "6")
+    assert pkg.plan_scan_shape(F32, 384, L2)[:2] == (16, 6)
