@@ -31,11 +31,12 @@ extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_ro
 // ---- f16 / bf16 batches: matrix-core filter + exact f64 re-evaluation (vg_batch_h.hip)
 extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k);
 extern "C" int vg_batch_h_queries_per_block(long long stride_bytes);
+extern "C" int vg_batch_h_plan(long long stride_bytes, int k, int nq, int *waves, int *blocks_per_cu);
 extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long long n_rows, long long stride_bytes, int dim, int type_code,
                                  const uint8_t *dev_xrows, long long xstride_bytes,
                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
                                  const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
-                                 uint64_t *dev_out_keys, unsigned long long *dev_evals, hipStream_t stream);
+                                 uint64_t *dev_out_keys, unsigned long long *dev_evals, int waves, hipStream_t stream);
 extern "C" int vg_tile_major_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, uint8_t *dev_out, hipStream_t stream);
 extern "C" int vg_f32_to_bf16_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int dim,
                                      uint8_t *dev_out, long long ostride, hipStream_t stream);
@@ -207,13 +208,15 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     }
     const bool half = (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) || f32_filter;
     const long long fstride = f32_filter ? bf16_shadow_stride(c) : c->stride;       // row stride of what the matrix core reads
-    const int QPB = quantized ? vg_batch_i8_queries_per_block(c->stride) : (half ? vg_batch_h_queries_per_block(fstride) : 128);
+    // f16 / bf16 / f32-through-bf16 batches: the kernel comes as one 8-wavefront workgroup per CU or as two of four (vg_batch_h_plan)
+    int h_waves = 8, h_bpc = 1;
+    if (half && vg_batch_h_plan(fstride, k, nq, &h_waves, &h_bpc) != 0) return -1;
+    const int QPB = quantized ? vg_batch_i8_queries_per_block(c->stride) : (half ? h_waves * 32 : 128);
     const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
     const int G = nq_pad / QPB;
-    // partitions: enough workgroups to cover the chip (G * npart ~ CUs), a multiple of 8 (one per XCD), <= 256
-    // (VG_BATCH_BPC: workgroups per CU the partition count aims at - an experiment switch for kernels built with
-    // 4-wavefront workgroups, two of which fit a CU)
-    int npart = std::max(1, c->cu_count * std::max(1, env_int("VG_BATCH_BPC", 1)) / G);
+    // partitions: enough workgroups to cover the chip (G * npart ~ CUs x workgroups per CU), a multiple of 8 (one per XCD), <= 256
+    // (VG_BATCH_BPC overrides the workgroups per CU the partition count aims at)
+    int npart = std::max(1, c->cu_count * std::max(1, env_int("VG_BATCH_BPC", half ? h_bpc : 1)) / G);
     if (npart >= 8) npart = (npart / 8) * 8;
     npart = std::min(npart, 256);
     const long long ntiles = (c->n_rows + 31) / 32;
@@ -276,7 +279,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
         }
         rc = vg_batch_h_launch(hrows, hrows_tiled, c->n_rows, fstride, c->dim,
                                f32_filter ? 2 : (c->vtype == VG_TYPE_BF16 ? 1 : 0), c->d_rows, c->stride, (const uint8_t *)c->d_bq,
-                               nq_pad, nq, k, mode, root, c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys, dev_evals, c->stream);
+                               nq_pad, nq, k, mode, root, c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys, dev_evals, h_waves, c->stream);
         if (rc == 0 && dev_evals)
             HIP_TRY(hipMemcpyAsync(c->h_filter_evals + 1, dev_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     }

@@ -38,9 +38,11 @@ typedef int vgh_i32x4 __attribute__((ext_vector_type(4)));
 #endif
 #define VGH_WAVES_LONG 4                // ... and for rows up to 2 KiB: A alone is up to 256 registers, one wavefront per SIMD
 #define VGH_WAVES_OF(NTB) ((NTB) <= 32 ? VGH_WAVES : VGH_WAVES_LONG)
-#ifndef VGH_MIN_BLOCKS
-#define VGH_MIN_BLOCKS 1                // workgroups per CU the register budget is cut for (2 with -DVGH_WAVES=4: two half-size workgroups per CU, an experiment)
-#endif
+// Rows of up to 768 bytes (NTB <= 24) also come as 4-wavefront workgroups of which TWO share a CU (W = 4): a tile barrier then couples
+// four wavefronts instead of eight and the two workgroups' DMA / gate / survivor phases drift apart - 1024 x 10M x 384: f32 dot
+// 9.07 -> 8.58 ms, f32 L2 8.67 -> 8.36, f16 dot 8.70 -> 8.61 (profiles/r5t_batch_h_two_4wave_workgroups_per_cu.txt; ONE such workgroup
+// per CU: 10.8 ms).  Chosen per launch (vg_batch_h_plan): both workgroups' LDS - tiles + 32 k-key lists per wavefront - must fit.
+#define VGH_HAS_W4(NTB) ((NTB) <= 24)
 #define VGH_QPW 32
 #define VGH_TILE 32
 #define VGH_MAX_K 32
@@ -122,9 +124,9 @@ __device__ __forceinline__ vgh_f32x16 vgh_mfma(const vgh_i32x4 &a, const vgh_i32
 // BOUND = the pre-pass variant: no exact evaluation at all.  A pair that passes the filter enters its list with an UPPER
 // BOUND of its distance (the filter's own estimate plus its error bound); the k-th smallest bound of a query is then an
 // upper bound of its final k-th best distance - the start threshold of the real pass, which scans every row.
-template <int VT, int NTB, int MODE, bool BOUND>
-__global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), VGH_MIN_BLOCKS) void vg_batch_h_kernel(BatchArgsH a) {
-    constexpr int WAVES = VGH_WAVES_OF(NTB), THREADS = 64 * WAVES, QPB = WAVES * VGH_QPW;
+template <int VT, int NTB, int MODE, bool BOUND, int W>
+__global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB)) ? 2 : 1) void vg_batch_h_kernel(BatchArgsH a) {
+    constexpr int WAVES = W, THREADS = 64 * WAVES, QPB = WAVES * VGH_QPW;
     constexpr int XU = ((NTB <= 32) ? 1 : 2) * (VT == T_F32 ? 2 : 1);    // 16-byte chunks per lane in the exact evaluation
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);
     // VT == T_F32: an f32 corpus.  The matrix core reads a bf16 SHADOW copy of it (BOTH inputs of every product rounded to
@@ -589,65 +591,73 @@ __global__ __launch_bounds__(64 * VGH_WAVES_OF(NTB), VGH_MIN_BLOCKS) void vg_bat
 #ifndef VGH_TU
 #define VGH_TU 0
 #endif
-extern "C" int vgh_launch_real_f16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);
-extern "C" int vgh_launch_real_bf16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);
-extern "C" int vgh_launch_real_f32(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);   // -DVGH_TU=3
-extern "C" int vgh_launch_bound_f16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);    // -DVGH_TU=2
-extern "C" int vgh_launch_bound_bf16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);   // -DVGH_TU=4
-extern "C" int vgh_launch_bound_f32(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream);    // -DVGH_TU=5
+extern "C" int vgh_launch_real_f16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream);
+extern "C" int vgh_launch_real_bf16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream);
+extern "C" int vgh_launch_real_f32(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream);   // -DVGH_TU=3
+extern "C" int vgh_launch_bound_f16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream);    // -DVGH_TU=2
+extern "C" int vgh_launch_bound_bf16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream);   // -DVGH_TU=4
+extern "C" int vgh_launch_bound_f32(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream);    // -DVGH_TU=5
 
-template <int VT, int NTB, int MODE, bool BOUND>
+template <int VT, int NTB, int MODE, bool BOUND, int W>
 static int launch_h(const BatchArgsH &a, int blocks, size_t smem, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_h_kernel<VT, NTB, MODE, BOUND>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_h_kernel<VT, NTB, MODE, BOUND, W>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((vg_batch_h_kernel<VT, NTB, MODE, BOUND>), dim3((unsigned)blocks), dim3(64 * VGH_WAVES_OF(NTB)), smem, stream, a);
+    hipLaunchKernelGGL((vg_batch_h_kernel<VT, NTB, MODE, BOUND, W>), dim3((unsigned)blocks), dim3(64 * W), smem, stream, a);
     return (int)hipGetLastError();
 }
-template <int VT, int NTB, bool BOUND>
+template <int VT, int NTB, bool BOUND, int W>
 static int launch_h_mode(const BatchArgsH &a, int blocks, size_t smem, hipStream_t stream) {
-    if (a.mode == VGH_COS) return launch_h<VT, NTB, VGH_COS, BOUND>(a, blocks, smem, stream);
-    if (a.mode == VGH_L2) return launch_h<VT, NTB, VGH_L2, BOUND>(a, blocks, smem, stream);
-    return launch_h<VT, NTB, VGH_DOT, BOUND>(a, blocks, smem, stream);
+    if (a.mode == VGH_COS) return launch_h<VT, NTB, VGH_COS, BOUND, W>(a, blocks, smem, stream);
+    if (a.mode == VGH_L2) return launch_h<VT, NTB, VGH_L2, BOUND, W>(a, blocks, smem, stream);
+    return launch_h<VT, NTB, VGH_DOT, BOUND, W>(a, blocks, smem, stream);
+}
+template <int VT, int NTB, bool BOUND>
+static int launch_h_waves(const BatchArgsH &a, int waves, int blocks, size_t smem, hipStream_t stream) {
+    if constexpr (VGH_HAS_W4(NTB)) {
+        if (waves == 4) return launch_h_mode<VT, NTB, BOUND, 4>(a, blocks, smem, stream);
+    }
+    if (waves != VGH_WAVES_OF(NTB)) return -1;
+    return launch_h_mode<VT, NTB, BOUND, VGH_WAVES_OF(NTB)>(a, blocks, smem, stream);
 }
 template <int VT, bool BOUND>
-static int launch_h_ntb(const BatchArgsH &a, int ntb, int blocks, size_t smem, hipStream_t stream) {
-    if (ntb == 8) return launch_h_mode<VT, 8, BOUND>(a, blocks, smem, stream);
-    if (ntb == 16) return launch_h_mode<VT, 16, BOUND>(a, blocks, smem, stream);
-    if (ntb == 24) return launch_h_mode<VT, 24, BOUND>(a, blocks, smem, stream);
-    if (ntb == 32) return launch_h_mode<VT, 32, BOUND>(a, blocks, smem, stream);
-    if (ntb == 48) return launch_h_mode<VT, 48, BOUND>(a, blocks, smem, stream);
-    return launch_h_mode<VT, 64, BOUND>(a, blocks, smem, stream);
+static int launch_h_ntb(const BatchArgsH &a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
+    if (ntb == 8) return launch_h_waves<VT, 8, BOUND>(a, waves, blocks, smem, stream);
+    if (ntb == 16) return launch_h_waves<VT, 16, BOUND>(a, waves, blocks, smem, stream);
+    if (ntb == 24) return launch_h_waves<VT, 24, BOUND>(a, waves, blocks, smem, stream);
+    if (ntb == 32) return launch_h_waves<VT, 32, BOUND>(a, waves, blocks, smem, stream);
+    if (ntb == 48) return launch_h_waves<VT, 48, BOUND>(a, waves, blocks, smem, stream);
+    return launch_h_waves<VT, 64, BOUND>(a, waves, blocks, smem, stream);
 }
 
 #if VGH_TU == 1 || defined(VGH_TU_ALL)
-extern "C" int vgh_launch_real_bf16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
-    return launch_h_ntb<T_BF16, false>(*a, ntb, blocks, smem, stream);
+extern "C" int vgh_launch_real_bf16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_BF16, false>(*a, ntb, waves, blocks, smem, stream);
 }
 #endif
 #if VGH_TU == 2 || defined(VGH_TU_ALL)
-extern "C" int vgh_launch_bound_f16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
-    return launch_h_ntb<T_F16, true>(*a, ntb, blocks, smem, stream);
+extern "C" int vgh_launch_bound_f16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_F16, true>(*a, ntb, waves, blocks, smem, stream);
 }
 #endif
 #if VGH_TU == 4 || defined(VGH_TU_ALL)
-extern "C" int vgh_launch_bound_bf16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
-    return launch_h_ntb<T_BF16, true>(*a, ntb, blocks, smem, stream);
+extern "C" int vgh_launch_bound_bf16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_BF16, true>(*a, ntb, waves, blocks, smem, stream);
 }
 #endif
 #if VGH_TU == 5 || defined(VGH_TU_ALL)
-extern "C" int vgh_launch_bound_f32(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
-    return launch_h_ntb<T_F32, true>(*a, ntb, blocks, smem, stream);
+extern "C" int vgh_launch_bound_f32(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_F32, true>(*a, ntb, waves, blocks, smem, stream);
 }
 #endif
 #if VGH_TU == 3 || defined(VGH_TU_ALL)
-extern "C" int vgh_launch_real_f32(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
-    return launch_h_ntb<T_F32, false>(*a, ntb, blocks, smem, stream);
+extern "C" int vgh_launch_real_f32(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_F32, false>(*a, ntb, waves, blocks, smem, stream);
 }
 #endif
 #if VGH_TU == 0
-extern "C" int vgh_launch_real_f16(const BatchArgsH *a, int ntb, int blocks, size_t smem, hipStream_t stream) {
-    return launch_h_ntb<T_F16, false>(*a, ntb, blocks, smem, stream);
+extern "C" int vgh_launch_real_f16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_F16, false>(*a, ntb, waves, blocks, smem, stream);
 }
 
 extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
@@ -665,13 +675,30 @@ static int vgh_ntb(long long stride_bytes) {
     return 0;
 }
 
+static size_t vgh_lds_bytes(int NTB, int k, int waves) {
+    return (size_t)2 * NTB * 1024 + 1024 + (size_t)waves * VGH_QPW * (8 + 4 + 4) + (size_t)waves * VGH_QPW * k * 8;
+}
+// What a batch of nq queries over rows of stride_bytes is launched with: wavefronts per workgroup (= 32 queries each) and the
+// workgroups per CU the partition count should aim at.  Two 4-wavefront workgroups per CU where that form exists (NTB <= 24), both
+// fit the CU's LDS (k <= 27 at 768-byte rows) and the batch fills at least two of them per partition (nq > 128); VG_BATCH_H_WAVES=8
+// keeps round 3's single 8-wavefront workgroup, =4 forces the new form wherever it is instantiated and fits.
+extern "C" int vg_batch_h_plan(long long stride_bytes, int k, int nq, int *waves, int *blocks_per_cu) {
+    const int NTB = vgh_ntb(stride_bytes);
+    if (!NTB || k < 1 || k > VGH_MAX_K) return -1;
+    int w = VGH_WAVES_OF(NTB), bpc = 1;
+    const char *e = getenv("VG_BATCH_H_WAVES");
+    const int forced = (e && *e) ? atoi(e) : 0;
+    if (VGH_HAS_W4(NTB) && forced != 8 && 2 * vgh_lds_bytes(NTB, k, 4) + 2048 <= (size_t)160 * 1024 && (nq > 4 * VGH_QPW || forced == 4)) { w = 4; bpc = 2; }
+    if (waves) *waves = w;
+    if (blocks_per_cu) *blocks_per_cu = bpc;
+    return 0;
+}
 extern "C" int vg_batch_h_queries_per_block(long long stride_bytes) { return VGH_WAVES_OF(vgh_ntb(stride_bytes)) * VGH_QPW; }
 
-extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k) {
+extern "C" size_t vg_batch_h_lds_bytes(long long stride_bytes, int k) {          // (the default 8-wavefront form: the larger of the two)
     const int NTB = vgh_ntb(stride_bytes);
     if (!NTB || k < 1 || k > VGH_MAX_K) return 0;
-    const size_t waves = (size_t)VGH_WAVES_OF(NTB);
-    const size_t b = (size_t)2 * NTB * 1024 + 1024 + waves * VGH_QPW * (8 + 4 + 4) + waves * VGH_QPW * k * 8;
+    const size_t b = vgh_lds_bytes(NTB, k, VGH_WAVES_OF(NTB));
     return b <= 160 * 1024 ? b : 0;
 }
 
@@ -769,9 +796,12 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
                                  const uint8_t *dev_xrows, long long xstride_bytes,
                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
                                  const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
-                                 uint64_t *dev_out_keys, unsigned long long *dev_evals, hipStream_t stream) {
-    const size_t smem = vg_batch_h_lds_bytes(stride_bytes, k);
-    if (!smem || nq_pad % vg_batch_h_queries_per_block(stride_bytes) != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
+                                 uint64_t *dev_out_keys, unsigned long long *dev_evals, int waves, hipStream_t stream) {
+    const int ntb = vgh_ntb(stride_bytes);
+    if (!ntb || k < 1 || k > VGH_MAX_K || (waves != VGH_WAVES_OF(ntb) && !(waves == 4 && VGH_HAS_W4(ntb)))) return -1;
+    const size_t smem = vgh_lds_bytes(ntb, k, waves);
+    const int qpb = waves * VGH_QPW;
+    if (smem > (size_t)160 * 1024 || nq_pad % qpb != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
     if (mode < VGH_DOT || mode > VGH_L2 || !dev_row_nn) return -1;
     BatchArgsH a;
     a.rows = dev_rows; a.tiled = rows_tiled; a.queries = dev_queries; a.row_nn = dev_row_nn; a.cand = dev_cand;
@@ -779,15 +809,14 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
     a.cerr = (float)(dim + 64) * 4.76837158203125e-7f + (type_code == 2 ? 0.0078125f + 1.52587890625e-5f : 0.0f);   // (D+64) 2^-21 [+ 2u + u^2, u = 2^-8: query AND row are rounded to bf16]
     a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;
     a.mode = mode; a.root = root; a.dim = dim; a.evals = dev_evals;
-    const int ntb = vgh_ntb(stride_bytes);
-    const int G = nq_pad / vg_batch_h_queries_per_block(stride_bytes);
+    const int G = nq_pad / qpb;
     const int blocks = G * ((npart + 7) / 8) * 8;
     const long long ntiles = (n_rows + VGH_TILE - 1) / VGH_TILE;
     auto launch = [&](const BatchArgsH &b, bool bound) -> int {
-        if (bound) return type_code == 2 ? vgh_launch_bound_f32(&b, ntb, blocks, smem, stream)
-                                         : (type_code == 1 ? vgh_launch_bound_bf16(&b, ntb, blocks, smem, stream) : vgh_launch_bound_f16(&b, ntb, blocks, smem, stream));
-        if (type_code == 2) return vgh_launch_real_f32(&b, ntb, blocks, smem, stream);
-        return type_code == 1 ? vgh_launch_real_bf16(&b, ntb, blocks, smem, stream) : vgh_launch_real_f16(&b, ntb, blocks, smem, stream);
+        if (bound) return type_code == 2 ? vgh_launch_bound_f32(&b, ntb, waves, blocks, smem, stream)
+                                         : (type_code == 1 ? vgh_launch_bound_bf16(&b, ntb, waves, blocks, smem, stream) : vgh_launch_bound_f16(&b, ntb, waves, blocks, smem, stream));
+        if (type_code == 2) return vgh_launch_real_f32(&b, ntb, waves, blocks, smem, stream);
+        return type_code == 1 ? vgh_launch_real_bf16(&b, ntb, waves, blocks, smem, stream) : vgh_launch_real_f16(&b, ntb, waves, blocks, smem, stream);
     };
     // Large corpora: a BOUND pre-pass over the first 1/512 of the rows (round 3; 1/32 before) gives every query an upper bound of its final
     // k-th best distance (no exact evaluations - with thresholds starting at +Inf they were a quarter of the whole

@@ -591,6 +591,37 @@ def test_batch_half_matrix_core_filter_vs_single_scans(pkg, orc, vt, metric, mon
         c.close()
 
 
+@pytest.mark.parametrize("vt", [dg.F32, dg.F16, dg.BF16])
+def test_batch_half_workgroup_forms_agree(pkg, vt, monkeypatch):
+    """the f16 / bf16 / f32-through-bf16 batch kernel comes as one 8-wavefront workgroup per CU or - rows up to 768 bytes, both
+    workgroups' LDS fitting - as two of four (vg_batch_h_plan): the same keys out of both, bit for bit, over the row lengths that
+    have both forms, a k where the second workgroup no longer fits (the plan must fall back by itself) and a batch too small for it."""
+    monkeypatch.setenv("VG_F32_FILTER", "1")
+    monkeypatch.setenv("VG_BATCH_MFMA", "1")
+    rng = np.random.default_rng(17)
+    for dim in ((8, 100, 192) if vt == dg.F32 else (8, 100, 256, 384)):
+        n = 70_000
+        rows = dg.corpus(vt, n, dim, 9100 + dim)
+        rows[5000] = rows[17]
+        c = pkg.Corpus(vt, dim)
+        c.append(rows)
+        for metric in (dg.DOT, dg.L2, dg.COSINE):
+            for nq, k in ((300, 20), (513, 27), (300, 32), (100, 10)):
+                qs = dg.corpus(vt, nq, dim, 9200 + dim + nq)
+                qs[0] = rows[17]
+                got = {}
+                for form in ("8", "4", ""):
+                    if form:
+                        monkeypatch.setenv("VG_BATCH_H_WAVES", form)
+                    else:
+                        monkeypatch.delenv("VG_BATCH_H_WAVES", raising=False)
+                    got[form] = c.scan_topk_batch(metric, qs, k)
+                for form in ("4", ""):
+                    for a, b in zip(got["8"], got[form]):
+                        assert np.array_equal(a, b), (dg.TYPE_NAMES[vt], dim, metric, nq, k, form)
+        c.close()
+
+
 @pytest.mark.parametrize("vt", [dg.F16, dg.BF16])
 def test_batch_half_two_pass_launch_and_partitions(pkg, vt, monkeypatch):
     """enough rows for the two-pass launch (pre-pass thresholds) and many partitions; clustered data so that the
