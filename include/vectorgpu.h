@@ -227,6 +227,10 @@ int vg_profile_mean_ms_ex(vg_corpus *c, int *n_launches, float *scan_ms, float *
 /* the launch shape the plain scan kernel would run a row of `dim` elements of `vtype` with under `metric`: lanes sharing a row,
  * 16-byte chunks per lane, and whether the row takes the long-row kernel instead (pure host logic - no device, no corpus) */
 int vg_plan_scan_shape(int vtype, int dim, int metric, int *lanes_per_row, int *chunks_per_lane, int *long_rows);
+/* the form a batch of nq queries over f16 / bf16 rows (or the bf16 shadow rows of an f32 corpus) of stride_bytes runs in: wavefronts
+ * per workgroup (32 queries each) and workgroups per CU - one of eight, or two of four where both fit the CU's LDS.  Host logic
+ * only; returns -1 for rows the matrix-core kernel does not serve */
+int vg_batch_h_plan(long long stride_bytes, int k, int nq, int *waves, int *blocks_per_cu);
 /* name of the scan kernel variant chosen for (metric) on this corpus, e.g. "scan_f32_l2_u6_lpr16" */
 const char *vg_scan_kernel_name(vg_corpus *c, int metric);
 /* filter scan: f32 rows evaluated exactly by the filter-scan launches since the last call (then reset) - how selective the

@@ -102,6 +102,7 @@ def lib():
         "vg_profile_mean_ms": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "vg_scan_kernel_name": (C.c_char_p, [vp, i32]),
         "vg_plan_scan_shape": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "vg_batch_h_plan": (i32, [i64, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
         "vg_profile_mean_ms_ex": (i32, [vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
         "vg_corpus_find_rowid": (i64, [vp, i64]),
         "vg_corpus_patch_rows": (i32, [vp, vp, i64, vp, i64]),
@@ -152,6 +153,15 @@ def device_count():
 
 def backend_name():
     return lib().vg_backend_name().decode()
+
+
+def plan_batch_half_form(stride_bytes, k, nq):
+    """(wavefronts per workgroup, workgroups per CU) of an f16 / bf16 / f32-via-bf16 batch, or None if the matrix-core kernel does not
+    serve such rows - host logic only"""
+    w, b = C.c_int(0), C.c_int(0)
+    if lib().vg_batch_h_plan(stride_bytes, k, nq, C.byref(w), C.byref(b)) != 0:
+        return None
+    return w.value, b.value
 
 
 def plan_scan_shape(vtype, dim, metric):

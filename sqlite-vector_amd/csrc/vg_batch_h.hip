@@ -688,7 +688,8 @@ extern "C" int vg_batch_h_plan(long long stride_bytes, int k, int nq, int *waves
     int w = VGH_WAVES_OF(NTB), bpc = 1;
     const char *e = getenv("VG_BATCH_H_WAVES");
     const int forced = (e && *e) ? atoi(e) : 0;
-    if (VGH_HAS_W4(NTB) && forced != 8 && 2 * vgh_lds_bytes(NTB, k, 4) + 2048 <= (size_t)160 * 1024 && (nq > 4 * VGH_QPW || forced == 4)) { w = 4; bpc = 2; }
+    if (VGH_HAS_W4(NTB) && forced != 8 && 2 * vgh_lds_bytes(NTB, k, 4) + 4096 <= (size_t)160 * 1024 && (nq > 4 * VGH_QPW || forced == 4)) { w = 4; bpc = 2; }
+    if (vgh_lds_bytes(NTB, k, w) > (size_t)160 * 1024) return -1;                 // (2 KiB rows with k >= 30: not served, as vg_batch_h_lds_bytes says)
     if (waves) *waves = w;
     if (blocks_per_cu) *blocks_per_cu = bpc;
     return 0;

@@ -126,3 +126,30 @@ def test_launch_shape_rules(pkg, monkeypatch):
     # the experiment override reaches the same function
     monkeypatch.setenv("VG_LPR_LOG2", "4"); monkeypatch.setenv("VG_U", "6")
     assert pkg.plan_scan_shape(F32, 384, L2)[:2] == (16, 6)
+
+
+def test_half_batch_workgroup_form_plan(pkg, monkeypatch):
+    """vg_batch_h_plan (host logic): two 4-wavefront workgroups per CU only for rows of up to 768 bytes, while BOTH workgroups' LDS
+    (tiles + 32 k-key lists per wavefront) fits the CU's 160 KB and the batch fills two workgroups per partition; one workgroup of
+    eight otherwise (one of four for rows of 1 - 2 KiB, whose query block alone takes the register file)."""
+    monkeypatch.delenv("VG_BATCH_H_WAVES", raising=False)
+    plan = pkg.plan_batch_half_form
+    assert plan(768, 20, 1024) == (4, 2) and plan(768, 27, 1024) == (4, 2) and plan(768, 28, 1024) == (8, 1) and plan(768, 32, 300) == (8, 1)
+    assert plan(768, 20, 129) == (4, 2) and plan(768, 20, 128) == (8, 1) and plan(768, 20, 1) == (8, 1)
+    assert plan(512, 32, 1024) == (4, 2) and plan(256, 32, 300) == (4, 2) and plan(64, 1, 4096) == (4, 2)
+    assert plan(1024, 20, 1024) == (8, 1) and plan(800, 20, 1024) == (8, 1)          # 1 KiB rows: no second form
+    assert plan(1536, 20, 1024) == (4, 1) and plan(2048, 10, 1024) == (4, 1)          # long rows: one 4-wavefront workgroup
+    assert plan(2049, 10, 1024) is None and plan(768, 0, 10) is None and plan(768, 33, 10) is None
+    for k in range(1, 33):                                                           # the chosen form always fits
+        for stride in (32, 256, 512, 768, 1024, 1536, 2048):
+            if plan(stride, k, 1024) is None:
+                assert stride == 2048 and k >= 30                                     # (the one combination whose lists do not fit at all)
+                continue
+            w, b = plan(stride, k, 1024)
+            ntb = [n for n in (8, 16, 24, 32, 48, 64) if n * 32 >= stride][0]
+            lds = 2 * ntb * 1024 + 1024 + w * 32 * 16 + w * 32 * k * 8
+            assert b * lds <= 160 * 1024, (stride, k, w, b, lds)
+    monkeypatch.setenv("VG_BATCH_H_WAVES", "8")
+    assert plan(768, 20, 1024) == (8, 1)
+    monkeypatch.setenv("VG_BATCH_H_WAVES", "4")
+    assert plan(768, 20, 100) == (4, 2) and plan(768, 30, 1024) == (8, 1) and plan(1024, 20, 1024) == (8, 1)
