@@ -121,6 +121,7 @@ def lib():
         "vg_shards_set_scan_filter": (i32, [vp, i32]),
         "vg_shards_set_gather": (i32, [vp, i32]),
         "vg_shards_gather_stats": (i32, [vp, vp]),
+        "vg_shards_tie_stats": (i32, [vp, vp]),
         "vg_shards_rowids": (i32, [vp, i64, i64, vp]),
         "vg_scan_topk_reference": (i32, [vp, i32, vp, i32, vp, vp, C.POINTER(i32)]),
         "vg_stat_rows_appended": (C.c_longlong, []),
@@ -388,6 +389,12 @@ class Shards:
         out = np.zeros(2, dtype=np.uint64)
         serving = lib().vg_shards_gather_stats(self.h, _ptr(out))
         return {"host": int(out[0]), "rccl": int(out[1]), "rccl_serving": bool(serving)}
+
+    def tie_stats(self):
+        """reference-order scans of this handle so far (same four counters as Corpus.tie_stats)"""
+        out = np.zeros(4, dtype=np.uint64)
+        _check(lib().vg_shards_tie_stats(self.h, _ptr(out)))
+        return dict(zip(("scans", "with_a_tie_among_the_k_plus_1_best", "fused_replays", "store_mode_replays"), (int(x) for x in out)))
 
     def scan_topk(self, metric, query, k):
         query = np.ascontiguousarray(query)

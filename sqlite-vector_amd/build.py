@@ -49,7 +49,7 @@ def _hipcc():
 
 def build_gpu_library(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "vectorgpu.h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "vectorgpu.h"), os.path.join(ROOT, "include", "vectorgpu_diag.h")]
     if not force and not _newer(LIB, srcs + hdrs):
         return LIB
     # one object per translation unit (compiled concurrently), then one link

@@ -23,11 +23,11 @@ static const int kAllowedU[] = {1, 2, 3, 4, 6, 8};
 // under the 128-VGPR cap of 16 wavefronts per CU.  The query stays in registers as RAW halves (vg_scan.h launders it
 // every batch so the compiler cannot hoist widened copies out of the loop); with that U = 6 fits for everything but
 // bf16 dot / cosine, which spill beyond U = 3 (measured 2.4 TB/s at U = 6).
-static int max_chunks_per_lane(int vtype, int acc) {
+static int max_chunks_per_lane(int vtype, int acc, bool bf16_l2_u3) {
     if (vtype == VG_TYPE_F16) return 6;
     // bf16: dot / cosine spill beyond 3.  L2 / L1 fit 6; with the unconditional batch loads L2 measures 2 % faster at 8 lanes x 6
     // (10M x 384: 6.55 / 6.69 against 6.43 / 6.57 TB/s in two alternating passes), L1 2 % slower (profiles/r5d_shape_ab_f32_half.txt)
-    if (vtype == VG_TYPE_BF16) return (acc == A_L2 && !env_int("VG_SHAPE_BF16_L2_U3", 0)) ? 6 : 3;
+    if (vtype == VG_TYPE_BF16) return (acc == A_L2 && !bf16_l2_u3) ? 6 : 3;
     return 8;
 }
 
@@ -42,10 +42,24 @@ static int max_chunks_per_lane(int vtype, int acc) {
 // prefetch really in flight behind the arithmetic 16 x 3 wins on every metric (10M x 384 f16: L2 6.91 -> 6.91, cosine 6.53 -> 6.85,
 // dot 6.54 -> 7.01, L1 6.90 -> 6.97 TB/s; 5M x 768: 6.34-6.54 -> 6.65-6.77, profiles/r5c_shape_sweep_unconditional_loads.txt).
 // bf16 takes at most 3 chunks per lane anyway (max_chunks_per_lane).
-static int shape_pref(int vtype, int l2, int U, bool ragged) {
+// the experiment switches of the shape choice, read ONCE per choice (they sat inside its loops: ~20 getenv calls per scan launch on a
+// path that is tuned to ~34 us per query)
+struct ShapeEnv { bool f16_round3, pref_round1, bf16_l2_u3, int_short_round3, force_long; int lpr_log2, u; };
+static ShapeEnv shape_env() {
+    ShapeEnv e;
+    e.f16_round3 = env_int("VG_SHAPE_F16_ROUND3", 0) != 0;
+    e.pref_round1 = env_int("VG_SHAPE_PREF_ROUND1", 0) != 0;
+    e.bf16_l2_u3 = env_int("VG_SHAPE_BF16_L2_U3", 0) != 0;
+    e.int_short_round3 = env_int("VG_SHAPE_INT_SHORT_ROUND3", 0) != 0;
+    e.force_long = env_int("VG_FORCE_LONG", 0) != 0;
+    e.lpr_log2 = env_int("VG_LPR_LOG2", -1);
+    e.u = env_int("VG_U", -1);
+    return e;
+}
+static int shape_pref(const ShapeEnv &env, int vtype, int l2, int U, bool ragged) {
     static const int pref[9] = {0, 1, 2, 4, 5, 0, 6, 0, 3};
-    const bool wide = (vtype == VG_TYPE_F32 || vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8 || (vtype == VG_TYPE_F16 && !env_int("VG_SHAPE_F16_ROUND3", 0))) &&
-                      !env_int("VG_SHAPE_PREF_ROUND1", 0);
+    const bool wide = (vtype == VG_TYPE_F32 || vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8 || (vtype == VG_TYPE_F16 && !env.f16_round3)) &&
+                      !env.pref_round1;
     if (wide && U == 3) return 7;
     // rows no shape covers exactly (e.g. 100 floats = 25 chunks): 2 chunks per lane at twice the lanes beat 4 (longer contiguous
     // runs over rows that are not line-aligned): 15M x 100 f32 5.3 -> 6.1-6.6 TB/s (profiles/r4q_short_rows_shape_ab.txt)
@@ -54,8 +68,9 @@ static int shape_pref(int vtype, int l2, int U, bool ragged) {
 }
 
 bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap) {
-    const int max_u = std::min(max_chunks_per_lane(vtype, acc), u_cap);
-    const bool round1 = env_int("VG_SHAPE_PREF_ROUND1", 0) != 0;
+    const ShapeEnv env = shape_env();
+    const int max_u = std::min(max_chunks_per_lane(vtype, acc, env.bf16_l2_u3), u_cap);
+    const bool round1 = env.pref_round1;
     // Short rows (3 .. 8 chunks): with ONE chunk per lane a batch is one load + a whole epilogue (butterfly, conversions, sqrt /
     // divide, key, ballot) for 64 / lanes-per-row rows - half the lanes per row with 2 chunks each amortise it over twice the rows.
     // f32 (32 floats: 5.9 -> 6.2 TB/s on every metric) and - re-measured with the unconditional batch loads,
@@ -64,7 +79,7 @@ bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap) {
     // overlap; with it in flight one chunk per lane wins on every metric (64 bytes L2 5.4 -> 6.0, 100 bytes 4.3 -> 5.0, 128 bytes 5.4 -> 6.1).
     const bool short_rows = !round1 && nch >= 3 && nch <= 8 &&
                             (vtype == VG_TYPE_F32 || vtype == VG_TYPE_F16 || vtype == VG_TYPE_BF16 ||
-                             (env_int("VG_SHAPE_INT_SHORT_ROUND3", 0) && (vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8) && (acc == A_L2 || acc == A_COS)));
+                             (env.int_short_round3 && (vtype == VG_TYPE_U8 || vtype == VG_TYPE_I8) && (acc == A_L2 || acc == A_COS)));
     double best_eff = -1.0;
     for (int l2 = 0; l2 <= 6; ++l2) {                        // (the best cover any shape reaches: "ragged" rows have none at 1.0)
         const int lpr = 1 << l2, need = (nch + lpr - 1) / lpr;
@@ -80,13 +95,13 @@ bool vg_choose_shape(int nch, int vtype, int acc, VgShape *out, int u_cap) {
         if (!U) continue;
         double eff = (double)nch / ((double)lpr * U);
         int flag = (lpr >= 8 || lpr >= nch || (short_rows && U == 2)) ? 1 : 0;
-        const int pr = shape_pref(vtype, l2, U, ragged);
+        const int pr = shape_pref(env, vtype, l2, U, ragged);
         bool better = eff > best_eff + 1e-9 ||
                       (fabs(eff - best_eff) <= 1e-9 && (flag > best_flag || (flag == best_flag && pr > best_pref)));
         if (better) { best_eff = eff; best_flag = flag; best_pref = pr; best.lpr_log2 = l2; best.U = U; }
     }
-    if (best.U == 0 || env_int("VG_FORCE_LONG", 0)) { best.lpr_log2 = 6; best.U = VG_LONG_U; best.long_rows = true; }
-    int fl = env_int("VG_LPR_LOG2", -1), fu = env_int("VG_U", -1);   // experiment overrides
+    if (best.U == 0 || env.force_long) { best.lpr_log2 = 6; best.U = VG_LONG_U; best.long_rows = true; }
+    int fl = env.lpr_log2, fu = env.u;   // experiment overrides
     if (!best.long_rows && fl >= 0 && fu > 0 && (nch + (1 << fl) - 1) / (1 << fl) <= fu) { best.lpr_log2 = fl; best.U = fu; }
     *out = best;
     return true;
@@ -178,6 +193,14 @@ static bool use_nt_loads(const vg_corpus *c, int64_t n_rows) {
     return n_rows * c->stride > (256ll << 20);
 }
 
+// batch order of the top-k scan (ScanArgs.order); VG_SCAN_ORDER=0 / 1 forces one
+static int scan_order_for(const vg_corpus *c, int64_t n_rows) {
+    const int force = env_int("VG_SCAN_ORDER", -1);
+    if (force >= 0) return force ? 1 : 0;
+    (void)c; (void)n_rows;
+    return 0;
+}
+
 int vg_metric_to_acc(int metric) {
     switch (metric) {
         case VG_DIST_L2: case VG_DIST_SQUARED_L2: return A_L2;
@@ -259,12 +282,16 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     if (acc < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
     const int64_t n_rows = (plan.n_rows >= 0) ? std::min<int64_t>(plan.n_rows, c->n_rows) : c->n_rows;
     if (plan.ref_emit) c->ref_prefix_rows = -1;              // (set by whichever launch below really emits)
-    if (plan.allow_filter && plan.n_rows < 0 && !dev_out_dist && k <= VG_MAX_FUSED_K) {
+    Shape s;
+    choose_shape(c->nch, c->vtype, acc, &s);
+    // tie_order = reference over a SMALL corpus: the whole corpus is the replay's prefix - one "top-k + store" launch of the EX kernel
+    // leaves every distance behind and an empty candidate stream (no pre-pass, no second scan on a tie)
+    const bool whole_prefix = plan.ref_emit && !dev_out_dist && plan.n_rows < 0 && k > 0 && k <= VG_MAX_FUSED_K && !s.long_rows &&
+                              n_rows < VG_REF_EMIT_MIN_ROWS;
+    if (!whole_prefix && plan.allow_filter && plan.n_rows < 0 && !dev_out_dist && k <= VG_MAX_FUSED_K) {
         int rcf = vg_launch_scan_filter(c, metric, dev_query, k, dev_out_keys, stream, plan.ref_emit, plan.final_out);
         if (rcf != -1) return rcf;
     }
-    Shape s;
-    choose_shape(c->nch, c->vtype, acc, &s);
     // f16 / bf16 cosine: the row norms come from a cached vector (computed once per appended row) instead of being
     // re-accumulated in f64 on every scan - the f64 chain is what bounds these kernels, not HBM
     if (acc == A_COS && (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) && !s.long_rows && env_int("VG_HALF_COSN", 1)) {
@@ -281,7 +308,16 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     // k-th best is every list's start threshold and the line below which an accepted row is emitted.  Both are EX kernels (vg_scan_ex.hip).
     const bool emitting = plan.ref_emit && !dev_out_dist && !s.long_rows && plan.n_rows < 0 && k <= VG_MAX_FUSED_K &&
                           n_rows >= VG_REF_EMIT_MIN_ROWS;
-    const bool prefix_pass = plan.store_prefix && !dev_out_dist && !s.long_rows && k > 0;
+    float *store_prefix = plan.store_prefix;
+    unsigned long long *emit_reset = plan.emit_reset;
+    if (whole_prefix) {
+        int rcb = vg_ensure_ref_buffers(c, n_rows);
+        if (rcb != VG_OK) return rcb;
+        store_prefix = c->d_ref_prefix;
+        emit_reset = c->d_below;
+        c->ref_prefix_rows = n_rows;
+    }
+    const bool prefix_pass = store_prefix && !dev_out_dist && !s.long_rows && k > 0;
     scan_fn_t fn = (emitting || prefix_pass) ? vg_pick_scan_kernel_ex(c->vtype, acc, s.U) : pick_kernel(c->vtype, acc, s, use_nt_loads(c, n_rows));
     if (!fn) return vg_fail(VG_ERR_UNSUPPORTED, "no scan kernel for type %s", type_tag(c->vtype));
 
@@ -312,8 +348,9 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     a.init_keys = nullptr;
     a.emit = nullptr;
     a.emit_cap = 0;
-    a.emit_reset = plan.emit_reset;
-    if (prefix_pass) a.out_dist = plan.store_prefix;       // top-k + store (EX kernel, k > 0)
+    a.emit_reset = emit_reset;
+    a.order = scan_order_for(c, n_rows);
+    if (prefix_pass) a.out_dist = store_prefix;            // top-k + store (EX kernel, k > 0)
     else a.emit_reset = nullptr;
     size_t qbytes = (size_t)c->nch * 16;
     if (s.long_rows) {

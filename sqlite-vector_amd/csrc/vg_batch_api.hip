@@ -395,6 +395,17 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     return VG_OK;
 }
 
+// Does a batch over this corpus return, for every (query, row) pair, the very float the single-query scan computes?  tie_order =
+// reference looks for ties in a batch's keys and is defined on the single scan's arithmetic: integer sums are exact, f16 / bf16
+// survivors carry the single scan's f64 arithmetic, f32 rows through the bf16 filter are re-evaluated with the single scan's f32
+// chain - but the f32 matrix-core kernel (a k-ordered fmaf chain) and the multi-query scan (another launch shape) sum in another
+// order, and a tie under the single scan's arithmetic could go unnoticed in their keys.
+bool vg_batch_keys_are_scan_exact(const vg_corpus *c, int metric, int k) {
+    if (c->vtype != VG_TYPE_F32) return true;
+    if (!batch_f32_filter_eligible(c, metric, k)) return false;
+    return vg_batch_lds_bytes(c->stride, k) == 0 || (batch_f32_filter_short_rows(c) && !c->filter_disabled);
+}
+
 extern "C" int vg_batch_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals) {
     if (!c || !out_evals) return vg_fail(VG_ERR_INVALID, "vg_batch_filter_exact_evals: NULL argument");
     *out_evals = 0;
@@ -423,7 +434,9 @@ extern "C" int vg_scan_topk_batch(vg_corpus *c, int metric, const void *queries,
         const int k1 = k + 1;
         std::vector<uint64_t> keys1((size_t)nq * k1);
         std::vector<int> cnt1((size_t)nq, 0);
-        int rcb = (k1 <= 64) ? vg_scan_topk_batch_keys(c, metric, queries, nq, k1, keys1.data(), cnt1.data()) : VG_ERR_UNSUPPORTED;
+        // (k = 64: no slot to look for a tie with; f32 batches off the bf16 filter: not the single scan's floats - both query by query)
+        int rcb = (k1 <= 64 && vg_batch_keys_are_scan_exact(c, metric, k1)) ? vg_scan_topk_batch_keys(c, metric, queries, nq, k1, keys1.data(), cnt1.data())
+                                                                             : VG_ERR_UNSUPPORTED;
         if (rcb != VG_OK && rcb != VG_ERR_UNSUPPORTED) return rcb;
         for (int i = 0; i < nq; ++i) {
             bool tie = (rcb != VG_OK);

@@ -42,6 +42,8 @@ struct ScanArgs {
                                //   reference's k slots (it is below the k-th best of SOME earlier rows, hence possibly of all of them)
     unsigned emit_cap;
     unsigned long long *emit_reset;   // zeroed by this launch's first thread (the prefix pass resets the counter of the pass behind it)
+    int order;                 // top-k mode: 0 = grid-stride batches (the whole chip sweeps one contiguous window), 1 = every workgroup owns a
+                               //   contiguous run of batches, its 16 wavefronts striding inside it (one CU stays on one page for many iterations)
 };
 
 // ------------------------------------------------------------------------------------------ keys

@@ -438,8 +438,15 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
         // filter is tried again.
         // (the mirror holds the counter as of the last launch whose copy has LANDED and, in word [2], how many filter launches had
         // finished by then: averaging over launches still in flight would bias the figure low)
-        const unsigned long long now = *(volatile unsigned long long *)c->h_filter_evals;
-        const long long landed = (long long)*(volatile unsigned long long *)(c->h_filter_evals + 2);
+        // (the two words are written by different threads of the merge's workgroup: read [2], [0], [2] again and retry on a mismatch,
+        // so that a copy landing in between cannot pair one launch's count with the next launch's number)
+        unsigned long long now = 0;
+        long long landed = 0;
+        for (int attempt = 0; attempt < 4; ++attempt) {
+            landed = (long long)*(volatile unsigned long long *)(c->h_filter_evals + 2);
+            now = *(volatile unsigned long long *)c->h_filter_evals;
+            if (landed == (long long)*(volatile unsigned long long *)(c->h_filter_evals + 2)) break;
+        }
         const long long launches = std::min<long long>(c->filter_launches, landed) - c->filter_launches_seen;
         if (launches >= 2) {
             if ((now - c->filter_evals_seen) / (unsigned long long)launches > (unsigned long long)(c->n_rows / 8) && !env_int("VG_SCAN_FILTER_NO_GUARD", 0))

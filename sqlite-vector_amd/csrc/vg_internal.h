@@ -6,6 +6,7 @@
 #pragma once
 
 #include "../../include/vectorgpu.h"
+#include "../../include/vectorgpu_diag.h"
 
 #include <hip/hip_runtime.h>
 
@@ -186,6 +187,13 @@ static inline int64_t vg_ref_prefix_for(int64_t n_rows) {
     return p;
 }
 int vg_ensure_ref_buffers(vg_corpus *c, int64_t prefix_rows);       // vg_reforder.hip: d_ref_prefix / d_below / h_ref
+#define VG_REF_FIRST_PAIRS 8191       // candidate pairs that travel with the counter in the first copy (nearly always all of them)
+// vg_reforder.hip: what the last emitting launch of a corpus left behind, brought to the host (enqueue the copies, then wait)
+int vg_ref_emitted_enqueue(vg_corpus *c);
+int vg_ref_emitted_wait(vg_corpus *c, const float **prefix, int64_t *prefix_rows, unsigned long long **pairs, unsigned long long *count,
+                        bool *overflow);
+struct VgRefSlots;
+void vg_ref_offer_run(VgRefSlots &slots, const float *d, int64_t n, int64_t g0);   // a run of consecutive rows offered to the slots
 
 // next slot of the profiling ring (nullptr when profiling is off)
 static inline hipEvent_t *vg_prof_slot(vg_corpus *c, uint8_t flags) {
@@ -217,6 +225,7 @@ bool vg_scan_filter_would_serve(const vg_corpus *c, int metric, int k);   // vg_
 bool vg_scan_filter_policy(const vg_corpus *c);      // vg_filter.hip: filter switched on for this corpus and the corpus large enough for the shadow copy to pay
 int vg_ensure_filter_counters(vg_corpus *c);         // vg_filter.hip: d_filter_evals[2] + pinned mirror
 bool vg_scan_filter_name(vg_corpus *c, int metric, char *out, size_t out_len);   // vg_filter.hip: kernel name when the filter serves the scan
+bool vg_batch_keys_are_scan_exact(const vg_corpus *c, int metric, int k);   // vg_batch_api.hip: a batch's floats are the single scan's
 long long vg_bf16_shadow_stride(const vg_corpus *c);               // vg_batch_api.hip: row stride of the bf16 shadow copy of an f32 corpus
 int vg_ensure_bf16_shadow(vg_corpus *c);                           // vg_batch_api.hip: build / extend it (corpus stream)
 int vg_multi_queries_per_pass(const vg_corpus *c, int metric);     // vg_multi.hip: queries per pass of the multi-query scan, 0 = none

@@ -157,34 +157,65 @@ int vg_ensure_ref_buffers(vg_corpus *c, int64_t prefix_rows) {
     return ensure_ref_pinned(c);
 }
 
-// The reference's slots replayed over what the last emitting launch left on the device: the prefix pass' distances (rows 0 .. P-1, all
-// of them) and the candidate stream (every later row that can enter the slots; a superset, in any order).  1 = the stream overflowed.
-static int replay_emitted(vg_corpus *c, int k, VgRefSlots &slots) {
+// What the last emitting launch left on the device comes to the host in two steps, so that a caller with several shards can put all
+// the copies in flight before it waits for any: the prefix pass' distances (rows 0 .. P-1 of this corpus, all of them) and the
+// candidate stream (every later row that can enter the reference's slots; a superset, in any order).
+int vg_ref_emitted_enqueue(vg_corpus *c) {
     const int64_t P = c->ref_prefix_rows;
+    if (P <= 0 || !c->d_ref_prefix || !c->d_below || !c->h_ref) return vg_fail(VG_ERR_INVALID, "vg_ref_emitted_enqueue: the last launch did not emit");
+    HIP_TRY(hipSetDevice(c->device));
     float *prefix = reinterpret_cast<float *>(c->h_ref);
     unsigned long long *head = reinterpret_cast<unsigned long long *>(c->h_ref + (size_t)VG_REF_PREFIX_MAX * 4);
-    const size_t first = 8191;
     HIP_TRY(hipMemcpyAsync(prefix, c->d_ref_prefix, (size_t)P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(head, c->d_below, (first + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(head, c->d_below, (VG_REF_FIRST_PAIRS + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    return VG_OK;
+}
+// waits for those copies; *overflow: the stream held more pairs than the device buffer does (the caller takes the store-mode replay).
+// The pointers stay valid until the next reference-order call on this corpus.
+int vg_ref_emitted_wait(vg_corpus *c, const float **prefix, int64_t *prefix_rows, unsigned long long **pairs, unsigned long long *count,
+                        bool *overflow) {
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const unsigned long long count = head[0];
-    if (count > (unsigned long long)VG_BELOW_CAP) return 1;
-    if (count > first) {
-        HIP_TRY(hipMemcpyAsync(head + 1 + first, c->d_below + 1 + first, (size_t)(count - first) * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long *head = reinterpret_cast<unsigned long long *>(c->h_ref + (size_t)VG_REF_PREFIX_MAX * 4);
+    const unsigned long long n = head[0];
+    *overflow = n > (unsigned long long)VG_BELOW_CAP;
+    *prefix = reinterpret_cast<const float *>(c->h_ref);
+    *prefix_rows = c->ref_prefix_rows;
+    *pairs = head + 1;
+    *count = *overflow ? 0 : n;
+    if (!*overflow && n > VG_REF_FIRST_PAIRS) {
+        HIP_TRY(hipMemcpyAsync(head + 1 + VG_REF_FIRST_PAIRS, c->d_below + 1 + VG_REF_FIRST_PAIRS, (size_t)(n - VG_REF_FIRST_PAIRS) * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    slots.init(k);
-    // the prefix: nearly every row is no candidate once the slots are warm - look at 16 rows at a time (a min the compiler vectorises)
+    return VG_OK;
+}
+
+// a run of consecutive rows (positions g0 ..) offered to the slots.  Nearly every row is no candidate once the slots are warm: look at
+// 16 rows at a time (a min the compiler vectorises)
+void vg_ref_offer_run(VgRefSlots &slots, const float *d, int64_t n, int64_t g0) {
     int64_t i = 0;
-    for (; i + 16 <= P; i += 16) {
-        float m = prefix[i];
-        for (int j = 1; j < 16; ++j) m = prefix[i + j] < m ? prefix[i + j] : m;     // (NaN never wins: it cannot enter either)
-        if (!((double)m < slots.cur_max) && !(prefix[i] != prefix[i])) continue;     // (a leading NaN would hide the rest: take the slow way)
-        for (int j = 0; j < 16; ++j) slots.offer(prefix[i + j], i + j);
+    for (; i + 16 <= n; i += 16) {
+        float m = d[i];
+        for (int j = 1; j < 16; ++j) m = d[i + j] < m ? d[i + j] : m;               // (NaN never wins: it cannot enter either)
+        if (!((double)m < slots.cur_max) && !(d[i] != d[i])) continue;              // (a leading NaN would hide the rest: take the slow way)
+        for (int j = 0; j < 16; ++j) slots.offer(d[i + j], g0 + i + j);
     }
-    for (; i < P; ++i) slots.offer(prefix[i], i);
+    for (; i < n; ++i) slots.offer(d[i], g0 + i);
+}
+
+// The reference's slots replayed over them.  *overflow as above.
+static int replay_emitted(vg_corpus *c, int k, VgRefSlots &slots, bool *overflow) {
+    int rc = vg_ref_emitted_enqueue(c);
+    if (rc != VG_OK) return rc;
+    const float *prefix = nullptr;
+    int64_t P = 0;
+    unsigned long long *pairs = nullptr, count = 0;
+    if ((rc = vg_ref_emitted_wait(c, &prefix, &P, &pairs, &count, overflow)) != VG_OK) return rc;
+    if (*overflow) return VG_OK;
+    slots.init(k);
+    vg_ref_offer_run(slots, prefix, P, 0);
     // the rows behind it, in scan order (position is the high word of a pair)
-    unsigned long long *pairs = head + 1;
     std::sort(pairs, pairs + count);
     for (unsigned long long j = 0; j < count; ++j) {
         const int64_t pos = (int64_t)(pairs[j] >> 32);
@@ -210,11 +241,17 @@ extern "C" int vg_scan_topk_reference(vg_corpus *c, int metric, const void *quer
     if (!out_rowids || !out_dist) return vg_fail(VG_ERR_INVALID, "vg_scan_topk_reference: NULL output");
     if (vg_metric_to_acc(metric) < 0) return vg_fail(VG_ERR_INVALID, "unknown distance metric %d", metric);
     ++c->ref_stats[0];
-    if (k + 1 > 64 || env_int("VG_REF_STORE_MODE", 0)) return reference_store_mode_replay(c, metric, query, k, out_rowids, out_dist, out_count);
-    const int k1 = k + 1;
-    const bool can_emit = c->n_rows >= VG_REF_EMIT_MIN_ROWS;
+    VgShape shape;
+    vg_plain_scan_shape(c, metric, &shape);
+    const bool can_emit = !shape.long_rows;                 // (rows too long for a register-resident shape have no emitting kernel)
+    // k = 64: the lists have no 65th slot to look for a tie with - the scan runs emitting with k slots and the slots are ALWAYS replayed
+    // (the candidate stream of k-slot lists is still a superset of the rows that can enter k slots)
+    const bool always = (k == VG_WAVE_HOST);
+    if (k > VG_WAVE_HOST || (always && !can_emit) || env_int("VG_REF_STORE_MODE", 0))
+        return reference_store_mode_replay(c, metric, query, k, out_rowids, out_dist, out_count);
+    const int k1 = always ? k : k + 1;
     // scans through a filter kernel have a pre-pass anyway (emitting is free); plain-kernel scans pay for one only while ties are around
-    bool emit = can_emit && (c->ref_hot > 0 || vg_scan_filter_would_serve(c, metric, k1) || env_int("VG_REF_ALWAYS_EMIT", 0));
+    bool emit = can_emit && (always || c->ref_hot > 0 || vg_scan_filter_would_serve(c, metric, k1) || env_int("VG_REF_ALWAYS_EMIT", 0));
     for (int attempt = 0; attempt < 2; ++attempt) {
         uint64_t keys[64];
         int rc = vg_scan_topk_enqueue_plan(c, metric, query, k1, emit);
@@ -222,7 +259,7 @@ extern "C" int vg_scan_topk_reference(vg_corpus *c, int metric, const void *quer
         if (rc != VG_OK) return rc;
         int cnt = 0;
         while (cnt < k1 && keys[cnt] != VG_KEY_EMPTY) ++cnt;
-        bool tie = false;
+        bool tie = always;
         for (int i = 1; i < cnt; ++i) tie |= (keys[i] >> 32) == (keys[i - 1] >> 32);
         if (!tie) {
             const int take = std::min(cnt, k);
@@ -235,13 +272,14 @@ extern "C" int vg_scan_topk_reference(vg_corpus *c, int metric, const void *quer
             return VG_OK;
         }
         if (attempt == 0) ++c->ref_stats[1];
-        c->ref_hot = 16;        // (break-even: a plain-kernel scan pays ~85 us for prefix pass + emitting kernel, a tie without them a
-                                // second ~1.2 ms scan - emitting pays from one tie in ~14 queries on)
+        if (!always) c->ref_hot = 16;   // (break-even: a plain-kernel scan pays ~85 us for prefix pass + emitting kernel, a tie without them a
+                                        // second ~1.2 ms scan - emitting pays from one tie in ~14 queries on)
         if (emit && c->ref_prefix_rows > 0) {
             VgRefSlots slots;
-            rc = replay_emitted(c, k, slots);
-            if (rc == 1) break;                             // too many candidates (heavy ties / descending distances): store mode
+            bool overflow = false;
+            rc = replay_emitted(c, k, slots, &overflow);
             if (rc != VG_OK) return rc;
+            if (overflow) break;                            // too many candidates (heavy ties / descending distances): store mode
             const int n = slots.finish();
             for (int i = 0; i < n; ++i) {
                 out_dist[i] = slots.dist[(size_t)i];
@@ -251,7 +289,7 @@ extern "C" int vg_scan_topk_reference(vg_corpus *c, int metric, const void *quer
             ++c->ref_stats[2];
             return VG_OK;
         }
-        if (emit || !can_emit) break;                       // this corpus cannot emit (long rows, small): store mode
+        if (emit || !can_emit) break;                       // this corpus cannot emit (long rows): store mode
         emit = true;                                        // a tie and nothing emitted: scan again, emitting
     }
     return reference_store_mode_replay(c, metric, query, k, out_rowids, out_dist, out_count);

@@ -132,9 +132,15 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
     const int flush_every = VG_STORE_FLOATS / rpb;                    // iterations that fill the staging area
     long long per_wave = (nbatch + nwaves - 1) / nwaves;
     per_wave = ((per_wave + flush_every - 1) / flush_every) * flush_every;
-    const long long wstride = store_mode ? 1 : nwaves;
+    long long wstride = store_mode ? 1 : nwaves;
     long long b = store_mode ? gw * per_wave : gw;
-    const long long b_end = store_mode ? ((gw + 1) * per_wave < nbatch ? (gw + 1) * per_wave : nbatch) : nbatch;
+    long long b_end = store_mode ? ((gw + 1) * per_wave < nbatch ? (gw + 1) * per_wave : nbatch) : nbatch;
+    if (a.order == 1 && !store_mode) {                                // block-contiguous order (ScanArgs.order)
+        const long long per_block = (nbatch + gridDim.x - 1) / gridDim.x;
+        wstride = VG_WAVES_PER_BLOCK;
+        b = (long long)blockIdx.x * per_block + wave;
+        b_end = ((long long)blockIdx.x + 1) * per_block < nbatch ? ((long long)blockIdx.x + 1) * per_block : nbatch;
+    }
     float *line = reinterpret_cast<float *>(smem + a.store_lds_off) + wave * VG_STORE_FLOATS;    // store mode only
     int in_line = 0;
     long long line_row0 = b * rpb;                                    // a multiple of VG_STORE_FLOATS: 16-byte aligned

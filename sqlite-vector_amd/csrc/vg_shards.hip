@@ -52,6 +52,9 @@ struct vg_shards {
     uint64_t *h_gather = nullptr;              // pinned: S x 64 keys
     bool rccl_failed = false;
     unsigned long long gather_calls[2] = {0, 0};
+    // tie_order = reference (see shards_scan_topk_fused): the same counters and the same "ties were seen recently" rule as one corpus'
+    int ref_hot = 0;
+    unsigned long long ref_stats[4] = {0, 0, 0, 0};   // reference-order scans | with a tie among the k+1 best | fused replays | store-mode replays
 };
 
 // ---- librccl.so, resolved at run time
@@ -214,7 +217,15 @@ static int rccl_scan_and_gather(vg_shards *s, int metric, const void *query, int
     HIP_TRY(hipSetDevice(s->devices[0]));
     HIP_TRY(hipMemcpyAsync(s->h_gather, s->d_gather[0], (size_t)s->S * VG_WAVE_KEYS * sizeof(uint64_t), hipMemcpyDeviceToHost, c0->stream));
     HIP_TRY(hipStreamSynchronize(c0->stream));                 // (every shard's keys arrived on device 0: all scans are done)
-    for (int i = 0; i < s->S; ++i) { s->sh[(size_t)i]->enqueued = false; vg_collect_timing(s->sh[(size_t)i]); }
+    for (int i = 0; i < s->S; ++i) {
+        vg_corpus *c = s->sh[(size_t)i];
+        c->enqueued = false;
+        if (c->profiling && i > 0) {                           // its own all-gather kernel (and the events behind it) may still be running
+            HIP_TRY(hipSetDevice(s->devices[(size_t)i]));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        vg_collect_timing(c);
+    }
     memcpy(out_keys, s->h_gather, (size_t)s->S * VG_WAVE_KEYS * sizeof(uint64_t));
     ++s->gather_calls[1];
     return VG_OK;
@@ -224,7 +235,10 @@ extern "C" int vg_shards_set_gather(vg_shards *s, int mode) {
     if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
     if (mode != 0 && mode != 1) return fail(VG_ERR_INVALID, "vg_shards_set_gather: 0 = host, 1 = rccl");
     s->gather_mode = mode;
-    if (mode == 1) s->rccl_failed = false;                     // (asked again explicitly: try again)
+    if (mode == 1 && s->rccl_failed) {                         // asked again explicitly: try again, with communicators of its own
+        rccl_release(s);                                       // (the ones of a failed group call may be broken)
+        s->rccl_failed = false;
+    }
     return VG_OK;
 }
 // [0] queries answered through the host gather, [1] through the RCCL all-gather; returns the mode in effect (1 only when RCCL serves)
@@ -447,6 +461,9 @@ struct ShardsSrc {
 };
 }
 
+// the store-mode replay: every shard scans again leaving all its distances resident, the host replays a prefix and asks the shards
+// for the later rows below the bound (vg_reforder.hip).  What is left for k > 64, rows too long for an emitting kernel and candidate
+// streams that overflow.
 static int shards_scan_topk_reference(vg_shards *s, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist,
                                       int *out_count) {
     int rc = VG_OK;
@@ -461,6 +478,134 @@ static int shards_scan_topk_reference(vg_shards *s, int metric, const void *quer
         out_rowids[i] = vg_shards_rowid_at(s, slots.pos[(size_t)i]);
     }
     *out_count = cnt;
+    ++s->ref_stats[3];
+    return VG_OK;
+}
+
+// The reference's slots replayed over what the shards' emitting launches left behind (vg_scan_topk_reference does the same for one
+// corpus).  Every shard ran its own prefix pass over ITS first P_i rows and emitted, behind them, every row that beats the k-th best
+// of the shard's EARLIER rows: local order is monotone in global order, so those rows precede the row globally too and the union of
+// the shards' streams is a superset of the rows that can enter the slots.  Offering a row that cannot enter is a no-op, so replaying
+// the union in GLOBAL scan order ends in exactly the reference's slots - no second scan, whatever the number of shards.
+// *overflow: a shard's stream did not fit its buffer / a shard could not emit (the caller takes the store-mode replay).
+static int shards_replay_emitted(vg_shards *s, int k, VgRefSlots &slots, bool *overflow) {
+    struct Part { const float *prefix = nullptr; int64_t P = 0; unsigned long long *pairs = nullptr; unsigned long long count = 0; };
+    std::vector<Part> parts((size_t)s->S);
+    *overflow = false;
+    for (int i = 0; i < s->S; ++i) {
+        vg_corpus *c = s->sh[(size_t)i];
+        if (c->n_rows == 0) continue;
+        if (c->ref_prefix_rows <= 0) { *overflow = true; return VG_OK; }
+        int rc = vg_ref_emitted_enqueue(c);                    // every shard's copies in flight before the first wait
+        if (rc != VG_OK) return rc;
+    }
+    struct GCand { int64_t gpos; float d; };
+    std::vector<GCand> cand;
+    int64_t max_p = 0;
+    for (int i = 0; i < s->S; ++i) {
+        vg_corpus *c = s->sh[(size_t)i];
+        if (c->n_rows == 0) continue;
+        Part &pt = parts[(size_t)i];
+        bool ovf = false;
+        int rc = vg_ref_emitted_wait(c, &pt.prefix, &pt.P, &pt.pairs, &pt.count, &ovf);
+        if (rc != VG_OK) return rc;
+        if (ovf) *overflow = true;                             // (keep draining the other shards' streams: their copies are in flight)
+        max_p = std::max(max_p, pt.P);
+    }
+    if (*overflow) return VG_OK;
+    for (int i = 0; i < s->S; ++i) {
+        const Part &pt = parts[(size_t)i];
+        for (unsigned long long j = 0; j < pt.count; ++j) {
+            const int64_t local = (int64_t)(pt.pairs[j] >> 32);
+            if (local < pt.P) continue;                        // (the main pass covers the prefix rows again)
+            const uint32_t bits = (uint32_t)pt.pairs[j];
+            float d;
+            memcpy(&d, &bits, 4);
+            cand.push_back(GCand{global_of(s, i, local), d});
+        }
+    }
+    std::sort(cand.begin(), cand.end(), [](const GCand &x, const GCand &y) { return x.gpos < y.gpos; });
+    slots.init(k);
+    // the prefixes, block by block in global order (local block lb of shard i is global block lb * S + i), the candidates in between
+    size_t ci = 0;
+    for (int64_t lb = 0; lb * s->B < max_p; ++lb)
+        for (int i = 0; i < s->S; ++i) {
+            const Part &pt = parts[(size_t)i];
+            const int64_t l0 = lb * s->B;
+            if (l0 >= pt.P) continue;
+            const int64_t len = std::min<int64_t>(s->B, pt.P - l0);
+            const int64_t g0 = global_of(s, i, l0);
+            for (; ci < cand.size() && cand[ci].gpos < g0; ++ci) slots.offer(cand[ci].d, cand[ci].gpos);
+            vg_ref_offer_run(slots, pt.prefix + l0, len, g0);
+        }
+    for (; ci < cand.size(); ++ci) slots.offer(cand[ci].d, cand[ci].gpos);
+    return VG_OK;
+}
+
+// tie_order = reference for k <= 64 over several shards, the fused form: every shard's ordinary top-k scan with one more list slot;
+// a tie among the merged k + 1 best -> the replay above.  The policy is one corpus' (vg_scan_topk_reference): scans through a filter
+// kernel always emit, plain-kernel scans only while ties are around (a first tie costs one more scan of every shard, emitting);
+// k = 64 has no 65th slot: it runs emitting with k slots and always replays.
+static int shards_scan_topk_fused(vg_shards *s, int metric, const void *query, int k, bool force_emit, int64_t *out_rowids,
+                                  double *out_dist, int *out_count) {
+    ++s->ref_stats[0];
+    const bool always = (k == VG_WAVE_KEYS);
+    const int kk = always ? k : k + 1;
+    vg_corpus *probe = nullptr;
+    for (auto *c : s->sh) if (c->n_rows > 0) { probe = c; break; }
+    bool emit = force_emit || always || s->ref_hot > 0 || (probe && vg_scan_filter_would_serve(probe, metric, kk));
+    std::vector<uint64_t> keys((size_t)s->S * VG_WAVE_KEYS);
+    std::vector<int> counts((size_t)s->S, VG_WAVE_KEYS);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int rc = -1;
+        if (!emit && s->gather_mode == 1 && rccl_ready(s)) {      // (an emitting scan leaves more than 64 keys behind: host gather)
+            rc = rccl_scan_and_gather(s, metric, query, kk, keys.data());
+            if (rc != VG_OK) s->rccl_failed = true;
+        }
+        if (rc != VG_OK) {
+            rc = VG_OK;
+            for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue_plan(s->sh[(size_t)i], metric, query, kk, emit);
+            for (int i = 0; i < s->S; ++i) {
+                int rc2 = vg_scan_topk_collect(s->sh[(size_t)i], &keys[(size_t)i * VG_WAVE_KEYS]);
+                if (rc == VG_OK) rc = rc2;
+            }
+            if (rc != VG_OK) return rc;
+            ++s->gather_calls[0];
+        }
+        if (!always) {
+            const int got = merge_lists(s, keys.data(), VG_WAVE_KEYS, counts.data(), kk, out_rowids, out_dist, k);
+            if (got >= 0) {
+                *out_count = got;
+                if (s->ref_hot > 0) --s->ref_hot;
+                return VG_OK;
+            }
+            s->ref_hot = 16;
+        }
+        if (attempt == 0) ++s->ref_stats[1];
+        if (emit) {
+            VgRefSlots slots;
+            bool overflow = false;
+            rc = shards_replay_emitted(s, k, slots, &overflow);
+            if (rc != VG_OK) return rc;
+            if (overflow) break;
+            const int n = slots.finish();
+            for (int i = 0; i < n; ++i) {
+                out_dist[i] = slots.dist[(size_t)i];
+                out_rowids[i] = vg_shards_rowid_at(s, slots.pos[(size_t)i]);
+            }
+            *out_count = n;
+            ++s->ref_stats[2];
+            return VG_OK;
+        }
+        emit = true;                                               // a tie and nothing emitted: scan again, emitting
+    }
+    return shards_scan_topk_reference(s, metric, query, k, out_rowids, out_dist, out_count);
+}
+
+extern "C" int vg_shards_tie_stats(const vg_shards *s, unsigned long long *out4) {
+    if (!s || !out4) return fail(VG_ERR_INVALID, "vg_shards_tie_stats: NULL argument");
+    if (s->S == 1) return vg_corpus_tie_stats(s->sh[0], out4);
+    for (int i = 0; i < 4; ++i) out4[i] = s->ref_stats[i];
     return VG_OK;
 }
 
@@ -472,21 +617,20 @@ extern "C" int vg_shards_scan_topk(vg_shards *s, int metric, const void *query, 
     if (k <= 0 || s->n_rows == 0) return VG_OK;
     if (!out_rowids || !out_dist) return fail(VG_ERR_INVALID, "vg_shards_scan_topk: NULL output");
     const bool ref = s->tie_order == VG_TIE_REFERENCE;
-    if (ref && k + 1 > VG_WAVE_KEYS) return shards_scan_topk_reference(s, metric, query, k, out_rowids, out_dist, out_count);
+    if (ref && k > VG_WAVE_KEYS) { ++s->ref_stats[0]; return shards_scan_topk_reference(s, metric, query, k, out_rowids, out_dist, out_count); }
+    if (ref) return shards_scan_topk_fused(s, metric, query, k, false, out_rowids, out_dist, out_count);
     if (k <= VG_WAVE_KEYS) {
-        // every shard in flight before the first wait: S scans run concurrently, one host thread.  tie_order = reference: one more
-        // list slot; only a tie among the k + 1 best sends the query to the replay (vg_scan_topk_reference explains why)
-        const int kk = ref ? k + 1 : k;
+        // every shard in flight before the first wait: S scans run concurrently, one host thread
         std::vector<uint64_t> keys((size_t)s->S * VG_WAVE_KEYS);
         std::vector<int> counts((size_t)s->S, VG_WAVE_KEYS);
         int rc = -1;
         if (s->gather_mode == 1 && rccl_ready(s)) {
-            rc = rccl_scan_and_gather(s, metric, query, kk, keys.data());
+            rc = rccl_scan_and_gather(s, metric, query, k, keys.data());
             if (rc != VG_OK) s->rccl_failed = true;            // (the host gather serves this query and the ones after it)
         }
         if (rc != VG_OK) {
             rc = VG_OK;
-            for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue(s->sh[(size_t)i], metric, query, kk);
+            for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue(s->sh[(size_t)i], metric, query, k);
             for (int i = 0; i < s->S; ++i) {
                 int rc2 = vg_scan_topk_collect(s->sh[(size_t)i], &keys[(size_t)i * VG_WAVE_KEYS]);
                 if (rc == VG_OK) rc = rc2;
@@ -494,9 +638,7 @@ extern "C" int vg_shards_scan_topk(vg_shards *s, int metric, const void *query, 
             if (rc != VG_OK) return rc;
             ++s->gather_calls[0];
         }
-        const int got = merge_lists(s, keys.data(), VG_WAVE_KEYS, counts.data(), kk, out_rowids, out_dist, ref ? k : -1);
-        if (got < 0) return shards_scan_topk_reference(s, metric, query, k, out_rowids, out_dist, out_count);
-        *out_count = got;
+        *out_count = merge_lists(s, keys.data(), VG_WAVE_KEYS, counts.data(), k, out_rowids, out_dist);
         return VG_OK;
     }
     const int kk = (int)std::min<int64_t>((int64_t)k, s->n_rows);
@@ -518,8 +660,26 @@ extern "C" int vg_shards_scan_topk_batch(vg_shards *s, int metric, const void *q
     for (int i = 0; i < nq; ++i) out_counts[i] = 0;
     if (k <= 0 || s->n_rows == 0) return VG_OK;
     if (!out_rowids || !out_dist) return fail(VG_ERR_INVALID, "vg_shards_scan_topk_batch: NULL output");
-    const bool ref = s->tie_order == VG_TIE_REFERENCE;      // (one more list slot; only the queries with a tie are replayed one by one)
+    const bool ref = s->tie_order == VG_TIE_REFERENCE;      // (one more list slot; only the queries with a tie are answered again, one by one)
     const size_t qbytes = (size_t)s->dim * s->es;
+    if (ref && k >= VG_WAVE_KEYS) {                          // no slot to look for a tie with: every query through the single-query form
+        for (int q = 0; q < nq; ++q) {
+            int rc1 = vg_shards_scan_topk(s, metric, (const uint8_t *)queries + (size_t)q * qbytes, k, out_rowids + (size_t)q * k,
+                                          out_dist + (size_t)q * k, &out_counts[q]);
+            if (rc1 != VG_OK) return rc1;
+        }
+        return VG_OK;
+    }
+    // f32 rows on the f32 matrix cores sum in another order than the single scans the reference order is defined on: a tie under the
+    // single scan's arithmetic could go unnoticed in the batch's keys - such batches are answered query by query
+    if (ref && s->vtype == VG_TYPE_F32 && !vg_batch_keys_are_scan_exact(s->sh[0], metric, k + 1)) {
+        for (int q = 0; q < nq; ++q) {
+            int rc1 = shards_scan_topk_fused(s, metric, (const uint8_t *)queries + (size_t)q * qbytes, k, false, out_rowids + (size_t)q * k,
+                                             out_dist + (size_t)q * k, &out_counts[q]);
+            if (rc1 != VG_OK) return rc1;
+        }
+        return VG_OK;
+    }
     const int kk = (int)std::min<int64_t>((int64_t)k + (ref ? 1 : 0), s->n_rows);
     std::vector<uint64_t> keys((size_t)s->S * nq * kk);
     std::vector<int> counts((size_t)s->S * nq, 0);
@@ -535,9 +695,9 @@ extern "C" int vg_shards_scan_topk_batch(vg_shards *s, int metric, const void *q
             qcounts[(size_t)i] = counts[(size_t)i * nq + q];
         }
         int got = merge_lists(s, qkeys.data(), kk, qcounts.data(), kk, out_rowids + (size_t)q * k, out_dist + (size_t)q * k, ref ? k : -1);
-        if (got < 0) {
-            int rc1 = shards_scan_topk_reference(s, metric, (const uint8_t *)queries + (size_t)q * qbytes, k, out_rowids + (size_t)q * k,
-                                                 out_dist + (size_t)q * k, &got);
+        if (got < 0) {                                       // a tie: this query again through the emitting scans + the replay
+            int rc1 = shards_scan_topk_fused(s, metric, (const uint8_t *)queries + (size_t)q * qbytes, k, true, out_rowids + (size_t)q * k,
+                                             out_dist + (size_t)q * k, &got);
             if (rc1 != VG_OK) return rc1;
         }
         out_counts[q] = got;

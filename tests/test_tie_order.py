@@ -111,6 +111,11 @@ def test_reference_tie_order_on_device_equals_the_reference(pkg, orc, vt):
                 s_ids, s_d = sh.scan_topk(metric, q, k)
                 assert s_ids.tolist() == want_ids.tolist(), ("shards", vt, dim, n, metric, k)
                 assert np.array_equal(s_d, want_d)
+        # only k > 64 (no fused list that long) may take the store-mode replay - one corpus and three shards alike, small corpora
+        # (the whole corpus is the replay's prefix) and k = 64 (always replayed from what the scan emitted) included
+        for st in (c.tie_stats(), sh.tie_stats()):
+            assert st["store_mode_replays"] == 2 * len(dg.ALL_METRICS), (vt, dim, n, st)
+            assert st["fused_replays"] >= len(dg.ALL_METRICS), (vt, dim, n, st)      # (k = 64 alone replays once per metric)
         # batches in this mode are one replayed scan per query
         qs = rows[rng.integers(0, n, 5)].copy()
         bi, bd, bc = c.scan_topk_batch(dg.L2, qs, 20)

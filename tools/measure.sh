@@ -37,6 +37,15 @@ for step in "$@"; do
     matrix)   ( echo "# default path"; python tools/tools_kernel_matrix.py --rows 10000000 --dims 384 --types 1,2,3 --filter -1
                 echo "# filter off (plain kernels)"; python tools/tools_kernel_matrix.py --rows 10000000 --dims 384 --types 1,2,3,4,5 --filter 0 ) 2>&1 | grep -v amdgpu.ids > "$OUT/kernel_matrix.txt"; cut -c1-300 "$OUT/kernel_matrix.txt" ;;
     stage)    timeout 600 python bench.py --workload stage 2> "$OUT/bench_stage.err" | tail -1 > "$OUT/bench_stage.json"; cut -c1-2500 "$OUT/bench_stage.json" ;;
+    tlb)      # the plain f32 scan at 10M vs 100M rows: kernel time per batch order, then the translation / wait counters of the same dispatches
+              rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
+              for n in 10000000 100000000; do timeout 600 python tools/scan_size_probe.py --rows $n --orders 0,1,0,1 2>/dev/null | grep '^{'; done > "$OUT/scan_size_orders.jsonl"; cat "$OUT/scan_size_orders.jsonl"
+              cd /tmp
+              for n in 10000000 100000000; do for set in "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum" $VG_PMC_EXTRA_SETS; do
+                  tagc=$(echo $set | cut -d' ' -f1)
+                  timeout 600 rocprofv3 --pmc $set --kernel-trace -f csv -d "$OUT/tlb/n${n}_$tagc" -o run -- python "$REPO/tools/scan_size_probe.py" --rows $n --scans 4 --orders 0,1 > /dev/null 2> "$OUT/tlb_n${n}_$tagc.err" || echo "pmc set failed: $set"
+              done; done
+              cd "$REPO"; python tools/summarize_pmc_dir.py "$OUT/tlb" > "$OUT/tlb_summary.txt" 2>&1; cat "$OUT/tlb_summary.txt" ;;
     shards)   timeout 600 python tools/shards_gather_bench.py 2> "$OUT/shards_gather.err" | grep '^{' > "$OUT/shards_gather.json"; cat "$OUT/shards_gather.json" ;;
     probe)    hipcc --offload-arch=gfx950 -O3 tools/valu_probe.hip -o /tmp/valu_probe 2>/dev/null && /tmp/valu_probe > "$OUT/valu_probe.txt" 2>&1; grep "waves/CU  4" "$OUT/valu_probe.txt" ;;
     *)        echo "unknown step $step" ;;
