@@ -36,7 +36,10 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
                                  const uint8_t *dev_xrows, long long xstride_bytes,
                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
                                  const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
-                                 uint64_t *dev_out_keys, unsigned long long *dev_evals, int waves, hipStream_t stream);
+                                 uint64_t *dev_out_keys, unsigned long long *dev_evals, int waves,
+                                 uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, hipStream_t stream);
+extern "C" int vg_batch_h_split(long long stride_bytes, int k);        // vg_batch_h.hip: the split form is on for such rows
+#define VG_BPAIR_CAP 2048               // candidate pairs per filter wavefront and stage (a batch that overflows one falls back to the fused kernel)
 extern "C" int vg_tile_major_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, uint8_t *dev_out, hipStream_t stream);
 extern "C" int vg_f32_to_bf16_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int dim,
                                      uint8_t *dev_out, long long ostride, hipStream_t stream);
@@ -210,7 +213,13 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     const long long fstride = f32_filter ? bf16_shadow_stride(c) : c->stride;       // row stride of what the matrix core reads
     // f16 / bf16 / f32-through-bf16 batches: the kernel comes as one 8-wavefront workgroup per CU or as two of four (vg_batch_h_plan)
     int h_waves = 8, h_bpc = 1;
-    if (half && vg_batch_h_plan(fstride, k, nq, &h_waves, &h_bpc) != 0) return -1;
+    const bool h_split = half && vg_batch_h_split(fstride, k) != 0 && !c->bsplit_off;
+    if (half && c->bsplit_off) {                           // (a batch overflowed the split form's pair buffer: the fused kernel, 8-wavefront form)
+        h_waves = vg_batch_h_queries_per_block(fstride) / 32;
+        if (vg_batch_h_lds_bytes(fstride, k) == 0) return -1;
+    } else if (half && vg_batch_h_plan(fstride, k, nq, &h_waves, &h_bpc) != 0) return -1;
+    uint32_t split_overflow = 0;
+    bool split_used = false;
     const int QPB = quantized ? vg_batch_i8_queries_per_block(c->stride) : (half ? h_waves * 32 : 128);
     const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
     const int G = nq_pad / QPB;
@@ -277,9 +286,26 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
             if (rce != VG_OK) return rce;
             dev_evals = c->d_filter_evals + 1;
         }
+        // the split form (vg_batch_h.hip, FILTER kind): one region of VG_BPAIR_CAP candidate pairs per filter wavefront + their counts
+        uint64_t *dev_pairs = nullptr;
+        uint32_t *dev_pair_counts = nullptr;
+        const int n_regions = G * npart * h_waves;
+        if (h_split && !c->bsplit_off) {
+            const size_t need = (size_t)n_regions * VG_BPAIR_CAP * sizeof(uint64_t), needc = ((size_t)n_regions + 1) * sizeof(uint32_t);
+            if (c->bpairs_bytes < need) { if (c->d_bpairs) hipFree(c->d_bpairs); c->d_bpairs = nullptr; c->bpairs_bytes = 0;
+                                          if (hipMalloc(&c->d_bpairs, need) == hipSuccess) c->bpairs_bytes = need; else (void)hipGetLastError(); }
+            if (c->bpcount_bytes < needc) { if (c->d_bpcounts) hipFree(c->d_bpcounts); c->d_bpcounts = nullptr; c->bpcount_bytes = 0;
+                                            if (hipMalloc(&c->d_bpcounts, needc) == hipSuccess) c->bpcount_bytes = needc; else (void)hipGetLastError(); }
+            if (c->bpairs_bytes >= need && c->bpcount_bytes >= needc) { dev_pairs = c->d_bpairs; dev_pair_counts = c->d_bpcounts; }
+        }
         rc = vg_batch_h_launch(hrows, hrows_tiled, c->n_rows, fstride, c->dim,
                                f32_filter ? 2 : (c->vtype == VG_TYPE_BF16 ? 1 : 0), c->d_rows, c->stride, (const uint8_t *)c->d_bq,
-                               nq_pad, nq, k, mode, root, c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys, dev_evals, h_waves, c->stream);
+                               nq_pad, nq, k, mode, root, c->d_xnorm, c->d_bcand, npart, tiles_per_part, c->d_bkeys, dev_evals, h_waves,
+                               dev_pairs, dev_pair_counts, VG_BPAIR_CAP, c->stream);
+        if (rc == 0 && dev_pairs) {                      // a region ran full (data the filter cannot separate): the fused kernel answers
+            HIP_TRY(hipMemcpyAsync(&split_overflow, dev_pair_counts + n_regions, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            split_used = true;
+        }
         if (rc == 0 && dev_evals)
             HIP_TRY(hipMemcpyAsync(c->h_filter_evals + 1, dev_evals, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     }
@@ -294,6 +320,10 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     HIP_TRY(hipMemcpyAsync(keys.data(), c->d_bkeys, (size_t)nq * 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     vg_collect_timing(c);
+    if (split_used && split_overflow != 0) {               // the pair buffer ran full somewhere: this batch again through the fused kernel
+        c->bsplit_off = true;                              // (and the next ones: such data keeps doing that)
+        return scan_topk_batch_mfma(c, metric, queries, nq, k, out_keys, out_counts);
+    }
     if (f32_filter && f32_mfma_serves) {
         // Selectivity guard.  An exact evaluation occupies a whole wavefront (and stalls its workgroup at the tile barrier):
         // the filter pays while few pairs need one.  On data it cannot separate (rows nearly identical to each other) nearly

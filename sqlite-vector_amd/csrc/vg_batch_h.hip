@@ -46,13 +46,27 @@ typedef int vgh_i32x4 __attribute__((ext_vector_type(4)));
 #define VGH_QPW 32
 #define VGH_TILE 32
 #define VGH_MAX_K 32
-#define VGH_BPIPE 4
+#ifndef VGH_BPIPE
+#define VGH_BPIPE 4                     // B-operand ds_read_b128s in flight ahead of the MFMA that consumes them
+#endif
 #define VGH_NORM_LO 1.0e-30f            // sum x^2 outside [LO, HI] (or NaN): the filter does not judge the row / query
 #define VGH_NORM_HI 1.0e30f
 #define VGH_ACCEPT 3.0e38f
 #ifndef VGH_ABLATE
 #define VGH_ABLATE 0                    // measurement builds (wrong results): 1 = filter computed, survivors dropped; 2 = no filter
 #endif
+
+#ifndef VGH_CHAINS
+#define VGH_CHAINS 1                    // 2 (with VGH_PIPE): even and odd k steps sum into accumulators of their own.  Measured, same box, 1024 x 10M x 384
+#endif                                  // f32 through the bf16 filter: 8.19 ms against 8.05 with one chain (profiles/r6k_*): off
+#ifndef VGH_STAGGER
+#define VGH_STAGGER 1                   // FILTER kind, 8 wavefronts: the two wavefronts of a SIMD run half a tile apart (see the tile loop)
+#endif
+#ifndef VGH_PIPE
+#define VGH_PIPE 0                      // 1: the gate of tile i-1 runs in the issue gaps of tile i's MFMA chain.  Measured 8.05 ms against 7.95 without
+                                        // (same box, profiles/r6k_*): the 16 register copies it needs cost what the gate it hides costs
+#endif
+static __device__ __attribute__((aligned(16))) uint32_t vgh_zero_chunk[4] = {0u, 0u, 0u, 0u};   // where a lane with nothing to load points its load
 
 enum { VGH_DOT = 0, VGH_COS = 1, VGH_L2 = 2 };
 
@@ -96,6 +110,13 @@ struct BatchArgsH {
     const uint64_t *init_keys;
     int seed;                 // staged real passes (vg_batch_common.h): partition 0 starts its lists from init_keys
     unsigned long long *evals;   // exact evaluations of the real passes (one atomic per wavefront; the host's selectivity guard), or NULL
+    // ---- the split form (KIND = FILTER + vg_batch_hx_kernel): every wavefront of the filter kernel owns one REGION of pair_cap pairs,
+    // region = ((g * npart_total + part_base + part) * waves + wave); a pair = (query in the wavefront's 32) << 32 | row, appended in
+    // scan order; pair_counts[region] = pairs written, pair_counts[n_regions] = overflow flag (a region was full: the host repeats
+    // the batch through the fused kernel)
+    uint64_t *pairs;
+    uint32_t *pair_counts;
+    int pair_cap, n_regions;
 };
 
 template <int OFF>
@@ -124,8 +145,19 @@ __device__ __forceinline__ vgh_f32x16 vgh_mfma(const vgh_i32x4 &a, const vgh_i32
 // BOUND = the pre-pass variant: no exact evaluation at all.  A pair that passes the filter enters its list with an UPPER
 // BOUND of its distance (the filter's own estimate plus its error bound); the k-th smallest bound of a query is then an
 // upper bound of its final k-th best distance - the start threshold of the real pass, which scans every row.
-template <int VT, int NTB, int MODE, bool BOUND, int W>
-__global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB)) ? 2 : 1) void vg_batch_h_kernel(BatchArgsH a) {
+// KIND: VGH_REAL (filter + exact evaluation + lists, all in one kernel), VGH_BOUNDK (the pre-pass above), VGH_FILTER - the filter
+// alone: pairs that pass are APPENDED to the wavefront's region of a device buffer and evaluated afterwards by vg_batch_hx_kernel.
+// Why: with the exact evaluations (an HBM round trip each, ~3500 cycles, 8 or 4 wavefronts waiting at the tile barrier) and the lists
+// gone from the streaming kernel its LDS holds a tile ring NB deep instead of 2 - and the LDS-DMA stream is what bounds this kernel:
+// ~25-29 GB/s per CU (profiles/r6b_*: 61 GB per 1024-query batch through LDS in 8.3 ms with two 4-wavefront workgroups per CU, each
+// streaming the copy for its own 128 queries).  One 8-wavefront workgroup streams a tile once for 256 queries - half the bytes - and
+// with NB - 1 tiles in flight their latency (~2000 cycles each) is covered.
+enum { VGH_REAL = 0, VGH_BOUNDK = 1, VGH_FILTER = 2 };
+#define VGH_RING_OF(NTB) ((NTB) <= 16 ? 6 : (NTB) <= 24 ? 5 : (NTB) <= 32 ? 4 : (NTB) <= 48 ? 3 : 2)
+template <int VT, int NTB, int MODE, int KIND, int W>
+__global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB) && KIND != VGH_FILTER) ? 2 : 1) void vg_batch_h_kernel(BatchArgsH a) {
+    constexpr bool BOUND = (KIND == VGH_BOUNDK), FILT = (KIND == VGH_FILTER);
+    constexpr int NB = FILT ? VGH_RING_OF(NTB) : 2;                     // tile buffers in LDS (NB - 1 tiles in flight)
     constexpr int WAVES = W, THREADS = 64 * WAVES, QPB = WAVES * VGH_QPW;
     constexpr int XU = ((NTB <= 32) ? 1 : 2) * (VT == T_F32 ? 2 : 1);    // 16-byte chunks per lane in the exact evaluation
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);
@@ -139,11 +171,11 @@ __global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB)) ? 2 : 1) void v
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int TILE_BYTES = NTB * 2 * 512;                           // chunk column c of the 32 rows at c * 512 + row * 16
     uint8_t *tile0 = smem;
-    float *rstat_lds = reinterpret_cast<float *>(smem + 2 * TILE_BYTES);                 // [2 slots][4 tiles][32]: sum x^2
+    float *rstat_lds = reinterpret_cast<float *>(smem + NB * TILE_BYTES);                // [2 slots][4 tiles][32]: sum x^2
     double *qq_lds = reinterpret_cast<double *>(rstat_lds + 2 * 128);                    // [waves][32]: sum q^2 (f64)
     uint32_t *qsp_lds = reinterpret_cast<uint32_t *>(qq_lds + WAVES * VGH_QPW);       // [waves][32]: query holds Inf / NaN
     float *thr_lds = reinterpret_cast<float *>(qsp_lds + WAVES * VGH_QPW);            // [waves][32]: k-th best so far
-    uint64_t *lists = reinterpret_cast<uint64_t *>(thr_lds + WAVES * VGH_QPW);        // [waves][32][k]
+    uint64_t *lists = reinterpret_cast<uint64_t *>(thr_lds + WAVES * VGH_QPW);        // [waves][32][k]  (not in the FILTER kind)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -220,12 +252,12 @@ __global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB)) ? 2 : 1) void v
         if (q0 + lane >= a.nq_real) t = -INFINITY;
         thr_w[lane] = t;
     }
-    {
+    if constexpr (!FILT) {
         const bool seeded = a.seed != 0 && part == 0;                  // (exact keys of rows no later stage meets again)
         for (int s = lane; s < VGH_QPW * k; s += 64)
             wave_lists[s] = seeded ? a.init_keys[(long long)(q0 + s / k) * 64 + s % k] : VG_EMPTY_KEY;
     }
-    for (int s = tid; s < 2 * TILE_BYTES / 4; s += THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = 0u;   // pad columns
+    for (int s = tid; s < NB * TILE_BYTES / 4; s += THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = 0u;   // pad columns
     __syncthreads();
 
     // ---- tile streaming by LDS-DMA (vg_batch_i8.hip): piece p = chunk columns 2p, 2p+1 of all 32 rows
@@ -240,7 +272,10 @@ __global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB)) ? 2 : 1) void v
     // of them share one M0 set-up (the instruction offset moves the global and the LDS address alike); from a row-major
     // corpus (the bf16 shadow of an f32 corpus, which the single-query filter scan reads by rows) every lane gathers its
     // 16 bytes of row (l & 31) and a piece is one instruction.
-    constexpr int NISSUE_T = WAVES == 8 ? 4 : WAVES;                // issuing wavefronts on the tile-major copy ...
+#ifndef VGH_FILTER_ISSUERS
+#define VGH_FILTER_ISSUERS 8            // (every wavefront issues its share of a tile's DMA pieces: 8.50 -> 8.33 ms against four issuers)
+#endif
+    constexpr int NISSUE_T = WAVES == 8 ? (FILT ? VGH_FILTER_ISSUERS : 4) : WAVES;   // issuing wavefronts on the tile-major copy ...
     constexpr int NPIECE = (NTB + NISSUE_T - 1) / NISSUE_T;
     // ... while a row-major gather (measured: 10.5 vs 10.0 ms from four wavefronts) stays spread over all of them
     const int nissue = a.tiled != 0 ? NISSUE_T : WAVES, np_mine = a.tiled != 0 ? NPIECE : (NTB + WAVES - 1) / WAVES;
@@ -365,18 +400,37 @@ __global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB)) ? 2 : 1) void v
         }
     };
     vgb_static_for<0, 16>([&](auto rc) { set_gate(rc); });
+    // The tile boundary's FIRST test uses one multiplier for the lane's 16 registers - the largest: lane_term >= 0, so
+    //     max_r (acc[r] + gmul[r] * lane_term)  <=  max_r acc[r] + gmax * lane_term
+    // and a tile none of whose pairs can pass is recognised with 16 max operations (8 v_max3) and one fused multiply-add instead of 16
+    // of each; the per-register test behind it (rare: a few per cent of the tiles) stays exact.  Queries' multipliers differ by their
+    // norms only (dot: c |q|; cosine: threshold and norm; L2: all -1), so the looser test lets few more tiles through.
+    float gmax = -VGH_ACCEPT;
+    auto refresh_gmax = [&]() __attribute__((always_inline)) {
+        gmax = gmul[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) gmax = fmaxf(gmax, gmul[r]);
+    };
+    refresh_gmax();
 
     // ---- the exact distance of ONE (query, row) pair, by the whole wavefront (wave-uniform arguments): lane c takes
     // chunk c of the row - the single-query kernel with 64 lanes per row and one chunk per lane
-    auto exact_distance = [&](int qi_u, uint32_t row_u, float nn_u) __attribute__((always_inline)) -> float {
+    // (two halves: the loads - unconditional, lanes with nothing to load point at 16 zero bytes - and the arithmetic over what they
+    // brought; the deferred form issues the loads one tile before it does the arithmetic)
+    auto exact_loads = [&](bool really, int qi_u, uint32_t row_u, uint4 (&qv)[XU], uint4 (&xv)[XU]) __attribute__((always_inline)) {
         const uint8_t *qp = a.xqueries + (long long)(q0 + qi_u) * a.xstride;
         const uint8_t *xp = a.xrows + (unsigned long long)row_u * (unsigned long long)a.xstride;
-        uint4 qv[XU], xv[XU];
+        const uint8_t *zp = reinterpret_cast<const uint8_t *>(vgh_zero_chunk);
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
-            qv[u] = make_uint4(0u, 0u, 0u, 0u); xv[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (lane + 64 * u < xchunks) { qv[u] = reinterpret_cast<const uint4 *>(qp)[lane + 64 * u]; xv[u] = reinterpret_cast<const uint4 *>(xp)[lane + 64 * u]; }
+            const bool in = really && (lane + 64 * u < xchunks);
+            qv[u] = *reinterpret_cast<const uint4 *>(in ? qp + (long long)(lane + 64 * u) * 16 : zp);
+            xv[u] = *reinterpret_cast<const uint4 *>(in ? xp + (long long)(lane + 64 * u) * 16 : zp);
         }
+    };
+    auto exact_finish = [&](int qi_u, uint32_t row_u, float nn_u, const uint4 (&qv)[XU], const uint4 (&xv)[XU]) __attribute__((always_inline)) -> float {
+        const uint8_t *qp = a.xqueries + (long long)(q0 + qi_u) * a.xstride;
+        const uint8_t *xp = a.xrows + (unsigned long long)row_u * (unsigned long long)a.xstride;
         typename Exact::QStat qs;
         if constexpr (XF32) qs.qq = (float)qq_w[qi_u];
         else { qs.qq = qq_w[qi_u]; qs.qspecial = qsp_w[qi_u]; }
@@ -397,11 +451,29 @@ __global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB)) ? 2 : 1) void v
         }
         return vg_clamp(d);
     };
+    auto exact_distance = [&](int qi_u, uint32_t row_u, float nn_u) __attribute__((always_inline)) -> float {
+        uint4 qv[XU], xv[XU];
+        exact_loads(true, qi_u, row_u, qv, xv);
+        return exact_finish(qi_u, row_u, nn_u, qv, xv);
+    };
     bool bound_changed = false;
     unsigned n_exact = 0;                                // exact evaluations of this wavefront (wave-uniform)
 #if VGH_TIMING
     unsigned long long tk_cnt = 0, tk_regs = 0, tk_entries = 0, tk_exact = 0, tk_offer = 0, tk_phase = 0, tk_pairs = 0;
 #endif
+    // an exact distance offered to its query's list; a list that changes refreshes the filter gate of register r_u in the lanes
+    // (half hh) that hold the query (r_u is wave-uniform but not a constant here: the deferred pair brings its own)
+    auto offer = [&](float de, int qi_u, uint32_t row_u, int hh, int r_u) __attribute__((always_inline)) {
+        const float thr_u = thr_w[qi_u];
+        // strict: rows arrive in scan order, a row that only ties the k-th best has the larger position and loses
+        if (!(de < thr_u)) return;
+        uint64_t *list = wave_lists + qi_u * k;
+        const float nt = vgb_kth_distance(vgb_list_insert(list, k, lane, vg_make_key(de, row_u)));
+        if (nt < thr_u) {                                         // never loosens (a pre-pass bound outlives a not-yet-full list)
+            if (lane == 0) thr_w[qi_u] = nt;
+            if (h == hh) { vgb_static_for<0, 16>([&](auto rc) { if (r_u == decltype(rc)::value) set_gate(rc); }); refresh_gmax(); }
+        }
+    };
     // slow path: the pairs of register r that passed the filter
     auto reg_insert = [&](auto rc, float acc_r, long long row, float lane_term, bool force, float nn_row) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
@@ -441,42 +513,27 @@ __global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB)) ? 2 : 1) void v
             }
             return;
         }
-        const bool pass = (row < a.n_rows) && (q0 + q_lo + 4 * h < a.nq_real) && (force || fmaf(gmul[r], lane_term, acc_r) >= 0.0f);
-        unsigned long long m = __ballot(pass);
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int hh = src >> 5, qi_u = q_lo + 4 * hh;
-            const uint32_t row_u = (uint32_t)__builtin_amdgcn_readlane((int)row, src);
-            const float nn_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nn_row), src));
-            const float thr_u = thr_w[qi_u];
-            ++n_exact;
-            // every lane holds the same value (butterfly sums): say so, or the branch below counts as divergent
-            VGH_TICK(te0);
-            const float de = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, exact_distance(qi_u, row_u, nn_u))));
-#if VGH_TIMING
-            tk_cnt += 1ull << 32;
-            const unsigned long long te1 = __builtin_readcyclecounter();
-            tk_exact += te1 - te0; tk_pairs += 1;
-#endif
-            // strict: rows arrive in scan order, a row that only ties the k-th best has the larger position and loses
-            if (!(de < thr_u)) continue;
-            uint64_t *list = wave_lists + qi_u * k;
-            const float nt = vgb_kth_distance(vgb_list_insert(list, k, lane, vg_make_key(de, row_u)));
-            if (nt < thr_u) {                                     // never loosens (a pre-pass bound outlives a not-yet-full list)
-                if (lane == 0) thr_w[qi_u] = nt;
-                if (h == hh) set_gate(rc);
-            }
-        }
     };
 
     if (tile_first < tile_last) {
-        const uint32_t goff0 = lane_offset(tile_first);
-        vgb_static_for<0, NRUN>([&](auto rc) { dma_share(tile_first, goff0, 0, rc); });
+        vgb_static_for<0, NB - 1>([&](auto jc) {                     // tiles first .. first + NB - 2 into buffers 0 .. NB - 2
+            constexpr int j = decltype(jc)::value;
+            const long long tj = min(tile_first + j, tile_last - 1);
+            const uint32_t goffj = lane_offset(tj);
+            vgb_static_for<0, NRUN>([&](auto rc) { dma_share(tj, goffj, j, rc); });
+        });
         if (wave == 0) dma_stat_group(tile_first, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // an issuing wavefront that moves exactly NPIECE whole pieces per tile (the tile-major copy, its share full) may leave the pieces
+    // of the NB - 2 youngest tiles in flight at a tile's end: loads return in order, so "at most (NB - 2) * NPIECE outstanding" means
+    // the next tile's have landed.  Every other wavefront waits for everything it has issued.
+    const bool counted_wait = NB > 2 && all_full;
+    // FILTER kind: this wavefront's region of the pair buffer
+    const long long region = FILT ? ((long long)(g * a.npart_total + a.part_base + part) * WAVES + wave) : 0;
+    uint64_t *my_pairs = FILT ? a.pairs + region * a.pair_cap : nullptr;
+    unsigned n_pairs = 0;                                            // (wave-uniform)
 
     constexpr int BP = VGH_BPIPE < NTB ? VGH_BPIPE : NTB;
     vgh_i32x4 bq[BP];
@@ -484,18 +541,42 @@ __global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB)) ? 2 : 1) void v
     unsigned long long tk_loop = 0, tk_gate = 0, tk_surv = 0, tk_dma = 0, tk_bar = 0;
     const unsigned long long tk_begin = __builtin_readcyclecounter();
 #endif
-    for (long long tile = tile_first; tile < tile_last; ++tile) {
+    // PIPE (real passes): the gate of tile i-1 - one fused multiply-add + max per accumulator register - is spread over the issue
+    // gaps of tile i's MFMA chain (its own accumulators are long complete: no wait for the chain to drain, no VALU block between two
+    // k loops during which the SIMD's matrix pipe idles), its survivors follow that k loop.  One more trip of the loop gates the last
+    // tile (its k loop runs over a buffer that is not used).  The bound passes read s~ back out of the accumulator against the
+    // CURRENT start value and keep the tile-by-tile form.
+    constexpr bool PIPE = (VGH_PIPE != 0) && !BOUND;
+    constexpr bool STAGGER = (VGH_STAGGER != 0) && FILT && WAVES == 8;
+    constexpr int GPS = (16 + NTB - 1) / NTB;                         // gate registers per k step
+    vgh_f32x16 accp;                                                  // PIPE: the accumulators of the tile in front
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[r] = 0.0f;
+    float nn_p = 0.0f;
+    long long row_p = 0;
+    bool have_p = false;
+    const long long tile_stop = (PIPE && tile_first < tile_last) ? tile_last + 1 : tile_last;
+    for (long long tile = tile_first; tile < tile_stop; ++tile) {
         VGH_TICK(t0);
         const long long ti = tile - tile_first;
-        const int cur_buf = (int)(ti & 1);
-        const long long tile_next = min(tile + 1, tile_last - 1);
+        const int cur_buf = (int)(ti % NB), fill_buf = (int)((ti + NB - 1) % NB);
+        const long long tile_next = min(tile + NB - 1, tile_last - 1);        // the tile whose DMA this trip issues
         const uint32_t goff_next = lane_offset(tile_next);
         const bool stat_turn = ((ti + 1) & 3) == 0 && wave == (int)(((ti + 1) >> 2) & (NISSUE_T - 1));
         const long long row_cur = tile * VGH_TILE + x;
+        // the tile under the gate: this one, or (PIPE) the one in front
+        const bool force_p = !(nn_p >= VGH_NORM_LO && nn_p <= VGH_NORM_HI);
+        const float lane_term_p = force_p ? 0.0f : (L2M ? 0.5f * (1.0f - cerr) * nn_p : sqrtf(nn_p));
+        float margin = -INFINITY;
 
-        vgh_f32x16 acc;
+        // Two accumulator chains (CHAINS = 2): even k steps into acc (which starts at the gate's start values), odd ones into acc1 (zero);
+        // their sum is formed where PIPE copies the accumulators to accp anyway.  Between two MFMAs on the SAME accumulator every other
+        // instruction - the B-operand read and its wait, a DMA piece, the pipelined gate - breaks the back-to-back issue
+        // (MI355X_MICROARCH.md: +43 cycles for the first extra issue slot); with two chains the next MFMA never waits for the last one.
+        constexpr bool TWO = (VGH_CHAINS == 2) && PIPE && NTB >= 2;
+        vgh_f32x16 acc, acc1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = init_reg[r];
+        for (int r = 0; r < 16; ++r) { acc[r] = init_reg[r]; acc1[r] = 0.0f; }
         const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
         vgb_static_for<0, BP>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
@@ -506,59 +587,131 @@ __global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB)) ? 2 : 1) void v
             constexpr int in_flight_after = (NTB - 1 - t) < (BP - 1) ? (NTB - 1 - t) : (BP - 1);
             vgh_wait_lds<in_flight_after>(bq[t % BP]);
             const vgh_i32x4 b = bq[t % BP];
-            acc = vgh_mfma<FT>(areg[t], b, acc);
-            if constexpr (t + BP < NTB) vgh_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
+            if constexpr (TWO && (t & 1)) acc1 = vgh_mfma<FT>(areg[t], b, acc1);
+            else acc = vgh_mfma<FT>(areg[t], b, acc);
+            if constexpr (t + BP < NTB && VGH_ABLATE < 5) vgh_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
             // the next tile's DMA (runs of up to four pieces) over the first half of the k loop; every fourth tile one of
             // the issuing wavefronts adds the row norms of the four tiles after this one
             constexpr int NTD = (NTB + 1) / 2;
             vgb_static_for<0, NRUN>([&](auto rc) {
-                if constexpr (decltype(rc)::value * NTD / NRUN == t) dma_share(tile_next, goff_next, cur_buf ^ 1, rc);
+                if constexpr (decltype(rc)::value * NTD / NRUN == t && VGH_ABLATE < 3) dma_share(tile_next, goff_next, fill_buf, rc);
             });
             if constexpr (t == NTD) { if (stat_turn) dma_stat_group(tile + 1, (int)(((ti + 1) >> 2) & 1)); }
+            if constexpr (PIPE) {                                    // the gate of the tile in front, GPS registers per k step
+                vgb_static_for<t * GPS, ((t + 1) * GPS < 16 ? (t + 1) * GPS : 16)>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    margin = fmaxf(margin, accp[r]);
+                });
+            }
         });
         float nn_row = rstat_lds[((ti >> 2) & 1) * 128 + (ti & 3) * 32 + x];      // landed with its group of four tiles
+        // STAGGER: wavefronts 4-7 (the SECOND wavefront of every SIMD) meet the tile's barrier HERE, right behind their k loop, the
+        // first four at the end of the trip.  Past the first tile the halves therefore run half a trip apart: while one wavefront of a
+        // SIMD is in its k loop the other one gates, appends, waits for the DMA - the matrix pipe no longer idles while all eight do
+        // that together (lock step: 1240 of a tile's 3060 cycles, profiles/r6c_*).  The buffer rules hold: every wavefront has read
+        // tile i when it arrives at barrier i, and the issuing wavefronts (0-3) wait for tile i+1's pieces in front of theirs.
+        // (from a row-major corpus the second half issues DMA pieces too: they must have landed before ITS barrier)
+        if constexpr (STAGGER) {
+            if (wave >= WAVES / 2) {
+                if (counted_wait && !stat_turn) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NB - 2) * NPIECE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (VGH_ABLATE < 4) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
         if constexpr (XF32) nn_row = nn_row * nn_row;                // (the f32 corpus caches ||x||, not sum x^2)
 #if VGH_TIMING
-        asm volatile("s_nop 0" :: "v"(acc[15]));                      // the k loop's last MFMA has retired
+        if (!PIPE) asm volatile("s_nop 0" :: "v"(acc[15]));           // the k loop's last MFMA has retired
 #endif
         VGH_TICK(t1);
 
         // ---- tile boundary: one fused multiply-add + max per register, one ballot
-        const bool force = !(nn_row >= VGH_NORM_LO && nn_row <= VGH_NORM_HI);   // NaN / Inf / zero / out of range
-        const float lane_term = force ? 0.0f : (L2M ? 0.5f * (1.0f - cerr) * nn_row : sqrtf(nn_row));
-        float margin = -INFINITY;
-        vgb_static_for<0, 16>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            margin = fmaxf(margin, fmaf(gmul[r], lane_term, acc[r]));
-        });
-        unsigned pend = 0;
-        if (VGH_ABLATE != 2 && __ballot(force || margin >= 0.0f) != 0) {
+        const bool force = PIPE ? force_p : !(nn_row >= VGH_NORM_LO && nn_row <= VGH_NORM_HI);   // NaN / Inf / zero / out of range
+        const float lane_term = PIPE ? lane_term_p : (force ? 0.0f : (L2M ? 0.5f * (1.0f - cerr) * nn_row : sqrtf(nn_row)));
+        if constexpr (!PIPE) {
             vgb_static_for<0, 16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                pend |= __ballot(force || fmaf(gmul[r], lane_term, acc[r]) >= 0.0f) ? (1u << r) : 0u;
+                margin = fmaxf(margin, acc[r]);
             });
         }
-        if (VGH_ABLATE == 1) { if (pend) asm volatile("" :: "s"(pend)); pend = 0; }
+        if (VGH_ABLATE >= 2) asm volatile("" :: "v"(acc[0]), "v"(acc[15]), "v"(acc1[0]), "v"(acc1[15]));   // (measurement builds without the gate: keep the MFMA chain alive)
+        unsigned pend = 0;                                           // bound passes: registers with a passing lane; real passes: "any"
+        uint32_t mybits = 0u;                                        // real passes: bit r = this lane's pair of register r passed the filter
+        const bool gate_live = PIPE ? have_p : true;
+        const long long row_g = PIPE ? row_p : row_cur;              // the row this lane's pairs under the gate belong to
+        const float nn_g = PIPE ? nn_p : nn_row;
+        if (VGH_ABLATE < 2 && gate_live && __ballot(force || fmaf(gmax, lane_term, margin) >= 0.0f) != 0) {
+            vgb_static_for<0, 16>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                const bool pass_r = force || fmaf(gmul[r], lane_term, (PIPE ? accp[r] : acc[r])) >= 0.0f;
+                if constexpr (BOUND) pend |= __ballot(pass_r) ? (1u << r) : 0u;
+                else mybits |= pass_r ? (1u << r) : 0u;
+            });
+            if constexpr (!BOUND) {
+                if (!(row_g < a.n_rows)) mybits = 0u;
+                pend = __ballot(mybits != 0u) != 0ull ? 1u : 0u;
+            }
+        }
+        if (VGH_ABLATE == 1) { if (pend) asm volatile("" :: "s"(pend)); pend = 0; mybits = 0u; }
         VGH_TICK(t2);
 #if VGH_TIMING
         if (pend) tk_cnt += 1;
 #endif
-        if (pend) {
-            vgb_static_for<0, 16>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                if (pend & (1u << r)) reg_insert(rc, acc[r], row_cur, lane_term, force, nn_row);
-            });
-        }
         if constexpr (BOUND) {
-            if (bound_changed) { vgb_static_for<0, 16>([&](auto rc) { set_gate(rc); }); bound_changed = false; }
+            if (pend) {
+                vgb_static_for<0, 16>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if (pend & (1u << r)) reg_insert(rc, acc[r], row_cur, lane_term, force, nn_row);
+                });
+            }
+            if (bound_changed) { vgb_static_for<0, 16>([&](auto rc) { set_gate(rc); }); refresh_gmax(); bound_changed = false; }
+        } else {
+            // Real passes: ONE loop over the passing pairs, lanes ascending (a query's rows ascending: scan order) - the exact
+            // evaluation and the list insert exist once in the code instead of once per accumulator register.
+            if (pend) {
+                unsigned long long any;
+                while ((any = __ballot(mybits != 0u)) != 0ull) {
+                    const int src = __ffsll((long long)any) - 1;
+                    const uint32_t bits_u = (uint32_t)__builtin_amdgcn_readlane((int)mybits, src);
+                    const int r_u = __ffs((int)bits_u) - 1;
+                    if (lane == src) mybits &= mybits - 1u;
+                    const int hh = src >> 5, qi_u = (r_u & 3) + 8 * (r_u >> 2) + 4 * hh;
+                    if (q0 + qi_u >= a.nq_real) continue;
+                    const uint32_t row_u = (uint32_t)__builtin_amdgcn_readlane((int)row_g, src);
+                    const float nn_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, nn_g), src));
+                    ++n_exact;
+                    if constexpr (FILT) {
+                        if (n_pairs < (unsigned)a.pair_cap) { if (lane == 0) my_pairs[n_pairs] = ((uint64_t)(uint32_t)qi_u << 32) | row_u; }
+                        else if (lane == 0) a.pair_counts[a.n_regions] = 1u;     // region full: the host repeats the batch (fused kernel)
+                        ++n_pairs;
+                    } else {
+                        VGH_TICK(te0);
+                        // every lane holds the same value (butterfly sums): say so, or the branch in offer() counts as divergent
+                        const float de = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, exact_distance(qi_u, row_u, nn_u))));
+#if VGH_TIMING
+                        tk_cnt += 1ull << 32;
+                        const unsigned long long te1 = __builtin_readcyclecounter();
+                        tk_exact += te1 - te0; tk_pairs += 1;
+#endif
+                        offer(de, qi_u, row_u, hh, r_u);
+                    }
+                }
+            }
         }
         VGH_TICK(t3);
 #if VGH_TIMING
-        if (!BOUND && pend) { tk_regs += __builtin_popcount(pend); tk_entries += 1; tk_phase += t3 - t2; }
+        if (!BOUND && pend) { tk_entries += 1; tk_phase += t3 - t2; }
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (counted_wait && !stat_turn) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NB - 2) * NPIECE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the row norms it issued are its youngest load)
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accp[r] = TWO ? acc[r] + acc1[r] : acc[r];
+            nn_p = nn_row; row_p = row_cur; have_p = tile < tile_last;
+        }
         VGH_TICK(t4);
-        __syncthreads();
+        if constexpr (STAGGER) { if (wave < WAVES / 2) { asm volatile("" ::: "memory"); if (VGH_ABLATE < 4) __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } }
+        else __syncthreads();
 #if VGH_TIMING
         const unsigned long long t5 = __builtin_readcyclecounter();
         tk_loop += t1 - t0; tk_gate += t2 - t1; tk_surv += t3 - t2; tk_dma += t4 - t3; tk_bar += t5 - t4;
@@ -576,11 +729,109 @@ __global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB)) ? 2 : 1) void v
     }
 #endif
 
+    if constexpr (FILT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (no LDS-DMA of the ring may land after this workgroup's LDS is gone)
+        if (lane == 0) a.pair_counts[region] = n_pairs < (unsigned)a.pair_cap ? n_pairs : (unsigned)a.pair_cap;
+        return;
+    }
     for (int s = lane; s < VGH_QPW * 64; s += 64) {
         const int qi = s >> 6, slot = s & 63;
         a.cand[((long long)(q0 + qi) * a.npart_total + a.part_base + part) * 64 + slot] = (slot < k) ? wave_lists[qi * k + slot] : VG_EMPTY_KEY;
     }
     if (!BOUND && a.evals && lane == 0 && n_exact) atomicAdd(a.evals, (unsigned long long)n_exact);
+}
+
+// ---- the second half of the split form: the pairs the FILTER kernel let through, evaluated exactly.  One wavefront per region (the
+// filter wavefront that wrote it: 32 queries, one partition), its pairs in scan order - the same arithmetic (Accum of the single-query
+// kernel, 64 lanes per row), the same strict insertion into the same 32 sorted lists in LDS, the same output layout as the fused
+// kernel's slow path, so the lists are what that kernel would have written.  Small wavefronts (no A operand, no accumulators): a CU
+// holds dozens of them and their row fetches overlap instead of stalling a streaming workgroup one at a time.
+template <int VT, int MODE, int XU>
+__global__ __launch_bounds__(64) void vg_batch_hx_kernel(BatchArgsH a, int waves) {
+    constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2), XF32 = (VT == T_F32);
+    constexpr int ACC = COS ? (XF32 ? A_COS : A_COSN) : (L2M ? A_L2 : A_DOT);
+    typedef Accum<VT, ACC> Exact;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    double *qq_w = reinterpret_cast<double *>(smem);                     // [32] sum q^2
+    uint32_t *qsp_w = reinterpret_cast<uint32_t *>(qq_w + VGH_QPW);      // [32] query holds Inf / NaN
+    uint32_t *qhave = qsp_w + VGH_QPW;                                   // [32] the two above are valid
+    float *thr_w = reinterpret_cast<float *>(qhave + VGH_QPW);           // [32] k-th best so far
+    uint64_t *wave_lists = reinterpret_cast<uint64_t *>(thr_w + VGH_QPW);   // [32][k]
+    const int lane = threadIdx.x, k = a.k;
+    const long long region = blockIdx.x;
+    const int wave = (int)(region % waves);
+    const long long gp = region / waves;
+    const int part = (int)(gp % a.npart_total) - a.part_base, g = (int)(gp / a.npart_total);
+    if (part < 0 || part >= a.npart) return;
+    const int q0 = g * (waves * VGH_QPW) + wave * VGH_QPW;
+    const int xchunks = (int)(a.xstride / 16);
+    if (lane < VGH_QPW) {
+        float t = a.init_keys ? vgb_kth_distance(a.init_keys[(long long)(q0 + lane) * 64 + (k - 1)]) : INFINITY;
+        if (q0 + lane >= a.nq_real) t = -INFINITY;
+        thr_w[lane] = t;
+        qhave[lane] = 0u;
+    }
+    {
+        const bool seeded = a.seed != 0 && part == 0;
+        for (int s = lane; s < VGH_QPW * k; s += 64)
+            wave_lists[s] = seeded ? a.init_keys[(long long)(q0 + s / k) * 64 + s % k] : VG_EMPTY_KEY;
+    }
+    __syncthreads();
+    const unsigned n = a.pair_counts[region];
+    const uint64_t *my_pairs = a.pairs + region * a.pair_cap;
+    uint64_t pair_next = n ? my_pairs[0] : 0ull;
+    for (unsigned i = 0; i < n; ++i) {
+        const uint64_t pr = pair_next;
+        if (i + 1 < n) pair_next = my_pairs[i + 1];
+        const int qi_u = __builtin_amdgcn_readfirstlane((int)(pr >> 32));
+        const uint32_t row_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pr);
+        const uint8_t *qp = a.xqueries + (long long)(q0 + qi_u) * a.xstride;
+        const uint8_t *xp = a.xrows + (unsigned long long)row_u * (unsigned long long)a.xstride;
+        uint4 qv[XU], xv[XU];
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            qv[u] = make_uint4(0u, 0u, 0u, 0u); xv[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (lane + 64 * u < xchunks) { qv[u] = reinterpret_cast<const uint4 *>(qp)[lane + 64 * u]; xv[u] = reinterpret_cast<const uint4 *>(xp)[lane + 64 * u]; }
+        }
+        float nn_u = a.row_nn[row_u];
+        if (qhave[qi_u] == 0u) {                                         // the query's statistics, on first use (wave-uniform branch)
+            if constexpr (XF32) {
+                const typename Accum<T_F32, A_COS>::QStat st = Accum<T_F32, A_COS>::template query_stat<XU>(qv, 6);
+                if (lane == 0) { qq_w[qi_u] = (double)st.qq; qsp_w[qi_u] = 0u; qhave[qi_u] = 1u; }
+            } else {
+                const typename Accum<VT, A_COSN>::QStat st = Accum<VT, A_COSN>::template query_stat<XU>(qv, 6);
+                if (lane == 0) { qq_w[qi_u] = st.qq; qsp_w[qi_u] = st.qspecial; qhave[qi_u] = 1u; }
+            }
+            __syncthreads();                                             // (one wavefront: orders the LDS writes before the reads below)
+        }
+        typename Exact::QStat qs;
+        if constexpr (XF32) qs.qq = (float)qq_w[qi_u];
+        else { qs.qq = qq_w[qi_u]; qs.qspecial = qsp_w[qi_u]; }
+        Exact acc;
+        acc.init();
+#pragma unroll
+        for (int u = 0; u < XU; ++u) acc.chunk(qv[u], xv[u]);
+        float d;
+        if constexpr (XF32) {
+            d = acc.finish(qs, 6, a.root);
+        } else {
+            if constexpr (COS) d = acc.finish_cached_norm(qs, 6, nn_u);
+            else d = acc.finish(qs, 6, a.root);
+            if (__builtin_amdgcn_readfirstlane((int)acc.special(qs, 6)) != 0)
+                d = vg_slow_distance<VT, (COS ? A_COS : ACC)>(reinterpret_cast<const uint16_t *>(qp), reinterpret_cast<const uint16_t *>(xp), a.dim, a.root);
+        }
+        const float de = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vg_clamp(d))));
+        const float thr_u = thr_w[qi_u];
+        if (!(de < thr_u)) continue;                                     // strict: rows arrive in scan order (see the fused kernel)
+        const float nt = vgb_kth_distance(vgb_list_insert(wave_lists + qi_u * k, k, lane, vg_make_key(de, row_u)));
+        if (nt < thr_u && lane == 0) thr_w[qi_u] = nt;
+    }
+    __syncthreads();
+    for (int s = lane; s < VGH_QPW * 64; s += 64) {
+        const int qi = s >> 6, slot = s & 63;
+        a.cand[((long long)(q0 + qi) * a.npart_total + a.part_base + part) * 64 + slot] = (slot < k) ? wave_lists[qi * k + slot] : VG_EMPTY_KEY;
+    }
+    if (a.evals && lane == 0 && n) atomicAdd(a.evals, (unsigned long long)n);
 }
 
 // ---- host side
@@ -598,7 +849,7 @@ extern "C" int vgh_launch_bound_f16(const BatchArgsH *a, int ntb, int waves, int
 extern "C" int vgh_launch_bound_bf16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream);   // -DVGH_TU=4
 extern "C" int vgh_launch_bound_f32(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream);    // -DVGH_TU=5
 
-template <int VT, int NTB, int MODE, bool BOUND, int W>
+template <int VT, int NTB, int MODE, int BOUND, int W>
 static int launch_h(const BatchArgsH &a, int blocks, size_t smem, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_h_kernel<VT, NTB, MODE, BOUND, W>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -606,58 +857,108 @@ static int launch_h(const BatchArgsH &a, int blocks, size_t smem, hipStream_t st
     hipLaunchKernelGGL((vg_batch_h_kernel<VT, NTB, MODE, BOUND, W>), dim3((unsigned)blocks), dim3(64 * W), smem, stream, a);
     return (int)hipGetLastError();
 }
-template <int VT, int NTB, bool BOUND, int W>
+template <int VT, int NTB, int BOUND, int W>
 static int launch_h_mode(const BatchArgsH &a, int blocks, size_t smem, hipStream_t stream) {
     if (a.mode == VGH_COS) return launch_h<VT, NTB, VGH_COS, BOUND, W>(a, blocks, smem, stream);
     if (a.mode == VGH_L2) return launch_h<VT, NTB, VGH_L2, BOUND, W>(a, blocks, smem, stream);
     return launch_h<VT, NTB, VGH_DOT, BOUND, W>(a, blocks, smem, stream);
 }
-template <int VT, int NTB, bool BOUND>
+template <int VT, int NTB, int BOUND>
 static int launch_h_waves(const BatchArgsH &a, int waves, int blocks, size_t smem, hipStream_t stream) {
-    if constexpr (VGH_HAS_W4(NTB)) {
+    if constexpr (VGH_HAS_W4(NTB) && BOUND != VGH_FILTER) {
         if (waves == 4) return launch_h_mode<VT, NTB, BOUND, 4>(a, blocks, smem, stream);
     }
     if (waves != VGH_WAVES_OF(NTB)) return -1;
     return launch_h_mode<VT, NTB, BOUND, VGH_WAVES_OF(NTB)>(a, blocks, smem, stream);
 }
-template <int VT, bool BOUND>
+template <int VT, int BOUND>
 static int launch_h_ntb(const BatchArgsH &a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
+#ifdef VGH_ONLY_NTB                     // measurement builds: one row length only (a unit compiles in a minute instead of eight)
+    if (ntb != VGH_ONLY_NTB) return -1;
+    return launch_h_waves<VT, VGH_ONLY_NTB, BOUND>(a, waves, blocks, smem, stream);
+#else
     if (ntb == 8) return launch_h_waves<VT, 8, BOUND>(a, waves, blocks, smem, stream);
     if (ntb == 16) return launch_h_waves<VT, 16, BOUND>(a, waves, blocks, smem, stream);
     if (ntb == 24) return launch_h_waves<VT, 24, BOUND>(a, waves, blocks, smem, stream);
     if (ntb == 32) return launch_h_waves<VT, 32, BOUND>(a, waves, blocks, smem, stream);
     if (ntb == 48) return launch_h_waves<VT, 48, BOUND>(a, waves, blocks, smem, stream);
     return launch_h_waves<VT, 64, BOUND>(a, waves, blocks, smem, stream);
+#endif
 }
 
 #if VGH_TU == 1 || defined(VGH_TU_ALL)
 extern "C" int vgh_launch_real_bf16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
-    return launch_h_ntb<T_BF16, false>(*a, ntb, waves, blocks, smem, stream);
+    return launch_h_ntb<T_BF16, VGH_REAL>(*a, ntb, waves, blocks, smem, stream);
 }
 #endif
 #if VGH_TU == 2 || defined(VGH_TU_ALL)
 extern "C" int vgh_launch_bound_f16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
-    return launch_h_ntb<T_F16, true>(*a, ntb, waves, blocks, smem, stream);
+    return launch_h_ntb<T_F16, VGH_BOUNDK>(*a, ntb, waves, blocks, smem, stream);
 }
 #endif
 #if VGH_TU == 4 || defined(VGH_TU_ALL)
 extern "C" int vgh_launch_bound_bf16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
-    return launch_h_ntb<T_BF16, true>(*a, ntb, waves, blocks, smem, stream);
+    return launch_h_ntb<T_BF16, VGH_BOUNDK>(*a, ntb, waves, blocks, smem, stream);
 }
 #endif
 #if VGH_TU == 5 || defined(VGH_TU_ALL)
 extern "C" int vgh_launch_bound_f32(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
-    return launch_h_ntb<T_F32, true>(*a, ntb, waves, blocks, smem, stream);
+    return launch_h_ntb<T_F32, VGH_BOUNDK>(*a, ntb, waves, blocks, smem, stream);
 }
 #endif
 #if VGH_TU == 3 || defined(VGH_TU_ALL)
 extern "C" int vgh_launch_real_f32(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
-    return launch_h_ntb<T_F32, false>(*a, ntb, waves, blocks, smem, stream);
+    return launch_h_ntb<T_F32, VGH_REAL>(*a, ntb, waves, blocks, smem, stream);
+}
+#endif
+// the split form: the FILTER kind of the streaming kernel + the exact-evaluation kernel, one unit per element type (-DVGH_TU=6 / 7 / 8)
+template <int VT, int XU>
+static int launch_hx_mode(const BatchArgsH &a, int waves, int regions, size_t smem, hipStream_t stream) {
+    if (a.mode == VGH_COS) hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_COS, XU>), dim3((unsigned)regions), dim3(64), smem, stream, a, waves);
+    else if (a.mode == VGH_L2) hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_L2, XU>), dim3((unsigned)regions), dim3(64), smem, stream, a, waves);
+    else hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_DOT, XU>), dim3((unsigned)regions), dim3(64), smem, stream, a, waves);
+    return (int)hipGetLastError();
+}
+template <int VT>
+static int launch_hx(const BatchArgsH &a, int ntb, int waves, int regions, size_t smem, hipStream_t stream) {
+    const int xu = ((ntb <= 32) ? 1 : 2) * (VT == T_F32 ? 2 : 1);       // (the fused kernel's XU)
+    if (xu == 1) return launch_hx_mode<VT, 1>(a, waves, regions, smem, stream);
+    if (xu == 2) return launch_hx_mode<VT, 2>(a, waves, regions, smem, stream);
+    return launch_hx_mode<VT, 4>(a, waves, regions, smem, stream);
+}
+#if VGH_TU == 6 || defined(VGH_TU_ALL)
+extern "C" int vgh_launch_filter_f16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_F16, VGH_FILTER>(*a, ntb, waves, blocks, smem, stream);
+}
+extern "C" int vgh_launch_exact_f16(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream) {
+    return launch_hx<T_F16>(*a, ntb, waves, regions, smem, stream);
+}
+#endif
+#if VGH_TU == 7 || defined(VGH_TU_ALL)
+extern "C" int vgh_launch_filter_bf16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_BF16, VGH_FILTER>(*a, ntb, waves, blocks, smem, stream);
+}
+extern "C" int vgh_launch_exact_bf16(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream) {
+    return launch_hx<T_BF16>(*a, ntb, waves, regions, smem, stream);
+}
+#endif
+#if VGH_TU == 8 || defined(VGH_TU_ALL)
+extern "C" int vgh_launch_filter_f32(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
+    return launch_h_ntb<T_F32, VGH_FILTER>(*a, ntb, waves, blocks, smem, stream);
+}
+extern "C" int vgh_launch_exact_f32(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream) {
+    return launch_hx<T_F32>(*a, ntb, waves, regions, smem, stream);
 }
 #endif
 #if VGH_TU == 0
+extern "C" int vgh_launch_filter_f16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream);
+extern "C" int vgh_launch_filter_bf16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream);
+extern "C" int vgh_launch_filter_f32(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream);
+extern "C" int vgh_launch_exact_f16(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream);
+extern "C" int vgh_launch_exact_bf16(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream);
+extern "C" int vgh_launch_exact_f32(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream);
 extern "C" int vgh_launch_real_f16(const BatchArgsH *a, int ntb, int waves, int blocks, size_t smem, hipStream_t stream) {
-    return launch_h_ntb<T_F16, false>(*a, ntb, waves, blocks, smem, stream);
+    return launch_h_ntb<T_F16, VGH_REAL>(*a, ntb, waves, blocks, smem, stream);
 }
 
 extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
@@ -682,10 +983,24 @@ static size_t vgh_lds_bytes(int NTB, int k, int waves) {
 // workgroups per CU the partition count should aim at.  Two 4-wavefront workgroups per CU where that form exists (NTB <= 24), both
 // fit the CU's LDS (k <= 27 at 768-byte rows) and the batch fills at least two of them per partition (nq > 128); VG_BATCH_H_WAVES=8
 // keeps round 3's single 8-wavefront workgroup, =4 forces the new form wherever it is instantiated and fits.
+// The split form (filter kernel + exact-evaluation kernel, see the FILTER kind) serves every shape the fused kernel serves:
+// VG_BATCH_H_SPLIT=1 switches it on.
+extern "C" int vg_batch_h_split(long long stride_bytes, int k) {
+    const int NTB = vgh_ntb(stride_bytes);
+    if (!NTB || k < 1 || k > VGH_MAX_K) return 0;
+    const char *e = getenv("VG_BATCH_H_SPLIT"), *w = getenv("VG_BATCH_H_WAVES");
+    (void)w;
+    return (e && *e) ? atoi(e) != 0 : 0;                         // opt-in: the two forms measure equal (7.98 against 7.95 ms, profiles/r6k_*)
+}
 extern "C" int vg_batch_h_plan(long long stride_bytes, int k, int nq, int *waves, int *blocks_per_cu) {
     const int NTB = vgh_ntb(stride_bytes);
     if (!NTB || k < 1 || k > VGH_MAX_K) return -1;
     int w = VGH_WAVES_OF(NTB), bpc = 1;
+    if (vg_batch_h_split(stride_bytes, k)) {                     // one workgroup per CU: a tile is streamed once for all its queries
+        if (waves) *waves = w;
+        if (blocks_per_cu) *blocks_per_cu = 1;
+        return 0;
+    }
     const char *e = getenv("VG_BATCH_H_WAVES");
     const int forced = (e && *e) ? atoi(e) : 0;
     if (VGH_HAS_W4(NTB) && forced != 8 && 2 * vgh_lds_bytes(NTB, k, 4) + 4096 <= (size_t)160 * 1024 && (nq > 4 * VGH_QPW || forced == 4)) { w = 4; bpc = 2; }
@@ -797,8 +1112,10 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
                                  const uint8_t *dev_xrows, long long xstride_bytes,
                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
                                  const float *dev_row_nn, uint64_t *dev_cand, int npart, int tiles_per_part,
-                                 uint64_t *dev_out_keys, unsigned long long *dev_evals, int waves, hipStream_t stream) {
+                                 uint64_t *dev_out_keys, unsigned long long *dev_evals, int waves,
+                                 uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, hipStream_t stream) {
     const int ntb = vgh_ntb(stride_bytes);
+    const bool split = dev_pairs != nullptr && dev_pair_counts != nullptr && pair_cap > 0 && waves == VGH_WAVES_OF(ntb);
     if (!ntb || k < 1 || k > VGH_MAX_K || (waves != VGH_WAVES_OF(ntb) && !(waves == 4 && VGH_HAS_W4(ntb)))) return -1;
     const size_t smem = vgh_lds_bytes(ntb, k, waves);
     const int qpb = waves * VGH_QPW;
@@ -810,7 +1127,25 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
     a.cerr = (float)(dim + 64) * 4.76837158203125e-7f + (type_code == 2 ? 0.0078125f + 1.52587890625e-5f : 0.0f);   // (D+64) 2^-21 [+ 2u + u^2, u = 2^-8: query AND row are rounded to bf16]
     a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;
     a.mode = mode; a.root = root; a.dim = dim; a.evals = dev_evals;
+    a.pairs = dev_pairs; a.pair_counts = dev_pair_counts; a.pair_cap = pair_cap;
     const int G = nq_pad / qpb;
+    a.n_regions = G * npart * waves;
+    if (split) {
+        hipError_t e = hipMemsetAsync(dev_pair_counts + a.n_regions, 0, sizeof(uint32_t), stream);      // the overflow flag
+        if (e != hipSuccess) return (int)e;
+    }
+    const size_t smem_filter = (size_t)VGH_RING_OF(ntb) * ntb * 1024 + 1024 + (size_t)waves * VGH_QPW * (8 + 4 + 4);
+    const size_t smem_exact = (size_t)VGH_QPW * (8 + 4 + 4 + 4) + (size_t)VGH_QPW * k * 8;
+    auto launch_filter = [&](const BatchArgsH &b) -> int {
+        return type_code == 2 ? vgh_launch_filter_f32(&b, ntb, waves, G * ((npart + 7) / 8) * 8, smem_filter, stream)
+                              : (type_code == 1 ? vgh_launch_filter_bf16(&b, ntb, waves, G * ((npart + 7) / 8) * 8, smem_filter, stream)
+                                                : vgh_launch_filter_f16(&b, ntb, waves, G * ((npart + 7) / 8) * 8, smem_filter, stream));
+    };
+    auto launch_exact = [&](const BatchArgsH &b) -> int {
+        return type_code == 2 ? vgh_launch_exact_f32(&b, ntb, waves, b.n_regions, smem_exact, stream)
+                              : (type_code == 1 ? vgh_launch_exact_bf16(&b, ntb, waves, b.n_regions, smem_exact, stream)
+                                                : vgh_launch_exact_f16(&b, ntb, waves, b.n_regions, smem_exact, stream));
+    };
     const int blocks = G * ((npart + 7) / 8) * 8;
     const long long ntiles = (n_rows + VGH_TILE - 1) / VGH_TILE;
     auto launch = [&](const BatchArgsH &b, bool bound) -> int {
@@ -848,7 +1183,10 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
         a.tile_begin = bounds[s]; a.tile_end = bounds[s + 1];
         a.tiles_per_part = (int)((a.tile_end - a.tile_begin + npart - 1) / npart);
         a.seed = (s > 0) ? 1 : 0;
-        if ((rc = launch(a, false)) != 0) return rc;
+        if (split) {                                              // filter -> pairs -> exact evaluation + lists
+            if ((rc = launch_filter(a)) != 0) return rc;
+            if ((rc = launch_exact(a)) != 0) return rc;
+        } else if ((rc = launch(a, false)) != 0) return rc;
         if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, a.npart_total, npart, k, dev_out_keys, stream)) != 0) return rc;
         a.init_keys = dev_out_keys;
     }

@@ -136,6 +136,8 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->norm_ev) hipEventDestroy(c->norm_ev);
     if (c->d_bcand) hipFree(c->d_bcand);
     if (c->d_bkeys) hipFree(c->d_bkeys);
+    if (c->d_bpairs) hipFree(c->d_bpairs);
+    if (c->d_bpcounts) hipFree(c->d_bpcounts);
     for (hipEvent_t e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;

@@ -134,6 +134,10 @@ struct vg_corpus {
     void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
     uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;
     size_t bq_bytes = 0, bcand_bytes = 0, bkeys_bytes = 0;
+    uint64_t *d_bpairs = nullptr;  // half-precision batches, split form (vg_batch_h.hip): candidate pairs per filter wavefront ...
+    uint32_t *d_bpcounts = nullptr; // ... and their counts + overflow flag
+    size_t bpairs_bytes = 0, bpcount_bytes = 0;
+    bool bsplit_off = false;       // a batch overflowed a pair region: this corpus keeps the fused kernel
     int max_blocks = 0;
     int cu_count = 0;
 

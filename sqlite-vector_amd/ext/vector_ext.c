@@ -39,6 +39,7 @@ SQLITE_EXTENSION_INIT1
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 #include <strings.h>
 
@@ -74,6 +75,14 @@ static void fn_backend(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
     else sqlite3_result_text(ctx, "HIP (engine not loaded)", -1, SQLITE_STATIC);
 }
 
+/* vector_gpu_stats(): an addition over the reference's surface - what staging into HBM has cost this process, as JSON text */
+static void fn_gpu_stats(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
+    char *js = sqlite3_mprintf("{\"stage_passes\":%lld,\"rows_staged\":%lld,\"seconds_staging\":%.6f,\"seconds_in_engine_append\":%.6f}",
+                               g_stage_stats.passes, g_stage_stats.rows, g_stage_stats.seconds, g_stage_stats.append_seconds);
+    if (!js) { sqlite3_result_error_nomem(ctx); return; }
+    sqlite3_result_text(ctx, js, -1, sqlite3_free);
+}
+
 #ifdef _WIN32
 __declspec(dllexport)
 #endif
@@ -93,6 +102,7 @@ int sqlite3_vector_init(sqlite3 *db, char **pzErrMsg, const sqlite3_api_routines
     if (rc != SQLITE_OK) return rc;
     static const struct { const char *name; int nargs; void (*fn)(sqlite3_context *, int, sqlite3_value **); } fns[] = {
         {"vector_backend", 0, fn_backend},
+        {"vector_gpu_stats", 0, fn_gpu_stats},
         {"vector_init", 3, fn_vector_init},
         {"vector_quantize", 3, fn_quantize3},
         {"vector_quantize", 2, fn_quantize2},

@@ -143,6 +143,13 @@ def test_half_batch_workgroup_form_plan(pkg, monkeypatch):
     eight otherwise (one of four for rows of 1 - 2 KiB, whose query block alone takes the register file)."""
     monkeypatch.delenv("VG_BATCH_H_WAVES", raising=False)
     plan = pkg.plan_batch_half_form
+    # the split form (VG_BATCH_H_SPLIT=1: filter kernel + exact-evaluation kernel): ONE workgroup per CU, a tile streamed once for
+    # all its queries, whatever k and the batch size (the lists do not live in the streaming kernel's LDS)
+    monkeypatch.setenv("VG_BATCH_H_SPLIT", "1")
+    assert plan(768, 20, 1024) == (8, 1) and plan(768, 32, 100) == (8, 1) and plan(64, 1, 4096) == (8, 1) and plan(1024, 20, 1024) == (8, 1)
+    assert plan(1536, 20, 1024) == (4, 1) and plan(2048, 32, 1024) == (4, 1)
+    assert plan(2049, 10, 1024) is None and plan(768, 0, 10) is None and plan(768, 33, 10) is None
+    monkeypatch.delenv("VG_BATCH_H_SPLIT")               # the default: the fused kernel's forms
     assert plan(768, 20, 1024) == (4, 2) and plan(768, 27, 1024) == (4, 2) and plan(768, 28, 1024) == (8, 1) and plan(768, 32, 300) == (8, 1)
     assert plan(768, 20, 129) == (4, 2) and plan(768, 20, 128) == (8, 1) and plan(768, 20, 1) == (8, 1)
     assert plan(512, 32, 1024) == (4, 2) and plan(256, 32, 300) == (4, 2) and plan(64, 1, 4096) == (4, 2)

@@ -610,13 +610,18 @@ def test_batch_half_workgroup_forms_agree(pkg, vt, monkeypatch):
                 qs = dg.corpus(vt, nq, dim, 9200 + dim + nq)
                 qs[0] = rows[17]
                 got = {}
-                for form in ("8", "4", ""):
-                    if form:
+                for form in ("8", "4", "", "split"):
+                    monkeypatch.delenv("VG_BATCH_H_SPLIT", raising=False)
+                    if form == "split":                            # the filter kernel + exact-evaluation kernel pair (vg_batch_h.hip, FILTER kind)
+                        monkeypatch.delenv("VG_BATCH_H_WAVES", raising=False)
+                        monkeypatch.setenv("VG_BATCH_H_SPLIT", "1")
+                    elif form:
                         monkeypatch.setenv("VG_BATCH_H_WAVES", form)
                     else:
                         monkeypatch.delenv("VG_BATCH_H_WAVES", raising=False)
                     got[form] = c.scan_topk_batch(metric, qs, k)
-                for form in ("4", ""):
+                monkeypatch.delenv("VG_BATCH_H_SPLIT", raising=False)
+                for form in ("4", "", "split"):
                     for a, b in zip(got["8"], got[form]):
                         assert np.array_equal(a, b), (dg.TYPE_NAMES[vt], dim, metric, nq, k, form)
         c.close()

@@ -19,15 +19,17 @@ def main():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--nq", type=int, default=1024)
     ap.add_argument("--metric", type=int, default=4)
-    ap.add_argument("--type", default="f16", choices=("f16", "bf16"))
+    ap.add_argument("--type", default="f16", choices=("f16", "bf16", "f32"), help="f32: an f32 corpus through the bf16 filter (VG_F32_FILTER=1)")
     args = ap.parse_args()
     import torch
     torch.cuda.init()
     import __graft_entry__ as g
     pkg = g.load_package()
     lib = pkg.lib()
-    tdt = torch.float16 if args.type == "f16" else torch.bfloat16
-    vt = pkg.F16 if args.type == "f16" else pkg.BF16
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}[args.type]
+    vt = {"f16": pkg.F16, "bf16": pkg.BF16, "f32": pkg.F32}[args.type]
+    if args.type == "f32":
+        os.environ["VG_F32_FILTER"] = "1"
     c = pkg.Corpus(vt, args.dim, capacity=args.rows)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(42)
@@ -35,10 +37,12 @@ def main():
         nr = min(1_000_000, args.rows - r0)
         t = torch.randn((nr, args.dim), generator=gen, device="cuda", dtype=torch.float32).to(tdt)
         torch.cuda.synchronize()
-        c.append_device(t.data_ptr(), nr, args.dim * 2)
+        c.append_device(t.data_ptr(), nr, args.dim * pkg.TYPE_SIZE[vt])
         del t
     rng = np.random.default_rng(44)
-    qs = torch.from_numpy(rng.standard_normal((args.nq, args.dim), dtype=np.float32)).to(tdt).view(torch.int16).numpy().view(np.uint16)
+    qs = rng.standard_normal((args.nq, args.dim), dtype=np.float32)
+    if args.type != "f32":
+        qs = torch.from_numpy(qs).to(tdt).view(torch.int16).numpy().view(np.uint16)
     c.scan_topk_batch(args.metric, qs, 20)
     out = (C.c_ulonglong * 16)()
     lib.vg_batch_h_timing(out, 1)
