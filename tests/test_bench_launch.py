@@ -26,6 +26,10 @@ def test_gpus_n_self_launches_n_ranks():
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["ms_per_step"] > 0
+    # the contract's keys, checked on a line this test produced (not on a committed file)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "data", "config"):
+        assert key in out, key
+    assert out["value"] is None and "workload" in out["config"]                  # (it measures nothing and says so)
 
 
 def test_gpus_n_refuses_without_n_devices():
