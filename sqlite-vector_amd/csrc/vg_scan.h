@@ -149,8 +149,12 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_kernel(ScanArgs a) {
     // plain double buffering such rows have 1-2 KB per wavefront in flight and sit in s_waitcnt (dim-64 uint8 rows:
     // 4.0 -> 4.9 TB/s for L2, 4.8 -> 6.2 for dot).  Measured slower for f32 short rows and for U >= 3, which keep the
     // double buffer.
-    constexpr bool RING = (U <= 2) && (VT == T_U8 || VT == T_I8);
-    constexpr int NB = !RING ? 2 : (U == 2) ? 4 : 6;
+#ifndef VG_RING_F32
+#define VG_RING_F32 0                 // > 0: f32 rows with 3 chunks per lane (the C2 / C4 shape, 40 VGPRs) run the ring with that many buffers
+#endif
+    constexpr bool RING_F32 = (VG_RING_F32 > 0) && VT == T_F32 && U == 3 && !EX;
+    constexpr bool RING = ((U <= 2) && (VT == T_U8 || VT == T_I8)) || RING_F32;
+    constexpr int NB = !RING ? 2 : RING_F32 ? (VG_RING_F32 > 2 ? VG_RING_F32 : 3) : (U == 2) ? 4 : 6;
     uint4 buf[NB][U];
     float nn[NB];
 #pragma unroll

@@ -8,7 +8,7 @@ CMD="python /root/repo/tools/tools_batch_bench.py --type $T --dim $D --nq 1024 -
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM" \
-           "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LDS_CMD_FIFO_FULL SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_MISC SQ_LDS_UNALIGNED_STALL"; do
+           "SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LDS_CMD_FIFO_FULL SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_MISC SQ_LDS_UNALIGNED_STALL" "FETCH_SIZE" "SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVES"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set -f csv -d $OUT/p$i -- $CMD > /dev/null 2>&1
 done
