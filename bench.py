@@ -572,6 +572,30 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+BATCH_KERNEL_SOURCES = ("vg_batch_h.hip", "vg_batch_common.h", "vg_batch_api.hip", "vg_accum.h", "vg_half.h")
+
+
+def batch_traffic(entry):
+    """HBM bytes per BATCH (all launches of one vg_scan_topk_batch call) from the PMC pass recorded in profiles/pmc_traffic.json under
+    `entry` - only while the batch kernels' sources are the ones that pass was made on"""
+    import hashlib
+    try:
+        h = hashlib.sha256()
+        for name in BATCH_KERNEL_SOURCES:
+            with open(os.path.join(ROOT, "sqlite-vector_amd", "csrc", name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+        now = h.hexdigest()[:16]
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            ent = json.load(f).get(entry)
+        if not ent:
+            return None, None
+        if ent.get("kernel_source_hash") != now:
+            return None, "stale: measured on batch kernel sources %s, this build is %s" % (ent.get("kernel_source_hash"), now)
+        return ent["bytes_per_batch"], ent["source"]
+    except Exception:
+        return None, None
+
+
 def pmc_traffic(kernel_name, n_rows):
     """HBM bytes per launch measured by the PMC pass committed under profiles/ (same kernel, same N) - only when that pass was
     made on THESE kernel sources (pmc_traffic.json records the source hash of its build; tools/measure.sh refreshes it).
@@ -1142,6 +1166,9 @@ def also_c5(args, pkg, torch, corpus, n_rows, k):
                     int(np.sum(np.asarray(fres[0]) != np.asarray(plain_res[0]))), int(np.asarray(fres[0]).size)),
                 "last_batch_max_rel_distance_difference": float(np.max(np.abs(d_f - d_p) / np.maximum(np.abs(d_p), 1e-30))) if d_f.shape == d_p.shape else None,
             }
+            tb, tsrc = batch_traffic("batch_h_f32_via_bf16_dot_1024q@%d" % n_rows)
+            line["filter_batch"]["traffic"] = tb                # HBM bytes per batch (PMC FETCH_SIZE pass); the tile-major bf16 copy is 7.68 GB
+            line["filter_batch"]["traffic_source"] = tsrc
         except Exception as e:
             line["filter_batch"] = {"error": repr(e)}
         finally:
