@@ -419,6 +419,8 @@ def bench_sql_dropin(args, pkg, torch):
             out["staging"] = {"rows": d["rows_staged"], "seconds_in_staging_loops": d["seconds_staging"],
                               "of_which_in_engine_append_calls": d["seconds_in_engine_append"],
                               "of_which_sqlite3_step_and_blob_copy": d["seconds_staging"] - d["seconds_in_engine_append"],
+                              "count_star_s": d.get("seconds_count_star"), "hbm_reserve_s": d.get("seconds_hbm_reserve"),
+                              "parallel_reader_passes": d.get("parallel_reader_passes"),
                               "rows_per_s": d["rows_staged"] / d["seconds_staging"] if d["seconds_staging"] > 0 else None,
                               "GB_per_s": d["rows_staged"] * dim * (1 if quantized else 4) / d["seconds_staging"] / 1e9 if d["seconds_staging"] > 0 else None}
         lat = []

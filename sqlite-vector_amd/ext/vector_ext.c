@@ -40,6 +40,7 @@ SQLITE_EXTENSION_INIT1
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
+#include <unistd.h>
 #include <string.h>
 #include <strings.h>
 
@@ -77,8 +78,9 @@ static void fn_backend(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
 
 /* vector_gpu_stats(): an addition over the reference's surface - what staging into HBM has cost this process, as JSON text */
 static void fn_gpu_stats(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
-    char *js = sqlite3_mprintf("{\"stage_passes\":%lld,\"rows_staged\":%lld,\"seconds_staging\":%.6f,\"seconds_in_engine_append\":%.6f}",
-                               g_stage_stats.passes, g_stage_stats.rows, g_stage_stats.seconds, g_stage_stats.append_seconds);
+    char *js = sqlite3_mprintf("{\"stage_passes\":%lld,\"parallel_reader_passes\":%lld,\"rows_staged\":%lld,\"seconds_staging\":%.6f,\"seconds_in_engine_append\":%.6f,\"seconds_count_star\":%.6f,\"seconds_hbm_reserve\":%.6f}",
+                               g_stage_stats.passes, g_stage_stats.parallel_passes, g_stage_stats.rows, g_stage_stats.seconds, g_stage_stats.append_seconds,
+                               g_stage_stats.count_seconds, g_stage_stats.reserve_seconds);
     if (!js) { sqlite3_result_error_nomem(ctx); return; }
     sqlite3_result_text(ctx, js, -1, sqlite3_free);
 }

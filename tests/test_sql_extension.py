@@ -962,3 +962,135 @@ def test_the_reference_recall_recipe_runs_unchanged(ext_path, orc):
         assert tot == k and recall >= 0.8, (m, tot, recall)
         if ref is not None:
             assert (m, tot) == ref.execute(RECALL_SQL, (q.tobytes(), k)).fetchone()[:2]
+
+
+@pytest.mark.gpu
+def test_parallel_staging_readers_equal_the_single_loop(ext_path, orc, tmp_path, monkeypatch):
+    """a FILE database outside a transaction is staged by several reader connections over disjoint key ranges, appended in key order
+    (vext_staging.inc): the same corpus, hence the same answers, as the single sqlite3_step loop - with gaps in the keys, NULL
+    vectors, a very uneven key distribution; a short BLOB is the same error; an open transaction and an in-memory database keep
+    the single loop."""
+    import json
+    n, dim, k = 300_000, 8, 12
+    rng = np.random.default_rng(5)
+    rows = dg.corpus(dg.F32, n, dim, 91)
+    ids = np.cumsum(rng.integers(1, 4, n)).astype(np.int64)                 # gaps
+    ids[n // 2:] += 10_000_000                                              # ... and a large hole: most key ranges are empty
+    q = dg.query(dg.F32, dim, 92)
+    path = str(tmp_path / "par.db")
+    db0 = sqlite3.connect(path, isolation_level=None)
+    db0.execute("CREATE TABLE t (id INTEGER PRIMARY KEY, v BLOB)")
+    db0.execute("BEGIN")
+    db0.executemany("INSERT INTO t(id, v) VALUES (?, ?)", [(int(ids[i]), None if i % 1000 == 7 else rows[i].tobytes()) for i in range(n)])
+    db0.execute("COMMIT")
+    db0.close()
+    live = np.array([i % 1000 != 7 for i in range(n)])
+    d = orc.scan_distances(orc.AVX2, dg.L2, dg.F32, q, rows[live])
+    want_ids, want_d, _ = orc.topk_ordered(d, ids[live], k)
+
+    def open_db(p):
+        db = sqlite3.connect(p, isolation_level=None)
+        db.enable_load_extension(True)
+        db.load_extension(ext_path)
+        db.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2')" % dim)
+        return db
+
+    def stats(db):
+        return json.loads(db.execute("SELECT vector_gpu_stats()").fetchone()[0])
+
+    sql = "SELECT rowid, distance FROM vector_full_scan('t', 'v', ?, %d)" % k
+    res = {}
+    for threads in ("1", "4"):
+        monkeypatch.setenv("VECTORGPU_STAGE_THREADS", threads)
+        db = open_db(path)
+        before = stats(db)
+        res[threads] = db.execute(sql, (q.tobytes(),)).fetchall()
+        after = stats(db)
+        assert after["rows_staged"] - before["rows_staged"] == int(live.sum())
+        assert after["parallel_reader_passes"] - before["parallel_reader_passes"] == (1 if threads == "4" else 0)
+        # an append behind the watermark taken from the parallel pass goes up as one row
+        db.execute("INSERT INTO t(id, v) VALUES (?, ?)", (int(ids[-1]) + 5, q.tobytes()))
+        got = db.execute(sql, (q.tobytes(),)).fetchall()
+        assert got[0][0] == int(ids[-1]) + 5 and got[0][1] == 0.0
+        assert stats(db)["rows_staged"] - after["rows_staged"] == 1
+        db.execute("DELETE FROM t WHERE id = ?", (int(ids[-1]) + 5,))
+        db.close()
+    assert res["1"] == res["4"]
+    assert [r[0] for r in res["4"]] == want_ids.tolist() and np.allclose([r[1] for r in res["4"]], want_d, rtol=1e-5)
+    # inside a transaction other connections cannot see this one's rows: the single loop
+    monkeypatch.setenv("VECTORGPU_STAGE_THREADS", "4")
+    db = open_db(path)
+    db.execute("BEGIN")
+    db.execute("INSERT INTO t(id, v) VALUES (1000000000, ?)", (q.tobytes(),))
+    before = stats(db)
+    got = db.execute(sql, (q.tobytes(),)).fetchall()
+    assert got[0][0] == 1000000000 and stats(db)["parallel_reader_passes"] == before["parallel_reader_passes"]
+    db.execute("ROLLBACK")
+    # a short BLOB is reported like the single loop reports it
+    db.execute("UPDATE t SET v = x'0011' WHERE id = ?", (int(ids[123456]),))
+    db.close()
+    db = open_db(path)
+    with pytest.raises(sqlite3.Error) as ei:
+        db.execute(sql, (q.tobytes(),)).fetchall()
+    assert "Invalid vector blob found at rowid %d" % int(ids[123456]) in str(ei.value)
+    db.close()
+
+
+@pytest.mark.gpu
+def test_quantize_stages_in_front_of_its_transaction_and_reserves_by_key_span(ext_path, tmp_path, monkeypatch):
+    """vector_quantize outside a transaction stages the raw column BEFORE its BEGIN (vext_quantize.inc), where the parallel
+    readers can serve it, and the pass inside the transaction accepts that copy: the rows go up once.  The HBM reservation comes
+    from the key span (two B-tree descents instead of COUNT(*)'s walk over every leaf) - with deleted keys the span is larger than
+    the table, the answers are those of the exact count (VECTORGPU_EXACT_COUNT) and of the single loop."""
+    import json
+    n, dim, k = 250_000, 16, 10
+    rows = dg.corpus(dg.F32, n, dim, 17)
+    q = dg.query(dg.F32, dim, 18)
+    path = str(tmp_path / "qpre.db")
+    db0 = sqlite3.connect(path, isolation_level=None)
+    db0.execute("CREATE TABLE t (id INTEGER PRIMARY KEY, v BLOB)")
+    db0.execute("BEGIN")
+    db0.executemany("INSERT INTO t(id, v) VALUES (?, ?)", [(i - 1000, rows[i].tobytes()) for i in range(n)])   # (negative keys too)
+    db0.execute("DELETE FROM t WHERE id % 7 = 3")
+    db0.execute("COMMIT")
+    live = int(db0.execute("SELECT COUNT(*) FROM t").fetchone()[0])
+    db0.close()
+
+    def run(threads, exact):
+        monkeypatch.setenv("VECTORGPU_STAGE_THREADS", threads)
+        if exact:
+            monkeypatch.setenv("VECTORGPU_EXACT_COUNT", "1")
+        else:
+            monkeypatch.delenv("VECTORGPU_EXACT_COUNT", raising=False)
+        db = sqlite3.connect(path, isolation_level=None)
+        db.enable_load_extension(True)
+        db.load_extension(ext_path)
+        db.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2')" % dim)
+        s0 = json.loads(db.execute("SELECT vector_gpu_stats()").fetchone()[0])
+        assert db.execute("SELECT vector_quantize('t', 'v')").fetchone()[0] == live
+        s1 = json.loads(db.execute("SELECT vector_gpu_stats()").fetchone()[0])
+        full = db.execute("SELECT rowid, distance FROM vector_full_scan('t', 'v', ?, %d)" % k, (q.tobytes(),)).fetchall()
+        s2 = json.loads(db.execute("SELECT vector_gpu_stats()").fetchone()[0])
+        quant = db.execute("SELECT rowid, distance FROM vector_quantize_scan('t', 'v', ?, %d)" % k, (q.tobytes(),)).fetchall()
+        db.close()
+        return s0, s1, s2, full, quant
+
+    s0, s1, s2, full_p, quant_p = run("4", False)
+    assert s1["parallel_reader_passes"] - s0["parallel_reader_passes"] == 1
+    assert s1["rows_staged"] - s0["rows_staged"] == live                     # once, in front of the BEGIN
+    assert s2["rows_staged"] == s1["rows_staged"]                            # the full scan behind it: the copy is still current
+    _, _, _, full_1, quant_1 = run("1", True)
+    assert full_p == full_1 and quant_p == quant_1
+    # inside a transaction vector_quantize fails like the reference's (its own BEGIN), with nothing staged in front of it
+    monkeypatch.setenv("VECTORGPU_STAGE_THREADS", "4")
+    db = sqlite3.connect(path, isolation_level=None)
+    db.enable_load_extension(True)
+    db.load_extension(ext_path)
+    db.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2')" % dim)
+    db.execute("BEGIN")
+    before = json.loads(db.execute("SELECT vector_gpu_stats()").fetchone()[0])
+    with pytest.raises(sqlite3.Error):
+        db.execute("SELECT vector_quantize('t', 'v')").fetchone()
+    assert json.loads(db.execute("SELECT vector_gpu_stats()").fetchone()[0])["rows_staged"] == before["rows_staged"]
+    assert not db.in_transaction                 # (the failure path ends with ROLLBACK, sqlite-vector.c:1450: the caller's transaction is gone)
+    db.close()
