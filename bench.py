@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - vectors scanned / second for the sqlite-vector hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b|c5h|c5f|stage] [--no-also]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b|c5h|c5f|c5l|stage|sql] [--no-also]
 
 Default line (BASELINE.json configs[1]): 10M x 384 f32, L2, top-20, single query, corpus resident in HBM, answered by
 the PLAIN f32 scan kernel (vg_scan_kernel; the shadow-copy filter is switched off for this corpus), so that
@@ -67,6 +67,9 @@ WORKLOADS = {
     # c5 answered through the bf16 filter (VG_F32_FILTER=1: bf16 shadow copy on the matrix cores, f32 exact re-evaluation of the
     # survivors) instead of the f32 MFMA kernel - same question, same f32 distances, the GEMM at the bf16 rate
     "c5f": (1, np.float32, 384, 4, "batched 1024 queries x 10Mx384 f32 dot top-20 (bf16 MFMA filter over a shadow copy + exact f32 re-evaluation + fused top-k)"),
+    # long rows (not a BASELINE config): 1536-dimensional f32 embeddings - the K dimension split over the wavefronts of
+    # a workgroup (vg_batch_hl.hip), bf16 shadow copy on the matrix cores, exact f32 re-evaluation; reported next to one scan per query
+    "c5l": (1, np.float32, 1536, 4, "batched 1024 queries x 10Mx1536 f32 dot top-20 (K-split bf16 MFMA filter over a shadow copy + exact f32 re-evaluation)"),
 }
 F16_MFMA_PEAK_TF = 2500.0      # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
@@ -205,7 +208,7 @@ def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc
     steps, warmup = min(args.steps, 10), min(args.warmup, 2)
     quantized = corpus.vtype in (pkg.U8, pkg.I8)
     half = corpus.vtype == pkg.F16
-    filt = workload == "c5f"
+    filt = workload in ("c5f", "c5l")
     if quantized:
         batches = [rng.integers(0, 256, (nq, dim)).astype(np.uint8) for _ in range(2)]
     elif half:
@@ -247,14 +250,24 @@ def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_launch, kern_ms, _ = corpus.profile_mean_ms()
+    single = None
+    if workload == "c5l" and not use_dist:               # what the batch replaces: one scan per query (the plain kernel; HBM-bound)
+        path = corpus.last_batch_path()
+        corpus.set_profiling(False)
+        t1 = time.perf_counter()
+        for i in range(8):
+            corpus.scan_topk(metric, batches[0][i], k)
+        one_ms = (time.perf_counter() - t1) / 8 * 1e3
+        single = {"batch_path": path, "one_scan_per_query_ms": one_ms, "batch_ms_per_query": elapsed / steps * 1e3 / nq,
+                  "speedup_over_single_scans": one_ms / (elapsed / steps * 1e3 / nq)}
     flops = 2.0 * nq * n_rows * dim
     tf = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
     run_batched.last_result = last.get("res")
     if rank != 0:
         return None
-    return {
+    line = {
         "metric": "vectors scanned/sec (query x vector pairs), batched %s" % ("quantized cosine top-20 over Nx768 u8" if quantized else
-                                                                              ("dot top-20 over Nx384 f16" if half else "dot top-20 over Nx384 f32")),
+                                                                              ("dot top-20 over Nx384 f16" if half else "dot top-20 over Nx%d f32" % dim)),
         "value": nq * n_rows * n_gpus * steps / elapsed, "unit": "vectors/s", "n_gpus": n_gpus, "steps": steps,
         "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8" if quantized else ("f16" if half else "f32"), "data": "synthetic",
@@ -268,6 +281,11 @@ def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc
                      "kernel_ms": kern_ms, "launches_timed": n_launch, "flops_per_launch": flops,
                      "note": "kernel_ms = pre-pass + main pass + merges of one batch on one shard" +
                              ("; peak = the bf16 MFMA rate the filter runs at" if filt else "")}}
+    if workload == "c5l":
+        line["roofline"]["kernel"] = "vg_batch_hl_kernel<%d k-steps per wavefront> + vg_batch_hx_kernel" % (((dim * 2 + 31) // 32 + 3) // 4)
+    if single is not None:
+        line["against_single_scans"] = single
+    return line
 
 
 def sql_latency(ext_path, rows, queries, k, warmup, steps):
@@ -965,7 +983,7 @@ def main():
     corpus = make_shard(pkg, torch, vt, dim, n_rows, 42 + rank, device_index)
     corpus.set_rowid_base(1 + rank * n_rows)
     corpus.set_profiling(True)
-    if args.workload in ("c5", "c3b", "c5h", "c5f"):
+    if args.workload in ("c5", "c3b", "c5h", "c5f", "c5l"):
         out = run_batched(args, pkg, torch, corpus, args.workload, n_rows, dim, metric, k, desc, the_dist, shard, n_gpus, rank,
                           share=share)
         if out is not None:

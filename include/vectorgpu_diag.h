@@ -37,6 +37,10 @@ const char *vg_scan_kernel_name(vg_corpus *c, int metric);
 int vg_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals);
 /* the same for f32 batches through the bf16 filter (vg_scan_topk_batch): (query, row) pairs evaluated exactly since the last call */
 int vg_batch_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals);
+/* which path answered this corpus' last vg_scan_topk_batch[_keys] call: 0 none yet, 1 the f32 matrix-core kernel, 2 the int8 one,
+ * 3 the half-precision kernel (f16 / bf16 rows, f32 rows through their bf16 shadow copy), 4 the long-row form of it (1025 .. 3072
+ * elements: the K dimension split over a workgroup's wavefronts), 5 the multi-query scan, 6 one scan per query */
+int vg_batch_last_path(const vg_corpus *c);
 
 /* kernel milliseconds (HIP events on the corpus stream) and rows of the corpus' last vg_corpus_minmax (which = 0) /
  * vg_corpus_quantize_rows (1) pass, and - while profiling is on - of the last int8 shadow-copy pass of the filter scans (2) */

@@ -112,6 +112,7 @@ def lib():
         "vg_shards_delete_rows": (i32, [vp, vp, i64]),
         "vg_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
         "vg_batch_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
+        "vg_batch_last_path": (i32, [vp]),
         "vg_corpus_set_scan_filter": (i32, [vp, i32]),
         "vg_corpus_set_tie_order": (i32, [vp, i32]),
         "vg_corpus_tie_order": (i32, [vp]),
@@ -300,6 +301,10 @@ class Corpus:
     def delete_rows(self, positions):
         positions = np.ascontiguousarray(positions, dtype=np.int64)
         _check(lib().vg_corpus_delete_rows(self.h, _ptr(positions), positions.shape[0]))
+
+    def last_batch_path(self):
+        """1 f32 matrix-core kernel, 2 int8, 3 half-precision kernel, 4 its long-row form, 5 multi-query scan, 6 one scan per query"""
+        return lib().vg_batch_last_path(self.h)
 
     def batch_filter_exact_evals(self):
         v = C.c_ulonglong(0)

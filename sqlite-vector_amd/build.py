@@ -20,7 +20,7 @@ LIB = os.path.join(HERE, "libvectorgpu.so")
 VEC = os.path.join(HERE, "vector.so")
 
 # (source, object, extra flags): the two kernel families with the most template instantiations are compiled as several
-# translation units from one source file each (the half-precision batch kernels: 9 units), so that a from-scratch build is bounded
+# translation units from one source file each (the half-precision batch kernels: 9 + 6 units), so that a from-scratch build is bounded
 # by the total CPU time over the cores (~30 CPU-minutes: ~4 min on 8 cores) instead of by its longest unit
 HIP_UNITS = [("vg_api.hip", "vg_api.hip.o", []), ("vg_corpus.hip", "vg_corpus.hip.o", []), ("vg_batch_api.hip", "vg_batch_api.hip.o", []),
              ("vg_select.hip", "vg_select.hip.o", []), ("vg_batch.hip", "vg_batch.hip.o", []), ("vg_quant.hip", "vg_quant.hip.o", []),
@@ -30,7 +30,8 @@ HIP_UNITS = [("vg_api.hip", "vg_api.hip.o", []), ("vg_corpus.hip", "vg_corpus.hi
              ("vg_batch_h.hip", "vg_batch_h_bound.o", ["-DVGH_TU=2"]), ("vg_batch_h.hip", "vg_batch_h_f32.o", ["-DVGH_TU=3"]),
              ("vg_batch_h.hip", "vg_batch_h_bound_bf16.o", ["-DVGH_TU=4"]), ("vg_batch_h.hip", "vg_batch_h_bound_f32.o", ["-DVGH_TU=5"]),
              ("vg_batch_h.hip", "vg_batch_h_split_f16.o", ["-DVGH_TU=6"]), ("vg_batch_h.hip", "vg_batch_h_split_bf16.o", ["-DVGH_TU=7"]),
-             ("vg_batch_h.hip", "vg_batch_h_split_f32.o", ["-DVGH_TU=8"])]
+             ("vg_batch_h.hip", "vg_batch_h_split_f32.o", ["-DVGH_TU=8"])] + \
+            [("vg_batch_hl.hip", "vg_batch_hl_%d.o" % tu, ["-DVGHL_TU=%d" % tu]) for tu in range(6)]
 HIP_SOURCES = sorted(set(u[0] for u in HIP_UNITS))
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 

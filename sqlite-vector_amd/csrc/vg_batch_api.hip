@@ -185,6 +185,134 @@ static int ensure_i8_row_stats(vg_corpus *c) {
     return VG_OK;
 }
 
+// ---- rows of 1025 .. 3072 elements (f16 / bf16 corpora; f32 corpora through their bf16 shadow copy): vg_batch_hl.hip, the K dimension
+// split over the four wavefronts of a workgroup.  Always the split form (filter kernel -> candidate pairs -> exact evaluation) and always
+// from the tile-major copy; a batch whose pairs overflow a region (data the filter cannot separate, queries with Inf / NaN) is answered by
+// the multi-query scan, and so are the next ones over this corpus.
+extern "C" int vg_batch_hl_serves(long long stride_bytes, int k);
+extern "C" int vg_batch_hl_queries_per_block(long long stride_bytes);
+extern "C" int vg_batch_hl_regions(long long stride_bytes, int nq_pad, int npart);
+extern "C" int vg_batch_hl_launch(const uint8_t *dev_rows, long long n_rows, long long stride_bytes, int dim, int type_code,
+                                  const uint8_t *dev_xrows, long long xstride_bytes,
+                                  const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
+                                  const float *dev_row_nn, uint64_t *dev_cand, int npart,
+                                  uint64_t *dev_out_keys, unsigned long long *dev_evals,
+                                  uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, hipStream_t stream);
+static long long batch_long_stride(const vg_corpus *c) { return c->vtype == VG_TYPE_F32 ? bf16_shadow_stride(c) : c->stride; }
+static bool batch_long_eligible(const vg_corpus *c, int metric, int k) {
+    if (env_int("VG_BATCH_MFMA", 1) == 0 || env_int("VG_BATCH_LONG", 1) == 0 || metric == VG_DIST_L1 || c->tm_disabled) return false;
+    if (c->vtype != VG_TYPE_F32 && c->vtype != VG_TYPE_F16 && c->vtype != VG_TYPE_BF16) return false;
+    return vg_batch_hl_serves(batch_long_stride(c), k) != 0;
+}
+
+// sum q^2 of one host query in the corpus' element type (Inf / NaN elements give Inf / NaN)
+static double host_query_norm2(const vg_corpus *c, const uint8_t *q) {
+    double s = 0.0;
+    for (int e = 0; e < c->dim; ++e) {
+        float v;
+        if (c->vtype == VG_TYPE_F32) { memcpy(&v, q + (size_t)e * 4, 4); }
+        else {
+            uint16_t hbits;
+            memcpy(&hbits, q + (size_t)e * 2, 2);
+            uint32_t w;
+            if (c->vtype == VG_TYPE_BF16) w = (uint32_t)hbits << 16;
+            else {                                             // IEEE half -> float
+                const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16, ex = (hbits >> 10) & 0x1Fu, man = hbits & 0x3FFu;
+                if (ex == 0x1Fu) w = sign | 0x7F800000u | (man << 13);
+                else if (ex != 0) w = sign | ((ex + 112u) << 23) | (man << 13);
+                else if (man == 0) w = sign;
+                else { int sh = 0; uint32_t m = man; while (!(m & 0x400u)) { m <<= 1; ++sh; } w = sign | ((113u - sh) << 23) | ((m & 0x3FFu) << 13); }
+            }
+            memcpy(&v, &w, 4);
+        }
+        s += (double)v * (double)v;
+    }
+    return s;
+}
+
+static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys, int *out_counts) {
+    const bool f32 = (c->vtype == VG_TYPE_F32);
+    const long long fstride = batch_long_stride(c);
+    const int QPB = vg_batch_hl_queries_per_block(fstride);
+    const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
+    const int G = nq_pad / QPB;
+    int npart = std::max(1, c->cu_count * std::max(1, env_int("VG_BATCH_BPC", 1)) / G);
+    if (npart >= 8) npart = (npart / 8) * 8;
+    npart = std::min(npart, 256);
+    const long long ntiles = (c->n_rows + 31) / 32;
+    npart = (int)std::min<long long>(npart, ntiles);
+    int rcn = vg_ensure_row_norms(c);
+    if (rcn != VG_OK) return rcn;
+    rcn = f32 ? ensure_bf16_tile_major(c) : ensure_half_tile_major(c);
+    if (rcn == -1) return -1;                              // (no room for the copy: the multi-query scan)
+    if (rcn != VG_OK) return rcn;
+    const size_t qbytes = (size_t)nq_pad * c->stride;
+    const size_t candbytes = (size_t)nq_pad * vg_batch_lists_per_query(c->n_rows, npart) * 64 * sizeof(uint64_t);
+    const size_t keybytes = (size_t)nq_pad * 64 * sizeof(uint64_t);
+    if (c->bq_bytes < qbytes) { if (c->d_bq) hipFree(c->d_bq); c->d_bq = nullptr; c->bq_bytes = 0;
+                                HIP_TRY(hipMalloc(&c->d_bq, qbytes)); c->bq_bytes = qbytes; }
+    if (c->bcand_bytes < candbytes) { if (c->d_bcand) hipFree(c->d_bcand); c->d_bcand = nullptr; c->bcand_bytes = 0;
+                                      HIP_TRY(hipMalloc(&c->d_bcand, candbytes)); c->bcand_bytes = candbytes; }
+    if (c->bkeys_bytes < keybytes) { if (c->d_bkeys) hipFree(c->d_bkeys); c->d_bkeys = nullptr; c->bkeys_bytes = 0;
+                                     HIP_TRY(hipMalloc(&c->d_bkeys, keybytes)); c->bkeys_bytes = keybytes; }
+    const int n_regions = vg_batch_hl_regions(fstride, nq_pad, npart);
+    const size_t need = (size_t)n_regions * VG_BPAIR_CAP * sizeof(uint64_t), needc = ((size_t)n_regions + 1) * sizeof(uint32_t);
+    if (c->bpairs_bytes < need) { if (c->d_bpairs) hipFree(c->d_bpairs); c->d_bpairs = nullptr; c->bpairs_bytes = 0;
+                                  HIP_TRY(hipMalloc(&c->d_bpairs, need)); c->bpairs_bytes = need; }
+    if (c->bpcount_bytes < needc) { if (c->d_bpcounts) hipFree(c->d_bpcounts); c->d_bpcounts = nullptr; c->bpcount_bytes = 0;
+                                    HIP_TRY(hipMalloc(&c->d_bpcounts, needc)); c->bpcount_bytes = needc; }
+    std::vector<uint8_t> hq(qbytes, 0);                       // zero-padded rows of the corpus stride, zero rows up to nq_pad
+    const size_t row_bytes = (size_t)c->dim * c->es;
+    // A query the filter cannot judge (Inf / NaN elements, a norm of zero or out of range) would send EVERY row down the exact path -
+    // in the split form that is a pair per row: such queries leave the batch (a zero row stands in, its answer is dropped) and are
+    // answered by single scans below
+    std::vector<int> unjudged;
+    for (int i = 0; i < nq; ++i) {
+        const uint8_t *q = (const uint8_t *)queries + (size_t)i * row_bytes;
+        const double n2 = host_query_norm2(c, q);
+        if (!(n2 >= 1.0e-30 && n2 <= 1.0e30)) { unjudged.push_back(i); continue; }
+        memcpy(hq.data() + (size_t)i * c->stride, q, row_bytes);
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_bq, hq.data(), qbytes, hipMemcpyHostToDevice, c->stream));
+    hipEvent_t *evs = nullptr;
+    if (c->profiling) {
+        int slot = (int)(c->prof_launches % VG_PROF_RING);
+        evs = &c->ev[(size_t)slot * VG_PROF_EVS];
+        c->ev_flags[(size_t)slot] = 0;
+        ++c->prof_launches;
+        hipEventRecord(evs[0], c->stream);
+    }
+    const int mode = metric == VG_DIST_DOT ? 0 : (metric == VG_DIST_COSINE ? 1 : 2), root = metric == VG_DIST_L2 ? 1 : 0;
+    const int rc = vg_batch_hl_launch(c->d_rows_tm, c->n_rows, fstride, c->dim, f32 ? 2 : (c->vtype == VG_TYPE_BF16 ? 1 : 0), c->d_rows, c->stride,
+                                      (const uint8_t *)c->d_bq, nq_pad, nq, k, mode, root, c->d_xnorm, c->d_bcand, npart, c->d_bkeys, nullptr,
+                                      c->d_bpairs, c->d_bpcounts, VG_BPAIR_CAP, c->stream);
+    if (evs) { hipEventRecord(evs[2], c->stream); hipEventRecord(evs[3], c->stream); }
+    if (rc == -1) { hipStreamSynchronize(c->stream); return -1; }
+    if (rc != 0) return vg_fail(VG_ERR_HIP, "batched scan launch (long rows) failed: %s", hipGetErrorString((hipError_t)rc));
+    uint32_t overflow = 0;
+    std::vector<uint64_t> keys((size_t)nq * 64);
+    HIP_TRY(hipMemcpyAsync(&overflow, c->d_bpcounts + n_regions, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(keys.data(), c->d_bkeys, (size_t)nq * 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    vg_collect_timing(c);
+    if (overflow != 0) { c->blong_cooldown = 16; return -1; }   // (rows the filter cannot separate / judge: the next batches scan)
+    for (int i = 0; i < nq; ++i) {
+        int cnt = 0;
+        for (int j = 0; j < k; ++j) {
+            const uint64_t key = keys[(size_t)i * 64 + j];
+            if (key == VG_EMPTY_KEY) break;
+            out_keys[(size_t)i * k + cnt] = key;
+            ++cnt;
+        }
+        out_counts[i] = cnt;
+    }
+    for (int i : unjudged) {
+        const int rc1 = vg_scan_topk_keys(c, metric, (const uint8_t *)queries + (size_t)i * row_bytes, k, out_keys + (size_t)i * k, out_counts + i);
+        if (rc1 != VG_OK) return rc1;
+    }
+    return VG_OK;
+}
+
 static bool batch_mfma_eligible(const vg_corpus *c, int metric, int k) {
     if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
     if (c->vtype != VG_TYPE_F32) return false;
@@ -210,6 +338,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
         else if (rcs != VG_OK) return rcs;
     }
     const bool half = (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) || f32_filter;
+    c->last_batch_half = half;
     const long long fstride = f32_filter ? bf16_shadow_stride(c) : c->stride;       // row stride of what the matrix core reads
     // f16 / bf16 / f32-through-bf16 batches: the kernel comes as one 8-wavefront workgroup per CU or as two of four (vg_batch_h_plan)
     int h_waves = 8, h_bpc = 1;
@@ -395,6 +524,18 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     // A handful of queries over a corpus the filter scans serve: single scans (0.7 ms each at 10M x 384, whatever the type) beat one
     // 128- / 256-query-wide matrix pass (~2.9 ms however few of its query slots are used) up to three queries; they tie at four.
     const bool few = nq <= env_int("VG_BATCH_MIN_QUERIES", 4) - 1 && vg_scan_filter_would_serve(c, metric, k);
+    if (!few && batch_long_eligible(c, metric, k) && c->blong_cooldown > 0) --c->blong_cooldown;
+    else if (!few && batch_long_eligible(c, metric, k)) {
+        const int slice = std::max(256, env_int("VG_BATCH_SLICE", 4096));
+        int rc = VG_OK;
+        const size_t qbytes = (size_t)c->dim * c->es;
+        for (int q0 = 0; q0 < nq && rc == VG_OK; q0 += slice) {
+            const int nqs = std::min(slice, nq - q0);
+            rc = scan_topk_batch_long(c, metric, (const uint8_t *)queries + (size_t)q0 * qbytes, nqs, k, out_keys + (size_t)q0 * k, out_counts + q0);
+        }
+        if (rc != -1) { c->last_batch_path = 4; return rc; }
+        for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+    }
     if (!few && (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k) || batch_h_eligible(c, metric, k) ||
                  batch_f32_filter_eligible(c, metric, k))) {
         // very large batches go through in slices: the per-(query, partition) candidate lists are nq x ~128 x 512 B
@@ -406,17 +547,22 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
             rc = scan_topk_batch_mfma(c, metric, (const uint8_t *)queries + (size_t)q0 * qbytes, nqs, k, out_keys + (size_t)q0 * k,
                                       out_counts + q0);
         }
-        if (rc != -1) return rc;
+        if (rc != -1) {
+            const bool quantized = (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8);
+            c->last_batch_path = quantized ? 2 : ((c->vtype != VG_TYPE_F32 || c->last_batch_half) ? 3 : 1);
+            return rc;
+        }
         for (int i = 0; i < nq; ++i) out_counts[i] = 0;
     }
     // shapes the matrix-core kernels do not serve (f16 / bf16, L1, k > 32, rows > 512 floats / 1 KiB): the multi-query
     // scan (vg_scan_multi_kernel: 4 - or 2 for f16 / bf16 - queries share every row load of the HBM-bound pass) ...
     if (!few && k <= 64 && nq >= 2 && env_int("VG_MULTI_SCAN", 1)) {
         int rc = scan_topk_batch_multi(c, metric, queries, nq, k, out_keys, out_counts);
-        if (rc != -1) return rc;
+        if (rc != -1) { c->last_batch_path = 5; return rc; }
         for (int i = 0; i < nq; ++i) out_counts[i] = 0;
     }
     // ... or, when that has no kernel for the shape either (very long rows, k > 64), nq single-query scans
+    c->last_batch_path = 6;
     const uint8_t *q = (const uint8_t *)queries;
     for (int i = 0; i < nq; ++i) {
         int rc = vg_scan_topk_keys(c, metric, q + (size_t)i * c->dim * c->es, k, out_keys + (size_t)i * k, out_counts + i);
@@ -435,6 +581,8 @@ bool vg_batch_keys_are_scan_exact(const vg_corpus *c, int metric, int k) {
     if (!batch_f32_filter_eligible(c, metric, k)) return false;
     return vg_batch_lds_bytes(c->stride, k) == 0 || (batch_f32_filter_short_rows(c) && !c->filter_disabled);
 }
+
+extern "C" int vg_batch_last_path(const vg_corpus *c) { return c ? c->last_batch_path : 0; }
 
 extern "C" int vg_batch_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals) {
     if (!c || !out_evals) return vg_fail(VG_ERR_INVALID, "vg_batch_filter_exact_evals: NULL argument");

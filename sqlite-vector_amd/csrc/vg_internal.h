@@ -138,6 +138,9 @@ struct vg_corpus {
     uint32_t *d_bpcounts = nullptr; // ... and their counts + overflow flag
     size_t bpairs_bytes = 0, bpcount_bytes = 0;
     bool bsplit_off = false;       // a batch overflowed a pair region: this corpus keeps the fused kernel
+    int last_batch_path = 0;       // vg_batch_last_path (vectorgpu_diag.h)
+    bool last_batch_half = false;  // (the last matrix-core batch went through vg_batch_h.hip)
+    int blong_cooldown = 0;        // ... of the long-row kernel (vg_batch_hl.hip): the next batches over this corpus take the multi-query scan
     int max_blocks = 0;
     int cu_count = 0;
 

@@ -592,6 +592,108 @@ def test_batch_half_matrix_core_filter_vs_single_scans(pkg, orc, vt, metric, mon
 
 
 @pytest.mark.parametrize("vt", [dg.F32, dg.F16, dg.BF16])
+@pytest.mark.parametrize("metric", (dg.DOT, dg.COSINE, dg.L2, dg.SQUARED_L2))
+def test_batch_long_rows_matrix_core_path(pkg, orc, vt, metric, monkeypatch):
+    """rows of 1025 .. 3072 elements (1536- / 3072-dimensional embeddings): vg_batch_hl.hip splits the K dimension over the four
+    wavefronts of a workgroup (each keeps a quarter of every query's row in registers), sums the partial scores in LDS, filters,
+    and vg_batch_hx_kernel evaluates the candidates with the single scan's arithmetic - the lists are the single scans' lists,
+    with Inf / NaN / zero / huge rows and queries, exact duplicates, an odd chunk count, rows appended after a batch."""
+    for dim in (1032, 1536, 2000, 2048, 2056, 3072):              # 24 / 24 / 32 / 32 / 48 / 48 k-steps per wavefront; 2056: odd chunk count for halves
+        n = 4133
+        rows = dg.corpus(vt, n, dim, 7200 + dim)
+        _, edge = dg.edge_rows(vt, dim, 7300 + dim)
+        rows[100:100 + len(edge)] = edge
+        rows[2000] = rows[17]
+        if vt == dg.F32:
+            rows[3000:3010] *= np.float32(1e-3)
+        else:
+            rows[3000:3010] = dg.to_storage(vt, dg.storage_to_f64(vt, rows[3000:3010]).astype(np.float32) * np.float32(1e-3))
+        c = pkg.Corpus(vt, dim)
+        c.append(rows)
+        for nq, k in ((7, 1), (70, 20), (130, 32), (33, 5)):
+            qs = dg.corpus(vt, nq, dim, 7400 + dim + nq)
+            eq = dg.edge_queries(vt, dim, 7500 + dim)
+            for i, q in enumerate(eq[:min(len(eq), nq - 1)]):
+                qs[1 + i] = q                                              # zero / Inf / NaN queries: answered by single scans
+            qs[0] = rows[17]
+            monkeypatch.setenv("VG_BATCH_MFMA", "1")
+            ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+            assert c.last_batch_path() == 4, (dim, nq, k, c.last_batch_path())
+            monkeypatch.setenv("VG_BATCH_MFMA", "0")
+            monkeypatch.setenv("VG_MULTI_SCAN", "0")
+            ids0, dist0, cnt0 = c.scan_topk_batch(metric, qs, k)           # nq single-query scans
+            assert c.last_batch_path() == 6
+            monkeypatch.delenv("VG_MULTI_SCAN")
+            assert np.array_equal(cnt, cnt0), (dim, nq, k)
+            for i in range(nq):
+                m = cnt[i]
+                if metric == dg.DOT and vt == dg.F32:   # cancelling f32 sums: the bar is relative to the magnitude of the summed terms
+                    both = np.intersect1d(ids[i][:m], ids0[i][:m])
+                    assert len(both) >= m - 2, (dim, i)
+                    for r in both:
+                        a, b = dist[i][:m][ids[i][:m] == r][0], dist0[i][:m][ids0[i][:m] == r][0]
+                        scale = float(np.abs(rows[r - 1].astype(np.float64) * qs[i].astype(np.float64)).sum())
+                        assert (np.isinf(a) and a == b) or (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-5 * (abs(b) + scale) + 1e-6, (dim, i, r, a, b)
+                else:
+                    _same_topk_up_to_ties(ids[i][:m], dist[i][:m], ids0[i][:m], dist0[i][:m], rtol=1e-5)
+            want = orc.scan_distances(orc.AVX2, metric, vt, qs[0], rows)
+            m = cnt[0]
+            _check_float_distances(dist[0][:m].astype(np.float32), want[ids[0][:m] - 1], vt, metric, qs[0], rows[ids[0][:m] - 1])
+        if dim == 1536:                          # rows appended after a batch extend the tile-major copy and the cached norms
+            more = dg.corpus(vt, 500, dim, 7600)
+            q20 = dg.storage_to_f64(vt, qs[20:21]).astype(np.float32)[0] if vt != dg.F32 else qs[20]
+            more[7] = qs[20] if metric != dg.DOT else (dg.to_storage(vt, q20 * np.float32(50.0)) if vt != dg.F32 else q20 * np.float32(50.0))
+            c.append(more)
+            monkeypatch.setenv("VG_BATCH_MFMA", "1")
+            ids, dist, cnt = c.scan_topk_batch(metric, qs, 5)
+            assert c.last_batch_path() == 4
+            one_ids, one_dist = c.scan_topk(metric, qs[20], 5)
+            _same_topk_up_to_ties(ids[20][:cnt[20]], dist[20][:cnt[20]], one_ids, one_dist, rtol=1e-5)
+            if metric != dg.DOT:                 # (dot: the Inf / huge edge rows rank before it)
+                assert (n + 8) in ids[20].tolist(), (ids[20], dist[20])
+        c.close()
+
+
+@pytest.mark.parametrize("vt", [dg.F32, dg.BF16])
+def test_batch_long_rows_staged_passes_and_partitions(pkg, vt, monkeypatch):
+    """a corpus large enough for the long-row kernel's bound pre-pass, several stages and more than one tile per partition, two
+    query groups; a batch whose candidate pairs overflow a region (every row a duplicate of the query) is answered by one
+    scan per query (rows this long have no multi-query scan) and the next batches stay there for a while."""
+    dim, n, nq, k = 1536, 200_000, 100, 10
+    rows = dg.corpus(vt, n, dim, 7700)
+    qs = dg.corpus(vt, nq, dim, 7701)
+    rows[150_000] = qs[3]                                                  # late best rows: they beat every earlier stage's threshold
+    rows[199_999] = qs[64]
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    for metric in (dg.COSINE, dg.L2, dg.DOT):
+        monkeypatch.setenv("VG_BATCH_MFMA", "1")
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        assert c.last_batch_path() == 4
+        monkeypatch.setenv("VG_BATCH_MFMA", "0")
+        ids0, dist0, cnt0 = c.scan_topk_batch(metric, qs, k)               # what such rows had before: one scan per query
+        assert c.last_batch_path() == 6
+        assert np.array_equal(cnt, cnt0)
+        for i in range(nq):
+            _same_topk_up_to_ties(ids[i], dist[i], ids0[i], dist0[i], rtol=1e-5)
+        if metric != dg.DOT:
+            assert ids[3][0] == 150_001 and ids[64][0] == 200_000
+    c.close()
+    # unseparable data: 400k copies of one row - every pair passes the filter, the candidate regions overflow
+    one = dg.corpus(vt, 1, dim, 7702)
+    c = pkg.Corpus(vt, dim)
+    for _ in range(4):
+        c.append(np.repeat(one, 100_000, axis=0))
+    monkeypatch.setenv("VG_BATCH_MFMA", "1")
+    qs = np.repeat(one, 64, axis=0)
+    ids, dist, cnt = c.scan_topk_batch(dg.L2, qs, 5)
+    assert c.last_batch_path() == 6 and ids[0].tolist() == [1, 2, 3, 4, 5] and np.all(dist == 0.0)
+    ids, dist, cnt = c.scan_topk_batch(dg.L2, qs, 5)
+    assert c.last_batch_path() == 6                                        # (cooling down)
+    c.close()
+
+
+@pytest.mark.parametrize("vt", [dg.F32, dg.F16, dg.BF16])
 def test_batch_half_workgroup_forms_agree(pkg, vt, monkeypatch):
     """the f16 / bf16 / f32-through-bf16 batch kernel comes as one 8-wavefront workgroup per CU or - rows up to 768 bytes, both
     workgroups' LDS fitting - as two of four (vg_batch_h_plan): the same keys out of both, bit for bit, over the row lengths that
