@@ -195,7 +195,7 @@ extern "C" int vg_batch_hl_regions(long long stride_bytes, int nq_pad, int npart
 extern "C" int vg_batch_hl_launch(const uint8_t *dev_rows, long long n_rows, long long stride_bytes, int dim, int type_code,
                                   const uint8_t *dev_xrows, long long xstride_bytes,
                                   const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
-                                  const float *dev_row_nn, uint64_t *dev_cand, int npart,
+                                  const float *dev_row_nn, const float *dev_query_nn, uint64_t *dev_cand, int npart,
                                   uint64_t *dev_out_keys, unsigned long long *dev_evals,
                                   uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, hipStream_t stream);
 static long long batch_long_stride(const vg_corpus *c) { return c->vtype == VG_TYPE_F32 ? bf16_shadow_stride(c) : c->stride; }
@@ -236,7 +236,9 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
     const int QPB = vg_batch_hl_queries_per_block(fstride);
     const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
     const int G = nq_pad / QPB;
-    int npart = std::max(1, c->cu_count * std::max(1, env_int("VG_BATCH_BPC", 1)) / G);
+    // partitions: one workgroup per CU and query group (VG_BATCH_LONG_BPC rounds of them: measured, 1024 x 2M x 1536 - 1: 11.0 ms, 2: 11.9,
+    // 4: 14.7, 8: 20.9 - a workgroup's set-up, the A operand of 64 queries, is paid per partition)
+    int npart = std::max(1, c->cu_count * std::max(1, env_int("VG_BATCH_LONG_BPC", 1)) / G);
     if (npart >= 8) npart = (npart / 8) * 8;
     npart = std::min(npart, 256);
     const long long ntiles = (c->n_rows + 31) / 32;
@@ -246,7 +248,7 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
     rcn = f32 ? ensure_bf16_tile_major(c) : ensure_half_tile_major(c);
     if (rcn == -1) return -1;                              // (no room for the copy: the multi-query scan)
     if (rcn != VG_OK) return rcn;
-    const size_t qbytes = (size_t)nq_pad * c->stride;
+    const size_t qrows = (size_t)nq_pad * c->stride, qbytes = qrows + (size_t)nq_pad * sizeof(float);      // the query rows, then their norms
     const size_t candbytes = (size_t)nq_pad * vg_batch_lists_per_query(c->n_rows, npart) * 64 * sizeof(uint64_t);
     const size_t keybytes = (size_t)nq_pad * 64 * sizeof(uint64_t);
     if (c->bq_bytes < qbytes) { if (c->d_bq) hipFree(c->d_bq); c->d_bq = nullptr; c->bq_bytes = 0;
@@ -272,6 +274,8 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
         const double n2 = host_query_norm2(c, q);
         if (!(n2 >= 1.0e-30 && n2 <= 1.0e30)) { unjudged.push_back(i); continue; }
         memcpy(hq.data() + (size_t)i * c->stride, q, row_bytes);
+        const float n2f = (float)n2;
+        memcpy(hq.data() + qrows + (size_t)i * sizeof(float), &n2f, sizeof(float));
     }
     HIP_TRY(hipMemcpyAsync(c->d_bq, hq.data(), qbytes, hipMemcpyHostToDevice, c->stream));
     hipEvent_t *evs = nullptr;
@@ -284,8 +288,8 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
     }
     const int mode = metric == VG_DIST_DOT ? 0 : (metric == VG_DIST_COSINE ? 1 : 2), root = metric == VG_DIST_L2 ? 1 : 0;
     const int rc = vg_batch_hl_launch(c->d_rows_tm, c->n_rows, fstride, c->dim, f32 ? 2 : (c->vtype == VG_TYPE_BF16 ? 1 : 0), c->d_rows, c->stride,
-                                      (const uint8_t *)c->d_bq, nq_pad, nq, k, mode, root, c->d_xnorm, c->d_bcand, npart, c->d_bkeys, nullptr,
-                                      c->d_bpairs, c->d_bpcounts, VG_BPAIR_CAP, c->stream);
+                                      (const uint8_t *)c->d_bq, nq_pad, nq, k, mode, root, c->d_xnorm, reinterpret_cast<const float *>((const uint8_t *)c->d_bq + qrows),
+                                      c->d_bcand, npart, c->d_bkeys, nullptr, c->d_bpairs, c->d_bpcounts, VG_BPAIR_CAP, c->stream);
     if (evs) { hipEventRecord(evs[2], c->stream); hipEventRecord(evs[3], c->stream); }
     if (rc == -1) { hipStreamSynchronize(c->stream); return -1; }
     if (rc != 0) return vg_fail(VG_ERR_HIP, "batched scan launch (long rows) failed: %s", hipGetErrorString((hipError_t)rc));

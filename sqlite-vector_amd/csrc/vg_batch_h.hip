@@ -765,9 +765,9 @@ extern "C" int vgh_launch_real_f32(const BatchArgsH *a, int ntb, int waves, int 
 // the split form: the FILTER kind of the streaming kernel + the exact-evaluation kernel, one unit per element type (-DVGH_TU=6 / 7 / 8)
 template <int VT, int XU>
 static int launch_hx_mode(const BatchArgsH &a, int waves, int regions, size_t smem, hipStream_t stream) {
-    if (a.mode == VGH_COS) hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_COS, XU>), dim3((unsigned)regions), dim3(64), smem, stream, a, waves, 1);
-    else if (a.mode == VGH_L2) hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_L2, XU>), dim3((unsigned)regions), dim3(64), smem, stream, a, waves, 1);
-    else hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_DOT, XU>), dim3((unsigned)regions), dim3(64), smem, stream, a, waves, 1);
+    if (a.mode == VGH_COS) hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_COS, XU>), dim3((unsigned)regions), dim3(64 * VGHX_WAVES), smem, stream, a, waves, 1);
+    else if (a.mode == VGH_L2) hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_L2, XU>), dim3((unsigned)regions), dim3(64 * VGHX_WAVES), smem, stream, a, waves, 1);
+    else hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_DOT, XU>), dim3((unsigned)regions), dim3(64 * VGHX_WAVES), smem, stream, a, waves, 1);
     return (int)hipGetLastError();
 }
 template <int VT>
@@ -978,7 +978,7 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
     a.cerr = (float)(dim + 64) * 4.76837158203125e-7f + (type_code == 2 ? 0.0078125f + 1.52587890625e-5f : 0.0f);   // (D+64) 2^-21 [+ 2u + u^2, u = 2^-8: query AND row are rounded to bf16]
     a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;
     a.mode = mode; a.root = root; a.dim = dim; a.evals = dev_evals;
-    a.pairs = dev_pairs; a.pair_counts = dev_pair_counts; a.pair_cap = pair_cap;
+    a.pairs = dev_pairs; a.pair_counts = dev_pair_counts; a.pair_cap = pair_cap; a.qnn = nullptr;
     const int G = nq_pad / qpb;
     a.n_regions = G * npart * waves;
     if (split) {

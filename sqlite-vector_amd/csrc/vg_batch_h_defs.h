@@ -54,6 +54,7 @@ struct BatchArgsH {
     uint64_t *pairs;
     uint32_t *pair_counts;
     int pair_cap, n_regions;
+    const float *qnn;         // vg_batch_hl.hip: (float) sum q^2 per query (nq_pad), made by the host once per batch
 };
 
 template <int CTRL> __device__ __forceinline__ uint64_t vgh_dpp64(uint64_t v) {
@@ -77,8 +78,12 @@ __device__ __forceinline__ vgh_f32x16 vgh_mfma(const vgh_i32x4 &a, const vgh_i32
 // subs: pair regions per block (1: the filter wavefront's own; vg_batch_hl.hip: the 2 or 4 wavefronts that finish the scores of one
 // set of 32 queries write a region each - regions block * subs .. + subs - 1, read one after the other: a query's pairs all sit in ONE
 // of them, in scan order).
+// FOUR wavefronts per block: wavefront v evaluates the pairs of the queries with (query & 3) == v - every wavefront reads all pair
+// words of the block's regions and skips the others'.  A query's pairs stay with one wavefront, in order; its list, threshold and
+// statistics in LDS are touched by that wavefront only.
+#define VGHX_WAVES 4
 template <int VT, int MODE, int XU>
-__global__ __launch_bounds__(64) void vg_batch_hx_kernel(BatchArgsH a, int waves, int subs) {
+__global__ __launch_bounds__(64 * VGHX_WAVES) void vg_batch_hx_kernel(BatchArgsH a, int waves, int subs) {
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2), XF32 = (VT == T_F32);
     constexpr int ACC = COS ? (XF32 ? A_COS : A_COSN) : (L2M ? A_L2 : A_DOT);
     typedef Accum<VT, ACC> Exact;
@@ -88,7 +93,8 @@ __global__ __launch_bounds__(64) void vg_batch_hx_kernel(BatchArgsH a, int waves
     uint32_t *qhave = qsp_w + VGH_QPW;                                   // [32] the two above are valid
     float *thr_w = reinterpret_cast<float *>(qhave + VGH_QPW);           // [32] k-th best so far
     uint64_t *wave_lists = reinterpret_cast<uint64_t *>(thr_w + VGH_QPW);   // [32][k]
-    const int lane = threadIdx.x, k = a.k;
+    const int lane = threadIdx.x & 63, k = a.k;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long region = blockIdx.x;
     const int wave = (int)(region % waves);
     const long long gp = region / waves;
@@ -96,15 +102,16 @@ __global__ __launch_bounds__(64) void vg_batch_hx_kernel(BatchArgsH a, int waves
     if (part < 0 || part >= a.npart) return;
     const int q0 = g * (waves * VGH_QPW) + wave * VGH_QPW;
     const int xchunks = (int)(a.xstride / 16);
-    if (lane < VGH_QPW) {
-        float t = a.init_keys ? vgb_kth_distance(a.init_keys[(long long)(q0 + lane) * 64 + (k - 1)]) : INFINITY;
-        if (q0 + lane >= a.nq_real) t = -INFINITY;
-        thr_w[lane] = t;
-        qhave[lane] = 0u;
+    if (threadIdx.x < VGH_QPW) {
+        const int qi = threadIdx.x;
+        float t = a.init_keys ? vgb_kth_distance(a.init_keys[(long long)(q0 + qi) * 64 + (k - 1)]) : INFINITY;
+        if (q0 + qi >= a.nq_real) t = -INFINITY;
+        thr_w[qi] = t;
+        qhave[qi] = 0u;
     }
     {
         const bool seeded = a.seed != 0 && part == 0;
-        for (int s = lane; s < VGH_QPW * k; s += 64)
+        for (int s = threadIdx.x; s < VGH_QPW * k; s += 64 * VGHX_WAVES)
             wave_lists[s] = seeded ? a.init_keys[(long long)(q0 + s / k) * 64 + s % k] : VG_EMPTY_KEY;
     }
     __syncthreads();
@@ -112,22 +119,27 @@ __global__ __launch_bounds__(64) void vg_batch_hx_kernel(BatchArgsH a, int waves
     for (int sub = 0; sub < subs; ++sub) {
     const unsigned n = a.pair_counts[region * subs + sub];
     const uint64_t *my_pairs = a.pairs + (region * subs + sub) * a.pair_cap;
-    uint64_t pair_next = n ? my_pairs[0] : 0ull;
     n_all += n;
-    for (unsigned i = 0; i < n; ++i) {
-        const uint64_t pr = pair_next;
-        if (i + 1 < n) pair_next = my_pairs[i + 1];
+    // Two pair slots, A and B: the row (and query) of pair i+1 is in flight while pair i is evaluated - one wavefront walks its pairs in
+    // order (a query's list insertions are ordered), and with one HBM round trip per pair exposed the kernel took half as long as the
+    // filter kernel that feeds it (long rows, 6 KiB per evaluation: profiles/r7b_*)
+    auto issue = [&](uint64_t pr, uint4 (&qv)[XU], uint4 (&xv)[XU], float &nn) __attribute__((always_inline)) {
         const int qi_u = __builtin_amdgcn_readfirstlane((int)(pr >> 32));
         const uint32_t row_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pr);
         const uint8_t *qp = a.xqueries + (long long)(q0 + qi_u) * a.xstride;
         const uint8_t *xp = a.xrows + (unsigned long long)row_u * (unsigned long long)a.xstride;
-        uint4 qv[XU], xv[XU];
 #pragma unroll
         for (int u = 0; u < XU; ++u) {
             qv[u] = make_uint4(0u, 0u, 0u, 0u); xv[u] = make_uint4(0u, 0u, 0u, 0u);
             if (lane + 64 * u < xchunks) { qv[u] = reinterpret_cast<const uint4 *>(qp)[lane + 64 * u]; xv[u] = reinterpret_cast<const uint4 *>(xp)[lane + 64 * u]; }
         }
-        float nn_u = a.row_nn[row_u];
+        nn = a.row_nn[row_u];
+    };
+    auto evaluate = [&](uint64_t pr, const uint4 (&qv)[XU], const uint4 (&xv)[XU], float nn_u) __attribute__((always_inline)) {
+        const int qi_u = __builtin_amdgcn_readfirstlane((int)(pr >> 32));
+        const uint32_t row_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pr);
+        const uint8_t *qp = a.xqueries + (long long)(q0 + qi_u) * a.xstride;
+        const uint8_t *xp = a.xrows + (unsigned long long)row_u * (unsigned long long)a.xstride;
         if (qhave[qi_u] == 0u) {                                         // the query's statistics, on first use (wave-uniform branch)
             if constexpr (XF32) {
                 const typename Accum<T_F32, A_COS>::QStat st = Accum<T_F32, A_COS>::template query_stat<XU>(qv, 6);
@@ -136,7 +148,8 @@ __global__ __launch_bounds__(64) void vg_batch_hx_kernel(BatchArgsH a, int waves
                 const typename Accum<VT, A_COSN>::QStat st = Accum<VT, A_COSN>::template query_stat<XU>(qv, 6);
                 if (lane == 0) { qq_w[qi_u] = st.qq; qsp_w[qi_u] = st.qspecial; qhave[qi_u] = 1u; }
             }
-            __syncthreads();                                             // (one wavefront: orders the LDS writes before the reads below)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // (this wavefront's own LDS writes, read back below: in order)
+            __builtin_amdgcn_wave_barrier();
         }
         typename Exact::QStat qs;
         if constexpr (XF32) qs.qq = (float)qq_w[qi_u];
@@ -156,15 +169,43 @@ __global__ __launch_bounds__(64) void vg_batch_hx_kernel(BatchArgsH a, int waves
         }
         const float de = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vg_clamp(d))));
         const float thr_u = thr_w[qi_u];
-        if (!(de < thr_u)) continue;                                     // strict: rows arrive in scan order (see the fused kernel)
+        if (!(de < thr_u)) return;                                       // strict: rows arrive in scan order (see the fused kernel)
         const float nt = vgb_kth_distance(vgb_list_insert(wave_lists + qi_u * k, k, lane, vg_make_key(de, row_u)));
         if (nt < thr_u && lane == 0) thr_w[qi_u] = nt;
+    };
+    // the next pair of THIS wavefront at or behind position `from` (64 pair words per look: lane l reads word from + l); n if there is none
+    auto next_mine = [&](unsigned from, uint64_t &pr) __attribute__((always_inline)) -> unsigned {
+        for (; from < n; from += 64) {
+            const uint64_t w = (from + lane < n) ? my_pairs[from + lane] : 0ull;
+            const unsigned long long mine = __ballot(from + lane < n && (int)((w >> 32) & 3u) == wv);
+            if (mine != 0ull) {
+                const int src = __ffsll((long long)mine) - 1;
+                pr = vg_readlane64(w, src);
+                return from + (unsigned)src;
+            }
+        }
+        return n;
+    };
+    uint4 qvA[XU], xvA[XU], qvB[XU], xvB[XU];
+    float nnA = 0.0f, nnB = 0.0f;
+    uint64_t prA = 0ull, prB = 0ull;
+    unsigned iA = next_mine(0u, prA), iB = n;
+    if (iA < n) { issue(prA, qvA, xvA, nnA); iB = next_mine(iA + 1u, prB); }
+    while (iA < n) {
+        if (iB < n) issue(prB, qvB, xvB, nnB);
+        evaluate(prA, qvA, xvA, nnA);
+        iA = (iB < n) ? next_mine(iB + 1u, prA) : n;
+        if (iB < n) {
+            if (iA < n) issue(prA, qvA, xvA, nnA);
+            evaluate(prB, qvB, xvB, nnB);
+            iB = (iA < n) ? next_mine(iA + 1u, prB) : n;
+        }
     }
     }
     __syncthreads();
-    for (int s = lane; s < VGH_QPW * 64; s += 64) {
+    for (int s = threadIdx.x; s < VGH_QPW * 64; s += 64 * VGHX_WAVES) {
         const int qi = s >> 6, slot = s & 63;
         a.cand[((long long)(q0 + qi) * a.npart_total + a.part_base + part) * 64 + slot] = (slot < k) ? wave_lists[qi * k + slot] : VG_EMPTY_KEY;
     }
-    if (a.evals && lane == 0 && n_all) atomicAdd(a.evals, (unsigned long long)n_all);
+    if (a.evals && threadIdx.x == 0 && n_all) atomicAdd(a.evals, (unsigned long long)n_all);
 }

@@ -33,13 +33,12 @@
 #define VGHL_WAVES 4
 #define VGHL_QS(NTBP) ((NTBP) <= 24 ? 2 : 1)     // (two sets at 32 k-steps = 256 registers of A: the gate spills, its reloads drain the load ring)
 #define VGHL_MAX_KSTEPS (4 * 48)        // 6 KiB of half-precision elements per row: 3072
-
-template <int VT>
-__device__ __forceinline__ float vghl_elem(const uint8_t *row, int e) {
-    if constexpr (VT == T_F32) return reinterpret_cast<const float *>(row)[e];
-    else if constexpr (VT == T_F16) return (float)reinterpret_cast<const _Float16 *>(row)[e];
-    else return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(row)[e] << 16);
-}
+#ifndef VGHL_ABLATE
+#define VGHL_ABLATE 0                   // measurement builds (wrong results): 1 = no meeting in LDS / gate, 2 = no loads in the tile loop, 3 = neither
+#endif
+#ifndef VGHL_DEPTH
+#define VGHL_DEPTH(NTBP) ((NTBP) <= 32 ? 2 : 1)     // tiles of B in flight per wavefront (registers: DEPTH x NTBP x 4 next to A's QS x NTBP x 4)
+#endif
 
 template <int VT, int NTBP, int MODE, int KIND>
 __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchArgsH a) {
@@ -66,15 +65,10 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
     const int chunks_per_row = (int)(a.stride / 16);
     const int kbase = wave * NTBP;                                       // this wavefront's first k-step
 
-    // ---- per-query statistics: sum q^2 (a query with Inf / NaN elements or a norm out of range is one the filter cannot judge)
-    for (int qi = wave; qi < NQ; qi += VGHL_WAVES) {
-        const uint8_t *qrow = a.xqueries + (long long)(q0 + qi) * a.xstride;
-        double s = 0.0;
-        for (int e = lane; e < a.dim; e += 64) { const float v = vghl_elem<VT>(qrow, e); s += (double)v * (double)v; }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-        if (lane == 0) qq_l[qi] = (float)s;
-    }
+    // ---- per-query statistics: sum q^2, made by the host once per batch (a loop over the queries here cost every workgroup of every
+    // stage ~200 us: profiles/r7d_*); a query the filter cannot judge - Inf / NaN elements, a norm of zero or out of range - is not in
+    // the batch at all (vg_batch_api.hip answers it with a scan of its own): its slot holds a zero row and the norm 0
+    if (tid < NQ) qq_l[tid] = a.qnn[q0 + tid];
     if (tid < NQ) {                                      // thresholds: the pre-pass bound; padding queries never accept
         float t = a.init_keys ? vgb_kth_distance(a.init_keys[(long long)(q0 + tid) * 64 + (k - 1)]) : INFINITY;
         if (q0 + tid >= a.nq_real) t = -INFINITY;
@@ -176,45 +170,36 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
     uint64_t *my_pairs = BOUND ? nullptr : a.pairs + region * a.pair_cap;
     unsigned n_pairs = 0;                                                // (wave-uniform)
 
-    vgh_i32x4 breg[NTBP];
-    float nn_next = 0.0f;
+    // B ring: DEPTH tiles of this wavefront's k-steps in registers.  A load is issued right behind the MFMAs that free its registers, DEPTH
+    // tiles ahead: what is in flight per CU (4 wavefronts x DEPTH x NTBP KiB: 192 KiB) is what bounds the stream - with one tile
+    // (96 KiB at 24 k-steps) the first version ran at ~19 B / clk / CU from L2, 30 % of the matrix rate (profiles/r7b_*)
+    constexpr int DEPTH = BOUND ? 1 : VGHL_DEPTH(NTBP);                  // (the pre-pass - 1 / 512 of the rows - keeps its registers for the lists' code)
+    vgh_i32x4 breg[DEPTH][NTBP];
+    float nn_ring[DEPTH];
     if (tile_first < tile_last) {
-        const __amdgpu_buffer_rsrc_t rs0 = tile_rsrc(tile_first);
-        nn_next = a.row_nn[tile_first * VGH_TILE + x];                   // (the order of the tile loop: norms, then the tile's k-steps)
-        vgb_static_for<0, NTBP>([&](auto tc) __attribute__((always_inline)) { breg[decltype(tc)::value] = load_b(rs0, tc); });
+        vgb_static_for<0, DEPTH>([&](auto dc) __attribute__((always_inline)) {
+            constexpr int d = decltype(dc)::value;
+            const long long tj = min(tile_first + d, tile_last - 1);
+            const __amdgpu_buffer_rsrc_t rs0 = tile_rsrc(tj);
+            nn_ring[d] = a.row_nn[tj * VGH_TILE + x];                    // (the order of the tile loop: norms, then the tile's k-steps)
+            vgb_static_for<0, NTBP>([&](auto tc) __attribute__((always_inline)) { breg[d][decltype(tc)::value] = load_b(rs0, tc); });
+        });
     }
-    for (long long tile = tile_first; tile < tile_last; ++tile) {
-        const long long ti = tile - tile_first;
-        const long long tile_next = min(tile + 1, tile_last - 1);
-        const long long row_cur = tile * VGH_TILE + x;
-        const __amdgpu_buffer_rsrc_t rs_next = tile_rsrc(tile_next);
-        float nn_row = nn_next;
-        nn_next = a.row_nn[tile_next * VGH_TILE + x];                    // (in front of the next tile's loads: it lands first)
-        vgh_f32x16 acc[QS];
-#pragma unroll
-        for (int s = 0; s < QS; ++s)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
-        vgb_static_for<0, NTBP>([&](auto tc) __attribute__((always_inline)) {
-            constexpr int t = decltype(tc)::value;
-            const vgh_i32x4 b = breg[t];
-            vgb_static_for<0, QS>([&](auto sc) __attribute__((always_inline)) { constexpr int s = decltype(sc)::value; acc[s] = vgh_mfma<FT>(areg[s][t], b, acc[s]); });
-            breg[t] = load_b(rs_next, tc);                               // the next tile's bytes for the same k-step, a tile ahead
-        });
-        if constexpr (XF32) nn_row = nn_row * nn_row;                    // (the f32 corpus caches ||x||, not sum x^2)
-
-        // ---- the four partial scores meet in LDS; this wavefront takes registers [F wave, F wave + F)
-        float4 *red_w = red + ((ti & 1) * VGHL_WAVES + wave) * (QS * 4 * 64);
-        vgb_static_for<0, QS>([&](auto sc) __attribute__((always_inline)) {
-            constexpr int s = decltype(sc)::value;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4)
-                red_w[(s * 4 + q4) * 64 + lane] = make_float4(acc[s][4 * q4], acc[s][4 * q4 + 1], acc[s][4 * q4 + 2], acc[s][4 * q4 + 3]);
-        });
+    // One tile = its k loop, then the four partial scores MEET IN LDS: every wavefront writes its QS x 16 registers, one barrier, and
+    // wavefront w sums registers [F w, F w + F).  The meeting of tile i is finished in the MIDDLE of tile i+1's k loop (finish_prev):
+    // a wavefront that is early at the barrier has issued half of the next tile's MFMAs by then instead of idling from the end of its k
+    // loop on - one wavefront per SIMD, nobody else feeds its matrix pipe (ablation, 1024 x 2M x 1536: MFMA alone 4.3 ms, + loads 6.0,
+    // + meeting / gate / pairs at the tile's end 8.4, + exact evaluation 9.5: profiles/r7f_*).  Two LDS buffers: tile i+2 is written
+    // behind barrier i+1, which every wavefront reaches with its reads of tile i done.
+    bool have_prev = false;
+    float nn_prev = 0.0f;
+    long long row_prev = 0;
+    int par_prev = 0;
+    auto finish_prev = [&]() __attribute__((always_inline)) {
         __syncthreads();
         float fin[F];
         {
-            const float4 *red_r = red + (ti & 1) * VGHL_WAVES * (QS * 4 * 64);
+            const float4 *red_r = red + par_prev * VGHL_WAVES * (QS * 4 * 64);
 #pragma unroll
             for (int j4 = 0; j4 < QS; ++j4) {
                 float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -227,15 +212,15 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
             }
         }
         // ---- the gate (vg_batch_h.hip): fin + init + gmul * lane_term >= 0
-        const bool force = !(nn_row >= VGH_NORM_LO && nn_row <= VGH_NORM_HI);      // NaN / Inf / zero / out of range
-        const float lane_term = force ? 0.0f : (L2M ? 0.5f * (1.0f - cerr) * nn_row : sqrtf(nn_row));
+        const bool force = !(nn_prev >= VGH_NORM_LO && nn_prev <= VGH_NORM_HI);      // NaN / Inf / zero / out of range
+        const float lane_term = force ? 0.0f : (L2M ? 0.5f * (1.0f - cerr) * nn_prev : sqrtf(nn_prev));
         uint32_t mybits = 0u;
         vgb_static_for<0, F>([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value;
             const bool pass = force || fmaf(gmul_f[j], lane_term, fin[j] + init_f[j]) >= 0.0f;
             mybits |= pass ? (1u << j) : 0u;
         });
-        if (!(row_cur < a.n_rows)) mybits = 0u;
+        if (!(row_prev < a.n_rows)) mybits = 0u;
         if (__ballot(mybits != 0u) != 0ull) {
             if constexpr (BOUND) {
                 bool changed = false;
@@ -244,11 +229,11 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
                     if (__ballot((mybits >> j) & 1u) == 0ull) return;
                     // upper bound of the distance from the filter's estimate s~
                     const int r = rbase + j, q_lo = qset0 + (r & 3) + 8 * (r >> 2), qi_lane = q_lo + 4 * h;
-                    const float qqf = qq_l[qi_lane], na = sqrtf(qqf), nb = sqrtf(nn_row);
+                    const float qqf = qq_l[qi_lane], na = sqrtf(qqf), nb = sqrtf(nn_prev);
                     const float st = fin[j], E = cerr * na * nb;
                     float ub;
                     if (COS) ub = fminf(1.0f - st / (na * nb) + cerr + 1e-5f, 2.0f);
-                    else if (L2M) { const float d2 = fmaxf(qqf + nn_row - 2.0f * st + 2.0f * E + 1e-5f * (qqf + nn_row), 0.0f); ub = l2_root ? sqrtf(d2) : d2; }
+                    else if (L2M) { const float d2 = fmaxf(qqf + nn_prev - 2.0f * st + 2.0f * E + 1e-5f * (qqf + nn_prev), 0.0f); ub = l2_root ? sqrtf(d2) : d2; }
                     else ub = -st + E;
                     ub = ub + 1e-5f * fabsf(ub) + 1e-30f;
                     const bool qforce = !(qqf >= VGH_NORM_LO && qqf <= VGH_NORM_HI);
@@ -256,7 +241,7 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
                     if (__ballot(ok) == 0ull) return;
                     // only the SMALLEST bound of each query in this tile enters its list (k entries then stand for k different rows all
                     // the same, and a list costs one insert per (query, tile))
-                    uint64_t key = ok ? vg_make_key(ub, (uint32_t)row_cur) : VG_EMPTY_KEY;
+                    uint64_t key = ok ? vg_make_key(ub, (uint32_t)row_prev) : VG_EMPTY_KEY;
                     key = vgh_min64(key, vgh_dpp64<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(key));
                     key = vgh_min64(key, vgh_dpp64<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(key));
                     key = vgh_min64(key, vgh_dpp64<VG_DPP_ROW_HALF_MIRROR>(key));
@@ -283,14 +268,56 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
                     if (lane == src) mybits &= mybits - 1u;
                     const int r_u = rbase + j_u, qi_u = (r_u & 3) + 8 * (r_u >> 2) + 4 * (src >> 5);   // within the set
                     if (q0 + qset0 + qi_u >= a.nq_real) continue;
-                    const uint32_t row_u = (uint32_t)__builtin_amdgcn_readlane((int)row_cur, src);
+                    const uint32_t row_u = (uint32_t)__builtin_amdgcn_readlane((int)row_prev, src);
                     if (n_pairs < (unsigned)a.pair_cap) { if (lane == 0) my_pairs[n_pairs] = ((uint64_t)(uint32_t)qi_u << 32) | row_u; }
                     else if (lane == 0) a.pair_counts[a.n_regions] = 1u;     // region full: the host answers this batch another way
                     ++n_pairs;
                 }
             }
         }
+    };
+    auto do_tile = [&](long long tile, auto dc) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
+        constexpr int P = NTBP / 2;                                      // k-steps in front of the previous tile's meeting
+        const long long ti = tile - tile_first;
+        const long long tile_next = min(tile + DEPTH, tile_last - 1);
+        const __amdgpu_buffer_rsrc_t rs_next = tile_rsrc(tile_next);
+        float nn_row = nn_ring[d];
+        nn_ring[d] = a.row_nn[tile_next * VGH_TILE + x];                 // (in front of that tile's loads: it lands first)
+        vgh_f32x16 acc[QS];
+#pragma unroll
+        for (int s = 0; s < QS; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
+        auto k_step = [&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            const vgh_i32x4 b = breg[d][t];
+            vgb_static_for<0, QS>([&](auto sc) __attribute__((always_inline)) { constexpr int s = decltype(sc)::value; acc[s] = vgh_mfma<FT>(areg[s][t], b, acc[s]); });
+            if constexpr (!(VGHL_ABLATE & 2)) breg[d][t] = load_b(rs_next, tc);     // the same k-step of the tile DEPTH ahead
+        };
+        vgb_static_for<0, P>(k_step);
+        if constexpr ((VGHL_ABLATE & 1) == 0) { if (have_prev) finish_prev(); }
+        vgb_static_for<P, NTBP>(k_step);
+        if constexpr ((VGHL_ABLATE & 1) != 0) {
+            asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][15]), "v"(acc[QS - 1][0]), "v"(acc[QS - 1][15]));     // (keep the MFMA chains alive)
+            return;
+        }
+        if constexpr (XF32) nn_row = nn_row * nn_row;                    // (the f32 corpus caches ||x||, not sum x^2)
+        float4 *red_w = red + ((int)(ti & 1) * VGHL_WAVES + wave) * (QS * 4 * 64);
+        vgb_static_for<0, QS>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int s = decltype(sc)::value;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                red_w[(s * 4 + q4) * 64 + lane] = make_float4(acc[s][4 * q4], acc[s][4 * q4 + 1], acc[s][4 * q4 + 2], acc[s][4 * q4 + 3]);
+        });
+        have_prev = true; nn_prev = nn_row; row_prev = tile * VGH_TILE + x; par_prev = (int)(ti & 1);
+    };
+    for (long long tile0 = tile_first; tile0 < tile_last; tile0 += DEPTH) {
+        vgb_static_for<0, DEPTH>([&](auto dc) __attribute__((always_inline)) {
+            if (tile0 + decltype(dc)::value < tile_last) do_tile(tile0 + decltype(dc)::value, dc);     // (wave- and workgroup-uniform)
+        });
     }
+    if constexpr ((VGHL_ABLATE & 1) == 0) { if (have_prev) finish_prev(); }
     if constexpr (!BOUND) {
         if (lane == 0) a.pair_counts[region] = n_pairs < (unsigned)a.pair_cap ? n_pairs : (unsigned)a.pair_cap;
     } else {
@@ -344,9 +371,9 @@ static int launch_hl(const BatchArgsH &a, int ntbp, int blocks, size_t smem, hip
 template <int VT, int XU>
 static int launch_hlx_mode(const BatchArgsH &a, int sets, int blocks, size_t smem, hipStream_t stream) {
     const int subs = VGHL_WAVES / sets;
-    if (a.mode == VGH_COS) hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_COS, XU>), dim3((unsigned)blocks), dim3(64), smem, stream, a, sets, subs);
-    else if (a.mode == VGH_L2) hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_L2, XU>), dim3((unsigned)blocks), dim3(64), smem, stream, a, sets, subs);
-    else hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_DOT, XU>), dim3((unsigned)blocks), dim3(64), smem, stream, a, sets, subs);
+    if (a.mode == VGH_COS) hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_COS, XU>), dim3((unsigned)blocks), dim3(64 * VGHX_WAVES), smem, stream, a, sets, subs);
+    else if (a.mode == VGH_L2) hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_L2, XU>), dim3((unsigned)blocks), dim3(64 * VGHX_WAVES), smem, stream, a, sets, subs);
+    else hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_DOT, XU>), dim3((unsigned)blocks), dim3(64 * VGHX_WAVES), smem, stream, a, sets, subs);
     return (int)hipGetLastError();
 }
 template <int VT>
@@ -399,20 +426,21 @@ extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int l
 
 // dev_rows: the TILE-MAJOR copy of what the matrix core multiplies (type_code 0 / 1: the f16 / bf16 corpus; 2: the bf16 shadow copy of
 // an f32 corpus), stride_bytes per row; dev_xrows / xstride_bytes: the row-major corpus the exact evaluation reads; dev_queries: the
-// queries in the corpus' own type and stride (zero padded rows, zero rows up to nq_pad); dev_row_nn as for vg_batch_h_launch.
+// queries in the corpus' own type and stride (zero padded rows, zero rows up to nq_pad); dev_row_nn as for vg_batch_h_launch;
+// dev_query_nn: (float) sum q^2 per query, nq_pad of them (0 for the padding).
 // dev_pairs / dev_pair_counts: vg_batch_hl_regions() regions of pair_cap pairs + the counts + one overflow word (a region ran full:
 // *the caller* reads it back and answers the batch another way).  Returns 0, -1 if the shape is not served, a hipError_t otherwise.
 extern "C" int vg_batch_hl_launch(const uint8_t *dev_rows, long long n_rows, long long stride_bytes, int dim, int type_code,
                                   const uint8_t *dev_xrows, long long xstride_bytes,
                                   const uint8_t *dev_queries, int nq_pad, int nq_real, int k, int mode, int root,
-                                  const float *dev_row_nn, uint64_t *dev_cand, int npart,
+                                  const float *dev_row_nn, const float *dev_query_nn, uint64_t *dev_cand, int npart,
                                   uint64_t *dev_out_keys, unsigned long long *dev_evals,
                                   uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, hipStream_t stream) {
     const int ntbp = vghl_ntbp(stride_bytes);
     if (!ntbp || k < 1 || k > VGH_MAX_K || !dev_pairs || !dev_pair_counts || pair_cap < 1) return -1;
     const int sets = VGHL_QS(ntbp), qpb = sets * VGH_QPW;
     if (nq_pad % qpb != 0 || npart < 1 || npart > VG_SEL_MAX_HEADS || n_rows < 1) return -1;
-    if (mode < VGH_DOT || mode > VGH_L2 || !dev_row_nn) return -1;
+    if (mode < VGH_DOT || mode > VGH_L2 || !dev_row_nn || !dev_query_nn) return -1;
     if (xstride_bytes / 16 > 12 * 64) return -1;
     BatchArgsH a;
     a.rows = dev_rows; a.tiled = 1; a.queries = dev_queries; a.row_nn = dev_row_nn; a.cand = dev_cand;
@@ -420,7 +448,7 @@ extern "C" int vg_batch_hl_launch(const uint8_t *dev_rows, long long n_rows, lon
     a.cerr = (float)(dim + 64) * 4.76837158203125e-7f + (type_code == 2 ? 0.0078125f + 1.52587890625e-5f : 0.0f);
     a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;
     a.mode = mode; a.root = root; a.dim = dim; a.evals = dev_evals;
-    a.pairs = dev_pairs; a.pair_counts = dev_pair_counts; a.pair_cap = pair_cap;
+    a.pairs = dev_pairs; a.pair_counts = dev_pair_counts; a.pair_cap = pair_cap; a.qnn = dev_query_nn;
     const int G = nq_pad / qpb;
     a.n_regions = G * npart * VGHL_WAVES;
     hipError_t e = hipMemsetAsync(dev_pair_counts + a.n_regions, 0, sizeof(uint32_t), stream);          // the overflow flag

@@ -671,8 +671,8 @@ def test_batch_long_rows_staged_passes_and_partitions(pkg, vt, monkeypatch):
         ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
         assert c.last_batch_path() == 4
         monkeypatch.setenv("VG_BATCH_MFMA", "0")
-        ids0, dist0, cnt0 = c.scan_topk_batch(metric, qs, k)               # what such rows had before: one scan per query
-        assert c.last_batch_path() == 6
+        ids0, dist0, cnt0 = c.scan_topk_batch(metric, qs, k)               # what such rows had before: the multi-query scan (f32) / one scan per query
+        assert c.last_batch_path() == (5 if vt == dg.F32 else 6)
         assert np.array_equal(cnt, cnt0)
         for i in range(nq):
             _same_topk_up_to_ties(ids[i], dist[i], ids0[i], dist0[i], rtol=1e-5)
@@ -687,9 +687,9 @@ def test_batch_long_rows_staged_passes_and_partitions(pkg, vt, monkeypatch):
     monkeypatch.setenv("VG_BATCH_MFMA", "1")
     qs = np.repeat(one, 64, axis=0)
     ids, dist, cnt = c.scan_topk_batch(dg.L2, qs, 5)
-    assert c.last_batch_path() == 6 and ids[0].tolist() == [1, 2, 3, 4, 5] and np.all(dist == 0.0)
+    assert c.last_batch_path() in (5, 6) and ids[0].tolist() == [1, 2, 3, 4, 5] and np.all(dist == 0.0)
     ids, dist, cnt = c.scan_topk_batch(dg.L2, qs, 5)
-    assert c.last_batch_path() == 6                                        # (cooling down)
+    assert c.last_batch_path() in (5, 6)                                   # (cooling down)
     c.close()
 
 
