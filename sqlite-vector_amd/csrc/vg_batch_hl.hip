@@ -36,6 +36,9 @@
 #ifndef VGHL_ABLATE
 #define VGHL_ABLATE 0                   // measurement builds (wrong results): 1 = no meeting in LDS / gate, 2 = no loads in the tile loop, 3 = neither
 #endif
+#ifndef VGHL_MEET_GAP
+#define VGHL_MEET_GAP 3                 // k-steps of MFMAs between the LDS reads of the previous tile's partial scores and their use
+#endif
 #ifndef VGHL_DEPTH
 #define VGHL_DEPTH(NTBP) ((NTBP) <= 32 ? 2 : 1)     // tiles of B in flight per wavefront (registers: DEPTH x NTBP x 4 next to A's QS x NTBP x 4)
 #endif
@@ -195,21 +198,25 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
     float nn_prev = 0.0f;
     long long row_prev = 0;
     int par_prev = 0;
-    auto finish_prev = [&]() __attribute__((always_inline)) {
+    // (in two halves: the barrier and the LDS reads - and, VGHL_MEET_GAP k-steps of MFMAs later, when they have landed, the sums, the gate
+    // and the pairs)
+    float4 met[QS][VGHL_WAVES];
+    auto meet_prev = [&]() __attribute__((always_inline)) {
         __syncthreads();
+        const float4 *red_r = red + par_prev * VGHL_WAVES * (QS * 4 * 64);
+#pragma unroll
+        for (int j4 = 0; j4 < QS; ++j4)
+#pragma unroll
+            for (int src = 0; src < VGHL_WAVES; ++src) met[j4][src] = red_r[(src * QS * 4 + wave * QS + j4) * 64 + lane];
+    };
+    auto finish_prev = [&]() __attribute__((always_inline)) {
         float fin[F];
-        {
-            const float4 *red_r = red + par_prev * VGHL_WAVES * (QS * 4 * 64);
 #pragma unroll
-            for (int j4 = 0; j4 < QS; ++j4) {
-                float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-                for (int src = 0; src < VGHL_WAVES; ++src) {
-                    const float4 v = red_r[(src * QS * 4 + wave * QS + j4) * 64 + lane];
-                    sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-                }
-                fin[4 * j4] = sum.x; fin[4 * j4 + 1] = sum.y; fin[4 * j4 + 2] = sum.z; fin[4 * j4 + 3] = sum.w;
-            }
+        for (int j4 = 0; j4 < QS; ++j4) {
+            fin[4 * j4] = (met[j4][0].x + met[j4][1].x) + (met[j4][2].x + met[j4][3].x);
+            fin[4 * j4 + 1] = (met[j4][0].y + met[j4][1].y) + (met[j4][2].y + met[j4][3].y);
+            fin[4 * j4 + 2] = (met[j4][0].z + met[j4][1].z) + (met[j4][2].z + met[j4][3].z);
+            fin[4 * j4 + 3] = (met[j4][0].w + met[j4][1].w) + (met[j4][2].w + met[j4][3].w);
         }
         // ---- the gate (vg_batch_h.hip): fin + init + gmul * lane_term >= 0
         const bool force = !(nn_prev >= VGH_NORM_LO && nn_prev <= VGH_NORM_HI);      // NaN / Inf / zero / out of range
@@ -295,9 +302,12 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
             vgb_static_for<0, QS>([&](auto sc) __attribute__((always_inline)) { constexpr int s = decltype(sc)::value; acc[s] = vgh_mfma<FT>(areg[s][t], b, acc[s]); });
             if constexpr (!(VGHL_ABLATE & 2)) breg[d][t] = load_b(rs_next, tc);     // the same k-step of the tile DEPTH ahead
         };
+        constexpr int P2 = (P + VGHL_MEET_GAP < NTBP) ? P + VGHL_MEET_GAP : NTBP;
         vgb_static_for<0, P>(k_step);
+        if constexpr ((VGHL_ABLATE & 1) == 0) { if (have_prev) meet_prev(); }
+        vgb_static_for<P, P2>(k_step);
         if constexpr ((VGHL_ABLATE & 1) == 0) { if (have_prev) finish_prev(); }
-        vgb_static_for<P, NTBP>(k_step);
+        vgb_static_for<P2, NTBP>(k_step);
         if constexpr ((VGHL_ABLATE & 1) != 0) {
             asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][15]), "v"(acc[QS - 1][0]), "v"(acc[QS - 1][15]));     // (keep the MFMA chains alive)
             return;
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
             if (tile0 + decltype(dc)::value < tile_last) do_tile(tile0 + decltype(dc)::value, dc);     // (wave- and workgroup-uniform)
         });
     }
-    if constexpr ((VGHL_ABLATE & 1) == 0) { if (have_prev) finish_prev(); }
+    if constexpr ((VGHL_ABLATE & 1) == 0) { if (have_prev) { meet_prev(); finish_prev(); } }
     if constexpr (!BOUND) {
         if (lane == 0) a.pair_counts[region] = n_pairs < (unsigned)a.pair_cap ? n_pairs : (unsigned)a.pair_cap;
     } else {

@@ -235,3 +235,32 @@ def test_f32_768_batch_10m_through_the_bf16_filter(env):
             assert np.all(np.abs(dist[i] - one_dist) <= 1e-5 * (np.abs(one_dist) + scale) + 1e-6), (metric, i)
             assert len(set(ids[i].tolist()) ^ set(one_ids.tolist())) <= 2, (metric, i)
     c.close()
+
+
+@pytest.mark.parametrize("vt_name,dim", (("f32", 1536), ("bf16", 3072)))
+def test_long_rows_batch_10m(env, vt_name, dim):
+    """10M x 1536 f32 (61 GB + a 31 GB tile-major bf16 shadow copy) / 10M x 3072 bf16 (61 GB + its tile-major copy), 300 queries: rows
+    beyond 1024 elements run vg_batch_hl.hip - the K dimension split over the four wavefronts of a workgroup, 24 / 48 k-steps each,
+    bound pre-pass + eleven filter / exact stages, five query groups - and every list must be the single scan's list within the
+    type's bar (f32: 1e-5 relative; bf16: the f64 arithmetic's float result)."""
+    pkg, torch = env
+    vt = pkg.F32 if vt_name == "f32" else pkg.BF16
+    k, nq = 20, 300
+    c, blocks = _build(pkg, torch, vt, dim, 61)
+    del blocks
+    torch.cuda.empty_cache()
+    qf = np.random.default_rng(62).standard_normal((nq, dim), dtype=np.float32)
+    qs = qf if vt == pkg.F32 else torch.from_numpy(qf).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    for metric in (dg.DOT, dg.L2, dg.COSINE):
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        assert c.last_batch_path() == 4
+        assert np.all(cnt == k) and np.all(np.diff(dist, axis=1) >= 0)
+        for i in range(0, nq, 37):
+            one_ids, one_dist = c.scan_topk(metric, qs[i], k)
+            if vt == pkg.F32:
+                scale = float(np.abs(qf[i]).sum()) * 4.0 if metric == dg.DOT else (1.0 if metric == dg.COSINE else 0.0)
+                assert np.all(np.abs(dist[i] - one_dist) <= 1e-5 * (np.abs(one_dist) + scale) + 1e-6), (metric, i)
+            else:
+                assert np.allclose(dist[i], one_dist, rtol=1e-6, atol=1e-7), (metric, i)
+            assert len(set(ids[i].tolist()) ^ set(one_ids.tolist())) <= 2, (metric, i)
+    c.close()
