@@ -4,6 +4,7 @@ byte-for-byte against the reference extension / golden fixtures.  GPU part (-m g
 against the golden results of the reference's vector_full_scan / vector_quantize_scan."""
 import os
 import sqlite3
+import time
 import subprocess
 import sys
 
@@ -1026,7 +1027,31 @@ def test_parallel_staging_readers_equal_the_single_loop(ext_path, orc, tmp_path,
     got = db.execute(sql, (q.tobytes(),)).fetchall()
     assert got[0][0] == 1000000000 and stats(db)["parallel_reader_passes"] == before["parallel_reader_passes"]
     db.execute("ROLLBACK")
+    db.close()
+    # a TEMP table of the same name shadows main's in the reference's statement - and is invisible to the readers: the single loop
+    db = open_db(path)
+    db.execute("CREATE TEMP TABLE t (id INTEGER PRIMARY KEY, v BLOB)")
+    db.executemany("INSERT INTO temp.t(id, v) VALUES (?, ?)", [(i + 1, rows[i].tobytes()) for i in range(300)])
+    db.execute("INSERT INTO temp.t(id, v) VALUES (777777, ?)", (q.tobytes(),))
+    db.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2')" % dim)
+    before = stats(db)
+    got = db.execute(sql, (q.tobytes(),)).fetchall()
+    assert got[0][0] == 777777 and got[0][1] == 0.0 and stats(db)["parallel_reader_passes"] == before["parallel_reader_passes"]
+    db.close()
+    # a database this connection holds exclusively (locking_mode=EXCLUSIVE after a write): other connections get SQLITE_BUSY - the
+    # readers' probe sees that at once and the single loop stages, without an error and without waiting for a timeout
+    db = open_db(path)
+    db.execute("PRAGMA locking_mode=EXCLUSIVE")
+    db.execute("INSERT INTO t(id, v) VALUES (2000000000, ?)", (q.tobytes(),))
+    before = stats(db)
+    t0 = time.perf_counter()
+    got = db.execute(sql, (q.tobytes(),)).fetchall()
+    assert time.perf_counter() - t0 < 5.0
+    assert got[0][0] == 2000000000 and got[0][1] == 0.0 and stats(db)["parallel_reader_passes"] == before["parallel_reader_passes"]
+    db.execute("DELETE FROM t WHERE id = 2000000000")
+    db.close()
     # a short BLOB is reported like the single loop reports it
+    db = open_db(path)
     db.execute("UPDATE t SET v = x'0011' WHERE id = ?", (int(ids[123456]),))
     db.close()
     db = open_db(path)
