@@ -11,7 +11,7 @@ PMC FETCH_SIZE figure of profiles/pmc_traffic.json - emitted only while that fil
 A "step" is ONE complete query: upload the query, scan the whole shard, reduce to k candidates, bring the k keys back
 and decode them - what vector_full_scan's xFilter costs once the corpus is staged.
 
-The same run appends (N = 1, default workload only; --no-also skips them, --also filter,c3,c5,matrix,c4 picks):
+The same run appends (N = 1, default workload only; --no-also skips them, --also filter,c3,c5,matrix,c4,long picks):
   filter_scan  the SAME queries over the SAME corpus through the product's default path for a corpus of this size: the lower-bound
                filter over an int8 shadow copy + exact f32 re-evaluation of the candidates (vg_scan_filter.h).  It answers the
                f32 question with the f32 scan's rowids and distance bits but STREAMS int8: its rate is priced on the bytes it
@@ -23,6 +23,8 @@ The same run appends (N = 1, default workload only; --no-also skips them, --also
   also.c5      1024 queries x 10M x 384 f32 dot top-20 (configs[4]): own roofline (7.864 TFLOP per launch against the
                157.3 TF f32 MFMA peak, the f32 matrix-core kernel) and cpu_baseline; filter_batch (the product's default for a
                corpus of this size: bf16 matrix-core filter + exact f32 re-evaluation, priced on the bf16 peak)
+  also.long_rows       1024 queries x 10M x 1536 f32 dot top-20 (not a BASELINE config): the K-split matrix-core kernel for rows of
+               1025 .. 3072 elements, priced on the bf16 peak, with `against_single_scans` (what such batches were before)
   also.kernel_matrix   f16 / bf16 / int8 x L2 / cosine at 10M x 384 through their PLAIN kernels: frac of the HBM peak each
   also.c4_one_gpu      north_star's target sentence: 100M x 384 f32 L2 resident on ONE device, the plain kernel
 
@@ -88,7 +90,7 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=1024, help="queries per batch (workload c5)")
     ap.add_argument("--no-also", action="store_true", help="default workload: skip the filter_scan / c3 / c5 sub-results")
-    ap.add_argument("--also", default="filter,c3,c5,matrix,c4,c1", help="default workload: which sub-results to append (filter,c3,c5,matrix,c4,c1)")
+    ap.add_argument("--also", default="filter,c3,c5,matrix,c4,long,c1", help="default workload: which sub-results to append (filter,c3,c5,matrix,c4,long,c1)")
     ap.add_argument("--inprocess", action="store_true",
                     help="--gpus N in ONE process: the product's own multi-device form (vg_shards: block-cyclic deal over the N devices, "
                          "candidate gather by host copies and by one grouped RCCL all-gather), timed per query, same JSON contract")
@@ -1048,7 +1050,7 @@ def main():
     if n_gpus == 1 and args.workload == "c2" and "filter" in also_set:
         # ---- the same queries through the filter scan (the product's default path for this corpus)
         out["filter_scan"] = filter_scan_object(args, pkg, corpus, runner, metric, vt, dim, n_rows, plain_last)
-    if n_gpus == 1 and args.workload == "c2" and (also_set & {"c3", "c5", "matrix", "c4", "c1"}):
+    if n_gpus == 1 and args.workload == "c2" and (also_set & {"c3", "c5", "matrix", "c4", "long", "c1"}):
         # ---- configs[2] over its own corpus, then configs[4] over the f32 corpus (the MFMA-bound batch after the HBM-bound
         # lines: they are not timed on a package it has just heated), then the plain-kernel matrix and 100M x 384 on this device
         also = {}
@@ -1067,6 +1069,8 @@ def main():
         torch.cuda.empty_cache()
         if "matrix" in also_set:
             also["kernel_matrix"] = also_kernel_matrix(args, pkg, torch, shard, n_rows, k, device_index)
+        if "long" in also_set:
+            also["long_rows"] = also_long_rows(args, pkg, torch, k, device_index)
         if "c1" in also_set:
             also["c1"] = also_c1(args, pkg, torch)
         out["also"] = also
@@ -1158,6 +1162,24 @@ def also_c3(args, pkg, torch, shard, also_set, n_rows, k, nq, device_index):
                 line["nibble_filter_probe"] = {"error": repr(e)}
         c3.close()
         return line
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def also_long_rows(args, pkg, torch, k, device_index):
+    """not a BASELINE config: 1024 queries x 10M x 1536 f32 dot top-20 - rows longer than a wavefront's registers hold, the K dimension
+    split over a workgroup's wavefronts (vg_batch_hl.hip) - next to one scan per query, which is what such batches were until round 4"""
+    try:
+        vt, np_dtype, dim, metric, desc = WORKLOADS["c5l"]
+        n_rows = args.rows if args.rows else 10_000_000
+        c = make_shard(pkg, torch, vt, dim, n_rows, 77, device_index)
+        c.set_profiling(True)
+        try:
+            line = run_batched(args, pkg, torch, c, "c5l", n_rows, dim, metric, k, desc if n_rows == 10_000_000 else desc.replace("10M", "%gM" % (n_rows / 1e6)))
+        finally:
+            c.close()
+            torch.cuda.empty_cache()
+        return {kk: line[kk] for kk in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "against_single_scans") if kk in line}
     except Exception as e:
         return {"error": repr(e)}
 

@@ -740,6 +740,32 @@ def test_batch_tvf_equals_one_statement_per_query(ext_path, metric):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("metric", [dg.L2, dg.DOT, dg.COSINE])
+def test_batch_tvf_over_1536_dimensional_rows(ext_path, metric):
+    """vector_full_scan_batch over 1536-dimensional f32 vectors (rows longer than the half-precision matrix-core kernel's registers
+    hold: vg_batch_hl.hip splits the K dimension over a workgroup's wavefronts): the same rows as one vector_full_scan per query -
+    including a query of zeros and one with a NaN, which leave the matrix pass and get scans of their own."""
+    n, dim, k, nq = 6000, 1536, 8, 40
+    rows = dg.corpus(dg.F32, n, dim, 23)
+    qs = np.stack([dg.query(dg.F32, dim, 300 + i) for i in range(nq)])
+    qs[5] = 0.0
+    qs[6, 100] = np.float32(np.nan)
+    qs[7] = rows[1234]
+    db = connect(ext_path)
+    load_table(db, rows, dg.F32, metric)
+    got = db.execute("SELECT query, id, distance FROM vector_full_scan_batch('t','v',?,?)", (qs.tobytes(), k)).fetchall()
+    assert [g[0] for g in got] == sorted(g[0] for g in got)
+    for i in range(nq):
+        one = db.execute("SELECT id, distance FROM vector_full_scan('t','v',?,?)", (qs[i].tobytes(), k)).fetchall()
+        mine = [(g[1], g[2]) for g in got if g[0] == i]
+        assert len(one) == (k if i != 6 else 0)                           # (a NaN query: every distance is NaN, none is kept)
+        assert [m[0] for m in mine] == [o[0] for o in one], i
+        assert np.allclose([m[1] for m in mine], [o[1] for o in one], rtol=1e-5, atol=1e-5 if metric != dg.L2 else 1e-7, equal_nan=True), i
+    if metric != dg.DOT:
+        assert [g[1] for g in got if g[0] == 7][0] == 1235
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("vt", [dg.F16, dg.BF16])
 def test_half_precision_batch_tvf_equals_one_statement_per_query(ext_path, vt):
     """f16 / bf16 tables: the batch takes the matrix-core filter + exact re-evaluation (vg_batch_h.hip) and must give
