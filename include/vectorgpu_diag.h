@@ -57,6 +57,11 @@ int vg_shards_gather_stats(vg_shards *s, unsigned long long *out2);
  * replay (k > 64, rows too long for an emitting kernel, candidate-stream overflow) */
 int vg_corpus_tie_stats(const vg_corpus *c, unsigned long long *out4);
 int vg_shards_tie_stats(const vg_shards *s, unsigned long long *out4);
+/* bytes a corpus (all shards of a vg_shards handle) holds on its device(s), by allocation size: out3[0] the row matrix, [1] per-row data
+ * derived from it (the filter scans' shadow copies, the batch kernels' tile-major copies, norms, row statistics), [2] working buffers.
+ * The extension reports them through vector_gpu_memory(table, column). */
+int vg_corpus_device_bytes(const vg_corpus *c, long long *out3);
+int vg_shards_device_bytes(const vg_shards *s, long long *out3);
 /* building blocks (what vg_shards composes over several devices): all N distances of a query left in device memory
  * (enqueued, no wait); rows [pos0, pos0 + n) of them; every row >= pos0 whose distance is < bound as
  * (position << 32 | float bits) pairs in any order - *out_count may exceed cap, then only cap pairs were written. */

@@ -123,6 +123,8 @@ def lib():
         "vg_shards_set_gather": (i32, [vp, i32]),
         "vg_shards_gather_stats": (i32, [vp, vp]),
         "vg_shards_tie_stats": (i32, [vp, vp]),
+        "vg_corpus_device_bytes": (i32, [vp, vp]),
+        "vg_shards_device_bytes": (i32, [vp, vp]),
         "vg_shards_rowids": (i32, [vp, i64, i64, vp]),
         "vg_scan_topk_reference": (i32, [vp, i32, vp, i32, vp, vp, C.POINTER(i32)]),
         "vg_stat_rows_appended": (C.c_longlong, []),
@@ -301,6 +303,12 @@ class Corpus:
     def delete_rows(self, positions):
         positions = np.ascontiguousarray(positions, dtype=np.int64)
         _check(lib().vg_corpus_delete_rows(self.h, _ptr(positions), positions.shape[0]))
+
+    def device_bytes(self):
+        """(row matrix, derived per-row copies / statistics, working buffers) in bytes on the device"""
+        out = np.zeros(3, dtype=np.int64)
+        _check(lib().vg_corpus_device_bytes(self.h, _ptr(out)))
+        return tuple(int(x) for x in out)
 
     def last_batch_path(self):
         """1 f32 matrix-core kernel, 2 int8, 3 half-precision kernel, 4 its long-row form, 5 multi-query scan, 6 one scan per query"""

@@ -164,6 +164,28 @@ extern "C" int vg_corpus_dim(const vg_corpus *c) { return c ? c->dim : 0; }
 extern "C" int vg_corpus_type(const vg_corpus *c) { return c ? c->vtype : 0; }
 extern "C" int vg_corpus_device(const vg_corpus *c) { return c ? c->device : -1; }
 extern "C" int64_t vg_corpus_hbm_bytes(const vg_corpus *c) { return c ? c->cap_rows * c->stride : 0; }
+// what this corpus holds on its device, by allocation (the runtime knows every allocation's size): [0] the row matrix, [1] per-row data
+// derived from it - shadow copies of the filter scans, tile-major copies of the batch kernels, norms and row statistics - [2] working
+// buffers (queries, candidate lists, distances, pair regions, staging)
+extern "C" int vg_corpus_device_bytes(const vg_corpus *c, long long *out3) {
+    if (!c || !out3) return vg_fail(VG_ERR_INVALID, "vg_corpus_device_bytes: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    auto size_of = [](const void *p) -> long long {
+        if (!p) return 0;
+        size_t n = 0;
+        if (hipMemPtrGetInfo(const_cast<void *>(p), &n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        return (long long)n;
+    };
+    out3[0] = size_of(c->d_rows);
+    const void *derived[] = {c->d_rows_s8, c->d_sx, c->d_rows_tm, c->d_rows_bf, c->d_rows_q8, c->d_q8stat, c->d_rows_n4, c->d_n4stat, c->d_xnorm};
+    const void *working[] = {c->d_query, c->d_cand, c->d_cand_pre, c->d_keys, c->d_dist, c->d_below, c->d_ref_prefix, c->d_sel_keys, c->d_sel_sorted,
+                             c->d_sel_temp, c->d_sel_state, c->d_stage, c->d_filter_evals, c->d_bq, c->d_bcand, c->d_bkeys, c->d_bpairs, c->d_bpcounts};
+    out3[1] = 0; out3[2] = 0;
+    for (const void *p : derived) out3[1] += size_of(p);
+    for (const void *p : working) out3[2] += size_of(p);
+    return VG_OK;
+}
+
 extern "C" int vg_corpus_set_rowid_base(vg_corpus *c, int64_t base) {
     if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
     c->rowid_base = base;

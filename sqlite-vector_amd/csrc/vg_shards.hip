@@ -602,6 +602,19 @@ static int shards_scan_topk_fused(vg_shards *s, int metric, const void *query, i
     return shards_scan_topk_reference(s, metric, query, k, out_rowids, out_dist, out_count);
 }
 
+extern "C" int vg_corpus_device_bytes(const vg_corpus *c, long long *out3);
+extern "C" int vg_shards_device_bytes(const vg_shards *s, long long *out3) {
+    if (!s || !out3) return fail(VG_ERR_INVALID, "vg_shards_device_bytes: NULL argument");
+    out3[0] = out3[1] = out3[2] = 0;
+    for (int i = 0; i < s->S; ++i) {
+        long long one[3] = {0, 0, 0};
+        const int rc = vg_corpus_device_bytes(s->sh[(size_t)i], one);
+        if (rc != VG_OK) return rc;
+        for (int j = 0; j < 3; ++j) out3[j] += one[j];
+    }
+    return VG_OK;
+}
+
 extern "C" int vg_shards_tie_stats(const vg_shards *s, unsigned long long *out4) {
     if (!s || !out4) return fail(VG_ERR_INVALID, "vg_shards_tie_stats: NULL argument");
     if (s->S == 1) return vg_corpus_tie_stats(s->sh[0], out4);

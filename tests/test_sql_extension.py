@@ -740,6 +740,35 @@ def test_batch_tvf_equals_one_statement_per_query(ext_path, metric):
 
 
 @pytest.mark.gpu
+def test_vector_gpu_memory_reports_what_the_device_holds(ext_path):
+    """vector_gpu_memory(table, column): the row matrix, the per-row copies derived from it and the working buffers, per staged copy
+    (raw column / persisted quantization) - vector_quantize_memory keeps the reference's meaning"""
+    import json
+    n, dim = 3000, 384
+    rows = dg.corpus(dg.F32, n, dim, 5)
+    db = connect(ext_path)
+    load_table(db, rows, dg.F32, dg.COSINE)
+    m0 = json.loads(db.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
+    assert m0["column"]["staged"] == 0 and m0["total_bytes"] == 0
+    db.execute("SELECT rowid FROM vector_full_scan('t','v',?,5)", (rows[7].tobytes(),)).fetchall()
+    m1 = json.loads(db.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
+    assert m1["column"]["staged"] == 1 and m1["column"]["rows_bytes"] >= n * dim * 4 and m1["column"]["working_bytes"] > 0
+    assert m1["column"]["derived_bytes"] == 0 and m1["quantized"]["staged"] == 0   # (a small corpus: no shadow copy, norms computed in flight)
+    db.execute("SELECT count(*) FROM vector_full_scan_batch('t','v',?,5)", (rows[:9].tobytes(),)).fetchone()
+    m1b = json.loads(db.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
+    assert m1b["column"]["derived_bytes"] >= n * 4                             # the batch kernel's cached row norms
+    assert m1b["column"]["working_bytes"] > m1["column"]["working_bytes"]      # ... and its query / candidate buffers
+    db.execute("SELECT vector_quantize('t','v')")
+    db.execute("SELECT vector_quantize_preload('t','v')")
+    m2 = json.loads(db.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
+    assert m2["quantized"]["staged"] == 1 and m2["quantized"]["rows_bytes"] >= n * dim
+    assert m2["total_bytes"] == sum(m2[c][f] for c in ("column", "quantized") for f in ("rows_bytes", "derived_bytes", "working_bytes"))
+    assert db.execute("SELECT vector_quantize_memory('t','v')").fetchone()[0] == n * (dim + 8)     # the reference's number: the persisted records
+    with pytest.raises(sqlite3.OperationalError, match="vector_init"):
+        db.execute("SELECT vector_gpu_memory('nope','v')").fetchone()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("metric", [dg.L2, dg.DOT, dg.COSINE])
 def test_batch_tvf_over_1536_dimensional_rows(ext_path, metric):
     """vector_full_scan_batch over 1536-dimensional f32 vectors (rows longer than the half-precision matrix-core kernel's registers
