@@ -949,6 +949,39 @@ def test_device_appends_and_cross_stream_scan(pkg, orc):
     c.close()
 
 
+@pytest.mark.parametrize("vt", [dg.F32, dg.BF16])
+def test_in_process_shards_long_row_batches(pkg, vt):
+    """a batch over 1536-dimensional rows dealt over three logical shards: every shard answers through the long-row matrix-core
+    kernel (vg_batch_hl.hip) and the merged lists are the single corpus' lists - also in the reference's result order (bf16: the
+    batch keys are the single scan's floats, one more slot and a look for ties; f32: query by query)."""
+    dim, n, nq, k = 1536, 9_000, 40, 10
+    rows = dg.corpus(vt, n, dim, 63)
+    rows[7000] = rows[11]                                   # an exact duplicate in another shard: a tie at distance 0
+    qs = dg.corpus(vt, nq, dim, 64)
+    qs[3] = rows[11]
+    one = pkg.Corpus(vt, dim)
+    one.append(rows)
+    sh = pkg.Shards(vt, dim, [0, 0, 0], block_rows=1000)
+    sh.append(rows)
+    for metric in (dg.COSINE, dg.L2):
+        a = one.scan_topk_batch(metric, qs, k)
+        assert one.last_batch_path() == 4
+        b = sh.scan_topk_batch(metric, qs, k)
+        assert np.array_equal(a[2], b[2])
+        for i in range(nq):
+            _same_topk_up_to_ties(b[0][i], b[1][i], a[0][i], a[1][i], rtol=1e-5)
+        assert b[0][3][:2].tolist() == [12, 7001]
+    for c in (one, sh):
+        c.set_tie_order(pkg.TIE_REFERENCE)
+    a = one.scan_topk_batch(dg.L2, qs, k)
+    b = sh.scan_topk_batch(dg.L2, qs, k)
+    for i in range(nq):
+        one_ids, one_d = one.scan_topk(dg.L2, qs[i], k)
+        assert a[0][i].tolist() == one_ids.tolist() and b[0][i].tolist() == one_ids.tolist(), i
+        assert np.array_equal(a[1][i], one_d) and np.array_equal(b[1][i], one_d), i
+    one.close(); sh.close()
+
+
 @pytest.mark.parametrize("vt,metric", [(dg.F32, dg.L2), (dg.U8, dg.COSINE), (dg.I8, dg.L1), (dg.F32, dg.DOT)])
 def test_in_process_shards_equal_a_single_corpus(pkg, orc, vt, metric):
     """vg_shards (one logical corpus dealt block-cyclically over several devices of one process - here three logical
