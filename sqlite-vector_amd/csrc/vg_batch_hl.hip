@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
     // behind barrier i+1, which every wavefront reaches with its reads of tile i done.
     bool have_prev = false;
     float nn_prev = 0.0f;
-    long long row_prev = 0;
+    long long tile_prev = 0;                                           // (wave-uniform; the row is made from it and the lane where it is used)
     int par_prev = 0;
     // (in two halves: the barrier and the LDS reads - and, VGHL_MEET_GAP k-steps of MFMAs later, when they have landed, the sums, the gate
     // and the pairs)
@@ -209,15 +209,21 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
 #pragma unroll
             for (int src = 0; src < VGHL_WAVES; ++src) met[j4][src] = red_r[(src * QS * 4 + wave * QS + j4) * 64 + lane];
     };
+    // (... then one register group's sums per k-step - pairs of floats as they lie in the registers: v_pk_add_f32 without shuffles - and
+    // the gate: a burst of ~100 VALU instructions between two MFMAs idles the matrix pipe of a SIMD with one wavefront, spread over the
+    // k-steps they run in the MFMAs' shadow)
+    typedef float vghl_f2 __attribute__((ext_vector_type(2)));
+    float fin[F];
+    auto sum_prev = [&](auto jc) __attribute__((always_inline)) {
+        constexpr int j4 = decltype(jc)::value;
+        const vghl_f2 lo = (vghl_f2{met[j4][0].x, met[j4][0].y} + vghl_f2{met[j4][1].x, met[j4][1].y}) + (vghl_f2{met[j4][2].x, met[j4][2].y} + vghl_f2{met[j4][3].x, met[j4][3].y});
+        const vghl_f2 hi = (vghl_f2{met[j4][0].z, met[j4][0].w} + vghl_f2{met[j4][1].z, met[j4][1].w}) + (vghl_f2{met[j4][2].z, met[j4][2].w} + vghl_f2{met[j4][3].z, met[j4][3].w});
+        fin[4 * j4] = lo.x; fin[4 * j4 + 1] = lo.y; fin[4 * j4 + 2] = hi.x; fin[4 * j4 + 3] = hi.y;
+    };
     auto finish_prev = [&]() __attribute__((always_inline)) {
-        float fin[F];
-#pragma unroll
-        for (int j4 = 0; j4 < QS; ++j4) {
-            fin[4 * j4] = (met[j4][0].x + met[j4][1].x) + (met[j4][2].x + met[j4][3].x);
-            fin[4 * j4 + 1] = (met[j4][0].y + met[j4][1].y) + (met[j4][2].y + met[j4][3].y);
-            fin[4 * j4 + 2] = (met[j4][0].z + met[j4][1].z) + (met[j4][2].z + met[j4][3].z);
-            fin[4 * j4 + 3] = (met[j4][0].w + met[j4][1].w) + (met[j4][2].w + met[j4][3].w);
-        }
+        uint32_t x_now;                                                  // lane & 31, made HERE: as a loop invariant it is spilled, and its reload drains the load ring
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_and_b32 %0, 31, %0" : "=v"(x_now));
+        const long long row_prev = tile_prev * VGH_TILE + x_now;
         // ---- the gate (vg_batch_h.hip): fin + init + gmul * lane_term >= 0
         const bool force = !(nn_prev >= VGH_NORM_LO && nn_prev <= VGH_NORM_HI);      // NaN / Inf / zero / out of range
         const float lane_term = force ? 0.0f : (L2M ? 0.5f * (1.0f - cerr) * nn_prev : sqrtf(nn_prev));
@@ -302,12 +308,16 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
             vgb_static_for<0, QS>([&](auto sc) __attribute__((always_inline)) { constexpr int s = decltype(sc)::value; acc[s] = vgh_mfma<FT>(areg[s][t], b, acc[s]); });
             if constexpr (!(VGHL_ABLATE & 2)) breg[d][t] = load_b(rs_next, tc);     // the same k-step of the tile DEPTH ahead
         };
-        constexpr int P2 = (P + VGHL_MEET_GAP < NTBP) ? P + VGHL_MEET_GAP : NTBP;
-        vgb_static_for<0, P>(k_step);
-        if constexpr ((VGHL_ABLATE & 1) == 0) { if (have_prev) meet_prev(); }
-        vgb_static_for<P, P2>(k_step);
-        if constexpr ((VGHL_ABLATE & 1) == 0) { if (have_prev) finish_prev(); }
-        vgb_static_for<P2, NTBP>(k_step);
+        constexpr int P2 = P + VGHL_MEET_GAP;                            // (NTBP >= 24: P2 + QS < NTBP)
+        vgb_static_for<0, NTBP>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr ((VGHL_ABLATE & 1) == 0) {
+                if constexpr (t == P) { if (have_prev) meet_prev(); }
+                if constexpr (t >= P2 && t < P2 + QS) { if (have_prev) sum_prev(std::integral_constant<int, t - P2>{}); }
+                if constexpr (t == P2 + QS) { if (have_prev) finish_prev(); }
+            }
+            k_step(tc);
+        });
         if constexpr ((VGHL_ABLATE & 1) != 0) {
             asm volatile("" :: "v"(acc[0][0]), "v"(acc[0][15]), "v"(acc[QS - 1][0]), "v"(acc[QS - 1][15]));     // (keep the MFMA chains alive)
             return;
@@ -320,14 +330,16 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
             for (int q4 = 0; q4 < 4; ++q4)
                 red_w[(s * 4 + q4) * 64 + lane] = make_float4(acc[s][4 * q4], acc[s][4 * q4 + 1], acc[s][4 * q4 + 2], acc[s][4 * q4 + 3]);
         });
-        have_prev = true; nn_prev = nn_row; row_prev = tile * VGH_TILE + x; par_prev = (int)(ti & 1);
+        have_prev = true; nn_prev = nn_row; tile_prev = tile; par_prev = (int)(ti & 1);
     };
     for (long long tile0 = tile_first; tile0 < tile_last; tile0 += DEPTH) {
         vgb_static_for<0, DEPTH>([&](auto dc) __attribute__((always_inline)) {
             if (tile0 + decltype(dc)::value < tile_last) do_tile(tile0 + decltype(dc)::value, dc);     // (wave- and workgroup-uniform)
         });
     }
-    if constexpr ((VGHL_ABLATE & 1) == 0) { if (have_prev) { meet_prev(); finish_prev(); } }
+    if constexpr ((VGHL_ABLATE & 1) == 0) {
+        if (have_prev) { meet_prev(); vgb_static_for<0, QS>([&](auto jc) __attribute__((always_inline)) { sum_prev(jc); }); finish_prev(); }
+    }
     if constexpr (!BOUND) {
         if (lane == 0) a.pair_counts[region] = n_pairs < (unsigned)a.pair_cap ? n_pairs : (unsigned)a.pair_cap;
     } else {
