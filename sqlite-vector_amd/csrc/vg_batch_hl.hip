@@ -36,6 +36,9 @@
 #ifndef VGHL_ABLATE
 #define VGHL_ABLATE 0                   // measurement builds (wrong results): 1 = no meeting in LDS / gate, 2 = no loads in the tile loop, 3 = neither
 #endif
+#ifndef VGHL_MEET_AT
+#define VGHL_MEET_AT(NTBP) ((NTBP) / 2)   // the k-step in front of which the previous tile's partial scores meet (barrier + LDS reads)
+#endif
 #ifndef VGHL_MEET_GAP
 #define VGHL_MEET_GAP 3                 // k-steps of MFMAs between the LDS reads of the previous tile's partial scores and their use
 #endif
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
     };
     auto do_tile = [&](long long tile, auto dc) __attribute__((always_inline)) {
         constexpr int d = decltype(dc)::value;
-        constexpr int P = NTBP / 2;                                      // k-steps in front of the previous tile's meeting
+        constexpr int P = VGHL_MEET_AT(NTBP);                            // k-steps in front of the previous tile's meeting
         const long long ti = tile - tile_first;
         const long long tile_next = min(tile + DEPTH, tile_last - 1);
         const __amdgpu_buffer_rsrc_t rs_next = tile_rsrc(tile_next);

@@ -654,6 +654,26 @@ def test_batch_long_rows_matrix_core_path(pkg, orc, vt, metric, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("vt", [dg.F32, dg.F16])
+def test_batch_long_rows_tiny_corpora(pkg, vt):
+    """fewer rows than one 32-row tile, fewer than k, one row more than a tile; more queries than one workgroup holds; k = 32 (the
+    kernels' largest) and k = 33 (one more: the old path)"""
+    dim = 1536
+    for n in (1, 10, 31, 33, 70):
+        rows = dg.corpus(vt, n, dim, 7800 + n)
+        qs = dg.corpus(vt, 97, dim, 7900 + n)
+        c = pkg.Corpus(vt, dim)
+        c.append(rows)
+        for k in (1, 20, 32, 33):
+            ids, dist, cnt = c.scan_topk_batch(dg.L2, qs, k)
+            assert c.last_batch_path() == (4 if k <= 32 else (5 if vt == dg.F32 else 6)), (n, k, c.last_batch_path())
+            assert np.all(cnt == min(k, n))
+            for i in (0, 31, 32, 64, 96):
+                one_ids, one_dist = c.scan_topk(dg.L2, qs[i], k)
+                _same_topk_up_to_ties(ids[i][:cnt[i]], dist[i][:cnt[i]], one_ids, one_dist, rtol=1e-5)
+        c.close()
+
+
 @pytest.mark.parametrize("vt", [dg.F32, dg.BF16])
 def test_batch_long_rows_staged_passes_and_partitions(pkg, vt, monkeypatch):
     """a corpus large enough for the long-row kernel's bound pre-pass, several stages and more than one tile per partition, two
