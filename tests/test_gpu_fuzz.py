@@ -64,6 +64,8 @@ def test_random_batches_vs_single_scans(pkg, chunk):
         vt = int(rng.choice([dg.F32, dg.U8, dg.I8, dg.F16, dg.BF16]))
         metric = int(rng.choice(dg.ALL_METRICS))
         dim = int(rng.integers(1, 513)) if vt == dg.F32 else (int(rng.integers(1, 2200)) if vt in (dg.U8, dg.I8) else int(rng.integers(1, 1100)))
+        if vt in (dg.F32, dg.F16, dg.BF16) and rng.integers(0, 3) == 0:      # long rows: 513 .. 1024 (f32 through the bf16 filter), 1025 .. 3072
+            dim = int(rng.integers(513, 3300))                               # (the K-split kernel), beyond (the scans)
         n = int(rng.choice([rng.integers(1, 100), rng.integers(100, 5000), rng.integers(5000, 30000)]))
         nq = int(rng.choice([1, 3, 33, 129, 260]))
         k = int(rng.choice([1, 5, 20, 32, 40]))
