@@ -40,7 +40,7 @@
 #define VGHL_MEET_AT(NTBP) ((NTBP) / 2)   // the k-step in front of which the previous tile's partial scores meet (barrier + LDS reads)
 #endif
 #ifndef VGHL_MEET_GAP
-#define VGHL_MEET_GAP 3                 // k-steps of MFMAs between the LDS reads of the previous tile's partial scores and their use
+#define VGHL_MEET_GAP 6                 // k-steps of MFMAs between the LDS reads of the previous tile's partial scores and their use (3: + 2 %, profiles/r7s)
 #endif
 #ifndef VGHL_DEPTH
 #define VGHL_DEPTH(NTBP) ((NTBP) <= 32 ? 2 : 1)     // tiles of B in flight per wavefront (registers: DEPTH x NTBP x 4 next to A's QS x NTBP x 4)
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
             vgb_static_for<0, QS>([&](auto sc) __attribute__((always_inline)) { constexpr int s = decltype(sc)::value; acc[s] = vgh_mfma<FT>(areg[s][t], b, acc[s]); });
             if constexpr (!(VGHL_ABLATE & 2)) breg[d][t] = load_b(rs_next, tc);     // the same k-step of the tile DEPTH ahead
         };
-        constexpr int P2 = P + VGHL_MEET_GAP;                            // (NTBP >= 24: P2 + QS < NTBP)
+        constexpr int P2 = P + VGHL_MEET_GAP;
+        static_assert(P2 + QS < NTBP, "the meeting's steps must lie inside the k loop");
         vgb_static_for<0, NTBP>([&](auto tc) __attribute__((always_inline)) {
             constexpr int t = decltype(tc)::value;
             if constexpr ((VGHL_ABLATE & 1) == 0) {
