@@ -173,6 +173,41 @@ def test_c5_1024_queries_both_batch_paths_equal_the_reference_kernels(env, orc, 
     c.close()
 
 
+def test_long_rows_batch_equals_the_reference_kernels(env, orc):
+    """2M x 1536 f32 (the row length of common embedding models; rows longer than a wavefront's registers hold: vg_batch_hl.hip splits
+    the K dimension over a workgroup), a 256-query batch, dot / cosine / L2: rowids and distances against the REFERENCE's own kernel +
+    top-k loop over every row (same check as C2 / C5: every rank whose neighbours are separated by more than the f32 bar must be the
+    reference's rowid)."""
+    pkg, torch = env
+    dim, n, k, nq, blk = 1536, 2_000_000, 20, 256, 250_000
+    qs = np.random.default_rng(46).standard_normal((nq, dim), dtype=np.float32)
+    sample = list(range(0, nq, 32))                                         # 8 queries
+    metrics = (dg.DOT, dg.COSINE, dg.L2)
+    scanners = {m: RefScanner(orc, m, qs[sample], k + 1) for m in metrics}
+    pinned = torch.empty((blk, dim), dtype=torch.float32).pin_memory()
+    c = pkg.Corpus(pkg.F32, dim, capacity=n)
+    gen = torch.Generator(device="cuda")
+    for b in range(n // blk):
+        gen.manual_seed(4600 + b)
+        t = torch.randn((blk, dim), generator=gen, device="cuda", dtype=torch.float32)
+        torch.cuda.synchronize()
+        c.append_device(t.data_ptr(), blk, dim * 4)
+        pinned.copy_(t)
+        torch.cuda.synchronize()
+        for m in metrics:
+            scanners[m].feed(pinned.numpy(), b * blk)
+        del t
+    checked = 0
+    for m in metrics:
+        ids, dist, cnt = c.scan_topk_batch(m, qs, k)
+        assert c.last_batch_path() == 4 and np.all(cnt == k) and np.all(np.diff(dist, axis=1) >= 0)
+        for j, qi in enumerate(sample):
+            scale = float(np.abs(qs[qi]).sum()) * 4.0 if m == dg.DOT else (1.0 if m == dg.COSINE else 0.0)
+            checked += check_against_reference((m, qi), ids[qi], dist[qi], scanners[m].result(j), k, lambda d: 1e-5 * (abs(d) + scale))
+    assert checked >= len(metrics) * len(sample) * (k - 4), checked
+    c.close()
+
+
 def test_c4_100m_one_corpus_equals_8_logical_shards_equals_the_reference(env, orc):
     """config C4's corpus (100M x 384 f32 = 153.6 GB) resident on ONE MI355X: the single-corpus scan, the 8-shard scan (contiguous
     row ranges of 12.5M rows, one corpus each, candidate keys merged by shard.row_offsets + vg_merge_keys - the exact host code
