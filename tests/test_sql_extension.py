@@ -1161,6 +1161,20 @@ def test_quantize_stages_in_front_of_its_transaction_and_reserves_by_key_span(ex
     assert s2["rows_staged"] == s1["rows_staged"]                            # the full scan behind it: the copy is still current
     _, _, _, full_1, quant_1 = run("1", True)
     assert full_p == full_1 and quant_p == quant_1
+    # a vector_quantize that fails BEHIND its staging pass (a bad option string) must not leave that copy trusted: a row this connection
+    # inserts afterwards moves no data_version - the next scan has to see it
+    monkeypatch.setenv("VECTORGPU_STAGE_THREADS", "4")
+    db = sqlite3.connect(path, isolation_level=None)
+    db.enable_load_extension(True)
+    db.load_extension(ext_path)
+    db.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2')" % dim)
+    with pytest.raises(sqlite3.Error, match="quantization type"):
+        db.execute("SELECT vector_quantize('t', 'v', 'qtype=BOGUS')").fetchone()
+    db.execute("INSERT INTO t(id, v) VALUES (5000000, ?)", (q.tobytes(),))
+    got = db.execute("SELECT rowid, distance FROM vector_full_scan('t', 'v', ?, 3)", (q.tobytes(),)).fetchall()
+    assert got[0] == (5000000, 0.0)
+    db.execute("DELETE FROM t WHERE id = 5000000")
+    db.close()
     # inside a transaction vector_quantize fails like the reference's (its own BEGIN), with nothing staged in front of it
     monkeypatch.setenv("VECTORGPU_STAGE_THREADS", "4")
     db = sqlite3.connect(path, isolation_level=None)
