@@ -40,6 +40,7 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
                                  uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, hipStream_t stream);
 extern "C" int vg_batch_h_split(long long stride_bytes, int k);        // vg_batch_h.hip: the split form is on for such rows
 #define VG_BPAIR_CAP 2048               // candidate pairs per filter wavefront and stage (a batch that overflows one falls back to the fused kernel)
+#define VG_BPAIR_CAP_LONG 8192          // ... of the long-row kernel (64 KB per region, 1024 regions: its fallback is one scan per query)
 extern "C" int vg_tile_major_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, uint8_t *dev_out, hipStream_t stream);
 extern "C" int vg_f32_to_bf16_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int dim,
                                      uint8_t *dev_out, long long ostride, hipStream_t stream);
@@ -258,7 +259,7 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
     if (c->bkeys_bytes < keybytes) { if (c->d_bkeys) hipFree(c->d_bkeys); c->d_bkeys = nullptr; c->bkeys_bytes = 0;
                                      HIP_TRY(hipMalloc(&c->d_bkeys, keybytes)); c->bkeys_bytes = keybytes; }
     const int n_regions = vg_batch_hl_regions(fstride, nq_pad, npart);
-    const size_t need = (size_t)n_regions * VG_BPAIR_CAP * sizeof(uint64_t), needc = ((size_t)n_regions + 1) * sizeof(uint32_t);
+    const size_t need = (size_t)n_regions * VG_BPAIR_CAP_LONG * sizeof(uint64_t), needc = ((size_t)n_regions + 1) * sizeof(uint32_t);
     if (c->bpairs_bytes < need) { if (c->d_bpairs) hipFree(c->d_bpairs); c->d_bpairs = nullptr; c->bpairs_bytes = 0;
                                   HIP_TRY(hipMalloc(&c->d_bpairs, need)); c->bpairs_bytes = need; }
     if (c->bpcount_bytes < needc) { if (c->d_bpcounts) hipFree(c->d_bpcounts); c->d_bpcounts = nullptr; c->bpcount_bytes = 0;
@@ -272,7 +273,12 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
     for (int i = 0; i < nq; ++i) {
         const uint8_t *q = (const uint8_t *)queries + (size_t)i * row_bytes;
         const double n2 = host_query_norm2(c, q);
-        if (!(n2 >= 1.0e-30 && n2 <= 1.0e30)) { unjudged.push_back(i); continue; }
+        if (!(n2 >= 1.0e-30 && n2 <= 1.0e30)) {            // (its slot: a zero row and the norm -1 = "never passes")
+            unjudged.push_back(i);
+            const float gone = -1.0f;
+            memcpy(hq.data() + qrows + (size_t)i * sizeof(float), &gone, sizeof(float));
+            continue;
+        }
         memcpy(hq.data() + (size_t)i * c->stride, q, row_bytes);
         const float n2f = (float)n2;
         memcpy(hq.data() + qrows + (size_t)i * sizeof(float), &n2f, sizeof(float));
@@ -289,7 +295,7 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
     const int mode = metric == VG_DIST_DOT ? 0 : (metric == VG_DIST_COSINE ? 1 : 2), root = metric == VG_DIST_L2 ? 1 : 0;
     const int rc = vg_batch_hl_launch(c->d_rows_tm, c->n_rows, fstride, c->dim, f32 ? 2 : (c->vtype == VG_TYPE_BF16 ? 1 : 0), c->d_rows, c->stride,
                                       (const uint8_t *)c->d_bq, nq_pad, nq, k, mode, root, c->d_xnorm, reinterpret_cast<const float *>((const uint8_t *)c->d_bq + qrows),
-                                      c->d_bcand, npart, c->d_bkeys, nullptr, c->d_bpairs, c->d_bpcounts, VG_BPAIR_CAP, c->stream);
+                                      c->d_bcand, npart, c->d_bkeys, nullptr, c->d_bpairs, c->d_bpcounts, VG_BPAIR_CAP_LONG, c->stream);
     if (evs) { hipEventRecord(evs[2], c->stream); hipEventRecord(evs[3], c->stream); }
     if (rc == -1) { hipStreamSynchronize(c->stream); return -1; }
     if (rc != 0) return vg_fail(VG_ERR_HIP, "batched scan launch (long rows) failed: %s", hipGetErrorString((hipError_t)rc));

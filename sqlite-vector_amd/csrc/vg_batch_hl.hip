@@ -74,10 +74,11 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
     // ---- per-query statistics: sum q^2, made by the host once per batch (a loop over the queries here cost every workgroup of every
     // stage ~200 us: profiles/r7d_*); a query the filter cannot judge - Inf / NaN elements, a norm of zero or out of range - is not in
     // the batch at all (vg_batch_api.hip answers it with a scan of its own): its slot holds a zero row and the norm 0
-    if (tid < NQ) qq_l[tid] = a.qnn[q0 + tid];
-    if (tid < NQ) {                                      // thresholds: the pre-pass bound; padding queries never accept
+    if (tid < NQ) {                                      // thresholds: the pre-pass bound; padding queries - and the slots of queries that
+        const float n2 = a.qnn[q0 + tid];                //   left the batch (norm < 0) - never accept
+        qq_l[tid] = fmaxf(n2, 0.0f);
         float t = a.init_keys ? vgb_kth_distance(a.init_keys[(long long)(q0 + tid) * 64 + (k - 1)]) : INFINITY;
-        if (q0 + tid >= a.nq_real) t = -INFINITY;
+        if (q0 + tid >= a.nq_real || n2 < 0.0f) t = -INFINITY;
         thr_l[tid] = t;
     }
     if constexpr (BOUND) {
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
     const float cerr = a.cerr;
     const bool l2_root = a.root != 0;
     float init_f[F], gmul_f[F];
+    uint32_t live = 0u;                                  // bit j: register j's query is a real one (not padding, not taken out of the batch)
     auto set_gate = [&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         const int r = rbase + j, qi = qset0 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -150,7 +152,8 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
         if (thr == -INFINITY) {                          // padding queries never pass
             init_f[j] = COS ? 0.0f : -VGH_ACCEPT;
             gmul_f[j] = COS ? -VGH_ACCEPT : (L2M ? -1.0f : 0.0f);
-        }
+            live &= ~(1u << j);
+        } else live |= 1u << j;
     };
     vgb_static_for<0, F>([&](auto jc) __attribute__((always_inline)) { set_gate(jc); });
 
@@ -228,7 +231,12 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_and_b32 %0, 31, %0" : "=v"(x_now));
         const long long row_prev = tile_prev * VGH_TILE + x_now;
         // ---- the gate (vg_batch_h.hip): fin + init + gmul * lane_term >= 0
-        const bool force = !(nn_prev >= VGH_NORM_LO && nn_prev <= VGH_NORM_HI);      // NaN / Inf / zero / out of range
+        // A row of ZEROS is judged like any other (every product is exactly 0, the bound's |x| term too) - only NaN / Inf / out-of-range
+        // norms send a row's pairs down the exact path whatever their scores: a corpus with a fraction of empty vectors would
+        // otherwise fill the pair regions with them.  Cosine is the exception in form only: the reference gives a zero-norm row the
+        // distance 1.0 (distance-cpu.c:74-110), so its pairs pass iff the query's threshold has not dropped below that.
+        const bool zero_row = (nn_prev == 0.0f);
+        const bool force = !(nn_prev <= VGH_NORM_HI) || (nn_prev < VGH_NORM_LO && !zero_row);      // NaN / Inf / out of range
         const float lane_term = force ? 0.0f : (L2M ? 0.5f * (1.0f - cerr) * nn_prev : sqrtf(nn_prev));
         uint32_t mybits = 0u;
         vgb_static_for<0, F>([&](auto jc) __attribute__((always_inline)) {
@@ -236,6 +244,16 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
             const bool pass = force || fmaf(gmul_f[j], lane_term, fin[j] + init_f[j]) >= 0.0f;
             mybits |= pass ? (1u << j) : 0u;
         });
+        if (COS && __ballot(zero_row) != 0ull) {         // (rare: the thresholds come from LDS)
+            uint32_t keep = 0u;
+            vgb_static_for<0, F>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                const int r = rbase + j;
+                keep |= (thr_l[qset0 + (r & 3) + 8 * (r >> 2) + 4 * h] >= 0.99999f) ? (1u << j) : 0u;
+            });
+            if (zero_row) mybits &= keep;
+        }
+        mybits &= live;                                  // (also under a row that sends every pair down the exact path)
         if (!(row_prev < a.n_rows)) mybits = 0u;
         if (__ballot(mybits != 0u) != 0ull) {
             if constexpr (BOUND) {

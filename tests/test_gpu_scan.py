@@ -654,6 +654,42 @@ def test_batch_long_rows_matrix_core_path(pkg, orc, vt, metric, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("vt", [dg.F32, dg.BF16])
+def test_batch_long_rows_empty_vectors_and_unjudgeable_queries_stay_on_the_matrix_cores(pkg, vt):
+    """a corpus where one row in fifty is all zeros (empty documents) and a batch that carries zero / NaN / Inf queries: the zero rows
+    are judged by the filter like any other (their score is exactly 0; cosine gives them the reference's distance 1.0), the
+    unjudgeable queries leave the matrix pass for scans of their own - neither fills the candidate regions: the batch stays on the
+    long-row kernel and equals the single scans."""
+    dim, n, nq, k = 1536, 300_000, 70, 10
+    rows = dg.corpus(vt, n, dim, 8300)
+    rows[::50] = 0
+    qs = dg.corpus(vt, nq, dim, 8301)
+    qs[4] = 0
+    qf = dg.storage_to_f64(vt, qs[5:7]).astype(np.float32)
+    qf[0, 10] = np.nan
+    qf[1, 20] = np.inf
+    qs[5:7] = qf if vt == dg.F32 else dg.to_storage(vt, qf)
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    for metric in (dg.COSINE, dg.L2, dg.DOT):
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        assert c.last_batch_path() == 4, (metric, c.last_batch_path())
+        for i in list(range(0, nq, 9)) + [4, 5, 6]:
+            one_ids, one_dist = c.scan_topk(metric, qs[i], k)
+            assert cnt[i] == len(one_ids), (metric, i)
+            m = cnt[i]
+            if m:
+                assert np.allclose(dist[i][:m], one_dist, rtol=1e-5, atol=1e-6, equal_nan=True), (metric, i)
+                assert len(set(ids[i][:m].tolist()) ^ set(one_ids.tolist())) <= 2, (metric, i)
+    # the negated query of a cosine batch: every non-empty row lies beyond distance 1, the empty ones AT 1.0 - they are its best rows
+    neg = dg.to_storage(vt, -dg.storage_to_f64(vt, rows[1:2]).astype(np.float32)) if vt != dg.F32 else -rows[1:2]
+    far = np.repeat(neg, 8, axis=0)
+    ids, dist, cnt = c.scan_topk_batch(dg.COSINE, far, 3)
+    one_ids, one_dist = c.scan_topk(dg.COSINE, far[0], 3)
+    assert c.last_batch_path() == 4 and np.allclose(dist[0], one_dist, rtol=1e-5) and dist[0][0] <= 1.0 + 1e-5
+    c.close()
+
+
 @pytest.mark.parametrize("vt", [dg.F32, dg.F16])
 def test_batch_long_rows_tiny_corpora(pkg, vt):
     """fewer rows than one 32-row tile, fewer than k, one row more than a tile; more queries than one workgroup holds; k = 32 (the
