@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB) && KIND != VGH_F
         const bool stat_turn = ((ti + 1) & 3) == 0 && wave == (int)(((ti + 1) >> 2) & (NISSUE_T - 1));
         const long long row_cur = tile * VGH_TILE + x;
         // the tile under the gate: this one, or (PIPE) the one in front
-        const bool force_p = !(nn_p >= VGH_NORM_LO && nn_p <= VGH_NORM_HI);
+        const bool force_p = !(nn_p <= VGH_NORM_HI) || (nn_p < VGH_NORM_LO && nn_p != 0.0f);
         const float lane_term_p = force_p ? 0.0f : (L2M ? 0.5f * (1.0f - cerr) * nn_p : sqrtf(nn_p));
         float margin = -INFINITY;
 
@@ -570,7 +570,9 @@ __global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB) && KIND != VGH_F
         VGH_TICK(t1);
 
         // ---- tile boundary: one fused multiply-add + max per register, one ballot
-        const bool force = PIPE ? force_p : !(nn_row >= VGH_NORM_LO && nn_row <= VGH_NORM_HI);   // NaN / Inf / zero / out of range
+        // (a row of ZEROS is judged like any other: every product is exactly 0 and so is the bound's |x| term - a corpus with empty vectors
+        // would otherwise pay 256 exact evaluations per such row and workgroup; cosine gives it the reference's distance 1.0 below)
+        const bool force = PIPE ? force_p : (!(nn_row <= VGH_NORM_HI) || (nn_row < VGH_NORM_LO && nn_row != 0.0f));   // NaN / Inf / out of range
         const float lane_term = PIPE ? lane_term_p : (force ? 0.0f : (L2M ? 0.5f * (1.0f - cerr) * nn_row : sqrtf(nn_row)));
         if constexpr (!PIPE) {
             vgb_static_for<0, 16>([&](auto rc) {
@@ -587,7 +589,10 @@ __global__ __launch_bounds__(64 * W, (W == 4 && VGH_HAS_W4(NTB) && KIND != VGH_F
         if (VGH_ABLATE < 2 && gate_live && __ballot(force || fmaf(gmax, lane_term, margin) >= 0.0f) != 0) {
             vgb_static_for<0, 16>([&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                const bool pass_r = force || fmaf(gmul[r], lane_term, (PIPE ? accp[r] : acc[r])) >= 0.0f;
+                bool pass_r = force || fmaf(gmul[r], lane_term, (PIPE ? accp[r] : acc[r])) >= 0.0f;
+                if constexpr (COS) {                                 // a zero-norm row: distance 1.0 whatever the query (distance-cpu.c:74-110)
+                    if ((PIPE ? nn_p : nn_row) == 0.0f) pass_r = thr_w[(r & 3) + 8 * (r >> 2) + 4 * h] >= 0.99999f;
+                }
                 if constexpr (BOUND) pend |= __ballot(pass_r) ? (1u << r) : 0u;
                 else mybits |= pass_r ? (1u << r) : 0u;
             });

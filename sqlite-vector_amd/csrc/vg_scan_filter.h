@@ -377,15 +377,18 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_kernel(FilterScanArgs
         const float E = Q8 ? q8_sqi * q8_cur.y + q8_eqn * nrm * (1.0f + a.rel) + 4.0e-7f * fabsf(st)
                            : a.cerr * qn * nrm + esub_q + esub_x * nrm;
         // (L1 needs no norm: its bound is the f32 sum itself; a NaN / Inf / overflowing sum sends the row to the exact path)
+        // (a row of ZEROS is judged like any other - its estimate and its error term are exactly 0; a corpus with empty vectors would
+        // otherwise pay an exact evaluation per such row and query.  Its cosine distance is the reference's 1.0: see lb below)
+        const bool zero_row = !L1M && (nn == 0.0f);
         const bool judged = L1M ? (xq_special == 0u && st < 3.0e38f)
-                                : (q_ok && (XF32 ? (nrm >= 1.0e-15f && nrm <= 1.0e15f) : (nn >= 1.0e-30f && nn <= 1.0e30f)) &&
-                                   (!Q8 || (q8_cur.x > 0.0f && q8_cur.x <= 3.0e38f)));       // (sx = NaN: Inf / NaN elements)
+                                : (q_ok && (zero_row || ((XF32 ? (nrm >= 1.0e-15f && nrm <= 1.0e15f) : (nn >= 1.0e-30f && nn <= 1.0e30f)) &&
+                                                         (!Q8 || (q8_cur.x > 0.0f && q8_cur.x <= 3.0e38f)))));       // (sx = NaN: Inf / NaN elements)
         // lower bound of the distance (squared for L2)
         float lb;
         if (L1M) lb = st - 2.0f * a.rel * st;
         else if (mode == VGF_L2) lb = qq + nn - 2.0f * (st + E) - a.rel * (qq + nn);
         else if (mode == VGF_DOT) lb = -(st + E) - a.rel * qn * nrm;
-        else { const float r = (st + E) / (qn * nrm); lb = 1.0f - r - a.rel * fabsf(r) - 4.0e-6f; }   // (norms + the float epilogue)
+        else { const float r = (st + E) / (qn * nrm); lb = zero_row ? 1.0f - 4.0e-6f : 1.0f - r - a.rel * fabsf(r) - 4.0e-6f; }   // (norms + the float epilogue; zero norm: 1.0, distance-cpu.c:74-110)
         const bool cand = (sub == 0) && (row < a.n_rows) && (!judged || lb < thr_gate);
         unsigned long long m = __ballot(cand);
         while (m) {

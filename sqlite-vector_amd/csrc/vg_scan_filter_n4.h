@@ -140,11 +140,11 @@ __global__ __launch_bounds__(VG_BLOCK) void vg_scan_filter_n4_kernel(FilterScanA
         const float E = cs + 4.0e-7f * (fabsf(Af) + fabsf(mq) * lsf + cs) + 1.0e-30f;
         const float nn = (float)st_cur.x;
         const float nrm = sqrtf(nn);
-        const bool judged = q_ok && st_cur.x != 0u;
+        const bool judged = q_ok;                        // (a row of zeros too: estimate and error term are 0; its cosine distance is the reference's 1.0)
         float lb;
         if (mode == VGF_L2) lb = qq + nn - 2.0f * (st + E) - a.rel * (qq + nn);
         else if (mode == VGF_DOT) lb = -(st + E) - a.rel * qn * nrm;
-        else { const float r = (st + E) / (qn * nrm); lb = 1.0f - r - a.rel * fabsf(r) - 4.0e-6f; }
+        else { const float r = (st + E) / (qn * nrm); lb = (st_cur.x == 0u) ? 1.0f - 4.0e-6f : 1.0f - r - a.rel * fabsf(r) - 4.0e-6f; }
         const bool cand = (sub == 0) && (row < a.n_rows) && (!judged || lb < thr_gate);
         unsigned long long m = __ballot(cand);
         while (m) {

@@ -479,6 +479,56 @@ def test_nibble_filter_scan_is_bit_identical_to_the_plain_scan(pkg, orc, vt, dim
     c.close()
 
 
+@pytest.mark.parametrize("vt", [dg.F32, dg.F16, dg.U8])
+def test_filter_scans_judge_empty_vectors(pkg, orc, vt, monkeypatch):
+    """a corpus where one row in twenty-five is all zeros (empty documents): the filter scans judge such a row like any other (its
+    estimate and its error term are exactly 0; cosine gives it the reference's distance 1.0) instead of evaluating every one of them
+    exactly for every query - same rowids and distance bits as the plain scan, exact evaluations far below the number of empty rows,
+    and a query whose best rows ARE the empty ones (everything else beyond cosine distance 1) still finds them."""
+    monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
+    monkeypatch.setenv("VG_SCAN_FILTER_NO_GUARD", "1")
+    n, dim, k = 1_200_000, 128, 20                                          # (past 2^20 rows: the filter scans run with their pre-pass)
+    rows = dg.corpus(vt, n, dim, 9700)
+    rows[::25] = 0
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    qs = [dg.query(vt, dim, 9701 + i) for i in range(3)]
+    for metric in (dg.L2, dg.DOT, dg.COSINE):
+        for q in qs:
+            c.set_scan_filter(1)
+            c.scan_topk(metric, q, k)                                       # (the shadow copy; a probe)
+            c.filter_exact_evals()
+            ids1, d1 = c.scan_topk(metric, q, k)
+            evals = c.filter_exact_evals()
+            assert c.kernel_name(metric).startswith("scan_filter"), c.kernel_name(metric)
+            c.set_scan_filter(0)
+            ids0, d0 = c.scan_topk(metric, q, k)
+            assert ids1.tolist() == ids0.tolist() and dg.same_float_bits(d1, d0), (vt, metric)
+            if metric != dg.L2:              # (under L2 the empty rows ARE the nearest rows of a random query, tied at |q|: all of them are looked at)
+                assert evals < n // 25 // 2, (vt, metric, evals)            # (48k empty rows: before, every one was a candidate)
+    c.close()
+    if vt == dg.U8:
+        return
+    # all-positive rows and an all-negative query: every non-empty row lies beyond cosine distance 1, the empty ones AT 1.0 (the
+    # reference's value for a zero norm) - they are the best rows, in scan order
+    n = 300_000
+    pos = np.abs(dg.storage_to_f64(vt, dg.corpus(vt, n, dim, 9710))).astype(np.float32) + np.float32(0.01)
+    pos[::25] = 0
+    rows2 = pos if vt == dg.F32 else dg.to_storage(vt, pos)
+    qneg = -(np.abs(dg.storage_to_f64(vt, dg.corpus(vt, 1, dim, 9711))).astype(np.float32) + np.float32(0.01))[0]
+    qneg = qneg if vt == dg.F32 else dg.to_storage(vt, qneg[None, :])[0]
+    c = pkg.Corpus(vt, dim)
+    c.append(rows2)
+    c.set_scan_filter(1)
+    c.scan_topk(dg.COSINE, qneg, k)
+    ids1, d1 = c.scan_topk(dg.COSINE, qneg, k)
+    assert c.kernel_name(dg.COSINE).startswith("scan_filter")
+    c.set_scan_filter(0)
+    ids0, d0 = c.scan_topk(dg.COSINE, qneg, k)
+    assert ids1.tolist() == ids0.tolist() == [1 + 25 * i for i in range(k)] and np.all(d1 == 1.0) and np.all(d0 == 1.0)
+    c.close()
+
+
 @pytest.mark.parametrize("vt,dim", ((dg.U8, 64), (dg.I8, 48)))
 def test_nibble_filter_with_its_prepass_on_clustered_bytes(pkg, orc, vt, dim, monkeypatch):
     """n >= 2^20: the pre-pass threshold; bytes quantized from clustered unit-norm embeddings (values crowd a few levels: the
