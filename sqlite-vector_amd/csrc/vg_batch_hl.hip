@@ -6,20 +6,22 @@
 // FOUR wavefronts (one per SIMD, 512 registers each) that share ONE set of queries and split their rows four ways:
 //   * wavefront p keeps k-steps [p * NTBP, (p + 1) * NTBP) of QS x 32 queries (QS = 2 sets for NTBP <= 24, else 1) - up to 256 registers;
 //   * per 32-row tile it multiplies ITS slice of the tile (read straight from the tile-major copy into registers: each k-step is one
-//     1 KiB-contiguous global_load_dwordx4 per wavefront; no LDS - no two wavefronts of the workgroup read the same bytes - the loads of
-//     tile i+1 are issued behind the MFMAs of tile i that free their registers) into partial scores, QS x 16 registers per lane;
-//   * the four partial scores of every (query, row) pair meet in LDS: every wavefront writes its QS x 16 registers, one barrier, and
-//     wavefront w sums - and owns from there on - registers [4 QS w, 4 QS (w + 1)) of the QS x 16: the gate of vg_batch_h.hip (same
-//     bounds: |s~ - s| <= c |q||x|, c = (D + 64) 2^-21 [+ 2^-7 + 2^-16 behind a bf16 shadow]), then
+//     1 KiB-contiguous buffer_load_dwordx4 per wavefront; no LDS - no two wavefronts of the workgroup read the same bytes - the loads of
+//     tile i + DEPTH are issued behind the MFMAs of tile i that free their registers) into partial scores, QS x 16 registers per lane;
+//   * the four partial scores of every (query, row) pair meet in LDS: every wavefront writes its QS x 16 registers, one barrier - in the
+//     middle of the NEXT tile's k loop, its LDS reads, sums and gate spread over the following k-steps - and wavefront w sums, and owns
+//     from there on, registers [4 QS w, 4 QS (w + 1)) of the QS x 16: the gate of vg_batch_h.hip (same bounds: |s~ - s| <= c |q||x|,
+//     c = (D + 64) 2^-21 [+ 2^-7 + 2^-16 behind a bf16 shadow]; rows of zeros are judged, NaN / Inf / out-of-range norms pass), then
 //       FILTER kind: pairs that pass are appended to the wavefront's region of the pair buffer, evaluated exactly by
 //                    vg_batch_hx_kernel (vg_batch_h_defs.h: the single-query kernel's arithmetic, strict insertion in scan order);
 //       BOUNDK kind: the pre-pass - a pair enters its query's list with an UPPER BOUND of its distance, no exact evaluation.
 // The workgroups of one partition (same rows, other queries) sit on one XCD (blockIdx & 7): the tile-major copy streams from HBM once
 // per partition and from that XCD's L2 for the other query groups.
 //
-// Cost model (DESIGN.md): per tile a wavefront issues QS x NTBP MFMAs (32 cycles each) against NTBP KiB of loads - 64 queries per
-// workgroup at 1536 elements means 62 B / clk / CU from L2, which is about what a CU gets: the kernel is L2-bound near half the matrix
-// rate, 3072 elements (32 queries per workgroup) near a quarter.  Both are two orders of magnitude over one scan per query.
+// Cost model (DESIGN.md 3.5b): per tile a wavefront issues QS x NTBP MFMAs (32 cycles each) against NTBP KiB of loads - 64 queries per
+// workgroup at 1536 elements means 96 KB per tile and CU through the vector L1 at 64 B / clk: 1536 cycles, the tile's own MFMA time.
+// Measured: 0.36-0.38 of the bf16 peak at 1536 elements (MFMA pipe busy 44 %), 0.24 at 2048 / 3072 (32 queries per workgroup) - 70x
+// the default single-query path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
