@@ -101,15 +101,13 @@ def parse():
     return ap.parse_args()
 
 
-def make_shard(pkg, torch, vt, dim, n_rows, seed, device):
-    """synthetic shard generated on the device in blocks and handed to the C-ABI as a raw device pointer.
+def shard_blocks(pkg, torch, vt, dim, n_rows, seed):
+    """the synthetic shard's rows as device tensors, block by block (the same seeded stream every time it is walked).
     f32 / f16 / bf16: N(0,1); uint8: SURVEY 8(d)'s C3 data - an f32 U[0,1) source quantized with the reference's formula
     (offset = min = 0, scale = 255 / (max - min) = 255, sqlite-vector.c:517-548): (uint8)(v * 255 + 0.5); int8: N(0,1) * 40 rounded"""
-    corpus = pkg.Corpus(vt, dim, device=device, capacity=n_rows)
     gen = torch.Generator(device="cuda")
     gen.manual_seed(seed)
     block = 1_000_000
-    es = pkg.TYPE_SIZE[vt]
     for r0 in range(0, n_rows, block):
         nr = min(block, n_rows - r0)
         if vt == pkg.F32:
@@ -121,8 +119,16 @@ def make_shard(pkg, torch, vt, dim, n_rows, seed, device):
         else:
             t = torch.randn((nr, dim), generator=gen, device="cuda", dtype=torch.float32).mul_(40.0).round_().clamp_(-128, 127).to(torch.int8)
         torch.cuda.synchronize()
-        corpus.append_device(t.data_ptr(), nr, dim * es)
+        yield r0, t
         del t
+
+
+def make_shard(pkg, torch, vt, dim, n_rows, seed, device):
+    """synthetic shard (shard_blocks) generated on the device in blocks and handed to the C-ABI as a raw device pointer"""
+    corpus = pkg.Corpus(vt, dim, device=device, capacity=n_rows)
+    es = pkg.TYPE_SIZE[vt]
+    for r0, t in shard_blocks(pkg, torch, vt, dim, n_rows, seed):
+        corpus.append_device(t.data_ptr(), t.shape[0], dim * es)
     torch.cuda.empty_cache()
     return corpus
 
@@ -1149,6 +1155,38 @@ def also_c3(args, pkg, torch, shard, also_set, n_rows, k, nq, device_index):
                 c3.scan_topk(5, q3[(2 + i) % nq], k)
             tie["l1_ms_per_query_%s" % name] = (time.perf_counter() - t0) / 20 * 1e3
         tie["l1_reference_over_position"] = tie["l1_ms_per_query_reference"] / tie["l1_ms_per_query_position"]
+        # ... and CHECKED: the last of those tie-heavy queries against the reference's own kernel + slot loop over the whole corpus in
+        # scan order (oracle/_ref; rowids and distance bits at every rank) - the fused replay is timed above, this says it is right
+        try:
+            from oracle import orc
+            if orc.have_ref() and not args.no_cpu_baseline:
+                c3.set_tie_order(pkg.TIE_REFERENCE)
+                answers = [(qi, c3.scan_topk(5, q3[qi], k)) for qi in [(2 + i) % nq for i in range(20)]]
+                tied = [a for a in answers if np.any(np.diff(np.asarray(a[1][1], dtype=np.float32)) == 0)]       # equal distances inside the top k
+                picks = ([tied[0]] if tied else []) + [answers[-1]]
+                host = np.empty((n_rows, d3), dtype=np.uint8)
+                for r0, t in shard_blocks(pkg, torch, v3, d3, n_rows, 42):
+                    host[r0:r0 + t.shape[0]] = t.cpu().numpy()
+                ref = orc.RefKernels("avx2")
+                checked = []
+                for qi, (got_ids, got_d) in picks:
+                    t0 = time.perf_counter()
+                    want_ids, want_d = ref.scan_topk(5, v3, q3[qi], host, k)
+                    ref_s = time.perf_counter() - t0
+                    same = (np.asarray(got_ids).tolist() == np.asarray(want_ids).tolist() and
+                            np.array_equal(np.asarray(got_d, dtype=np.float32).view(np.uint32), np.asarray(want_d, dtype=np.float32).view(np.uint32)))
+                    d32 = np.asarray(want_d, dtype=np.float32)
+                    checked.append({"query": int(qi), "rowids_and_distance_bits": bool(same), "ties_among_the_%d" % k: int(np.sum(d32[1:] == d32[:-1])),
+                                    "reference_scan_s": ref_s})
+                    if not same:
+                        raise SystemExit("bench.py: the reference-order answer of L1 query %d differs from the reference's own scan: %r vs %r" % (
+                            qi, np.asarray(got_ids).tolist(), np.asarray(want_ids).tolist()))
+                del host
+                tie["l1_queries_checked_against_the_reference"] = {"queries_with_ties_inside_the_top_k": len(tied), "checked": checked}
+        except SystemExit:
+            raise
+        except Exception as e:
+            tie["l1_queries_checked_against_the_reference"] = {"error": repr(e)}
         if before is not None:
             after = c3.tie_stats()
             tie["l1_reference_path_counters"] = {kk: after[kk] - before[kk] for kk in after}
