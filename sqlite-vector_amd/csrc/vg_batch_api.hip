@@ -199,36 +199,13 @@ extern "C" int vg_batch_hl_launch(const uint8_t *dev_rows, long long n_rows, lon
                                   const float *dev_row_nn, const float *dev_query_nn, uint64_t *dev_cand, int npart,
                                   uint64_t *dev_out_keys, unsigned long long *dev_evals,
                                   uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, hipStream_t stream);
+extern "C" int vg_batch_hl_query_norms(const uint8_t *dev_queries, long long stride_bytes, int dim, int type_code, int nq_real, int nq_pad,
+                                       float *dev_out, hipStream_t stream);
 static long long batch_long_stride(const vg_corpus *c) { return c->vtype == VG_TYPE_F32 ? bf16_shadow_stride(c) : c->stride; }
 static bool batch_long_eligible(const vg_corpus *c, int metric, int k) {
     if (env_int("VG_BATCH_MFMA", 1) == 0 || env_int("VG_BATCH_LONG", 1) == 0 || metric == VG_DIST_L1 || c->tm_disabled) return false;
     if (c->vtype != VG_TYPE_F32 && c->vtype != VG_TYPE_F16 && c->vtype != VG_TYPE_BF16) return false;
     return vg_batch_hl_serves(batch_long_stride(c), k) != 0;
-}
-
-// sum q^2 of one host query in the corpus' element type (Inf / NaN elements give Inf / NaN)
-static double host_query_norm2(const vg_corpus *c, const uint8_t *q) {
-    double s = 0.0;
-    for (int e = 0; e < c->dim; ++e) {
-        float v;
-        if (c->vtype == VG_TYPE_F32) { memcpy(&v, q + (size_t)e * 4, 4); }
-        else {
-            uint16_t hbits;
-            memcpy(&hbits, q + (size_t)e * 2, 2);
-            uint32_t w;
-            if (c->vtype == VG_TYPE_BF16) w = (uint32_t)hbits << 16;
-            else {                                             // IEEE half -> float
-                const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16, ex = (hbits >> 10) & 0x1Fu, man = hbits & 0x3FFu;
-                if (ex == 0x1Fu) w = sign | 0x7F800000u | (man << 13);
-                else if (ex != 0) w = sign | ((ex + 112u) << 23) | (man << 13);
-                else if (man == 0) w = sign;
-                else { int sh = 0; uint32_t m = man; while (!(m & 0x400u)) { m <<= 1; ++sh; } w = sign | ((113u - sh) << 23) | ((m & 0x3FFu) << 13); }
-            }
-            memcpy(&v, &w, 4);
-        }
-        s += (double)v * (double)v;
-    }
-    return s;
 }
 
 static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys, int *out_counts) {
@@ -264,26 +241,32 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
                                   HIP_TRY(hipMalloc(&c->d_bpairs, need)); c->bpairs_bytes = need; }
     if (c->bpcount_bytes < needc) { if (c->d_bpcounts) hipFree(c->d_bpcounts); c->d_bpcounts = nullptr; c->bpcount_bytes = 0;
                                     HIP_TRY(hipMalloc(&c->d_bpcounts, needc)); c->bpcount_bytes = needc; }
-    std::vector<uint8_t> hq(qbytes, 0);                       // zero-padded rows of the corpus stride, zero rows up to nq_pad
+    // the queries go up through a PINNED buffer of the corpus (zero-padded rows of the corpus stride, zero rows up to nq_pad; the
+    // per-query norms come back through its tail): a pageable source is staged by the runtime at a fraction of the link's rate, and
+    // at 1024 x 6 KB that, a zero-filled vector and a scalar norm loop on the host were 1.35 ms of every batch (profiles/r8l)
     const size_t row_bytes = (size_t)c->dim * c->es;
-    // A query the filter cannot judge (Inf / NaN elements, a norm of zero or out of range) would send EVERY row down the exact path -
-    // in the split form that is a pair per row: such queries leave the batch (a zero row stands in, its answer is dropped) and are
-    // answered by single scans below
-    std::vector<int> unjudged;
-    for (int i = 0; i < nq; ++i) {
-        const uint8_t *q = (const uint8_t *)queries + (size_t)i * row_bytes;
-        const double n2 = host_query_norm2(c, q);
-        if (!(n2 >= 1.0e-30 && n2 <= 1.0e30)) {            // (its slot: a zero row and the norm -1 = "never passes")
-            unjudged.push_back(i);
-            const float gone = -1.0f;
-            memcpy(hq.data() + qrows + (size_t)i * sizeof(float), &gone, sizeof(float));
-            continue;
-        }
-        memcpy(hq.data() + (size_t)i * c->stride, q, row_bytes);
-        const float n2f = (float)n2;
-        memcpy(hq.data() + qrows + (size_t)i * sizeof(float), &n2f, sizeof(float));
+    if (c->h_bq_bytes < qbytes) {
+        if (c->h_bq) hipHostFree(c->h_bq);
+        c->h_bq = nullptr; c->h_bq_bytes = 0;
+        HIP_TRY(hipHostMalloc(&c->h_bq, qbytes));
+        c->h_bq_bytes = qbytes;
     }
-    HIP_TRY(hipMemcpyAsync(c->d_bq, hq.data(), qbytes, hipMemcpyHostToDevice, c->stream));
+    if (row_bytes == (size_t)c->stride) memcpy(c->h_bq, queries, (size_t)nq * row_bytes);
+    else
+        for (int i = 0; i < nq; ++i) {
+            memcpy(c->h_bq + (size_t)i * c->stride, (const uint8_t *)queries + (size_t)i * row_bytes, row_bytes);
+            memset(c->h_bq + (size_t)i * c->stride + row_bytes, 0, (size_t)c->stride - row_bytes);
+        }
+    if (nq_pad > nq) memset(c->h_bq + (size_t)nq * c->stride, 0, (size_t)(nq_pad - nq) * c->stride);
+    HIP_TRY(hipMemcpyAsync(c->d_bq, c->h_bq, qrows, hipMemcpyHostToDevice, c->stream));
+    // sum q^2 per query, on the device.  A query the filter cannot judge (Inf / NaN elements, a norm of zero or out of range) would
+    // send EVERY row down the exact path - in the split form that is a pair per row: its norm comes out as -1, the kernels multiply it as
+    // zero and let none of its pairs pass, and it is answered by a single scan below
+    float *dev_qnn = reinterpret_cast<float *>((uint8_t *)c->d_bq + qrows);
+    {
+        const int rcq = vg_batch_hl_query_norms((const uint8_t *)c->d_bq, c->stride, c->dim, f32 ? 2 : (c->vtype == VG_TYPE_BF16 ? 1 : 0), nq, nq_pad, dev_qnn, c->stream);
+        if (rcq != 0) return vg_fail(VG_ERR_HIP, "query norm pass failed: %s", hipGetErrorString((hipError_t)rcq));
+    }
     hipEvent_t *evs = nullptr;
     if (c->profiling) {
         int slot = (int)(c->prof_launches % VG_PROF_RING);
@@ -294,7 +277,7 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
     }
     const int mode = metric == VG_DIST_DOT ? 0 : (metric == VG_DIST_COSINE ? 1 : 2), root = metric == VG_DIST_L2 ? 1 : 0;
     const int rc = vg_batch_hl_launch(c->d_rows_tm, c->n_rows, fstride, c->dim, f32 ? 2 : (c->vtype == VG_TYPE_BF16 ? 1 : 0), c->d_rows, c->stride,
-                                      (const uint8_t *)c->d_bq, nq_pad, nq, k, mode, root, c->d_xnorm, reinterpret_cast<const float *>((const uint8_t *)c->d_bq + qrows),
+                                      (const uint8_t *)c->d_bq, nq_pad, nq, k, mode, root, c->d_xnorm, dev_qnn,
                                       c->d_bcand, npart, c->d_bkeys, nullptr, c->d_bpairs, c->d_bpcounts, VG_BPAIR_CAP_LONG, c->stream);
     if (evs) { hipEventRecord(evs[2], c->stream); hipEventRecord(evs[3], c->stream); }
     if (rc == -1) { hipStreamSynchronize(c->stream); return -1; }
@@ -303,9 +286,13 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
     std::vector<uint64_t> keys((size_t)nq * 64);
     HIP_TRY(hipMemcpyAsync(&overflow, c->d_bpcounts + n_regions, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(keys.data(), c->d_bkeys, (size_t)nq * 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    float *h_qnn = reinterpret_cast<float *>(c->h_bq + qrows);
+    HIP_TRY(hipMemcpyAsync(h_qnn, dev_qnn, (size_t)nq * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     vg_collect_timing(c);
     if (overflow != 0) { c->blong_cooldown = 16; return -1; }   // (rows the filter cannot separate / judge: the next batches scan)
+    std::vector<int> unjudged;
+    for (int i = 0; i < nq; ++i) if (h_qnn[i] < 0.0f) unjudged.push_back(i);
     for (int i = 0; i < nq; ++i) {
         int cnt = 0;
         for (int j = 0; j < k; ++j) {
@@ -380,11 +367,23 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
                                       HIP_TRY(hipMalloc(&c->d_bcand, candbytes)); c->bcand_bytes = candbytes; }
     if (c->bkeys_bytes < keybytes) { if (c->d_bkeys) hipFree(c->d_bkeys); c->d_bkeys = nullptr; c->bkeys_bytes = 0;
                                      HIP_TRY(hipMalloc(&c->d_bkeys, keybytes)); c->bkeys_bytes = keybytes; }
-    // queries: zero-padded rows of the corpus stride, zero rows up to nq_pad
-    std::vector<uint8_t> hq(qbytes, 0);
+    // queries: zero-padded rows of the corpus stride, zero rows up to nq_pad - through the corpus' pinned buffer (a pageable source is
+    // staged by the runtime at a fraction of the link's rate)
     const size_t row_bytes = (size_t)c->dim * c->es;
-    for (int i = 0; i < nq; ++i) memcpy(hq.data() + (size_t)i * c->stride, (const uint8_t *)queries + (size_t)i * row_bytes, row_bytes);
-    HIP_TRY(hipMemcpyAsync(c->d_bq, hq.data(), qbytes, hipMemcpyHostToDevice, c->stream));
+    if (c->h_bq_bytes < qbytes) {
+        if (c->h_bq) hipHostFree(c->h_bq);
+        c->h_bq = nullptr; c->h_bq_bytes = 0;
+        HIP_TRY(hipHostMalloc(&c->h_bq, qbytes));
+        c->h_bq_bytes = qbytes;
+    }
+    if (row_bytes == (size_t)c->stride) memcpy(c->h_bq, queries, (size_t)nq * row_bytes);
+    else
+        for (int i = 0; i < nq; ++i) {
+            memcpy(c->h_bq + (size_t)i * c->stride, (const uint8_t *)queries + (size_t)i * row_bytes, row_bytes);
+            memset(c->h_bq + (size_t)i * c->stride + row_bytes, 0, (size_t)c->stride - row_bytes);
+        }
+    if (nq_pad > nq) memset(c->h_bq + (size_t)nq * c->stride, 0, (size_t)(nq_pad - nq) * c->stride);
+    HIP_TRY(hipMemcpyAsync(c->d_bq, c->h_bq, qbytes, hipMemcpyHostToDevice, c->stream));
     if (quantized) {
         int rcn = ensure_i8_row_stats(c);
         if (rcn != VG_OK) return rcn;

@@ -73,9 +73,9 @@ __global__ __launch_bounds__(64 * VGHL_WAVES, 1) void vg_batch_hl_kernel(BatchAr
     const int chunks_per_row = (int)(a.stride / 16);
     const int kbase = wave * NTBP;                                       // this wavefront's first k-step
 
-    // ---- per-query statistics: sum q^2, made by the host once per batch (a loop over the queries here cost every workgroup of every
-    // stage ~200 us: profiles/r7d_*); a query the filter cannot judge - Inf / NaN elements, a norm of zero or out of range - is not in
-    // the batch at all (vg_batch_api.hip answers it with a scan of its own): its slot holds a zero row and the norm 0
+    // ---- per-query statistics: sum q^2, made once per batch by vg_query_norms_kernel (a loop over the queries here cost every workgroup
+    // of every stage ~200 us: profiles/r7d_*); a query the filter cannot judge - Inf / NaN elements, a norm of zero or out of range -
+    // carries the norm -1: it multiplies as zero, none of its pairs passes, vg_batch_api.hip answers it with a scan of its own
     if (tid < NQ) {                                      // thresholds: the pre-pass bound; padding queries - and the slots of queries that
         const float n2 = a.qnn[q0 + tid];                //   left the batch (norm < 0) - never accept
         qq_l[tid] = fmaxf(n2, 0.0f);
@@ -469,6 +469,37 @@ extern "C" int vg_batch_hl_regions(long long stride_bytes, int nq_pad, int npart
 
 extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
                                      uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
+
+// (float) sum q^2 of every query of a batch (f64 sums, one wavefront per query): what the kernels' gates and the A operand's "multiplies
+// as zero" rule read.  -1 for a query the filter cannot judge - Inf / NaN elements, a norm of zero or out of [1e-30, 1e30] - which the
+// host answers with a scan of its own; 0 for the padding slots.
+template <int TC>
+__global__ __launch_bounds__(256) void vg_query_norms_kernel(const uint8_t *queries, long long stride, int dim, int nq_real, int nq_pad, float *out) {
+    const int q = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (q >= nq_pad) return;
+    double s = 0.0;
+    if (q < nq_real) {
+        const uint8_t *row = queries + (long long)q * stride;
+        for (int e = lane; e < dim; e += 64) {
+            float v;
+            if constexpr (TC == 2) v = reinterpret_cast<const float *>(row)[e];
+            else if constexpr (TC == 0) v = (float)reinterpret_cast<const _Float16 *>(row)[e];
+            else v = __uint_as_float((uint32_t)reinterpret_cast<const uint16_t *>(row)[e] << 16);
+            s += (double)v * (double)v;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0) out[q] = (q >= nq_real) ? 0.0f : ((s >= 1.0e-30 && s <= 1.0e30) ? (float)s : -1.0f);
+}
+extern "C" int vg_batch_hl_query_norms(const uint8_t *dev_queries, long long stride_bytes, int dim, int type_code, int nq_real, int nq_pad,
+                                       float *dev_out, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((nq_pad * 64 + 255) / 256);
+    if (type_code == 2) hipLaunchKernelGGL(vg_query_norms_kernel<2>, dim3(blocks), dim3(256), 0, stream, dev_queries, stride_bytes, dim, nq_real, nq_pad, dev_out);
+    else if (type_code == 1) hipLaunchKernelGGL(vg_query_norms_kernel<1>, dim3(blocks), dim3(256), 0, stream, dev_queries, stride_bytes, dim, nq_real, nq_pad, dev_out);
+    else hipLaunchKernelGGL(vg_query_norms_kernel<0>, dim3(blocks), dim3(256), 0, stream, dev_queries, stride_bytes, dim, nq_real, nq_pad, dev_out);
+    return (int)hipGetLastError();
+}
 
 // dev_rows: the TILE-MAJOR copy of what the matrix core multiplies (type_code 0 / 1: the f16 / bf16 corpus; 2: the bf16 shadow copy of
 // an f32 corpus), stride_bytes per row; dev_xrows / xstride_bytes: the row-major corpus the exact evaluation reads; dev_queries: the

@@ -118,6 +118,7 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->append_ev) hipEventDestroy(c->append_ev);
     if (c->d_stage) hipFree(c->d_stage);
     if (c->d_bq) hipFree(c->d_bq);
+    if (c->h_bq) hipHostFree(c->h_bq);
     if (c->d_xnorm) hipFree(c->d_xnorm);
     if (c->d_sel_state) hipFree(c->d_sel_state);
     if (c->d_sx) hipFree(c->d_sx);

@@ -131,6 +131,8 @@ struct vg_corpus {
     long long bfilter_pairs = 0;                  // (query, row) pairs of the filtered batches since the guard last looked
     int bfilter_cooldown = 0;                     // > 0: that many batches take the f32 matrix-core kernel
     int64_t i8_rows = 0, i8_cap = 0;              // orders a caller-stream scan behind a norm pass on the corpus stream
+    uint8_t *h_bq = nullptr;       // long-row batches: the pinned buffer the padded queries go up through (+ their norms coming back)
+    size_t h_bq_bytes = 0;
     void *d_bq = nullptr;          // batched path: padded queries, per-(query, partition) candidates, final keys
     uint64_t *d_bcand = nullptr, *d_bkeys = nullptr;
     size_t bq_bytes = 0, bcand_bytes = 0, bkeys_bytes = 0;
