@@ -78,10 +78,12 @@ __device__ __forceinline__ vgh_f32x16 vgh_mfma(const vgh_i32x4 &a, const vgh_i32
 // subs: pair regions per block (1: the filter wavefront's own; vg_batch_hl.hip: the 2 or 4 wavefronts that finish the scores of one
 // set of 32 queries write a region each - regions block * subs .. + subs - 1, read one after the other: a query's pairs all sit in ONE
 // of them, in scan order).
-// FOUR wavefronts per block: wavefront v evaluates the pairs of the queries with (query & 3) == v - every wavefront reads all pair
+// EIGHT wavefronts per block (four: + 1 .. 2 % per batch, profiles/r8q): wavefront v evaluates the pairs of the queries with (query & 7) == v - every wavefront reads all pair
 // words of the block's regions and skips the others'.  A query's pairs stay with one wavefront, in order; its list, threshold and
 // statistics in LDS are touched by that wavefront only.
-#define VGHX_WAVES 4
+#ifndef VGHX_WAVES
+#define VGHX_WAVES 8
+#endif
 template <int VT, int MODE, int XU>
 __global__ __launch_bounds__(64 * VGHX_WAVES) void vg_batch_hx_kernel(BatchArgsH a, int waves, int subs) {
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2), XF32 = (VT == T_F32);
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(64 * VGHX_WAVES) void vg_batch_hx_kernel(BatchArgsH
     auto next_mine = [&](unsigned from, uint64_t &pr) __attribute__((always_inline)) -> unsigned {
         for (; from < n; from += 64) {
             const uint64_t w = (from + lane < n) ? my_pairs[from + lane] : 0ull;
-            const unsigned long long mine = __ballot(from + lane < n && (int)((w >> 32) & 3u) == wv);
+            const unsigned long long mine = __ballot(from + lane < n && (int)((w >> 32) & (unsigned)(VGHX_WAVES - 1)) == wv);
             if (mine != 0ull) {
                 const int src = __ffsll((long long)mine) - 1;
                 pr = vg_readlane64(w, src);
