@@ -1,0 +1,64 @@
+"""driven by tools/asan_host_check.sh: the extension's staging code - the single loop, the parallel reader threads, their fallbacks,
+vector_quantize's staging in front of its transaction - over the host-memory stub engine (tools/asan_stub_engine.c), under a sanitizer"""
+import os, sys, sqlite3, tempfile, json
+import numpy as np
+ext = sys.argv[1]
+n, dim, k = 260_000, 8, 5
+rng = np.random.default_rng(1)
+rows = rng.standard_normal((n, dim), dtype=np.float32)
+ids = np.cumsum(rng.integers(1, 4, n)).astype(np.int64)
+q = rows[1234].copy()
+tmp = tempfile.mkdtemp()
+path = os.path.join(tmp, "s.db")
+db = sqlite3.connect(path, isolation_level=None)
+db.execute("CREATE TABLE t (id INTEGER PRIMARY KEY, v BLOB)")
+db.execute("BEGIN")
+db.executemany("INSERT INTO t(id, v) VALUES (?, ?)", [(int(ids[i]), None if i % 5000 == 7 else rows[i].tobytes()) for i in range(n)])
+db.execute("COMMIT")
+db.close()
+
+def connect():
+    d = sqlite3.connect(path, isolation_level=None)
+    d.enable_load_extension(True)
+    d.load_extension(ext)
+    d.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2')" % dim)
+    return d
+
+sql = "SELECT rowid, distance FROM vector_full_scan('t', 'v', ?, %d)" % k
+res = {}
+for threads in ("1", "4", "8"):
+    os.environ["VECTORGPU_STAGE_THREADS"] = threads
+    d = connect()
+    res[threads] = d.execute(sql, (q.tobytes(),)).fetchall()
+    st = json.loads(d.execute("SELECT vector_gpu_stats()").fetchone()[0])
+    print("threads", threads, res[threads][0], "parallel passes so far", st["parallel_reader_passes"], json.loads(d.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])["total_bytes"] > 0)
+    d.execute("INSERT INTO t(id, v) VALUES (?, ?)", (int(ids[-1]) + 9, q.tobytes()))          # append: the watermark path
+    assert d.execute(sql, (q.tobytes(),)).fetchall()[0][0] in (int(ids[1234]), int(ids[-1]) + 9)
+    d.execute("DELETE FROM t WHERE id = ?", (int(ids[-1]) + 9,))
+    d.close()
+assert res["1"] == res["4"] == res["8"] and res["1"][0][0] == int(ids[1234])
+os.environ["VECTORGPU_STAGE_THREADS"] = "4"
+d = connect()                                            # vector_quantize: staged in front of its BEGIN, then a failing option string
+print("quantize", d.execute("SELECT vector_quantize('t', 'v')").fetchone())
+try: d.execute("SELECT vector_quantize('t', 'v', 'qtype=BOGUS')").fetchone()
+except sqlite3.Error as e: print("ERR", e)
+d.execute("INSERT INTO t(id, v) VALUES (900000000, ?)", (q.tobytes(),))
+print(d.execute(sql, (q.tobytes(),)).fetchall()[:2])
+d.execute("DELETE FROM t WHERE id = 900000000")
+d.execute("CREATE TEMP TABLE t (id INTEGER PRIMARY KEY, v BLOB)")                           # shadowed by a TEMP table: single loop
+d.executemany("INSERT INTO temp.t VALUES (?, ?)", [(i + 1, rows[i].tobytes()) for i in range(100)])
+d.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2')" % dim)
+print(d.execute(sql, (rows[3].tobytes(),)).fetchall()[0])
+d.close()
+d = connect()                                            # held exclusively: the readers' probe fails, single loop
+d.execute("PRAGMA locking_mode=EXCLUSIVE")
+d.execute("INSERT INTO t(id, v) VALUES (900000001, ?)", (q.tobytes(),))
+print(d.execute(sql, (q.tobytes(),)).fetchall()[0])
+d.execute("DELETE FROM t WHERE id = 900000001")
+d.execute("UPDATE t SET v = x'0011' WHERE id = ?", (int(ids[100000]),))                     # a short BLOB in the middle of a range
+d.close()
+d = connect()
+try: d.execute(sql, (q.tobytes(),)).fetchall()
+except sqlite3.Error as e: print("ERR", e)
+d.close()
+print("asan run done (staging)")
