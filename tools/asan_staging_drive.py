@@ -61,4 +61,24 @@ d = connect()
 try: d.execute(sql, (q.tobytes(),)).fetchall()
 except sqlite3.Error as e: print("ERR", e)
 d.close()
+# row-granular freshness (track_changes=1): UPDATE / DELETE / INSERT are patched into the staged copy from the update hook's log - the
+# answers must be those of a connection that stages the table afresh
+d = connect()
+d.execute("UPDATE t SET v = ? WHERE id = ?", (rows[0].tobytes(), int(ids[100000])))                   # (repair the short BLOB)
+d.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2,track_changes=1')" % dim)
+d.execute(sql, (q.tobytes(),)).fetchall()
+s0 = json.loads(d.execute("SELECT vector_gpu_stats()").fetchone()[0])["rows_staged"]
+d.execute("UPDATE t SET v = ? WHERE id IN (?, ?, ?)", (q.tobytes(), int(ids[10]), int(ids[150000]), int(ids[-1])))
+d.execute("DELETE FROM t WHERE id IN (?, ?)", (int(ids[1234]), int(ids[20])))
+d.execute("UPDATE t SET v = NULL WHERE id = ?", (int(ids[30]),))
+d.execute("INSERT INTO t(id, v) VALUES (?, ?)", (int(ids[-1]) + 100, q.tobytes()))
+got = d.execute("SELECT rowid, distance FROM vector_full_scan('t', 'v', ?, 6)", (q.tobytes(),)).fetchall()
+s1 = json.loads(d.execute("SELECT vector_gpu_stats()").fetchone()[0])["rows_staged"]
+d.close()
+os.environ["VECTORGPU_STAGE_THREADS"] = "1"
+d2 = connect()
+want = d2.execute("SELECT rowid, distance FROM vector_full_scan('t', 'v', ?, 6)", (q.tobytes(),)).fetchall()
+d2.close()
+assert sorted(got[:4]) == sorted(want[:4]) and got[0][1] == 0.0 and int(ids[1234]) not in [g[0] for g in got], (got, want)
+print("tracked changes: rows re-sent to the engine", s1 - s0, got[:4])
 print("asan run done (staging)")
