@@ -39,8 +39,12 @@ int vg_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals);
 int vg_batch_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals);
 /* which path answered this corpus' last vg_scan_topk_batch[_keys] call: 0 none yet, 1 the f32 matrix-core kernel, 2 the int8 one,
  * 3 the half-precision kernel (f16 / bf16 rows, f32 rows through their bf16 shadow copy), 4 the long-row form of it (1025 .. 3072
- * elements: the K dimension split over a workgroup's wavefronts), 5 the multi-query scan, 6 one scan per query */
+ * elements: the K dimension split over a workgroup's wavefronts), 5 the multi-query scan, 6 one scan per query, 7 the int8 filter over
+ * an f32 corpus' int8 shadow copy (vg_batch_q8.hip: batches of more than 256 queries over corpora of 2^20+ rows) */
 int vg_batch_last_path(const vg_corpus *c);
+/* how this corpus' last attempt at the int8 batch filter ended: 0 it answered, 1 no room for the tile-major int8 copy, 2 shape not
+ * served, 3 a pair region overflowed (the batch was answered by another path and the next 16 batches skip the int8 filter) */
+int vg_batch_q8_status(const vg_corpus *c);
 
 /* kernel milliseconds (HIP events on the corpus stream) and rows of the corpus' last vg_corpus_minmax (which = 0) /
  * vg_corpus_quantize_rows (1) pass, and - while profiling is on - of the last int8 shadow-copy pass of the filter scans (2) */

@@ -113,6 +113,7 @@ def lib():
         "vg_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
         "vg_batch_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
         "vg_batch_last_path": (i32, [vp]),
+        "vg_batch_q8_status": (i32, [vp]),
         "vg_corpus_set_scan_filter": (i32, [vp, i32]),
         "vg_corpus_set_tie_order": (i32, [vp, i32]),
         "vg_corpus_tie_order": (i32, [vp]),
@@ -309,6 +310,10 @@ class Corpus:
         out = np.zeros(3, dtype=np.int64)
         _check(lib().vg_corpus_device_bytes(self.h, _ptr(out)))
         return tuple(int(x) for x in out)
+
+    def batch_q8_status(self):
+        """how the last attempt at the int8 batch filter ended (vectorgpu_diag.h)"""
+        return lib().vg_batch_q8_status(self.h)
 
     def last_batch_path(self):
         """1 f32 matrix-core kernel, 2 int8, 3 half-precision kernel, 4 its long-row form, 5 multi-query scan, 6 one scan per query"""

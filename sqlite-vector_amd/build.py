@@ -25,6 +25,7 @@ VEC = os.path.join(HERE, "vector.so")
 HIP_UNITS = [("vg_api.hip", "vg_api.hip.o", []), ("vg_corpus.hip", "vg_corpus.hip.o", []), ("vg_batch_api.hip", "vg_batch_api.hip.o", []),
              ("vg_select.hip", "vg_select.hip.o", []), ("vg_batch.hip", "vg_batch.hip.o", []), ("vg_quant.hip", "vg_quant.hip.o", []),
              ("vg_shards.hip", "vg_shards.hip.o", []), ("vg_multi.hip", "vg_multi.hip.o", []), ("vg_reforder.hip", "vg_reforder.hip.o", []), ("vg_scan_ex.hip", "vg_scan_ex.hip.o", []), ("vg_filter.hip", "vg_filter.hip.o", []),
+             ("vg_batch_q8.hip", "vg_batch_q8.o", []),
              ("vg_batch_i8.hip", "vg_batch_i8.hip.o", []), ("vg_batch_i8.hip", "vg_batch_i8_pre.o", ["-DVGI_TU_PRE"]),
              ("vg_batch_h.hip", "vg_batch_h.hip.o", []), ("vg_batch_h.hip", "vg_batch_h_bf16.o", ["-DVGH_TU=1"]),
              ("vg_batch_h.hip", "vg_batch_h_bound.o", ["-DVGH_TU=2"]), ("vg_batch_h.hip", "vg_batch_h_f32.o", ["-DVGH_TU=3"]),

@@ -310,6 +310,160 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
     return VG_OK;
 }
 
+// ---- f32 corpora, large batches: the INTEGER matrix cores as the filter over the int8 shadow copy (vg_batch_q8.hip) - 64 queries per
+// wavefront, a quarter of the corpus' bytes streamed, the single scan's f32 arithmetic for the pairs that pass.  Default for batches of more
+// than 256 queries (a workgroup holds 512) over corpora the filter scans' policy covers; VG_BATCH_Q8=0 / 1 forces it off / on.
+extern "C" int vg_batch_q8_serves(long long q8stride_bytes, long long xstride_bytes, int k);
+extern "C" int vg_batch_q8_queries_per_block(void);
+extern "C" int vg_batch_q8_regions(int nq_pad, int npart);
+extern "C" size_t vg_batch_q8_work_bytes(int nq_pad, long long q8stride_bytes, long long xstride_bytes);
+extern "C" size_t vg_batch_q8_work_stat_offset(int nq_pad, long long q8stride_bytes, long long xstride_bytes);
+extern "C" size_t vg_batch_q8_work_perm_offset(int nq_pad, long long q8stride_bytes, long long xstride_bytes);
+extern "C" int vg_batch_q8_max_queries(void);
+extern "C" int vg_q8_rstat_launch(const void *dev_q8stat, const float *dev_xnorm, long long row0, long long n, void *dev_out, hipStream_t stream);
+extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rstat, long long n_rows, long long q8stride, int dim,
+                                  const uint8_t *dev_xrows, long long xstride, const float *dev_xnorm,
+                                  const uint8_t *dev_xqueries, void *dev_qwork, int nq_pad, int nq_real, int k, int mode, int root,
+                                  uint64_t *dev_cand, int npart, uint64_t *dev_out_keys, unsigned long long *dev_evals,
+                                  uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, hipStream_t stream);
+static long long q8_shadow_stride_of(const vg_corpus *c) { return (((long long)c->dim + 15) / 16) * 16; }
+static bool batch_q8_eligible(const vg_corpus *c, int metric, int k, int nq) {
+    if (env_int("VG_BATCH_MFMA", 1) == 0 || c->vtype != VG_TYPE_F32 || metric == VG_DIST_L1 || c->q8tm_disabled || c->filter_disabled) return false;
+    const int sw = env_int("VG_BATCH_Q8", -1);
+    if (sw == 0 || c->n_rows < (sw == 1 ? (1ll << 16) : (1ll << 20))) return false;     // (forced: from 2048 tiles on - the tests' sizes)
+    if (sw < 0 && (nq <= 256 || !vg_scan_filter_policy(c))) return false;             // (its own overflow guard: bq8_cooldown; the bf16 filter's does not apply)
+    return vg_batch_q8_serves(q8_shadow_stride_of(c), c->stride, k) != 0;
+}
+// the tile-major int8 copy + its per-row statistics, built from the row-major shadow copy (vg_filter.hip) and the cached norms, extended
+// per appended row; -1: no room (the caller takes another path)
+static int ensure_q8_tile_major(vg_corpus *c) {
+    int rc = vg_ensure_row_norms(c);
+    if (rc == VG_OK) rc = vg_ensure_q8_shadow(c);
+    if (rc == VG_ERR_NOMEM) { (void)hipGetLastError(); c->q8tm_disabled = true; return -1; }
+    if (rc != VG_OK) return rc;
+    const long long qs = q8_shadow_stride_of(c);
+    if (c->q8tm_cap < c->n_rows) {
+        const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_rows_q8tm) hipFree(c->d_rows_q8tm);
+        if (c->d_q8tm_stat) hipFree(c->d_q8tm_stat);
+        c->d_rows_q8tm = nullptr; c->d_q8tm_stat = nullptr; c->q8tm_cap = 0; c->q8tm_rows = 0;
+        const size_t tiles = (size_t)((cap + 31) / 32);
+        const size_t bytes = tiles * 32 * (size_t)qs, sbytes = (tiles + 2) * 32 * 16;
+        if (hipMalloc(&c->d_rows_q8tm, bytes) != hipSuccess || hipMalloc(&c->d_q8tm_stat, sbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->d_rows_q8tm) hipFree(c->d_rows_q8tm);
+            c->d_rows_q8tm = nullptr; c->d_q8tm_stat = nullptr; c->q8tm_disabled = true;
+            return -1;
+        }
+        HIP_TRY(hipMemsetAsync(c->d_rows_q8tm, 0, bytes, c->stream));                          // (rows past the end: defined bytes)
+        HIP_TRY(hipMemsetAsync(c->d_q8tm_stat, 0, sbytes, c->stream));
+        c->q8tm_cap = cap;
+    }
+    if (c->q8tm_rows < c->n_rows) {
+        const long long n = c->n_rows - c->q8tm_rows;
+        rc = vg_tile_major_launch(c->d_rows_q8, c->q8tm_rows, n, qs, c->d_rows_q8tm, c->stream);
+        if (rc == 0) rc = vg_q8_rstat_launch(c->d_q8stat, c->d_xnorm, c->q8tm_rows, n, c->d_q8tm_stat, c->stream);
+        if (rc != 0) return vg_fail(VG_ERR_HIP, "tile-major int8 pass failed: %s", hipGetErrorString((hipError_t)rc));
+        c->q8tm_rows = c->n_rows;
+    }
+    return VG_OK;
+}
+
+static int scan_topk_batch_q8(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys, int *out_counts) {
+    const long long qs = q8_shadow_stride_of(c);
+    const int QPB = vg_batch_q8_queries_per_block();
+    const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
+    const int G = nq_pad / QPB;
+    const int npart = std::min(256, std::max(8, (2 * c->cu_count / G) / 8 * 8));       // two 4-wavefront workgroups per CU
+    int rcn = ensure_q8_tile_major(c);
+    if (rcn == -1) { c->bq8_status = 1; return -1; }
+    if (rcn != VG_OK) return rcn;
+    rcn = vg_ensure_filter_counters(c);
+    if (rcn != VG_OK) return rcn;
+    const size_t qrows = (size_t)nq_pad * c->stride, qbytes = qrows + vg_batch_q8_work_bytes(nq_pad, qs, c->stride);
+    const size_t candbytes = (size_t)nq_pad * std::max(npart, 64) * 64 * sizeof(uint64_t);
+    const size_t keybytes = (size_t)nq_pad * 64 * sizeof(uint64_t);
+    if (c->bq_bytes < qbytes) { if (c->d_bq) hipFree(c->d_bq); c->d_bq = nullptr; c->bq_bytes = 0;
+                                HIP_TRY(hipMalloc(&c->d_bq, qbytes)); c->bq_bytes = qbytes; }
+    if (c->bcand_bytes < candbytes) { if (c->d_bcand) hipFree(c->d_bcand); c->d_bcand = nullptr; c->bcand_bytes = 0;
+                                      HIP_TRY(hipMalloc(&c->d_bcand, candbytes)); c->bcand_bytes = candbytes; }
+    if (c->bkeys_bytes < keybytes) { if (c->d_bkeys) hipFree(c->d_bkeys); c->d_bkeys = nullptr; c->bkeys_bytes = 0;
+                                     HIP_TRY(hipMalloc(&c->d_bkeys, keybytes)); c->bkeys_bytes = keybytes; }
+    const int n_regions = vg_batch_q8_regions(nq_pad, npart);
+    const size_t need = (size_t)n_regions * VG_BPAIR_CAP * sizeof(uint64_t), needc = ((size_t)n_regions + 1) * sizeof(uint32_t);
+    if (c->bpairs_bytes < need) { if (c->d_bpairs) hipFree(c->d_bpairs); c->d_bpairs = nullptr; c->bpairs_bytes = 0;
+                                  HIP_TRY(hipMalloc(&c->d_bpairs, need)); c->bpairs_bytes = need; }
+    if (c->bpcount_bytes < needc) { if (c->d_bpcounts) hipFree(c->d_bpcounts); c->d_bpcounts = nullptr; c->bpcount_bytes = 0;
+                                    HIP_TRY(hipMalloc(&c->d_bpcounts, needc)); c->bpcount_bytes = needc; }
+    // the f32 queries go up through the corpus' pinned buffer: zero-padded rows of the corpus stride, zero rows up to nq_pad; the queries'
+    // statistics (which of them the filter could judge) come back through its tail
+    const size_t row_bytes = (size_t)c->dim * c->es, statbytes = (size_t)nq_pad * 36;        // statistics + the permutation
+    if (c->h_bq_bytes < qrows + statbytes) {
+        if (c->h_bq) hipHostFree(c->h_bq);
+        c->h_bq = nullptr; c->h_bq_bytes = 0;
+        HIP_TRY(hipHostMalloc(&c->h_bq, qrows + statbytes));
+        c->h_bq_bytes = qrows + statbytes;
+    }
+    if (row_bytes == (size_t)c->stride) memcpy(c->h_bq, queries, (size_t)nq * row_bytes);
+    else
+        for (int i = 0; i < nq; ++i) {
+            memcpy(c->h_bq + (size_t)i * c->stride, (const uint8_t *)queries + (size_t)i * row_bytes, row_bytes);
+            memset(c->h_bq + (size_t)i * c->stride + row_bytes, 0, (size_t)c->stride - row_bytes);
+        }
+    if (nq_pad > nq) memset(c->h_bq + (size_t)nq * c->stride, 0, (size_t)(nq_pad - nq) * c->stride);
+    HIP_TRY(hipMemcpyAsync(c->d_bq, c->h_bq, qrows, hipMemcpyHostToDevice, c->stream));
+    hipEvent_t *evs = nullptr;
+    if (c->profiling) {
+        int slot = (int)(c->prof_launches % VG_PROF_RING);
+        evs = &c->ev[(size_t)slot * VG_PROF_EVS];
+        c->ev_flags[(size_t)slot] = 0;
+        ++c->prof_launches;
+        hipEventRecord(evs[0], c->stream);
+    }
+    const int mode = metric == VG_DIST_DOT ? 0 : (metric == VG_DIST_COSINE ? 1 : 2), root = metric == VG_DIST_L2 ? 1 : 0;
+    uint8_t *qwork = (uint8_t *)c->d_bq + qrows;
+    const int rc = vg_batch_q8_launch(c->d_rows_q8tm, c->d_q8tm_stat, c->n_rows, qs, c->dim, c->d_rows, c->stride, c->d_xnorm,
+                                      (const uint8_t *)c->d_bq, qwork, nq_pad, nq, k, mode, root, c->d_bcand, npart, c->d_bkeys,
+                                      c->d_filter_evals + 1, c->d_bpairs, c->d_bpcounts, VG_BPAIR_CAP, c->stream);
+    if (evs) { hipEventRecord(evs[2], c->stream); hipEventRecord(evs[3], c->stream); }
+    if (rc == -1) { hipStreamSynchronize(c->stream); c->bq8_status = 2; return -1; }
+    if (rc != 0) return vg_fail(VG_ERR_HIP, "batched scan launch (int8 filter) failed: %s", hipGetErrorString((hipError_t)rc));
+    // the lists come back in SORTED SLOT order (vg_batch_q8.hip sorts the batch by the int8 images' norms): slot p answers query perm[p]
+    uint32_t overflow = 0;
+    std::vector<uint64_t> keys((size_t)nq_pad * 64);
+    HIP_TRY(hipMemcpyAsync(&overflow, c->d_bpcounts + n_regions, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(keys.data(), c->d_bkeys, (size_t)nq_pad * 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    float *h_qstat = reinterpret_cast<float *>(c->h_bq + qrows);
+    int *h_perm = reinterpret_cast<int *>(c->h_bq + qrows + (size_t)nq_pad * 32);
+    HIP_TRY(hipMemcpyAsync(h_qstat, qwork + vg_batch_q8_work_stat_offset(nq_pad, qs, c->stride), (size_t)nq_pad * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h_perm, qwork + vg_batch_q8_work_perm_offset(nq_pad, qs, c->stride), (size_t)nq_pad * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_filter_evals + 1, c->d_filter_evals + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    vg_collect_timing(c);
+    if (overflow != 0) { c->bq8_cooldown = 16; c->bq8_status = 3; return -1; }   // (data the bound cannot separate: the next batches take the other paths)
+    c->bq8_status = 0;
+    std::vector<int> unjudged;
+    for (int p = 0; p < nq_pad; ++p) {
+        const int i = h_perm[p];
+        if (i < 0 || i >= nq) continue;                                 // (padding)
+        if (h_qstat[(size_t)p * 8 + 5] == 0.0f) { unjudged.push_back(i); continue; }
+        int cnt = 0;
+        for (int j = 0; j < k; ++j) {
+            const uint64_t key = keys[(size_t)p * 64 + j];
+            if (key == VG_EMPTY_KEY) break;
+            out_keys[(size_t)i * k + cnt] = key;
+            ++cnt;
+        }
+        out_counts[i] = cnt;
+    }
+    for (int i : unjudged) {                                            // queries the filter could not judge (Inf / NaN / zero / out of range): a single scan each
+        const int rc1 = vg_scan_topk_keys(c, metric, (const uint8_t *)queries + (size_t)i * row_bytes, k, out_keys + (size_t)i * k, out_counts + i);
+        if (rc1 != VG_OK) return rc1;
+    }
+    return VG_OK;
+}
+
 static bool batch_mfma_eligible(const vg_corpus *c, int metric, int k) {
     if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
     if (c->vtype != VG_TYPE_F32) return false;
@@ -545,6 +699,18 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
         if (rc != -1) { c->last_batch_path = 4; return rc; }
         for (int i = 0; i < nq; ++i) out_counts[i] = 0;
     }
+    if (!few && batch_q8_eligible(c, metric, k, nq) && c->bq8_cooldown > 0) --c->bq8_cooldown;
+    else if (!few && batch_q8_eligible(c, metric, k, nq)) {
+        const int slice = std::min(vg_batch_q8_max_queries(), std::max(512, env_int("VG_BATCH_SLICE", 4096)));
+        int rc = VG_OK;
+        const size_t qbytes = (size_t)c->dim * c->es;
+        for (int q0 = 0; q0 < nq && rc == VG_OK; q0 += slice) {
+            const int nqs = std::min(slice, nq - q0);
+            rc = scan_topk_batch_q8(c, metric, (const uint8_t *)queries + (size_t)q0 * qbytes, nqs, k, out_keys + (size_t)q0 * k, out_counts + q0);
+        }
+        if (rc != -1) { c->last_batch_path = 7; return rc; }
+        for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+    }
     if (!few && (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k) || batch_h_eligible(c, metric, k) ||
                  batch_f32_filter_eligible(c, metric, k))) {
         // very large batches go through in slices: the per-(query, partition) candidate lists are nq x ~128 x 512 B
@@ -592,6 +758,7 @@ bool vg_batch_keys_are_scan_exact(const vg_corpus *c, int metric, int k) {
 }
 
 extern "C" int vg_batch_last_path(const vg_corpus *c) { return c ? c->last_batch_path : 0; }
+extern "C" int vg_batch_q8_status(const vg_corpus *c) { return c ? c->bq8_status : 0; }
 
 extern "C" int vg_batch_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals) {
     if (!c || !out_evals) return vg_fail(VG_ERR_INVALID, "vg_batch_filter_exact_evals: NULL argument");

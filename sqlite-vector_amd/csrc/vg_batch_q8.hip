@@ -1,0 +1,724 @@
+// vg_batch_q8.hip - batched queries over an f32 corpus (rows up to 512 floats) with the INTEGER matrix cores as the filter:
+// Q x C^T on v_mfma_i32_32x32x32_i8 over the corpus' int8 shadow copy (the one the single-query filter scan streams, vg_filter.hip:
+// per row x = sx * xi + ex, integers xi in [-127, 127], sx = max|x| / 127, ||ex|| stored rounded up), the single-query kernel's own
+// f32 arithmetic for the pairs that pass (vg_batch_hx_kernel, vg_batch_h_defs.h).  The reference has no batched entry point: the
+// oracle of a batch is Q independent vFullScanRun calls (sqlite-vector.c:2071-2113) over distance-avx2.c:67-162.
+//
+// Why (round 5): the bf16 filter (vg_batch_h.hip) is bound by what surrounds its MFMAs - one 1 KiB B-operand read from LDS, one wait
+// and, per tile, the LDS-DMA issues and the barrier, all per 32 queries x 32 rows x 16 elements of matrix work.  int8 halves the A
+// operand (32 queries x 384 elements = 48 registers instead of 96), so a wavefront keeps TWO sets of 32 queries stationary and every
+// B read, every wait, every DMA piece and every barrier serves twice the matrix work at twice the K per instruction; the shadow copy
+// streamed is a quarter of the corpus (3.84 GB at 10M x 384) instead of half.
+//
+// The bound (vg_scan_filter.h, Q8 = true; no rounding argument involved - whatever integers the quantizers picked, the residuals are
+// what is left):  q = sq qi + eq,  x = sx xi + ex,
+//     q.x = sq sx (qi.xi) + sq (qi.ex) + eq.x        |q.x - sq sx (qi.xi)| <= sq ||qi|| ||ex|| + ||eq|| ||x||        (Cauchy-Schwarz)
+// with qi.xi an exact int32 from the matrix core.  A pair passes when the lower bound of its distance can beat the query's k-th best
+// so far; written per pair as ONE sum that must not be negative (t = (float)(qi.xi) * sx):
+//     dot      t sq + A ||ex|| + B ||x|| + gate(thr)                     >= 0      A = sq ||qi||,  B = ||eq|| + rel |q| (+ roundings)
+//     L2       t sq + A ||ex|| + B ||x|| - (1 - rel) |x|^2 / 2 + (gate(thr^2) - (1 - rel) |q|^2) / 2 >= 0
+//     cosine   t sq + A ||ex|| + B ||x|| - G(thr) |q| ||x||              >= 0      G = 1 - 4e-6 - gate(thr)
+// The tile boundary works in the query's own integer units (everything divided by sq): the lane's LARGEST accumulator of a query set is
+// compared, as an integer, with the set's loosest gate; the batch is SORTED by the norm of the int8 images so that the 32 queries of a
+// set share nearly the same gate (see vg_q8_query_prep_kernel).  Only accumulators that pass get the query's own four coefficients
+// (LDS), and the pairs that pass those go to the wavefront's two regions of the pair buffer (one per query set) in scan order.
+// Thresholds are fixed per launch and refreshed between stages over growing row ranges (the split form of vg_batch_h.hip); the first
+// stage - two tiles - lets every pair through and hands the next one exact lists.
+// Workgroup = FOUR wavefronts (one per SIMD), TWO workgroups per CU: the tile barrier couples four wavefronts, and while one workgroup's
+// wavefront waits (barrier, a tile with candidates) the other workgroup's wavefront on the same SIMD keeps the matrix pipe busy.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "vg_accum.h"
+#include "vg_batch_common.h"
+#include "vg_batch_h_defs.h"
+
+typedef int vgq_i32x16 __attribute__((ext_vector_type(16)));
+
+#define VGQ_WAVES 4                     // one wavefront per SIMD; two workgroups per CU
+#define VGQ_QS 2                        // query sets of 32 per wavefront
+#define VGQ_QPW (32 * VGQ_QS)
+#define VGQ_QPB (VGQ_WAVES * VGQ_QPW)   // 256 queries per workgroup
+#define VGQ_TILE 32
+#define VGQ_MAX_K 32
+#define VGQ_BPIPE 4
+#define VGQ_RING_OF(NTB) ((NTB) <= 8 ? 6 : (NTB) <= 12 ? 4 : 3)      // tile buffers: two workgroups' rings + statistics + queues fit 160 KB
+#define VGQ_QCAP 16                     // candidate lanes a wavefront collects before it looks at their accumulators (160 bytes each)
+#define VGQ_STAT_SLOTS 8                // ring of row-statistics groups (two tiles = 1 KiB each)
+#define VGQ_STAGE0_TILES 2              // the first stage: every pair passes (32 queries x 32 rows per region and tile <= the pair capacity)
+#ifndef VGQ_ABLATE
+#define VGQ_ABLATE 0                    // measurement builds (wrong results): 1 = candidates dropped; 2 = no gate; 3 = + no LDS-DMA; 4 = + no barrier
+#endif
+#ifndef VGQ_STATS
+#define VGQ_STATS 0                     // measurement builds: counters of the tile boundary (wave-tiles | that went on to single accumulators | candidates | pairs)
+#endif
+#if VGQ_STATS
+__device__ unsigned long long vgq_stats[8];
+extern "C" int vg_batch_q8_stats(unsigned long long *out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(vgq_stats), sizeof(vgq_stats)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vgq_stats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
+struct BatchArgsQ8 {
+    const uint8_t *rows;      // the TILE-MAJOR int8 shadow copy: tile t = rows 32t .. 32t+31 = 32 * stride contiguous bytes, chunk column c
+                              // of the 32 rows at c * 512 + row * 16 (vg_tile_major_kernel over the row-major shadow copy)
+    const float4 *rstat;      // per row: (sx | -1 = never judged, ||ex|| rounded up, ||x||, 0), readable for two tiles past the last one
+    const uint8_t *qcodes;    // nq_pad x stride int8 query images (vg_q8_query_prep_kernel), zero padded, in SORTED order (see there)
+    const float4 *qstat;      // per query two float4: (sq, sq ||qi|| up, ||eq|| up, |q|), (|q|^2, judged ? 1 : 0, 0, 0)
+    long long n_rows, stride; // stride: bytes per int8 row (multiple of 16)
+    int nq_pad, npart, k, mode, root;
+    float rel;                // (D + 64) 2^-22: what the cached norms and the exact evaluation themselves may be off by (vg_filter.hip)
+    int tiles_per_part;
+    long long tile_begin, tile_end;
+    int part_base, npart_total;
+    const uint64_t *init_keys; // NULL: every pair of a judged query passes (the first stage)
+    uint64_t *pairs;          // region = ((g * npart_total + part_base + part) * 8 + wave * 2 + set); a pair = (query in the set) << 32 | row
+    uint32_t *pair_counts;    // [region] pairs written; [flag_index] = overflow flag
+    int pair_cap, flag_index;
+};
+
+__device__ __forceinline__ int vgq_q8(float v, float inv) {                 // (vgf_q8 of vg_scan_filter.h)
+    const float t = rintf(v * inv);
+    return (int)fminf(fmaxf(t, -127.0f), 127.0f);
+}
+#define VGQ_JUDGE_LO 1.0e-10f           // queries / rows whose magnitude lies outside [LO, HI] are not judged (the gate divides by the query's scale)
+#define VGQ_JUDGE_HI 1.0e10f
+
+// ---- the queries' int8 images and statistics, one wavefront per query SLOT.  Slot p holds query perm[p] (perm == NULL: p): the batch is
+// SORTED by what a query's gate on the integer score is proportional to, so that the 32 queries of a set share nearly the same gate and one
+// integer comparison of the lane's largest accumulator against the set's loosest gate is tight (unsorted, with the wavefront's largest
+// coefficients: 64 % of the tiles went on to single pairs; profiles/r9b).  dot / cosine: the norm of the int8 image under the query's OWN
+// scale sq = max|q| / 127 (threshold / sq ~ z |q| / sq).  L2: the gate holds |x|^2 / sq and (thr^2 - |q|^2) / sq - two query-dependent
+// factors - so L2 batches share ONE scale (vg_q8_rank_kernel; a query whose own scale is larger, or 8 x smaller, is not judged) and sort by |q|.
+// keys_out != NULL: only the sort key and the own scale of every query (original order) are written.
+__global__ __launch_bounds__(256) void vg_q8_query_prep_kernel(const uint8_t *xq, long long xstride, int dim, int nq_real, int nq_pad, int mode,
+                                                               const int *perm, const float *common_scale, float *keys_out, float *scales_out,
+                                                               uint8_t *xq_sorted, uint8_t *codes, long long qstride, float4 *qstat) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (p >= nq_pad) return;
+    const int q = perm ? perm[p] : p;
+    const float *src = reinterpret_cast<const float *>(xq + (long long)q * xstride);
+    float mx = 0.0f;
+    uint32_t bad = 0;
+    for (int e = lane; e < dim; e += 64) { const float f = src[e]; mx = fmaxf(mx, fabsf(f)); bad |= !(fabsf(f) <= 3.0e38f) ? 1u : 0u; }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+    bool ok = q < nq_real && __ballot(bad != 0) == 0ull && mx >= VGQ_JUDGE_LO && mx <= VGQ_JUDGE_HI;
+    float sq = ok ? mx / 127.0f : 1.0f;
+    if (ok && common_scale && mode == VGH_L2) {                           // (phase 2 of an L2 batch)
+        const float cs = *common_scale;
+        ok = sq <= cs && sq * 8.0f >= cs;                                 // (its elements fit the shared grid, and use at least four bits of it)
+        sq = ok ? cs : 1.0f;
+    }
+    const float inv = 1.0f / sq;
+    uint32_t i2 = 0;
+    float e2s = 0.0f, q2s = 0.0f;
+    for (int e = lane; e < (int)qstride; e += 64) {
+        const float f = (ok && e < dim) ? src[e] : 0.0f;
+        const int qi = vgq_q8(f, inv);
+        const float r = fmaf(-sq, (float)qi, f);                          // one rounding
+        i2 += (uint32_t)(qi * qi);
+        e2s = fmaf(r, r, e2s);
+        q2s = fmaf(f, f, q2s);
+        if (codes) codes[(long long)p * qstride + e] = (uint8_t)(qi & 255);
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { i2 += __shfl_xor(i2, s); e2s += __shfl_xor(e2s, s); q2s += __shfl_xor(q2s, s); }
+    const bool judged = ok && q2s >= VGQ_JUDGE_LO * VGQ_JUDGE_LO && q2s <= VGQ_JUDGE_HI * VGQ_JUDGE_HI;
+    if (keys_out) {
+        if (lane == 0) { keys_out[p] = judged ? (mode == VGH_L2 ? sqrtf(q2s) : sqrtf((float)i2)) : INFINITY; scales_out[p] = judged ? sq : 0.0f; }
+        return;
+    }
+    if (xq_sorted)
+        for (int c = lane; c < (int)(xstride / 16); c += 64)
+            reinterpret_cast<uint4 *>(xq_sorted + (long long)p * xstride)[c] = reinterpret_cast<const uint4 *>(xq + (long long)q * xstride)[c];
+    if (lane == 0) {
+        const float sqi = sq * sqrtf((float)i2) * (1.0f + 1.0e-5f);
+        const float eqn = sqrtf(e2s) * (1.0f + 1.0e-4f);                  // (f32 sum of D squares, each off by 2^-23 of itself at most)
+        qstat[2 * p] = make_float4(sq, sqi, eqn, sqrtf(q2s));
+        qstat[2 * p + 1] = make_float4(q2s, judged ? 1.0f : 0.0f, 0.0f, 0.0f);
+    }
+}
+// perm[rank of query i by (key, i)] = i, and the scale an L2 batch shares: one workgroup, every thread ranks its queries against all of
+// them (nq_pad <= 4096).  The shared scale is the largest own scale that is at most 4 x the scale of the batch's MEDIAN query (by key): one
+// query with a single huge element must not take the int8 grid away from all the others (it is answered by a single scan instead).
+__global__ __launch_bounds__(1024) void vg_q8_rank_kernel(const float *keys, const float *scales, int nq_pad, int *perm, float *common_scale) {
+    extern __shared__ __attribute__((aligned(16))) float vgq_keys_lds[];
+    __shared__ float smax[16];
+    __shared__ int sjudged[16];
+    __shared__ float sref;
+    int judged = 0;
+    for (int i = threadIdx.x; i < nq_pad; i += 1024) { const float kv = keys[i]; vgq_keys_lds[i] = kv; judged += (kv < INFINITY) ? 1 : 0; }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) judged += __shfl_xor(judged, s);
+    if ((threadIdx.x & 63) == 0) sjudged[threadIdx.x >> 6] = judged;
+    if (threadIdx.x == 0) sref = 0.0f;
+    __syncthreads();
+    judged = 0;
+    for (int i = 0; i < 16; ++i) judged += sjudged[i];
+    const float4 *k4 = reinterpret_cast<const float4 *>(vgq_keys_lds);
+    for (int i = threadIdx.x; i < nq_pad; i += 1024) {
+        const float ki = vgq_keys_lds[i];
+        int rank = 0;
+        for (int j4 = 0; j4 < nq_pad / 4; ++j4) {                       // (nq_pad is a multiple of 256)
+            const float4 kj = k4[j4];
+            const int j = 4 * j4;
+            rank += (kj.x < ki || (kj.x == ki && j < i)) + (kj.y < ki || (kj.y == ki && j + 1 < i)) + (kj.z < ki || (kj.z == ki && j + 2 < i)) +
+                    (kj.w < ki || (kj.w == ki && j + 3 < i));
+        }
+        perm[rank] = i;
+        if (judged > 0 && rank == judged / 2) sref = scales[i];          // (the judged queries hold the first `judged` ranks)
+    }
+    __syncthreads();
+    const float ref4 = 4.0f * sref;
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < nq_pad; i += 1024) { const float sv = scales[i]; if (sv <= ref4) m = fmaxf(m, sv); }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = 0.0f; for (int i = 0; i < 16; ++i) t = fmaxf(t, smax[i]); *common_scale = t; }
+}
+
+// ---- per-row statistics in the layout the filter's LDS-DMA moves (16 bytes per row)
+__global__ __launch_bounds__(256) void vg_q8_rstat_kernel(const float2 *q8stat, const float *xnorm, long long row0, long long n, float4 *out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 s = q8stat[row0 + i];
+        const float nrm = xnorm[row0 + i];
+        const bool zero = (nrm == 0.0f) && (s.x == 0.0f) && (s.y == 0.0f);                              // every element is +-0
+        const bool judged = zero || ((nrm >= VGQ_JUDGE_LO && nrm <= VGQ_JUDGE_HI) && (s.x > 0.0f && s.x <= 3.0e38f));   // (sx = NaN: Inf / NaN elements)
+        out[row0 + i] = judged ? (zero ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(s.x, s.y, nrm, 0.0f)) : make_float4(-1.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+template <int OFF>
+__device__ __forceinline__ void vgq_lds_read128(vgh_i32x4 &dst, uint32_t lds_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vgq_wait_lds(vgh_i32x4 &v) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
+// NTB = 32-byte k-steps per int8 row (rows up to NTB * 32 elements)
+template <int NTB, int MODE>
+__global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArgsQ8 a) {
+    constexpr int WAVES = VGQ_WAVES, THREADS = 64 * WAVES, QS = VGQ_QS;
+    constexpr int NB = VGQ_RING_OF(NTB);                                // tile buffers in LDS (NB - 1 tiles in flight)
+    constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);
+    constexpr int TILE_BYTES = NTB * 2 * 512;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *tile0 = smem;
+    float4 *rstat_lds = reinterpret_cast<float4 *>(smem + NB * TILE_BYTES);              // [VGQ_STAT_SLOTS][2 tiles][32 rows]
+    float4 *kq_lds = rstat_lds + VGQ_STAT_SLOTS * 64;                                    // [waves][64 queries]: (a, bb, cc, uu)
+    uint64_t *pbuf_lds = reinterpret_cast<uint64_t *>(kq_lds + WAVES * 64);              // [waves][2 sets][64]: pairs on their way out
+    uint32_t *queue_lds = reinterpret_cast<uint32_t *>(pbuf_lds + WAVES * 128);          // [waves][VGQ_QCAP][40 dwords]: candidate lanes
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x = lane & 31, h = lane >> 5;
+
+    const int G = a.nq_pad / VGQ_QPB;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int g = idx % G;
+    const int part = (idx / G) * 8 + xcd;
+    if (part >= a.npart) return;
+    const int q0 = g * VGQ_QPB + wave * VGQ_QPW;                         // set s: queries q0 + 32 s .. + 31
+    const int chunks_per_row = (int)(a.stride / 16);
+
+    // ---- A operands: lane (x, h) keeps bytes [32t + 16h, +16) of query x of each set
+    vgh_i32x4 areg[QS][NTB];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+        const uint8_t *qrow = a.qcodes + (long long)(q0 + 32 * s + x) * a.stride;
+        vgb_static_for<0, NTB>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int off = 32 * t + 16 * h;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (off < a.stride) v = *reinterpret_cast<const uint4 *>(qrow + off);
+            areg[s][t] = vgh_i32x4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+        });
+    }
+    // ---- the gates, in the query's own integer units (everything divided by its scale sq): a pair (query r, row x) passes when
+    //     I sx + a_r ||ex|| + bb_r ||x|| + cc_r - [L2: m_x uu_r]  >=  0          I = qi.xi,  m_x = (1 - rel) |x|^2 / 2
+    //   dot     a = ||qi||, bb = (||eq|| + rel |q|) / sq, cc = gate(thr) / sq
+    //   L2      a, bb = ||eq|| / sq, cc = (gate(thr^2) - (1 - rel) |q|^2) / (2 sq), uu = 1 / sq
+    //   cosine  a, bb = ||eq|| / sq - G, cc = 0, uu = G = (1 - 4e-6 - gate(thr)) |q| / sq      (a zero row passes iff G <= 0: its distance is 1.0)
+    // each coefficient rounded towards "pass" by a relative 8e-6 (its own float evaluation; I sx, either sign, through a (||ex|| + ||x||)).
+    // Lane l computes query q0 + l's four numbers (thresholds are fixed for the launch: the lists live in the exact-evaluation kernel);
+    // the loosest of each over a query SET (the lane's half of the wavefront) feed the tile boundary's first test of that set.
+    float amax[QS], bbmax[QS], ccmax[QS], uumin[QS];
+    {
+        const int ql = q0 + lane;
+        const float4 s0 = a.qstat[2 * ql], s1 = a.qstat[2 * ql + 1];
+        const float sq = s0.x, sqi = s0.y, eqn = s0.z, qn = s0.w, qq = s1.x;
+        const float thr = a.init_keys ? vgb_kth_distance(a.init_keys[(long long)ql * 64 + (a.k - 1)]) : INFINITY;
+        // (a k-th best of -Inf - a dot product against a row holding Inf - cannot be beaten: nothing passes; thr + rel |thr| would be NaN)
+        const bool ok = (s1.y != 0.0f) && thr > -INFINITY;
+        const float rel = a.rel, up = 1.0f + 8.0e-6f, dn = 1.0f - 8.0e-6f;
+        const float u = 1.0f / sq;
+        const float av = sqi * u * (up + 5.0e-6f);
+        float bb = eqn * (1.0f + rel) * u * up + 5.0e-6f * av, cc = 0.0f, uu = 0.0f;
+        if (COS) {
+            const float gate = thr + rel * fabsf(thr) + 1e-30f;
+            const float gg = 1.0f - 4.0e-6f - gate;                       // a pair passes  <=>  r + rel |r| > gg,  r = (st + E) / (|q| |x|)
+            const float Gq = gg > 0.0f ? gg * qn / (1.0f + rel) * u * dn * dn : gg * qn / (1.0f - rel) * u * up * up;
+            uu = Gq;
+            bb = bb - Gq + 8.0e-6f * (fabsf(bb) + fabsf(Gq));
+        } else if (L2M) {
+            const float thr2 = a.root ? thr * thr : thr;
+            const float gate2 = thr2 * (1.0f + 2.0f * rel) + 1e-30f;
+            cc = 0.5f * (gate2 - (1.0f - rel) * qq) * u;
+            cc += 8.0e-6f * (fabsf(cc) + (gate2 + qq) * u);
+            uu = u * dn;
+        } else {
+            bb += rel * qn * u * up;
+            cc = (thr + rel * fabsf(thr) + 1e-30f) * u;
+            cc += 8.0e-6f * fabsf(cc);
+        }
+        // +Inf / NaN threshold (list not full, the first stage): accept everything
+        if (COS) { if (!(bb < VGH_ACCEPT)) bb = VGH_ACCEPT; if (!(uu > -VGH_ACCEPT)) uu = -VGH_ACCEPT; }
+        else if (!(cc < VGH_ACCEPT)) cc = VGH_ACCEPT;
+        if (!ok) { cc = -VGH_ACCEPT; bb = 0.0f; uu = COS ? VGH_ACCEPT : 0.0f; }     // padding / queries the filter cannot judge: never pass
+        kq_lds[wave * 64 + lane] = make_float4(ok ? av : 0.0f, bb, cc, uu);
+        float m1 = ok ? av : 0.0f, m2 = ok ? bb : -VGH_ACCEPT, m3 = ok ? cc : -VGH_ACCEPT, m4 = ok ? uu : VGH_ACCEPT;
+#pragma unroll
+        for (int s = 16; s >= 1; s >>= 1) {                               // over the 32 lanes of a half: one query set each
+            m1 = fmaxf(m1, __shfl_xor(m1, s)); m2 = fmaxf(m2, __shfl_xor(m2, s));
+            m3 = fmaxf(m3, __shfl_xor(m3, s)); m4 = fminf(m4, __shfl_xor(m4, s));
+        }
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            amax[s] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m1), 32 * s));
+            bbmax[s] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m2), 32 * s));
+            ccmax[s] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m3), 32 * s));
+            uumin[s] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m4), 32 * s));
+        }
+    }
+    const float4 *kq_w = kq_lds + wave * 64;
+    for (int s = tid; s < NB * TILE_BYTES / 4; s += THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = 0u;   // pad columns
+    __syncthreads();
+
+    // ---- tile streaming by LDS-DMA (vg_batch_h.hip's FILTER kind): piece p = chunk columns 2p, 2p+1 of all 32 rows = 1 KiB of the
+    // tile-major copy; wavefront w moves the contiguous pieces w * NPIECE .. + NPIECE - 1
+    const int npieces = (chunks_per_row + 1) / 2;
+    const long long tile_first = a.tile_begin + (long long)part * a.tiles_per_part;
+    const long long tile_last = min(tile_first + a.tiles_per_part, a.tile_end);
+    const int T = tile_first < tile_last ? (int)(tile_last - tile_first) : 0;
+    const unsigned long long stride_b = (unsigned long long)a.stride;
+    const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)tile0;
+    constexpr int NPIECE = (NTB + WAVES - 1) / WAVES;
+    static_assert(NPIECE <= 4, "rows up to 512 bytes");
+    auto piece_mask_of = [&](int p) -> uint64_t {
+        if (p >= npieces) return 0ull;
+        return (2 * p + 1 < chunks_per_row) ? ~0ull : 0xFFFFFFFFull;
+    };
+    const bool all_full = 2 * (wave * NPIECE + NPIECE) <= chunks_per_row;
+    const uint32_t lane_goff = (uint32_t)lane * 16u;
+    const uint32_t lds_rstat0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4 *)rstat_lds;
+    auto dma_stat_group = [&](long long tile2, int slot) {          // the row statistics of tiles tile2, tile2 + 1: 1 KiB
+        const uint8_t *b0 = reinterpret_cast<const uint8_t *>(a.rstat + tile2 * VGQ_TILE);
+        const uint32_t d0 = lds_rstat0 + (uint32_t)(slot * 1024);
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane_goff), "s"(b0), "s"(d0) : "memory");
+    };
+    auto dma_piece = [&](long long tile, int buf, int i) __attribute__((always_inline)) {
+        const int p = wave * NPIECE + i;
+        const uint64_t pmask = piece_mask_of(p);
+        if (pmask == 0) return;
+        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGQ_TILE) * stride_b + (unsigned)p * 1024u;
+        const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + p * 1024);
+        uint32_t keep;
+        uint64_t keep_exec;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_and_b64 exec, exec, %5\n\t"
+                     "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(keep_exec) : "v"(lane_goff), "s"(sbase), "s"(lds_dst), "s"(pmask) : "memory", "scc");
+    };
+    auto dma_run = [&](long long tile, int buf) __attribute__((always_inline)) {           // NPIECE (1 .. 4) whole pieces, back to back
+        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGQ_TILE) * stride_b + (unsigned)(wave * NPIECE) * 1024u;
+        const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + (wave * NPIECE) * 1024);
+        uint32_t keep;
+        if constexpr (NPIECE == 1)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
+        else if constexpr (NPIECE == 2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
+        else if constexpr (NPIECE == 3)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:1024\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                         "global_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
+    };
+    auto dma_share = [&](long long tile, int buf) __attribute__((always_inline)) {
+        if (all_full) dma_run(tile, buf);
+        else vgb_static_for<0, NPIECE>([&](auto pc) { dma_piece(tile, buf, decltype(pc)::value); });
+    };
+
+    // The row statistics (16 bytes per row) ride the same queue, two tiles = 1 KiB per instruction into a ring of VGQ_STAT_SLOTS groups,
+    // the wavefronts taking turns.  Group j (tiles 2j, 2j + 1 of this partition) is issued in trip 2j - NB, IN FRONT of that trip's
+    // pieces: a wavefront's loads return in order and its tile-end wait leaves at most (NB - 2) * NPIECE of them outstanding, so by the
+    // barrier of trip 2j - 3 at the latest the group has landed - without any wait of its own (waiting for it on the spot meant waiting
+    // for the pieces issued in the same trip: a full memory round trip every other tile, for all four wavefronts at the barrier).
+    constexpr int SPRE = (NB + 1) / 2;                               // groups loaded up front: j with 2j - NB < 0
+    if (T > 0) {
+        if (wave < SPRE && 2 * wave < T + 1) dma_stat_group(tile_first + 2 * wave, wave);
+        vgb_static_for<0, NB - 1>([&](auto jc) {                     // tiles first .. first + NB - 2 into buffers 0 .. NB - 2
+            constexpr int j = decltype(jc)::value;
+            dma_share(min(tile_first + j, tile_last - 1), j);
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool counted_wait = all_full;
+    const long long region0 = ((long long)(g * a.npart_total + a.part_base + part) * WAVES + wave) * QS;
+    uint64_t *pairs0 = a.pairs + region0 * a.pair_cap, *pairs1 = pairs0 + a.pair_cap;
+    unsigned n_pairs0 = 0, n_pairs1 = 0;                              // pairs in the regions so far (wave-uniform)
+    // Pairs are collected in LDS (64 per set and wavefront) and go out 64 at a time: a store issued in the middle of the streaming loop
+    // sits in the same in-order queue as the LDS-DMA pieces, and the tile-end wait "at most N outstanding" then waits for IT - a
+    // ~2 us write acknowledgement - before it can count the pieces behind it as landed (one store per passing pair: 6.7 ms per batch
+    // against 2.8 ms with the stores compiled out, profiles/r9e).
+    uint64_t *pbuf0 = pbuf_lds + wave * 128, *pbuf1 = pbuf0 + 64;
+    unsigned n_buf0 = 0, n_buf1 = 0;                                  // (wave-uniform)
+    auto flush = [&](uint64_t *buf, unsigned &n_buf, uint64_t *region, unsigned &n_pairs) __attribute__((always_inline)) {
+        if ((unsigned)lane < n_buf && n_pairs + (unsigned)lane < (unsigned)a.pair_cap) region[n_pairs + lane] = buf[lane];
+        if (n_pairs + n_buf > (unsigned)a.pair_cap && lane == 0) a.pair_counts[a.flag_index] = 1u;     // region full: the host answers the batch another way
+        n_pairs += n_buf;
+        n_buf = 0;
+    };
+    const float mfac = 0.5f * (1.0f - a.rel) * (1.0f - 8.0e-6f);
+    // the lane's two sets' gate coefficients (set = h for the lane's own accumulators: register r of lane (x, h) is query (r&3) + 8 (r>>2) + 4h
+    // of BOTH sets - acc0 holds set 0, acc1 set 1 - so every lane needs both sets' maxima)
+    // ---- the candidate queue.  A lane whose largest accumulator passes the first test is a CANDIDATE LANE: one row, 32 queries.  Looking at
+    // its 32 accumulators on the spot - which registers, then the query's own coefficients for each - was ~200 instructions and several
+    // LDS round trips of the whole wavefront for, on average, 1.3 such lanes (a quarter of all tiles: + 50 % on the streaming loop,
+    // profiles/r9f).  Instead the lane parks its accumulators, its row's statistics and its two thresholds in LDS (ten 16-byte writes)
+    // and the loop goes on; every VGQ_QCAP entries the wavefront looks at them together - lane (e, o) takes registers 8 o .. 8 o + 7 of
+    // entry e, all 64 lanes busy, eight steps - and the pairs that pass go to the pair buffers, entries ascending: a query's rows stay
+    // in scan order.
+#if VGQ_STATS
+    unsigned st_slow = 0, st_cand = 0, st_pairs = 0;
+#endif
+    uint32_t *queue_w = queue_lds + wave * (VGQ_QCAP * 40);
+    unsigned n_q = 0;                                                 // (wave-uniform)
+    auto process_queue = [&]() __attribute__((always_inline)) {
+        const int e = lane >> 2, o = lane & 3, set = o >> 1;
+        const bool live = (unsigned)e < n_q;
+        const uint32_t *ent = queue_w + e * 40;
+        const uint4 m0 = *reinterpret_cast<const uint4 *>(ent + 32), m1 = *reinterpret_cast<const uint4 *>(ent + 36);
+        const uint4 a0 = *reinterpret_cast<const uint4 *>(ent + 8 * o), a1 = *reinterpret_cast<const uint4 *>(ent + 8 * o + 4);
+        const uint32_t row_e = m0.x;
+        const int ithr_e = (int)(set ? m0.z : m0.y);
+        const float sx_e = __uint_as_float(m0.w), rx_e = __uint_as_float(m1.x), nx_e = __uint_as_float(m1.y);
+        const int h_e = (int)m1.z;
+        const float mx2_e = L2M ? mfac * nx_e * nx_e : 0.0f;
+        const int acc8[8] = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+        const unsigned long long set0_lanes = 0x3333333333333333ull;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = (o & 1) * 8 + i;                            // register within the set
+            const int qi = (r & 3) + 8 * (r >> 2) + 4 * h_e;
+            const float4 kq = kq_w[32 * set + qi];
+            const int I = acc8[i];
+            bool pass = live && I >= ithr_e;
+            if (sx_e < 0.0f) pass = pass && kq.z > -1.0e38f;                                       // a row that is never judged: every judged query
+            else if (COS && nx_e == 0.0f) pass = pass && kq.z > -1.0e38f && kq.w <= 0.0f;          // a zero row's cosine distance is 1.0 (distance-cpu.c:74-110)
+            else {
+                float lhs = fmaf((float)I, sx_e, fmaf(kq.x, rx_e, fmaf(kq.y, nx_e, kq.z)));
+                if constexpr (L2M) lhs = fmaf(-mx2_e, kq.w, lhs);
+                pass = pass && lhs >= 0.0f;
+            }
+            if (VGQ_ABLATE == 5) pass = false;
+            const unsigned long long pm = __ballot(pass);
+#if VGQ_STATS
+            st_cand += (unsigned)__popcll(__ballot(live && I >= ithr_e));
+            st_pairs += (unsigned)__popcll(pm);
+#endif
+            if (pm == 0ull) continue;
+            const unsigned long long pm0 = pm & set0_lanes, pm1 = pm & ~set0_lanes;
+            const unsigned c0 = (unsigned)__popcll(pm0), c1 = (unsigned)__popcll(pm1);
+            if (n_buf0 + c0 > 64u) flush(pbuf0, n_buf0, pairs0, n_pairs0);
+            if (n_buf1 + c1 > 64u) flush(pbuf1, n_buf1, pairs1, n_pairs1);
+            const unsigned long long mine = set ? pm1 : pm0;
+            const unsigned at = (set ? n_buf1 : n_buf0) + __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
+            if (pass) (set ? pbuf1 : pbuf0)[at] = ((uint64_t)(uint32_t)qi << 32) | row_e;
+            n_buf0 += c0; n_buf1 += c1;
+        }
+        n_q = 0;
+    };
+    constexpr int BP = VGQ_BPIPE < NTB ? VGQ_BPIPE : NTB;
+    vgh_i32x4 bq[BP];
+    int cur_buf = 0;
+    for (int ti = 0; ti < T; ++ti) {
+        const long long tile = tile_first + ti;
+        const int fill_buf = cur_buf == 0 ? NB - 1 : cur_buf - 1;
+        const long long tile_next = min(tile + NB - 1, tile_last - 1);        // the tile whose DMA this trip issues
+        const int sj = (ti + NB) >> 1;                                        // the statistics group this trip may issue
+        const bool stat_turn = ((ti + NB) & 1) == 0 && 2 * sj < T + 1 && wave == (sj & (WAVES - 1));
+        const long long row_cur = tile * VGQ_TILE + x;
+        vgq_i32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
+        const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
+        vgb_static_for<0, BP>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            vgq_lds_read128<1024 * t>(bq[t], baddr);
+        });
+        vgb_static_for<0, NTB>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int in_flight_after = (NTB - 1 - t) < (BP - 1) ? (NTB - 1 - t) : (BP - 1);
+            vgq_wait_lds<in_flight_after>(bq[t % BP]);
+            const vgh_i32x4 b = bq[t % BP];
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][t], b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[1][t], b, acc1, 0, 0, 0);
+            if constexpr (t + BP < NTB) vgq_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
+            if constexpr (t == 0 && VGQ_ABLATE < 3) {
+                if (stat_turn) dma_stat_group(tile_first + 2 * sj, sj & (VGQ_STAT_SLOTS - 1));
+                dma_share(tile_next, fill_buf);
+            }
+        });
+        const float4 rs = rstat_lds[((ti >> 1) & (VGQ_STAT_SLOTS - 1)) * 64 + (ti & 1) * 32 + x];
+        // ---- tile boundary.  First test, per query set: the lane's LARGEST accumulator of the set against the set's loosest gate, as an
+        // integer: I >= ithr = (-(amax ||ex|| + bbmax ||x|| + ccmax - m uumin)) / sx, rounded down.  Only a set with a lane that passes
+        // looks at single accumulators (the same integer comparison, eight registers at a time), and only those pairs get the query's
+        // own four coefficients.
+        if (VGQ_ABLATE >= 2) asm volatile("" :: "v"(acc0[0]), "v"(acc0[15]), "v"(acc1[0]), "v"(acc1[15]));
+        const bool force = rs.x < 0.0f;                                // Inf / NaN / out-of-range row: every judged query takes the exact path
+        const float sx = rs.x, rx = rs.y, nx = rs.z;
+        const bool zero = !force && sx == 0.0f;                        // (a row of zeros: I = 0 for every query)
+        const float inv_sx = __frcp_rn(sx);
+        const float mx2 = L2M ? mfac * nx * nx : 0.0f;
+        int ithr[QS];
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            float rest = fmaf(amax[s], rx, fmaf(bbmax[s], nx, COS ? 0.0f : ccmax[s]));
+            if constexpr (L2M) rest = fmaf(-mx2, uumin[s], rest);
+            if (COS && zero) rest = -uumin[s];                         // a zero row's cosine distance is 1.0 whatever the query (distance-cpu.c:74-110)
+            const float tf = -rest * inv_sx;
+            const float tfl = floorf(tf - 1.0f - 1.0e-6f * fabsf(tf));
+            int it = (tfl > -1.0e9f) ? ((tfl < 1.0e9f) ? (int)tfl : 1000000000) : -1000000000;      // (NaN: accept)
+            if (zero) it = (rest >= 0.0f) ? -1000000000 : 1000000000;
+            if (force) it = -1000000000;
+            if (!(row_cur < a.n_rows)) it = 2000000000;
+            ithr[s] = it;
+        }
+        if (VGQ_ABLATE < 2) {
+            // group maxima: registers 0-7 and 8-15 of each set
+            int gm[4];
+            gm[0] = max(max(max(acc0[0], acc0[1]), max(acc0[2], acc0[3])), max(max(acc0[4], acc0[5]), max(acc0[6], acc0[7])));
+            gm[1] = max(max(max(acc0[8], acc0[9]), max(acc0[10], acc0[11])), max(max(acc0[12], acc0[13]), max(acc0[14], acc0[15])));
+            gm[2] = max(max(max(acc1[0], acc1[1]), max(acc1[2], acc1[3])), max(max(acc1[4], acc1[5]), max(acc1[6], acc1[7])));
+            gm[3] = max(max(max(acc1[8], acc1[9]), max(acc1[10], acc1[11])), max(max(acc1[12], acc1[13]), max(acc1[14], acc1[15])));
+            const bool any0 = max(gm[0], gm[1]) >= ithr[0], any1 = max(gm[2], gm[3]) >= ithr[1];
+            const bool cand_lane = any0 || any1;
+            unsigned long long m = __ballot(cand_lane);
+            if (VGQ_ABLATE == 1) { asm volatile("" :: "s"(m)); m = 0ull; }
+#if VGQ_STATS
+            if (m) ++st_slow;
+#endif
+            while (m) {                                                  // (one trip unless the queue runs full)
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                const bool take = ((m >> lane) & 1ull) != 0ull && n_q + rank < (unsigned)VGQ_QCAP;
+                if (take) {
+                    uint32_t *ent = queue_w + (n_q + rank) * 40;
+                    vgb_static_for<0, 4>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        *reinterpret_cast<uint4 *>(ent + 4 * j) = make_uint4((uint32_t)acc0[4 * j], (uint32_t)acc0[4 * j + 1], (uint32_t)acc0[4 * j + 2], (uint32_t)acc0[4 * j + 3]);
+                        *reinterpret_cast<uint4 *>(ent + 16 + 4 * j) = make_uint4((uint32_t)acc1[4 * j], (uint32_t)acc1[4 * j + 1], (uint32_t)acc1[4 * j + 2], (uint32_t)acc1[4 * j + 3]);
+                    });
+                    *reinterpret_cast<uint4 *>(ent + 32) = make_uint4((uint32_t)row_cur, (uint32_t)ithr[0], (uint32_t)ithr[1], __float_as_uint(sx));
+                    *reinterpret_cast<uint4 *>(ent + 36) = make_uint4(__float_as_uint(rx), __float_as_uint(nx), (uint32_t)h, 0u);
+                }
+                const unsigned long long taken = __ballot(take);
+                n_q += (unsigned)__popcll(taken);
+                m &= ~taken;
+                if (n_q == (unsigned)VGQ_QCAP) process_queue();
+            }
+        }
+        // tile end: the next tile's pieces have landed (an issuing wavefront leaves the pieces of the NB - 2 youngest tiles in flight:
+        // loads return in order), barrier: every wavefront has read this tile, the next one is readable
+        if (counted_wait) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NB - 2) * NPIECE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::: "memory");
+        if (VGQ_ABLATE < 4) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cur_buf = cur_buf + 1 == NB ? 0 : cur_buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (no LDS-DMA of the ring may land after this workgroup's LDS is gone)
+#if VGQ_STATS
+    if (lane == 0) { atomicAdd(&vgq_stats[0], (unsigned long long)T); atomicAdd(&vgq_stats[1], (unsigned long long)st_slow);
+                     atomicAdd(&vgq_stats[2], (unsigned long long)st_cand); atomicAdd(&vgq_stats[3], (unsigned long long)st_pairs); }
+#endif
+    if (n_q) process_queue();
+    flush(pbuf0, n_buf0, pairs0, n_pairs0);
+    flush(pbuf1, n_buf1, pairs1, n_pairs1);
+    if (lane == 0) {
+        a.pair_counts[region0] = n_pairs0 < (unsigned)a.pair_cap ? n_pairs0 : (unsigned)a.pair_cap;
+        a.pair_counts[region0 + 1] = n_pairs1 < (unsigned)a.pair_cap ? n_pairs1 : (unsigned)a.pair_cap;
+    }
+}
+
+// ---- host side
+template <int NTB, int MODE>
+static int launch_q8(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_q8_kernel<NTB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((vg_batch_q8_kernel<NTB, MODE>), dim3((unsigned)blocks), dim3(64 * VGQ_WAVES), smem, stream, a);
+    return (int)hipGetLastError();
+}
+template <int NTB>
+static int launch_q8_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
+    if (a.mode == VGH_COS) return launch_q8<NTB, VGH_COS>(a, blocks, smem, stream);
+    if (a.mode == VGH_L2) return launch_q8<NTB, VGH_L2>(a, blocks, smem, stream);
+    return launch_q8<NTB, VGH_DOT>(a, blocks, smem, stream);
+}
+static int vgq_ntb(long long stride_bytes) {
+    const int ntb = (int)((stride_bytes + 31) / 32);
+    if (ntb <= 4) return 4;
+    if (ntb <= 8) return 8;
+    if (ntb <= 12) return 12;
+    if (ntb <= 16) return 16;
+    return 0;
+}
+static size_t vgq_lds_bytes(int NTB) {
+    return (size_t)VGQ_RING_OF(NTB) * NTB * 1024 + (size_t)VGQ_STAT_SLOTS * 1024 + (size_t)VGQ_WAVES * 64 * 16 + (size_t)VGQ_WAVES * 128 * 8 + (size_t)VGQ_WAVES * VGQ_QCAP * 160;
+}
+
+extern "C" int vgh_launch_exact_f32(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream);   // vg_batch_h.hip (-DVGH_TU=8)
+extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
+                                     uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
+
+// does the int8 batch filter serve rows of q8stride_bytes int8 elements (xstride_bytes: the f32 rows) with lists of k?
+extern "C" int vg_batch_q8_serves(long long q8stride_bytes, long long xstride_bytes, int k) {
+    return vgq_ntb(q8stride_bytes) != 0 && k >= 1 && k <= VGQ_MAX_K && xstride_bytes <= 2048;
+}
+extern "C" int vg_batch_q8_queries_per_block(void) { return VGQ_QPB; }
+extern "C" int vg_batch_q8_max_queries(void) { return 4096; }         // (the rank kernel's LDS)
+extern "C" int vg_batch_q8_regions(int nq_pad, int npart) { return (nq_pad / 32) * npart; }
+// scratch behind the nq_pad query rows the caller uploads: the sorted query rows, their int8 images, statistics, sort keys + own scales +
+// the permutation + the common scale
+extern "C" size_t vg_batch_q8_work_bytes(int nq_pad, long long q8stride_bytes, long long xstride_bytes) {
+    return (size_t)nq_pad * xstride_bytes + (size_t)nq_pad * q8stride_bytes + (size_t)nq_pad * 2 * sizeof(float4) + (size_t)nq_pad * 12 + 16;
+}
+// where the statistics (nq_pad x 32 bytes) and the permutation (nq_pad ints: slot -> query) sit in that scratch
+extern "C" size_t vg_batch_q8_work_stat_offset(int nq_pad, long long q8stride_bytes, long long xstride_bytes) {
+    return (size_t)nq_pad * xstride_bytes + (size_t)nq_pad * q8stride_bytes;
+}
+extern "C" size_t vg_batch_q8_work_perm_offset(int nq_pad, long long q8stride_bytes, long long xstride_bytes) {
+    return vg_batch_q8_work_stat_offset(nq_pad, q8stride_bytes, xstride_bytes) + (size_t)nq_pad * 2 * sizeof(float4) + (size_t)nq_pad * 8;
+}
+
+extern "C" int vg_q8_rstat_launch(const void *dev_q8stat, const float *dev_xnorm, long long row0, long long n, void *dev_out, hipStream_t stream) {
+    if (n <= 0) return 0;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(vg_q8_rstat_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const float2 *>(dev_q8stat), dev_xnorm, row0, n,
+                       reinterpret_cast<float4 *>(dev_out));
+    return (int)hipGetLastError();
+}
+
+// The whole batch: sort + query images -> staged passes over growing row ranges (int8 filter -> pairs -> exact evaluation -> merge), the
+// first of them two tiles wide with every gate open.
+// dev_rows_tm / dev_rstat: the tile-major int8 copy + its statistics; dev_xrows: the f32 corpus (xstride bytes per row); dev_xqueries: the
+// f32 queries, zero padded to nq_pad rows of xstride bytes; dev_qwork: vg_batch_q8_work_bytes() of scratch; dev_cand: npart lists of 64
+// keys per query; dev_pairs: vg_batch_q8_regions() x pair_cap pairs, dev_pair_counts: regions + 1 words.  On return dev_out_keys holds the
+// merged lists (nq_pad x 64) IN SORTED SLOT ORDER (slot p = query perm[p], the permutation is in the scratch) and
+// dev_pair_counts[regions] the overflow flag.  Returns 0, -1 if the shape is not served, a hipError_t otherwise.
+extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rstat, long long n_rows, long long q8stride, int dim,
+                                  const uint8_t *dev_xrows, long long xstride, const float *dev_xnorm,
+                                  const uint8_t *dev_xqueries, void *dev_qwork, int nq_pad, int nq_real, int k, int mode, int root,
+                                  uint64_t *dev_cand, int npart, uint64_t *dev_out_keys, unsigned long long *dev_evals,
+                                  uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, hipStream_t stream) {
+    const int ntb = vgq_ntb(q8stride);
+    if (!ntb || !vg_batch_q8_serves(q8stride, xstride, k) || nq_pad % VGQ_QPB != 0 || nq_pad > vg_batch_q8_max_queries() || npart < 8 || npart % 8 != 0 ||
+        npart > VG_SEL_MAX_HEADS) return -1;
+    if (mode < VGH_DOT || mode > VGH_L2 || !dev_xnorm || !dev_pairs || !dev_pair_counts || pair_cap < 32 * 32) return -1;
+    const long long ntiles = (n_rows + VGQ_TILE - 1) / VGQ_TILE;
+    if (ntiles < 2048) return -1;                                     // small corpora: the lists warm up inside a fused kernel instead
+    uint8_t *xq_sorted = reinterpret_cast<uint8_t *>(dev_qwork);
+    uint8_t *qcodes = xq_sorted + (size_t)nq_pad * xstride;
+    float4 *qstat = reinterpret_cast<float4 *>(qcodes + (size_t)nq_pad * q8stride);
+    float *qkeys = reinterpret_cast<float *>(qstat + (size_t)nq_pad * 2);
+    float *qscales = qkeys + nq_pad;
+    int *perm = reinterpret_cast<int *>(qscales + nq_pad);
+    float *common = reinterpret_cast<float *>(perm + nq_pad);
+    const dim3 pg((unsigned)((nq_pad + 3) / 4));
+    hipLaunchKernelGGL(vg_q8_query_prep_kernel, pg, dim3(256), 0, stream, dev_xqueries, xstride, dim, nq_real, nq_pad, mode, (const int *)nullptr,
+                       (const float *)nullptr, qkeys, qscales, (uint8_t *)nullptr, (uint8_t *)nullptr, q8stride, (float4 *)nullptr);
+    hipLaunchKernelGGL(vg_q8_rank_kernel, dim3(1), dim3(1024), (size_t)nq_pad * 4, stream, (const float *)qkeys, (const float *)qscales, nq_pad, perm, common);
+    hipLaunchKernelGGL(vg_q8_query_prep_kernel, pg, dim3(256), 0, stream, dev_xqueries, xstride, dim, nq_real, nq_pad, mode, (const int *)perm,
+                       (const float *)common, (float *)nullptr, (float *)nullptr, xq_sorted, qcodes, q8stride, qstat);
+    int rc = (int)hipGetLastError();
+    if (rc != 0) return rc;
+    const int G = nq_pad / VGQ_QPB;
+    const int flag_index = vg_batch_q8_regions(nq_pad, npart);
+    const int hx_waves = VGQ_WAVES * VGQ_QS;
+    const int xntb = (int)((((long long)dim * 2 + 15) / 16 * 16 + 31) / 32);      // k-steps of the bf16 image: what picks the exact kernel's chunks per lane
+    const size_t smem_exact = (size_t)VGH_QPW * (8 + 4 + 4 + 4) + (size_t)VGH_QPW * k * 8;
+    if ((rc = (int)hipMemsetAsync(dev_pair_counts + flag_index, 0, sizeof(uint32_t), stream)) != 0) return rc;
+
+    BatchArgsH hx;                                                    // the exact-evaluation kernel's view (vg_batch_hx_kernel)
+    hx.rows = nullptr; hx.tiled = 1; hx.queries = xq_sorted; hx.xrows = dev_xrows; hx.xqueries = xq_sorted; hx.xstride = xstride;
+    hx.cerr = 0.0f; hx.row_nn = dev_xnorm; hx.cand = dev_cand; hx.n_rows = n_rows; hx.stride = q8stride;
+    hx.nq_pad = nq_pad; hx.nq_real = nq_pad; hx.k = k; hx.mode = mode; hx.root = root; hx.dim = dim;      // (sorted slots: padding and unjudged queries sit at the end - the filter passes none of their pairs)
+    hx.pairs = dev_pairs; hx.pair_counts = dev_pair_counts; hx.pair_cap = pair_cap; hx.qnn = nullptr; hx.evals = dev_evals;
+    hx.tiles_per_part = 0; hx.tile_begin = 0; hx.tile_end = 0; hx.part_base = 0;
+
+    BatchArgsQ8 a;
+    a.rows = dev_rows_tm; a.rstat = reinterpret_cast<const float4 *>(dev_rstat); a.qcodes = qcodes; a.qstat = qstat;
+    a.n_rows = n_rows; a.stride = q8stride; a.nq_pad = nq_pad; a.k = k; a.mode = mode; a.root = root;
+    a.rel = (float)(dim + 64) * 2.384185791015625e-7f;               // (D + 64) 2^-22
+    a.part_base = 0;
+    a.pairs = dev_pairs; a.pair_counts = dev_pair_counts; a.pair_cap = pair_cap; a.flag_index = flag_index;
+    const size_t smem = vgq_lds_bytes(ntb);
+    // Stages over growing row ranges: the lists are merged after every stage and the next one starts from every query's k-th best over
+    // all rows so far.  Stage 0: two tiles, every gate open (1024 pairs per region and tile), exact lists behind it - no pre-pass kernel of
+    // another kind.  Then x8 while a stage is small (its launches are what it costs), x4 from 1/32 of the corpus on (fewer pairs for the
+    // exact evaluation: ~k ln(growth) rows per query truly enter, several times that pass the int8 bound).
+    long long bounds[24];
+    int nstages = 0;
+    {
+        const char *es = getenv("VG_BATCH_STAGES");
+        const int late_growth = (es && *es && atoi(es) > 100) ? atoi(es) : 400;
+        bounds[0] = 0;
+        long long b = VGQ_STAGE0_TILES;
+        while (b < ntiles && nstages + 2 < 24 && ntiles - b > b / 4) {      // (no sliver at the end)
+            bounds[++nstages] = b;
+            b = (b < ntiles / 32) ? b * 8 : b * late_growth / 100;
+        }
+        bounds[++nstages] = ntiles;
+    }
+    for (int s = 0; s < nstages; ++s) {
+        a.tile_begin = bounds[s]; a.tile_end = bounds[s + 1];
+        const long long tiles_s = a.tile_end - a.tile_begin;
+        // a stage of few tiles runs over fewer partitions: fewer regions for the exact-evaluation kernel, fewer lists for the merge
+        const int np = s == 0 ? 8 : (int)std::min<long long>(npart, std::max<long long>(8, (tiles_s / 4) / 8 * 8));
+        a.npart = np; a.npart_total = np;
+        a.tiles_per_part = (int)((tiles_s + np - 1) / np);
+        a.init_keys = s == 0 ? nullptr : dev_out_keys;
+        hx.npart = np; hx.npart_total = np; hx.n_regions = vg_batch_q8_regions(nq_pad, np);
+        hx.init_keys = a.init_keys; hx.seed = (s > 0) ? 1 : 0;
+        const int blocks = G * np;
+        if (ntb == 4) rc = launch_q8_mode<4>(a, blocks, smem, stream);
+        else if (ntb == 8) rc = launch_q8_mode<8>(a, blocks, smem, stream);
+        else if (ntb == 12) rc = launch_q8_mode<12>(a, blocks, smem, stream);
+        else rc = launch_q8_mode<16>(a, blocks, smem, stream);
+        if (rc != 0) return rc;
+        if ((rc = vgh_launch_exact_f32(&hx, xntb, hx_waves, hx.n_regions, smem_exact, stream)) != 0) return rc;
+        if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, np, np, k, dev_out_keys, stream)) != 0) return rc;
+    }
+    return 0;
+}

@@ -129,6 +129,8 @@ extern "C" void vg_corpus_destroy(vg_corpus *c) {
     if (c->d_n4stat) hipFree(c->d_n4stat);
     if (c->d_rows_q8) hipFree(c->d_rows_q8);
     if (c->d_q8stat) hipFree(c->d_q8stat);
+    if (c->d_rows_q8tm) hipFree(c->d_rows_q8tm);
+    if (c->d_q8tm_stat) hipFree(c->d_q8tm_stat);
     if (c->d_filter_evals) hipFree(c->d_filter_evals);
     if (c->h_filter_evals) hipHostFree(c->h_filter_evals);
     if (c->d_below) hipFree(c->d_below);
@@ -153,6 +155,7 @@ extern "C" int vg_corpus_clear(vg_corpus *c) {
     c->tm_rows = 0;
     c->bf_rows = 0;
     c->q8_rows = 0;
+    c->q8tm_rows = 0;
     c->n4_rows = 0;
     c->n4_probe = 0;
     c->rowids.clear();
@@ -178,7 +181,7 @@ extern "C" int vg_corpus_device_bytes(const vg_corpus *c, long long *out3) {
         return (long long)n;
     };
     out3[0] = size_of(c->d_rows);
-    const void *derived[] = {c->d_rows_s8, c->d_sx, c->d_rows_tm, c->d_rows_bf, c->d_rows_q8, c->d_q8stat, c->d_rows_n4, c->d_n4stat, c->d_xnorm};
+    const void *derived[] = {c->d_rows_s8, c->d_sx, c->d_rows_tm, c->d_rows_bf, c->d_rows_q8, c->d_q8stat, c->d_rows_q8tm, c->d_q8tm_stat, c->d_rows_n4, c->d_n4stat, c->d_xnorm};
     const void *working[] = {c->d_query, c->d_cand, c->d_cand_pre, c->d_keys, c->d_dist, c->d_below, c->d_ref_prefix, c->d_sel_keys, c->d_sel_sorted,
                              c->d_sel_temp, c->d_sel_state, c->d_stage, c->d_filter_evals, c->d_bq, c->d_bcand, c->d_bkeys, c->d_bpairs, c->d_bpcounts};
     out3[1] = 0; out3[2] = 0;
@@ -406,6 +409,7 @@ static void invalidate_derived_from(vg_corpus *c, int64_t pos) {
     c->tm_rows = std::min(c->tm_rows, pos);
     c->bf_rows = std::min(c->bf_rows, pos);
     c->q8_rows = std::min(c->q8_rows, pos);
+    c->q8tm_rows = std::min(c->q8tm_rows, pos);
     c->n4_rows = std::min(c->n4_rows, pos);
     c->dist_valid_rows = 0;
 }

@@ -108,6 +108,12 @@ struct vg_corpus {
     uint8_t *d_rows_q8 = nullptr;                 // f32 corpora: int8 shadow copy for the single-query filter scan (vg_filter.hip) ...
     void *d_q8stat = nullptr;                     // ... and per row (scale, residual norm) as float2
     int64_t q8_rows = 0, q8_cap = 0;
+    uint8_t *d_rows_q8tm = nullptr;               // f32 corpora: the TILE-MAJOR copy of that int8 shadow, what the int8 batch filter streams (vg_batch_q8.hip) ...
+    void *d_q8tm_stat = nullptr;                  // ... and per row (scale | -1, residual norm, ||x||, 0) as float4, two tiles of slack behind the last row
+    int64_t q8tm_rows = 0, q8tm_cap = 0;
+    bool q8tm_disabled = false;                   // (it did not fit: batches keep the bf16 filter / the f32 matrix-core kernel)
+    int bq8_cooldown = 0;                         // > 0: a batch overflowed a pair region - that many batches take the other paths
+    int bq8_status = 0;                           // the last int8-filter batch: 0 answered, 1 no room for the copies, 2 shape not served, 3 a pair region overflowed (vg_batch_q8_status)
     uint8_t *d_rows_n4 = nullptr;                 // uint8 / int8 corpora: high-nibble shadow copy for the filter scan (vg_scan_filter_n4.h) ...
     void *d_n4stat = nullptr;                     // ... and per row (sum x^2, sum of low nibbles, their centred norm), 16 bytes
     int64_t n4_rows = 0, n4_cap = 0;
@@ -237,6 +243,7 @@ bool vg_scan_filter_name(vg_corpus *c, int metric, char *out, size_t out_len);  
 bool vg_batch_keys_are_scan_exact(const vg_corpus *c, int metric, int k);   // vg_batch_api.hip: a batch's floats are the single scan's
 long long vg_bf16_shadow_stride(const vg_corpus *c);               // vg_batch_api.hip: row stride of the bf16 shadow copy of an f32 corpus
 int vg_ensure_bf16_shadow(vg_corpus *c);                           // vg_batch_api.hip: build / extend it (corpus stream)
+int vg_ensure_q8_shadow(vg_corpus *c);                             // vg_filter.hip: the int8 shadow copy + per-row (scale, residual norm)
 int vg_multi_queries_per_pass(const vg_corpus *c, int metric);     // vg_multi.hip: queries per pass of the multi-query scan, 0 = none
 int vg_launch_scan_multi(vg_corpus *c, int metric, const uint8_t *dev_queries, int k, uint64_t *dev_cand,
                          uint64_t *dev_out_keys, hipStream_t stream);   // vg_multi.hip; -1: no multi-query kernel for this shape

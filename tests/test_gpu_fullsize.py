@@ -18,6 +18,16 @@ pytestmark = pytest.mark.gpu
 
 N = 10_000_000
 
+def f32_bar(metric, q, d):
+    """north_star's f32 bar taken literally: 1e-5 RELATIVE to the distance - for every metric, at every rank.  Only a dot product
+    that sits inside its own cancellation floor (|d| <= 1e-3 sum |q_i x_i|, ~ 4 sum |q_i| for N(0,1) rows - no winner of these
+    corpora does: |d| ~ 90 against ~1.2) keeps the sum |q_i x_i| term, because there no summation order has relative accuracy."""
+    d = np.abs(np.asarray(d, dtype=np.float64))
+    if metric != dg.DOT:
+        return 1e-5 * d
+    scale = float(np.abs(np.asarray(q, dtype=np.float64)).sum()) * 4.0
+    return np.where(d > 1e-3 * scale, 1e-5 * d, 1e-5 * (d + scale))
+
 
 @pytest.fixture(scope="module")
 def env():
@@ -167,10 +177,7 @@ def test_c5_batched_10m(env, metric):
             # at most one row per query, and the distance sequences still agree within the bar (checked below)
             assert len(set(ids[i].tolist()) ^ set(one_ids.tolist())) <= 2, i
             swapped += 1
-        scale = 1.0 if metric != dg.L2 else 0.0
-        if metric == dg.DOT:
-            scale = float(np.abs(qs[i]).sum()) * 4.0                           # ~ sum |q_i x_i| for N(0,1) rows
-        assert np.all(np.abs(dist[i] - one_dist) <= 1e-5 * (np.abs(one_dist) + scale)), i
+        assert np.all(np.abs(dist[i] - one_dist) <= f32_bar(metric, qs[i], one_dist)), i
     assert swapped <= 8, swapped                                         # (rowid parity with the REFERENCE's kernel: test_gpu_reference_parity.py)
     c.close()
 
@@ -231,8 +238,7 @@ def test_f32_768_batch_10m_through_the_bf16_filter(env):
         assert np.all(cnt == k) and np.all(np.diff(dist, axis=1) >= 0)
         for i in range(0, nq, 11):
             one_ids, one_dist = c.scan_topk(metric, qs[i], k)
-            scale = float(np.abs(qs[i]).sum()) * 4.0 if metric == dg.DOT else (1.0 if metric == dg.COSINE else 0.0)
-            assert np.all(np.abs(dist[i] - one_dist) <= 1e-5 * (np.abs(one_dist) + scale) + 1e-6), (metric, i)
+            assert np.all(np.abs(dist[i] - one_dist) <= f32_bar(metric, qs[i], one_dist)), (metric, i)
             assert len(set(ids[i].tolist()) ^ set(one_ids.tolist())) <= 2, (metric, i)
     c.close()
 
@@ -258,8 +264,7 @@ def test_long_rows_batch_10m(env, vt_name, dim):
         for i in range(0, nq, 37):
             one_ids, one_dist = c.scan_topk(metric, qs[i], k)
             if vt == pkg.F32:
-                scale = float(np.abs(qf[i]).sum()) * 4.0 if metric == dg.DOT else (1.0 if metric == dg.COSINE else 0.0)
-                assert np.all(np.abs(dist[i] - one_dist) <= 1e-5 * (np.abs(one_dist) + scale) + 1e-6), (metric, i)
+                assert np.all(np.abs(dist[i] - one_dist) <= f32_bar(metric, qf[i], one_dist)), (metric, i)
             else:
                 assert np.allclose(dist[i], one_dist, rtol=1e-6, atol=1e-7), (metric, i)
             assert len(set(ids[i].tolist()) ^ set(one_ids.tolist())) <= 2, (metric, i)
