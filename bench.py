@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - vectors scanned / second for the sqlite-vector hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b|c5h|c5f|c5l|stage|sql] [--no-also]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--workload c1|c2|c3|c5|c3b|c5h|c5f|c5q|c5l|stage|sql] [--no-also]
 
 Default line (BASELINE.json configs[1]): 10M x 384 f32, L2, top-20, single query, corpus resident in HBM, answered by
 the PLAIN f32 scan kernel (vg_scan_kernel; the shadow-copy filter is switched off for this corpus), so that
@@ -70,6 +70,9 @@ WORKLOADS = {
     # c5 answered through the bf16 filter (VG_F32_FILTER=1: bf16 shadow copy on the matrix cores, f32 exact re-evaluation of the
     # survivors) instead of the f32 MFMA kernel - same question, same f32 distances, the GEMM at the bf16 rate
     "c5f": (1, np.float32, 384, 4, "batched 1024 queries x 10Mx384 f32 dot top-20 (bf16 MFMA filter over a shadow copy + exact f32 re-evaluation + fused top-k)"),
+    # c5 through the product's DEFAULT path for a batch of this size (round 5): the int8 shadow copy on the integer matrix cores as the filter
+    # (vg_batch_q8.hip), exact f32 re-evaluation of the pairs that pass - priced on the int8 MFMA rate, the instruction it runs on
+    "c5q": (1, np.float32, 384, 4, "batched 1024 queries x 10Mx384 f32 dot top-20 (int8 MFMA filter over the int8 shadow copy + exact f32 re-evaluation)"),
     # long rows (not a BASELINE config): 1536-dimensional f32 embeddings - the K dimension split over the wavefronts of
     # a workgroup (vg_batch_hl.hip), bf16 shadow copy on the matrix cores, exact f32 re-evaluation; reported next to one scan per query
     "c5l": (1, np.float32, 1536, 4, "batched 1024 queries x 10Mx1536 f32 dot top-20 (K-split bf16 MFMA filter over a shadow copy + exact f32 re-evaluation)"),
@@ -133,91 +136,104 @@ def make_shard(pkg, torch, vt, dim, n_rows, seed, device):
     return corpus
 
 
-def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows, seconds=10.0, all_cores=True):
-    """reference kernel + reference top-k loop, one core, bounded sample (`seconds` of CPU work)."""
+_SAMPLES = {}
+
+
+def corpus_sample(pkg, torch, vt, dim, n_rows, seed, want):
+    """the first `want` rows of the synthetic shard (shard_blocks: the same seeded device stream the GPU corpus was built from), copied
+    back to the host: SURVEY 8(d)'s "same inputs" - the CPU legs time the reference on rows the GPU scanned, not on a numpy look-alike"""
+    want = int(min(want, n_rows))
+    key = (vt, dim, seed)
+    have = _SAMPLES.get(key)
+    if have is not None and have.shape[0] >= want:
+        return have[:want]
+    parts, got = [], 0
+    for r0, t in shard_blocks(pkg, torch, vt, dim, n_rows, seed):
+        take = min(t.shape[0], want - got)
+        h = t[:take].cpu()
+        parts.append(h.view(torch.int16).numpy().view(np.uint16) if vt in (pkg.F16, pkg.BF16) else h.numpy())
+        got += take
+        if got >= want:
+            break
+    _SAMPLES[key] = np.ascontiguousarray(np.concatenate(parts))
+    return _SAMPLES[key]
+
+
+def rows_at(pkg, torch, vt, dim, n_rows, seed, positions):
+    """{position: row} for a handful of positions of the synthetic shard, regenerated from its seeded device stream"""
+    want = sorted(set(int(p) for p in positions))
+    out, i = {}, 0
+    for r0, t in shard_blocks(pkg, torch, vt, dim, n_rows, seed):
+        while i < len(want) and want[i] < r0 + t.shape[0]:
+            out[want[i]] = t[want[i] - r0].cpu().numpy().copy()
+            i += 1
+        if i >= len(want):
+            break
+    return out
+
+
+def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows, seconds=10.0, all_cores=True, rows=None, queries=None):
+    """reference kernel + reference top-k loop, one core, bounded sample (`seconds` of CPU work).  rows / queries: rows of the GPU's own
+    corpus (corpus_sample) and the queries the GPU timed; without them (a box without torch) a numpy stream of the same distribution."""
     from oracle import orc
-    rng = np.random.default_rng(42)
-    if vt == 1:
-        rows = rng.standard_normal((sample_rows, dim), dtype=np.float32)
-        q = rng.standard_normal(dim, dtype=np.float32)
-    else:                                        # SURVEY 8(d): f32 U[0,1) quantized with the reference's formula
-        rows = quantize_unit_uniform_np(rng.random((sample_rows, dim), dtype=np.float32))
-        q = quantize_unit_uniform_np(rng.random(dim, dtype=np.float32))
-    kind, runner = "port", None
+    same_inputs = rows is not None and queries is not None
+    if not same_inputs:
+        rng = np.random.default_rng(42)
+        if vt == 1:
+            rows = rng.standard_normal((sample_rows, dim), dtype=np.float32)
+            queries = rng.standard_normal((4, dim), dtype=np.float32)
+        else:                                        # SURVEY 8(d): f32 U[0,1) quantized with the reference's formula
+            rows = quantize_unit_uniform_np(rng.random((sample_rows, dim), dtype=np.float32))
+            queries = quantize_unit_uniform_np(rng.random((4, dim), dtype=np.float32))
+    queries = np.ascontiguousarray(queries)
+    one = np.ascontiguousarray(rows[:sample_rows])
+    sample_rows = one.shape[0]
+    q = queries[0]
+    kind, ref = "port", None
     if orc.have_ref():
         ref = orc.RefKernels("avx2")
         kind = "reference"
-        work = lambda v: ref.scan_topk(metric, vt, q, v, k)              # noqa: E731
+        work = lambda v, qq: ref.scan_topk(metric, vt, qq, v, k)         # noqa: E731
         label = "oracle/_ref/libref_avx2.so (reference distance-avx2.c kernel via dispatch table, backend %s)" % ref.backend_name
     else:
-        work = lambda v: orc.scan_topk_reference(orc.AVX2, metric, vt, q, v, None, k)   # noqa: E731
+        work = lambda v, qq: orc.scan_topk_reference(orc.AVX2, metric, vt, qq, v, None, k)   # noqa: E731
         label = "oracle/liboracle.so (C restatement, AVX2 order, scalar)"
-    runner = lambda: work(rows)                   # noqa: E731
-    runner()                                     # warm (page in)
+    work(one, q)                                 # warm (page in)
     reps, t0 = 0, time.perf_counter()
     while True:
-        runner()
+        work(one, queries[reps % len(queries)])
         reps += 1
         el = time.perf_counter() - t0
         if el > seconds or reps >= 40:
             break
     out = {"value": sample_rows * reps / el, "unit": "vectors/s", "cores": 1, "kind": kind,
-           "sample": "%d queries over a %dx%d %s sample, top-%d, %s; host has %d logical cores" %
-                     (reps, sample_rows, dim, np.dtype(np_dtype).name, k, label, os.cpu_count())}
+           "sample": "%d queries over %s, %dx%d %s, top-%d, %s; host has %d logical cores" %
+                     (reps, "the first rows of the GPU's own corpus (copied back) with the queries the GPU timed" if same_inputs
+                      else "a numpy sample of the corpus' distribution", sample_rows, dim, np.dtype(np_dtype).name, k, label, os.cpu_count())}
     if not all_cores:
         return out
-    # A ROW-SPLIT of one corpus over every logical core of the host (SURVEY 8d): thread i runs the reference's single-threaded loop
-    # (kernel + top-k) over rows [i P, (i+1) P) of ONE matrix, query after query; a query's answer is the merge of the per-range lists
-    # by (distance, position) - checked once against the unsplit scan.  >= 8k rows per range = ~1 ms of kernel work per call (the
-    # Python dispatch of a call is noise next to it); the matrix is the sample tiled up to nthreads x P rows (its values do not matter
-    # to the time; no two threads stream the same memory).
+    # A ROW SPLIT of one corpus over every logical core of the host (SURVEY 8d: a generous upper bound - the reference itself is one
+    # thread): oracle.c's pthread harness (orc_scan_topk_threads) - thread i loops the reference's kernel inside the reference's top-k loop
+    # over rows [i P, (i+1) P); a query's answer is the merge of the per-range lists, checked once against the unsplit scan.  No
+    # interpreter in the timed loop.
     try:
-        import threading
+        if ref is None:
+            raise RuntimeError("needs oracle/_ref (the reference's own kernel)")
         nthreads = max(1, os.cpu_count() or 1)
-        per_thread = max(8192, min(65536, (6 << 30) // max(1, nthreads * dim * rows.itemsize)))
-        need = nthreads * per_thread
-        big = np.tile(rows, ((need + sample_rows - 1) // sample_rows, 1))[:need] if need > sample_rows else rows[:need]
-        per_thread = big.shape[0] // nthreads
-        views = [big[i * per_thread:(i + 1) * per_thread] for i in range(nthreads)]
-        counts = [0] * nthreads
-        first = [None] * nthreads                     # every range's list for the first query
-        go, stop = threading.Event(), threading.Event()
-
-        def worker(i):                                # every thread loops on its own rows: no per-call dispatch from a pool
-            first[i] = work(views[i])                 # warm - and the first query's list over this range
-            go.wait()
-            while not stop.is_set():
-                work(views[i])
-                counts[i] += 1
-
-        ths = [threading.Thread(target=worker, args=(i,)) for i in range(nthreads)]
-        for t in ths:
-            t.start()
-        time.sleep(0.5)
-        t1 = time.perf_counter()
-        go.set()
-        time.sleep(4.0)
-        stop.set()
-        for t in ths:
-            t.join()
-        el2 = time.perf_counter() - t1
-        merged_ok = None
-        try:                                          # merge the ranges' lists of that query by (distance, position); compare with the unsplit scan
-            cand = []
-            for i, res in enumerate(first):
-                ids_i, dist_i = res[0], res[1]
-                cand += [(float(d), int(r) + i * per_thread) for r, d in zip(np.asarray(ids_i).tolist(), np.asarray(dist_i).tolist())]
-            cand.sort()
-            whole = work(big[:nthreads * per_thread])
-            merged_ok = [c[1] for c in cand[:k]] == np.asarray(whole[0]).tolist()[:k] or sorted(c[0] for c in cand[:k]) == sorted(np.asarray(whole[1]).tolist()[:k])
-        except Exception:
-            merged_ok = None
-        out["all_cores"] = {"value": per_thread * sum(counts) / el2, "unit": "vectors/s", "cores": nthreads,
-                            "rows": nthreads * per_thread, "merged_lists_equal_the_unsplit_scan": merged_ok,
-                            "note": "a row-split of ONE %d x %d matrix: %d threads = every logical core, thread i loops the reference's "
-                                    "single-threaded kernel + top-k over rows [i P, (i+1) P), P = %d (ctypes releases the GIL); a query's "
-                                    "answer = the merge of the %d lists (done once, untimed: %d x %d candidates)" % (
-                                        nthreads * per_thread, dim, nthreads, per_thread, nthreads, nthreads, k)}
+        per = rows.shape[0] // nthreads
+        if per < 2048:
+            raise RuntimeError("sample too small for %d threads" % nthreads)
+        big = rows[:per * nthreads]
+        rate, per, ids, d, cnt = ref.scan_topk_all_cores(metric, vt, queries[:8], big, k, nthreads, 4.0)
+        cand = sorted((float(dd), int(i) - 1 + t * per) for t in range(nthreads) for i, dd in zip(ids[t][:cnt[t]], d[t][:cnt[t]]))[:k]
+        whole = work(big, q)
+        merged_ok = [c[1] + 1 for c in cand] == np.asarray(whole[0]).tolist()[:k] or sorted(c[0] for c in cand) == sorted(np.asarray(whole[1]).tolist()[:k])
+        out["all_cores"] = {"value": rate, "unit": "vectors/s", "cores": nthreads, "rows": int(per * nthreads),
+                            "merged_lists_equal_the_unsplit_scan": bool(merged_ok),
+                            "note": "a row split of ONE %d x %d matrix (%s) over %d pthreads = every logical core (oracle/oracle.c orc_scan_topk_threads): thread i "
+                                    "loops the reference's single-threaded kernel + top-k over rows [i P, (i+1) P), P = %d, 4 s; a query's answer = the merge "
+                                    "of the %d lists (done once, untimed)" % (per * nthreads, dim, "rows of the GPU's corpus" if same_inputs else "numpy sample",
+                                                                             nthreads, per, nthreads)}
     except Exception as e:
         out["all_cores"] = {"value": None, "note": "unavailable: %r" % (e,)}
     return out
@@ -235,13 +251,14 @@ def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc
     quantized = corpus.vtype in (pkg.U8, pkg.I8)
     half = corpus.vtype == pkg.F16
     filt = workload in ("c5f", "c5l")
+    q8 = workload == "c5q"
     if quantized:
         batches = [rng.integers(0, 256, (nq, dim)).astype(np.uint8) for _ in range(2)]
     elif half:
         batches = [rng.standard_normal((nq, dim), dtype=np.float32).astype(np.float16) for _ in range(2)]
     else:
         batches = [rng.standard_normal((nq, dim), dtype=np.float32) for _ in range(2)]
-    peak = I8_MFMA_PEAK_TOPS if quantized else (F16_MFMA_PEAK_TF if (half or filt) else F32_MFMA_PEAK_TF)
+    peak = I8_MFMA_PEAK_TOPS if (quantized or q8) else (F16_MFMA_PEAK_TF if (half or filt) else F32_MFMA_PEAK_TF)
     use_dist = dist is not None
     offsets = [i * n_rows for i in range(n_gpus)]
     xdev = "cpu" if share else "cuda"                       # (share: ranks on one device exchange over gloo, host tensors)
@@ -302,13 +319,15 @@ def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc
         "config": {"workload": desc, "rows_per_gpu": n_rows, "dim": dim, "k": k, "queries_per_batch": nq,
                    "sharding": "row-range shard per GPU, RCCL all_gather of nq x k candidate keys per rank" if n_gpus > 1 else "single shard",
                    "backend": pkg.backend_name()},
-        "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TOP/s" if quantized else "TFLOP/s",
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TOP/s" if (quantized or q8) else "TFLOP/s",
                      "frac": tf / peak, "traffic": None,
-                     "kernel": ("vg_batch_i8_kernel<%d>" % ((dim + 31) // 32)) if quantized else
+                     "kernel": ("vg_batch_q8_kernel<%d> + vg_batch_hx_kernel" % ((dim + 31) // 32)) if q8 else ("vg_batch_i8_kernel<%d>" % ((dim + 31) // 32)) if quantized else
                                (("vg_batch_h_kernel<%d>" % ((dim + 15) // 16)) if (half or filt) else ("vg_batch_kernel<%d>" % ((dim + 7) // 8))),
                      "kernel_ms": kern_ms, "launches_timed": n_launch, "flops_per_launch": flops,
                      "note": "kernel_ms = pre-pass + main pass + merges of one batch on one shard" +
-                             ("; peak = the bf16 MFMA rate the filter runs at" if filt else "")}}
+                             ("; peak = the bf16 MFMA rate the filter runs at" if filt else "") +
+                             ("; query images + staged filter / exact-evaluation / merge launches of one batch; peak = the int8 MFMA rate the filter runs at" if q8 else ""),
+                     "batch_path": corpus.last_batch_path()}}
     if workload == "c5l":
         line["roofline"]["kernel"] = "vg_batch_hl_kernel<%d k-steps per wavefront> + vg_batch_hx_kernel" % (((dim * 2 + 31) // 32 + 3) // 4)
         tb, tsrc = batch_traffic("batch_hl_f32_via_bf16_dot_%dq_%d@%d" % (nq, dim, n_rows))
@@ -1001,6 +1020,7 @@ def main():
     vt, np_dtype, dim, metric, desc = WORKLOADS[args.workload]
     if args.workload == "c5f":
         os.environ["VG_F32_FILTER"] = "1"
+        os.environ["VG_BATCH_Q8"] = "0"
     k = args.k
     # one GPU: config C2 / C3 / C5 as stated (10M rows).  Several GPUs: config C4's shard, 12.5M rows per rank - 8 ranks scan
     # the stated 100M rows; every rank count keeps that shard size (weak scaling)
@@ -1015,12 +1035,14 @@ def main():
     corpus = make_shard(pkg, torch, vt, dim, n_rows, 42 + rank, device_index)
     corpus.set_rowid_base(1 + rank * n_rows)
     corpus.set_profiling(True)
-    if args.workload in ("c5", "c3b", "c5h", "c5f", "c5l"):
+    if args.workload in ("c5", "c3b", "c5h", "c5f", "c5q", "c5l"):
+        if args.workload == "c5":
+            corpus.set_scan_filter(0)                                 # the f32 matrix-core kernel (the filters are the default for a corpus of this size)
         out = run_batched(args, pkg, torch, corpus, args.workload, n_rows, dim, metric, k, desc, the_dist, shard, n_gpus, rank,
                           share=share)
         if out is not None:
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = batch_cpu_baseline(args, vt, np_dtype, dim, metric, k)
+                out["cpu_baseline"] = batch_cpu_baseline(args, vt, np_dtype, dim, metric, k, sample=(pkg, torch, n_rows, 42 + rank))
             print(json.dumps(out))
         corpus.close()
         if use_dist:
@@ -1066,7 +1088,9 @@ def main():
     plain_last = dict(runner.last)
     if rank == 0 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(vt, np_dtype, dim, metric, k, args.cpu_sample_rows)
+            want = max(args.cpu_sample_rows, min(4_000_000, (os.cpu_count() or 1) * 8192))
+            sample = corpus_sample(pkg, torch, vt, dim, n_rows, 42 + rank, want)
+            out["cpu_baseline"] = cpu_baseline(vt, np_dtype, dim, metric, k, args.cpu_sample_rows, rows=sample, queries=queries[args.warmup:args.warmup + 8])
         except Exception as e:                                        # the checker is optional on a bare box
             out["cpu_baseline"] = {"value": None, "unit": "vectors/s", "cores": 0, "kind": "port", "sample": "unavailable: %r" % (e,)}
 
@@ -1099,6 +1123,8 @@ def main():
             also["c1"] = also_c1(args, pkg, torch)
         out["also"] = also
     if rank == 0:
+        if "also" in out:
+            out["summary"] = make_summary(out)       # LAST key of the line: what north_star asks for, where a tail of the line still shows it
         print(json.dumps(out))
     if corpus is not None:
         corpus.close()
@@ -1106,6 +1132,33 @@ def main():
         dist.barrier()                 # (rank 0 was timing the CPU baseline meanwhile)
         dist.destroy_process_group()
     return 0
+
+
+def make_summary(out):
+    """a compact digest (< 1 KB) of the line's extras - the fractions north_star's target sentence is about - as the line's last key"""
+    def g(d, *path):
+        for p in path:
+            if not isinstance(d, dict) or p not in d:
+                return None
+            d = d[p]
+        return round(d, 4) if isinstance(d, float) else d
+    a = out.get("also", {})
+    c5 = a.get("c5", {})
+    return {
+        "c2_10m_frac_of_hbm_peak": g(out, "roofline", "frac"), "c2_kernel_ms": g(out, "roofline", "kernel_ms"),
+        "c4_100m_one_gpu_frac_of_hbm_peak": g(a, "c4_one_gpu", "roofline", "frac"), "c4_100m_kernel_ms": g(a, "c4_one_gpu", "roofline", "kernel_ms"),
+        "c3_u8_cosine_frac_of_hbm_peak": g(a, "c3", "roofline", "frac"),
+        "c5_f32_mfma": {"ms_per_step": g(c5, "ms_per_step"), "frac_of_f32_mfma_peak": g(c5, "roofline", "frac")},
+        "c5_bf16_filter": {"ms_per_step": g(c5, "filter_batch", "ms_per_step"), "frac_of_bf16_peak": g(c5, "filter_batch", "frac_of_bf16_peak")},
+        "c5_default_int8_filter": {"ms_per_step": g(c5, "int8_filter_batch", "ms_per_step"), "frac_of_int8_peak": g(c5, "int8_filter_batch", "frac_of_int8_peak"),
+                                   "batch_path": g(c5, "int8_filter_batch", "batch_path"),
+                                   "bit_identical_to_bf16_filter": g(c5, "int8_filter_batch", "last_batch_bit_identical_to_the_bf16_filter"),
+                                   "max_rel_vs_reference_kernel": g(c5, "int8_filter_batch", "last_batch_max_rel_difference_from_the_reference_kernel")},
+        "long_rows_1536": {"ms_per_step": g(a, "long_rows", "ms_per_step"), "frac_of_bf16_peak": g(a, "long_rows", "roofline", "frac")},
+        "c1_sql_p50_ms": g(a, "c1", "p50_query_latency_ms"),
+        "cpu_reference_1_core_vectors_per_s": g(out, "cpu_baseline", "value"),
+        "cpu_reference_all_cores": {"vectors_per_s": g(out, "cpu_baseline", "all_cores", "value"), "cores": g(out, "cpu_baseline", "all_cores", "cores")},
+    }
 
 
 def c3_queries(nq, dim):
@@ -1129,7 +1182,8 @@ def also_c3(args, pkg, torch, shard, also_set, n_rows, k, nq, device_index):
         r3 = SingleQueryRunner(pkg, torch, None, shard, c3, v3, d3, m3, k, n_rows, 1, q3)
         line, _ = single_query_line(args, pkg, r3, c3, "c3", v3, d3, m3, k, n_rows, 1, desc3)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(v3, t3, d3, m3, k, args.cpu_sample_rows, seconds=5.0, all_cores=False)
+            line["cpu_baseline"] = cpu_baseline(v3, t3, d3, m3, k, args.cpu_sample_rows, seconds=5.0, all_cores=False,
+                                                rows=corpus_sample(pkg, torch, v3, d3, n_rows, 42, args.cpu_sample_rows), queries=q3[args.warmup:args.warmup + 8])
         # what the reference's result order costs (its rowids among equal distances; the default of the SQL surface for
         # quantized scans): the same host entry point (vg_scan_topk: host query in, host rowids out) in both orders
         tie = {}
@@ -1246,20 +1300,21 @@ def also_c5(args, pkg, torch, corpus, n_rows, k):
         v5, t5, d5, m5, desc5 = WORKLOADS["c5"]
         line = run_batched(args, pkg, torch, corpus, "c5", n_rows, d5, m5, k, desc5)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = batch_cpu_baseline(args, v5, t5, d5, m5, k, seconds=5.0)
+            line["cpu_baseline"] = batch_cpu_baseline(args, v5, t5, d5, m5, k, seconds=5.0, sample=(pkg, torch, n_rows, 42))
         # the same batches through the bf16 filter (VG_F32_FILTER=1, the shadow copy the filter scan above has made): the
         # GEMM at the bf16 rate over HALF the bytes, every survivor re-evaluated with the f32 single-scan arithmetic.
         # Priced on the bf16 MFMA peak and reported next to the f32 MFMA line, never as its roofline.
+        plain_res = run_batched.last_result
         try:
-            plain_res = run_batched.last_result
             os.environ["VG_F32_FILTER"] = "1"
+            os.environ["VG_BATCH_Q8"] = "0"
             fl = run_batched(args, pkg, torch, corpus, "c5f", n_rows, d5, m5, k, WORKLOADS["c5f"][4])
             fres = run_batched.last_result
             same_ids = bool(np.array_equal(np.asarray(fres[0]), np.asarray(plain_res[0])))
             d_f, d_p = np.asarray(fres[1], dtype=np.float64), np.asarray(plain_res[1], dtype=np.float64)
             line["filter_batch"] = {
                 "what": "the same batches through vg_batch_h_kernel over the bf16 shadow copy (matrix cores as a lower-bound "
-                        "filter) + exact f32 re-evaluation of the survivors: the f32 single scans' distances",
+                        "filter) + exact f32 re-evaluation of the survivors (VG_F32_FILTER=1 VG_BATCH_Q8=0: round 4's default path)",
                 "value": fl["value"], "unit": "vectors/s", "ms_per_step": fl["ms_per_step"], "dtype_streamed": "bf16",
                 "kernel": fl["roofline"]["kernel"], "kernel_ms": fl["roofline"]["kernel_ms"],
                 "achieved_TFLOPs_of_the_QxNxD_product": fl["roofline"]["achieved"], "peak_bf16_TFLOPs": F16_MFMA_PEAK_TF,
@@ -1277,6 +1332,54 @@ def also_c5(args, pkg, torch, corpus, n_rows, k):
             line["filter_batch"] = {"error": repr(e)}
         finally:
             os.environ.pop("VG_F32_FILTER", None)
+            os.environ.pop("VG_BATCH_Q8", None)
+        # the product's DEFAULT path for this batch (round 5): the int8 shadow copy on the integer matrix cores as the filter, 64 queries per
+        # wavefront (vg_batch_q8.hip), the same exact f32 re-evaluation behind it - priced on the int8 MFMA rate
+        try:
+            corpus.set_scan_filter(-1)
+            corpus.batch_filter_exact_evals()
+            ql = run_batched(args, pkg, torch, corpus, "c5q", n_rows, d5, m5, k, WORKLOADS["c5q"][4])
+            qres = run_batched.last_result
+            fres = locals().get("fres")
+            ib = {"what": "the same batches through the default path: vg_batch_q8_kernel over the int8 shadow copy (3.84 GB streamed) + vg_batch_hx_kernel "
+                          "(exact f32 re-evaluation of the pairs that pass), staged over growing row ranges",
+                  "batch_path": ql["roofline"].get("batch_path"), "value": ql["value"], "unit": "vectors/s", "ms_per_step": ql["ms_per_step"],
+                  "dtype_streamed": "int8", "kernel": ql["roofline"]["kernel"], "kernel_ms": ql["roofline"]["kernel_ms"],
+                  "achieved_TOPs_of_the_QxNxD_product": ql["roofline"]["achieved"], "peak_int8_TOPs": I8_MFMA_PEAK_TOPS, "frac_of_int8_peak": ql["roofline"]["frac"],
+                  "speedup_over_f32_mfma_kernel": line["ms_per_step"] / ql["ms_per_step"],
+                  "speedup_over_bf16_filter": (line["filter_batch"]["ms_per_step"] / ql["ms_per_step"]) if "ms_per_step" in line.get("filter_batch", {}) else None,
+                  "last_batch_bit_identical_to_the_bf16_filter": bool(fres is not None and np.array_equal(np.asarray(qres[0]), np.asarray(fres[0])) and
+                                                                      np.array_equal(np.asarray(qres[1]), np.asarray(fres[1]))),
+                  "exact_evaluations_per_query": None}
+            try:
+                ib["exact_evaluations_per_query"] = corpus.batch_filter_exact_evals() / float(args.batch * (min(args.steps, 10) + min(args.warmup, 2)))
+            except Exception:
+                pass
+            # the last batch's winners against the REFERENCE's own kernel: the rows the GPU returned for 8 of its queries, regenerated from the seeded
+            # stream, distance-avx2.c's dot through the dispatch table (oracle/_ref) - the f32 bar is 1e-5 relative
+            try:
+                from oracle import orc
+                if orc.have_ref():
+                    ref = orc.RefKernels("avx2")
+                    qb = batch_queries(v5, args.batch, d5, which=(min(args.steps, 10) - 1) % 2)
+                    ids = np.asarray(qres[0])
+                    pick = list(range(0, args.batch, max(1, args.batch // 8)))[:8]
+                    need = sorted(set(int(r) - 1 for qi in pick for r in ids[qi][:k]))
+                    got = rows_at(pkg, torch, v5, d5, n_rows, 42, need)
+                    worst = 0.0
+                    for qi in pick:
+                        for j in range(k):
+                            dref = ref.distance(m5, v5, qb[qi], got[int(ids[qi][j]) - 1])
+                            worst = max(worst, abs(float(np.asarray(qres[1])[qi][j]) - dref) / max(abs(dref), 1e-30))
+                    ib["last_batch_max_rel_difference_from_the_reference_kernel"] = worst
+                    ib["reference_check"] = "%d queries x %d returned rows, reference distance-avx2.c dot on the same rows (oracle/_ref/libref_avx2.so)" % (len(pick), k)
+            except Exception as e:
+                ib["reference_check"] = "unavailable: %r" % (e,)
+            line["int8_filter_batch"] = ib
+        except Exception as e:
+            line["int8_filter_batch"] = {"error": repr(e)}
+        finally:
+            corpus.set_scan_filter(0)
         return line
     except Exception as e:
         return {"error": repr(e)}
@@ -1460,11 +1563,33 @@ def bench_stage(args, pkg, torch):
     return 0
 
 
-def batch_cpu_baseline(args, vt, np_dtype, dim, metric, k, seconds=10.0):
+def batch_queries(vt, nq, dim, which=0):
+    """the batches run_batched times (its seeded stream, batch `which` of two)"""
+    rng = np.random.default_rng(44)
+    out = None
+    for _ in range(which + 1):
+        if vt in (4, 5):
+            out = rng.integers(0, 256, (nq, dim)).astype(np.uint8)
+        elif vt == 2:
+            out = rng.standard_normal((nq, dim), dtype=np.float32).astype(np.float16)
+        else:
+            out = rng.standard_normal((nq, dim), dtype=np.float32)
+    return out
+
+
+def batch_cpu_baseline(args, vt, np_dtype, dim, metric, k, seconds=10.0, sample=None):
     """the reference has no batched entry point: its batch is Q independent scans, so its (query, vector) pair rate is its
-    single-scan rate for the batch's metric"""
+    single-scan rate for the batch's metric - timed over rows of the GPU's corpus with queries of the timed batch (sample = (pkg, torch,
+    rows of the corpus, its seed))"""
     try:
-        out = cpu_baseline(vt, np_dtype, dim, metric, k, args.cpu_sample_rows, seconds=seconds, all_cores=False)
+        rows = queries = None
+        if sample is not None and vt != 3:
+            pkg, torch, n_rows, seed = sample
+            rows = corpus_sample(pkg, torch, vt, dim, n_rows, seed, args.cpu_sample_rows)
+            queries = batch_queries(vt, args.batch, dim)[:8]
+            if vt == 2:
+                queries = queries.view(np.uint16)
+        out = cpu_baseline(vt, np_dtype, dim, metric, k, args.cpu_sample_rows, seconds=seconds, all_cores=False, rows=rows, queries=queries)
         out["sample"] += "; a batch of Q queries costs the reference Q such scans: (query, vector) pairs/s = this rate"
         return out
     except Exception as e:

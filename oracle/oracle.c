@@ -13,6 +13,9 @@
 #include "oracle.h"
 
 #include <float.h>
+#include <pthread.h>
+#include <sched.h>
+#include <time.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -782,6 +785,83 @@ int orc_scan_topk_with_fn(orc_distance_fn fn, const void *query, const void *row
         }
     }
     return k - sort_slots(out_dist, out_rowids, k);
+}
+
+/* ------------------------------------------------------------------ the reference's scan on every host core (bench.py's cpu_baseline.all_cores)
+ *
+ * The reference is single-threaded: one vFullScanRun walks the table (sqlite-vector.c:2089-2107).  The generous upper bound SURVEY 8(d)
+ * asks for is an embarrassingly parallel ROW SPLIT of one corpus: thread i runs that loop - the reference's own kernel (fn, out of its
+ * dispatch table: distance-avx2.c:67-100 for f32 L2) inside the slot loop above - over rows [i P, (i+1) P), query after query, for
+ * `seconds`; a query's answer would be the k-way merge of the per-thread lists (the caller checks that once, untimed).  Plain pthreads:
+ * no interpreter lock anywhere near the timed loop (round 4 drove this from Python threads: 4.2x one core on 256 threads). */
+typedef struct {
+    orc_distance_fn fn;
+    const uint8_t *queries;          /* nq queries of query_stride bytes, taken round robin */
+    int nq;
+    int64_t query_stride;
+    const uint8_t *rows;
+    int64_t n_rows, row_stride;
+    int dim, k;
+    volatile int *go, *stop;
+    int64_t scans;                   /* completed scans of this thread's range while the clock ran */
+    int64_t *first_ids;              /* k: the list of query 0 over this range (positions 1-based within the range) */
+    double *first_dist;
+    int first_cnt;
+} orc_thread_arg;
+
+static void *orc_thread_main(void *p) {
+    orc_thread_arg *a = (orc_thread_arg *)p;
+    int64_t ids[256];
+    double dist[256];
+    a->first_cnt = orc_scan_topk_with_fn(a->fn, a->queries, a->rows, a->n_rows, a->row_stride, a->dim, NULL, a->k, a->first_ids, a->first_dist);
+    while (!*a->go) sched_yield();
+    int qi = 0;
+    while (!*a->stop) {
+        qi = qi + 1 == a->nq ? 0 : qi + 1;
+        orc_scan_topk_with_fn(a->fn, a->queries + (int64_t)qi * a->query_stride, a->rows, a->n_rows, a->row_stride, a->dim, NULL, a->k, ids, dist);
+        a->scans += 1;
+    }
+    return NULL;
+}
+
+/* returns 0; out_first_*: nthreads x k (the per-range lists of query 0), out_counts: nthreads, out_rows_per_thread, out_elapsed (s),
+ * out_scans: total completed range scans while the clock ran (vectors scanned = out_scans * rows_per_thread) */
+int orc_scan_topk_threads(orc_distance_fn fn, const void *queries, int nq, int64_t query_stride, const void *rows, int64_t n_rows,
+                          int64_t row_stride, int dim, int k, int nthreads, double seconds, int64_t *out_first_ids, double *out_first_dist,
+                          int *out_counts, int64_t *out_rows_per_thread, double *out_elapsed, int64_t *out_scans) {
+    if (nthreads < 1 || k < 1 || k > 256 || nq < 1 || n_rows < nthreads) return -1;
+    const int64_t per = n_rows / nthreads;
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    orc_thread_arg *args = (orc_thread_arg *)calloc((size_t)nthreads, sizeof(orc_thread_arg));
+    if (!th || !args) { free(th); free(args); return -2; }
+    volatile int go = 0, stop = 0;
+    int started = 0;
+    for (int i = 0; i < nthreads; ++i) {
+        orc_thread_arg *a = &args[i];
+        a->fn = fn; a->queries = (const uint8_t *)queries; a->nq = nq; a->query_stride = query_stride;
+        a->rows = (const uint8_t *)rows + (int64_t)i * per * row_stride; a->n_rows = per; a->row_stride = row_stride;
+        a->dim = dim; a->k = k; a->go = &go; a->stop = &stop; a->scans = 0;
+        a->first_ids = out_first_ids + (int64_t)i * k; a->first_dist = out_first_dist + (int64_t)i * k;
+        if (pthread_create(&th[i], NULL, orc_thread_main, a) != 0) break;
+        ++started;
+    }
+    struct timespec t0, t1, nap;
+    nap.tv_sec = 0; nap.tv_nsec = 300 * 1000 * 1000;                /* every thread finishes its first (warm) scan before the clock starts */
+    nanosleep(&nap, NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    go = 1;
+    nap.tv_sec = (time_t)seconds; nap.tv_nsec = (long)((seconds - (double)(time_t)seconds) * 1e9);
+    nanosleep(&nap, NULL);
+    stop = 1;
+    for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    int64_t scans = 0;
+    for (int i = 0; i < started; ++i) { scans += args[i].scans; out_counts[i] = args[i].first_cnt; }
+    *out_rows_per_thread = per;
+    *out_elapsed = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    *out_scans = scans;
+    free(th); free(args);
+    return started == nthreads ? 0 : -3;
 }
 
 /* ------------------------------------------------------------------ quantizer */

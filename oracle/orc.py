@@ -55,6 +55,9 @@ def _lib():
     lib.orc_scan_topk_with_fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                           C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.orc_quantize.restype = None
+    lib.orc_scan_topk_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_scan_topk_threads.restype = C.c_int
     lib.orc_quantize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int]
     lib.orc_quant_params.restype = None
     lib.orc_quant_params.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
@@ -210,6 +213,23 @@ class RefKernels:
         cnt = lib().orc_scan_topk_with_fn(fnptr, _ptr(query), _ptr(rows), rows.shape[0], rows.strides[0],
                                           rows.shape[1], None, k, _ptr(out_ids), _ptr(out_d))
         return out_ids[:cnt], out_d[:cnt]
+
+    def scan_topk_all_cores(self, metric, vtype, queries, rows, k, nthreads, seconds):
+        """the reference's kernel inside the reference's top-k loop on `nthreads` pthreads, a row split of `rows` (oracle.c:
+        orc_scan_topk_threads); returns (vectors scanned per second, rows per thread, per-range lists of query 0: ids, dist, counts)"""
+        rows = np.ascontiguousarray(rows)
+        queries = np.ascontiguousarray(queries)
+        fnptr = C.cast(self.table[metric][vtype], C.c_void_p)
+        first_ids = np.zeros((nthreads, k), dtype=np.int64)
+        first_d = np.zeros((nthreads, k), dtype=np.float64)
+        counts = np.zeros(nthreads, dtype=np.int32)
+        per, el, scans = C.c_int64(0), C.c_double(0.0), C.c_int64(0)
+        rc = lib().orc_scan_topk_threads(fnptr, _ptr(queries), queries.shape[0], queries.strides[0], _ptr(rows), rows.shape[0], rows.strides[0],
+                                         rows.shape[1], k, nthreads, float(seconds), _ptr(first_ids), _ptr(first_d), _ptr(counts),
+                                         C.byref(per), C.byref(el), C.byref(scans))
+        if rc != 0:
+            raise RuntimeError("orc_scan_topk_threads: %d" % rc)
+        return scans.value * per.value / el.value, per.value, first_ids, first_d, counts
 
     def scan(self, metric, vtype, query, rows):
         rows = np.ascontiguousarray(rows)

@@ -55,6 +55,8 @@ struct BatchArgsH {
     uint32_t *pair_counts;
     int pair_cap, n_regions;
     const float *qnn;         // vg_batch_hl.hip: (float) sum q^2 per query (nq_pad), made by the host once per batch
+    int lds_pairs;            // vg_batch_hx_kernel: copy a region's pairs into LDS first (the launch provides pair_cap * 8 more bytes of it): the walk
+                              // over them - 64 pair words per look, one look per pair - then costs LDS reads instead of an L2 round trip each
 };
 
 template <int CTRL> __device__ __forceinline__ uint64_t vgh_dpp64(uint64_t v) {
@@ -121,6 +123,13 @@ __global__ __launch_bounds__(64 * VGHX_WAVES) void vg_batch_hx_kernel(BatchArgsH
     for (int sub = 0; sub < subs; ++sub) {
     const unsigned n = a.pair_counts[region * subs + sub];
     const uint64_t *my_pairs = a.pairs + (region * subs + sub) * a.pair_cap;
+    if (a.lds_pairs) {                                                // (block-uniform)
+        uint64_t *lp = wave_lists + VGH_QPW * k;
+        __syncthreads();                                              // (the previous sub-region's copy is no longer read)
+        for (unsigned i = threadIdx.x; i < n; i += 64 * VGHX_WAVES) lp[i] = my_pairs[i];
+        __syncthreads();
+        my_pairs = lp;
+    }
     n_all += n;
     // Two pair slots, A and B: the row (and query) of pair i+1 is in flight while pair i is evaluated - one wavefront walks its pairs in
     // order (a query's list insertions are ordered), and with one HBM round trip per pair exposed the kernel took half as long as the

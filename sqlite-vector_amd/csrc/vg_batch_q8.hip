@@ -671,14 +671,14 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     const int flag_index = vg_batch_q8_regions(nq_pad, npart);
     const int hx_waves = VGQ_WAVES * VGQ_QS;
     const int xntb = (int)((((long long)dim * 2 + 15) / 16 * 16 + 31) / 32);      // k-steps of the bf16 image: what picks the exact kernel's chunks per lane
-    const size_t smem_exact = (size_t)VGH_QPW * (8 + 4 + 4 + 4) + (size_t)VGH_QPW * k * 8;
+    const size_t smem_exact = (size_t)VGH_QPW * (8 + 4 + 4 + 4) + (size_t)VGH_QPW * k * 8 + (size_t)pair_cap * 8;      // (+ the region's pairs)
     if ((rc = (int)hipMemsetAsync(dev_pair_counts + flag_index, 0, sizeof(uint32_t), stream)) != 0) return rc;
 
     BatchArgsH hx;                                                    // the exact-evaluation kernel's view (vg_batch_hx_kernel)
     hx.rows = nullptr; hx.tiled = 1; hx.queries = xq_sorted; hx.xrows = dev_xrows; hx.xqueries = xq_sorted; hx.xstride = xstride;
     hx.cerr = 0.0f; hx.row_nn = dev_xnorm; hx.cand = dev_cand; hx.n_rows = n_rows; hx.stride = q8stride;
     hx.nq_pad = nq_pad; hx.nq_real = nq_pad; hx.k = k; hx.mode = mode; hx.root = root; hx.dim = dim;      // (sorted slots: padding and unjudged queries sit at the end - the filter passes none of their pairs)
-    hx.pairs = dev_pairs; hx.pair_counts = dev_pair_counts; hx.pair_cap = pair_cap; hx.qnn = nullptr; hx.evals = dev_evals;
+    hx.pairs = dev_pairs; hx.pair_counts = dev_pair_counts; hx.pair_cap = pair_cap; hx.qnn = nullptr; hx.evals = dev_evals; hx.lds_pairs = 1;
     hx.tiles_per_part = 0; hx.tile_begin = 0; hx.tile_end = 0; hx.part_base = 0;
 
     BatchArgsQ8 a;
@@ -701,7 +701,7 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
         long long b = VGQ_STAGE0_TILES;
         while (b < ntiles && nstages + 2 < 24 && ntiles - b > b / 4) {      // (no sliver at the end)
             bounds[++nstages] = b;
-            b = (b < ntiles / 32) ? b * 8 : b * late_growth / 100;
+            b = (b < ntiles / 256) ? b * 8 : ((b < ntiles / 16) ? b * 4 : b * late_growth / 100);
         }
         bounds[++nstages] = ntiles;
     }
