@@ -1141,7 +1141,7 @@ def make_summary(out):
             if not isinstance(d, dict) or p not in d:
                 return None
             d = d[p]
-        return round(d, 4) if isinstance(d, float) else d
+        return float("%.4g" % d) if isinstance(d, float) else d
     a = out.get("also", {})
     c5 = a.get("c5", {})
     return {

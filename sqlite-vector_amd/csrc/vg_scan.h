@@ -369,6 +369,8 @@ __global__ __launch_bounds__(256) void vg_half_rownorm_kernel(const uint8_t *row
             }
         }
         const double s = vg_group_sum((s0 + s1) + (s2 + s3), 4);
-        if (sub == 0) out[row0 + r] = (float)s;
+        // (a sum that is not zero must not READ as zero: the filters judge a row of zeros - and only that - by its norm being exactly 0;
+        //  bf16 elements below ~1e-23 square to less than the smallest float: such a row keeps the smallest one and stays unjudged)
+        if (sub == 0) { const float f = (float)s; out[row0 + r] = (s > 0.0 && f == 0.0f) ? 1.401298464324817e-45f : f; }
     }
 }

@@ -99,9 +99,9 @@ static void fn_gpu_memory(sqlite3_context *ctx, int argc, sqlite3_value **argv) 
 
 /* vector_gpu_stats(): an addition over the reference's surface - what staging into HBM has cost this process, as JSON text */
 static void fn_gpu_stats(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
+    const stage_stats g = stage_stats_read();
     char *js = sqlite3_mprintf("{\"stage_passes\":%lld,\"parallel_reader_passes\":%lld,\"rows_staged\":%lld,\"seconds_staging\":%.6f,\"seconds_in_engine_append\":%.6f,\"seconds_count_star\":%.6f,\"seconds_hbm_reserve\":%.6f}",
-                               g_stage_stats.passes, g_stage_stats.parallel_passes, g_stage_stats.rows, g_stage_stats.seconds, g_stage_stats.append_seconds,
-                               g_stage_stats.count_seconds, g_stage_stats.reserve_seconds);
+                               g.passes, g.parallel_passes, g.rows, g.seconds, g.append_seconds, g.count_seconds, g.reserve_seconds);
     if (!js) { sqlite3_result_error_nomem(ctx); return; }
     sqlite3_result_text(ctx, js, -1, sqlite3_free);
 }

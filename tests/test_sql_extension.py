@@ -1117,6 +1117,53 @@ def test_parallel_staging_readers_equal_the_single_loop(ext_path, orc, tmp_path,
 
 
 @pytest.mark.gpu
+def test_wal_snapshot_is_staged_by_the_single_loop_not_by_reader_connections(ext_path, orc, tmp_path, monkeypatch):
+    """a statement that calls vector_full_scan already holds a read transaction.  In WAL mode that is a snapshot - reader
+    connections opened by the parallel staging pass would see commits made SINCE (and data_version, frozen while the snapshot is held,
+    could not tell).  Here another connection commits a new best row after the statement has taken its snapshot and before the scan
+    stages the table (a scalar function in front of the scan does the commit): that statement must not see the row - the reference,
+    which reads the table inside the statement's own transaction (sqlite-vector.c:2077), would not - and the next statement must."""
+    import json
+    monkeypatch.setenv("VECTORGPU_STAGE_THREADS", "4")
+    n, dim, k = 250_000, 4, 5
+    rows = dg.corpus(dg.F32, n, dim, 93)
+    q = dg.query(dg.F32, dim, 94)
+    path = str(tmp_path / "wal.db")
+    db0 = sqlite3.connect(path, isolation_level=None)
+    assert db0.execute("PRAGMA journal_mode=WAL").fetchone()[0].lower() == "wal"
+    db0.execute("CREATE TABLE t (id INTEGER PRIMARY KEY, v BLOB)")
+    db0.execute("BEGIN")
+    db0.executemany("INSERT INTO t(id, v) VALUES (?, ?)", [(i + 1, rows[i].tobytes()) for i in range(n)])
+    db0.execute("COMMIT")
+    db = sqlite3.connect(path, isolation_level=None)
+    db.enable_load_extension(True)
+    db.load_extension(ext_path)
+    db.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2')" % dim)
+    poked = []
+
+    def poke():
+        if not poked:
+            db0.execute("INSERT INTO t(id, v) VALUES (?, ?)", (n + 1, q.tobytes()))      # distance 0: the new best row, committed by ANOTHER connection
+            poked.append(1)
+        return 1
+
+    db.create_function("poke", 0, poke)
+    # the statement's read transaction starts when it starts (it reads t in the first sub-select); poke() then runs before the scan's xFilter
+    got = db.execute("SELECT s.c, f.rowid, f.distance FROM (SELECT COUNT(*) + poke() AS c FROM t) AS s, vector_full_scan('t', 'v', ?, %d) AS f" % k,
+                     (q.tobytes(),)).fetchall()
+    assert poked and got[0][0] == n + 1                                   # (COUNT(*) of the snapshot + 1: the committed row is not in it)
+    assert (n + 1) not in [r[1] for r in got], got
+    d = orc.scan_distances(orc.AVX2, dg.L2, dg.F32, q, rows)
+    want_ids, want_d, _ = orc.topk_ordered(d, None, k)
+    assert [r[1] for r in got] == want_ids.tolist()
+    st = json.loads(db.execute("SELECT vector_gpu_stats()").fetchone()[0])
+    assert st["parallel_reader_passes"] == 0, st                         # WAL + an open read transaction: the single loop
+    got2 = db.execute("SELECT rowid, distance FROM vector_full_scan('t', 'v', ?, %d)" % k, (q.tobytes(),)).fetchall()
+    assert got2[0] == (n + 1, 0.0), got2                                  # the next statement sees the commit (data_version moved: re-staged)
+    db.close(); db0.close()
+
+
+@pytest.mark.gpu
 def test_quantize_stages_in_front_of_its_transaction_and_reserves_by_key_span(ext_path, tmp_path, monkeypatch):
     """vector_quantize outside a transaction stages the raw column BEFORE its BEGIN (vext_quantize.inc), where the parallel
     readers can serve it, and the pass inside the transaction accepts that copy: the rows go up once.  The HBM reservation comes
