@@ -1008,6 +1008,7 @@ def main():
 
     import __graft_entry__ as g
     pkg = g.load_package()
+    pkg.AUTO_RELOAD = False                  # (the switches are read at corpus creation; this file re-reads them where it changes the environment)
     shard = load_shard_module()
     if args.workload == "c1":
         if not args.rows:
@@ -1308,6 +1309,7 @@ def also_c5(args, pkg, torch, corpus, n_rows, k):
         try:
             os.environ["VG_F32_FILTER"] = "1"
             os.environ["VG_BATCH_Q8"] = "0"
+            pkg.reload_switches()
             fl = run_batched(args, pkg, torch, corpus, "c5f", n_rows, d5, m5, k, WORKLOADS["c5f"][4])
             fres = run_batched.last_result
             same_ids = bool(np.array_equal(np.asarray(fres[0]), np.asarray(plain_res[0])))
@@ -1333,6 +1335,7 @@ def also_c5(args, pkg, torch, corpus, n_rows, k):
         finally:
             os.environ.pop("VG_F32_FILTER", None)
             os.environ.pop("VG_BATCH_Q8", None)
+            pkg.reload_switches()
         # the product's DEFAULT path for this batch (round 5): the int8 shadow copy on the integer matrix cores as the filter, 64 queries per
         # wavefront (vg_batch_q8.hip), the same exact f32 re-evaluation behind it - priced on the int8 MFMA rate
         try:
@@ -1488,9 +1491,11 @@ def bench_stage(args, pkg, torch):
     lo_w, hi_w, _ = w.minmax()
     w.quantize_rows(255.0 / max(hi_w - lo_w, 1e-6), lo_w, pkg.QUANT_U8, 0, 8192)
     os.environ["VG_SCAN_FILTER_MIN_MB"] = "0"
+    pkg.reload_switches()
     w.set_scan_filter(1)
     w.scan_topk(1, host[0], args.k)
     os.environ.pop("VG_SCAN_FILTER_MIN_MB", None)
+    pkg.reload_switches()
     w.close()
     c = pkg.Corpus(pkg.F32, dim, capacity=n)
     c.append(host[:4096])                                   # warm: pinned buffers, stream
@@ -1546,6 +1551,7 @@ def bench_stage(args, pkg, torch):
     res["quantize"] = priced("vg_quantize_kernel<f32>", q_ms, q_rows * dim * 5, q_rows)
     try:
         os.environ["VG_SCAN_FILTER_MIN_MB"] = "0"
+        pkg.reload_switches()
         c.set_scan_filter(1)
         c.set_profiling(True)
         c.scan_topk(1, host[0], args.k)                      # the first filter scan builds the shadow copy
@@ -1555,6 +1561,7 @@ def bench_stage(args, pkg, torch):
         res["q8_shadow"] = {"error": repr(e)}
     finally:
         os.environ.pop("VG_SCAN_FILTER_MIN_MB", None)
+        pkg.reload_switches()
     out["quantize"] = res
     out["value"] = out["staging"]["achieved"]
     out["roofline"] = dict(res["quantize"])

@@ -41,6 +41,9 @@ int vg_batch_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals);
  * 3 the half-precision kernel (f16 / bf16 rows, f32 rows through their bf16 shadow copy), 4 the long-row form of it (1025 .. 3072
  * elements: the K dimension split over a workgroup's wavefronts), 5 the multi-query scan, 6 one scan per query, 7 the int8 filter over
  * an f32 corpus' int8 shadow copy (vg_batch_q8.hip: batches of more than 256 queries over corpora of 2^20+ rows) */
+/* The engine reads its environment switches (VG_*, csrc/vg_switches.h) when the library is loaded and whenever a corpus / a shard set is
+ * created - never on a query's path.  A test that changes one between two calls on an existing corpus re-reads them with this. */
+void vg_reload_switches(void);
 int vg_batch_last_path(const vg_corpus *c);
 /* how this corpus' last attempt at the int8 batch filter ended: 0 it answered, 1 no room for the tile-major int8 copy, 2 shape not
  * served, 3 a pair region overflowed (the batch was answered by another path and the next 16 batches skip the int8 filter) */

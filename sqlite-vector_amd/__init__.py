@@ -38,7 +38,24 @@ class VectorGpuError(RuntimeError):
 _lib = None
 
 
+# The engine reads its VG_* environment switches when the library is loaded and whenever a corpus / shard set is created - not per query
+# (csrc/vg_switches.h).  Tests and tools flip switches between two calls on one corpus: with AUTO_RELOAD every call through this module
+# re-reads them first (a few microseconds); bench.py turns it off and calls reload_switches() where it changes the environment.
+AUTO_RELOAD = True
+
+
+def reload_switches():
+    _load().vg_reload_switches()
+
+
 def lib():
+    L = _load()
+    if AUTO_RELOAD:
+        L.vg_reload_switches()
+    return L
+
+
+def _load():
     """Load libvectorgpu.so (fails loudly if it has not been built: there is no fallback path)."""
     global _lib
     if _lib is not None:
@@ -112,6 +129,7 @@ def lib():
         "vg_shards_delete_rows": (i32, [vp, vp, i64]),
         "vg_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
         "vg_batch_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
+        "vg_reload_switches": (None, []),
         "vg_batch_last_path": (i32, [vp]),
         "vg_batch_q8_status": (i32, [vp]),
         "vg_corpus_set_scan_filter": (i32, [vp, i32]),

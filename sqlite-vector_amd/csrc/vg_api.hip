@@ -47,13 +47,13 @@ static int max_chunks_per_lane(int vtype, int acc, bool bf16_l2_u3) {
 struct ShapeEnv { bool f16_round3, pref_round1, bf16_l2_u3, int_short_round3, force_long; int lpr_log2, u; };
 static ShapeEnv shape_env() {
     ShapeEnv e;
-    e.f16_round3 = env_int("VG_SHAPE_F16_ROUND3", 0) != 0;
-    e.pref_round1 = env_int("VG_SHAPE_PREF_ROUND1", 0) != 0;
-    e.bf16_l2_u3 = env_int("VG_SHAPE_BF16_L2_U3", 0) != 0;
-    e.int_short_round3 = env_int("VG_SHAPE_INT_SHORT_ROUND3", 0) != 0;
-    e.force_long = env_int("VG_FORCE_LONG", 0) != 0;
-    e.lpr_log2 = env_int("VG_LPR_LOG2", -1);
-    e.u = env_int("VG_U", -1);
+    e.f16_round3 = vg_sw(SW_VG_SHAPE_F16_ROUND3, 0) != 0;
+    e.pref_round1 = vg_sw(SW_VG_SHAPE_PREF_ROUND1, 0) != 0;
+    e.bf16_l2_u3 = vg_sw(SW_VG_SHAPE_BF16_L2_U3, 0) != 0;
+    e.int_short_round3 = vg_sw(SW_VG_SHAPE_INT_SHORT_ROUND3, 0) != 0;
+    e.force_long = vg_sw(SW_VG_FORCE_LONG, 0) != 0;
+    e.lpr_log2 = vg_sw(SW_VG_LPR_LOG2, -1);
+    e.u = vg_sw(SW_VG_U, -1);
     return e;
 }
 static int shape_pref(const ShapeEnv &env, int vtype, int l2, int U, bool ragged) {
@@ -188,14 +188,14 @@ static scan_fn_t pick_kernel(int vtype, int acc, const Shape &s, bool nt) {
 
 // stream with non-temporal loads once the corpus cannot live in the 256 MiB Infinity Cache anyway
 static bool use_nt_loads(const vg_corpus *c, int64_t n_rows) {
-    int force = env_int("VG_NT", -1);
+    int force = vg_sw(SW_VG_NT, -1);
     if (force >= 0) return force != 0;
     return n_rows * c->stride > (256ll << 20);
 }
 
 // batch order of the top-k scan (ScanArgs.order); VG_SCAN_ORDER=0 / 1 forces one
 static int scan_order_for(const vg_corpus *c, int64_t n_rows) {
-    const int force = env_int("VG_SCAN_ORDER", -1);
+    const int force = vg_sw(SW_VG_SCAN_ORDER, -1);
     if (force >= 0) return force ? 1 : 0;
     (void)c; (void)n_rows;
     return 0;
@@ -227,7 +227,7 @@ extern "C" const char *vg_scan_kernel_name(vg_corpus *c, int metric) {
     Shape s;
     int acc = vg_metric_to_acc(metric);
     if (acc < 0 || !choose_shape(c->nch, c->vtype, acc, &s)) return "";
-    if (acc == A_COS && (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) && !s.long_rows && env_int("VG_HALF_COSN", 1)) acc = A_COSN;
+    if (acc == A_COS && (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) && !s.long_rows && vg_sw(SW_VG_HALF_COSN, 1)) acc = A_COSN;
     if (!s.long_rows && vg_scan_filter_name(c, metric, c->kernel_name, sizeof(c->kernel_name))) return c->kernel_name;
     snprintf(c->kernel_name, sizeof(c->kernel_name), "scan%s_%s_%s_u%d_lpr%d%s", s.long_rows ? "_long" : "",
              type_tag(c->vtype), acc_tag(acc), s.U, 1 << s.lpr_log2, use_nt_loads(c, c->n_rows) ? "_nt" : "");
@@ -294,7 +294,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     }
     // f16 / bf16 cosine: the row norms come from a cached vector (computed once per appended row) instead of being
     // re-accumulated in f64 on every scan - the f64 chain is what bounds these kernels, not HBM
-    if (acc == A_COS && (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) && !s.long_rows && env_int("VG_HALF_COSN", 1)) {
+    if (acc == A_COS && (c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16) && !s.long_rows && vg_sw(SW_VG_HALF_COSN, 1)) {
         int rcn = vg_ensure_row_norms(c);
         if (rcn != VG_OK) return rcn;
         acc = A_COSN;
@@ -324,7 +324,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
     const int rpb = VG_WAVE >> s.lpr_log2;
     const long long nbatch = (n_rows + rpb - 1) / rpb;
     // 16-wave workgroups: one per CU is what ~96 VGPRs admit (5 waves/SIMD); a second one only queues behind it
-    const int bpc = std::max(1, std::min(8, env_int("VG_BLOCKS_PER_CU", 1)));
+    const int bpc = std::max(1, std::min(8, vg_sw(SW_VG_BLOCKS_PER_CU, 1)));
     long long blocks = (nbatch + VG_WAVES_PER_BLOCK - 1) / VG_WAVES_PER_BLOCK;
     blocks = std::max<long long>(1, std::min<long long>(blocks, (long long)c->cu_count * bpc));
     blocks = std::min<long long>(blocks, VG_SEL_MAX_HEADS);          // the final rank-select handles <= 256 lists
@@ -405,7 +405,7 @@ static int launch_scan(vg_corpus *c, int metric, const uint8_t *dev_query, int k
 
 // latency path for small corpora (see vg_scan_topk): below this size the H2D/D2H staging copies dominate
 static bool host_direct(const vg_corpus *c) {
-    const int v = env_int("VG_HOST_DIRECT", -1);
+    const int v = vg_sw(SW_VG_HOST_DIRECT, -1);
     if (v >= 0) return v != 0;
     return c->n_rows * c->stride <= (64ll << 20);
 }
@@ -528,7 +528,7 @@ static int scan_topk_large_k(vg_corpus *c, int metric, const void *query, int k,
     // radix select (three histogram passes + gather + a sort of ~k keys); the full N-key sort only when the k-th
     // distance has so many ties that the gathered set would not fit
     int sel = 1;
-    if (env_int("VG_RADIX_SELECT", 1)) {
+    if (vg_sw(SW_VG_RADIX_SELECT, 1)) {
         if (!c->d_sel_state) HIP_TRY(hipMalloc(&c->d_sel_state, (4 + 2048) * sizeof(uint32_t)));
         uint32_t got = 0;
         sel = vg_select_topk_keys(c->d_dist, c->n_rows, (uint32_t)take, c->d_sel_keys, c->d_sel_sorted, (uint32_t)std::min<int64_t>(c->sel_cap, 0xFFFFFFFFll),
@@ -568,7 +568,7 @@ int vg_scan_topk_enqueue_plan(vg_corpus *c, int metric, const void *query, int k
     } else {
         // the query is staged into HBM (every workgroup reads it); the k winners are written by the final merge's one workgroup
         // straight into the pinned h_keys (VG_KEYS_DIRECT=0: into d_keys + a copy command, the form measured against it)
-        const bool keys_direct = env_int("VG_KEYS_DIRECT", 1) != 0;
+        const bool keys_direct = vg_sw(SW_VG_KEYS_DIRECT, 1) != 0;
         HIP_TRY(hipMemcpyAsync(c->d_query, c->h_query, (size_t)c->stride, hipMemcpyHostToDevice, c->stream));
         if (keys_direct) plan.final_out = c->h_keys;
         rc = launch_scan(c, metric, c->d_query, k, c->d_keys, nullptr, c->stream, plan);

@@ -461,8 +461,7 @@ extern "C" size_t vg_batch_lds_bytes(long long stride_bytes, int k) {
 // How many candidate lists a query owns in `dev_cand` for this shape (the caller sizes the buffer with it): npart for
 // a single pass, 2 * npart with the pre-pass (see vg_batch_launch).
 extern "C" int vg_batch_prepass_tiles(long long n_rows, int npart) {
-    const char *e = getenv("VG_BATCH_PREPASS");
-    const int denom = (e && *e) ? atoi(e) : 64;                  // pre-pass over 1/denom of the corpus; 0 = off
+    const int denom = vg_sw(SW_VG_BATCH_PREPASS, 64);                  // pre-pass over 1/denom of the corpus; 0 = off
     const long long ntiles = (n_rows + VGB_TILE - 1) / VGB_TILE;
     if (denom <= 0 || ntiles < 65536 || 2 * npart > VG_SEL_MAX_HEADS) return 0;   // < 2M rows: a single pass
     long long t = ntiles / denom;

@@ -54,12 +54,12 @@ extern "C" int vg_f32_to_bf16_launch(const uint8_t *dev_rows, long long row0, lo
 long long vg_bf16_shadow_stride(const vg_corpus *c) { return (((long long)c->dim * 2 + 15) / 16) * 16; }
 static long long bf16_shadow_stride(const vg_corpus *c) { return vg_bf16_shadow_stride(c); }
 static bool batch_f32_filter_short_rows(const vg_corpus *c) {
-    const int sw = env_int("VG_F32_FILTER", -1);
+    const int sw = vg_sw(SW_VG_F32_FILTER, -1);
     if (sw >= 0) return sw != 0;
     return vg_scan_filter_policy(c) && c->bfilter_cooldown == 0;
 }
 static bool batch_f32_filter_eligible(const vg_corpus *c, int metric, int k) {
-    if (env_int("VG_BATCH_MFMA", 1) == 0 || c->vtype != VG_TYPE_F32 || metric == VG_DIST_L1) return false;
+    if (vg_sw(SW_VG_BATCH_MFMA, 1) == 0 || c->vtype != VG_TYPE_F32 || metric == VG_DIST_L1) return false;
     if (c->dim <= 512 && !batch_f32_filter_short_rows(c)) return false;
     return vg_batch_h_lds_bytes(bf16_shadow_stride(c), k) != 0;
 }
@@ -88,7 +88,7 @@ int vg_ensure_bf16_shadow(vg_corpus *c) {
 extern "C" int vg_f32_to_bf16_tm_launch(const uint8_t *dev_rows, long long row0, long long n, long long stride, int dim,
                                         uint8_t *dev_out, long long ostride, hipStream_t stream);
 static int ensure_bf16_tile_major(vg_corpus *c) {
-    if (env_int("VG_BATCH_TILE_MAJOR", 1) == 0 || c->tm_disabled) return -1;
+    if (vg_sw(SW_VG_BATCH_TILE_MAJOR, 1) == 0 || c->tm_disabled) return -1;
     const long long bs = bf16_shadow_stride(c);
     if (c->tm_cap < c->n_rows) {
         const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
@@ -123,7 +123,7 @@ static int ensure_f32_batch_shadow(vg_corpus *c, const uint8_t **rows, int *tile
 // extended per appended row; without it every LDS-DMA instruction gathers 32-byte runs from 32 rows - vg_batch_i8.hip).  A corpus
 // it does not fit next to keeps the row-major gather.
 static int ensure_half_tile_major(vg_corpus *c) {
-    if (env_int("VG_BATCH_TILE_MAJOR", 1) == 0 || c->tm_disabled) return -1;
+    if (vg_sw(SW_VG_BATCH_TILE_MAJOR, 1) == 0 || c->tm_disabled) return -1;
     if (c->tm_cap < c->n_rows) {
         const int64_t cap = std::max<int64_t>(c->cap_rows, c->n_rows);
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -143,14 +143,14 @@ static int ensure_half_tile_major(vg_corpus *c) {
 }
 
 static bool batch_h_eligible(const vg_corpus *c, int metric, int k) {
-    if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
+    if (vg_sw(SW_VG_BATCH_MFMA, 1) == 0) return false;
     if (c->vtype != VG_TYPE_F16 && c->vtype != VG_TYPE_BF16) return false;
     if (metric == VG_DIST_L1) return false;
     return vg_batch_h_lds_bytes(c->stride, k) != 0;
 }
 
 static bool batch_i8_eligible(const vg_corpus *c, int metric, int k) {
-    if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
+    if (vg_sw(SW_VG_BATCH_MFMA, 1) == 0) return false;
     if (c->vtype != VG_TYPE_U8 && c->vtype != VG_TYPE_I8) return false;
     if (metric == VG_DIST_L1) return false;
     return vg_batch_i8_lds_bytes(c->stride, k) != 0;
@@ -203,7 +203,7 @@ extern "C" int vg_batch_hl_query_norms(const uint8_t *dev_queries, long long str
                                        float *dev_out, hipStream_t stream);
 static long long batch_long_stride(const vg_corpus *c) { return c->vtype == VG_TYPE_F32 ? bf16_shadow_stride(c) : c->stride; }
 static bool batch_long_eligible(const vg_corpus *c, int metric, int k) {
-    if (env_int("VG_BATCH_MFMA", 1) == 0 || env_int("VG_BATCH_LONG", 1) == 0 || metric == VG_DIST_L1 || c->tm_disabled) return false;
+    if (vg_sw(SW_VG_BATCH_MFMA, 1) == 0 || vg_sw(SW_VG_BATCH_LONG, 1) == 0 || metric == VG_DIST_L1 || c->tm_disabled) return false;
     if (c->vtype != VG_TYPE_F32 && c->vtype != VG_TYPE_F16 && c->vtype != VG_TYPE_BF16) return false;
     return vg_batch_hl_serves(batch_long_stride(c), k) != 0;
 }
@@ -216,7 +216,7 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
     const int G = nq_pad / QPB;
     // partitions: one workgroup per CU and query group (VG_BATCH_LONG_BPC rounds of them: measured, 1024 x 2M x 1536 - 1: 11.0 ms, 2: 11.9,
     // 4: 14.7, 8: 20.9 - a workgroup's set-up, the A operand of 64 queries, is paid per partition)
-    int npart = std::max(1, c->cu_count * std::max(1, env_int("VG_BATCH_LONG_BPC", 1)) / G);
+    int npart = std::max(1, c->cu_count * std::max(1, vg_sw(SW_VG_BATCH_LONG_BPC, 1)) / G);
     if (npart >= 8) npart = (npart / 8) * 8;
     npart = std::min(npart, 256);
     const long long ntiles = (c->n_rows + 31) / 32;
@@ -328,8 +328,8 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
                                   uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, hipStream_t stream);
 static long long q8_shadow_stride_of(const vg_corpus *c) { return (((long long)c->dim + 15) / 16) * 16; }
 static bool batch_q8_eligible(const vg_corpus *c, int metric, int k, int nq) {
-    if (env_int("VG_BATCH_MFMA", 1) == 0 || c->vtype != VG_TYPE_F32 || metric == VG_DIST_L1 || c->q8tm_disabled || c->filter_disabled) return false;
-    const int sw = env_int("VG_BATCH_Q8", -1);
+    if (vg_sw(SW_VG_BATCH_MFMA, 1) == 0 || c->vtype != VG_TYPE_F32 || metric == VG_DIST_L1 || c->q8tm_disabled || c->filter_disabled) return false;
+    const int sw = vg_sw(SW_VG_BATCH_Q8, -1);
     if (sw == 0 || c->n_rows < (sw == 1 ? (1ll << 16) : (1ll << 20))) return false;     // (forced: from 2048 tiles on - the tests' sizes)
     if (sw < 0 && (nq <= 256 || !vg_scan_filter_policy(c))) return false;             // (its own overflow guard: bq8_cooldown; the bf16 filter's does not apply)
     return vg_batch_q8_serves(q8_shadow_stride_of(c), c->stride, k) != 0;
@@ -465,7 +465,7 @@ static int scan_topk_batch_q8(vg_corpus *c, int metric, const void *queries, int
 }
 
 static bool batch_mfma_eligible(const vg_corpus *c, int metric, int k) {
-    if (env_int("VG_BATCH_MFMA", 1) == 0) return false;
+    if (vg_sw(SW_VG_BATCH_MFMA, 1) == 0) return false;
     if (c->vtype != VG_TYPE_F32) return false;
     if (metric == VG_DIST_L1) return false;                       // no matrix form
     return vg_batch_lds_bytes(c->stride, k) != 0;
@@ -478,7 +478,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     bool f32_filter = (c->vtype == VG_TYPE_F32) && batch_f32_filter_eligible(c, metric, k) &&
                       (vg_batch_lds_bytes(c->stride, k) == 0 || batch_f32_filter_short_rows(c));
     const bool f32_mfma_serves = (c->vtype == VG_TYPE_F32) && vg_batch_lds_bytes(c->stride, k) != 0;
-    if (c->vtype == VG_TYPE_F32 && c->bfilter_cooldown > 0 && env_int("VG_F32_FILTER", -1) < 0) --c->bfilter_cooldown;
+    if (c->vtype == VG_TYPE_F32 && c->bfilter_cooldown > 0 && vg_sw(SW_VG_F32_FILTER, -1) < 0) --c->bfilter_cooldown;
     const uint8_t *f32_shadow = nullptr;                   // f32 through the bf16 filter: the shadow copy its matrix core reads
     int f32_shadow_tiled = 0;
     if (f32_filter && f32_mfma_serves) {
@@ -505,7 +505,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
     const int G = nq_pad / QPB;
     // partitions: enough workgroups to cover the chip (G * npart ~ CUs x workgroups per CU), a multiple of 8 (one per XCD), <= 256
     // (VG_BATCH_BPC overrides the workgroups per CU the partition count aims at)
-    int npart = std::max(1, c->cu_count * std::max(1, env_int("VG_BATCH_BPC", half ? h_bpc : 1)) / G);
+    int npart = std::max(1, c->cu_count * std::max(1, vg_sw(SW_VG_BATCH_BPC, half ? h_bpc : 1)) / G);
     if (npart >= 8) npart = (npart / 8) * 8;
     npart = std::min(npart, 256);
     const long long ntiles = (c->n_rows + 31) / 32;
@@ -623,7 +623,7 @@ static int scan_topk_batch_mfma(vg_corpus *c, int metric, const void *queries, i
         // take the f32 matrix-core kernel, then the filter is tried again.  (Rows of 513+ floats have no such kernel: no guard.)
         const unsigned long long now = c->h_filter_evals[1];
         const unsigned long long pairs = (unsigned long long)nq * (unsigned long long)c->n_rows;
-        if ((now - c->bfilter_evals_seen) > pairs / 256 && env_int("VG_F32_FILTER", -1) < 0) c->bfilter_cooldown = 64;
+        if ((now - c->bfilter_evals_seen) > pairs / 256 && vg_sw(SW_VG_F32_FILTER, -1) < 0) c->bfilter_cooldown = 64;
         c->bfilter_evals_seen = now;
     }
     for (int i = 0; i < nq; ++i) {
@@ -686,10 +686,10 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     HIP_TRY(hipSetDevice(c->device));
     // A handful of queries over a corpus the filter scans serve: single scans (0.7 ms each at 10M x 384, whatever the type) beat one
     // 128- / 256-query-wide matrix pass (~2.9 ms however few of its query slots are used) up to three queries; they tie at four.
-    const bool few = nq <= env_int("VG_BATCH_MIN_QUERIES", 4) - 1 && vg_scan_filter_would_serve(c, metric, k);
+    const bool few = nq <= vg_sw(SW_VG_BATCH_MIN_QUERIES, 4) - 1 && vg_scan_filter_would_serve(c, metric, k);
     if (!few && batch_long_eligible(c, metric, k) && c->blong_cooldown > 0) --c->blong_cooldown;
     else if (!few && batch_long_eligible(c, metric, k)) {
-        const int slice = std::max(256, env_int("VG_BATCH_SLICE", 4096));
+        const int slice = std::max(256, vg_sw(SW_VG_BATCH_SLICE, 4096));
         int rc = VG_OK;
         const size_t qbytes = (size_t)c->dim * c->es;
         for (int q0 = 0; q0 < nq && rc == VG_OK; q0 += slice) {
@@ -701,7 +701,7 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     }
     if (!few && batch_q8_eligible(c, metric, k, nq) && c->bq8_cooldown > 0) --c->bq8_cooldown;
     else if (!few && batch_q8_eligible(c, metric, k, nq)) {
-        const int slice = std::min(vg_batch_q8_max_queries(), std::max(512, env_int("VG_BATCH_SLICE", 4096)));
+        const int slice = std::min(vg_batch_q8_max_queries(), std::max(512, vg_sw(SW_VG_BATCH_SLICE, 4096)));
         int rc = VG_OK;
         const size_t qbytes = (size_t)c->dim * c->es;
         for (int q0 = 0; q0 < nq && rc == VG_OK; q0 += slice) {
@@ -714,7 +714,7 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     if (!few && (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k) || batch_h_eligible(c, metric, k) ||
                  batch_f32_filter_eligible(c, metric, k))) {
         // very large batches go through in slices: the per-(query, partition) candidate lists are nq x ~128 x 512 B
-        const int slice = std::max(256, env_int("VG_BATCH_SLICE", 4096));
+        const int slice = std::max(256, vg_sw(SW_VG_BATCH_SLICE, 4096));
         int rc = VG_OK;
         const size_t qbytes = (size_t)c->dim * c->es;
         for (int q0 = 0; q0 < nq && rc == VG_OK; q0 += slice) {
@@ -731,7 +731,7 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     }
     // shapes the matrix-core kernels do not serve (f16 / bf16, L1, k > 32, rows > 512 floats / 1 KiB): the multi-query
     // scan (vg_scan_multi_kernel: 4 - or 2 for f16 / bf16 - queries share every row load of the HBM-bound pass) ...
-    if (!few && k <= 64 && nq >= 2 && env_int("VG_MULTI_SCAN", 1)) {
+    if (!few && k <= 64 && nq >= 2 && vg_sw(SW_VG_MULTI_SCAN, 1)) {
         int rc = scan_topk_batch_multi(c, metric, queries, nq, k, out_keys, out_counts);
         if (rc != -1) { c->last_batch_path = 5; return rc; }
         for (int i = 0; i < nq; ++i) out_counts[i] = 0;

@@ -7,6 +7,7 @@
 #include <type_traits>
 
 #include "vg_lists.h"
+#include "vg_switches.h"
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)  (a plain "#pragma unroll" gives up on the
 // kernels' k loops and demotes the register-resident operands to scratch)
@@ -52,8 +53,7 @@ __device__ __forceinline__ float vgb_kth_distance(uint64_t kth) {
 #include <cstdlib>
 #define VGB_PREPASS_DENOM_DEFAULT 512
 static inline int vgb_stage_bounds(long long ntiles, long long pre_tiles, long long *bounds, int max_stages, int default_growth_pct = 400) {
-    const char *e = getenv("VG_BATCH_STAGES");
-    const int growth_pct = (e && *e) ? atoi(e) : default_growth_pct;
+    const int growth_pct = vg_sw(SW_VG_BATCH_STAGES, default_growth_pct);
     int n = 0;
     bounds[0] = 0;
     if (pre_tiles > 0 && growth_pct > 100) {

@@ -844,9 +844,7 @@ static size_t vgh_lds_bytes(int NTB, int k, int waves) {
 extern "C" int vg_batch_h_split(long long stride_bytes, int k) {
     const int NTB = vgh_ntb(stride_bytes);
     if (!NTB || k < 1 || k > VGH_MAX_K) return 0;
-    const char *e = getenv("VG_BATCH_H_SPLIT"), *w = getenv("VG_BATCH_H_WAVES");
-    (void)w;
-    return (e && *e) ? atoi(e) != 0 : 0;                         // opt-in: the two forms measure equal (7.98 against 7.95 ms, profiles/r6k_*)
+    return vg_sw(SW_VG_BATCH_H_SPLIT, 0) != 0;                         // opt-in: the two forms measure equal (7.98 against 7.95 ms, profiles/r6k_*)
 }
 extern "C" int vg_batch_h_plan(long long stride_bytes, int k, int nq, int *waves, int *blocks_per_cu) {
     const int NTB = vgh_ntb(stride_bytes);
@@ -857,8 +855,7 @@ extern "C" int vg_batch_h_plan(long long stride_bytes, int k, int nq, int *waves
         if (blocks_per_cu) *blocks_per_cu = 1;
         return 0;
     }
-    const char *e = getenv("VG_BATCH_H_WAVES");
-    const int forced = (e && *e) ? atoi(e) : 0;
+    const int forced = vg_sw(SW_VG_BATCH_H_WAVES, 0);
     if (VGH_HAS_W4(NTB) && forced != 8 && 2 * vgh_lds_bytes(NTB, k, 4) + 4096 <= (size_t)160 * 1024 && (nq > 4 * VGH_QPW || forced == 4)) { w = 4; bpc = 2; }
     if (vgh_lds_bytes(NTB, k, w) > (size_t)160 * 1024) return -1;                 // (2 KiB rows with k >= 30: not served, as vg_batch_h_lds_bytes says)
     if (waves) *waves = w;
@@ -1016,8 +1013,7 @@ extern "C" int vg_batch_h_launch(const uint8_t *dev_rows, int rows_tiled, long l
     // at 1024 x 10M x 384; 1/64 12.2, 1/8 12.4, 1/4 13.9.)
     long long pre = 0;
     {
-        const char *e = getenv("VG_BATCH_PREPASS");
-        const int denom = (e && *e) ? atoi(e) : VGB_PREPASS_DENOM_DEFAULT;     // (vg_batch_common.h: re-measured in round 3)
+        const int denom = vg_sw(SW_VG_BATCH_PREPASS, VGB_PREPASS_DENOM_DEFAULT);     // (vg_batch_common.h: re-measured in round 3)
         if (denom > 0 && ntiles >= 65536) pre = ((ntiles / denom + npart - 1) / npart) * npart;      // whole partitions; < 2M rows: one pass
     }
     int rc;

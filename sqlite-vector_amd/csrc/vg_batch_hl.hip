@@ -550,8 +550,7 @@ extern "C" int vg_batch_hl_launch(const uint8_t *dev_rows, long long n_rows, lon
     // (vg_batch_common.h) - the split form has no feedback inside a stage: a small corpus gets a small first stage instead
     long long pre = 0;
     {
-        const char *ev = getenv("VG_BATCH_PREPASS");
-        const int denom = (ev && *ev) ? atoi(ev) : VGB_PREPASS_DENOM_DEFAULT;
+        const int denom = vg_sw(SW_VG_BATCH_PREPASS, VGB_PREPASS_DENOM_DEFAULT);
         if (denom > 0) pre = ((std::max<long long>(ntiles / denom, 2 * (long long)k) + npart - 1) / npart) * npart;
         if (pre * 2 > ntiles) pre = ntiles;              // a small corpus: bounds over all of it, then ONE filter + exact stage
     }

@@ -740,8 +740,7 @@ extern "C" int vg_batch_i8_launch(const uint8_t *dev_rows_signed, long long n_ro
     // start threshold; the real pass scans every row from there.  Both write lists 0 .. npart-1 of the candidate buffer.
     long long pre = 0;
     {
-        const char *e = getenv("VG_BATCH_PREPASS");
-        const int denom = (e && *e) ? atoi(e) : VGB_PREPASS_DENOM_DEFAULT;     // (vg_batch_common.h: re-measured in round 3)
+        const int denom = vg_sw(SW_VG_BATCH_PREPASS, VGB_PREPASS_DENOM_DEFAULT);     // (vg_batch_common.h: re-measured in round 3)
         if (denom > 0 && ntiles >= 65536) pre = ((ntiles / denom + npart - 1) / npart) * npart;      // < 2M rows: one pass
     }
     int rc;

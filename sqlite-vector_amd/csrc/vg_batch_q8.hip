@@ -695,8 +695,8 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     long long bounds[24];
     int nstages = 0;
     {
-        const char *es = getenv("VG_BATCH_STAGES");
-        const int late_growth = (es && *es && atoi(es) > 100) ? atoi(es) : 200;
+        const int sw_growth = vg_sw(SW_VG_BATCH_STAGES, 0);
+        const int late_growth = sw_growth > 100 ? sw_growth : 200;
         bounds[0] = 0;
         long long b = VGQ_STAGE0_TILES;
         while (b < ntiles && nstages + 2 < 24 && ntiles - b > b / 4) {      // (no sliver at the end)

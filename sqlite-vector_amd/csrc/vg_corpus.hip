@@ -53,9 +53,79 @@ extern "C" const char *vg_backend_name(void) {
     return name;
 }
 
+
+// ---- the environment switches (vg_switches.h): the one place that calls getenv
+struct VgSwitchName { const char *name; int lab; };
+static const VgSwitchName vg_switch_names[VGSW_COUNT] = {
+    {"VECTORGPU_SHARD_GATHER", 0},
+    {"VG_BATCH_BPC", 1},
+    {"VG_BATCH_H_SPLIT", 0},
+    {"VG_BATCH_H_WAVES", 0},
+    {"VG_BATCH_LONG", 0},
+    {"VG_BATCH_LONG_BPC", 1},
+    {"VG_BATCH_MFMA", 0},
+    {"VG_BATCH_MIN_QUERIES", 1},
+    {"VG_BATCH_PREPASS", 1},
+    {"VG_BATCH_Q8", 0},
+    {"VG_BATCH_SLICE", 0},
+    {"VG_BATCH_STAGES", 0},
+    {"VG_BATCH_TILE_MAJOR", 0},
+    {"VG_BLOCKS_PER_CU", 1},
+    {"VG_F32_FILTER", 0},
+    {"VG_FILTER_LPR_LOG2", 1},
+    {"VG_FILTER_U", 1},
+    {"VG_FORCE_LONG", 0},
+    {"VG_HALF_COSN", 1},
+    {"VG_HOST_DIRECT", 1},
+    {"VG_KEYS_DIRECT", 1},
+    {"VG_LPR_LOG2", 0},
+    {"VG_MULTI_SCAN", 0},
+    {"VG_NT", 1},
+    {"VG_Q8_TWO_READS", 1},
+    {"VG_RADIX_SELECT", 0},
+    {"VG_REF_ALWAYS_EMIT", 1},
+    {"VG_REF_STORE_MODE", 0},
+    {"VG_SCAN_FILTER", 0},
+    {"VG_SCAN_FILTER_MIN_MB", 0},
+    {"VG_SCAN_FILTER_MIRROR_COPY", 1},
+    {"VG_SCAN_FILTER_N4", 0},
+    {"VG_SCAN_FILTER_NO_GUARD", 0},
+    {"VG_SCAN_FILTER_PREMERGE", 1},
+    {"VG_SCAN_FILTER_PREPASS", 1},
+    {"VG_SCAN_FILTER_PREPASS_DIV", 1},
+    {"VG_SCAN_FILTER_SHADOW", 0},
+    {"VG_SCAN_ORDER", 1},
+    {"VG_SHAPE_BF16_L2_U3", 0},
+    {"VG_SHAPE_F16_ROUND3", 0},
+    {"VG_SHAPE_INT_SHORT_ROUND3", 0},
+    {"VG_SHAPE_PREF_ROUND1", 0},
+    {"VG_U", 0},
+};
+int vg_switch_values[VGSW_COUNT];
+void vg_switches_read(void) {
+    for (int i = 0; i < VGSW_COUNT; ++i) {
+        int v = VGSW_UNSET;
+#ifndef VG_LAB
+        if (!vg_switch_names[i].lab)
+#endif
+        {
+            const char *e = getenv(vg_switch_names[i].name);
+            if (e && *e) {
+                if (i == SW_VG_SCAN_FILTER_SHADOW) v = (unsigned char)e[0];                     // 'b' / 'r': the bf16 copy / the rows themselves
+                else if (i == SW_VECTORGPU_SHARD_GATHER) v = (e[0] == 'r' || e[0] == 'R') ? 1 : 0;                 // "rccl"
+                else v = atoi(e);
+            }
+        }
+        vg_switch_values[i] = v;
+    }
+}
+__attribute__((constructor)) static void vg_switches_at_load(void) { vg_switches_read(); }     // (before the first corpus: the table is never all zeros)
+extern "C" void vg_reload_switches(void) { vg_switches_read(); }
+
 extern "C" int vg_corpus_create(int device, int vtype, int dim, int64_t capacity_rows_hint, vg_corpus **out) {
     if (!out) return vg_fail(VG_ERR_INVALID, "vg_corpus_create: out is NULL");
     *out = nullptr;
+    vg_switches_read();                                       // a corpus takes the environment's switches as they are NOW (vg_switches.h)
     int es = vg_elem_size(vtype);
     if (es == 0) return vg_fail(VG_ERR_INVALID, "vg_corpus_create: unknown vector type %d", vtype);
     if (dim <= 0) return vg_fail(VG_ERR_INVALID, "vg_corpus_create: dimension must be positive (got %d)", dim);

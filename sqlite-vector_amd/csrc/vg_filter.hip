@@ -17,11 +17,11 @@ typedef void (*filter_fn_t)(FilterScanArgs);
 static bool scan_filter_enabled(const vg_corpus *c) {
     if (c->filter_disabled) return false;
     if (c->scan_filter_mode >= 0) return c->scan_filter_mode != 0;
-    return env_int("VG_SCAN_FILTER", 1) != 0;
+    return vg_sw(SW_VG_SCAN_FILTER, 1) != 0;
 }
 // (vg_batch_api.hip: f32 batches follow the same switch and the same size threshold - they read the shadow copy these scans make)
 bool vg_scan_filter_policy(const vg_corpus *c) {
-    return scan_filter_enabled(c) && c->n_rows * c->stride >= (long long)env_int("VG_SCAN_FILTER_MIN_MB", 3072) * (1ll << 20);
+    return scan_filter_enabled(c) && c->n_rows * c->stride >= (long long)vg_sw(SW_VG_SCAN_FILTER_MIN_MB, 3072) * (1ll << 20);
 }
 // Would a single top-k scan of this corpus go through a filter scan right now?  (vg_batch_api.hip: a handful of queries are then
 // cheaper as single scans than as one 128- / 256-query-wide matrix pass.)
@@ -45,7 +45,7 @@ int vg_ensure_filter_counters(vg_corpus *c) {
 static bool filter_uses_q8(const vg_corpus *c, int metric);
 // uint8 / int8 corpora: the nibble filter (vg_scan_filter_n4.h) - half the bytes.  Its bound assumes sums below 2^31 (the plain
 // kernel's arithmetic is modular like the reference's): rows of at most 16384 elements.  Sizes (D = 768, measured): see below.
-static bool n4_explicit(const vg_corpus *c) { return c->scan_filter_mode == 1 || env_int("VG_SCAN_FILTER_N4", -1) == 1; }
+static bool n4_explicit(const vg_corpus *c) { return c->scan_filter_mode == 1 || vg_sw(SW_VG_SCAN_FILTER_N4, -1) == 1; }
 static bool scan_filter_serves_n4(const vg_corpus *c, int metric) {
     if (c->vtype != VG_TYPE_U8 && c->vtype != VG_TYPE_I8) return false;
     if (metric != VG_DIST_L2 && metric != VG_DIST_SQUARED_L2 && metric != VG_DIST_DOT && metric != VG_DIST_COSINE) return false;
@@ -59,10 +59,10 @@ static bool scan_filter_serves_n4(const vg_corpus *c, int metric) {
     // with the plain kernel (probed again once it has doubled).  vg_corpus_set_scan_filter(c, 1) / the extension's
     // scan_filter=1 / VG_SCAN_FILTER_N4=1 switch it on without a probe (the guard still watches), VG_SCAN_FILTER_N4=0 off.
     if (!n4_explicit(c)) {
-        if (env_int("VG_SCAN_FILTER_N4", -1) == 0) return false;
+        if (vg_sw(SW_VG_SCAN_FILTER_N4, -1) == 0) return false;
         if (c->n4_probe == 2 && c->n_rows < 2 * c->n4_probe_rows) return false;
     }
-    if (env_int("VG_SCAN_FILTER_MIN_MB", -1) >= 0) return c->n_rows * c->stride >= (long long)env_int("VG_SCAN_FILTER_MIN_MB", 0) * (1ll << 20);
+    if (vg_sw(SW_VG_SCAN_FILTER_MIN_MB, -1) >= 0) return c->n_rows * c->stride >= (long long)vg_sw(SW_VG_SCAN_FILTER_MIN_MB, 0) * (1ll << 20);
     return c->n_rows >= (1 << 20) && c->n_rows * c->stride >= (768ll << 20);
 }
 static bool scan_filter_serves(const vg_corpus *c, int metric) {
@@ -71,14 +71,14 @@ static bool scan_filter_serves(const vg_corpus *c, int metric) {
     if (c->vtype != VG_TYPE_F32 && !half) return false;
     if (metric == VG_DIST_L1 && !half) return false;         // (the f32 L1 scan already streams at the HBM ceiling: nothing to skip)
     if (metric != VG_DIST_L2 && metric != VG_DIST_SQUARED_L2 && metric != VG_DIST_DOT && metric != VG_DIST_COSINE && metric != VG_DIST_L1) return false;
-    if (half && metric == VG_DIST_COSINE && !env_int("VG_HALF_COSN", 1)) return false;
+    if (half && metric == VG_DIST_COSINE && !vg_sw(SW_VG_HALF_COSN, 1)) return false;
     if (!scan_filter_enabled(c)) return false;
     // int8 shadow copy (measured, profiles/r3a_int8_filter_size_threshold.txt, D = 384): from 2^20 rows - where the pre-pass
     // starts - the filter wins at every size tried (1.2M rows: 0.09 + 0.035 ms against 0.27 f32 / 0.17 f16); below, without a
     // pre-pass, it only ties.  In bytes: a quarter / half of the stream has to buy back ~45 us of pre-pass and second launch.
-    if (filter_uses_q8(c, metric) && env_int("VG_SCAN_FILTER_MIN_MB", -1) < 0)
+    if (filter_uses_q8(c, metric) && vg_sw(SW_VG_SCAN_FILTER_MIN_MB, -1) < 0)
         return c->n_rows >= (1 << 20) && c->n_rows * c->stride >= (512ll << 20);
-    return c->n_rows * c->stride >= (long long)env_int("VG_SCAN_FILTER_MIN_MB", half ? 1024 : 3072) * (1ll << 20);
+    return c->n_rows * c->stride >= (long long)vg_sw(SW_VG_SCAN_FILTER_MIN_MB, half ? 1024 : 3072) * (1ll << 20);
 }
 
 template <int XT, int MODE, bool NT, bool Q8>
@@ -327,8 +327,8 @@ static long long q8_shadow_stride(const vg_corpus *c) { return (((long long)c->d
 static bool filter_uses_q8(const vg_corpus *c, int metric) {
     if (c->vtype != VG_TYPE_F32 && c->vtype != VG_TYPE_F16 && c->vtype != VG_TYPE_BF16) return false;
     if (metric == VG_DIST_L1 || c->q8_disabled) return false;
-    const char *e = getenv("VG_SCAN_FILTER_SHADOW");
-    return !(e && (e[0] == 'b' || e[0] == 'B' || e[0] == 'r' || e[0] == 'R'));
+    const int e = vg_sw(SW_VG_SCAN_FILTER_SHADOW, 0);                 // (its first letter)
+    return !(e == 'b' || e == 'B' || e == 'r' || e == 'R');
 }
 int vg_ensure_q8_shadow(vg_corpus *c) {
     const long long qs = q8_shadow_stride(c);
@@ -351,7 +351,7 @@ int vg_ensure_q8_shadow(vg_corpus *c) {
         const long long n = c->n_rows - c->q8_rows;
         const long long blocks = std::min<long long>((n * 16 + 255) / 256, 256 * 32);
         // rows of up to 128 chunks: the single-read kernel (the row lives in registers between its two sweeps)
-        to_q8_fn_t reg = env_int("VG_Q8_TWO_READS", 0) ? nullptr
+        to_q8_fn_t reg = vg_sw(SW_VG_Q8_TWO_READS, 0) ? nullptr
                        : (c->vtype == VG_TYPE_F32 ? pick_to_q8_reg<T_F32>(c->nch) : (c->vtype == VG_TYPE_F16 ? pick_to_q8_reg<T_F16>(c->nch) : pick_to_q8_reg<T_BF16>(c->nch)));
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->profiling) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, c->stream); }
@@ -422,7 +422,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     vg_choose_shape(nch_b, VG_TYPE_U8, A_DOT, &s, filter_u_cap(c));
     if (s.long_rows) return -1;
     {   // experiment override of the filter's own launch shape
-        const int fl = env_int("VG_FILTER_LPR_LOG2", -1), fu = env_int("VG_FILTER_U", -1);
+        const int fl = vg_sw(SW_VG_FILTER_LPR_LOG2, -1), fu = vg_sw(SW_VG_FILTER_U, -1);
         if (fl >= 0 && fl <= 6 && fu > 0 && (nch_b + (1 << fl) - 1) / (1 << fl) <= fu &&
             (n4 ? pick_n4<true>(c->vtype, filter_mode_of(metric), fu) : pick_filter<true>(c->vtype, filter_mode_of(metric), fu, q8))) { s.lpr_log2 = fl; s.U = fu; }
     }
@@ -449,7 +449,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
         }
         const long long launches = std::min<long long>(c->filter_launches, landed) - c->filter_launches_seen;
         if (launches >= 2) {
-            if ((now - c->filter_evals_seen) / (unsigned long long)launches > (unsigned long long)(c->n_rows / 8) && !env_int("VG_SCAN_FILTER_NO_GUARD", 0))
+            if ((now - c->filter_evals_seen) / (unsigned long long)launches > (unsigned long long)(c->n_rows / 8) && !vg_sw(SW_VG_SCAN_FILTER_NO_GUARD, 0))
                 c->filter_cooldown = 256;
             // the pre-pass' share of the rows follows the same average: many candidates (a loose bound on this data) are worth a
             // tighter start threshold - a longer pre-pass; few are not (measured, profiles/r3m: nibble filter on the C3 bytes,
@@ -472,7 +472,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
         HIP_TRY(hipEventRecord(c->norm_ev, c->stream));
         HIP_TRY(hipStreamWaitEvent(stream, c->norm_ev, 0));
     }
-    const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (scan_rows * bs > (256ll << 20));
+    const bool nt = (vg_sw(SW_VG_NT, -1) >= 0) ? vg_sw(SW_VG_NT, -1) != 0 : (scan_rows * bs > (256ll << 20));
     const int mode = filter_mode_of(metric);
     filter_fn_t fn = n4 ? (nt ? pick_n4<true>(c->vtype, mode, s.U) : pick_n4<false>(c->vtype, mode, s.U))
                         : (nt ? pick_filter<true>(c->vtype, mode, s.U, q8) : pick_filter<false>(c->vtype, mode, s.U, q8));
@@ -506,7 +506,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     // tie_order = reference (ref_emit): the pre-pass doubles as the replay's prefix pass (it also stores its rows' distances) and the
     // filter kernel emits the later rows that can enter the reference's slots - a probing launch never does (its answer is discarded)
     const bool emitting = ref_emit && !probing && scan_rows >= VG_REF_EMIT_MIN_ROWS;
-    const bool prepass = (env_int("VG_SCAN_FILTER_PREPASS", 1) != 0 && scan_rows >= (1 << 20)) || emitting;
+    const bool prepass = (vg_sw(SW_VG_SCAN_FILTER_PREPASS, 1) != 0 && scan_rows >= (1 << 20)) || emitting;
     hipEvent_t *evs = probing ? nullptr : vg_prof_slot(c, (uint8_t)(VG_EVF_MERGE | (prepass ? VG_EVF_PREPASS : 0)));
     if (evs) hipEventRecord(evs[0], stream);
     a.init_keys = nullptr;
@@ -517,7 +517,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     if (prepass) {
         ScanPlan pre;
         // (1/128 of the rows: 38 us instead of 60 at 10M x 384 for ~2x the exact evaluations of the 0.6 ms pass - measured, profiles/r2y)
-        pre.n_rows = std::max<int64_t>(65536, scan_rows / std::max(1, env_int("VG_SCAN_FILTER_PREPASS_DIV", c->filter_prepass_div)));
+        pre.n_rows = std::max<int64_t>(65536, scan_rows / std::max(1, vg_sw(SW_VG_SCAN_FILTER_PREPASS_DIV, c->filter_prepass_div)));
         if (scan_rows < (1 << 20)) pre.n_rows = vg_ref_prefix_for(scan_rows);      // (a pre-pass only because of the replay)
         pre.allow_filter = false;
         pre.record = false;
@@ -535,7 +535,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
         // vg_kth_head): one launch less on the query's critical path (pre-pass 37 -> 26 us, the filter kernel + 4 us: 0.684 -> 0.676 ms per query).  VG_SCAN_FILTER_PREMERGE=1: round 2's
         // form (merge launch, init_keys) - also what serves a staged query too long to leave the head scratch free.
         int n_pre_lists = 0;
-        const bool unmerged = !env_int("VG_SCAN_FILTER_PREMERGE", 0) &&
+        const bool unmerged = !vg_sw(SW_VG_SCAN_FILTER_PREMERGE, 0) &&
                               smem >= (size_t)VG_PUBLISH_LDS_BYTES &&
                               (size_t)c->nch * 16 + ((q8 && !f32) ? (size_t)nch_b * 64 : 0) + 64 <= (size_t)VG_PUBLISH_LDS_BYTES - VG_KTH_HEAD_SCRATCH_BYTES - 16;
         if (unmerged) {
@@ -557,7 +557,7 @@ int vg_launch_scan_filter(vg_corpus *c, int metric, const uint8_t *dev_query, in
     // merge's workgroup copies them into the pinned mirror on its way (VG_SCAN_FILTER_MIRROR_COPY=1: a copy command behind the
     // merge, the earlier form; sending that down a side stream behind the filter kernel was measured too: the event record + wait
     // cost more than the copy holds up the key read-back - 0.684 against 0.676 ms per query, profiles/r4v_filter_floor_ab.txt).
-    const bool mirror_in_merge = !probing && env_int("VG_SCAN_FILTER_MIRROR_COPY", 0) == 0;
+    const bool mirror_in_merge = !probing && vg_sw(SW_VG_SCAN_FILTER_MIRROR_COPY, 0) == 0;
     const int rcm = vg_launch_merge_one((const uint64_t *)c->d_cand, (int)blocks, k, (final_out && !probing) ? final_out : dev_out_keys, stream,
                                         mirror_in_merge ? c->d_filter_evals : nullptr, mirror_in_merge ? c->h_filter_evals : nullptr);
     if (evs) hipEventRecord(evs[3], stream);
@@ -600,7 +600,7 @@ bool vg_scan_filter_name(vg_corpus *c, int metric, char *out, size_t out_len) {
     vg_choose_shape((int)(bs / 16), VG_TYPE_U8, A_DOT, &fs, filter_u_cap(c));
     vg_plain_scan_shape(c, metric, &xs);
     if (fs.long_rows || xs.long_rows) return false;
-    const bool nt = (env_int("VG_NT", -1) >= 0) ? env_int("VG_NT", -1) != 0 : (c->n_rows * bs > (256ll << 20));
+    const bool nt = (vg_sw(SW_VG_NT, -1) >= 0) ? vg_sw(SW_VG_NT, -1) != 0 : (c->n_rows * bs > (256ll << 20));
     static const char *mtag[4] = {"l2", "dot", "cos", "l1"};
     snprintf(out, out_len, "scan_filter_%s_%s%s_u%d_lpr%d%s", filter_type_tag(c->vtype), mtag[filter_mode_of(metric)],
              (c->vtype == VG_TYPE_U8 || c->vtype == VG_TYPE_I8) ? "_n4" : (filter_uses_q8(c, metric) ? "_q8" : (c->vtype == VG_TYPE_F32 ? "_bf16" : "")),

@@ -166,11 +166,7 @@ struct vg_corpus {
     long long pass_rows[3] = {0, 0, 0};
 };
 
-static inline int env_int(const char *name, int dflt) {
-    const char *s = getenv(name);
-    if (!s || !*s) return dflt;
-    return atoi(s);
-}
+#include "vg_switches.h"            // the environment switches: vg_sw(SW_..., default)
 
 // What one scan launch covers.  n_rows < 0: the whole corpus; a prefix otherwise (the filter scan's plain pre-pass).
 struct ScanPlan {

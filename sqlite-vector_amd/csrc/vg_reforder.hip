@@ -247,11 +247,11 @@ extern "C" int vg_scan_topk_reference(vg_corpus *c, int metric, const void *quer
     // k = 64: the lists have no 65th slot to look for a tie with - the scan runs emitting with k slots and the slots are ALWAYS replayed
     // (the candidate stream of k-slot lists is still a superset of the rows that can enter k slots)
     const bool always = (k == VG_WAVE_HOST);
-    if (k > VG_WAVE_HOST || (always && !can_emit) || env_int("VG_REF_STORE_MODE", 0))
+    if (k > VG_WAVE_HOST || (always && !can_emit) || vg_sw(SW_VG_REF_STORE_MODE, 0))
         return reference_store_mode_replay(c, metric, query, k, out_rowids, out_dist, out_count);
     const int k1 = always ? k : k + 1;
     // scans through a filter kernel have a pre-pass anyway (emitting is free); plain-kernel scans pay for one only while ties are around
-    bool emit = can_emit && (always || c->ref_hot > 0 || vg_scan_filter_would_serve(c, metric, k1) || env_int("VG_REF_ALWAYS_EMIT", 0));
+    bool emit = can_emit && (always || c->ref_hot > 0 || vg_scan_filter_would_serve(c, metric, k1) || vg_sw(SW_VG_REF_ALWAYS_EMIT, 0));
     for (int attempt = 0; attempt < 2; ++attempt) {
         uint64_t keys[64];
         int rc = vg_scan_topk_enqueue_plan(c, metric, query, k1, emit);

@@ -140,8 +140,8 @@ extern "C" int vg_shards_create(const int *devices, int n_devices, int vtype, in
     s->vtype = vtype;
     s->dim = dim;
     {
-        const char *g = getenv("VECTORGPU_SHARD_GATHER");
-        s->gather_mode = (g && (g[0] == 'r' || g[0] == 'R')) ? 1 : 0;
+        vg_switches_read();                                           // (a shard set, like a corpus, takes the environment as it is now)
+        s->gather_mode = vg_sw(SW_VECTORGPU_SHARD_GATHER, 0);
     }
     for (int i = 0; i < n_devices; ++i) {
         vg_corpus *c = nullptr;
