@@ -58,6 +58,9 @@ long long vg_stat_rows_appended(void);
 /* ---- counters ---- */
 /* queries of a shards handle served by [0] the host gather, [1] the RCCL all-gather; returns 1 while RCCL serves */
 int vg_shards_gather_stats(vg_shards *s, unsigned long long *out2);
+/* 1 when every query's per-shard work (enqueue + collect) runs on the handle's persistent host threads, one per shard: the default
+ * for shards on more than one device, VECTORGPU_SHARD_THREADS=1 / 0 forces it (vg_shards.hip: pool_run) */
+int vg_shards_threaded(const vg_shards *s);
 /* counters of the reference-order scans of this corpus / shards handle so far: [0] scans, [1] scans whose k + 1 best distances held a
  * tie (the others cost what a tie_order = position scan costs; k = 64 has no 65th slot and always counts), [2] of those, answered by
  * the fused replay (prefix pass + the candidates the scan emitted: no second pass over the corpus), [3] answered by the store-mode

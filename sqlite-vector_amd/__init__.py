@@ -142,6 +142,7 @@ def _load():
         "vg_shards_set_gather": (i32, [vp, i32]),
         "vg_shards_gather_stats": (i32, [vp, vp]),
         "vg_shards_tie_stats": (i32, [vp, vp]),
+        "vg_shards_threaded": (i32, [vp]),
         "vg_corpus_device_bytes": (i32, [vp, vp]),
         "vg_shards_device_bytes": (i32, [vp, vp]),
         "vg_shards_rowids": (i32, [vp, i64, i64, vp]),
@@ -425,6 +426,11 @@ class Shards:
         out = np.zeros(2, dtype=np.uint64)
         serving = lib().vg_shards_gather_stats(self.h, _ptr(out))
         return {"host": int(out[0]), "rccl": int(out[1]), "rccl_serving": bool(serving)}
+
+    @property
+    def threaded(self):
+        """every query's per-shard work runs on the handle's persistent host threads (one per shard)"""
+        return bool(lib().vg_shards_threaded(self.h))
 
     def tie_stats(self):
         """reference-order scans of this handle so far (same four counters as Corpus.tie_stats)"""

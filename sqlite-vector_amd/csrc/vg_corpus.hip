@@ -58,6 +58,7 @@ extern "C" const char *vg_backend_name(void) {
 struct VgSwitchName { const char *name; int lab; };
 static const VgSwitchName vg_switch_names[VGSW_COUNT] = {
     {"VECTORGPU_SHARD_GATHER", 0},
+    {"VECTORGPU_SHARD_THREADS", 0},
     {"VG_BATCH_BPC", 1},
     {"VG_BATCH_H_SPLIT", 0},
     {"VG_BATCH_H_WAVES", 0},

@@ -27,7 +27,10 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -55,6 +58,8 @@ struct vg_shards {
     // tie_order = reference (see shards_scan_topk_fused): the same counters and the same "ties were seen recently" rule as one corpus'
     int ref_hot = 0;
     unsigned long long ref_stats[4] = {0, 0, 0, 0};   // reference-order scans | with a tie among the k+1 best | fused replays | store-mode replays
+    struct ShardPool *pool = nullptr;          // persistent host threads, one per shard behind the first (see pool_run)
+    int threaded = 0;                          // per-query issue + collect of the shards on those threads
 };
 
 // ---- librccl.so, resolved at run time
@@ -111,6 +116,79 @@ static inline int64_t global_of(const vg_shards *s, int shard, int64_t local) {
     return ((local / s->B) * s->S + shard) * s->B + local % s->B;
 }
 
+// ---- PERSISTENT host threads for the per-query work (one thread issued S x (hipSetDevice + H2D + launches) and then collected
+// S times - on eight real devices ~0.1 ms of a 2.4 ms scan of a 12.5M-row shard).  Shard i >= 1 has a thread of its own, bound to the
+// shard's device once; a query wakes them all, the calling thread serves shard 0 itself, and every thread enqueues AND collects its
+// shard.  On by default when the shards sit on more than one device; VECTORGPU_SHARD_THREADS=1 / 0 forces it (the tests run it over
+// logical shards of one device).
+struct ShardPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable go, done;
+    uint64_t epoch = 0;
+    int pending = 0;
+    bool quit = false;
+    std::function<int(int)> job;
+    std::vector<int> rc;
+    std::vector<std::string> msg;
+};
+static void pool_worker(vg_shards *s, ShardPool *p, int shard) {
+    hipSetDevice(s->devices[(size_t)shard]);
+    uint64_t seen = 0;
+    for (;;) {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->go.wait(lk, [&] { return p->quit || p->epoch != seen; });
+        if (p->quit) return;
+        seen = p->epoch;
+        lk.unlock();
+        const int r = p->job(shard);
+        const std::string m = r != VG_OK ? vg_last_error() : "";
+        lk.lock();
+        p->rc[(size_t)shard] = r;
+        if (r != VG_OK) p->msg[(size_t)shard] = m;
+        if (--p->pending == 0) p->done.notify_one();
+    }
+}
+static void pool_release(vg_shards *s) {
+    ShardPool *p = s->pool;
+    if (!p) return;
+    { std::lock_guard<std::mutex> lk(p->mu); p->quit = true; }
+    p->go.notify_all();
+    for (auto &t : p->th) t.join();
+    delete p;
+    s->pool = nullptr;
+}
+// fn(shard) for every shard at once; the first failure's code and message are re-raised on the calling thread
+template <typename F>
+static int pool_run(vg_shards *s, F fn) {
+    if (s->S == 1) return fn(0);
+    if (!s->pool) {
+        s->pool = new ShardPool();
+        s->pool->rc.assign((size_t)s->S, VG_OK);
+        s->pool->msg.assign((size_t)s->S, std::string());
+        for (int i = 1; i < s->S; ++i) s->pool->th.emplace_back(pool_worker, s, s->pool, i);
+    }
+    ShardPool *p = s->pool;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->job = fn;
+        p->pending = s->S - 1;
+        std::fill(p->rc.begin(), p->rc.end(), VG_OK);
+        ++p->epoch;
+    }
+    p->go.notify_all();
+    const int r0 = fn(0);
+    const std::string m0 = r0 != VG_OK ? vg_last_error() : "";
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->done.wait(lk, [&] { return p->pending == 0; });
+    }
+    if (r0 != VG_OK) return fail(r0, m0.c_str());
+    for (int i = 1; i < s->S; ++i)
+        if (p->rc[(size_t)i] != VG_OK) return fail(p->rc[(size_t)i], p->msg[(size_t)i].c_str());
+    return VG_OK;
+}
+
 // run fn(shard) for every shard concurrently (one host thread each: the per-corpus calls block on their stream);
 // the first failure's code and message are re-raised on the calling thread
 template <typename F>
@@ -155,6 +233,11 @@ extern "C" int vg_shards_create(const int *devices, int n_devices, int vtype, in
         s->sh.push_back(c);
     }
     s->es = (vtype == VG_TYPE_F32) ? 4 : (vtype == VG_TYPE_F16 || vtype == VG_TYPE_BF16) ? 2 : 1;
+    {
+        bool many = false;
+        for (int d : s->devices) many = many || d != s->devices[0];
+        s->threaded = vg_sw(SW_VECTORGPU_SHARD_THREADS, many ? 1 : 0) != 0 && s->S > 1;
+    }
     *out = s;
     return VG_OK;
 }
@@ -170,6 +253,7 @@ static void rccl_release(vg_shards *s) {
 
 extern "C" void vg_shards_destroy(vg_shards *s) {
     if (!s) return;
+    pool_release(s);
     rccl_release(s);
     for (auto *p : s->sh) vg_corpus_destroy(p);
     delete s;
@@ -564,10 +648,17 @@ static int shards_scan_topk_fused(vg_shards *s, int metric, const void *query, i
         }
         if (rc != VG_OK) {
             rc = VG_OK;
-            for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue_plan(s->sh[(size_t)i], metric, query, kk, emit);
-            for (int i = 0; i < s->S; ++i) {
-                int rc2 = vg_scan_topk_collect(s->sh[(size_t)i], &keys[(size_t)i * VG_WAVE_KEYS]);
-                if (rc == VG_OK) rc = rc2;
+            if (s->threaded) {
+                rc = pool_run(s, [&](int i) {
+                    const int r = vg_scan_topk_enqueue_plan(s->sh[(size_t)i], metric, query, kk, emit);
+                    return r != VG_OK ? r : vg_scan_topk_collect(s->sh[(size_t)i], &keys[(size_t)i * VG_WAVE_KEYS]);
+                });
+            } else {
+                for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue_plan(s->sh[(size_t)i], metric, query, kk, emit);
+                for (int i = 0; i < s->S; ++i) {
+                    int rc2 = vg_scan_topk_collect(s->sh[(size_t)i], &keys[(size_t)i * VG_WAVE_KEYS]);
+                    if (rc == VG_OK) rc = rc2;
+                }
             }
             if (rc != VG_OK) return rc;
             ++s->gather_calls[0];
@@ -615,6 +706,8 @@ extern "C" int vg_shards_device_bytes(const vg_shards *s, long long *out3) {
     return VG_OK;
 }
 
+extern "C" int vg_shards_threaded(const vg_shards *s) { return s ? s->threaded : 0; }
+
 extern "C" int vg_shards_tie_stats(const vg_shards *s, unsigned long long *out4) {
     if (!s || !out4) return fail(VG_ERR_INVALID, "vg_shards_tie_stats: NULL argument");
     if (s->S == 1) return vg_corpus_tie_stats(s->sh[0], out4);
@@ -643,10 +736,17 @@ extern "C" int vg_shards_scan_topk(vg_shards *s, int metric, const void *query, 
         }
         if (rc != VG_OK) {
             rc = VG_OK;
-            for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue(s->sh[(size_t)i], metric, query, k);
-            for (int i = 0; i < s->S; ++i) {
-                int rc2 = vg_scan_topk_collect(s->sh[(size_t)i], &keys[(size_t)i * VG_WAVE_KEYS]);
-                if (rc == VG_OK) rc = rc2;
+            if (s->threaded) {
+                rc = pool_run(s, [&](int i) {
+                    const int r = vg_scan_topk_enqueue(s->sh[(size_t)i], metric, query, k);
+                    return r != VG_OK ? r : vg_scan_topk_collect(s->sh[(size_t)i], &keys[(size_t)i * VG_WAVE_KEYS]);
+                });
+            } else {
+                for (int i = 0; i < s->S && rc == VG_OK; ++i) rc = vg_scan_topk_enqueue(s->sh[(size_t)i], metric, query, k);
+                for (int i = 0; i < s->S; ++i) {
+                    int rc2 = vg_scan_topk_collect(s->sh[(size_t)i], &keys[(size_t)i * VG_WAVE_KEYS]);
+                    if (rc == VG_OK) rc = rc2;
+                }
             }
             if (rc != VG_OK) return rc;
             ++s->gather_calls[0];

@@ -7,6 +7,7 @@
 
 enum VgSwitch {
     SW_VECTORGPU_SHARD_GATHER,
+    SW_VECTORGPU_SHARD_THREADS,
     SW_VG_BATCH_BPC,                       // LAB
     SW_VG_BATCH_H_SPLIT,
     SW_VG_BATCH_H_WAVES,

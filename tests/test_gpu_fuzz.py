@@ -136,6 +136,7 @@ def test_reference_order_fuzz(pkg, orc, chunk, monkeypatch):
             c = pkg.Corpus(vt, dim)
             c.append(rows)
         else:
+            monkeypatch.setenv("VECTORGPU_SHARD_THREADS", str(seed & 1))    # the per-shard work on host threads, or issued by this one
             c = pkg.Shards(vt, dim, [0] * shards, block_rows=int(rng.choice([257, 4099, 65536])))
             c.append(rows)
         c.set_scan_filter(1 if filt else 0)

@@ -1038,10 +1038,13 @@ def test_in_process_shards_long_row_batches(pkg, vt):
     one.close(); sh.close()
 
 
+@pytest.mark.parametrize("threads", (0, 1))
 @pytest.mark.parametrize("vt,metric", [(dg.F32, dg.L2), (dg.U8, dg.COSINE), (dg.I8, dg.L1), (dg.F32, dg.DOT)])
-def test_in_process_shards_equal_a_single_corpus(pkg, orc, vt, metric):
+def test_in_process_shards_equal_a_single_corpus(pkg, orc, vt, metric, threads, monkeypatch):
     """vg_shards (one logical corpus dealt block-cyclically over several devices of one process - here three logical
-    shards on device 0): every call returns bit-for-bit what one corpus holding all rows returns."""
+    shards on device 0): every call returns bit-for-bit what one corpus holding all rows returns.  threads = 1: each query's
+    per-shard enqueue + collect runs on the handle's persistent host threads, the way it does by default on several devices."""
+    monkeypatch.setenv("VECTORGPU_SHARD_THREADS", str(threads))
     dim, n, block = 72, 20_011, 1000                       # ragged last block; low-entropy rows force distance ties
     rows = dg.corpus(vt, n, dim, 61, low_entropy=vt != dg.F32)
     q = dg.query(vt, dim, 62, low_entropy=vt != dg.F32)
@@ -1049,6 +1052,7 @@ def test_in_process_shards_equal_a_single_corpus(pkg, orc, vt, metric):
     one = pkg.Corpus(vt, dim)
     one.append(rows, rowids)
     sh = pkg.Shards(vt, dim, [0, 0, 0], block_rows=block)
+    assert sh.threaded == bool(threads)
     sh.reserve(n)
     for r0 in range(0, n, 3333):                            # appends that straddle block boundaries
         sh.append(rows[r0:r0 + 3333], rowids[r0:r0 + 3333])

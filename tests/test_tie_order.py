@@ -83,9 +83,11 @@ def pkg():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("vt", (dg.U8, dg.I8, dg.F32))
-def test_reference_tie_order_on_device_equals_the_reference(pkg, orc, vt):
+def test_reference_tie_order_on_device_equals_the_reference(pkg, orc, vt, monkeypatch):
     """low-entropy rows (distances tie constantly): rowids AND order must be the reference's for every metric; one corpus
-    and 3 logical shards with ragged blocks; k below / at / above the fused limit; n below and above the prefix."""
+    and 3 logical shards with ragged blocks (their per-query work on the handle's host threads, as on several devices); k below /
+    at / above the fused limit; n below and above the prefix."""
+    monkeypatch.setenv("VECTORGPU_SHARD_THREADS", "1")
     rng = np.random.default_rng(31 + vt)
     for dim, n in ((16, 500), (48, 70_001), (8, 1_200_000)):
         rows = dg.corpus(vt, n, dim, 600 + dim, low_entropy=True)
@@ -96,6 +98,7 @@ def test_reference_tie_order_on_device_equals_the_reference(pkg, orc, vt):
         c = pkg.Corpus(vt, dim)
         c.append(rows, ids)
         sh = pkg.Shards(vt, dim, [0, 0, 0], block_rows=4099)
+        assert sh.threaded
         sh.append(rows, ids)
         c.set_tie_order(pkg.TIE_REFERENCE)
         sh.set_tie_order(pkg.TIE_REFERENCE)
