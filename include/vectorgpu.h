@@ -230,6 +230,26 @@ int vg_corpus_set_tie_order(vg_corpus *c, int mode);
 int vg_corpus_tie_order(const vg_corpus *c);
 int vg_shards_set_tie_order(vg_shards *s, int mode);
 int vg_scan_topk_reference(vg_corpus *c, int metric, const void *query, int k, int64_t *out_rowids, double *out_dist, int *out_count);
+/* ---- out-of-core scans: a table that does not fit device memory ----
+ * The reference scans a table of ANY size: vFullScanRun walks the statement's rows one by one (sqlite-vector.c:2071-2113) and keeps k
+ * slots.  Its form here: the caller hands the rows over in scan order, the device holds TWO slabs of slab_rows rows each - one being
+ * filled through the pinned bounce buffers, the other one being scanned on a host thread of its own - and what is carried from slab to
+ * slab is what the reference carries from row to row: the k best so far (tie_order = position: merged by (distance, scan position);
+ * tie_order = reference: the slot state itself, offered the rows of each later slab that lie below the bound reached, vg_refslots.h).
+ * Results are those of vg_scan_topk over one corpus holding all rows, bit for bit.  k = 0: every row's distance and rowid instead
+ * (the *_stream functions), fetched with vg_slab_scan_all.  rowid_base: implicit rowid of scan position p = rowid_base + p where the
+ * caller passes rowids = NULL.  The handle serves one query; the extension makes one per scan of a table it cannot keep resident
+ * (VECTORGPU_HBM_LIMIT or the device's free memory: INTEGRATION.md). */
+typedef struct vg_slab_scan vg_slab_scan;
+int  vg_slab_scan_begin(int device, int vtype, int dim, int metric, const void *query, int k, int tie_order, int64_t slab_rows,
+                        int64_t rowid_base, vg_slab_scan **out);
+int  vg_slab_scan_rows(vg_slab_scan *s, const void *host_rows, int64_t n_rows, int64_t row_stride_bytes, const int64_t *rowids);
+int  vg_slab_scan_records(vg_slab_scan *s, const void *host_records, int64_t n_records);   /* [int64 LE rowid | dim bytes] records (uint8 / int8) */
+int  vg_slab_scan_finish(vg_slab_scan *s, int64_t *out_rowids, double *out_dist, int *out_count);
+int  vg_slab_scan_all(vg_slab_scan *s, int64_t *out_rows, const float **out_dist, const int64_t **out_rowids);   /* k = 0, after finish; valid until destroy */
+void vg_slab_scan_destroy(vg_slab_scan *s);
+int  vg_device_memory(int device, long long *out_free_bytes, long long *out_total_bytes);
+
 /* ---- per-corpus switches ---- */
 /* The lower-bound filter scans of single top-k queries (see vg_scan_topk): 0 = off (plain scans, no shadow copy is built),
  * -1 = default (environment VG_SCAN_FILTER, else on): f32 / f16 / bf16 corpora from 2^20 rows and 512 MB through an int8 shadow

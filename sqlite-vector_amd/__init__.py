@@ -143,6 +143,13 @@ def _load():
         "vg_shards_gather_stats": (i32, [vp, vp]),
         "vg_shards_tie_stats": (i32, [vp, vp]),
         "vg_shards_threaded": (i32, [vp]),
+        "vg_slab_scan_begin": (i32, [i32, i32, i32, i32, vp, i32, i32, i64, i64, vp]),
+        "vg_slab_scan_rows": (i32, [vp, vp, i64, i64, vp]),
+        "vg_slab_scan_records": (i32, [vp, vp, i64]),
+        "vg_slab_scan_finish": (i32, [vp, vp, vp, vp]),
+        "vg_slab_scan_all": (i32, [vp, vp, vp, vp]),
+        "vg_slab_scan_destroy": (None, [vp]),
+        "vg_device_memory": (i32, [i32, vp, vp]),
         "vg_corpus_device_bytes": (i32, [vp, vp]),
         "vg_shards_device_bytes": (i32, [vp, vp]),
         "vg_shards_rowids": (i32, [vp, i64, i64, vp]),
@@ -364,6 +371,56 @@ class Corpus:
         out = np.zeros(4, dtype=np.uint64)
         _check(lib().vg_corpus_tie_stats(self.h, _ptr(out)))
         return dict(zip(("scans", "with_a_tie_among_the_k_plus_1_best", "fused_replays", "store_mode_replays"), (int(x) for x in out)))
+
+
+class SlabScan:
+    """One query over a table handed over slab by slab (include/vectorgpu.h: vg_slab_scan_*): the device holds two slabs."""
+
+    def __init__(self, vtype, dim, metric, query, k, slab_rows, tie_order=0, device=0, rowid_base=1):
+        self.h = C.c_void_p()
+        self.k = k
+        query = np.ascontiguousarray(query)
+        _check(lib().vg_slab_scan_begin(device, vtype, dim, metric, _ptr(query), k, tie_order, slab_rows, rowid_base, C.byref(self.h)))
+
+    def rows(self, rows, rowids=None):
+        rows = np.ascontiguousarray(rows)
+        ids = None if rowids is None else np.ascontiguousarray(rowids, dtype=np.int64)
+        _check(lib().vg_slab_scan_rows(self.h, _ptr(rows), rows.shape[0], rows.strides[0] if rows.ndim == 2 else 0, None if ids is None else _ptr(ids)))
+
+    def records(self, recs, n):
+        recs = np.ascontiguousarray(recs)
+        _check(lib().vg_slab_scan_records(self.h, _ptr(recs), n))
+
+    def finish(self):
+        ids = np.zeros(max(self.k, 1), dtype=np.int64)
+        dist = np.zeros(max(self.k, 1), dtype=np.float64)
+        cnt = C.c_int(0)
+        _check(lib().vg_slab_scan_finish(self.h, _ptr(ids), _ptr(dist), C.byref(cnt)))
+        return ids[:cnt.value], dist[:cnt.value]
+
+    def all(self):
+        """k = 0 scans, after finish(): (distances, rowids) of every row in scan order"""
+        n = C.c_int64(0)
+        pd, pi = C.c_void_p(), C.c_void_p()
+        _check(lib().vg_slab_scan_all(self.h, C.byref(n), C.byref(pd), C.byref(pi)))
+        if n.value == 0:
+            return np.zeros(0, dtype=np.float32), np.zeros(0, dtype=np.int64)
+        d = np.ctypeslib.as_array(C.cast(pd, C.POINTER(C.c_float)), shape=(n.value,)).copy()
+        i = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_int64)), shape=(n.value,)).copy()
+        return d, i
+
+    def close(self):
+        if self.h:
+            lib().vg_slab_scan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+
+def device_memory(device=0):
+    f, t = C.c_longlong(0), C.c_longlong(0)
+    _check(lib().vg_device_memory(device, C.byref(f), C.byref(t)))
+    return f.value, t.value
 
 
 class Shards:

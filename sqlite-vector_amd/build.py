@@ -24,7 +24,7 @@ VEC = os.path.join(HERE, "vector.so")
 # by the total CPU time over the cores (~30 CPU-minutes: ~4 min on 8 cores) instead of by its longest unit
 HIP_UNITS = [("vg_api.hip", "vg_api.hip.o", []), ("vg_corpus.hip", "vg_corpus.hip.o", []), ("vg_batch_api.hip", "vg_batch_api.hip.o", []),
              ("vg_select.hip", "vg_select.hip.o", []), ("vg_batch.hip", "vg_batch.hip.o", []), ("vg_quant.hip", "vg_quant.hip.o", []),
-             ("vg_shards.hip", "vg_shards.hip.o", []), ("vg_multi.hip", "vg_multi.hip.o", []), ("vg_reforder.hip", "vg_reforder.hip.o", []), ("vg_scan_ex.hip", "vg_scan_ex.hip.o", []), ("vg_filter.hip", "vg_filter.hip.o", []),
+             ("vg_shards.hip", "vg_shards.hip.o", []), ("vg_multi.hip", "vg_multi.hip.o", []), ("vg_reforder.hip", "vg_reforder.hip.o", []), ("vg_slabscan.hip", "vg_slabscan.hip.o", []), ("vg_scan_ex.hip", "vg_scan_ex.hip.o", []), ("vg_filter.hip", "vg_filter.hip.o", []),
              ("vg_batch_q8.hip", "vg_batch_q8.o", []),
              ("vg_batch_i8.hip", "vg_batch_i8.hip.o", []), ("vg_batch_i8.hip", "vg_batch_i8_pre.o", ["-DVGI_TU_PRE"]),
              ("vg_batch_h.hip", "vg_batch_h.hip.o", []), ("vg_batch_h.hip", "vg_batch_h_bf16.o", ["-DVGH_TU=1"]),

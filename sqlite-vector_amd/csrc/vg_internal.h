@@ -205,6 +205,7 @@ int vg_ref_emitted_wait(vg_corpus *c, const float **prefix, int64_t *prefix_rows
                         bool *overflow);
 struct VgRefSlots;
 void vg_ref_offer_run(VgRefSlots &slots, const float *d, int64_t n, int64_t g0);   // a run of consecutive rows offered to the slots
+int vg_ref_replay_slab(vg_corpus *c, int metric, const void *query, int k, VgRefSlots &slots, int64_t gbase, bool fresh);   // vg_reforder.hip
 
 // next slot of the profiling ring (nullptr when profiling is off)
 static inline hipEvent_t *vg_prof_slot(vg_corpus *c, uint8_t flags) {

@@ -147,6 +147,22 @@ static int reference_store_mode_replay(vg_corpus *c, int metric, const void *que
     return VG_OK;
 }
 
+// one slab of a table scanned slab by slab (vg_slabscan.hip): all of the slab's distances stay on the device, the slots the earlier slabs
+// left are offered the slab's rows in scan order (a fresh stream: prefix + candidates; a continued one: the rows below the bound reached)
+int vg_ref_replay_slab(vg_corpus *c, int metric, const void *query, int k, VgRefSlots &slots, int64_t gbase, bool fresh) {
+    int rc = vg_scan_distances_resident(c, metric, query);
+    if (rc != VG_OK) return rc;
+    CorpusSrc src{c, c->ref_pairs};
+    if (fresh) {
+        if ((rc = vg_ref_replay(src, c->n_rows, k, slots)) != VG_OK) return rc;
+        if (gbase) for (int i = 0; i < k; ++i) if (slots.pos[(size_t)i] >= 0) slots.pos[(size_t)i] += gbase;
+    } else if ((rc = vg_ref_replay_more(src, c->n_rows, k, slots, gbase)) != VG_OK) return rc;
+    vg_collect_timing(c);
+    ++c->ref_stats[0];
+    ++c->ref_stats[3];
+    return VG_OK;
+}
+
 int vg_ensure_ref_buffers(vg_corpus *c, int64_t prefix_rows) {
     if (c->ref_prefix_cap < prefix_rows) {
         if (c->d_ref_prefix) { HIP_TRY(hipStreamSynchronize(c->stream)); hipFree(c->d_ref_prefix); c->d_ref_prefix = nullptr; c->ref_prefix_cap = 0; }

@@ -110,3 +110,34 @@ static int vg_ref_replay(Src &src, int64_t n, int k, VgRefSlots &slots) {
     }
     return 0;
 }
+
+// The same stream CONTINUED: `slots` holds the state the rows before this stretch left (vg_slabscan.hip: a table scanned slab by slab);
+// the stretch's rows are positions [0, n) of src and global positions gbase + [0, n).  No prefix: the bound the earlier rows reached is
+// already low, so the rows below it are few.  (A first stretch - slots fresh - is replayed by vg_ref_replay itself.)
+template <class Src>
+static int vg_ref_replay_more(Src &src, int64_t n, int k, VgRefSlots &slots, int64_t gbase) {
+    if (n <= 0 || k <= 0) return 0;
+    const int64_t P = vg_ref_prefix_rows(n, k);
+    std::vector<float> buf;
+    std::vector<VgRefCand> cand;
+    int64_t g = 0;
+    int rc;
+    while (g < n) {
+        bool overflow = false;
+        cand.clear();
+        const float bound = slots.bound();
+        if (bound == INFINITY) overflow = true;
+        else if ((rc = src.below(g, bound, cand, &overflow)) != 0) return rc;
+        if (!overflow) {
+            std::sort(cand.begin(), cand.end(), [](const VgRefCand &a, const VgRefCand &b) { return a.gpos < b.gpos; });
+            for (const VgRefCand &c : cand) slots.offer(c.d, gbase + c.gpos);
+            break;
+        }
+        const int64_t cnt = std::min<int64_t>(n - g, std::max<int64_t>(P, 1 << 20));
+        buf.resize((size_t)cnt);
+        if ((rc = src.fetch(g, cnt, buf.data())) != 0) return rc;
+        for (int64_t i = 0; i < cnt; ++i) slots.offer(buf[(size_t)i], gbase + g + i);
+        g += cnt;
+    }
+    return 0;
+}

@@ -90,9 +90,13 @@ static void fn_gpu_memory(sqlite3_context *ctx, int argc, sqlite3_value **argv) 
     if ((t->full || t->quant) && !gpu_load()) { ctx_error(ctx, SQLITE_ERROR, "%s", gpu_error()); return; }
     if (t->full && G.corpus_device_bytes(t->full, f) != VG_OK) { ctx_error(ctx, SQLITE_ERROR, "%s", gpu_error()); return; }
     if (t->quant && G.corpus_device_bytes(t->quant, q) != VG_OK) { ctx_error(ctx, SQLITE_ERROR, "%s", gpu_error()); return; }
-    char *js = sqlite3_mprintf("{\"column\":{\"staged\":%d,\"rows_bytes\":%lld,\"derived_bytes\":%lld,\"working_bytes\":%lld},"
-                               "\"quantized\":{\"staged\":%d,\"rows_bytes\":%lld,\"derived_bytes\":%lld,\"working_bytes\":%lld},\"total_bytes\":%lld}",
-                               t->full ? 1 : 0, f[0], f[1], f[2], t->quant ? 1 : 0, q[0], q[1], q[2], f[0] + f[1] + f[2] + q[0] + q[1] + q[2]);
+    /* out_of_core: the table (its quantized records) did not fit the device at its last scan - nothing is resident, every scan reads the
+     * rows again through two slabs of slab_rows rows (vext_staging.inc: ooc_plan) */
+    char *js = sqlite3_mprintf("{\"column\":{\"staged\":%d,\"rows_bytes\":%lld,\"derived_bytes\":%lld,\"working_bytes\":%lld,\"out_of_core\":%d,\"slab_rows\":%lld},"
+                               "\"quantized\":{\"staged\":%d,\"rows_bytes\":%lld,\"derived_bytes\":%lld,\"working_bytes\":%lld,\"out_of_core\":%d,\"slab_rows\":%lld},\"total_bytes\":%lld}",
+                               t->full ? 1 : 0, f[0], f[1], f[2], t->full_ooc, (long long)(t->full_ooc ? t->full_slab_rows : 0),
+                               t->quant ? 1 : 0, q[0], q[1], q[2], t->quant_ooc, (long long)(t->quant_ooc ? t->quant_slab_rows : 0),
+                               f[0] + f[1] + f[2] + q[0] + q[1] + q[2]);
     if (!js) { sqlite3_result_error_nomem(ctx); return; }
     sqlite3_result_text(ctx, js, -1, sqlite3_free);
 }
@@ -100,8 +104,11 @@ static void fn_gpu_memory(sqlite3_context *ctx, int argc, sqlite3_value **argv) 
 /* vector_gpu_stats(): an addition over the reference's surface - what staging into HBM has cost this process, as JSON text */
 static void fn_gpu_stats(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
     const stage_stats g = stage_stats_read();
-    char *js = sqlite3_mprintf("{\"stage_passes\":%lld,\"parallel_reader_passes\":%lld,\"rows_staged\":%lld,\"seconds_staging\":%.6f,\"seconds_in_engine_append\":%.6f,\"seconds_count_star\":%.6f,\"seconds_hbm_reserve\":%.6f}",
-                               g.passes, g.parallel_passes, g.rows, g.seconds, g.append_seconds, g.count_seconds, g.reserve_seconds);
+    pthread_mutex_lock(&g_stage_mu);
+    const long long os = ooc_stat_scans, orows = ooc_stat_rows;
+    pthread_mutex_unlock(&g_stage_mu);
+    char *js = sqlite3_mprintf("{\"stage_passes\":%lld,\"parallel_reader_passes\":%lld,\"rows_staged\":%lld,\"seconds_staging\":%.6f,\"seconds_in_engine_append\":%.6f,\"seconds_count_star\":%.6f,\"seconds_hbm_reserve\":%.6f,\"out_of_core_scans\":%lld,\"out_of_core_rows\":%lld}",
+                               g.passes, g.parallel_passes, g.rows, g.seconds, g.append_seconds, g.count_seconds, g.reserve_seconds, os, orows);
     if (!js) { sqlite3_result_error_nomem(ctx); return; }
     sqlite3_result_text(ctx, js, -1, sqlite3_free);
 }

@@ -1235,3 +1235,72 @@ def test_quantize_stages_in_front_of_its_transaction_and_reserves_by_key_span(ex
     assert json.loads(db.execute("SELECT vector_gpu_stats()").fetchone()[0])["rows_staged"] == before["rows_staged"]
     assert not db.in_transaction                 # (the failure path ends with ROLLBACK, sqlite-vector.c:1450: the caller's transaction is gone)
     db.close()
+
+
+# ------------------------------------------------------------------------------------------------ out of core
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", mg.SQL_SCAN_CASES + mg.SQL_QUANT_CASES, ids=["ooc-" + c[0] for c in mg.SQL_SCAN_CASES + mg.SQL_QUANT_CASES])
+def test_golden_cases_out_of_core(ext_path, case, monkeypatch):
+    """VECTORGPU_HBM_LIMIT below the table's size: nothing is resident, every scan walks the table again through two slabs
+    (vg_slabscan.hip; the reference walks the table for every scan too, sqlite-vector.c:2071-2113) - the golden answers of the
+    reference extension, the persisted quantization bytes included (vector_quantize runs slab by slab as well)."""
+    monkeypatch.setenv("VECTORGPU_HBM_LIMIT", "16K")
+    if case in mg.SQL_QUANT_CASES:
+        test_vector_quantize_scan_vs_reference_golden(ext_path, case)
+        test_vector_quantize_persists_the_reference_bytes(ext_path, case)
+    else:
+        test_vector_full_scan_vs_reference_golden(ext_path, case)
+
+
+@pytest.mark.gpu
+def test_out_of_core_tables_report_it_and_come_back_when_they_fit(ext_path, orc, monkeypatch):
+    import json
+    n, dim, k = 30_000, 48, 25
+    rows = dg.corpus(dg.F32, n, dim, 9100)
+    rows[20_000:20_030] = rows[7]                                                  # exact duplicates: ties across slabs
+    q = rows[7].copy()
+    db = connect(ext_path)
+    load_table(db, rows, dg.F32, dg.L2)
+    want = db.execute("SELECT rowid, distance FROM vector_full_scan('t','v',?,?)", (q.tobytes(), k)).fetchall()
+    mem = json.loads(db.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
+    assert mem["column"]["staged"] == 1 and mem["column"]["out_of_core"] == 0
+    stream = db.execute("SELECT rowid, distance FROM vector_full_scan_stream('t','v',?) ", (q.tobytes(),)).fetchall()
+    db.execute("INSERT INTO t(id, v) VALUES (?, ?)", (n + 1, rows[0].tobytes()))    # (a write: the next scan re-plans)
+    monkeypatch.setenv("VECTORGPU_HBM_LIMIT", "1")                                 # 1 MiB < 5.8 MB
+    for order in ("position", "reference"):
+        monkeypatch.setenv("VECTORGPU_TIE_ORDER", order)
+        db2 = connect(ext_path)
+        load_table(db2, rows, dg.F32, dg.L2)
+        got = db2.execute("SELECT rowid, distance FROM vector_full_scan('t','v',?,?)", (q.tobytes(), k)).fetchall()
+        mem = json.loads(db2.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
+        assert mem["column"]["staged"] == 0 and mem["column"]["out_of_core"] == 1 and mem["column"]["rows_bytes"] == 0
+        assert 64 <= mem["column"]["slab_rows"] < n // 4
+        if order == "position":
+            assert got == want
+        else:
+            ref = orc.topk_reference(np.array([d for _, d in stream], dtype=np.float32), np.array([i for i, _ in stream], dtype=np.int64), k)
+            assert [g[0] for g in got] == ref[0].tolist() and [g[1] for g in got] == ref[1].tolist()
+        # the *_stream function and the batch function walk the slabs too
+        got_s = db2.execute("SELECT rowid, distance FROM vector_full_scan_stream('t','v',?)", (q.tobytes(),)).fetchall()
+        assert got_s == stream
+        if order == "position":
+            qs = np.stack([rows[7], rows[99], rows[12345]])
+            b = db2.execute("SELECT query, id, distance FROM vector_full_scan_batch('t','v',?,?)", (qs.tobytes(), 5)).fetchall()
+            for j in range(3):
+                one = db2.execute("SELECT rowid, distance FROM vector_full_scan('t','v',?,5)", (qs[j].tobytes(),)).fetchall()
+                assert [(r, d) for (qn, r, d) in b if qn == j] == one
+        # rows written since are seen by the next scan (there is no copy to go stale)
+        db2.execute("DELETE FROM t WHERE id=?", (got[0][0],))
+        again = db2.execute("SELECT rowid FROM vector_full_scan('t','v',?,?)", (q.tobytes(), k)).fetchall()
+        assert got[0][0] not in [r[0] for r in again] and len(again) == k
+        db2.close()
+    stats = json.loads(db.execute("SELECT vector_gpu_stats()").fetchone()[0])
+    assert stats["out_of_core_scans"] >= 8 and stats["out_of_core_rows"] >= 8 * (n - 1)
+    # the limit lifted: the table is resident again
+    monkeypatch.delenv("VECTORGPU_HBM_LIMIT")
+    monkeypatch.delenv("VECTORGPU_TIE_ORDER")
+    db3 = connect(ext_path)
+    load_table(db3, rows, dg.F32, dg.L2)
+    assert db3.execute("SELECT rowid, distance FROM vector_full_scan('t','v',?,?)", (q.tobytes(), k)).fetchall() == want
+    mem = json.loads(db3.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
+    assert mem["column"]["staged"] == 1 and mem["column"]["out_of_core"] == 0

@@ -135,3 +135,16 @@ int vg_shards_delete_rows(vg_shards *s, const int64_t *pos, int64_t n) {
     return 0;
 }
 int vg_shards_device_bytes(const vg_shards *s, long long *out3) { out3[0] = (long long)s->cap * s->dim * 4; out3[1] = 0; out3[2] = 0; return 0; }
+
+/* out-of-core scans: the stub holds everything in host memory and reports plenty of it free - nothing ever goes out of core here */
+typedef struct vg_slab_scan vg_slab_scan;
+int vg_slab_scan_begin(int device, int vtype, int dim, int metric, const void *q, int k, int tie, int64_t slab_rows, int64_t rowid_base, vg_slab_scan **out) {
+    (void)device; (void)vtype; (void)dim; (void)metric; (void)q; (void)k; (void)tie; (void)slab_rows; (void)rowid_base; (void)out;
+    return fail("stub engine: no out-of-core scans");
+}
+int vg_slab_scan_rows(vg_slab_scan *s, const void *rows, int64_t n, int64_t stride, const int64_t *ids) { (void)s; (void)rows; (void)n; (void)stride; (void)ids; return fail("stub engine: no out-of-core scans"); }
+int vg_slab_scan_records(vg_slab_scan *s, const void *rec, int64_t n) { (void)s; (void)rec; (void)n; return fail("stub engine: no out-of-core scans"); }
+int vg_slab_scan_finish(vg_slab_scan *s, int64_t *ids, double *d, int *n) { (void)s; (void)ids; (void)d; (void)n; return fail("stub engine: no out-of-core scans"); }
+int vg_slab_scan_all(vg_slab_scan *s, int64_t *n, const float **d, const int64_t **ids) { (void)s; (void)n; (void)d; (void)ids; return fail("stub engine: no out-of-core scans"); }
+void vg_slab_scan_destroy(vg_slab_scan *s) { (void)s; }
+int vg_device_memory(int device, long long *free_bytes, long long *total_bytes) { (void)device; *free_bytes = 1ll << 40; *total_bytes = 1ll << 40; return 0; }
