@@ -57,6 +57,7 @@ enum { COL_TBL = 0, COL_VECTOR = 1, COL_K = 2, COL_MEMIDX = 3, COL_ID = 4, COL_D
 
 /* The extension is ONE translation unit (every function static, one exported symbol) kept in parts by concern: */
 #include "vext_gpulib.inc"
+#include "vext_shared.inc"
 #include "vext_context.inc"
 #include "vext_tracking.inc"
 #include "vext_sqlutil.inc"
@@ -88,14 +89,25 @@ static void fn_gpu_memory(sqlite3_context *ctx, int argc, sqlite3_value **argv) 
     if (!t) { ctx_error(ctx, SQLITE_ERROR, "Vector context not found for table '%s' and column '%s'. Ensure that vector_init() has been called before using vector_gpu_memory().", tbl, col); return; }
     long long f[3] = {0, 0, 0}, q[3] = {0, 0, 0};
     if ((t->full || t->quant) && !gpu_load()) { ctx_error(ctx, SQLITE_ERROR, "%s", gpu_error()); return; }
-    if (t->full && G.corpus_device_bytes(t->full, f) != VG_OK) { ctx_error(ctx, SQLITE_ERROR, "%s", gpu_error()); return; }
-    if (t->quant && G.corpus_device_bytes(t->quant, q) != VG_OK) { ctx_error(ctx, SQLITE_ERROR, "%s", gpu_error()); return; }
+    int frc = VG_OK, qrc = VG_OK, fsh = 0, qsh = 0;
+    full_lock(t);
+    if (t->full) frc = G.corpus_device_bytes(t->full, f);
+    full_unlock(t);
+    quant_lock(t);
+    if (t->quant) qrc = G.corpus_device_bytes(t->quant, q);
+    quant_unlock(t);
+    if (frc != VG_OK || qrc != VG_OK) { ctx_error(ctx, SQLITE_ERROR, "%s", gpu_error()); return; }
+    /* sharers: connections of this process holding this very copy (vext_shared.inc; 0 = the connection's own) - the bytes are held ONCE */
+    pthread_mutex_lock(&g_shared_mu);
+    if (t->full_sh) fsh = t->full_sh->refs;
+    if (t->quant_sh) qsh = t->quant_sh->refs;
+    pthread_mutex_unlock(&g_shared_mu);
     /* out_of_core: the table (its quantized records) did not fit the device at its last scan - nothing is resident, every scan reads the
      * rows again through two slabs of slab_rows rows (vext_staging.inc: ooc_plan) */
-    char *js = sqlite3_mprintf("{\"column\":{\"staged\":%d,\"rows_bytes\":%lld,\"derived_bytes\":%lld,\"working_bytes\":%lld,\"out_of_core\":%d,\"slab_rows\":%lld},"
-                               "\"quantized\":{\"staged\":%d,\"rows_bytes\":%lld,\"derived_bytes\":%lld,\"working_bytes\":%lld,\"out_of_core\":%d,\"slab_rows\":%lld},\"total_bytes\":%lld}",
-                               t->full ? 1 : 0, f[0], f[1], f[2], t->full_ooc, (long long)(t->full_ooc ? t->full_slab_rows : 0),
-                               t->quant ? 1 : 0, q[0], q[1], q[2], t->quant_ooc, (long long)(t->quant_ooc ? t->quant_slab_rows : 0),
+    char *js = sqlite3_mprintf("{\"column\":{\"staged\":%d,\"rows_bytes\":%lld,\"derived_bytes\":%lld,\"working_bytes\":%lld,\"out_of_core\":%d,\"slab_rows\":%lld,\"sharers\":%d},"
+                               "\"quantized\":{\"staged\":%d,\"rows_bytes\":%lld,\"derived_bytes\":%lld,\"working_bytes\":%lld,\"out_of_core\":%d,\"slab_rows\":%lld,\"sharers\":%d},\"total_bytes\":%lld}",
+                               t->full ? 1 : 0, f[0], f[1], f[2], t->full_ooc, (long long)(t->full_ooc ? t->full_slab_rows : 0), fsh,
+                               t->quant ? 1 : 0, q[0], q[1], q[2], t->quant_ooc, (long long)(t->quant_ooc ? t->quant_slab_rows : 0), qsh,
                                f[0] + f[1] + f[2] + q[0] + q[1] + q[2]);
     if (!js) { sqlite3_result_error_nomem(ctx); return; }
     sqlite3_result_text(ctx, js, -1, sqlite3_free);
@@ -107,8 +119,15 @@ static void fn_gpu_stats(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
     pthread_mutex_lock(&g_stage_mu);
     const long long os = ooc_stat_scans, orows = ooc_stat_rows;
     pthread_mutex_unlock(&g_stage_mu);
-    char *js = sqlite3_mprintf("{\"stage_passes\":%lld,\"parallel_reader_passes\":%lld,\"rows_staged\":%lld,\"seconds_staging\":%.6f,\"seconds_in_engine_append\":%.6f,\"seconds_count_star\":%.6f,\"seconds_hbm_reserve\":%.6f,\"out_of_core_scans\":%lld,\"out_of_core_rows\":%lld}",
-                               g.passes, g.parallel_passes, g.rows, g.seconds, g.append_seconds, g.count_seconds, g.reserve_seconds, os, orows);
+    long long sh_n = 0, sh_refs = 0, sh_att, sh_pub;
+    pthread_mutex_lock(&g_shared_mu);
+    for (shared_corpus *e = g_shared; e; e = e->next) { ++sh_n; sh_refs += e->refs; }
+    sh_att = g_shared_attached; sh_pub = g_shared_published;
+    pthread_mutex_unlock(&g_shared_mu);
+    char *js = sqlite3_mprintf("{\"stage_passes\":%lld,\"parallel_reader_passes\":%lld,\"rows_staged\":%lld,\"seconds_staging\":%.6f,\"seconds_in_engine_append\":%.6f,\"seconds_count_star\":%.6f,\"seconds_hbm_reserve\":%.6f,\"out_of_core_scans\":%lld,\"out_of_core_rows\":%lld,"
+                               "\"shared_copies\":%lld,\"shared_references\":%lld,\"shared_attachments\":%lld,\"shared_published\":%lld}",
+                               g.passes, g.parallel_passes, g.rows, g.seconds, g.append_seconds, g.count_seconds, g.reserve_seconds, os, orows,
+                               sh_n, sh_refs, sh_att, sh_pub);
     if (!js) { sqlite3_result_error_nomem(ctx); return; }
     sqlite3_result_text(ctx, js, -1, sqlite3_free);
 }
@@ -117,7 +136,9 @@ static void fn_gpu_stats(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
 __declspec(dllexport)
 #endif
 int sqlite3_vector_init(sqlite3 *db, char **pzErrMsg, const sqlite3_api_routines *pApi) {
-    SQLITE_EXTENSION_INIT2(pApi);
+    /* SQLITE_EXTENSION_INIT2 is a plain store to a process global; every load_extension() of every connection repeats it with the same
+     * routines table - connections opened from several threads at once would race on it with the calls that read it (TSan).  Stored once. */
+    if (__atomic_load_n(&sqlite3_api, __ATOMIC_ACQUIRE) == NULL) __atomic_store_n(&sqlite3_api, pApi, __ATOMIC_RELEASE);
     gpu_load();                                   /* best effort now; scans report the reason if it failed */
     int rc = sqlite3_exec(db, "CREATE TABLE IF NOT EXISTS _sqliteai_vector (tblname TEXT, colname TEXT, key TEXT, value ANY, PRIMARY KEY(tblname, colname, key));", NULL, NULL, NULL);
     if (rc != SQLITE_OK) return rc;

@@ -1304,3 +1304,120 @@ def test_out_of_core_tables_report_it_and_come_back_when_they_fit(ext_path, orc,
     assert db3.execute("SELECT rowid, distance FROM vector_full_scan('t','v',?,?)", (q.tobytes(), k)).fetchall() == want
     mem = json.loads(db3.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
     assert mem["column"]["staged"] == 1 and mem["column"]["out_of_core"] == 0
+
+
+# ------------------------------------------------------------------------------------------------ one staged copy per process
+@pytest.mark.gpu
+def test_connections_of_one_process_share_one_staged_copy(ext_path, orc, tmp_path):
+    """8 threads x 8 connections over one database file (vext_shared.inc): ONE copy of the column and ONE copy of the preloaded
+    quantization on the device, whatever connection asks; a commit moves every connection - at its next scan - to the copy of the new
+    file state; the last reference frees the memory.  WAL databases and connections inside a transaction keep copies of their own."""
+    import json
+    import threading
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    n, dim, k = 200_000, 64, 10
+    rows = dg.corpus(dg.F32, n, dim, 9300)
+    q = dg.query(dg.F32, dim, 9301)
+    path = str(tmp_path / "shared.db")
+    db = sqlite3.connect(path, isolation_level=None)
+    db.execute("CREATE TABLE t (id INTEGER PRIMARY KEY, v BLOB)")
+    db.execute("BEGIN")
+    db.executemany("INSERT INTO t(id, v) VALUES (?, ?)", [(i + 1, rows[i].tobytes()) for i in range(n)])
+    db.execute("COMMIT")
+    db.close()
+
+    def connect_file(p=path):
+        c = sqlite3.connect(p, isolation_level=None, check_same_thread=False, timeout=60)
+        c.enable_load_extension(True)
+        c.load_extension(ext_path)
+        c.execute("SELECT vector_init('t','v','type=FLOAT32,dimension=%d,distance=L2')" % dim)
+        return c
+
+    first = connect_file()
+    base = json.loads(first.execute("SELECT vector_gpu_stats()").fetchone()[0])
+    free0, _ = pkg.device_memory(0)
+    sql = "SELECT rowid, distance FROM vector_full_scan('t','v',?,?)"
+    want = first.execute(sql, (q.tobytes(), k)).fetchall()
+    d = orc.scan_distances(orc.AVX2, dg.L2, dg.F32, q, rows)
+    assert [w[0] for w in want] == orc.topk_ordered(d, None, k)[0].tolist()
+    first.execute("SELECT vector_quantize('t','v')")
+    first.execute("SELECT vector_quantize_preload('t','v')")
+    qsql = "SELECT rowid, distance FROM vector_quantize_scan('t','v',?,?)"
+    qwant = first.execute(qsql, (q.tobytes(), k)).fetchall()
+    free1, _ = pkg.device_memory(0)
+    conns, errors = [[] for _ in range(8)], []
+    barrier = threading.Barrier(8)
+
+    def worker(i):
+        try:
+            for _ in range(8):
+                conns[i].append(connect_file())
+            barrier.wait()
+            for c in conns[i]:
+                assert c.execute(sql, (q.tobytes(), k)).fetchall() == want
+                c.execute("SELECT vector_quantize_preload('t','v')")
+                assert c.execute(qsql, (q.tobytes(), k)).fetchall() == qwant
+            barrier.wait()
+            if i == 0:
+                conns[0][0].execute("INSERT INTO t(id, v) VALUES (?, ?)", (n + 1, q.tobytes()))      # a new best row, committed
+            barrier.wait()
+            for c in conns[i]:
+                got = c.execute(sql, (q.tobytes(), k)).fetchall()
+                assert got[0] == (n + 1, 0.0) and got[1:] == want[:k - 1]
+            barrier.wait()
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((i, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:                                    # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors[:3]
+    st = json.loads(first.execute("SELECT vector_gpu_stats()").fetchone()[0])
+    mem = json.loads(conns[5][2].execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
+    # `first` has not scanned since the write: it still holds the copy of the old file state (alone), the 64 others share the new one;
+    # the quantized records did not change with the INSERT into t - but the file did, so whoever scans them again moves on
+    assert mem["column"]["sharers"] == 64 and mem["column"]["staged"] == 1
+    assert st["shared_copies"] >= 2 and st["shared_references"] >= 64 + 64 + 1
+    # 2 x 64 first scans of the column + 64 preloads: each file state was staged once
+    assert st["stage_passes"] - base["stage_passes"] <= 6, (st, base)
+    free2, _ = pkg.device_memory(0)
+    table_bytes = n * dim * 4
+    assert free0 - free2 < 4 * table_bytes + (512 << 20), (free0, free1, free2)         # not 64 copies (3.3 GB): a few, plus working buffers
+    # a connection inside a transaction sees its own uncommitted rows: a copy of its own
+    c = conns[1][1]
+    c.execute("BEGIN")
+    c.execute("DELETE FROM t WHERE id=?", (n + 1,))
+    assert c.execute(sql, (q.tobytes(), k)).fetchall() == want
+    assert json.loads(c.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])["column"]["sharers"] == 0
+    assert conns[2][2].execute(sql, (q.tobytes(), k)).fetchall()[0] == (n + 1, 0.0)      # (the others: the committed state)
+    c.execute("ROLLBACK")
+    assert c.execute(sql, (q.tobytes(), k)).fetchall()[0] == (n + 1, 0.0)
+    assert json.loads(c.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])["column"]["sharers"] == 64
+    for cs in conns:
+        for cc in cs:
+            cc.close()
+    first.close()
+    fresh = connect_file()
+    assert json.loads(fresh.execute("SELECT vector_gpu_stats()").fetchone()[0])["shared_copies"] == 0
+    fresh.close()
+    # WAL: the change counter of the main file does not follow commits - every connection keeps its own copy
+    wal = str(tmp_path / "wal.db")
+    db = sqlite3.connect(wal, isolation_level=None)
+    db.execute("PRAGMA journal_mode=WAL")
+    db.execute("CREATE TABLE t (id INTEGER PRIMARY KEY, v BLOB)")
+    db.executemany("INSERT INTO t(id, v) VALUES (?, ?)", [(i + 1, rows[i].tobytes()) for i in range(3000)])
+    db.close()
+    a, b = connect_file(wal), connect_file(wal)
+    ra = a.execute(sql, (q.tobytes(), k)).fetchall()
+    assert b.execute(sql, (q.tobytes(), k)).fetchall() == ra
+    assert json.loads(b.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])["column"]["sharers"] == 0
+    a.execute("INSERT INTO t(id, v) VALUES (99999, ?)", (q.tobytes(),))
+    assert b.execute(sql, (q.tobytes(), k)).fetchall()[0] == (99999, 0.0)
+    a.close(); b.close()

@@ -81,4 +81,51 @@ want = d2.execute("SELECT rowid, distance FROM vector_full_scan('t', 'v', ?, 6)"
 d2.close()
 assert sorted(got[:4]) == sorted(want[:4]) and got[0][1] == 0.0 and int(ids[1234]) not in [g[0] for g in got], (got, want)
 print("tracked changes: rows re-sent to the engine", s1 - s0, got[:4])
+# one staged copy per process (vext_shared.inc): 8 threads x 8 connections over one database file take references to ONE copy; a commit
+# from one of them moves everybody (lazily, at their next scan) to the copy of the new file state, and the old one is freed with its last
+# reference.  Every thread scans while the others attach / detach: the registry, the per-copy scan mutex and the statistics under TSan.
+import threading
+os.environ["VECTORGPU_STAGE_THREADS"] = "4"
+base = json.loads(connect().execute("SELECT vector_gpu_stats()").fetchone()[0])
+conns, errors = [[] for _ in range(8)], []
+barrier = threading.Barrier(8)
+def worker(i):
+    try:
+        for _ in range(8):
+            c = sqlite3.connect(path, isolation_level=None, check_same_thread=False, timeout=60)
+            c.enable_load_extension(True)
+            c.load_extension(ext)
+            c.execute("SELECT vector_init('t', 'v', 'type=FLOAT32,dimension=%d,distance=L2')" % dim)
+            conns[i].append(c)
+        barrier.wait()
+        for c in conns[i]:
+            assert c.execute(sql, (q.tobytes(),)).fetchall() == want[:k], "shared scan"
+        barrier.wait()
+        if i == 0:                                        # one writer: a new best row
+            conns[0][0].execute("INSERT INTO t(id, v) VALUES (?, ?)", (int(ids[-1]) + 500, q.tobytes()))
+        barrier.wait()
+        for c in conns[i]:
+            got = c.execute(sql, (q.tobytes(),)).fetchall()
+            assert got[0][1] == 0.0 and int(ids[-1]) + 500 in [g[0] for g in got], ("after the write", got)
+        barrier.wait()
+    except Exception as e:                                # noqa
+        errors.append((i, repr(e)))
+        try: barrier.abort()
+        except Exception: pass
+want = connect().execute(sql, (q.tobytes(),)).fetchall()
+th = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+[t.start() for t in th]; [t.join() for t in th]
+assert not errors, errors
+st = json.loads(conns[0][0].execute("SELECT vector_gpu_stats()").fetchone()[0])
+mem = json.loads(conns[3][5].execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
+print("shared copies", st["shared_copies"], "references", st["shared_references"], "sharers seen by one connection", mem["column"]["sharers"],
+      "stage passes for 2 x 64 first scans", st["stage_passes"] - base["stage_passes"])
+assert st["shared_copies"] == 1 and st["shared_references"] == 64 and mem["column"]["sharers"] == 64
+assert st["stage_passes"] - base["stage_passes"] <= 4       # (the copy of each file state is staged once, not 64 times)
+for cs in conns:
+    for c in cs: c.close()
+d = connect()
+assert json.loads(d.execute("SELECT vector_gpu_stats()").fetchone()[0])["shared_copies"] == 0      # the last reference freed it
+d.execute("DELETE FROM t WHERE id = ?", (int(ids[-1]) + 500,))
+d.close()
 print("asan run done (staging)")
