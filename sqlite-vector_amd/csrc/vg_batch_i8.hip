@@ -57,6 +57,9 @@ typedef int vgi_i32x4 __attribute__((ext_vector_type(4)));
 
 enum { VGI_DOT = 0, VGI_COS = 1, VGI_L2 = 2 };
 
+#ifndef VGI_ABLATE
+#define VGI_ABLATE 0                    // measurement builds of the pipelined schedule (tools/build_i8_variants.sh ab1 -DVGI_ABLATE=1; WRONG results):
+#endif                                  //   1 no slow path  2 + no fast test  3 + no DMA (tiles go stale)  4 + no barrier: MFMAs + B reads only
 #ifndef VGI_TIMING
 #define VGI_TIMING 0                    // measurement builds (tools/tools_i8_timing.py, tools/build_i8_variants.sh timing -DVGI_TIMING=1)
 #endif
@@ -500,7 +503,8 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
                     vgi_wait_lds<BP - 1>(bq[t % BP]);
                     cur = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[t], bq[t % BP], cur, 0, 0, 0);
                     if constexpr (t == M) {
-                        const bool any = judge_any(jm_i, jm_f, pcx, pxx) && prev_valid;
+                        const bool any = VGI_ABLATE >= 1 ? false : (judge_any(jm_i, jm_f, pcx, pxx) && prev_valid);
+                        if (VGI_ABLATE >= 2) asm volatile("" :: "v"(prev));        // (the accumulators stay alive without their test)
                         VGI_TICK(ts0);
                         // this tile's row sums for the next step; then every LDS read in flight has returned (the slow path may
                         // move registers around), my DMA pieces of tile t+1 have landed, barrier
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(car));
                         vgb_static_for<0, BP>([&](auto bc) { vgi_wait_lds<0>(bq[decltype(bc)::value]); });
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __syncthreads();
+                        if (VGI_ABLATE < 4) __syncthreads();
                         VGI_TICK(ts1);
                         if (any) judge_slow(prev, tile - 1, psx, pxx);
 #if VGI_TIMING
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
                     }
                     if constexpr (t + BP < NTB) vgi_lds_read128<1024 * (t + BP)>(bq[t % BP], base_cur);
                     else vgi_lds_read128<1024 * (t + BP - NTB)>(bq[t % BP], base_next);
-                    if constexpr (t >= 1 && t < M) {
+                    if constexpr (VGI_ABLATE < 2 && t >= 1 && t < M) {
                         vgb_static_for<0, 8>([&](auto ic) {
                             if constexpr (1 + decltype(ic)::value * (M - 1) / 8 == t) {
                                 judge_item(ic, prev, pcx, jm_i, jm_f);
@@ -528,9 +532,9 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
                             }
                         });
                     }
-                    if constexpr (t == M + 1) { if (grp == 0) dma_tile(tile_dma, bdma); }
-                    if constexpr (t == M + 1 + (NTB - M - 1) / 2) { if (grp == 1 && NISSUE == WAVES) dma_tile(tile_dma, bdma); }
-                    if constexpr (t == NTB - 1) { if (stat_turn) dma_stat_group(tile + 2, ((ti + 2) >> 2) & 1); }
+                    if constexpr (VGI_ABLATE < 3 && t == M + 1) { if (grp == 0) dma_tile(tile_dma, bdma); }
+                    if constexpr (VGI_ABLATE < 3 && t == M + 1 + (NTB - M - 1) / 2) { if (grp == 1 && NISSUE == WAVES) dma_tile(tile_dma, bdma); }
+                    if constexpr (VGI_ABLATE < 3 && t == NTB - 1) { if (stat_turn) dma_stat_group(tile + 2, ((ti + 2) >> 2) & 1); }
                     __builtin_amdgcn_sched_barrier(0);
                 });
 #if VGI_TIMING
@@ -544,7 +548,8 @@ __global__ __launch_bounds__(64 * VGI_WAVES_OF(NTB), 1) void vg_batch_i8_kernel(
             }
             // the last tile: nothing left to hide its test under (`car` holds its row sums since its own mid-step)
             vgb_static_for<0, BP>([&](auto bc) { vgi_wait_lds<0>(bq[decltype(bc)::value]); });
-            if (T & 1) judge_all(accA, tile_last - 1, car);
+            if (VGI_ABLATE >= 1) { asm volatile("" :: "v"(accA)); asm volatile("" :: "v"(accB)); }
+            else if (T & 1) judge_all(accA, tile_last - 1, car);
             else judge_all(accB, tile_last - 1, car);
 #if VGI_TIMING
             if (!PRE && lane == 0) {
