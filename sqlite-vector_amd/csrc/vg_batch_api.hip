@@ -320,15 +320,16 @@ extern "C" size_t vg_batch_q8_work_bytes(int nq_pad, long long q8stride_bytes, l
 extern "C" size_t vg_batch_q8_work_stat_offset(int nq_pad, long long q8stride_bytes, long long xstride_bytes);
 extern "C" size_t vg_batch_q8_work_perm_offset(int nq_pad, long long q8stride_bytes, long long xstride_bytes);
 extern "C" int vg_batch_q8_max_queries(void);
-extern "C" int vg_q8_rstat_launch(const void *dev_q8stat, const float *dev_xnorm, long long row0, long long n, void *dev_out, hipStream_t stream);
+extern "C" int vg_q8_rstat_launch(const void *dev_q8stat, const float *dev_xnorm, long long row0, long long n, void *dev_out, int nn_squared, hipStream_t stream);
 extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rstat, long long n_rows, long long q8stride, int dim,
                                   const uint8_t *dev_xrows, long long xstride, const float *dev_xnorm,
                                   const uint8_t *dev_xqueries, void *dev_qwork, int nq_pad, int nq_real, int k, int mode, int root,
                                   uint64_t *dev_cand, int npart, uint64_t *dev_out_keys, unsigned long long *dev_evals,
-                                  uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, hipStream_t stream);
+                                  uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, int type_code, hipStream_t stream);
 static long long q8_shadow_stride_of(const vg_corpus *c) { return (((long long)c->dim + 15) / 16) * 16; }
 static bool batch_q8_eligible(const vg_corpus *c, int metric, int k, int nq) {
-    if (vg_sw(SW_VG_BATCH_MFMA, 1) == 0 || c->vtype != VG_TYPE_F32 || metric == VG_DIST_L1 || c->q8tm_disabled || c->filter_disabled) return false;
+    const bool served_type = c->vtype == VG_TYPE_F32 || c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16;   // (the int8 image of the row, whatever it is stored as)
+    if (vg_sw(SW_VG_BATCH_MFMA, 1) == 0 || !served_type || metric == VG_DIST_L1 || c->q8tm_disabled || c->filter_disabled) return false;
     const int sw = vg_sw(SW_VG_BATCH_Q8, -1);
     if (sw == 0 || c->n_rows < (sw == 1 ? (1ll << 16) : (1ll << 20))) return false;     // (forced: from 2048 tiles on - the tests' sizes)
     if (sw < 0 && (nq <= 256 || !vg_scan_filter_policy(c))) return false;             // (its own overflow guard: bq8_cooldown; the bf16 filter's does not apply)
@@ -363,7 +364,7 @@ static int ensure_q8_tile_major(vg_corpus *c) {
     if (c->q8tm_rows < c->n_rows) {
         const long long n = c->n_rows - c->q8tm_rows;
         rc = vg_tile_major_launch(c->d_rows_q8, c->q8tm_rows, n, qs, c->d_rows_q8tm, c->stream);
-        if (rc == 0) rc = vg_q8_rstat_launch(c->d_q8stat, c->d_xnorm, c->q8tm_rows, n, c->d_q8tm_stat, c->stream);
+        if (rc == 0) rc = vg_q8_rstat_launch(c->d_q8stat, c->d_xnorm, c->q8tm_rows, n, c->d_q8tm_stat, c->vtype == VG_TYPE_F32 ? 0 : 1, c->stream);
         if (rc != 0) return vg_fail(VG_ERR_HIP, "tile-major int8 pass failed: %s", hipGetErrorString((hipError_t)rc));
         c->q8tm_rows = c->n_rows;
     }
@@ -425,7 +426,8 @@ static int scan_topk_batch_q8(vg_corpus *c, int metric, const void *queries, int
     uint8_t *qwork = (uint8_t *)c->d_bq + qrows;
     const int rc = vg_batch_q8_launch(c->d_rows_q8tm, c->d_q8tm_stat, c->n_rows, qs, c->dim, c->d_rows, c->stride, c->d_xnorm,
                                       (const uint8_t *)c->d_bq, qwork, nq_pad, nq, k, mode, root, c->d_bcand, npart, c->d_bkeys,
-                                      c->d_filter_evals + 1, c->d_bpairs, c->d_bpcounts, VG_BPAIR_CAP, c->stream);
+                                      c->d_filter_evals + 1, c->d_bpairs, c->d_bpcounts, VG_BPAIR_CAP,
+                                      c->vtype == VG_TYPE_F32 ? 2 : (c->vtype == VG_TYPE_BF16 ? 1 : 0), c->stream);
     if (evs) { hipEventRecord(evs[2], c->stream); hipEventRecord(evs[3], c->stream); }
     if (rc == -1) { hipStreamSynchronize(c->stream); c->bq8_status = 2; return -1; }
     if (rc != 0) return vg_fail(VG_ERR_HIP, "batched scan launch (int8 filter) failed: %s", hipGetErrorString((hipError_t)rc));

@@ -97,17 +97,23 @@ __device__ __forceinline__ int vgq_q8(float v, float inv) {                 // (
 // scale sq = max|q| / 127 (threshold / sq ~ z |q| / sq).  L2: the gate holds |x|^2 / sq and (thr^2 - |q|^2) / sq - two query-dependent
 // factors - so L2 batches share ONE scale (vg_q8_rank_kernel; a query whose own scale is larger, or 8 x smaller, is not judged) and sort by |q|.
 // keys_out != NULL: only the sort key and the own scale of every query (original order) are written.
+// (qtype: the element type of the queries = the corpus' own: 0 f16, 1 bf16, 2 f32 - the int8 image is taken of the widened value)
 __global__ __launch_bounds__(256) void vg_q8_query_prep_kernel(const uint8_t *xq, long long xstride, int dim, int nq_real, int nq_pad, int mode,
                                                                const int *perm, const float *common_scale, float *keys_out, float *scales_out,
-                                                               uint8_t *xq_sorted, uint8_t *codes, long long qstride, float4 *qstat) {
+                                                               uint8_t *xq_sorted, uint8_t *codes, long long qstride, float4 *qstat, int qtype) {
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (p >= nq_pad) return;
     const int q = perm ? perm[p] : p;
-    const float *src = reinterpret_cast<const float *>(xq + (long long)q * xstride);
+    const uint8_t *srcb = xq + (long long)q * xstride;
+    auto elem = [&](int e) -> float {
+        if (qtype == 2) return reinterpret_cast<const float *>(srcb)[e];
+        const uint32_t b = reinterpret_cast<const uint16_t *>(srcb)[e];
+        return qtype == 0 ? vg_h2f(b) : vg_b2f(b);
+    };
     float mx = 0.0f;
     uint32_t bad = 0;
-    for (int e = lane; e < dim; e += 64) { const float f = src[e]; mx = fmaxf(mx, fabsf(f)); bad |= !(fabsf(f) <= 3.0e38f) ? 1u : 0u; }
+    for (int e = lane; e < dim; e += 64) { const float f = elem(e); mx = fmaxf(mx, fabsf(f)); bad |= !(fabsf(f) <= 3.0e38f) ? 1u : 0u; }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
     bool ok = q < nq_real && __ballot(bad != 0) == 0ull && mx >= VGQ_JUDGE_LO && mx <= VGQ_JUDGE_HI;
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256) void vg_q8_query_prep_kernel(const uint8_t *xq
     uint32_t i2 = 0;
     float e2s = 0.0f, q2s = 0.0f;
     for (int e = lane; e < (int)qstride; e += 64) {
-        const float f = (ok && e < dim) ? src[e] : 0.0f;
+        const float f = (ok && e < dim) ? elem(e) : 0.0f;
         const int qi = vgq_q8(f, inv);
         const float r = fmaf(-sq, (float)qi, f);                          // one rounding
         i2 += (uint32_t)(qi * qi);
@@ -188,10 +194,11 @@ __global__ __launch_bounds__(1024) void vg_q8_rank_kernel(const float *keys, con
 }
 
 // ---- per-row statistics in the layout the filter's LDS-DMA moves (16 bytes per row)
-__global__ __launch_bounds__(256) void vg_q8_rstat_kernel(const float2 *q8stat, const float *xnorm, long long row0, long long n, float4 *out) {
+// (nn_squared: f16 / bf16 corpora cache (float) sum x^2 per row, f32 corpora ||x|| itself)
+__global__ __launch_bounds__(256) void vg_q8_rstat_kernel(const float2 *q8stat, const float *xnorm, long long row0, long long n, float4 *out, int nn_squared) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float2 s = q8stat[row0 + i];
-        const float nrm = xnorm[row0 + i];
+        const float nrm = nn_squared ? sqrtf(xnorm[row0 + i]) : xnorm[row0 + i];
         const bool zero = (nrm == 0.0f) && (s.x == 0.0f) && (s.y == 0.0f);                              // every element is +-0
         const bool judged = zero || ((nrm >= VGQ_JUDGE_LO && nrm <= VGQ_JUDGE_HI) && (s.x > 0.0f && s.x <= 3.0e38f));   // (sx = NaN: Inf / NaN elements)
         // a row that is never judged reads as "every gate open" without a test of its own: a huge residual norm drives the integer
@@ -602,6 +609,8 @@ static size_t vgq_lds_bytes(int NTB) {
 }
 
 extern "C" int vgh_launch_exact_f32(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream);   // vg_batch_h.hip (-DVGH_TU=8)
+extern "C" int vgh_launch_exact_f16(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream);   // (-DVGH_TU=6)
+extern "C" int vgh_launch_exact_bf16(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream);  // (-DVGH_TU=7)
 extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
                                      uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
 
@@ -625,12 +634,12 @@ extern "C" size_t vg_batch_q8_work_perm_offset(int nq_pad, long long q8stride_by
     return vg_batch_q8_work_stat_offset(nq_pad, q8stride_bytes, xstride_bytes) + (size_t)nq_pad * 2 * sizeof(float4) + (size_t)nq_pad * 8;
 }
 
-extern "C" int vg_q8_rstat_launch(const void *dev_q8stat, const float *dev_xnorm, long long row0, long long n, void *dev_out, hipStream_t stream) {
+extern "C" int vg_q8_rstat_launch(const void *dev_q8stat, const float *dev_xnorm, long long row0, long long n, void *dev_out, int nn_squared, hipStream_t stream) {
     if (n <= 0) return 0;
     long long blocks = (n + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(vg_q8_rstat_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const float2 *>(dev_q8stat), dev_xnorm, row0, n,
-                       reinterpret_cast<float4 *>(dev_out));
+                       reinterpret_cast<float4 *>(dev_out), nn_squared);
     return (int)hipGetLastError();
 }
 
@@ -645,8 +654,9 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
                                   const uint8_t *dev_xrows, long long xstride, const float *dev_xnorm,
                                   const uint8_t *dev_xqueries, void *dev_qwork, int nq_pad, int nq_real, int k, int mode, int root,
                                   uint64_t *dev_cand, int npart, uint64_t *dev_out_keys, unsigned long long *dev_evals,
-                                  uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, hipStream_t stream) {
+                                  uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, int type_code, hipStream_t stream) {
     const int ntb = vgq_ntb(q8stride);
+    if (type_code < 0 || type_code > 2) return -1;
     if (!ntb || !vg_batch_q8_serves(q8stride, xstride, k) || nq_pad % VGQ_QPB != 0 || nq_pad > vg_batch_q8_max_queries() || npart < 8 || npart % 8 != 0 ||
         npart > VG_SEL_MAX_HEADS) return -1;
     if (mode < VGH_DOT || mode > VGH_L2 || !dev_xnorm || !dev_pairs || !dev_pair_counts || pair_cap < 32 * 32) return -1;
@@ -661,16 +671,17 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     float *common = reinterpret_cast<float *>(perm + nq_pad);
     const dim3 pg((unsigned)((nq_pad + 3) / 4));
     hipLaunchKernelGGL(vg_q8_query_prep_kernel, pg, dim3(256), 0, stream, dev_xqueries, xstride, dim, nq_real, nq_pad, mode, (const int *)nullptr,
-                       (const float *)nullptr, qkeys, qscales, (uint8_t *)nullptr, (uint8_t *)nullptr, q8stride, (float4 *)nullptr);
+                       (const float *)nullptr, qkeys, qscales, (uint8_t *)nullptr, (uint8_t *)nullptr, q8stride, (float4 *)nullptr, type_code);
     hipLaunchKernelGGL(vg_q8_rank_kernel, dim3(1), dim3(1024), (size_t)nq_pad * 4, stream, (const float *)qkeys, (const float *)qscales, nq_pad, perm, common);
     hipLaunchKernelGGL(vg_q8_query_prep_kernel, pg, dim3(256), 0, stream, dev_xqueries, xstride, dim, nq_real, nq_pad, mode, (const int *)perm,
-                       (const float *)common, (float *)nullptr, (float *)nullptr, xq_sorted, qcodes, q8stride, qstat);
+                       (const float *)common, (float *)nullptr, (float *)nullptr, xq_sorted, qcodes, q8stride, qstat, type_code);
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
     const int G = nq_pad / VGQ_QPB;
     const int flag_index = vg_batch_q8_regions(nq_pad, npart);
     const int hx_waves = VGQ_WAVES * VGQ_QS;
-    const int xntb = (int)((((long long)dim * 2 + 15) / 16 * 16 + 31) / 32);      // k-steps of the bf16 image: what picks the exact kernel's chunks per lane
+    // k-steps of the exact kernel's shape: an f32 corpus is described by its bf16 image (what picks the chunks per lane), f16 / bf16 by themselves
+    const int xntb = type_code == 2 ? (int)((((long long)dim * 2 + 15) / 16 * 16 + 31) / 32) : (int)((xstride + 31) / 32);
     const size_t smem_exact = (size_t)VGH_QPW * (8 + 4 + 4 + 4) + (size_t)VGH_QPW * k * 8 + (size_t)pair_cap * 8;      // (+ the region's pairs)
     if ((rc = (int)hipMemsetAsync(dev_pair_counts + flag_index, 0, sizeof(uint32_t), stream)) != 0) return rc;
 
@@ -721,7 +732,10 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
         else if (ntb == 12) rc = launch_q8_mode<12>(a, blocks, smem, stream);
         else rc = launch_q8_mode<16>(a, blocks, smem, stream);
         if (rc != 0) return rc;
-        if ((rc = vgh_launch_exact_f32(&hx, xntb, hx_waves, hx.n_regions, smem_exact, stream)) != 0) return rc;
+        rc = type_code == 2 ? vgh_launch_exact_f32(&hx, xntb, hx_waves, hx.n_regions, smem_exact, stream)
+                            : (type_code == 1 ? vgh_launch_exact_bf16(&hx, xntb, hx_waves, hx.n_regions, smem_exact, stream)
+                                              : vgh_launch_exact_f16(&hx, xntb, hx_waves, hx.n_regions, smem_exact, stream));
+        if (rc != 0) return rc;
         if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, np, np, k, dev_out_keys, stream)) != 0) return rc;
     }
     return 0;

@@ -167,3 +167,40 @@ def test_int8_filter_after_patched_and_deleted_rows(pkg, monkeypatch):
     ids3, dist3, cnt3 = f.scan_topk_batch(dg.L2, qs, k)
     assert dg.same_float_bits(dist2, dist3)
     c.close(); f.close()
+
+
+@pytest.mark.parametrize("vt", (dg.F16, dg.BF16))
+@pytest.mark.parametrize("dim", (100, 384))
+def test_int8_filter_batch_over_half_precision_corpora(pkg, orc, vt, dim, monkeypatch):
+    """f16 / bf16 corpora through the same int8 filter (the image is taken of the widened elements; the pairs that pass carry the single
+    scan's arithmetic for the type, vg_batch_hx_kernel): rowids, distance bits and counts of the type's own matrix-core filter path."""
+    rng = np.random.default_rng(7400 + dim + vt)
+    n, nq, k = 90_001, 300, 20
+    rows32 = rng.standard_normal((n, dim), dtype=np.float32)
+    qs32 = rng.standard_normal((nq, dim), dtype=np.float32)
+    qs32[5] = 0.0
+    qs32[7] *= np.float32(300.0)
+    qs32[9, 0] = np.float32(50.0)
+    rows32 = _adversarial(rows32, qs32, rng)
+    rows32[6005] = rng.standard_normal(dim).astype(np.float32) * np.float32(6e4 if vt == dg.F16 else 1e12)      # (f16: the largest norms it can hold)
+    rows32[6004] = rng.standard_normal(dim).astype(np.float32) * np.float32(1e-4 if vt == dg.F16 else 1e-12)
+    rows, qs = dg.to_storage(vt, rows32), dg.to_storage(vt, qs32)
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    for metric in (dg.DOT, dg.COSINE, dg.L2):
+        monkeypatch.setenv("VG_BATCH_Q8", "1")
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        assert c.last_batch_path() == 7, (vt, dim, metric, c.last_batch_path(), c.batch_q8_status())
+        monkeypatch.setenv("VG_BATCH_Q8", "0")
+        ids0, dist0, cnt0 = c.scan_topk_batch(metric, qs, k)
+        assert c.last_batch_path() == 3
+        assert np.array_equal(cnt, cnt0), (vt, dim, metric)
+        for i in range(nq):
+            m = cnt[i]
+            assert ids[i][:m].tolist() == ids0[i][:m].tolist() and dg.same_float_bits(dist[i][:m], dist0[i][:m]), (vt, dim, metric, i)
+        # ... which is the single scan's answer
+        for i in (0, 3, 9, 40):
+            one_ids, one_d = c.scan_topk(metric, qs[i], k)
+            assert ids[i][:cnt[i]].tolist() == one_ids.tolist() and dg.same_float_bits(dist[i][:cnt[i]], one_d), (vt, dim, metric, i)
+    monkeypatch.delenv("VG_BATCH_Q8")
+    c.close()
