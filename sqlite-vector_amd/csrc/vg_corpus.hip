@@ -289,6 +289,26 @@ static int corpus_reserve(vg_corpus *c, int64_t need_rows) {
     return VG_OK;
 }
 
+// Give back what a too-generous reservation holds beyond the rows that arrived (the extension reserves from a cheap UPPER bound of the
+// table's row count - the key span - which sparse keys can put several times above the count; the per-row copies derived later - norms,
+// shadow and tile-major copies - are sized by cap_rows too, so the excess would multiply: ADVICE r4).  A no-op within 25 % + 1024 rows.
+extern "C" int vg_corpus_trim(vg_corpus *c) {
+    if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
+    const int64_t keep = std::max<int64_t>(c->n_rows, 1024);
+    if (!c->d_rows || c->cap_rows <= keep + keep / 4 + 1024) return VG_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    uint8_t *nb = nullptr;
+    if (hipMalloc(&nb, (size_t)(keep * c->stride)) != hipSuccess) { (void)hipGetLastError(); return VG_OK; }   // (no room for the smaller copy: keep the large one)
+    hipError_t e = hipSuccess;
+    if (c->n_rows > 0) e = hipMemcpyAsync(nb, c->d_rows, (size_t)(c->n_rows * c->stride), hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { hipFree(nb); return vg_fail(VG_ERR_HIP, "corpus trim copy failed: %s", hipGetErrorString(e)); }
+    hipFree(c->d_rows);
+    c->d_rows = nb;
+    c->cap_rows = keep;
+    return VG_OK;
+}
+
 extern "C" int vg_corpus_reserve(vg_corpus *c, int64_t capacity_rows) {
     if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
     HIP_TRY(hipSetDevice(c->device));

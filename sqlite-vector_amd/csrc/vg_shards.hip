@@ -360,6 +360,16 @@ extern "C" int vg_shards_reserve(vg_shards *s, int64_t total_rows) {
     return VG_OK;
 }
 
+extern "C" int vg_corpus_trim(vg_corpus *c);
+extern "C" int vg_shards_trim(vg_shards *s) {
+    if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
+    for (int i = 0; i < s->S; ++i) {
+        int rc = vg_corpus_trim(s->sh[(size_t)i]);
+        if (rc != VG_OK) return rc;
+    }
+    return VG_OK;
+}
+
 extern "C" int vg_shards_set_rowid_base(vg_shards *s, int64_t base) {
     if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");
     s->rowid_base = base;

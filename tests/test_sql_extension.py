@@ -1421,3 +1421,30 @@ def test_connections_of_one_process_share_one_staged_copy(ext_path, orc, tmp_pat
     a.execute("INSERT INTO t(id, v) VALUES (99999, ?)", (q.tobytes(),))
     assert b.execute(sql, (q.tobytes(), k)).fetchall()[0] == (99999, 0.0)
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_sparse_keys_do_not_leave_an_oversized_reservation(ext_path, tmp_path):
+    """the staging pass reserves device memory from the key span (two B-tree descents instead of a COUNT(*) walk); with sparse keys in a
+    file that holds other tables too the span is several times the row count - the excess is handed back once the rows have arrived
+    (vg_corpus_trim), before the per-row copies sized by the reservation are made"""
+    import json
+    n, dim = 20_000, 64
+    rows = dg.corpus(dg.F32, n, dim, 9500)
+    db = sqlite3.connect(str(tmp_path / "sparse.db"), isolation_level=None)
+    db.enable_load_extension(True)
+    db.load_extension(ext_path)
+    db.execute("CREATE TABLE filler (x BLOB)")
+    db.execute("BEGIN")
+    db.executemany("INSERT INTO filler VALUES (?)", [(b"\0" * 4000,) for _ in range(6000)])          # 24 MB of other pages
+    db.execute("COMMIT")
+    load_table(db, rows, dg.F32, dg.L2, rowids=[7 * i + 3 for i in range(n)])                       # span = 7 n
+    q = rows[11]
+    got = db.execute("SELECT rowid, distance FROM vector_full_scan('t','v',?,5)", (q.tobytes(),)).fetchall()
+    assert got[0] == (7 * 11 + 3, 0.0)
+    mem = json.loads(db.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
+    assert n * dim * 4 <= mem["column"]["rows_bytes"] <= int(1.3 * n * dim * 4) + 1024 * dim * 4, mem
+    db.execute("INSERT INTO t(id, v) VALUES (?, ?)", (7 * n + 100, q.tobytes()))                     # appends still extend the copy
+    got = db.execute("SELECT rowid FROM vector_full_scan('t','v',?,2)", (q.tobytes(),)).fetchall()
+    assert sorted(g[0] for g in got) == [7 * 11 + 3, 7 * n + 100]
+    db.close()

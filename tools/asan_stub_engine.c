@@ -148,3 +148,5 @@ int vg_slab_scan_finish(vg_slab_scan *s, int64_t *ids, double *d, int *n) { (voi
 int vg_slab_scan_all(vg_slab_scan *s, int64_t *n, const float **d, const int64_t **ids) { (void)s; (void)n; (void)d; (void)ids; return fail("stub engine: no out-of-core scans"); }
 void vg_slab_scan_destroy(vg_slab_scan *s) { (void)s; }
 int vg_device_memory(int device, long long *free_bytes, long long *total_bytes) { (void)device; *free_bytes = 1ll << 40; *total_bytes = 1ll << 40; return 0; }
+
+int vg_shards_trim(vg_shards *s) { (void)s; return 0; }
