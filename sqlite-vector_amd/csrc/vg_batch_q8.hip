@@ -93,7 +93,7 @@ __device__ __forceinline__ int vgq_q8(float v, float inv) {                 // (
 // ---- the queries' int8 images and statistics, one wavefront per query SLOT.  Slot p holds query perm[p] (perm == NULL: p): the batch is
 // SORTED by what a query's gate on the integer score is proportional to, so that the 32 queries of a set share nearly the same gate and one
 // integer comparison of the lane's largest accumulator against the set's loosest gate is tight (unsorted, with the wavefront's largest
-// coefficients: 64 % of the tiles went on to single pairs; profiles/r9b).  dot / cosine: the norm of the int8 image under the query's OWN
+// coefficients: 64 % of the tiles went on to single pairs; docs/ROUND5_NOTEBOOK.md §2).  dot / cosine: the norm of the int8 image under the query's OWN
 // scale sq = max|q| / 127 (threshold / sq ~ z |q| / sq).  L2: the gate holds |x|^2 / sq and (thr^2 - |q|^2) / sq - two query-dependent
 // factors - so L2 batches share ONE scale (vg_q8_rank_kernel; a query whose own scale is larger, or 8 x smaller, is not judged) and sort by |q|.
 // keys_out != NULL: only the sort key and the own scale of every query (original order) are written.
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
     // Pairs are collected in LDS (64 per set and wavefront) and go out 64 at a time: a store issued in the middle of the streaming loop
     // sits in the same in-order queue as the LDS-DMA pieces, and the tile-end wait "at most N outstanding" then waits for IT - a
     // ~2 us write acknowledgement - before it can count the pieces behind it as landed (one store per passing pair: 6.7 ms per batch
-    // against 2.8 ms with the stores compiled out, profiles/r9e).
+    // against 2.8 ms with the stores compiled out, docs/ROUND5_NOTEBOOK.md §2).
     uint64_t *pbuf0 = pbuf_lds + wave * 128, *pbuf1 = pbuf0 + 64;
     unsigned n_buf0 = 0, n_buf1 = 0;                                  // (wave-uniform)
     auto flush = [&](uint64_t *buf, unsigned &n_buf, uint64_t *region, unsigned &n_pairs) __attribute__((always_inline)) {
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
     // ---- the candidate queue.  A lane whose largest accumulator passes the first test is a CANDIDATE LANE: one row, 32 queries.  Looking at
     // its 32 accumulators on the spot - which registers, then the query's own coefficients for each - was ~200 instructions and several
     // LDS round trips of the whole wavefront for, on average, 1.3 such lanes (a quarter of all tiles: + 50 % on the streaming loop,
-    // profiles/r9f).  Instead the lane parks its accumulators, its row's statistics and its two thresholds in LDS (ten 16-byte writes)
+    // docs/ROUND5_NOTEBOOK.md §2).  Instead the lane parks its accumulators, its row's statistics and its two thresholds in LDS (ten 16-byte writes)
     // and the loop goes on; every VGQ_QCAP entries the wavefront looks at them together - lane (e, o) takes registers 8 o .. 8 o + 7 of
     // entry e, all 64 lanes busy, eight steps - and the pairs that pass go to the pair buffers, entries ascending: a query's rows stay
     // in scan order.
