@@ -23,8 +23,9 @@ The same run appends (N = 1, default workload only; --no-also skips them, --also
   also.c5      1024 queries x 10M x 384 f32 dot top-20 (configs[4]): own roofline (7.864 TFLOP per launch against the
                157.3 TF f32 MFMA peak, the f32 matrix-core kernel) and cpu_baseline; filter_batch (the product's default for a
                corpus of this size: bf16 matrix-core filter + exact f32 re-evaluation, priced on the bf16 peak)
-  also.long_rows       1024 queries x 10M x 1536 f32 dot top-20 (not a BASELINE config): the K-split matrix-core kernel for rows of
-               1025 .. 3072 elements, priced on the bf16 peak, with `against_single_scans` (what such batches were before)
+  also.long_rows       1024 queries x 10M x 1536 f32 dot top-20 (not a BASELINE config): the default path for such rows (int8 matrix-core
+               filter, a tile's K in three ring parts; priced on the int8 peak) with `against_single_scans` (what such batches were
+               before) and `bf16_ksplit_batch` (round 4's K-split bf16 kernel, the same batches, bit-identical answers)
   also.kernel_matrix   f16 / bf16 / int8 x L2 / cosine at 10M x 384 through their PLAIN kernels: frac of the HBM peak each
   also.c4_one_gpu      north_star's target sentence: 100M x 384 f32 L2 resident on ONE device, the plain kernel
 
@@ -75,7 +76,7 @@ WORKLOADS = {
     "c5q": (1, np.float32, 384, 4, "batched 1024 queries x 10Mx384 f32 dot top-20 (int8 MFMA filter over the int8 shadow copy + exact f32 re-evaluation)"),
     # long rows (not a BASELINE config): 1536-dimensional f32 embeddings - the K dimension split over the wavefronts of
     # a workgroup (vg_batch_hl.hip), bf16 shadow copy on the matrix cores, exact f32 re-evaluation; reported next to one scan per query
-    "c5l": (1, np.float32, 1536, 4, "batched 1024 queries x 10Mx1536 f32 dot top-20 (K-split bf16 MFMA filter over a shadow copy + exact f32 re-evaluation)"),
+    "c5l": (1, np.float32, 1536, 4, "batched 1024 queries x 10Mx1536 f32 dot top-20 (default path: int8 MFMA filter, a tile's K in three ring parts + exact f32 re-evaluation; VG_BATCH_Q8=0: the K-split bf16 MFMA filter)"),
 }
 F16_MFMA_PEAK_TF = 2500.0      # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
@@ -331,7 +332,9 @@ def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc
                              ("; peak = the bf16 MFMA rate the filter runs at" if filt else "") +
                              ("; query images + staged filter / exact-evaluation / merge launches of one batch; peak = the int8 MFMA rate the filter runs at" if q8 else ""),
                      "batch_path": corpus.last_batch_path()}}
-    if workload == "c5l":
+    if workload == "c5l" and q8:
+        line["roofline"]["kernel"] = "vg_batch_q8_kernel<16 k-steps x %d K-parts, 8 wavefronts x 32 queries> + vg_batch_hx_kernel" % (((dim + 31) // 32 + 15) // 16)
+    elif workload == "c5l":
         line["roofline"]["kernel"] = "vg_batch_hl_kernel<%d k-steps per wavefront> + vg_batch_hx_kernel" % (((dim * 2 + 31) // 32 + 3) // 4)
         tb, tsrc = batch_traffic("batch_hl_f32_via_bf16_dot_%dq_%d@%d" % (nq, dim, n_rows))
         line["roofline"]["traffic"] = tb
@@ -1158,7 +1161,11 @@ def make_summary(out):
                                    "batch_path": g(c5, "int8_filter_batch", "batch_path"),
                                    "bit_identical_to_bf16_filter": g(c5, "int8_filter_batch", "last_batch_bit_identical_to_the_bf16_filter"),
                                    "max_rel_vs_reference_kernel": g(c5, "int8_filter_batch", "last_batch_max_rel_difference_from_the_reference_kernel")},
-        "long_rows_1536": {"ms_per_step": g(a, "long_rows", "ms_per_step"), "frac_of_bf16_peak": g(a, "long_rows", "roofline", "frac")},
+        "long_rows_1536": {"ms_per_step": g(a, "long_rows", "ms_per_step"), "frac": g(a, "long_rows", "roofline", "frac"),
+                           "of": "int8 peak" if g(a, "long_rows", "roofline", "batch_path") == 7 else "bf16 peak",
+                           "batch_path": g(a, "long_rows", "roofline", "batch_path"),
+                           "bf16_ksplit_ms_per_step": g(a, "long_rows", "bf16_ksplit_batch", "ms_per_step"),
+                           "bit_identical_to_bf16_ksplit": g(a, "long_rows", "bf16_ksplit_batch", "last_batch_bit_identical_to_the_default_path")},
         "c1_sql_p50_ms": g(a, "c1", "p50_query_latency_ms"),
         "cpu_reference_1_core_vectors_per_s": g(out, "cpu_baseline", "value"),
         "cpu_reference_all_cores": {"vectors_per_s": g(out, "cpu_baseline", "all_cores", "value"), "cores": g(out, "cpu_baseline", "all_cores", "cores")},
@@ -1290,10 +1297,32 @@ def also_long_rows(args, pkg, torch, k, device_index):
         c.set_profiling(True)
         try:
             line = run_batched(args, pkg, torch, c, "c5l", n_rows, dim, metric, k, desc if n_rows == 10_000_000 else desc.replace("10M", "%gM" % (n_rows / 1e6)))
+            first = run_batched.last_result
+            # the same batches through round 4's path for such rows (the K-split bf16 kernel), priced on the bf16 peak
+            try:
+                os.environ["VG_BATCH_Q8"] = "0"
+                pkg.reload_switches()
+                c.close()
+                c = make_shard(pkg, torch, vt, dim, n_rows, 77, device_index)
+                c.set_profiling(True)
+                old = run_batched(args, pkg, torch, c, "c5l", n_rows, dim, metric, k, desc)
+                ores = run_batched.last_result
+                line["bf16_ksplit_batch"] = {
+                    "what": "VG_BATCH_Q8=0: vg_batch_hl_kernel (bf16 shadow copy, K split over a workgroup's wavefronts) + exact f32 re-evaluation",
+                    "ms_per_step": old["ms_per_step"], "kernel": old["roofline"]["kernel"], "kernel_ms": old["roofline"]["kernel_ms"],
+                    "frac_of_bf16_peak": old["roofline"]["frac"], "batch_path": old["roofline"].get("batch_path"),
+                    "default_path_speedup": old["ms_per_step"] / line["ms_per_step"],
+                    "last_batch_bit_identical_to_the_default_path": bool(np.array_equal(np.asarray(first[0]), np.asarray(ores[0])) and
+                                                                         np.array_equal(np.asarray(first[1], dtype=np.float32).view(np.uint32), np.asarray(ores[1], dtype=np.float32).view(np.uint32)))}
+            except Exception as e:                                    # noqa: BLE001
+                line["bf16_ksplit_batch"] = {"error": repr(e)}
+            finally:
+                os.environ.pop("VG_BATCH_Q8", None)
+                pkg.reload_switches()
         finally:
             c.close()
             torch.cuda.empty_cache()
-        return {kk: line[kk] for kk in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "against_single_scans") if kk in line}
+        return {kk: line[kk] for kk in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "against_single_scans", "bf16_ksplit_batch") if kk in line}
     except Exception as e:
         return {"error": repr(e)}
 

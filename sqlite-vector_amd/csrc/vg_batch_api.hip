@@ -326,6 +326,7 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
                                   const uint8_t *dev_xqueries, void *dev_qwork, int nq_pad, int nq_real, int k, int mode, int root,
                                   uint64_t *dev_cand, int npart, uint64_t *dev_out_keys, unsigned long long *dev_evals,
                                   uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, int type_code, hipStream_t stream);
+extern "C" int vg_batch_q8_workgroups_per_cu(long long q8stride_bytes);
 static long long q8_shadow_stride_of(const vg_corpus *c) { return (((long long)c->dim + 15) / 16) * 16; }
 static bool batch_q8_eligible(const vg_corpus *c, int metric, int k, int nq) {
     const bool served_type = c->vtype == VG_TYPE_F32 || c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16;   // (the int8 image of the row, whatever it is stored as)
@@ -376,7 +377,7 @@ static int scan_topk_batch_q8(vg_corpus *c, int metric, const void *queries, int
     const int QPB = vg_batch_q8_queries_per_block();
     const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
     const int G = nq_pad / QPB;
-    const int npart = std::min(256, std::max(8, (2 * c->cu_count / G) / 8 * 8));       // two 4-wavefront workgroups per CU
+    const int npart = std::min(256, std::max(8, (vg_batch_q8_workgroups_per_cu(qs) * c->cu_count / G) / 8 * 8));       // two 4-wavefront workgroups per CU (long rows: one of 8)
     int rcn = ensure_q8_tile_major(c);
     if (rcn == -1) { c->bq8_status = 1; return -1; }
     if (rcn != VG_OK) return rcn;
@@ -689,18 +690,7 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
     // A handful of queries over a corpus the filter scans serve: single scans (0.7 ms each at 10M x 384, whatever the type) beat one
     // 128- / 256-query-wide matrix pass (~2.9 ms however few of its query slots are used) up to three queries; they tie at four.
     const bool few = nq <= vg_sw(SW_VG_BATCH_MIN_QUERIES, 4) - 1 && vg_scan_filter_would_serve(c, metric, k);
-    if (!few && batch_long_eligible(c, metric, k) && c->blong_cooldown > 0) --c->blong_cooldown;
-    else if (!few && batch_long_eligible(c, metric, k)) {
-        const int slice = std::max(256, vg_sw(SW_VG_BATCH_SLICE, 4096));
-        int rc = VG_OK;
-        const size_t qbytes = (size_t)c->dim * c->es;
-        for (int q0 = 0; q0 < nq && rc == VG_OK; q0 += slice) {
-            const int nqs = std::min(slice, nq - q0);
-            rc = scan_topk_batch_long(c, metric, (const uint8_t *)queries + (size_t)q0 * qbytes, nqs, k, out_keys + (size_t)q0 * k, out_counts + q0);
-        }
-        if (rc != -1) { c->last_batch_path = 4; return rc; }
-        for (int i = 0; i < nq; ++i) out_counts[i] = 0;
-    }
+    // (the int8 filter first: it serves rows up to 1536 elements too; what it hands back - or does not serve - goes on to the K-split bf16 kernel)
     if (!few && batch_q8_eligible(c, metric, k, nq) && c->bq8_cooldown > 0) --c->bq8_cooldown;
     else if (!few && batch_q8_eligible(c, metric, k, nq)) {
         const int slice = std::min(vg_batch_q8_max_queries(), std::max(512, vg_sw(SW_VG_BATCH_SLICE, 4096)));
@@ -711,6 +701,18 @@ extern "C" int vg_scan_topk_batch_keys(vg_corpus *c, int metric, const void *que
             rc = scan_topk_batch_q8(c, metric, (const uint8_t *)queries + (size_t)q0 * qbytes, nqs, k, out_keys + (size_t)q0 * k, out_counts + q0);
         }
         if (rc != -1) { c->last_batch_path = 7; return rc; }
+        for (int i = 0; i < nq; ++i) out_counts[i] = 0;
+    }
+    if (!few && batch_long_eligible(c, metric, k) && c->blong_cooldown > 0) --c->blong_cooldown;
+    else if (!few && batch_long_eligible(c, metric, k)) {
+        const int slice = std::max(256, vg_sw(SW_VG_BATCH_SLICE, 4096));
+        int rc = VG_OK;
+        const size_t qbytes = (size_t)c->dim * c->es;
+        for (int q0 = 0; q0 < nq && rc == VG_OK; q0 += slice) {
+            const int nqs = std::min(slice, nq - q0);
+            rc = scan_topk_batch_long(c, metric, (const uint8_t *)queries + (size_t)q0 * qbytes, nqs, k, out_keys + (size_t)q0 * k, out_counts + q0);
+        }
+        if (rc != -1) { c->last_batch_path = 4; return rc; }
         for (int i = 0; i < nq; ++i) out_counts[i] = 0;
     }
     if (!few && (batch_mfma_eligible(c, metric, k) || batch_i8_eligible(c, metric, k) || batch_h_eligible(c, metric, k) ||

@@ -415,19 +415,19 @@ static int launch_hl(const BatchArgsH &a, int ntbp, int blocks, size_t smem, hip
 #endif
 }
 template <int VT, int XU>
-static int launch_hlx_mode(const BatchArgsH &a, int sets, int blocks, size_t smem, hipStream_t stream) {
-    const int subs = VGHL_WAVES / sets;
+static int launch_hlx_mode(const BatchArgsH &a, int sets, int blocks, size_t smem, hipStream_t stream, int subs_given = 0) {
+    const int subs = subs_given ? subs_given : VGHL_WAVES / sets;
     if (a.mode == VGH_COS) hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_COS, XU>), dim3((unsigned)blocks), dim3(64 * VGHX_WAVES), smem, stream, a, sets, subs);
     else if (a.mode == VGH_L2) hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_L2, XU>), dim3((unsigned)blocks), dim3(64 * VGHX_WAVES), smem, stream, a, sets, subs);
     else hipLaunchKernelGGL((vg_batch_hx_kernel<VT, VGH_DOT, XU>), dim3((unsigned)blocks), dim3(64 * VGHX_WAVES), smem, stream, a, sets, subs);
     return (int)hipGetLastError();
 }
 template <int VT>
-static int launch_hlx(const BatchArgsH &a, int sets, int blocks, size_t smem, hipStream_t stream) {
+static int launch_hlx(const BatchArgsH &a, int sets, int blocks, size_t smem, hipStream_t stream, int subs_given = 0) {
     const int xu = (int)((a.xstride / 16 + 63) / 64);                    // 16-byte chunks per lane of the exact evaluation (64 lanes per row)
-    if (xu <= 4) return launch_hlx_mode<VT, 4>(a, sets, blocks, smem, stream);
-    if (xu <= 8) return launch_hlx_mode<VT, 8>(a, sets, blocks, smem, stream);
-    if (xu <= 12) return launch_hlx_mode<VT, 12>(a, sets, blocks, smem, stream);
+    if (xu <= 4) return launch_hlx_mode<VT, 4>(a, sets, blocks, smem, stream, subs_given);
+    if (xu <= 8) return launch_hlx_mode<VT, 8>(a, sets, blocks, smem, stream, subs_given);
+    if (xu <= 12) return launch_hlx_mode<VT, 12>(a, sets, blocks, smem, stream, subs_given);
     return -1;
 }
 
@@ -444,16 +444,20 @@ extern "C" int vghl_exact_f32(const BatchArgsH *a, int sets, int blocks, size_t 
 #if VGHL_TU == 1
 extern "C" int vghl_filter_f16(const BatchArgsH *a, int ntbp, int blocks, size_t smem, hipStream_t stream) { return launch_hl<T_F16, VGH_FILTER>(*a, ntbp, blocks, smem, stream); }
 extern "C" int vghl_exact_f16(const BatchArgsH *a, int sets, int blocks, size_t smem, hipStream_t stream) { return launch_hlx<T_F16>(*a, sets, blocks, smem, stream); }
+// (vg_batch_q8.hip's long rows: `waves` 32-query regions per query group, one region per block)
+extern "C" int vghl_exact_regions_f16(const BatchArgsH *a, int waves, int regions, size_t smem, hipStream_t stream) { return launch_hlx<T_F16>(*a, waves, regions, smem, stream, 1); }
 #elif VGHL_TU == 2
 extern "C" int vghl_bound_bf16(const BatchArgsH *a, int ntbp, int blocks, size_t smem, hipStream_t stream) { return launch_hl<T_BF16, VGH_BOUNDK>(*a, ntbp, blocks, smem, stream); }
 #elif VGHL_TU == 3
 extern "C" int vghl_filter_bf16(const BatchArgsH *a, int ntbp, int blocks, size_t smem, hipStream_t stream) { return launch_hl<T_BF16, VGH_FILTER>(*a, ntbp, blocks, smem, stream); }
 extern "C" int vghl_exact_bf16(const BatchArgsH *a, int sets, int blocks, size_t smem, hipStream_t stream) { return launch_hlx<T_BF16>(*a, sets, blocks, smem, stream); }
+extern "C" int vghl_exact_regions_bf16(const BatchArgsH *a, int waves, int regions, size_t smem, hipStream_t stream) { return launch_hlx<T_BF16>(*a, waves, regions, smem, stream, 1); }
 #elif VGHL_TU == 4
 extern "C" int vghl_bound_f32(const BatchArgsH *a, int ntbp, int blocks, size_t smem, hipStream_t stream) { return launch_hl<T_F32, VGH_BOUNDK>(*a, ntbp, blocks, smem, stream); }
 #elif VGHL_TU == 5
 extern "C" int vghl_filter_f32(const BatchArgsH *a, int ntbp, int blocks, size_t smem, hipStream_t stream) { return launch_hl<T_F32, VGH_FILTER>(*a, ntbp, blocks, smem, stream); }
 extern "C" int vghl_exact_f32(const BatchArgsH *a, int sets, int blocks, size_t smem, hipStream_t stream) { return launch_hlx<T_F32>(*a, sets, blocks, smem, stream); }
+extern "C" int vghl_exact_regions_f32(const BatchArgsH *a, int waves, int regions, size_t smem, hipStream_t stream) { return launch_hlx<T_F32>(*a, waves, regions, smem, stream, 1); }
 #else
 extern "C" int vghl_bound_f16(const BatchArgsH *a, int ntbp, int blocks, size_t smem, hipStream_t stream) { return launch_hl<T_F16, VGH_BOUNDK>(*a, ntbp, blocks, smem, stream); }
 

@@ -43,6 +43,13 @@ typedef int vgq_i32x16 __attribute__((ext_vector_type(16)));
 #define VGQ_QS 2                        // query sets of 32 per wavefront
 #define VGQ_QPW (32 * VGQ_QS)
 #define VGQ_QPB (VGQ_WAVES * VGQ_QPW)   // 256 queries per workgroup
+// LONG rows (513 .. 1536 elements; round 5): a row's whole A operand for two query sets does not fit the register file (2 x 48 k-steps x 4 =
+// 384 VGPRs at 1536) - ONE set per wavefront (192), EIGHT wavefronts per workgroup (still 256 queries per pass over the copy), one workgroup
+// per CU, and the ring moves SUB-tiles: 32 rows x NTB k-steps = one K-part of a tile (contiguous in the tile-major copy); the accumulators
+// are carried over a tile's KS parts and the tile boundary runs behind the last one.
+#define VGQL_WAVES 8
+#define VGQL_QS 1
+#define VGQL_RING 6
 #define VGQ_TILE 32
 #define VGQ_MAX_K 32
 #define VGQ_BPIPE 4
@@ -217,18 +224,19 @@ __device__ __forceinline__ void vgq_wait_lds(vgh_i32x4 &v) {
 }
 
 // NTB = 32-byte k-steps per int8 row (rows up to NTB * 32 elements)
-template <int NTB, int MODE>
-__global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArgsQ8 a) {
-    constexpr int WAVES = VGQ_WAVES, THREADS = 64 * WAVES, QS = VGQ_QS;
-    constexpr int NB = VGQ_RING_OF(NTB);                                // tile buffers in LDS (NB - 1 tiles in flight)
+// WAVES x QS x 32 = 256 queries per workgroup; KS = K-parts per tile (1: the whole row is one ring buffer)
+template <int NTB, int MODE, int WAVES = VGQ_WAVES, int QS = VGQ_QS, int KS = 1>
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_kernel(BatchArgsQ8 a) {
+    constexpr int THREADS = 64 * WAVES, QPW = 32 * QS, QENT = 16 * QS + 8;
+    constexpr int NB = KS == 1 ? VGQ_RING_OF(NTB) : VGQL_RING;          // ring buffers in LDS (NB - 1 of them in flight)
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);
     constexpr int TILE_BYTES = NTB * 2 * 512;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tile0 = smem;
     float4 *rstat_lds = reinterpret_cast<float4 *>(smem + NB * TILE_BYTES);              // [VGQ_STAT_SLOTS][2 tiles][32 rows]
-    float4 *kq_lds = rstat_lds + VGQ_STAT_SLOTS * 64;                                    // [waves][64 queries]: (a, bb, cc, uu)
-    uint64_t *pbuf_lds = reinterpret_cast<uint64_t *>(kq_lds + WAVES * 64);              // [waves][2 sets][64]: pairs on their way out
-    uint32_t *queue_lds = reinterpret_cast<uint32_t *>(pbuf_lds + WAVES * 128);          // [waves][VGQ_QCAP][40 dwords]: candidate lanes
+    float4 *kq_lds = rstat_lds + VGQ_STAT_SLOTS * 64;                                    // [waves][QPW queries]: (a, bb, cc, uu)
+    uint64_t *pbuf_lds = reinterpret_cast<uint64_t *>(kq_lds + WAVES * QPW);             // [waves][QS sets][64]: pairs on their way out
+    uint32_t *queue_lds = reinterpret_cast<uint32_t *>(pbuf_lds + WAVES * QS * 64);      // [waves][VGQ_QCAP][QENT dwords]: candidate lanes
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -239,15 +247,15 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
     const int g = idx % G;
     const int part = (idx / G) * 8 + xcd;
     if (part >= a.npart) return;
-    const int q0 = g * VGQ_QPB + wave * VGQ_QPW;                         // set s: queries q0 + 32 s .. + 31
+    const int q0 = g * VGQ_QPB + wave * QPW;                             // set s: queries q0 + 32 s .. + 31
     const int chunks_per_row = (int)(a.stride / 16);
 
     // ---- A operands: lane (x, h) keeps bytes [32t + 16h, +16) of query x of each set
-    vgh_i32x4 areg[QS][NTB];
+    vgh_i32x4 areg[QS][KS * NTB];
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
         const uint8_t *qrow = a.qcodes + (long long)(q0 + 32 * s + x) * a.stride;
-        vgb_static_for<0, NTB>([&](auto tc) {
+        vgb_static_for<0, KS * NTB>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             const int off = 32 * t + 16 * h;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
     // the loosest of each over a query SET (the lane's half of the wavefront) feed the tile boundary's first test of that set.
     float amax[QS], bbmax[QS], ccmax[QS], uumin[QS];
     {
-        const int ql = q0 + lane;
+        const int ql = q0 + (lane & (QPW - 1));                          // (one set per wavefront: both halves compute the same 32 queries)
         const float4 s0 = a.qstat[2 * ql], s1 = a.qstat[2 * ql + 1];
         const float sq = s0.x, sqi = s0.y, eqn = s0.z, qn = s0.w, qq = s1.x;
         const float thr = a.init_keys ? vgb_kth_distance(a.init_keys[(long long)ql * 64 + (a.k - 1)]) : INFINITY;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
         if (COS) { if (!(bb < VGH_ACCEPT)) bb = VGH_ACCEPT; if (!(uu > -VGH_ACCEPT)) uu = -VGH_ACCEPT; }
         else if (!(cc < VGH_ACCEPT)) cc = VGH_ACCEPT;
         if (!ok) { cc = -VGH_ACCEPT; bb = 0.0f; uu = COS ? VGH_ACCEPT : 0.0f; }     // padding / queries the filter cannot judge: never pass
-        kq_lds[wave * 64 + lane] = make_float4(ok ? av : 0.0f, bb, cc, uu);
+        kq_lds[wave * QPW + (lane & (QPW - 1))] = make_float4(ok ? av : 0.0f, bb, cc, uu);
         float m1 = ok ? av : 0.0f, m2 = ok ? bb : -VGH_ACCEPT, m3 = ok ? cc : -VGH_ACCEPT, m4 = ok ? uu : VGH_ACCEPT;
 #pragma unroll
         for (int s = 16; s >= 1; s >>= 1) {                               // over the 32 lanes of a half: one query set each
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
             uumin[s] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m4), 32 * s));
         }
     }
-    const float4 *kq_w = kq_lds + wave * 64;
+    const float4 *kq_w = kq_lds + wave * QPW;
     for (int s = tid; s < NB * TILE_BYTES / 4; s += THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = 0u;   // pad columns
     __syncthreads();
 
@@ -324,12 +332,17 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
     const unsigned long long stride_b = (unsigned long long)a.stride;
     const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)tile0;
     constexpr int NPIECE = (NTB + WAVES - 1) / WAVES;
-    static_assert(NPIECE <= 4, "rows up to 512 bytes");
-    auto piece_mask_of = [&](int p) -> uint64_t {
-        if (p >= npieces) return 0ull;
-        return (2 * p + 1 < chunks_per_row) ? ~0ull : 0xFFFFFFFFull;
+    static_assert(NPIECE <= 4, "ring buffers of up to 512-byte (sub-)rows");
+    // K-part `part` of a tile = pieces part * NTB .. + NTB - 1 of its rows (contiguous: the copy is chunk-column major within a tile)
+    auto piece_mask_of = [&](int part_k, int p) -> uint64_t {
+        const int gp = part_k * NTB + p;
+        if (p >= NTB || gp >= npieces) return 0ull;
+        return (2 * gp + 1 < chunks_per_row) ? ~0ull : 0xFFFFFFFFull;
     };
-    const bool all_full = 2 * (wave * NPIECE + NPIECE) <= chunks_per_row;
+    auto full_of = [&](int part_k) -> bool { return wave * NPIECE + NPIECE <= NTB && 2 * (part_k * NTB + wave * NPIECE + NPIECE) <= chunks_per_row; };
+    bool all_parts_full = true;
+#pragma unroll
+    for (int kp = 0; kp < KS; ++kp) all_parts_full = all_parts_full && full_of(kp);
     const uint32_t lane_goff = (uint32_t)lane * 16u;
     const uint32_t lds_rstat0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4 *)rstat_lds;
     auto dma_stat_group = [&](long long tile2, int slot) {          // the row statistics of tiles tile2, tile2 + 1: 1 KiB
@@ -339,11 +352,11 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(lane_goff), "s"(b0), "s"(d0) : "memory");
     };
-    auto dma_piece = [&](long long tile, int buf, int i) __attribute__((always_inline)) {
+    auto dma_piece = [&](long long tile, int part_k, int buf, int i) __attribute__((always_inline)) {
         const int p = wave * NPIECE + i;
-        const uint64_t pmask = piece_mask_of(p);
+        const uint64_t pmask = piece_mask_of(part_k, p);
         if (pmask == 0) return;
-        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGQ_TILE) * stride_b + (unsigned)p * 1024u;
+        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGQ_TILE) * stride_b + (unsigned)(part_k * NTB + p) * 1024u;
         const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + p * 1024);
         uint32_t keep;
         uint64_t keep_exec;
@@ -351,8 +364,8 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
                      "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep), "=&s"(keep_exec) : "v"(lane_goff), "s"(sbase), "s"(lds_dst), "s"(pmask) : "memory", "scc");
     };
-    auto dma_run = [&](long long tile, int buf) __attribute__((always_inline)) {           // NPIECE (1 .. 4) whole pieces, back to back
-        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGQ_TILE) * stride_b + (unsigned)(wave * NPIECE) * 1024u;
+    auto dma_run = [&](long long tile, int part_k, int buf) __attribute__((always_inline)) {           // NPIECE (1 .. 4) whole pieces, back to back
+        const uint8_t *sbase = a.rows + (unsigned long long)(tile * VGQ_TILE) * stride_b + (unsigned)(part_k * NTB + wave * NPIECE) * 1024u;
         const uint32_t lds_dst = lds_tile0 + (uint32_t)(buf * TILE_BYTES + (wave * NPIECE) * 1024);
         uint32_t keep;
         if constexpr (NPIECE == 1)
@@ -372,9 +385,12 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
                          "global_load_lds_dwordx4 %1, %2 offset:3072\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(lane_goff), "s"(sbase), "s"(lds_dst) : "memory");
     };
-    auto dma_share = [&](long long tile, int buf) __attribute__((always_inline)) {
-        if (all_full) dma_run(tile, buf);
-        else vgb_static_for<0, NPIECE>([&](auto pc) { dma_piece(tile, buf, decltype(pc)::value); });
+    // ring trip u = K-part u % KS of tile tile_first + u / KS
+    auto dma_share = [&](int u, int buf) __attribute__((always_inline)) {
+        const int part_k = KS == 1 ? 0 : u % KS;
+        const long long tile = tile_first + (KS == 1 ? u : u / KS);
+        if (KS == 1 ? all_parts_full : full_of(part_k)) dma_run(tile, part_k, buf);
+        else vgb_static_for<0, NPIECE>([&](auto pc) { dma_piece(tile, part_k, buf, decltype(pc)::value); });
     };
 
     // The row statistics (16 bytes per row) ride the same queue, two tiles = 1 KiB per instruction into a ring of VGQ_STAT_SLOTS groups,
@@ -382,25 +398,28 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
     // pieces: a wavefront's loads return in order and its tile-end wait leaves at most (NB - 2) * NPIECE of them outstanding, so by the
     // barrier of trip 2j - 3 at the latest the group has landed - without any wait of its own (waiting for it on the spot meant waiting
     // for the pieces issued in the same trip: a full memory round trip every other tile, for all four wavefronts at the barrier).
-    constexpr int SPRE = (NB + 1) / 2;                               // groups loaded up front: j with 2j - NB < 0
+    // (K-parts: a group is issued LEAD = 2 tiles = 2 KS trips ahead - more than the NB - 2 trips the counted wait may leave outstanding)
+    constexpr int LEAD = KS == 1 ? NB : 2;                           // tiles between a group's issue and its first use
+    constexpr int SPRE = (LEAD + 1) / 2;                             // groups loaded up front: j with 2j - LEAD < 0
+    const int U = T * KS;                                            // ring trips of this partition
     if (T > 0) {
         if (wave < SPRE && 2 * wave < T + 1) dma_stat_group(tile_first + 2 * wave, wave);
-        vgb_static_for<0, NB - 1>([&](auto jc) {                     // tiles first .. first + NB - 2 into buffers 0 .. NB - 2
+        vgb_static_for<0, NB - 1>([&](auto jc) {                     // trips 0 .. NB - 2 into buffers 0 .. NB - 2
             constexpr int j = decltype(jc)::value;
-            dma_share(min(tile_first + j, tile_last - 1), j);
+            dma_share(min(j, U - 1), j);
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const bool counted_wait = all_full;
+    const bool counted_wait = all_parts_full;
     const long long region0 = ((long long)(g * a.npart_total + a.part_base + part) * WAVES + wave) * QS;
-    uint64_t *pairs0 = a.pairs + region0 * a.pair_cap, *pairs1 = pairs0 + a.pair_cap;
+    uint64_t *pairs0 = a.pairs + region0 * a.pair_cap, *pairs1 = pairs0 + (QS > 1 ? a.pair_cap : 0);
     unsigned n_pairs0 = 0, n_pairs1 = 0;                              // pairs in the regions so far (wave-uniform)
     // Pairs are collected in LDS (64 per set and wavefront) and go out 64 at a time: a store issued in the middle of the streaming loop
     // sits in the same in-order queue as the LDS-DMA pieces, and the tile-end wait "at most N outstanding" then waits for IT - a
     // ~2 us write acknowledgement - before it can count the pieces behind it as landed (one store per passing pair: 6.7 ms per batch
     // against 2.8 ms with the stores compiled out, docs/ROUND5_NOTEBOOK.md §2).
-    uint64_t *pbuf0 = pbuf_lds + wave * 128, *pbuf1 = pbuf0 + 64;
+    uint64_t *pbuf0 = pbuf_lds + wave * (QS * 64), *pbuf1 = pbuf0 + (QS > 1 ? 64 : 0);
     unsigned n_buf0 = 0, n_buf1 = 0;                                  // (wave-uniform)
     auto flush = [&](uint64_t *buf, unsigned &n_buf, uint64_t *region, unsigned &n_pairs) __attribute__((always_inline)) {
         if ((unsigned)lane < n_buf && n_pairs + (unsigned)lane < (unsigned)a.pair_cap) region[n_pairs + lane] = buf[lane];
@@ -421,13 +440,14 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
 #if VGQ_STATS
     unsigned st_slow = 0, st_cand = 0, st_pairs = 0;
 #endif
-    uint32_t *queue_w = queue_lds + wave * (VGQ_QCAP * 40);
+    uint32_t *queue_w = queue_lds + wave * (VGQ_QCAP * QENT);
     unsigned n_q = 0;                                                 // (wave-uniform)
     auto process_queue = [&]() __attribute__((always_inline)) {
-        const int e = lane >> 2, o = lane & 3, set = o >> 1;
-        const uint32_t *ent = queue_w + e * 40;
-        const uint4 m0 = *reinterpret_cast<const uint4 *>(ent + 32), m1 = *reinterpret_cast<const uint4 *>(ent + 36);
-        const uint4 a0 = *reinterpret_cast<const uint4 *>(ent + 8 * o), a1 = *reinterpret_cast<const uint4 *>(ent + 8 * o + 4);
+        constexpr int RPL = 4 * QS;                                   // accumulator registers of an entry per lane (four lanes per entry)
+        const int e = lane >> 2, o = lane & 3, set = QS > 1 ? o >> 1 : 0;
+        const uint32_t *ent = queue_w + e * QENT;
+        const uint4 m0 = *reinterpret_cast<const uint4 *>(ent + 16 * QS), m1 = *reinterpret_cast<const uint4 *>(ent + 16 * QS + 4);
+        const uint4 a0 = *reinterpret_cast<const uint4 *>(ent + RPL * o), a1 = *reinterpret_cast<const uint4 *>(ent + RPL * o + (QS > 1 ? 4 : 0));
         const uint32_t row_e = m0.x;
         const bool live = (unsigned)e < n_q && (long long)row_e < a.n_rows;      // (rows behind the corpus' end in its last tile read as zero rows)
         const int ithr_e = (int)(set ? m0.z : m0.y);
@@ -435,10 +455,10 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
         const int h_e = (int)m1.z;
         const float mx2_e = L2M ? mfac * nx_e * nx_e : 0.0f;
         const int acc8[8] = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
-        const unsigned long long set0_lanes = 0x3333333333333333ull;
+        const unsigned long long set0_lanes = QS > 1 ? 0x3333333333333333ull : ~0ull;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = (o & 1) * 8 + i;                            // register within the set
+        for (int i = 0; i < RPL; ++i) {
+            const int r = (QS > 1 ? (o & 1) * 8 : o * 4) + i;         // register within the set
             const int qi = (r & 3) + 8 * (r >> 2) + 4 * h_e;
             const float4 kq = kq_w[32 * set + qi];
             const int I = acc8[i];
@@ -473,14 +493,17 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
     int cur_buf = 0;
     for (int ti = 0; ti < T; ++ti) {
         const long long tile = tile_first + ti;
-        const int fill_buf = cur_buf == 0 ? NB - 1 : cur_buf - 1;
-        const long long tile_next = min(tile + NB - 1, tile_last - 1);        // the tile whose DMA this trip issues
-        const int sj = (ti + NB) >> 1;                                        // the statistics group this trip may issue
-        const bool stat_turn = ((ti + NB) & 1) == 0 && 2 * sj < T + 1 && wave == (sj & (WAVES - 1));
+        const int sj = (ti + LEAD) >> 1;                                      // the statistics group this tile's first trip may issue
+        const bool stat_turn = ((ti + LEAD) & 1) == 0 && 2 * sj < T + 1 && wave == (sj & (WAVES - 1));
         const long long row_cur = tile * VGQ_TILE + x;
         vgq_i32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
+        // one ring trip per K-part of the tile (KS = 1: the whole row): the accumulators run on across the parts
+        vgb_static_for<0, KS>([&](auto kc) {
+        constexpr int kp = decltype(kc)::value;
+        const int fill_buf = cur_buf == 0 ? NB - 1 : cur_buf - 1;
+        const int u_next = min(ti * KS + kp + NB - 1, U - 1);                 // the trip whose DMA this trip issues
         const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
         vgb_static_for<0, BP>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
@@ -491,18 +514,19 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
             constexpr int in_flight_after = (NTB - 1 - t) < (BP - 1) ? (NTB - 1 - t) : (BP - 1);
             vgq_wait_lds<in_flight_after>(bq[t % BP]);
             const vgh_i32x4 b = bq[t % BP];
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][t], b, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[1][t], b, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][kp * NTB + t], b, acc0, 0, 0, 0);
+            if constexpr (QS > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[QS - 1][kp * NTB + t], b, acc1, 0, 0, 0);
             if constexpr (t + BP < NTB) vgq_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
             if constexpr (t == 0 && VGQ_ABLATE < 3) {
-                if (stat_turn) dma_stat_group(tile_first + 2 * sj, sj & (VGQ_STAT_SLOTS - 1));
-                dma_share(tile_next, fill_buf);
+                if (kp == 0 && stat_turn) dma_stat_group(tile_first + 2 * sj, sj & (VGQ_STAT_SLOTS - 1));
+                dma_share(u_next, fill_buf);
             }
             // nothing else moves into the k loop: left alone, the compiler sinks the tile boundary's float work (thresholds from the row
             // statistics) between the MFMAs - and every extra issue slot between two MFMAs on one accumulator stalls the chain
-            // (MI355X_MICROARCH.md: + 43 cycles for the first one): last stage of 1024 x 10M x 384 2.65 ms against 1.88 (profiles/r9i)
+            // (MI355X_MICROARCH.md: + 43 cycles for the first one): last stage of 1024 x 10M x 384 2.65 ms against 1.88
             __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (kp == KS - 1) {
         const float4 rs = rstat_lds[((ti >> 1) & (VGQ_STAT_SLOTS - 1)) * 64 + (ti & 1) * 32 + x];
         // ---- tile boundary.  First test, per query set: the lane's LARGEST accumulator of the set against the set's loosest gate, as an
         // integer: I >= ithr = (-(amax ||ex|| + bbmax ||x|| + ccmax - m uumin)) / sx, rounded down.  Only a set with a lane that passes
@@ -512,7 +536,7 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
         const float sx = rs.x, rx = rs.y, nx = rs.z;
         const float inv_sx = __frcp_rn(sx);                            // (a zero row: +Inf - its accumulators are all 0 and the sign of `rest` decides)
         const float mx2 = L2M ? mfac * nx * nx : 0.0f;
-        int ithr[QS];
+        int ithr[2] = {0x7FFFFFFF, 0x7FFFFFFF};
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
             // I >= ithr  <=  I sx + rest >= 0;  ithr = floor(-(rest + sx) / sx) less a relative 1e-6: the "- 1" of the rounding rides in `rest`,
@@ -531,10 +555,12 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
             int gm[4];
             gm[0] = max(max(max(acc0[0], acc0[1]), max(acc0[2], acc0[3])), max(max(acc0[4], acc0[5]), max(acc0[6], acc0[7])));
             gm[1] = max(max(max(acc0[8], acc0[9]), max(acc0[10], acc0[11])), max(max(acc0[12], acc0[13]), max(acc0[14], acc0[15])));
-            gm[2] = max(max(max(acc1[0], acc1[1]), max(acc1[2], acc1[3])), max(max(acc1[4], acc1[5]), max(acc1[6], acc1[7])));
-            gm[3] = max(max(max(acc1[8], acc1[9]), max(acc1[10], acc1[11])), max(max(acc1[12], acc1[13]), max(acc1[14], acc1[15])));
-            const bool any0 = max(gm[0], gm[1]) >= ithr[0], any1 = max(gm[2], gm[3]) >= ithr[1];
-            const bool cand_lane = any0 || any1;
+            bool cand_lane = max(gm[0], gm[1]) >= ithr[0];
+            if constexpr (QS > 1) {
+                gm[2] = max(max(max(acc1[0], acc1[1]), max(acc1[2], acc1[3])), max(max(acc1[4], acc1[5]), max(acc1[6], acc1[7])));
+                gm[3] = max(max(max(acc1[8], acc1[9]), max(acc1[10], acc1[11])), max(max(acc1[12], acc1[13]), max(acc1[14], acc1[15])));
+                cand_lane = cand_lane || max(gm[2], gm[3]) >= ithr[1];
+            }
             unsigned long long m = __ballot(cand_lane);
             if (VGQ_ABLATE == 1) { asm volatile("" :: "s"(m)); m = 0ull; }
 #if VGQ_STATS
@@ -544,14 +570,15 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 const bool take = ((m >> lane) & 1ull) != 0ull && n_q + rank < (unsigned)VGQ_QCAP;
                 if (take && VGQ_ABLATE != 7) {
-                    uint32_t *ent = queue_w + (n_q + rank) * 40;
+                    uint32_t *ent = queue_w + (n_q + rank) * QENT;
                     vgb_static_for<0, 4>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
                         *reinterpret_cast<uint4 *>(ent + 4 * j) = make_uint4((uint32_t)acc0[4 * j], (uint32_t)acc0[4 * j + 1], (uint32_t)acc0[4 * j + 2], (uint32_t)acc0[4 * j + 3]);
-                        *reinterpret_cast<uint4 *>(ent + 16 + 4 * j) = make_uint4((uint32_t)acc1[4 * j], (uint32_t)acc1[4 * j + 1], (uint32_t)acc1[4 * j + 2], (uint32_t)acc1[4 * j + 3]);
+                        if constexpr (QS > 1)
+                            *reinterpret_cast<uint4 *>(ent + 16 + 4 * j) = make_uint4((uint32_t)acc1[4 * j], (uint32_t)acc1[4 * j + 1], (uint32_t)acc1[4 * j + 2], (uint32_t)acc1[4 * j + 3]);
                     });
-                    *reinterpret_cast<uint4 *>(ent + 32) = make_uint4((uint32_t)row_cur, (uint32_t)ithr[0], (uint32_t)ithr[1], __float_as_uint(sx));
-                    *reinterpret_cast<uint4 *>(ent + 36) = make_uint4(__float_as_uint(rx), __float_as_uint(nx), (uint32_t)h, 0u);
+                    *reinterpret_cast<uint4 *>(ent + 16 * QS) = make_uint4((uint32_t)row_cur, (uint32_t)ithr[0], (uint32_t)ithr[1], __float_as_uint(sx));
+                    *reinterpret_cast<uint4 *>(ent + 16 * QS + 4) = make_uint4(__float_as_uint(rx), __float_as_uint(nx), (uint32_t)h, 0u);
                 }
                 const unsigned long long taken = __ballot(take);
                 n_q += (unsigned)__popcll(taken);
@@ -559,14 +586,16 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
                 if (n_q == (unsigned)VGQ_QCAP) { if (VGQ_ABLATE == 7 || VGQ_ABLATE == 8) n_q = 0; else process_queue(); }
             }
         }
-        // tile end: the next tile's pieces have landed (an issuing wavefront leaves the pieces of the NB - 2 youngest tiles in flight:
-        // loads return in order), barrier: every wavefront has read this tile, the next one is readable
+        }
+        // trip end: the next trip's pieces have landed (an issuing wavefront leaves the pieces of the NB - 2 youngest trips in flight:
+        // loads return in order), barrier: every wavefront has read this buffer, the next one is readable
         if (counted_wait) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NB - 2) * NPIECE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" ::: "memory");
         if (VGQ_ABLATE < 4) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         cur_buf = cur_buf + 1 == NB ? 0 : cur_buf + 1;
+        });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (no LDS-DMA of the ring may land after this workgroup's LDS is gone)
 #if VGQ_STATS
@@ -575,10 +604,10 @@ __global__ __launch_bounds__(64 * VGQ_WAVES, 2) void vg_batch_q8_kernel(BatchArg
 #endif
     if (n_q && VGQ_ABLATE != 7 && VGQ_ABLATE != 8) process_queue();
     flush(pbuf0, n_buf0, pairs0, n_pairs0);
-    flush(pbuf1, n_buf1, pairs1, n_pairs1);
+    if (QS > 1) flush(pbuf1, n_buf1, pairs1, n_pairs1);
     if (lane == 0) {
         a.pair_counts[region0] = n_pairs0 < (unsigned)a.pair_cap ? n_pairs0 : (unsigned)a.pair_cap;
-        a.pair_counts[region0 + 1] = n_pairs1 < (unsigned)a.pair_cap ? n_pairs1 : (unsigned)a.pair_cap;
+        if (QS > 1) a.pair_counts[region0 + 1] = n_pairs1 < (unsigned)a.pair_cap ? n_pairs1 : (unsigned)a.pair_cap;
     }
 }
 
@@ -596,6 +625,34 @@ static int launch_q8_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStre
     if (a.mode == VGH_L2) return launch_q8<NTB, VGH_L2>(a, blocks, smem, stream);
     return launch_q8<NTB, VGH_DOT>(a, blocks, smem, stream);
 }
+// long rows: KS K-parts of NTB k-steps, one query set per wavefront, eight wavefronts
+template <int NTB, int KS, int MODE>
+static int launch_q8l(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
+    auto kern = vg_batch_q8_kernel<NTB, MODE, VGQL_WAVES, VGQL_QS, KS>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * VGQL_WAVES), smem, stream, a);
+    return (int)hipGetLastError();
+}
+template <int NTB, int KS>
+static int launch_q8l_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
+    if (a.mode == VGH_COS) return launch_q8l<NTB, KS, VGH_COS>(a, blocks, smem, stream);
+    if (a.mode == VGH_L2) return launch_q8l<NTB, KS, VGH_L2>(a, blocks, smem, stream);
+    return launch_q8l<NTB, KS, VGH_DOT>(a, blocks, smem, stream);
+}
+// rows of 513 .. 1536 int8 elements: (k-steps per K-part) * 8 + (K-parts), 0 if not served
+static int vgql_cfg(long long stride_bytes) {
+    const int ntb = (int)((stride_bytes + 31) / 32);
+    if (ntb <= 16) return 0;
+    if (ntb <= 24) return 12 * 8 + 2;
+    if (ntb <= 32) return 16 * 8 + 2;
+    if (ntb <= 48) return 16 * 8 + 3;
+    return 0;
+}
+static size_t vgql_lds_bytes(int NTB) {
+    return (size_t)VGQL_RING * NTB * 1024 + (size_t)VGQ_STAT_SLOTS * 1024 + (size_t)VGQL_WAVES * 32 * VGQL_QS * 16 + (size_t)VGQL_WAVES * VGQL_QS * 64 * 8 +
+           (size_t)VGQL_WAVES * VGQ_QCAP * (16 * VGQL_QS + 8) * 4;
+}
 static int vgq_ntb(long long stride_bytes) {
     const int ntb = (int)((stride_bytes + 31) / 32);
     if (ntb <= 4) return 4;
@@ -611,13 +668,19 @@ static size_t vgq_lds_bytes(int NTB) {
 extern "C" int vgh_launch_exact_f32(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream);   // vg_batch_h.hip (-DVGH_TU=8)
 extern "C" int vgh_launch_exact_f16(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream);   // (-DVGH_TU=6)
 extern "C" int vgh_launch_exact_bf16(const BatchArgsH *a, int ntb, int waves, int regions, size_t smem, hipStream_t stream);  // (-DVGH_TU=7)
+// the same kernel with more chunks per lane (rows beyond 4 KiB f32 / 2 KiB f16 - bf16): vg_batch_hl.hip's instantiations
+extern "C" int vghl_exact_regions_f16(const BatchArgsH *a, int waves, int regions, size_t smem, hipStream_t stream);
+extern "C" int vghl_exact_regions_bf16(const BatchArgsH *a, int waves, int regions, size_t smem, hipStream_t stream);
+extern "C" int vghl_exact_regions_f32(const BatchArgsH *a, int waves, int regions, size_t smem, hipStream_t stream);
 extern "C" int vg_batch_merge_launch(const uint64_t *dev_cand, int nq_pad, int lists_per_query, int npart, int k,
                                      uint64_t *dev_out_keys, hipStream_t stream);        // vg_batch.hip
 
 // does the int8 batch filter serve rows of q8stride_bytes int8 elements (xstride_bytes: the f32 rows) with lists of k?
 extern "C" int vg_batch_q8_serves(long long q8stride_bytes, long long xstride_bytes, int k) {
-    return vgq_ntb(q8stride_bytes) != 0 && k >= 1 && k <= VGQ_MAX_K && xstride_bytes <= 2048;
+    return (vgq_ntb(q8stride_bytes) != 0 || vgql_cfg(q8stride_bytes) != 0) && k >= 1 && k <= VGQ_MAX_K && xstride_bytes <= 6144;
 }
+// workgroups of the filter kernel a CU holds at once (what the caller sizes the partition count by)
+extern "C" int vg_batch_q8_workgroups_per_cu(long long q8stride_bytes) { return vgq_ntb(q8stride_bytes) != 0 ? 2 : 1; }
 extern "C" int vg_batch_q8_queries_per_block(void) { return VGQ_QPB; }
 extern "C" int vg_batch_q8_max_queries(void) { return 4096; }         // (the rank kernel's LDS)
 extern "C" int vg_batch_q8_regions(int nq_pad, int npart) { return (nq_pad / 32) * npart; }
@@ -655,7 +718,8 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
                                   const uint8_t *dev_xqueries, void *dev_qwork, int nq_pad, int nq_real, int k, int mode, int root,
                                   uint64_t *dev_cand, int npart, uint64_t *dev_out_keys, unsigned long long *dev_evals,
                                   uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, int type_code, hipStream_t stream) {
-    const int ntb = vgq_ntb(q8stride);
+    const int lcfg = vgql_cfg(q8stride);
+    const int ntb = lcfg ? lcfg / 8 : vgq_ntb(q8stride), ks = lcfg ? lcfg % 8 : 1;
     if (type_code < 0 || type_code > 2) return -1;
     if (!ntb || !vg_batch_q8_serves(q8stride, xstride, k) || nq_pad % VGQ_QPB != 0 || nq_pad > vg_batch_q8_max_queries() || npart < 8 || npart % 8 != 0 ||
         npart > VG_SEL_MAX_HEADS) return -1;
@@ -698,7 +762,8 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     a.rel = (float)(dim + 64) * 2.384185791015625e-7f;               // (D + 64) 2^-22
     a.part_base = 0;
     a.pairs = dev_pairs; a.pair_counts = dev_pair_counts; a.pair_cap = pair_cap; a.flag_index = flag_index;
-    const size_t smem = vgq_lds_bytes(ntb);
+    const size_t smem = lcfg ? vgql_lds_bytes(ntb) : vgq_lds_bytes(ntb);
+    const bool long_exact = xstride > (type_code == 2 ? 4096 : 2048);       // rows beyond what the short exact kernel's chunks per lane cover
     // Stages over growing row ranges: the lists are merged after every stage and the next one starts from every query's k-th best over
     // all rows so far.  Stage 0: two tiles, every gate open (1024 pairs per region and tile), exact lists behind it - no pre-pass kernel of
     // another kind.  Then x8 while a stage is small (its launches are what it costs), x2 from 1/32 of the corpus on (fewer pairs for the
@@ -727,11 +792,21 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
         hx.npart = np; hx.npart_total = np; hx.n_regions = vg_batch_q8_regions(nq_pad, np);
         hx.init_keys = a.init_keys; hx.seed = (s > 0) ? 1 : 0;
         const int blocks = G * np;
-        if (ntb == 4) rc = launch_q8_mode<4>(a, blocks, smem, stream);
+        if (lcfg) {
+            if (ntb == 12) rc = launch_q8l_mode<12, 2>(a, blocks, smem, stream);
+            else if (ks == 2) rc = launch_q8l_mode<16, 2>(a, blocks, smem, stream);
+            else rc = launch_q8l_mode<16, 3>(a, blocks, smem, stream);
+        }
+        else if (ntb == 4) rc = launch_q8_mode<4>(a, blocks, smem, stream);
         else if (ntb == 8) rc = launch_q8_mode<8>(a, blocks, smem, stream);
         else if (ntb == 12) rc = launch_q8_mode<12>(a, blocks, smem, stream);
         else rc = launch_q8_mode<16>(a, blocks, smem, stream);
         if (rc != 0) return rc;
+        if (long_exact)
+            rc = type_code == 2 ? vghl_exact_regions_f32(&hx, hx_waves, hx.n_regions, smem_exact, stream)
+                                : (type_code == 1 ? vghl_exact_regions_bf16(&hx, hx_waves, hx.n_regions, smem_exact, stream)
+                                                  : vghl_exact_regions_f16(&hx, hx_waves, hx.n_regions, smem_exact, stream));
+        else
         rc = type_code == 2 ? vgh_launch_exact_f32(&hx, xntb, hx_waves, hx.n_regions, smem_exact, stream)
                             : (type_code == 1 ? vgh_launch_exact_bf16(&hx, xntb, hx_waves, hx.n_regions, smem_exact, stream)
                                               : vgh_launch_exact_f16(&hx, xntb, hx_waves, hx.n_regions, smem_exact, stream));

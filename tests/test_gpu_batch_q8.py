@@ -204,3 +204,49 @@ def test_int8_filter_batch_over_half_precision_corpora(pkg, orc, vt, dim, monkey
             assert ids[i][:cnt[i]].tolist() == one_ids.tolist() and dg.same_float_bits(dist[i][:cnt[i]], one_d), (vt, dim, metric, i)
     monkeypatch.delenv("VG_BATCH_Q8")
     c.close()
+
+
+@pytest.mark.parametrize("vt,dim", [(dg.F32, 600), (dg.F32, 1024), (dg.F32, 1400), (dg.F32, 1536), (dg.F16, 1536), (dg.BF16, 1040)])
+def test_int8_filter_batch_over_long_rows(pkg, orc, vt, dim, monkeypatch):
+    """rows of 513 .. 1536 elements: one query set per wavefront, eight wavefronts, the ring in K-parts of a tile (vg_batch_q8.hip, KS = 2 / 3)
+    - the answers of the bf16 / f16 matrix-core paths for such rows (vg_batch_h.hip up to 1024 elements, the K-split vg_batch_hl.hip
+    beyond), bit for bit, which are the single scan's"""
+    rng = np.random.default_rng(7500 + dim + vt)
+    n, nq, k = 66_003, 300, 20
+    rows32 = rng.standard_normal((n, dim), dtype=np.float32)
+    qs32 = rng.standard_normal((nq, dim), dtype=np.float32)
+    qs32[5] = 0.0
+    qs32[9, 0] = np.float32(50.0)
+    rows32 = _adversarial(rows32, qs32, rng)
+    if vt == dg.F16:
+        rows32[6005] = rng.standard_normal(dim).astype(np.float32) * np.float32(1e3)
+        rows32[6004] = rng.standard_normal(dim).astype(np.float32) * np.float32(1e-4)
+    rows, qs = dg.to_storage(vt, rows32), dg.to_storage(vt, qs32)
+    c = pkg.Corpus(vt, dim)
+    c.append(rows)
+    for metric in (dg.DOT, dg.COSINE, dg.L2):
+        monkeypatch.setenv("VG_BATCH_Q8", "1")
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        assert c.last_batch_path() == 7, (vt, dim, metric, c.last_batch_path(), c.batch_q8_status())
+        monkeypatch.setenv("VG_BATCH_Q8", "0")
+        monkeypatch.setenv("VG_F32_FILTER", "1")
+        ids0, dist0, cnt0 = c.scan_topk_batch(metric, qs, k)
+        assert c.last_batch_path() in (3, 4), c.last_batch_path()
+        monkeypatch.delenv("VG_F32_FILTER")
+        assert np.array_equal(cnt, cnt0), (vt, dim, metric)
+        unjudged = (5,) + ((9,) if metric == dg.L2 else ())
+        for i in range(nq):
+            m = cnt[i]
+            if i in unjudged and vt == dg.F32:                 # (a single scan here, in-kernel evaluation there: another f32 summation order)
+                assert np.allclose(dist[i][:m], dist0[i][:m], rtol=1e-5, atol=1e-30), (vt, dim, metric, i)
+                continue
+            assert ids[i][:m].tolist() == ids0[i][:m].tolist() and dg.same_float_bits(dist[i][:m], dist0[i][:m]), (vt, dim, metric, i)
+        for i in (0, 3, 40):
+            one_ids, one_d = c.scan_topk(metric, qs[i], k)
+            assert ids[i][:cnt[i]].tolist() == one_ids.tolist(), (vt, dim, metric, i)
+            if vt != dg.F32:
+                assert dg.same_float_bits(dist[i][:cnt[i]], one_d)
+            else:
+                assert np.allclose(dist[i][:cnt[i]], one_d, rtol=1e-5, atol=1e-30)
+    monkeypatch.delenv("VG_BATCH_Q8")
+    c.close()

@@ -245,10 +245,10 @@ def test_f32_768_batch_10m_through_the_bf16_filter(env):
 
 @pytest.mark.parametrize("vt_name,dim", (("f32", 1536), ("bf16", 3072)))
 def test_long_rows_batch_10m(env, vt_name, dim):
-    """10M x 1536 f32 (61 GB + a 31 GB tile-major bf16 shadow copy) / 10M x 3072 bf16 (61 GB + its tile-major copy), 300 queries: rows
-    beyond 1024 elements run vg_batch_hl.hip - the K dimension split over the four wavefronts of a workgroup, 24 / 48 k-steps each,
-    bound pre-pass + eleven filter / exact stages, five query groups - and every list must be the single scan's list within the
-    type's bar (f32: 1e-5 relative; bf16: the f64 arithmetic's float result)."""
+    """10M x 1536 f32 (61 GB + its int8 shadow and tile-major copies, 2 x 15 GB) / 10M x 3072 bf16 (61 GB + its tile-major copy), 300
+    queries: f32 rows of 1536 elements take the int8 filter (vg_batch_q8.hip: one query set per wavefront, eight wavefronts, a tile's K in
+    three ring parts), bf16 rows of 3072 the K-split bf16 kernel (vg_batch_hl.hip: 48 k-steps per wavefront) - and every list must be the
+    single scan's list within the type's bar (f32: 1e-5 relative; bf16: the f64 arithmetic's float result)."""
     pkg, torch = env
     vt = pkg.F32 if vt_name == "f32" else pkg.BF16
     k, nq = 20, 300
@@ -259,7 +259,8 @@ def test_long_rows_batch_10m(env, vt_name, dim):
     qs = qf if vt == pkg.F32 else torch.from_numpy(qf).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
     for metric in (dg.DOT, dg.L2, dg.COSINE):
         ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
-        assert c.last_batch_path() == 4
+        # rows up to 1536 elements: the int8 filter with a tile's K in three ring parts (round 5's default); beyond: the K-split bf16 kernel
+        assert c.last_batch_path() == (7 if dim <= 1536 else 4), c.last_batch_path()
         assert np.all(cnt == k) and np.all(np.diff(dist, axis=1) >= 0)
         for i in range(0, nq, 37):
             one_ids, one_dist = c.scan_topk(metric, qs[i], k)

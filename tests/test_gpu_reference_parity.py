@@ -210,15 +210,19 @@ def test_long_rows_batch_equals_the_reference_kernels(env, orc):
             scanners[m].feed(pinned.numpy(), b * blk)
         del t
     checked = 0
-    for m in metrics:
+    # both paths such rows have: the K-split bf16 kernel (path 4: the default for a 256-query batch) and the int8 filter with a tile's K in
+    # three ring parts (path 7: the default from 257 queries and 2^20 rows on; forced here)
+    for m, force_q8 in [(m, f) for f in ("0", "1") for m in metrics]:
+        os.environ["VG_BATCH_Q8"] = force_q8
         ids, dist, cnt = c.scan_topk_batch(m, qs, k)
-        assert c.last_batch_path() == 4 and np.all(cnt == k) and np.all(np.diff(dist, axis=1) >= 0)
+        os.environ.pop("VG_BATCH_Q8")
+        assert c.last_batch_path() == (7 if force_q8 == "1" else 4) and np.all(cnt == k) and np.all(np.diff(dist, axis=1) >= 0)
         for j, qi in enumerate(sample):
             # dot: the literal relative bar (dot_tol); cosine = 1 - r with r ~ 0.1: 1e-5 relative to the DISTANCE (~0.9) is the bar
             # as stated; L2: relative
             tol = dot_tol(float(np.abs(qs[qi]).sum()) * 4.0) if m == dg.DOT else (lambda d: 1e-5 * abs(d))
             checked += check_against_reference((m, qi), ids[qi], dist[qi], scanners[m].result(j), k, tol)
-    assert checked >= len(metrics) * len(sample) * (k - 4), checked
+    assert checked >= 2 * len(metrics) * len(sample) * (k - 4), checked
     c.close()
 
 
