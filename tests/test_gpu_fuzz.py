@@ -92,6 +92,40 @@ def test_random_batches_vs_single_scans(pkg, chunk):
         c.close()
 
 
+@pytest.mark.parametrize("chunk", range(2))
+def test_random_int8_filter_batches_vs_single_scans(pkg, chunk, monkeypatch):
+    """the int8 matrix-core filter (vg_batch_q8.hip; forced: its default starts at 2^20 rows and 257 queries) on random shapes - every
+    row-length class (k-steps 4 / 8 / 12 / 16, K in two and three ring parts up to 1536 elements), the three float types, the four metrics
+    it serves, ragged last tiles, batches that are nearly all padding: against the single-query kernel like the batches above."""
+    monkeypatch.setenv("VG_BATCH_Q8", "1")
+    rng = np.random.default_rng(2500 + chunk)
+    for _ in range(6 * _scale()):
+        vt = int(rng.choice([dg.F32, dg.F32, dg.F16, dg.BF16]))
+        metric = int(rng.choice([dg.L2, dg.SQUARED_L2, dg.DOT, dg.COSINE]))
+        dim = int(rng.choice([rng.integers(1, 129), rng.integers(129, 513), rng.integers(513, 1025), rng.integers(1025, 1537)]))
+        n = int(rng.integers(65_537, 90_000)) if dim > 512 else int(rng.integers(65_537, 200_000))
+        nq = int(rng.choice([7, 33, 129, 260, 300]))
+        k = int(rng.choice([1, 5, 20, 32]))
+        seed = int(rng.integers(0, 1 << 30))
+        rows = dg.corpus(vt, n, dim, seed)
+        qs = dg.corpus(vt, nq, dim, seed + 1)
+        c = pkg.Corpus(vt, dim)
+        c.append(rows)
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        tag = (vt, metric, dim, n, nq, k, seed, c.last_batch_path(), c.batch_q8_status())
+        assert c.last_batch_path() == 7, tag
+        for i in sorted(set([0, nq // 2, nq - 1])):
+            one_ids, one_dist = c.scan_topk(metric, qs[i], k)
+            assert cnt[i] == len(one_ids), tag
+            if vt in (dg.F16, dg.BF16):         # the pairs that pass carry the single scan's f64 arithmetic: the same floats
+                assert ids[i][:cnt[i]].tolist() == one_ids.tolist() and dg.same_float_bits(dist[i][:cnt[i]], one_dist), tag
+            else:                               # (f32: the single scan's chain, another launch shape's summation order)
+                scale = float(np.abs(qs[i]).sum()) * 4.0 if metric == dg.DOT else (1.0 if metric == dg.COSINE else 0.0)
+                assert np.all(np.abs(dist[i][:cnt[i]] - one_dist) <= 1e-5 * (np.abs(one_dist) + scale) + 1e-6), tag
+                assert len(set(ids[i][:cnt[i]].tolist()) ^ set(one_ids.tolist())) <= 2, tag
+        c.close()
+
+
 def _tie_cases(seed, count):
     """(type, metric, dim, rows, k, value levels, planted duplicates, filter scans forced, shards, seed): corpora whose distances tie
     at every density from "never" to "constantly", on both sides of the sizes where the reference-order scan changes its form
