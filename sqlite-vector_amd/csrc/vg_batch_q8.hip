@@ -772,7 +772,8 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     int nstages = 0;
     {
         const int sw_growth = vg_sw(SW_VG_BATCH_STAGES, 0);
-        const int late_growth = sw_growth > 100 ? sw_growth : 200;
+        // (long rows: an exact evaluation reads up to 6 KB - tighter thresholds pay for a few more launches: x1.5; 20.8 -> 20.0 ms at 10M x 1536)
+        const int late_growth = sw_growth > 100 ? sw_growth : (lcfg ? 150 : 200);
         bounds[0] = 0;
         long long b = VGQ_STAGE0_TILES;
         while (b < ntiles && nstages + 2 < 24 && ntiles - b > b / 4) {      // (no sliver at the end)
