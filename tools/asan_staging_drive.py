@@ -81,6 +81,23 @@ want = d2.execute("SELECT rowid, distance FROM vector_full_scan('t', 'v', ?, 6)"
 d2.close()
 assert sorted(got[:4]) == sorted(want[:4]) and got[0][1] == 0.0 and int(ids[1234]) not in [g[0] for g in got], (got, want)
 print("tracked changes: rows re-sent to the engine", s1 - s0, got[:4])
+# a table beyond VECTORGPU_HBM_LIMIT: nothing is staged, every scan feeds the rows to the engine slab by slab (vext_staging.inc: ooc_plan,
+# ooc_scan_full; the stream and batch functions; vector_quantize slab by slab) - the answers of the resident table
+os.environ["VECTORGPU_HBM_LIMIT"] = "1"                   # 1 MiB < 8.3 MB
+d = connect()
+got_ooc = d.execute(sql, (q.tobytes(),)).fetchall()
+mem = json.loads(d.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
+assert mem["column"]["out_of_core"] == 1 and mem["column"]["staged"] == 0, mem
+stream = d.execute("SELECT count(*), min(distance) FROM vector_full_scan_stream('t', 'v', ?)", (q.tobytes(),)).fetchone()
+batch = d.execute("SELECT query, id FROM vector_full_scan_batch('t', 'v', ?, 3)", (np.stack([q, rows[5]]).tobytes(),)).fetchall()
+print("out of core:", got_ooc[:2], "stream rows", stream, "batch", batch[:3], "quantize", d.execute("SELECT vector_quantize('t', 'v', 'max_memory=1MB')").fetchone())
+del os.environ["VECTORGPU_HBM_LIMIT"]
+d.close()
+d = connect()
+want_res = d.execute(sql, (q.tobytes(),)).fetchall()
+assert [g[0] for g in got_ooc] == [w[0] for w in want_res] and stream[0] == d.execute("SELECT count(v) FROM t").fetchone()[0], (got_ooc, want_res, stream)
+assert [b[1] for b in batch if b[0] == 0] == [w[0] for w in want_res[:3]], batch
+d.close()
 # one staged copy per process (vext_shared.inc): 8 threads x 8 connections over one database file take references to ONE copy; a commit
 # from one of them moves everybody (lazily, at their next scan) to the copy of the new file state, and the old one is freed with its last
 # reference.  Every thread scans while the others attach / detach: the registry, the per-copy scan mutex and the statistics under TSan.

@@ -136,17 +136,69 @@ int vg_shards_delete_rows(vg_shards *s, const int64_t *pos, int64_t n) {
 }
 int vg_shards_device_bytes(const vg_shards *s, long long *out3) { out3[0] = (long long)s->cap * s->dim * 4; out3[1] = 0; out3[2] = 0; return 0; }
 
-/* out-of-core scans: the stub holds everything in host memory and reports plenty of it free - nothing ever goes out of core here */
-typedef struct vg_slab_scan vg_slab_scan;
+/* out-of-core scans (vg_slab_scan_*): the stub keeps the k best (distance, position) so far and, for k = 0, every distance - enough for the
+ * extension's slab-feeding loops (ooc_scan_full, the stream and batch forms, vector_quantize slab by slab) to run under the sanitizers.
+ * It reports 1 TiB of free memory: a table goes out of core here only under VECTORGPU_HBM_LIMIT. */
+typedef struct vg_slab_scan {
+    int dim, k;
+    int64_t rowid_base, seen;
+    float *q;
+    double *best_d; int64_t *best_id; int nbest;
+    float *all_d; int64_t *all_id; int64_t all_n, all_cap;
+} vg_slab_scan;
+void vg_slab_scan_destroy(vg_slab_scan *s) { if (s) { free(s->q); free(s->best_d); free(s->best_id); free(s->all_d); free(s->all_id); free(s); } }
 int vg_slab_scan_begin(int device, int vtype, int dim, int metric, const void *q, int k, int tie, int64_t slab_rows, int64_t rowid_base, vg_slab_scan **out) {
-    (void)device; (void)vtype; (void)dim; (void)metric; (void)q; (void)k; (void)tie; (void)slab_rows; (void)rowid_base; (void)out;
-    return fail("stub engine: no out-of-core scans");
+    (void)device; (void)metric; (void)tie; (void)slab_rows;
+    if (vtype != 1) return fail("stub engine: f32 only");
+    vg_slab_scan *s = (vg_slab_scan *)calloc(1, sizeof(*s));
+    if (!s) return fail("out of memory");
+    s->dim = dim; s->k = k; s->rowid_base = rowid_base;
+    s->q = (float *)malloc((size_t)dim * sizeof(float));
+    s->best_d = (double *)malloc((size_t)(k > 0 ? k : 1) * sizeof(double));
+    s->best_id = (int64_t *)malloc((size_t)(k > 0 ? k : 1) * sizeof(int64_t));
+    if (!s->q || !s->best_d || !s->best_id) { vg_slab_scan_destroy(s); return fail("out of memory"); }
+    memcpy(s->q, q, (size_t)dim * sizeof(float));
+    *out = s;
+    return 0;
 }
-int vg_slab_scan_rows(vg_slab_scan *s, const void *rows, int64_t n, int64_t stride, const int64_t *ids) { (void)s; (void)rows; (void)n; (void)stride; (void)ids; return fail("stub engine: no out-of-core scans"); }
-int vg_slab_scan_records(vg_slab_scan *s, const void *rec, int64_t n) { (void)s; (void)rec; (void)n; return fail("stub engine: no out-of-core scans"); }
-int vg_slab_scan_finish(vg_slab_scan *s, int64_t *ids, double *d, int *n) { (void)s; (void)ids; (void)d; (void)n; return fail("stub engine: no out-of-core scans"); }
-int vg_slab_scan_all(vg_slab_scan *s, int64_t *n, const float **d, const int64_t **ids) { (void)s; (void)n; (void)d; (void)ids; return fail("stub engine: no out-of-core scans"); }
-void vg_slab_scan_destroy(vg_slab_scan *s) { (void)s; }
+int vg_slab_scan_rows(vg_slab_scan *s, const void *rows, int64_t n, int64_t stride, const int64_t *ids) {
+    for (int64_t r = 0; r < n; ++r) {
+        const float *x = (const float *)((const uint8_t *)rows + r * stride);
+        float acc = 0.0f;
+        for (int e = 0; e < s->dim; ++e) { const float d = s->q[e] - x[e]; acc += d * d; }
+        const double dist = (double)sqrtf(acc);
+        const int64_t id = ids ? ids[r] : s->rowid_base + s->seen;
+        ++s->seen;
+        if (s->k == 0) {
+            if (s->all_n == s->all_cap) {
+                const int64_t cap = s->all_cap ? 2 * s->all_cap : 4096;
+                float *d2 = (float *)realloc(s->all_d, (size_t)cap * sizeof(float));
+                if (!d2) return fail("out of memory");
+                s->all_d = d2;
+                int64_t *i2 = (int64_t *)realloc(s->all_id, (size_t)cap * sizeof(int64_t));
+                if (!i2) return fail("out of memory");
+                s->all_id = i2; s->all_cap = cap;
+            }
+            s->all_d[s->all_n] = (float)dist; s->all_id[s->all_n] = id; ++s->all_n;
+            continue;
+        }
+        int at = s->nbest;                                           /* insert behind equal distances: (distance, position) order */
+        while (at > 0 && s->best_d[at - 1] > dist) --at;
+        if (at >= s->k) continue;
+        const int last = s->nbest < s->k ? s->nbest : s->k - 1;
+        for (int j = last; j > at; --j) { s->best_d[j] = s->best_d[j - 1]; s->best_id[j] = s->best_id[j - 1]; }
+        s->best_d[at] = dist; s->best_id[at] = id;
+        if (s->nbest < s->k) ++s->nbest;
+    }
+    return 0;
+}
+int vg_slab_scan_records(vg_slab_scan *s, const void *rec, int64_t n) { (void)s; (void)rec; (void)n; return fail("stub engine: no quantized records"); }
+int vg_slab_scan_finish(vg_slab_scan *s, int64_t *ids, double *d, int *n) {
+    for (int i = 0; i < s->nbest; ++i) { ids[i] = s->best_id[i]; d[i] = s->best_d[i]; }
+    *n = s->nbest;
+    return 0;
+}
+int vg_slab_scan_all(vg_slab_scan *s, int64_t *n, const float **d, const int64_t **ids) { *n = s->all_n; *d = s->all_d; *ids = s->all_id; return 0; }
 int vg_device_memory(int device, long long *free_bytes, long long *total_bytes) { (void)device; *free_bytes = 1ll << 40; *total_bytes = 1ll << 40; return 0; }
 
 int vg_shards_trim(vg_shards *s) { (void)s; return 0; }
