@@ -1448,3 +1448,61 @@ def test_sparse_keys_do_not_leave_an_oversized_reservation(ext_path, tmp_path):
     got = db.execute("SELECT rowid FROM vector_full_scan('t','v',?,2)", (q.tobytes(),)).fetchall()
     assert sorted(g[0] for g in got) == [7 * 11 + 3, 7 * n + 100]
     db.close()
+
+
+@pytest.mark.gpu
+def test_out_of_core_scan_through_the_parallel_readers(ext_path, orc, tmp_path, monkeypatch):
+    """a FILE table of 260 000 rows beyond VECTORGPU_HBM_LIMIT: the slabs are fed by the staging pass' reader connections over key ranges
+    (2.5 x one sqlite3_step loop) - the single statement's answer, rowids and distance bits, both tie orders; a writer committing
+    between scans is seen by the next one"""
+    import json
+    n, dim, k = 260_000, 32, 15
+    rows = dg.corpus(dg.F32, n, dim, 9600)
+    rows[200_000:200_020] = rows[5]
+    q = rows[5].copy()
+    path = str(tmp_path / "ooc.db")
+    db = sqlite3.connect(path, isolation_level=None)
+    db.execute("CREATE TABLE t (id INTEGER PRIMARY KEY, v BLOB)")
+    db.execute("BEGIN")
+    db.executemany("INSERT INTO t(id, v) VALUES (?, ?)", [(3 * i + 1, rows[i].tobytes()) for i in range(n)])
+    db.execute("COMMIT")
+    db.close()
+    sql = "SELECT rowid, distance FROM vector_full_scan('t','v',?,?)"
+
+    def connect_file():
+        c = sqlite3.connect(path, isolation_level=None)
+        c.enable_load_extension(True)
+        c.load_extension(ext_path)
+        c.execute("SELECT vector_init('t','v','type=FLOAT32,dimension=%d,distance=L2')" % dim)
+        return c
+
+    resident = connect_file()
+    want = resident.execute(sql, (q.tobytes(), k)).fetchall()
+    stream = resident.execute("SELECT rowid, distance FROM vector_full_scan_stream('t','v',?)", (q.tobytes(),)).fetchall()
+    resident.close()                                                               # (a live copy of the table would be SHARED by the connections below)
+    monkeypatch.setenv("VECTORGPU_HBM_LIMIT", "2")                                 # 2 MiB < 33 MB
+    res = {}
+    for threads in ("1", "4"):
+        monkeypatch.setenv("VECTORGPU_STAGE_THREADS", threads)
+        c = connect_file()
+        p0 = json.loads(c.execute("SELECT vector_gpu_stats()").fetchone()[0])["parallel_reader_passes"]
+        t0 = time.perf_counter()
+        res[threads] = c.execute(sql, (q.tobytes(), k)).fetchall()
+        dt = time.perf_counter() - t0
+        st = json.loads(c.execute("SELECT vector_gpu_stats()").fetchone()[0])
+        assert st["parallel_reader_passes"] - p0 == (1 if threads == "4" else 0), (threads, st)
+        assert json.loads(c.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])["column"]["out_of_core"] == 1
+        print("out-of-core scan of 260k x 32 f32, %s reader thread(s): %.3f s" % (threads, dt))
+        c.close()
+    assert res["1"] == want and res["4"] == want
+    monkeypatch.setenv("VECTORGPU_TIE_ORDER", "reference")
+    c = connect_file()
+    ref = c.execute(sql, (q.tobytes(), k)).fetchall()
+    oref = orc.topk_reference(np.array([d for _, d in stream], dtype=np.float32), np.array([i for i, _ in stream], dtype=np.int64), k)
+    assert [r[0] for r in ref] == oref[0].tolist() and [r[1] for r in ref] == oref[1].tolist()
+    other = sqlite3.connect(path, isolation_level=None)
+    other.execute("DELETE FROM t WHERE id=?", (ref[0][0],))                         # another connection commits
+    other.close()
+    again = c.execute(sql, (q.tobytes(), k)).fetchall()
+    assert ref[0][0] not in [r[0] for r in again] and len(again) == k
+    c.close()

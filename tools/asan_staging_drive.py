@@ -84,8 +84,16 @@ print("tracked changes: rows re-sent to the engine", s1 - s0, got[:4])
 # a table beyond VECTORGPU_HBM_LIMIT: nothing is staged, every scan feeds the rows to the engine slab by slab (vext_staging.inc: ooc_plan,
 # ooc_scan_full; the stream and batch functions; vector_quantize slab by slab) - the answers of the resident table
 os.environ["VECTORGPU_HBM_LIMIT"] = "1"                   # 1 MiB < 8.3 MB
+os.environ["VECTORGPU_STAGE_THREADS"] = "1"               # the single statement feeds the slabs ...
+d = connect()
+got_single = d.execute(sql, (q.tobytes(),)).fetchall()
+d.close()
+os.environ["VECTORGPU_STAGE_THREADS"] = "4"               # ... or four reader connections over key ranges
+s_before = json.loads(connect().execute("SELECT vector_gpu_stats()").fetchone()[0])["parallel_reader_passes"]
 d = connect()
 got_ooc = d.execute(sql, (q.tobytes(),)).fetchall()
+assert got_ooc == got_single, (got_ooc, got_single)
+assert json.loads(d.execute("SELECT vector_gpu_stats()").fetchone()[0])["parallel_reader_passes"] == s_before + 1
 mem = json.loads(d.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])
 assert mem["column"]["out_of_core"] == 1 and mem["column"]["staged"] == 0, mem
 stream = d.execute("SELECT count(*), min(distance) FROM vector_full_scan_stream('t', 'v', ?)", (q.tobytes(),)).fetchone()
