@@ -14,6 +14,8 @@ import pytest
 
 import datagen as dg
 
+# The *_equals_single_scans tests compare HIP with HIP (a batch path against the single-query kernel at 10M rows); the chain is anchored to the
+# reference by tests/test_gpu_reference_parity.py (the reference's own kernel over every row) and test_c2 / test_c3 here (the oracle).
 pytestmark = pytest.mark.gpu
 
 N = 10_000_000
@@ -157,7 +159,7 @@ def test_c3_u8_cosine_10m_bit_exact(env, orc):
 
 
 @pytest.mark.parametrize("metric", (dg.DOT, dg.COSINE, dg.L2))
-def test_c5_batched_10m(env, metric):
+def test_c5_batched_10m_equals_single_scans(env, metric):
     """config C5's shape (10M x 384 f32, top-20, a batch of queries on the matrix cores) against the per-query scan
     kernel (itself checked against the reference arithmetic above and in test_gpu_scan.py): same rowids, distances
     within 1e-5.  At this size the batch runs as pre-pass + main pass (thresholds from the first 1/64 of the corpus)."""
@@ -183,7 +185,7 @@ def test_c5_batched_10m(env, metric):
 
 
 @pytest.mark.parametrize("vt_name", ("f16", "bf16"))
-def test_half_precision_batch_10m(env, vt_name):
+def test_half_precision_batch_10m_equals_single_scans(env, vt_name):
     """10M x 384 f16 / 10M x 768 bf16, a batch of 300 queries (two query groups, bound-only pre-pass + real pass): the matrix cores
     only filter, the survivors carry the single scan's f64 arithmetic - so every list must be the single scan's list
     (distances within one rounding of the float result, rows equal unless two distances tie within that)."""
@@ -205,7 +207,7 @@ def test_half_precision_batch_10m(env, vt_name):
 
 
 @pytest.mark.parametrize("nq", (200, 520))
-def test_quantized_batch_10m_bit_exact(env, nq):
+def test_quantized_batch_10m_bit_exact_with_single_scans(env, nq):
     """10M x 768 uint8, batches on the integer matrix cores with the two-pass launch (tile-minimum pre-pass + real pass
     over every row): one query group over 256 partitions (nq = 200) and three groups (nq = 520).  Integer arithmetic:
     every list must equal the single scan's list bit for bit, ties included."""
@@ -224,7 +226,7 @@ def test_quantized_batch_10m_bit_exact(env, nq):
     c.close()
 
 
-def test_f32_768_batch_10m_through_the_bf16_filter(env):
+def test_f32_768_batch_10m_through_the_filters_equals_single_scans(env):
     """10M x 768 f32 (30.7 GB + a 15.4 GB bf16 shadow copy), 200 queries: rows too long for the f32 matrix-core kernel run
     the half-precision kernel as a filter; every list must be the single f32 scan's list within the f32 bar."""
     pkg, torch = env
@@ -244,7 +246,7 @@ def test_f32_768_batch_10m_through_the_bf16_filter(env):
 
 
 @pytest.mark.parametrize("vt_name,dim", (("f32", 1536), ("bf16", 3072)))
-def test_long_rows_batch_10m(env, vt_name, dim):
+def test_long_rows_batch_10m_equals_single_scans(env, vt_name, dim):
     """10M x 1536 f32 (61 GB + its int8 shadow and tile-major copies, 2 x 15 GB) / 10M x 3072 bf16 (61 GB + its tile-major copy), 300
     queries: f32 rows of 1536 elements take the int8 filter (vg_batch_q8.hip: one query set per wavefront, eight wavefronts, a tile's K in
     three ring parts), bf16 rows of 3072 the K-split bf16 kernel (vg_batch_hl.hip: 48 k-steps per wavefront) - and every list must be the
