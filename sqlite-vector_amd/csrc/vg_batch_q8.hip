@@ -227,8 +227,8 @@ __device__ __forceinline__ void vgq_wait_lds(vgh_i32x4 &v) {
 // WAVES x QS x 32 = 256 queries per workgroup; KS = K-parts per tile (1: the whole row is one ring buffer)
 template <int NTB, int MODE, int WAVES = VGQ_WAVES, int QS = VGQ_QS, int KS = 1>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_kernel(BatchArgsQ8 a) {
-    constexpr int THREADS = 64 * WAVES, QPW = 32 * QS, QENT = 16 * QS + 8;
-    constexpr int NB = KS == 1 ? VGQ_RING_OF(NTB) : VGQL_RING;          // ring buffers in LDS (NB - 1 of them in flight)
+    constexpr int THREADS = 64 * WAVES, QPW = 32 * QS, QENT = 16 * QS + 8, QPB = WAVES * QPW;
+    constexpr int NB = WAVES == 4 ? VGQ_RING_OF(NTB) : VGQL_RING;       // ring buffers in LDS (NB - 1 of them in flight); one workgroup per CU: six
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);
     constexpr int TILE_BYTES = NTB * 2 * 512;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -242,12 +242,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x = lane & 31, h = lane >> 5;
 
-    const int G = a.nq_pad / VGQ_QPB;
+    const int G = a.nq_pad / QPB;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int g = idx % G;
     const int part = (idx / G) * 8 + xcd;
     if (part >= a.npart) return;
-    const int q0 = g * VGQ_QPB + wave * QPW;                             // set s: queries q0 + 32 s .. + 31
+    const int q0 = g * QPB + wave * QPW;                                 // set s: queries q0 + 32 s .. + 31
     const int chunks_per_row = (int)(a.stride / 16);
 
     // ---- A operands: lane (x, h) keeps bytes [32t + 16h, +16) of query x of each set
@@ -625,6 +625,25 @@ static int launch_q8_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStre
     if (a.mode == VGH_L2) return launch_q8<NTB, VGH_L2>(a, blocks, smem, stream);
     return launch_q8<NTB, VGH_DOT>(a, blocks, smem, stream);
 }
+// the WIDE form of the short-row kernel: eight wavefronts x two query sets = 512 queries per workgroup, one workgroup per CU - a tile is
+// brought in once for 512 queries instead of once per 256 (half the LDS-DMA issues and half the L2 traffic per pair), six ring buffers
+template <int NTB, int MODE>
+static int launch_q8w(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
+    auto kern = vg_batch_q8_kernel<NTB, MODE, 8, 2, 1>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * 8), smem, stream, a);
+    return (int)hipGetLastError();
+}
+template <int NTB>
+static int launch_q8w_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
+    if (a.mode == VGH_COS) return launch_q8w<NTB, VGH_COS>(a, blocks, smem, stream);
+    if (a.mode == VGH_L2) return launch_q8w<NTB, VGH_L2>(a, blocks, smem, stream);
+    return launch_q8w<NTB, VGH_DOT>(a, blocks, smem, stream);
+}
+static size_t vgqw_lds_bytes(int NTB) {
+    return (size_t)VGQL_RING * NTB * 1024 + (size_t)VGQ_STAT_SLOTS * 1024 + (size_t)8 * 64 * 16 + (size_t)8 * 128 * 8 + (size_t)8 * VGQ_QCAP * 160;
+}
 // long rows: KS K-parts of NTB k-steps, one query set per wavefront, eight wavefronts
 template <int NTB, int KS, int MODE>
 static int launch_q8l(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
@@ -741,9 +760,7 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
                        (const float *)common, (float *)nullptr, (float *)nullptr, xq_sorted, qcodes, q8stride, qstat, type_code);
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
-    const int G = nq_pad / VGQ_QPB;
     const int flag_index = vg_batch_q8_regions(nq_pad, npart);
-    const int hx_waves = VGQ_WAVES * VGQ_QS;
     // k-steps of the exact kernel's shape: an f32 corpus is described by its bf16 image (what picks the chunks per lane), f16 / bf16 by themselves
     const int xntb = type_code == 2 ? (int)((((long long)dim * 2 + 15) / 16 * 16 + 31) / 32) : (int)((xstride + 31) / 32);
     const size_t smem_exact = (size_t)VGH_QPW * (8 + 4 + 4 + 4) + (size_t)VGH_QPW * k * 8 + (size_t)pair_cap * 8;      // (+ the region's pairs)
@@ -762,8 +779,12 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     a.rel = (float)(dim + 64) * 2.384185791015625e-7f;               // (D + 64) 2^-22
     a.part_base = 0;
     a.pairs = dev_pairs; a.pair_counts = dev_pair_counts; a.pair_cap = pair_cap; a.flag_index = flag_index;
-    const size_t smem = lcfg ? vgql_lds_bytes(ntb) : vgq_lds_bytes(ntb);
+    // short rows: the wide form (512 queries per workgroup) whenever the padded batch is a multiple of 512 (VG_BATCH_H_WAVES=4: the 256-query form)
+    const bool wide = !lcfg && nq_pad % 512 == 0 && vg_sw(SW_VG_BATCH_H_WAVES, 8) != 4;
+    const size_t smem = lcfg ? vgql_lds_bytes(ntb) : (wide ? vgqw_lds_bytes(ntb) : vgq_lds_bytes(ntb));
     const bool long_exact = xstride > (type_code == 2 ? 4096 : 2048);       // rows beyond what the short exact kernel's chunks per lane cover
+    const int G = nq_pad / (wide ? 512 : VGQ_QPB);
+    const int hx_waves = wide ? 16 : VGQ_WAVES * VGQ_QS;                    // 32-query regions per query group and partition
     // Stages over growing row ranges: the lists are merged after every stage and the next one starts from every query's k-th best over
     // all rows so far.  Stage 0: two tiles, every gate open (1024 pairs per region and tile), exact lists behind it - no pre-pass kernel of
     // another kind.  Then x8 while a stage is small (its launches are what it costs), x2 from 1/32 of the corpus on (fewer pairs for the
@@ -797,6 +818,12 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
             if (ntb == 12) rc = launch_q8l_mode<12, 2>(a, blocks, smem, stream);
             else if (ks == 2) rc = launch_q8l_mode<16, 2>(a, blocks, smem, stream);
             else rc = launch_q8l_mode<16, 3>(a, blocks, smem, stream);
+        }
+        else if (wide) {
+            if (ntb == 4) rc = launch_q8w_mode<4>(a, blocks, smem, stream);
+            else if (ntb == 8) rc = launch_q8w_mode<8>(a, blocks, smem, stream);
+            else if (ntb == 12) rc = launch_q8w_mode<12>(a, blocks, smem, stream);
+            else rc = launch_q8w_mode<16>(a, blocks, smem, stream);
         }
         else if (ntb == 4) rc = launch_q8_mode<4>(a, blocks, smem, stream);
         else if (ntb == 8) rc = launch_q8_mode<8>(a, blocks, smem, stream);
