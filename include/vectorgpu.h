@@ -64,6 +64,7 @@ void    vg_corpus_destroy(vg_corpus *c);
 int     vg_corpus_clear(vg_corpus *c);
 int     vg_corpus_reserve(vg_corpus *c, int64_t capacity_rows);   /* grow HBM to hold that many rows (no-op if it does) */
 int     vg_corpus_trim(vg_corpus *c);                              /* give back a reservation more than 25 % above the rows held */
+int     vg_corpus_clone(const vg_corpus *src, vg_corpus **out);    /* the same rows, rowids and switches again (device-to-device copy): copy-on-write */
 int64_t vg_corpus_rows(const vg_corpus *c);
 int     vg_corpus_dim(const vg_corpus *c);
 int     vg_corpus_type(const vg_corpus *c);
@@ -193,6 +194,7 @@ int64_t vg_shards_rows(const vg_shards *s);
 vg_corpus *vg_shards_shard(const vg_shards *s, int i);          /* borrow shard i (profiling, introspection) */
 int     vg_shards_reserve(vg_shards *s, int64_t total_rows);
 int     vg_shards_trim(vg_shards *s);                                                      /* vg_corpus_trim on every shard */
+int     vg_shards_clone(const vg_shards *src, vg_shards **out);                            /* vg_corpus_clone of every shard */
 int     vg_shards_set_rowid_base(vg_shards *s, int64_t base);
 int     vg_shards_append(vg_shards *s, const void *host_rows, int64_t n_rows, int64_t row_stride_bytes, const int64_t *rowids);
 int     vg_shards_append_records(vg_shards *s, const void *host_records, int64_t n_records);

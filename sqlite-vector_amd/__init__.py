@@ -73,6 +73,8 @@ def _load():
         "vg_corpus_clear": (i32, [vp]),
         "vg_corpus_reserve": (i32, [vp, i64]),
         "vg_corpus_trim": (i32, [vp]),
+        "vg_corpus_clone": (i32, [vp, vp]),
+        "vg_shards_clone": (i32, [vp, vp]),
         "vg_shards_trim": (i32, [vp]),
         "vg_corpus_rows": (i64, [vp]),
         "vg_corpus_dim": (i32, [vp]),

@@ -360,6 +360,28 @@ extern "C" int vg_shards_reserve(vg_shards *s, int64_t total_rows) {
     return VG_OK;
 }
 
+extern "C" int vg_corpus_clone(const vg_corpus *src, vg_corpus **out);
+extern "C" int vg_shards_clone(const vg_shards *src, vg_shards **out) {
+    if (!src || !out) return fail(VG_ERR_INVALID, "vg_shards_clone: NULL argument");
+    *out = nullptr;
+    vg_shards *s = nullptr;
+    int rc = vg_shards_create(src->devices.data(), src->S, src->vtype, src->dim, src->B, &s);
+    if (rc != VG_OK) return rc;
+    for (int i = 0; i < src->S; ++i) {
+        vg_corpus *c = nullptr;
+        rc = vg_corpus_clone(src->sh[(size_t)i], &c);
+        if (rc != VG_OK) { vg_shards_destroy(s); return rc; }
+        vg_corpus_destroy(s->sh[(size_t)i]);                                  // (the empty corpus vg_shards_create made)
+        s->sh[(size_t)i] = c;
+    }
+    s->n_rows = src->n_rows;
+    s->rowid_base = src->rowid_base;
+    s->tie_order = src->tie_order;
+    s->gather_mode = src->gather_mode;
+    *out = s;
+    return VG_OK;
+}
+
 extern "C" int vg_corpus_trim(vg_corpus *c);
 extern "C" int vg_shards_trim(vg_shards *s) {
     if (!s) return fail(VG_ERR_INVALID, "shards handle is NULL");

@@ -1407,6 +1407,21 @@ def test_connections_of_one_process_share_one_staged_copy(ext_path, orc, tmp_pat
     fresh = connect_file()
     assert json.loads(fresh.execute("SELECT vector_gpu_stats()").fetchone()[0])["shared_copies"] == 0
     fresh.close()
+    # copy-on-write: a connection that wrote while others hold the copy clones it on the device and appends its own rows - no pass over the table
+    a, b = connect_file(), connect_file()
+    ra = a.execute(sql, (q.tobytes(), k)).fetchall()
+    assert b.execute(sql, (q.tobytes(), k)).fetchall() == ra
+    assert json.loads(b.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])["column"]["sharers"] == 2
+    staged0 = json.loads(a.execute("SELECT vector_gpu_stats()").fetchone()[0])["rows_staged"]
+    a.execute("INSERT INTO t(id, v) VALUES (?, ?)", (n + 2, (q * np.float32(1.0000001)).tobytes()))
+    got = a.execute(sql, (q.tobytes(), k)).fetchall()
+    assert {got[0][0], got[1][0]} == {n + 1, n + 2}
+    st_a = json.loads(a.execute("SELECT vector_gpu_stats()").fetchone()[0])
+    assert st_a["rows_staged"] - staged0 == 1, (st_a["rows_staged"], staged0)          # the one new row, not the table
+    assert b.execute(sql, (q.tobytes(), k)).fetchall() == got                         # b moves to a's copy without reading anything
+    assert json.loads(b.execute("SELECT vector_gpu_stats()").fetchone()[0])["rows_staged"] - staged0 == 1
+    assert json.loads(b.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])["column"]["sharers"] == 2
+    a.close(); b.close()
     # WAL: the change counter of the main file does not follow commits - every connection keeps its own copy
     wal = str(tmp_path / "wal.db")
     db = sqlite3.connect(wal, isolation_level=None)

@@ -202,3 +202,15 @@ int vg_slab_scan_all(vg_slab_scan *s, int64_t *n, const float **d, const int64_t
 int vg_device_memory(int device, long long *free_bytes, long long *total_bytes) { (void)device; *free_bytes = 1ll << 40; *total_bytes = 1ll << 40; return 0; }
 
 int vg_shards_trim(vg_shards *s) { (void)s; return 0; }
+
+int vg_shards_clone(const vg_shards *src, vg_shards **out) {
+    vg_shards *s = (vg_shards *)calloc(1, sizeof(*s));
+    if (!s) return fail("out of memory");
+    s->vtype = src->vtype; s->dim = src->dim;
+    if (grow(s, src->n > 0 ? src->n : 1)) { free(s); return -1; }
+    memcpy(s->rows, src->rows, (size_t)src->n * src->dim * sizeof(float));
+    memcpy(s->ids, src->ids, (size_t)src->n * sizeof(int64_t));
+    s->n = src->n;
+    *out = s;
+    return 0;
+}
