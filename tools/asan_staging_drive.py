@@ -149,6 +149,21 @@ assert st["shared_copies"] == 1 and st["shared_references"] == 64 and mem["colum
 assert st["stage_passes"] - base["stage_passes"] <= 4       # (the copy of each file state is staged once, not 64 times)
 for cs in conns:
     for c in cs: c.close()
+# copy-on-write: a writer among holders clones the copy (vg_shards_clone) and appends its own row; the other holder moves over for free
+a, b = connect(), connect()
+qq = rows[77].copy()
+ra = a.execute(sql, (qq.tobytes(),)).fetchall()
+assert b.execute(sql, (qq.tobytes(),)).fetchall() == ra and ra[0][0] == int(ids[77])
+staged0 = json.loads(a.execute("SELECT vector_gpu_stats()").fetchone()[0])["rows_staged"]
+a.execute("INSERT INTO t(id, v) VALUES (?, ?)", (int(ids[-1]) + 600, qq.tobytes()))
+ga = a.execute(sql, (qq.tobytes(),)).fetchall()
+assert [g[0] for g in ga[:2]] == [int(ids[77]), int(ids[-1]) + 600], ga
+assert json.loads(a.execute("SELECT vector_gpu_stats()").fetchone()[0])["rows_staged"] - staged0 == 1
+assert b.execute(sql, (qq.tobytes(),)).fetchall() == ga
+assert json.loads(b.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])["column"]["sharers"] == 2
+a.execute("DELETE FROM t WHERE id = ?", (int(ids[-1]) + 600,))
+a.close(); b.close()
+print("copy-on-write: one row re-sent for a commit among two holders")
 d = connect()
 assert json.loads(d.execute("SELECT vector_gpu_stats()").fetchone()[0])["shared_copies"] == 0      # the last reference freed it
 d.execute("DELETE FROM t WHERE id = ?", (int(ids[-1]) + 500,))
