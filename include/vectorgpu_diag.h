@@ -82,6 +82,8 @@ int vg_resident_distances_below(vg_corpus *c, int64_t pos0, float bound, uint64_
 /* host-only: the same replay over n distances the caller holds (scan order); returns the count (<= k) or -1.
  * below_cap <= 0: the device path's candidate capacity. */
 int vg_reference_topk_replay(const float *dist, int64_t n, int k, int64_t below_cap, int64_t *out_pos, double *out_dist);
+/* the same stream handed over slab by slab (the out-of-core scan's continuation of the slot state, host-only: CPU tests) */
+int vg_reference_topk_replay_slabs(const float *dist, int64_t n, int k, int64_t slab_rows, int64_t below_cap, int64_t *out_pos, double *out_dist);
 
 
 #ifdef __cplusplus

@@ -160,6 +160,7 @@ def _load():
         "vg_scan_topk_reference": (i32, [vp, i32, vp, i32, vp, vp, C.POINTER(i32)]),
         "vg_stat_rows_appended": (C.c_longlong, []),
         "vg_reference_topk_replay": (i32, [vp, i64, i32, i64, vp, vp]),
+        "vg_reference_topk_replay_slabs": (i32, [vp, i64, i32, i64, i64, vp, vp]),
         "vg_scan_distances_resident": (i32, [vp, i32, vp]),
         "vg_resident_distances_fetch": (i32, [vp, i64, i64, vp]),
         "vg_resident_distances_below": (i32, [vp, i64, C.c_float, vp, i64, C.POINTER(i64)]),
@@ -549,6 +550,17 @@ def reference_topk_replay(dist, k, below_cap=0):
     cnt = lib().vg_reference_topk_replay(_ptr(dist), dist.shape[0], k, below_cap, _ptr(pos), _ptr(out))
     if cnt < 0:
         raise VectorGpuError("vg_reference_topk_replay: bad arguments")
+    return pos[:cnt], out[:cnt]
+
+
+def reference_topk_replay_slabs(dist, k, slab_rows, below_cap=0):
+    """the same stream handed over slab by slab (the out-of-core scan's continuation of the slot state) -> (positions, distances)"""
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    pos = np.zeros(max(k, 1), dtype=np.int64)
+    out = np.zeros(max(k, 1), dtype=np.float64)
+    cnt = lib().vg_reference_topk_replay_slabs(_ptr(dist), dist.shape[0], k, slab_rows, below_cap, _ptr(pos), _ptr(out))
+    if cnt < 0:
+        raise VectorGpuError("vg_reference_topk_replay_slabs: bad arguments")
     return pos[:cnt], out[:cnt]
 
 

@@ -344,6 +344,27 @@ extern "C" int vg_reference_topk_replay(const float *dist, int64_t n, int k, int
     return cnt;
 }
 
+// the same stream handed over SLAB BY SLAB (what vg_slabscan.hip does with a table that does not fit the device): the first slab is replayed
+// like a corpus, every later one continues the slots it inherits (vg_ref_replay_more) - a host-only twin of vg_ref_replay_slab for the CPU tests
+extern "C" int vg_reference_topk_replay_slabs(const float *dist, int64_t n, int k, int64_t slab_rows, int64_t below_cap, int64_t *out_pos, double *out_dist) {
+    if (!dist || n < 0 || k < 0 || slab_rows < 1 || !out_pos || !out_dist) { vg_fail(VG_ERR_INVALID, "vg_reference_topk_replay_slabs: bad argument"); return -1; }
+    VgRefSlots slots;
+    slots.init(k);
+    bool fresh = true;
+    for (int64_t base = 0; base < n; base += slab_rows) {
+        const int64_t cnt = std::min<int64_t>(slab_rows, n - base);
+        HostSrc src{dist + base, cnt, below_cap > 0 ? below_cap : VG_BELOW_CAP};
+        if (fresh) {
+            if (vg_ref_replay(src, cnt, k, slots) != 0) return -1;
+            if (base) for (int i = 0; i < k; ++i) if (slots.pos[(size_t)i] >= 0) slots.pos[(size_t)i] += base;
+            fresh = false;
+        } else if (vg_ref_replay_more(src, cnt, k, slots, base) != 0) return -1;
+    }
+    const int got = slots.finish();
+    for (int i = 0; i < got; ++i) { out_pos[i] = slots.pos[(size_t)i]; out_dist[i] = slots.dist[(size_t)i]; }
+    return got;
+}
+
 extern "C" int vg_corpus_set_tie_order(vg_corpus *c, int mode) {
     if (!c) return vg_fail(VG_ERR_INVALID, "corpus is NULL");
     if (mode != VG_TIE_POSITION && mode != VG_TIE_REFERENCE) return vg_fail(VG_ERR_INVALID, "unknown tie order %d", mode);

@@ -57,6 +57,22 @@ def test_host_replay_equals_the_reference_slot_algorithm(pkg_cpu, orc, chunk):
             assert np.array_equal(got_d, want_d, equal_nan=True)
 
 
+@pytest.mark.parametrize("chunk", range(4))
+def test_host_replay_slab_by_slab_equals_the_reference_slot_algorithm(pkg_cpu, orc, chunk):
+    """the out-of-core scan's form of the replay (vg_slabscan.hip / vg_ref_replay_more): the stream arrives in slabs, the slot state -
+    distances, positions, the index of the current maximum - is carried from one slab to the next; any slab size, the overflow path
+    included, must end in the reference's slots"""
+    rng = np.random.default_rng(9900 + chunk)
+    for i in range(30):
+        d, k = _streams(9500 + 100 * chunk + i)
+        want_ids, want_d = orc.topk_reference(d, None, k)
+        for slab in (1, int(rng.integers(2, 50)), int(rng.integers(50, 5000)), len(d) + 5):
+            for cap in (0, 3):
+                pos, got_d = pkg_cpu.reference_topk_replay_slabs(d, k, slab, cap)
+                assert (pos + 1).tolist() == want_ids.tolist(), (chunk, i, slab, cap, k, len(d))
+                assert np.array_equal(got_d, want_d, equal_nan=True)
+
+
 def test_reference_examples_from_the_survey(pkg_cpu):
     """SURVEY section 7 probes: [5,5,3] k=2 -> rowids {3,2}; [3,5,5,5,1] k=3 -> {5,1,3}"""
     pos, d = pkg_cpu.reference_topk_replay(np.array([5, 5, 3], np.float32), 2)
