@@ -173,6 +173,53 @@ def rows_at(pkg, torch, vt, dim, n_rows, seed, positions):
     return out
 
 
+def host_description():
+    """what the CPU legs ran on: CPU model, logical CPUs of the host, the process' affinity mask, the cgroup CPU quota, free memory"""
+    d = {"logical_cpus": os.cpu_count()}
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except Exception:
+        cpus = list(range(os.cpu_count() or 1))
+    d["affinity_cpus"] = len(cpus)
+    d["affinity_cpus_list"] = cpus
+    try:
+        with open("/proc/cpuinfo") as f:
+            txt = f.read()
+        models = [ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("model name")]
+        d["cpu_model"] = models[0] if models else None
+        d["sockets"] = len(set(ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("physical id"))) or None
+    except Exception:
+        d["cpu_model"] = None
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                d["cgroup_cpu_max"] = " ".join(txt)
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                    per = float(f2.read().split()[0])
+                d["cgroup_cpu_max"] = "%d %d" % (q, per)
+                if q > 0:
+                    quota = q / per
+            break
+        except Exception:
+            continue
+    d["cgroup_cpu_quota_cores"] = quota
+    try:
+        with open("/proc/meminfo") as f:
+            for ln in f:
+                if ln.startswith("MemAvailable"):
+                    d["mem_available_bytes"] = int(ln.split()[1]) * 1024
+    except Exception:
+        pass
+    return d
+
+
 def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows, seconds=10.0, all_cores=True, rows=None, queries=None):
     """reference kernel + reference top-k loop, one core, bounded sample (`seconds` of CPU work).  rows / queries: rows of the GPU's own
     corpus (corpus_sample) and the queries the GPU timed; without them (a box without torch) a numpy stream of the same distribution."""
@@ -213,28 +260,43 @@ def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows, seconds=10.0, all_co
                       else "a numpy sample of the corpus' distribution", sample_rows, dim, np.dtype(np_dtype).name, k, label, os.cpu_count())}
     if not all_cores:
         return out
-    # A ROW SPLIT of one corpus over every logical core of the host (a generous upper bound - the reference itself is one
-    # thread): oracle.c's pthread harness (orc_scan_topk_threads) - thread i loops the reference's kernel inside the reference's top-k loop
-    # over rows [i P, (i+1) P); a query's answer is the merge of the per-range lists, checked once against the unsplit scan.  No
-    # interpreter in the timed loop.
+    # A ROW SPLIT of one corpus over the host cores THIS PROCESS MAY USE (a generous upper bound - the reference itself is one
+    # thread): oracle.c's pthread harness (orc_scan_topk_threads_pinned) - thread i, pinned to the i-th CPU of the process' affinity mask, loops
+    # the reference's kernel inside the reference's top-k loop over its own range of the rows; a query's answer is the merge of the per-range
+    # lists, checked once against the unsplit scan.  No interpreter in the timed loop.  Every thread's private copy holds its range several
+    # times over (>= 64K rows: ~100 MB at 1.5 KB rows), so the timed scans stream from memory, not from a cache-resident 12 MB slice.
+    host = host_description()
+    out["host"] = {kk: vv for kk, vv in host.items() if kk != "affinity_cpus_list"}
     try:
         if ref is None:
             raise RuntimeError("needs oracle/_ref (the reference's own kernel)")
-        nthreads = max(1, os.cpu_count() or 1)
-        per = rows.shape[0] // nthreads
-        if per < 2048:
+        cpus = host["affinity_cpus_list"]
+        nthreads = len(cpus)
+        quota = host.get("cgroup_cpu_quota_cores")
+        if quota and quota < nthreads:                       # a CFS quota below the mask: more runnable threads than the quota only get throttled
+            nthreads = max(1, int(quota))
+        per = min(rows.shape[0] // nthreads, 16384)
+        if per < 1024:
             raise RuntimeError("sample too small for %d threads" % nthreads)
+        row_bytes = int(rows.strides[0])
+        repeat = max(1, -(-65536 // per))
+        budget = min(48 << 30, int(host.get("mem_available_bytes") or (8 << 30)) // 3)        # private copies: at most a third of what is free
+        repeat = max(1, min(repeat, budget // max(1, nthreads * per * row_bytes)))
         big = rows[:per * nthreads]
-        rate, per, ids, d, cnt = ref.scan_topk_all_cores(metric, vt, queries[:8], big, k, nthreads, 4.0)
+        rate, per, ids, d, cnt, pinned = ref.scan_topk_all_cores(metric, vt, queries[:8], big, k, nthreads, 4.0, cpus=cpus[:nthreads], repeat=repeat)
         cand = sorted((float(dd), int(i) - 1 + t * per) for t in range(nthreads) for i, dd in zip(ids[t][:cnt[t]], d[t][:cnt[t]]))[:k]
         whole = work(big, q)
         merged_ok = [c[1] + 1 for c in cand] == np.asarray(whole[0]).tolist()[:k] or sorted(c[0] for c in cand) == sorted(np.asarray(whole[1]).tolist()[:k])
-        out["all_cores"] = {"value": rate, "unit": "vectors/s", "cores": nthreads, "rows": int(per * nthreads),
-                            "merged_lists_equal_the_unsplit_scan": bool(merged_ok),
-                            "note": "a row split of ONE %d x %d matrix (%s) over %d pthreads = every logical core (oracle/oracle.c orc_scan_topk_threads): thread i "
-                                    "loops the reference's single-threaded kernel + top-k over rows [i P, (i+1) P), P = %d, 4 s; a query's answer = the merge "
-                                    "of the %d lists (done once, untimed)" % (per * nthreads, dim, "rows of the GPU's corpus" if same_inputs else "numpy sample",
-                                                                             nthreads, per, nthreads)}
+        out["all_cores"] = {"value": rate, "unit": "vectors/s", "cores": nthreads, "threads_pinned": int(pinned),
+                            "GB_per_s": rate * row_bytes / 1e9, "x_one_core": rate / out["value"] if out["value"] else None,
+                            "rows_per_thread_per_timed_scan": int(per * repeat), "private_copy_MB_per_thread": per * repeat * row_bytes / 1e6,
+                            "rows": int(per * nthreads), "merged_lists_equal_the_unsplit_scan": bool(merged_ok),
+                            "limited_by": ("cgroup cpu.max quota of %.1f cores (affinity mask: %d CPUs)" % (quota, len(cpus))) if (quota and quota < len(cpus))
+                                          else "the affinity mask (%d of the host's %d logical CPUs)" % (len(cpus), os.cpu_count() or 0),
+                            "note": "a row split of ONE %d x %d matrix (%s) over %d pinned pthreads (oracle/oracle.c orc_scan_topk_threads_pinned): thread i "
+                                    "loops the reference's single-threaded kernel + top-k over its range (P = %d rows, held %d x in memory its own CPU "
+                                    "touched first), 4 s; a query's answer = the merge of the %d lists (done once, untimed)"
+                                    % (per * nthreads, dim, "rows of the GPU's corpus" if same_inputs else "numpy sample", nthreads, per, repeat, nthreads)}
     except Exception as e:
         out["all_cores"] = {"value": None, "note": "unavailable: %r" % (e,)}
     return out
@@ -329,17 +391,19 @@ def run_batched(args, pkg, torch, corpus, workload, n_rows, dim, metric, k, desc
                                (("vg_batch_h_kernel<%d>" % ((dim + 15) // 16)) if (half or filt) else ("vg_batch_kernel<%d>" % ((dim + 7) // 8))),
                      "kernel_ms": kern_ms, "launches_timed": n_launch, "flops_per_launch": flops,
                      "note": "kernel_ms = pre-pass + main pass + merges of one batch on one shard" +
-                             ("; peak = the bf16 MFMA rate the filter runs at" if filt else "") +
-                             ("; query images + staged filter / exact-evaluation / merge launches of one batch; peak = the int8 MFMA rate the filter runs at" if q8 else ""),
+                             ("; query images + staged filter / exact-evaluation / merge launches of one batch; peak = the int8 MFMA rate the filter runs at" if q8
+                              else ("; peak = the bf16 MFMA rate the filter runs at" if filt else "")),
                      "batch_path": corpus.last_batch_path()}}
     if workload == "c5l" and q8:
         line["roofline"]["kernel"] = "vg_batch_q8_kernel<16 k-steps x %d K-parts, 8 wavefronts x 32 queries> + vg_batch_hx_kernel" % (((dim + 31) // 32 + 15) // 16)
     elif workload == "c5l":
         line["roofline"]["kernel"] = "vg_batch_hl_kernel<%d k-steps per wavefront> + vg_batch_hx_kernel" % (((dim * 2 + 31) // 32 + 3) // 4)
-        tb, tsrc = batch_traffic("batch_hl_f32_via_bf16_dot_%dq_%d@%d" % (nq, dim, n_rows))
-        line["roofline"]["traffic"] = tb
-        if tsrc:
-            line["roofline"]["traffic_source"] = tsrc
+    # HBM bytes per BATCH from the PMC pass over the same batches (tools/pmc_batch.sh --json: FETCH_SIZE summed over every launch of one
+    # vg_scan_topk_batch call), while the batch kernels' sources are the ones that pass ran on
+    tb, tsrc = batch_traffic(batch_traffic_entry(corpus.last_batch_path(), "u8" if quantized else ("f16" if half else "f32"), metric, nq, dim, n_rows))
+    line["roofline"]["traffic"] = tb
+    if tsrc:
+        line["roofline"]["traffic_source"] = tsrc
     if single is not None:
         line["against_single_scans"] = single
     return line
@@ -649,19 +713,30 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-BATCH_KERNEL_SOURCES = ("vg_batch_h.hip", "vg_batch_hl.hip", "vg_batch_h_defs.h", "vg_batch_common.h", "vg_batch_api.hip", "vg_accum.h", "vg_half.h")
+BATCH_KERNEL_SOURCES = ("vg_batch.hip", "vg_batch_h.hip", "vg_batch_hl.hip", "vg_batch_q8.hip", "vg_batch_i8.hip", "vg_batch_h_defs.h", "vg_batch_common.h",
+                        "vg_batch_api.hip", "vg_accum.h", "vg_half.h")
+METRIC_NAMES = {1: "l2", 2: "l2sq", 3: "cosine", 4: "dot", 5: "l1"}
+
+
+def batch_traffic_entry(path, dtype, metric, nq, dim, n_rows):
+    """key of a batched workload in profiles/pmc_traffic.json: batch path (vg_corpus_last_batch_path), element type, metric, batch size, row length @ rows"""
+    return "batch_path%d_%s_%s_%dq_%d@%d" % (path, dtype, METRIC_NAMES.get(metric, str(metric)), nq, dim, n_rows)
+
+
+def batch_kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for name in BATCH_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "sqlite-vector_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def batch_traffic(entry):
     """HBM bytes per BATCH (all launches of one vg_scan_topk_batch call) from the PMC pass recorded in profiles/pmc_traffic.json under
     `entry` - only while the batch kernels' sources are the ones that pass was made on"""
-    import hashlib
     try:
-        h = hashlib.sha256()
-        for name in BATCH_KERNEL_SOURCES:
-            with open(os.path.join(ROOT, "sqlite-vector_amd", "csrc", name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
-        now = h.hexdigest()[:16]
+        now = batch_kernel_source_hash()
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ent = json.load(f).get(entry)
         if not ent:
@@ -964,6 +1039,29 @@ def selftest_launch(args, rank, world):
     return 0
 
 
+def rccl_record(torch, dist, share, n_dev):
+    """what the collective layer saw, for the N > 1 line: the backend, the RCCL version torch was built against, the communicator's size,
+    and an all_gather of (rank, device) pairs run once, untimed - a SCALE record then states by itself which ranks exchanged candidates"""
+    rec = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices_visible": n_dev}
+    try:
+        rec["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())       # (torch's name for RCCL on ROCm)
+    except Exception as e:
+        rec["nccl_version"] = "unavailable: %r" % (e,)
+    try:
+        dev = "cpu" if share else "cuda"
+        mine = torch.tensor([dist.get_rank(), torch.cuda.current_device()], dtype=torch.int64, device=dev)
+        got = torch.empty((dist.get_world_size(), 2), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(got, mine)
+        if not share:
+            torch.cuda.synchronize()
+        pairs = got.cpu().tolist()
+        rec["ranks_in_communicator"] = len(set(p[0] for p in pairs))
+        rec["rank_devices"] = [p[1] for p in sorted(pairs)]
+    except Exception as e:
+        rec["ranks_in_communicator"] = "all_gather failed: %r" % (e,)
+    return rec
+
+
 def load_shard_module():
     import importlib.util
     spec = importlib.util.spec_from_file_location("vg_shard", os.path.join(ROOT, "sqlite-vector_amd", "shard.py"))
@@ -1047,7 +1145,10 @@ def main():
             corpus.set_scan_filter(0)                                 # the f32 matrix-core kernel (the filters are the default for a corpus of this size)
         out = run_batched(args, pkg, torch, corpus, args.workload, n_rows, dim, metric, k, desc, the_dist, shard, n_gpus, rank,
                           share=share)
+        rccl = rccl_record(torch, dist, share, n_dev) if use_dist else None      # (a collective: every rank)
         if out is not None:
+            if rccl is not None:
+                out["rccl"] = rccl
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = batch_cpu_baseline(args, vt, np_dtype, dim, metric, k, sample=(pkg, torch, n_rows, 42 + rank))
             print(json.dumps(out))
@@ -1090,6 +1191,7 @@ def main():
         ab = out["roofline"]["algorithmic_bytes_per_launch"]
         out["roofline"]["per_rank"] = [{"rank": i, "kernel_ms": ms, "achieved": ab / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                                         "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0} for i, ms in enumerate(per)]
+        out["rccl"] = rccl_record(torch, dist, share, n_dev)
         if share:
             out["config"]["note"] = "VG_BENCH_SHARE_DEVICES=1: %d ranks share %d device(s), exchange over gloo - a functional check, not a measurement" % (n_gpus, n_dev)
     plain_last = dict(runner.last)
@@ -1158,17 +1260,29 @@ def make_summary(out):
         "c5_f32_mfma": {"ms_per_step": g(c5, "ms_per_step"), "frac_of_f32_mfma_peak": g(c5, "roofline", "frac")},
         "c5_bf16_filter": {"ms_per_step": g(c5, "filter_batch", "ms_per_step"), "frac_of_bf16_peak": g(c5, "filter_batch", "frac_of_bf16_peak")},
         "c5_default_int8_filter": {"ms_per_step": g(c5, "int8_filter_batch", "ms_per_step"), "frac_of_int8_peak": g(c5, "int8_filter_batch", "frac_of_int8_peak"),
-                                   "batch_path": g(c5, "int8_filter_batch", "batch_path"),
+                                   "batch_path": g(c5, "int8_filter_batch", "batch_path"), "hbm_traffic_bytes_per_batch": g(c5, "int8_filter_batch", "traffic"),
                                    "bit_identical_to_bf16_filter": g(c5, "int8_filter_batch", "last_batch_bit_identical_to_the_bf16_filter"),
                                    "max_rel_vs_reference_kernel": g(c5, "int8_filter_batch", "last_batch_max_rel_difference_from_the_reference_kernel")},
         "long_rows_1536": {"ms_per_step": g(a, "long_rows", "ms_per_step"), "frac": g(a, "long_rows", "roofline", "frac"),
                            "of": "int8 peak" if g(a, "long_rows", "roofline", "batch_path") == 7 else "bf16 peak",
-                           "batch_path": g(a, "long_rows", "roofline", "batch_path"),
+                           "batch_path": g(a, "long_rows", "roofline", "batch_path"), "hbm_traffic_bytes_per_batch": g(a, "long_rows", "roofline", "traffic"),
                            "bf16_ksplit_ms_per_step": g(a, "long_rows", "bf16_ksplit_batch", "ms_per_step"),
                            "bit_identical_to_bf16_ksplit": g(a, "long_rows", "bf16_ksplit_batch", "last_batch_bit_identical_to_the_default_path")},
+        # what a user of vector_full_scan / vector_quantize_scan gets by default at this size: the filter scans
+        "c2_default_filter_scan": {"ms_per_step": g(out, "filter_scan", "ms_per_step"), "kernel_ms": g(out, "filter_scan", "kernel_ms"),
+                                   "frac_on_streamed": g(out, "filter_scan", "frac_on_streamed"),
+                                   "exact_evaluations_per_query": g(out, "filter_scan", "exact_evaluations_per_query"),
+                                   "outside_kernel_us": g(out, "filter_scan", "caller_view", "outside_kernel_us")},
+        "c3_default_nibble_filter_scan": {"ms_per_step": g(a, "c3", "filter_scan", "ms_per_step"), "kernel_ms": g(a, "c3", "filter_scan", "kernel_ms"),
+                                          "frac_on_streamed": g(a, "c3", "filter_scan", "frac_on_streamed"),
+                                          "exact_evaluations_per_query": g(a, "c3", "filter_scan", "exact_evaluations_per_query"),
+                                          "outside_kernel_us": g(a, "c3", "filter_scan", "caller_view", "outside_kernel_us")},
+        "clustered": g(a, "clustered", "summary"),
         "c1_sql_p50_ms": g(a, "c1", "p50_query_latency_ms"),
         "cpu_reference_1_core_vectors_per_s": g(out, "cpu_baseline", "value"),
-        "cpu_reference_all_cores": {"vectors_per_s": g(out, "cpu_baseline", "all_cores", "value"), "cores": g(out, "cpu_baseline", "all_cores", "cores")},
+        "cpu_reference_all_cores": {"vectors_per_s": g(out, "cpu_baseline", "all_cores", "value"), "cores": g(out, "cpu_baseline", "all_cores", "cores"),
+                                    "GB_per_s": g(out, "cpu_baseline", "all_cores", "GB_per_s"), "x_one_core": g(out, "cpu_baseline", "all_cores", "x_one_core"),
+                                    "limited_by": g(out, "cpu_baseline", "all_cores", "limited_by"), "cpu_model": g(out, "cpu_baseline", "host", "cpu_model")},
     }
 
 
@@ -1359,9 +1473,8 @@ def also_c5(args, pkg, torch, corpus, n_rows, k):
                     int(np.sum(np.asarray(fres[0]) != np.asarray(plain_res[0]))), int(np.asarray(fres[0]).size)),
                 "last_batch_max_rel_distance_difference": float(np.max(np.abs(d_f - d_p) / np.maximum(np.abs(d_p), 1e-30))) if d_f.shape == d_p.shape else None,
             }
-            tb, tsrc = batch_traffic("batch_h_f32_via_bf16_dot_1024q@%d" % n_rows)
-            line["filter_batch"]["traffic"] = tb                # HBM bytes per batch (PMC FETCH_SIZE pass); the tile-major bf16 copy is 7.68 GB
-            line["filter_batch"]["traffic_source"] = tsrc
+            line["filter_batch"]["traffic"] = fl["roofline"].get("traffic")      # HBM bytes per batch (PMC FETCH_SIZE pass); the tile-major bf16 copy is 7.68 GB
+            line["filter_batch"]["traffic_source"] = fl["roofline"].get("traffic_source")
         except Exception as e:
             line["filter_batch"] = {"error": repr(e)}
         finally:
@@ -1385,6 +1498,7 @@ def also_c5(args, pkg, torch, corpus, n_rows, k):
                   "speedup_over_bf16_filter": (line["filter_batch"]["ms_per_step"] / ql["ms_per_step"]) if "ms_per_step" in line.get("filter_batch", {}) else None,
                   "last_batch_bit_identical_to_the_bf16_filter": bool(fres is not None and np.array_equal(np.asarray(qres[0]), np.asarray(fres[0])) and
                                                                       np.array_equal(np.asarray(qres[1]), np.asarray(fres[1]))),
+                  "traffic": ql["roofline"].get("traffic"), "traffic_source": ql["roofline"].get("traffic_source"),
                   "exact_evaluations_per_query": None}
             try:
                 ib["exact_evaluations_per_query"] = corpus.batch_filter_exact_evals() / float(args.batch * (min(args.steps, 10) + min(args.warmup, 2)))

@@ -10,6 +10,9 @@
  *
  * Citations: file:line relative to /root/reference/src/.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE 1              /* pthread_setaffinity_np, CPU_SET (the all-cores harness of the CPU baseline) */
+#endif
 #include "oracle.h"
 
 #include <float.h>
@@ -807,6 +810,9 @@ typedef struct {
     int64_t *first_ids;              /* k: the list of query 0 over this range (positions 1-based within the range) */
     double *first_dist;
     int first_cnt;
+    int cpu;                         /* >= 0: the logical CPU this thread pins itself to (one of the process' affinity mask) */
+    int repeat;                      /* the thread's private copy holds its range `repeat` times over: the timed scans stream that much memory */
+    int pinned;                      /* out: pthread_setaffinity_np succeeded */
 } orc_thread_arg;
 
 static void *orc_thread_main(void *p) {
@@ -815,17 +821,30 @@ static void *orc_thread_main(void *p) {
     double dist[256];
     /* the thread's range in memory it touched first itself: on a multi-socket host the pages then live on the thread's own NUMA node (one
      * numpy array, written by one thread, sits on one node: 256 threads streamed it at 84 GB/s, 2.1x one core) */
+    a->pinned = 0;
+    if (a->cpu >= 0) {                                               /* before the first touch: the pages follow the thread's CPU */
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(a->cpu, &set);
+        a->pinned = pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0;
+    }
     const size_t bytes = (size_t)a->n_rows * (size_t)a->row_stride;
-    uint8_t *mine = (uint8_t *)malloc(bytes);
-    if (mine) { memcpy(mine, a->rows, bytes); a->rows = mine; }
+    const int rep = a->repeat > 1 ? a->repeat : 1;
+    uint8_t *mine = (uint8_t *)malloc(bytes * (size_t)rep);
+    int have = 0;
+    if (mine) { for (have = 0; have < rep; ++have) memcpy(mine + (size_t)have * bytes, a->rows, bytes); a->rows = mine; }
+    else have = 1;
+    /* the checked list: query 0 over the range itself (the first of the copies) */
     a->first_cnt = orc_scan_topk_with_fn(a->fn, a->queries, a->rows, a->n_rows, a->row_stride, a->dim, NULL, a->k, a->first_ids, a->first_dist);
+    const int64_t timed_rows = a->n_rows * have;
+    orc_scan_topk_with_fn(a->fn, a->queries, a->rows, timed_rows, a->row_stride, a->dim, NULL, a->k, ids, dist);       /* warm */
     __sync_fetch_and_add(a->ready, 1);
     while (!*a->go) sched_yield();
     int qi = 0;
     while (!*a->stop) {
         qi = qi + 1 == a->nq ? 0 : qi + 1;
-        orc_scan_topk_with_fn(a->fn, a->queries + (int64_t)qi * a->query_stride, a->rows, a->n_rows, a->row_stride, a->dim, NULL, a->k, ids, dist);
-        a->scans += 1;
+        orc_scan_topk_with_fn(a->fn, a->queries + (int64_t)qi * a->query_stride, a->rows, timed_rows, a->row_stride, a->dim, NULL, a->k, ids, dist);
+        a->scans += have;                                            /* in units of one pass over the thread's range */
     }
     free(mine);
     return NULL;
@@ -836,6 +855,17 @@ static void *orc_thread_main(void *p) {
 int orc_scan_topk_threads(orc_distance_fn fn, const void *queries, int nq, int64_t query_stride, const void *rows, int64_t n_rows,
                           int64_t row_stride, int dim, int k, int nthreads, double seconds, int64_t *out_first_ids, double *out_first_dist,
                           int *out_counts, int64_t *out_rows_per_thread, double *out_elapsed, int64_t *out_scans) {
+    return orc_scan_topk_threads_pinned(fn, queries, nq, query_stride, rows, n_rows, row_stride, dim, k, nthreads, seconds, NULL, 1, out_first_ids,
+                                        out_first_dist, out_counts, out_rows_per_thread, out_elapsed, out_scans, NULL);
+}
+
+/* the same with thread i pinned to logical CPU cpus[i] (NULL: the scheduler places them) and every thread's private copy holding its range
+ * `repeat` times over - a thread then streams repeat x P rows per timed scan (far beyond its caches) from memory its own CPU touched first;
+ * out_pinned (may be NULL): threads whose pthread_setaffinity_np succeeded.  out_scans counts passes over P rows. */
+int orc_scan_topk_threads_pinned(orc_distance_fn fn, const void *queries, int nq, int64_t query_stride, const void *rows, int64_t n_rows,
+                                 int64_t row_stride, int dim, int k, int nthreads, double seconds, const int *cpus, int repeat,
+                                 int64_t *out_first_ids, double *out_first_dist, int *out_counts, int64_t *out_rows_per_thread,
+                                 double *out_elapsed, int64_t *out_scans, int *out_pinned) {
     if (nthreads < 1 || k < 1 || k > 256 || nq < 1 || n_rows < nthreads) return -1;
     const int64_t per = n_rows / nthreads;
     pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
@@ -849,6 +879,7 @@ int orc_scan_topk_threads(orc_distance_fn fn, const void *queries, int nq, int64
         a->rows = (const uint8_t *)rows + (int64_t)i * per * row_stride; a->n_rows = per; a->row_stride = row_stride;
         a->dim = dim; a->k = k; a->go = &go; a->stop = &stop; a->ready = &ready; a->scans = 0;
         a->first_ids = out_first_ids + (int64_t)i * k; a->first_dist = out_first_dist + (int64_t)i * k;
+        a->cpu = cpus ? cpus[i] : -1; a->repeat = repeat; a->pinned = 0;
         if (pthread_create(&th[i], NULL, orc_thread_main, a) != 0) break;
         ++started;
     }
@@ -863,7 +894,9 @@ int orc_scan_topk_threads(orc_distance_fn fn, const void *queries, int nq, int64
     for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     int64_t scans = 0;
-    for (int i = 0; i < started; ++i) { scans += args[i].scans; out_counts[i] = args[i].first_cnt; }
+    int pinned = 0;
+    for (int i = 0; i < started; ++i) { scans += args[i].scans; out_counts[i] = args[i].first_cnt; pinned += args[i].pinned; }
+    if (out_pinned) *out_pinned = pinned;
     *out_rows_per_thread = per;
     *out_elapsed = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     *out_scans = scans;

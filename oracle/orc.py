@@ -58,6 +58,10 @@ def _lib():
     lib.orc_scan_topk_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                           C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_scan_topk_threads.restype = C.c_int
+    lib.orc_scan_topk_threads_pinned.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                                 C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p]
+    lib.orc_scan_topk_threads_pinned.restype = C.c_int
     lib.orc_quantize.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int]
     lib.orc_quant_params.restype = None
     lib.orc_quant_params.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
@@ -214,22 +218,27 @@ class RefKernels:
                                           rows.shape[1], None, k, _ptr(out_ids), _ptr(out_d))
         return out_ids[:cnt], out_d[:cnt]
 
-    def scan_topk_all_cores(self, metric, vtype, queries, rows, k, nthreads, seconds):
+    def scan_topk_all_cores(self, metric, vtype, queries, rows, k, nthreads, seconds, cpus=None, repeat=1):
         """the reference's kernel inside the reference's top-k loop on `nthreads` pthreads, a row split of `rows` (oracle.c:
-        orc_scan_topk_threads); returns (vectors scanned per second, rows per thread, per-range lists of query 0: ids, dist, counts)"""
+        orc_scan_topk_threads_pinned): thread i pinned to logical CPU cpus[i] (None: unpinned), its private copy holding its range `repeat`
+        times over; returns (vectors scanned per second, rows per thread, per-range lists of query 0: ids, dist, counts, threads pinned)"""
         rows = np.ascontiguousarray(rows)
         queries = np.ascontiguousarray(queries)
         fnptr = C.cast(self.table[metric][vtype], C.c_void_p)
         first_ids = np.zeros((nthreads, k), dtype=np.int64)
         first_d = np.zeros((nthreads, k), dtype=np.float64)
         counts = np.zeros(nthreads, dtype=np.int32)
-        per, el, scans = C.c_int64(0), C.c_double(0.0), C.c_int64(0)
-        rc = lib().orc_scan_topk_threads(fnptr, _ptr(queries), queries.shape[0], queries.strides[0], _ptr(rows), rows.shape[0], rows.strides[0],
-                                         rows.shape[1], k, nthreads, float(seconds), _ptr(first_ids), _ptr(first_d), _ptr(counts),
-                                         C.byref(per), C.byref(el), C.byref(scans))
+        per, el, scans, pinned = C.c_int64(0), C.c_double(0.0), C.c_int64(0), C.c_int(0)
+        cpu_arr = np.ascontiguousarray(np.asarray(cpus, dtype=np.int32)) if cpus is not None else None
+        if cpu_arr is not None and cpu_arr.shape[0] < nthreads:
+            raise ValueError("cpus: one logical CPU per thread")
+        rc = lib().orc_scan_topk_threads_pinned(fnptr, _ptr(queries), queries.shape[0], queries.strides[0], _ptr(rows), rows.shape[0], rows.strides[0],
+                                                rows.shape[1], k, nthreads, float(seconds), _ptr(cpu_arr) if cpu_arr is not None else None, int(repeat),
+                                                _ptr(first_ids), _ptr(first_d), _ptr(counts), C.byref(per), C.byref(el), C.byref(scans),
+                                                C.byref(pinned))
         if rc != 0:
-            raise RuntimeError("orc_scan_topk_threads: %d" % rc)
-        return scans.value * per.value / el.value, per.value, first_ids, first_d, counts
+            raise RuntimeError("orc_scan_topk_threads_pinned: %d" % rc)
+        return scans.value * per.value / el.value, per.value, first_ids, first_d, counts, pinned.value
 
     def scan(self, metric, vtype, query, rows):
         rows = np.ascontiguousarray(rows)

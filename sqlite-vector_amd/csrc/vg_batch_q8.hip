@@ -57,11 +57,29 @@ typedef int vgq_i32x16 __attribute__((ext_vector_type(16)));
 #define VGQ_QCAP 16                     // candidate lanes a wavefront collects before it looks at their accumulators (160 bytes each)
 #define VGQ_STAT_SLOTS 8                // ring of row-statistics groups (two tiles = 1 KiB each)
 #define VGQ_STAGE0_TILES 2              // the first stage: every pair passes (32 queries x 32 rows per region and tile <= the pair capacity)
+#ifndef VGQ_TPB
+#define VGQ_TPB 3                       // short rows: ring trips (tiles) per workgroup barrier where the ring has six buffers (see the tile loop)
+#endif
 #ifndef VGQ_ABLATE
 #define VGQ_ABLATE 0                    // measurement builds (wrong results): 1 = candidates dropped; 2 = no gate; 3 = + no LDS-DMA; 4 = + no barrier
 #endif
 #ifndef VGQ_STATS
 #define VGQ_STATS 0                     // measurement builds: counters of the tile boundary (wave-tiles | that went on to single accumulators | candidates | pairs)
+#endif
+#ifndef VGQ_TIMING
+#define VGQ_TIMING 0                    // measurement builds: shader-clock ticks per wavefront class (tools/r6_q8_timing.py)
+#endif
+#if VGQ_TIMING
+// [0..7] wavefronts 0-3, [8..15] wavefronts 4-7 of the eight-wavefront forms: whole tile loop | k loops | boundaries | trip-end wait + barrier | wave-tiles | boundaries that queued a candidate | queue runs | -
+__device__ unsigned long long vgq_ticks[16];
+extern "C" int vg_batch_q8_timing(unsigned long long *out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(vgq_ticks), sizeof(vgq_ticks)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vgq_ticks), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define VGQ_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define VGQ_TICK(var)
 #endif
 #if VGQ_STATS
 __device__ unsigned long long vgq_stats[8];
@@ -399,12 +417,22 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
     // barrier of trip 2j - 3 at the latest the group has landed - without any wait of its own (waiting for it on the spot meant waiting
     // for the pieces issued in the same trip: a full memory round trip every other tile, for all four wavefronts at the barrier).
     // (K-parts: a group is issued LEAD = 2 tiles = 2 KS trips ahead - more than the NB - 2 trips the counted wait may leave outstanding)
+    // TRIPS PER BARRIER (round 6).  Measured with a cycle counter per wavefront (profiles/r10_q8_cycles_per_wave_tile.txt): the SIMD's arbiter
+    // favours the older of its two wavefronts, so waves 0-3 finish a tile's MFMAs after ~1 000 cycles and waves 4-7 after ~1 650; then the
+    // younger half runs its boundary and everybody meets at the barrier - ~1 300 of a tile's ~3 000 cycles with no MFMA in the pipe, because a
+    // wavefront that is done with tile t may not start tile t + 1.  The ring is six tiles deep, so the barrier can wait: M trips form a GROUP,
+    // the workgroup meets once per group, and inside a group a wavefront goes from tile to tile on its own (the older half's next k loop runs
+    // under the younger half's boundary).  Group g reads buffers that landed before its first tile; its tiles issue the DMA of a later group into the
+    // buffers of group g - 1, which every wavefront has left (the barrier in between).  M = 1 is the barrier per trip of round 5.
+    constexpr int M = KS > 1 ? 1 : (NB % VGQ_TPB == 0 && NB >= 2 * VGQ_TPB ? VGQ_TPB : (NB % 2 == 0 && NB >= 4 ? 2 : 1));
+    constexpr int LOOK = NB / M - 1;                                 // groups beyond the current one that are resident or on their way
+    static_assert(LOOK >= 1 && NB % M == 0, "ring of whole groups");
     constexpr int LEAD = KS == 1 ? NB : 2;                           // tiles between a group's issue and its first use
     constexpr int SPRE = (LEAD + 1) / 2;                             // groups loaded up front: j with 2j - LEAD < 0
     const int U = T * KS;                                            // ring trips of this partition
     if (T > 0) {
         if (wave < SPRE && 2 * wave < T + 1) dma_stat_group(tile_first + 2 * wave, wave);
-        vgb_static_for<0, NB - 1>([&](auto jc) {                     // trips 0 .. NB - 2 into buffers 0 .. NB - 2
+        vgb_static_for<0, NB - M>([&](auto jc) {                     // trips 0 .. NB - M - 1 into buffers 0 .. NB - M - 1
             constexpr int j = decltype(jc)::value;
             dma_share(min(j, U - 1), j);
         });
@@ -491,47 +519,13 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
     constexpr int BP = VGQ_BPIPE < NTB ? VGQ_BPIPE : NTB;
     vgh_i32x4 bq[BP];
     int cur_buf = 0;
-    for (int ti = 0; ti < T; ++ti) {
-        const long long tile = tile_first + ti;
-        const int sj = (ti + LEAD) >> 1;                                      // the statistics group this tile's first trip may issue
-        const bool stat_turn = ((ti + LEAD) & 1) == 0 && 2 * sj < T + 1 && wave == (sj & (WAVES - 1));
-        const long long row_cur = tile * VGQ_TILE + x;
-        vgq_i32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
-        // one ring trip per K-part of the tile (KS = 1: the whole row): the accumulators run on across the parts
-        vgb_static_for<0, KS>([&](auto kc) {
-        constexpr int kp = decltype(kc)::value;
-        const int fill_buf = cur_buf == 0 ? NB - 1 : cur_buf - 1;
-        const int u_next = min(ti * KS + kp + NB - 1, U - 1);                 // the trip whose DMA this trip issues
-        const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
-        vgb_static_for<0, BP>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            vgq_lds_read128<1024 * t>(bq[t], baddr);
-        });
-        vgb_static_for<0, NTB>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            constexpr int in_flight_after = (NTB - 1 - t) < (BP - 1) ? (NTB - 1 - t) : (BP - 1);
-            vgq_wait_lds<in_flight_after>(bq[t % BP]);
-            const vgh_i32x4 b = bq[t % BP];
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][kp * NTB + t], b, acc0, 0, 0, 0);
-            if constexpr (QS > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[QS - 1][kp * NTB + t], b, acc1, 0, 0, 0);
-            if constexpr (t + BP < NTB) vgq_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
-            if constexpr (t == 0 && VGQ_ABLATE < 3) {
-                if (kp == 0 && stat_turn) dma_stat_group(tile_first + 2 * sj, sj & (VGQ_STAT_SLOTS - 1));
-                dma_share(u_next, fill_buf);
-            }
-            // nothing else moves into the k loop: left alone, the compiler sinks the tile boundary's float work (thresholds from the row
-            // statistics) between the MFMAs - and every extra issue slot between two MFMAs on one accumulator stalls the chain
-            // (MI355X_MICROARCH.md: + 43 cycles for the first one): last stage of 1024 x 10M x 384 2.65 ms against 1.88
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        if constexpr (kp == KS - 1) {
+    // ---- tile boundary of tile ti over the accumulators acc0 / acc1.  First test, per query set: the lane's LARGEST accumulator of the set
+    // against the set's loosest gate, as an integer: I >= ithr = (-(amax ||ex|| + bbmax ||x|| + ccmax - m uumin)) / sx, rounded down.  Only a
+    // set with a lane that passes looks at single accumulators (the same integer comparison, eight registers at a time), and only those
+    // pairs get the query's own four coefficients.
+    auto boundary = [&](int ti, const vgq_i32x16 &acc0, const vgq_i32x16 &acc1) __attribute__((always_inline)) {
+        const long long row_cur = (tile_first + ti) * VGQ_TILE + x;
         const float4 rs = rstat_lds[((ti >> 1) & (VGQ_STAT_SLOTS - 1)) * 64 + (ti & 1) * 32 + x];
-        // ---- tile boundary.  First test, per query set: the lane's LARGEST accumulator of the set against the set's loosest gate, as an
-        // integer: I >= ithr = (-(amax ||ex|| + bbmax ||x|| + ccmax - m uumin)) / sx, rounded down.  Only a set with a lane that passes
-        // looks at single accumulators (the same integer comparison, eight registers at a time), and only those pairs get the query's
-        // own four coefficients.
         if (VGQ_ABLATE >= 2) asm volatile("" :: "v"(acc0[0]), "v"(acc0[15]), "v"(acc1[0]), "v"(acc1[15]));
         const float sx = rs.x, rx = rs.y, nx = rs.z;
         const float inv_sx = __frcp_rn(sx);                            // (a zero row: +Inf - its accumulators are all 0 and the sign of `rest` decides)
@@ -586,17 +580,79 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
                 if (n_q == (unsigned)VGQ_QCAP) { if (VGQ_ABLATE == 7 || VGQ_ABLATE == 8) n_q = 0; else process_queue(); }
             }
         }
-        }
-        // trip end: the next trip's pieces have landed (an issuing wavefront leaves the pieces of the NB - 2 youngest trips in flight:
-        // loads return in order), barrier: every wavefront has read this buffer, the next one is readable
-        if (counted_wait) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NB - 2) * NPIECE) : "memory");
+    };
+    vgq_i32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
+#ifdef VGQ_PRIO_EXPERIMENT
+    if (VGQ_PRIO_EXPERIMENT == 1 && WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(2);
+    if (VGQ_PRIO_EXPERIMENT == 2 && WAVES == 8 && (wave & 1)) __builtin_amdgcn_s_setprio(2);
+#endif
+#if VGQ_TIMING
+    unsigned long long tk_k = 0, tk_b = 0, tk_w = 0, tk_v = 0;
+    const unsigned long long tk_loop0 = __builtin_readcyclecounter();
+#endif
+    for (int ti = 0; ti < T; ++ti) {
+        const int sj = (ti + LEAD) >> 1;                                      // the statistics group this tile's first trip may issue
+        const bool stat_turn = ((ti + LEAD) & 1) == 0 && 2 * sj < T + 1 && wave == (sj & (WAVES - 1));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
+        // one ring trip per K-part of the tile (KS = 1: the whole row): the accumulators run on across the parts
+        vgb_static_for<0, KS>([&](auto kc) {
+        constexpr int kp = decltype(kc)::value;
+        VGQ_TICK(tk0);
+        const int fill_buf = cur_buf + NB - M >= NB ? cur_buf - M : cur_buf + NB - M;   // (a buffer of the previous group)
+        const int u_next = min(ti * KS + kp + NB - M, U - 1);                 // the trip whose DMA this trip issues
+        const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
+        vgb_static_for<0, BP>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            vgq_lds_read128<1024 * t>(bq[t], baddr);
+        });
+        vgb_static_for<0, NTB>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int in_flight_after = (NTB - 1 - t) < (BP - 1) ? (NTB - 1 - t) : (BP - 1);
+            vgq_wait_lds<in_flight_after>(bq[t % BP]);
+            const vgh_i32x4 b = bq[t % BP];
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][kp * NTB + t], b, acc0, 0, 0, 0);
+            if constexpr (QS > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[QS - 1][kp * NTB + t], b, acc1, 0, 0, 0);
+            if constexpr (t + BP < NTB) vgq_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
+            if constexpr (t == 0 && VGQ_ABLATE < 3) {
+                if (kp == 0 && stat_turn) dma_stat_group(tile_first + 2 * sj, sj & (VGQ_STAT_SLOTS - 1));
+                dma_share(u_next, fill_buf);
+            }
+            // nothing else moves into the k loop: left alone, the compiler sinks the tile boundary's float work (thresholds from the row
+            // statistics) between the MFMAs - and every extra issue slot between two MFMAs on one accumulator stalls the chain
+            // (MI355X_MICROARCH.md: + 43 cycles for the first one): last stage of 1024 x 10M x 384 2.65 ms against 1.88
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        VGQ_TICK(tk1);
+        if constexpr (kp == KS - 1) boundary(ti, acc0, acc1);
+        VGQ_TICK(tk2);
+        // group end: the next group's pieces have landed (an issuing wavefront leaves the pieces of the (LOOK - 1) M youngest trips in
+        // flight: loads return in order), barrier: every wavefront has read this group's buffers, the next group's are readable
+        if (M == 1 || (ti * KS + kp) % M == M - 1) {
+        if (counted_wait) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LOOK - 1) * M * NPIECE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" ::: "memory");
+#if VGQ_TIMING
+        { const unsigned long long tkv = __builtin_readcyclecounter(); tk_v += tkv - tk2; }
+#endif
         if (VGQ_ABLATE < 4) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        }
         cur_buf = cur_buf + 1 == NB ? 0 : cur_buf + 1;
+#if VGQ_TIMING
+        { const unsigned long long tk3 = __builtin_readcyclecounter(); tk_k += tk1 - tk0; tk_b += tk2 - tk1; tk_w += tk3 - tk2; }
+#endif
         });
     }
+#if VGQ_TIMING
+    if (lane == 0 && T > 64) {
+        const int o = (WAVES == 8 && wave >= 4) ? 8 : 0;
+        atomicAdd(&vgq_ticks[o + 0], __builtin_readcyclecounter() - tk_loop0); atomicAdd(&vgq_ticks[o + 1], tk_k); atomicAdd(&vgq_ticks[o + 2], tk_b);
+        atomicAdd(&vgq_ticks[o + 3], tk_w); atomicAdd(&vgq_ticks[o + 4], (unsigned long long)T); atomicAdd(&vgq_ticks[o + 5], tk_v);
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (no LDS-DMA of the ring may land after this workgroup's LDS is gone)
 #if VGQ_STATS
     if (lane == 0) { atomicAdd(&vgq_stats[0], (unsigned long long)T); atomicAdd(&vgq_stats[1], (unsigned long long)st_slow);
