@@ -327,6 +327,9 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
                                   uint64_t *dev_cand, int npart, uint64_t *dev_out_keys, unsigned long long *dev_evals,
                                   uint64_t *dev_pairs, uint32_t *dev_pair_counts, int pair_cap, int type_code, hipStream_t stream);
 extern "C" int vg_batch_q8_workgroups_per_cu(long long q8stride_bytes);
+extern "C" size_t vg_batch_q8_pack_bytes(int nq_pad, int k);
+extern "C" int vg_batch_q8_pack_launch(const uint64_t *dev_keys, const void *dev_qwork, int nq_pad, long long q8stride, long long xstride, int k,
+                                       const uint32_t *dev_overflow_flag, const unsigned long long *dev_evals, void *dev_out, hipStream_t stream);
 static long long q8_shadow_stride_of(const vg_corpus *c) { return (((long long)c->dim + 15) / 16) * 16; }
 static bool batch_q8_eligible(const vg_corpus *c, int metric, int k, int nq) {
     const bool served_type = c->vtype == VG_TYPE_F32 || c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16;   // (the int8 image of the row, whatever it is stored as)
@@ -400,7 +403,8 @@ static int scan_topk_batch_q8(vg_corpus *c, int metric, const void *queries, int
                                     HIP_TRY(hipMalloc(&c->d_bpcounts, needc)); c->bpcount_bytes = needc; }
     // the f32 queries go up through the corpus' pinned buffer: zero-padded rows of the corpus stride, zero rows up to nq_pad; the queries'
     // statistics (which of them the filter could judge) come back through its tail
-    const size_t row_bytes = (size_t)c->dim * c->es, statbytes = (size_t)nq_pad * 36;        // statistics + the permutation
+    const size_t packbytes = vg_batch_q8_pack_bytes(nq_pad, k);                              // what comes back, packed by the device: one copy
+    const size_t row_bytes = (size_t)c->dim * c->es, statbytes = (packbytes + 15) / 16 * 16;
     if (c->h_bq_bytes < qrows + statbytes) {
         if (c->h_bq) hipHostFree(c->h_bq);
         c->h_bq = nullptr; c->h_bq_bytes = 0;
@@ -432,28 +436,28 @@ static int scan_topk_batch_q8(vg_corpus *c, int metric, const void *queries, int
     if (evs) { hipEventRecord(evs[2], c->stream); hipEventRecord(evs[3], c->stream); }
     if (rc == -1) { hipStreamSynchronize(c->stream); c->bq8_status = 2; return -1; }
     if (rc != 0) return vg_fail(VG_ERR_HIP, "batched scan launch (int8 filter) failed: %s", hipGetErrorString((hipError_t)rc));
-    // the lists come back in SORTED SLOT order (vg_batch_q8.hip sorts the batch by the int8 images' norms): slot p answers query perm[p]
-    uint32_t overflow = 0;
-    std::vector<uint64_t> keys((size_t)nq_pad * 64);
-    HIP_TRY(hipMemcpyAsync(&overflow, c->d_bpcounts + n_regions, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(keys.data(), c->d_bkeys, (size_t)nq_pad * 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    float *h_qstat = reinterpret_cast<float *>(c->h_bq + qrows);
-    int *h_perm = reinterpret_cast<int *>(c->h_bq + qrows + (size_t)nq_pad * 32);
-    HIP_TRY(hipMemcpyAsync(h_qstat, qwork + vg_batch_q8_work_stat_offset(nq_pad, qs, c->stride), (size_t)nq_pad * 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(h_perm, qwork + vg_batch_q8_work_perm_offset(nq_pad, qs, c->stride), (size_t)nq_pad * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_filter_evals + 1, c->d_filter_evals + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    // the lists come back in SORTED SLOT order (vg_batch_q8.hip sorts the batch by the int8 images' norms): slot p answers query perm[p];
+    // overflow flag, evaluation counter, permutation, judged flags and the k keys of every slot packed by the device into one buffer
+    // (straight into the pinned, device-mapped buffer - like the single scans' h_keys: a copy command behind the last kernel started ~0.17 ms late)
+    uint32_t *h_pack = reinterpret_cast<uint32_t *>(c->h_bq + qrows);
+    int rcp = vg_batch_q8_pack_launch(c->d_bkeys, qwork, nq_pad, qs, c->stride, k, c->d_bpcounts + n_regions, c->d_filter_evals + 1, h_pack, c->stream);
+    if (rcp != 0) return vg_fail(VG_ERR_HIP, "batched scan (int8 filter): result pack failed: %s", hipGetErrorString((hipError_t)rcp));
     HIP_TRY(hipStreamSynchronize(c->stream));
     vg_collect_timing(c);
-    if (overflow != 0) { c->bq8_cooldown = 16; c->bq8_status = 3; return -1; }   // (data the bound cannot separate: the next batches take the other paths)
+    c->h_filter_evals[1] = (unsigned long long)h_pack[2] | ((unsigned long long)h_pack[3] << 32);
+    if (h_pack[0] != 0) { c->bq8_cooldown = 16; c->bq8_status = 3; return -1; }   // (data the bound cannot separate: the next batches take the other paths)
     c->bq8_status = 0;
+    const int *h_perm = reinterpret_cast<const int *>(h_pack + 4);
+    const uint32_t *h_judged = h_pack + 4 + nq_pad;
+    const uint64_t *keys = reinterpret_cast<const uint64_t *>(h_pack + 4 + 2 * (size_t)nq_pad);
     std::vector<int> unjudged;
     for (int p = 0; p < nq_pad; ++p) {
         const int i = h_perm[p];
         if (i < 0 || i >= nq) continue;                                 // (padding)
-        if (h_qstat[(size_t)p * 8 + 5] == 0.0f) { unjudged.push_back(i); continue; }
+        if (h_judged[p] == 0u) { unjudged.push_back(i); continue; }
         int cnt = 0;
         for (int j = 0; j < k; ++j) {
-            const uint64_t key = keys[(size_t)p * 64 + j];
+            const uint64_t key = keys[(size_t)p * k + j];
             if (key == VG_EMPTY_KEY) break;
             out_keys[(size_t)i * k + cnt] = key;
             ++cnt;

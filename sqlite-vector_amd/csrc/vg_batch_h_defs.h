@@ -55,6 +55,10 @@ struct BatchArgsH {
     uint32_t *pair_counts;
     int pair_cap, n_regions;
     const float *qnn;         // vg_batch_hl.hip: (float) sum q^2 per query (nq_pad), made by the host once per batch
+    int part_group;           // vg_batch_hx_kernel (round 6): > 1 = ONE block walks the regions of part_group consecutive partitions of its 32 queries, one after the
+                              // other in scan order, into ONE set of lists: a late stage of the int8 filter has ~17 pairs per region, and 4 096 blocks that each
+                              // load 32 thresholds and write 32 x 64 keys (16 KB, which the merge reads again) cost ~65 us whatever the pairs; npart_total must be
+                              // a multiple, part_base 0, subs 1; the lists come out as npart_total / part_group lists per query
     int lds_pairs;            // vg_batch_hx_kernel: copy a region's pairs into LDS first (the launch provides pair_cap * 8 more bytes of it): the walk
                               // over them - 64 pair words per look, one look per pair - then costs LDS reads instead of an L2 round trip each
 };
@@ -99,11 +103,15 @@ __global__ __launch_bounds__(64 * VGHX_WAVES) void vg_batch_hx_kernel(BatchArgsH
     uint64_t *wave_lists = reinterpret_cast<uint64_t *>(thr_w + VGH_QPW);   // [32][k]
     const int lane = threadIdx.x & 63, k = a.k;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long region = blockIdx.x;
-    const int wave = (int)(region % waves);
-    const long long gp = region / waves;
-    const int part = (int)(gp % a.npart_total) - a.part_base, g = (int)(gp / a.npart_total);
+    const int PG = a.part_group > 1 ? a.part_group : 1;
+    const int lists_total = a.npart_total / PG;                        // lists per query this launch writes
+    const int wave = (int)(blockIdx.x % waves);
+    const long long gp = blockIdx.x / waves;
+    const int list_idx = (int)(gp % lists_total);                        // (PG == 1: the partition, counted from part_base)
+    const int g = (int)(gp / lists_total);
+    const int part = PG > 1 ? list_idx * PG : list_idx - a.part_base;
     if (part < 0 || part >= a.npart) return;
+    const long long region = PG > 1 ? ((long long)(g * a.npart_total + part) * waves + wave) : (long long)blockIdx.x;
     const int q0 = g * (waves * VGH_QPW) + wave * VGH_QPW;
     const int xchunks = (int)(a.xstride / 16);
     if (threadIdx.x < VGH_QPW) {
@@ -120,9 +128,11 @@ __global__ __launch_bounds__(64 * VGHX_WAVES) void vg_batch_hx_kernel(BatchArgsH
     }
     __syncthreads();
     unsigned n_all = 0;
-    for (int sub = 0; sub < subs; ++sub) {
-    const unsigned n = a.pair_counts[region * subs + sub];
-    const uint64_t *my_pairs = a.pairs + (region * subs + sub) * a.pair_cap;
+    const int nsub = PG > 1 ? min(PG, a.npart - part) : subs;
+    for (int sub = 0; sub < nsub; ++sub) {
+    const long long reg_s = PG > 1 ? region + (long long)sub * waves : region * subs + sub;
+    const unsigned n = a.pair_counts[reg_s];
+    const uint64_t *my_pairs = a.pairs + reg_s * a.pair_cap;
     if (a.lds_pairs) {                                                // (block-uniform)
         uint64_t *lp = wave_lists + VGH_QPW * k;
         __syncthreads();                                              // (the previous sub-region's copy is no longer read)
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(64 * VGHX_WAVES) void vg_batch_hx_kernel(BatchArgsH
     __syncthreads();
     for (int s = threadIdx.x; s < VGH_QPW * 64; s += 64 * VGHX_WAVES) {
         const int qi = s >> 6, slot = s & 63;
-        a.cand[((long long)(q0 + qi) * a.npart_total + a.part_base + part) * 64 + slot] = (slot < k) ? wave_lists[qi * k + slot] : VG_EMPTY_KEY;
+        a.cand[((long long)(q0 + qi) * lists_total + list_idx) * 64 + slot] = (slot < k) ? wave_lists[qi * k + slot] : VG_EMPTY_KEY;
     }
     if (a.evals && threadIdx.x == 0 && n_all) atomicAdd(a.evals, (unsigned long long)n_all);
 }

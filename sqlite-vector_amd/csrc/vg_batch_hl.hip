@@ -529,7 +529,7 @@ extern "C" int vg_batch_hl_launch(const uint8_t *dev_rows, long long n_rows, lon
     a.cerr = (float)(dim + 64) * 4.76837158203125e-7f + (type_code == 2 ? 0.0078125f + 1.52587890625e-5f : 0.0f);
     a.n_rows = n_rows; a.stride = stride_bytes; a.nq_pad = nq_pad; a.nq_real = nq_real; a.npart = npart; a.k = k;
     a.mode = mode; a.root = root; a.dim = dim; a.evals = dev_evals;
-    a.pairs = dev_pairs; a.pair_counts = dev_pair_counts; a.pair_cap = pair_cap; a.qnn = dev_query_nn; a.lds_pairs = 0;
+    a.pairs = dev_pairs; a.pair_counts = dev_pair_counts; a.pair_cap = pair_cap; a.qnn = dev_query_nn; a.lds_pairs = 0; a.part_group = 0;
     const int G = nq_pad / qpb;
     a.n_regions = G * npart * VGHL_WAVES;
     hipError_t e = hipMemsetAsync(dev_pair_counts + a.n_regions, 0, sizeof(uint32_t), stream);          // the overflow flag

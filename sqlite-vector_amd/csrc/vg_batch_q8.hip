@@ -54,12 +54,28 @@ typedef int vgq_i32x16 __attribute__((ext_vector_type(16)));
 #define VGQ_MAX_K 32
 #define VGQ_BPIPE 4
 #define VGQ_RING_OF(NTB) ((NTB) <= 8 ? 6 : (NTB) <= 12 ? 4 : 3)      // tile buffers: two workgroups' rings + statistics + queues fit 160 KB
+#ifndef VGQW_RING
+#define VGQW_RING 6                     // tile buffers of the wide form (eight wavefronts x two query sets, one workgroup per CU)
+#endif
+#define VGQW_RING_OF(NTB) ((VGQW_RING) * (NTB) <= 112 ? (VGQW_RING) : 6)
+#ifndef VGQ_DMA_AT_END
+#define VGQ_DMA_AT_END 1                // wide form: waves 0-3 issue a group's LDS-DMA behind their last boundary of the group, where they would wait for waves 4-7 (see the tile loop)
+#endif
 #define VGQ_QCAP 16                     // candidate lanes a wavefront collects before it looks at their accumulators (160 bytes each)
 #define VGQ_STAT_SLOTS 8                // ring of row-statistics groups (two tiles = 1 KiB each)
 #define VGQ_STAGE0_TILES 2              // the first stage: every pair passes (32 queries x 32 rows per region and tile <= the pair capacity)
 #ifndef VGQ_TPB
 #define VGQ_TPB 3                       // short rows: ring trips (tiles) per workgroup barrier where the ring has six buffers (see the tile loop)
 #endif
+#ifndef VGQ_PRE_TILES
+#define VGQ_PRE_TILES 1024              // the bound-only pre-pass: tiles it covers (at most 1/8 of the corpus; <= 2048: vg_q8_pre_select_kernel keeps 32 tile minima per lane)
+#endif
+#ifndef VGQ_HX_GROUP
+#define VGQ_HX_GROUP 4                  // partitions one exact-evaluation block walks at most (BatchArgsH.part_group)
+#endif
+#ifndef VGQ_FIRST_MULT
+#define VGQ_FIRST_MULT 4                // the first real stage ends at VGQ_FIRST_MULT x the pre-pass' tiles (long rows: 1 x - their bound is twice as wide
+#endif                                  // against the spread of the scores, and an exact evaluation reads up to 6 KB); measured: profiles/r10_q8_schedule_sweep.txt
 #ifndef VGQ_ABLATE
 #define VGQ_ABLATE 0                    // measurement builds (wrong results): 1 = candidates dropped; 2 = no gate; 3 = + no LDS-DMA; 4 = + no barrier
 #endif
@@ -106,6 +122,7 @@ struct BatchArgsQ8 {
     uint64_t *pairs;          // region = ((g * npart_total + part_base + part) * 8 + wave * 2 + set); a pair = (query in the set) << 32 | row
     uint32_t *pair_counts;    // [region] pairs written; [flag_index] = overflow flag
     int pair_cap, flag_index;
+    float *premin;            // PRE kernels: [tile - tile_begin][nq_pad] - per query slot the SMALLEST upper bound of the distance over the tile's 32 rows
 };
 
 __device__ __forceinline__ int vgq_q8(float v, float inv) {                 // (vgf_q8 of vg_scan_filter.h)
@@ -124,7 +141,7 @@ __device__ __forceinline__ int vgq_q8(float v, float inv) {                 // (
 // keys_out != NULL: only the sort key and the own scale of every query (original order) are written.
 // (qtype: the element type of the queries = the corpus' own: 0 f16, 1 bf16, 2 f32 - the int8 image is taken of the widened value)
 __global__ __launch_bounds__(256) void vg_q8_query_prep_kernel(const uint8_t *xq, long long xstride, int dim, int nq_real, int nq_pad, int mode,
-                                                               const int *perm, const float *common_scale, float *keys_out, float *scales_out,
+                                                               const int *perm, const float *common_scale, const float *all_scales, float *keys_out, float *scales_out,
                                                                uint8_t *xq_sorted, uint8_t *codes, long long qstride, float4 *qstat, int qtype) {
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
@@ -143,10 +160,18 @@ __global__ __launch_bounds__(256) void vg_q8_query_prep_kernel(const uint8_t *xq
     for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
     bool ok = q < nq_real && __ballot(bad != 0) == 0ull && mx >= VGQ_JUDGE_LO && mx <= VGQ_JUDGE_HI;
     float sq = ok ? mx / 127.0f : 1.0f;
-    if (ok && common_scale && mode == VGH_L2) {                           // (phase 2 of an L2 batch)
-        const float cs = *common_scale;
+    if (common_scale && mode == VGH_L2) {                                 // (phase 2 of an L2 batch)
+        // the shared scale = the largest own scale that is at most 4 x the scale of the batch's MEDIAN query (*common_scale, vg_q8_rank_kernel):
+        // 16 loads per lane + one reduction per wavefront - cheaper than a launch of its own
+        const float ref4 = 4.0f * *common_scale;
+        float cs = 0.0f;
+        for (int j = lane; j < nq_pad; j += 64) { const float sv = all_scales[j]; if (sv <= ref4) cs = fmaxf(cs, sv); }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) cs = fmaxf(cs, __shfl_xor(cs, s));
+        if (ok) {
         ok = sq <= cs && sq * 8.0f >= cs;                                 // (its elements fit the shared grid, and use at least four bits of it)
         sq = ok ? cs : 1.0f;
+        }
     }
     const float inv = 1.0f / sq;
     uint32_t i2 = 0;
@@ -177,45 +202,34 @@ __global__ __launch_bounds__(256) void vg_q8_query_prep_kernel(const uint8_t *xq
         qstat[2 * p + 1] = make_float4(q2s, judged ? 1.0f : 0.0f, 0.0f, 0.0f);
     }
 }
-// perm[rank of query i by (key, i)] = i, and the scale an L2 batch shares: one workgroup, every thread ranks its queries against all of
-// them (nq_pad <= 4096).  The shared scale is the largest own scale that is at most 4 x the scale of the batch's MEDIAN query (by key): one
-// query with a single huge element must not take the int8 grid away from all the others (it is answered by a single scan instead).
-__global__ __launch_bounds__(1024) void vg_q8_rank_kernel(const float *keys, const float *scales, int nq_pad, int *perm, float *common_scale) {
+// perm[rank of query i by (key, i)] = i, and the scale of the batch's MEDIAN query (by key) - what an L2 batch's shared scale is taken
+// from (vg_q8_query_prep_kernel, phase 2: one query with a single huge element must not take the int8 grid away from all the others; it is
+// answered by a single scan instead).  nq_pad / 256 workgroups, every thread ranks ONE query against all of them (nq_pad <= 4096: 16 KB of
+// keys in LDS per workgroup); round 5 ran this in one workgroup: 46 us of a 5 ms batch.
+__global__ __launch_bounds__(256) void vg_q8_rank_kernel(const float *keys, const float *scales, int nq_pad, int *perm, float *median_scale) {
     extern __shared__ __attribute__((aligned(16))) float vgq_keys_lds[];
-    __shared__ float smax[16];
-    __shared__ int sjudged[16];
-    __shared__ float sref;
+    __shared__ int sjudged[4];
     int judged = 0;
-    for (int i = threadIdx.x; i < nq_pad; i += 1024) { const float kv = keys[i]; vgq_keys_lds[i] = kv; judged += (kv < INFINITY) ? 1 : 0; }
+    for (int i = threadIdx.x; i < nq_pad; i += 256) { const float kv = keys[i]; vgq_keys_lds[i] = kv; judged += (kv < INFINITY) ? 1 : 0; }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) judged += __shfl_xor(judged, s);
     if ((threadIdx.x & 63) == 0) sjudged[threadIdx.x >> 6] = judged;
-    if (threadIdx.x == 0) sref = 0.0f;
     __syncthreads();
-    judged = 0;
-    for (int i = 0; i < 16; ++i) judged += sjudged[i];
+    judged = sjudged[0] + sjudged[1] + sjudged[2] + sjudged[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && judged == 0) *median_scale = 0.0f;
     const float4 *k4 = reinterpret_cast<const float4 *>(vgq_keys_lds);
-    for (int i = threadIdx.x; i < nq_pad; i += 1024) {
-        const float ki = vgq_keys_lds[i];
-        int rank = 0;
-        for (int j4 = 0; j4 < nq_pad / 4; ++j4) {                       // (nq_pad is a multiple of 256)
-            const float4 kj = k4[j4];
-            const int j = 4 * j4;
-            rank += (kj.x < ki || (kj.x == ki && j < i)) + (kj.y < ki || (kj.y == ki && j + 1 < i)) + (kj.z < ki || (kj.z == ki && j + 2 < i)) +
-                    (kj.w < ki || (kj.w == ki && j + 3 < i));
-        }
-        perm[rank] = i;
-        if (judged > 0 && rank == judged / 2) sref = scales[i];          // (the judged queries hold the first `judged` ranks)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq_pad) return;
+    const float ki = vgq_keys_lds[i];
+    int rank = 0;
+    for (int j4 = 0; j4 < nq_pad / 4; ++j4) {                           // (nq_pad is a multiple of 256)
+        const float4 kj = k4[j4];
+        const int j = 4 * j4;
+        rank += (kj.x < ki || (kj.x == ki && j < i)) + (kj.y < ki || (kj.y == ki && j + 1 < i)) + (kj.z < ki || (kj.z == ki && j + 2 < i)) +
+                (kj.w < ki || (kj.w == ki && j + 3 < i));
     }
-    __syncthreads();
-    const float ref4 = 4.0f * sref;
-    float m = 0.0f;
-    for (int i = threadIdx.x; i < nq_pad; i += 1024) { const float sv = scales[i]; if (sv <= ref4) m = fmaxf(m, sv); }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
-    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) { float t = 0.0f; for (int i = 0; i < 16; ++i) t = fmaxf(t, smax[i]); *common_scale = t; }
+    perm[rank] = i;
+    if (judged > 0 && rank == judged / 2) *median_scale = scales[i];     // (the judged queries hold the first `judged` ranks; one writer)
 }
 
 // ---- per-row statistics in the layout the filter's LDS-DMA moves (16 bytes per row)
@@ -232,6 +246,41 @@ __global__ __launch_bounds__(256) void vg_q8_rstat_kernel(const float2 *q8stat, 
     }
 }
 
+// ---- the start thresholds out of the pre-pass: per query slot the k-th smallest of its tile minima (premin[tile][slot], n_tiles <= 2048),
+// one wavefront per slot: 32 values per lane, k rounds of "take the smallest out".  Written as the slot's k-th KEY (what the filter and the
+// exact-evaluation kernels read a start threshold from), one ulp-ish above the bound: their tests are strict.  Fewer than k witnesses: no
+// threshold (every gate open).
+__global__ __launch_bounds__(256) void vg_q8_pre_select_kernel(const float *premin, int n_tiles, int nq_pad, int k, uint64_t *out_keys) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (p >= nq_pad) return;
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { const int t = lane + 64 * i; v[i] = t < n_tiles ? premin[(long long)t * nq_pad + p] : INFINITY; }
+    float kth = INFINITY;
+    for (int round = 0; round < k; ++round) {
+        float m = v[0];
+        int mi = 0;
+#pragma unroll
+        for (int i = 1; i < 32; ++i) if (v[i] < m) { m = v[i]; mi = i; }
+        float w = m;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) w = fminf(w, __shfl_xor(w, sft));
+        kth = w;
+        if (!(w < INFINITY)) break;                                       // (fewer than k finite minima)
+        const unsigned long long holders = __ballot(m == w);
+        if (lane == __ffsll((long long)holders) - 1) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) if (i == mi) v[i] = INFINITY;
+        }
+    }
+    for (int j = lane; j < 64; j += 64) {
+        uint64_t key = VG_EMPTY_KEY;
+        if (j == k - 1 && kth < INFINITY) key = vg_make_key(kth + 1.0e-6f * fabsf(kth) + 1.0e-30f, 0xFFFFFFFFu);
+        out_keys[(long long)p * 64 + j] = key;
+    }
+}
+
 template <int OFF>
 __device__ __forceinline__ void vgq_lds_read128(vgh_i32x4 &dst, uint32_t lds_addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFF) : "memory");
@@ -243,12 +292,32 @@ __device__ __forceinline__ void vgq_wait_lds(vgh_i32x4 &v) {
 
 // NTB = 32-byte k-steps per int8 row (rows up to NTB * 32 elements)
 // WAVES x QS x 32 = 256 queries per workgroup; KS = K-parts per tile (1: the whole row is one ring buffer)
-template <int NTB, int MODE, int WAVES = VGQ_WAVES, int QS = VGQ_QS, int KS = 1>
+// PRE = the bound-only pre-pass (round 6): no gate, no pairs - per (query, tile) the smallest UPPER bound of the distance (see pre_boundary)
+template <int NTB, int MODE, int WAVES = VGQ_WAVES, int QS = VGQ_QS, int KS = 1, bool PRE = false>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_kernel(BatchArgsQ8 a) {
     constexpr int THREADS = 64 * WAVES, QPW = 32 * QS, QENT = 16 * QS + 8, QPB = WAVES * QPW;
-    constexpr int NB = WAVES == 4 ? VGQ_RING_OF(NTB) : VGQL_RING;       // ring buffers in LDS (NB - 1 of them in flight); one workgroup per CU: six
+    constexpr int NB = WAVES == 4 ? VGQ_RING_OF(NTB) : (KS == 1 && QS == 2 ? VGQW_RING_OF(NTB) : VGQL_RING);   // ring buffers in LDS; one workgroup per CU: six
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);
     constexpr int TILE_BYTES = NTB * 2 * 512;
+    // TRIPS PER BARRIER (round 6).  Measured with a cycle counter per wavefront (profiles/r10_q8_cycles_per_wave_tile.txt): the SIMD's arbiter
+    // favours the older of its two wavefronts, so waves 0-3 finish a tile's MFMAs after ~1 000 cycles and waves 4-7 after ~1 650; then the
+    // younger half runs its boundary and everybody meets at the barrier - ~1 300 of a tile's ~3 000 cycles with no MFMA in the pipe, because a
+    // wavefront that is done with tile t may not start tile t + 1.  The ring is six tiles deep, so the barrier can wait: M trips form a GROUP,
+    // the workgroup meets once per group, and inside a group a wavefront goes from tile to tile on its own (the older half's next k loop runs
+    // under the younger half's boundary).  Group g reads buffers that landed before its first tile; its tiles issue the DMA of a later group into the
+    // buffers of group g - 1, which every wavefront has left (the barrier in between).  M = 1 is the barrier per trip of round 5.
+    // (K-parts: a group is one tile's KS trips - the boundary sits behind the last of them anyway)
+    constexpr int M = KS > 1 ? (VGQ_TPB > 1 && NB % KS == 0 && NB >= 2 * KS ? KS : 1)
+                             : (NB % VGQ_TPB == 0 && NB >= 2 * VGQ_TPB ? VGQ_TPB : (NB % 2 == 0 && NB >= 4 ? 2 : 1));
+    constexpr int LOOK = NB / M - 1;                                 // groups beyond the current one that are resident or on their way
+    static_assert(LOOK >= 1 && NB % M == 0, "ring of whole groups");
+    // WHO ISSUES THE LDS-DMA, AND WHEN.  Inside the k loop an LDS-DMA instruction holds its wavefront's issue for ~100-200 cycles: with every
+    // wavefront issuing its share at the head of every k loop that was ~290 of a tile's ~2 600 cycles (profiles/r10_*).  Waves 0-3 - the older
+    // wavefront of every SIMD, which the arbiter serves first - reach a group's barrier ~2 000 cycles before waves 4-7: in the wide form they
+    // issue the WHOLE group behind their last boundary of a group (time they would spend waiting), two groups ahead (LOOK >= 2: the group
+    // issued one barrier ago is the one the counted wait confirms).
+    constexpr bool ATEND = VGQ_DMA_AT_END != 0 && WAVES == 8 && KS == 1 && M > 1 && LOOK >= 2;
+    constexpr int NISSUE = ATEND ? 4 : WAVES;                        // wavefronts that issue tile pieces
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tile0 = smem;
     float4 *rstat_lds = reinterpret_cast<float4 *>(smem + NB * TILE_BYTES);              // [VGQ_STAT_SLOTS][2 tiles][32 rows]
@@ -322,6 +391,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
         if (COS) { if (!(bb < VGH_ACCEPT)) bb = VGH_ACCEPT; if (!(uu > -VGH_ACCEPT)) uu = -VGH_ACCEPT; }
         else if (!(cc < VGH_ACCEPT)) cc = VGH_ACCEPT;
         if (!ok) { cc = -VGH_ACCEPT; bb = 0.0f; uu = COS ? VGH_ACCEPT : 0.0f; }     // padding / queries the filter cannot judge: never pass
+        if constexpr (PRE)                                                // (sq or 0 = not judged, sq ||qi|| up, ||eq|| + rel |q| up, |q|)
+            kq_lds[wave * QPW + (lane & (QPW - 1))] = make_float4(s1.y != 0.0f ? sq : 0.0f, sqi * (1.0f + 1.0e-5f),
+                                                                  (eqn * (1.0f + rel) + rel * qn) * (1.0f + 1.0e-5f), qn);
+        else
         kq_lds[wave * QPW + (lane & (QPW - 1))] = make_float4(ok ? av : 0.0f, bb, cc, uu);
         float m1 = ok ? av : 0.0f, m2 = ok ? bb : -VGH_ACCEPT, m3 = ok ? cc : -VGH_ACCEPT, m4 = ok ? uu : VGH_ACCEPT;
 #pragma unroll
@@ -349,7 +422,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
     const int T = tile_first < tile_last ? (int)(tile_last - tile_first) : 0;
     const unsigned long long stride_b = (unsigned long long)a.stride;
     const uint32_t lds_tile0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)tile0;
-    constexpr int NPIECE = (NTB + WAVES - 1) / WAVES;
+    constexpr int NPIECE = (NTB + NISSUE - 1) / NISSUE;
     static_assert(NPIECE <= 4, "ring buffers of up to 512-byte (sub-)rows");
     // K-part `part` of a tile = pieces part * NTB .. + NTB - 1 of its rows (contiguous: the copy is chunk-column major within a tile)
     auto piece_mask_of = [&](int part_k, int p) -> uint64_t {
@@ -417,16 +490,6 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
     // barrier of trip 2j - 3 at the latest the group has landed - without any wait of its own (waiting for it on the spot meant waiting
     // for the pieces issued in the same trip: a full memory round trip every other tile, for all four wavefronts at the barrier).
     // (K-parts: a group is issued LEAD = 2 tiles = 2 KS trips ahead - more than the NB - 2 trips the counted wait may leave outstanding)
-    // TRIPS PER BARRIER (round 6).  Measured with a cycle counter per wavefront (profiles/r10_q8_cycles_per_wave_tile.txt): the SIMD's arbiter
-    // favours the older of its two wavefronts, so waves 0-3 finish a tile's MFMAs after ~1 000 cycles and waves 4-7 after ~1 650; then the
-    // younger half runs its boundary and everybody meets at the barrier - ~1 300 of a tile's ~3 000 cycles with no MFMA in the pipe, because a
-    // wavefront that is done with tile t may not start tile t + 1.  The ring is six tiles deep, so the barrier can wait: M trips form a GROUP,
-    // the workgroup meets once per group, and inside a group a wavefront goes from tile to tile on its own (the older half's next k loop runs
-    // under the younger half's boundary).  Group g reads buffers that landed before its first tile; its tiles issue the DMA of a later group into the
-    // buffers of group g - 1, which every wavefront has left (the barrier in between).  M = 1 is the barrier per trip of round 5.
-    constexpr int M = KS > 1 ? 1 : (NB % VGQ_TPB == 0 && NB >= 2 * VGQ_TPB ? VGQ_TPB : (NB % 2 == 0 && NB >= 4 ? 2 : 1));
-    constexpr int LOOK = NB / M - 1;                                 // groups beyond the current one that are resident or on their way
-    static_assert(LOOK >= 1 && NB % M == 0, "ring of whole groups");
     constexpr int LEAD = KS == 1 ? NB : 2;                           // tiles between a group's issue and its first use
     constexpr int SPRE = (LEAD + 1) / 2;                             // groups loaded up front: j with 2j - LEAD < 0
     const int U = T * KS;                                            // ring trips of this partition
@@ -440,6 +503,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const bool counted_wait = all_parts_full;
+    int next_stat = SPRE;                                             // (ATEND) the next statistics group to issue
     const long long region0 = ((long long)(g * a.npart_total + a.part_base + part) * WAVES + wave) * QS;
     uint64_t *pairs0 = a.pairs + region0 * a.pair_cap, *pairs1 = pairs0 + (QS > 1 ? a.pair_cap : 0);
     unsigned n_pairs0 = 0, n_pairs1 = 0;                              // pairs in the regions so far (wave-uniform)
@@ -581,6 +645,73 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
             }
         }
     };
+    // ---- PRE: what a tile says about every query's k-th best WITHOUT an exact evaluation.  The bound that lets the filter reject a pair
+    // also bounds a pair's distance from ABOVE: q.x >= sq sx I - sq ||qi|| ||ex|| - ||eq|| ||x|| =: s_lo, so the distance the exact
+    // evaluation would compute for (query, row) is at most U(s_lo) (dot: -s_lo; L2: |q|^2 + |x|^2 - 2 s_lo; cosine: 1 - s_lo / (|q| |x|)),
+    // every float step rounded towards "larger".  The smallest U over a tile's 32 rows belongs to ONE row; the k-th smallest of a query's
+    // tile minima (vg_q8_pre_select_kernel) therefore stands for k different rows whose exact distances are no larger: a valid start
+    // threshold for the first real stage - without the five warm-up stages (two tiles with every gate open, then x8, x8, x8, x8) that cost
+    // 1.0 of a 1024 x 10M x 384 batch's 5.2 ms (profiles/r10_q8_stage_timeline_before.txt).
+    auto pre_boundary = [&](int ti, const vgq_i32x16 &acc0, const vgq_i32x16 &acc1) __attribute__((always_inline)) -> float {
+        const long long tile = tile_first + ti;
+        const long long row_cur = tile * VGQ_TILE + x;
+        const float4 rs = rstat_lds[((ti >> 1) & (VGQ_STAT_SLOTS - 1)) * 64 + (ti & 1) * 32 + x];
+        const float sx = rs.x, rx = rs.y, nx = rs.z;
+        const bool row_ok = row_cur < a.n_rows && nx >= 0.0f;            // (a row that is never judged: no witness)
+        const float rel = a.rel;
+        float keep = INFINITY;
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float4 kq = kq_w[32 * s + qi];                      // (sq, A, B, |q|): one address per half - a broadcast read
+                const int I = s ? acc1[r] : acc0[r];
+                const float t = (float)I * sx;
+                const float E = fmaf(kq.y, rx, kq.z * nx);
+                float s_lo = fmaf(kq.x, t, -E);
+                s_lo -= 1.0e-5f * (fabsf(kq.x * t) + E) + 1.0e-30f;
+                float U;
+                if constexpr (COS) {
+                    const float den = kq.w * nx;
+                    const float ratio = s_lo >= 0.0f ? s_lo / (den * (1.0f + 4.0f * rel)) : s_lo * (1.0f + 4.0f * rel) / den;
+                    U = nx == 0.0f ? 1.0f : fminf(1.0f - ratio + 8.0e-6f + 2.0f * rel, 2.0f);
+                } else if constexpr (L2M) {
+                    const float qq = kq.w * kq.w * (1.0f + 1.0e-6f);
+                    float U2 = fmaf(-2.0f, s_lo, (qq + nx * nx) * (1.0f + 4.0f * rel));
+                    U2 = fmaxf(U2 * (1.0f + 8.0f * rel), 0.0f) + 1.0e-30f;
+                    U = (a.root ? sqrtf(U2) : U2) * (1.0f + 1.0e-6f);
+                } else {
+                    U = -s_lo;
+                    U += 1.0e-6f * fabsf(U);
+                }
+                if (fabsf(U) < 1.0e-5f) U = 1.0e-5f;                      // (nearly_zero_float32 moves a tiny distance to 0: sqlite-vector.c:994-996)
+                if (!(row_ok && kq.x > 0.0f) || !(U == U)) U = INFINITY;
+                // the smallest over the half's 32 lanes = the tile's 32 rows
+                uint32_t ub = __float_as_uint(U);
+                auto fmin_u = [](uint32_t p, uint32_t q) { return __float_as_uint(fminf(__uint_as_float(p), __uint_as_float(q))); };
+                ub = fmin_u(ub, vg_dpp_u32<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(ub));
+                ub = fmin_u(ub, vg_dpp_u32<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(ub));
+                ub = fmin_u(ub, vg_dpp_u32<VG_DPP_ROW_HALF_MIRROR>(ub));
+                ub = fmin_u(ub, vg_dpp_u32<VG_DPP_ROW_MIRROR>(ub));
+                ub = fmin_u(ub, (uint32_t)__shfl_xor((int)ub, 16));
+                if ((x & 15) == r && (x >> 4) == s) keep = __uint_as_float(ub);
+            }
+        }
+        return keep;                                                      // lane (x, h) keeps query 32 (x >> 4) + qi(x & 15, h) of the wavefront
+    };
+    // (the minima leave BEHIND a group's barrier: a store in front of it sits in the LDS-DMA's in-order queue and the group-end wait then
+    //  waits for its acknowledgement - 116 us for 2 048 tiles against ~40)
+    float pre_keep[M > 0 ? M : 1];
+    auto pre_store = [&](int ti_first, int count) __attribute__((always_inline)) {
+        if ((x >> 4) < QS) {
+            const int r = x & 15;
+            const int qw = 32 * (x >> 4) + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                if (j < count) a.premin[(tile_first + ti_first + j - a.tile_begin) * (long long)a.nq_pad + q0 + qw] = pre_keep[j];
+        }
+    };
     vgq_i32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
@@ -595,6 +726,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
     for (int ti = 0; ti < T; ++ti) {
         const int sj = (ti + LEAD) >> 1;                                      // the statistics group this tile's first trip may issue
         const bool stat_turn = ((ti + LEAD) & 1) == 0 && 2 * sj < T + 1 && wave == (sj & (WAVES - 1));
+#ifdef VGQ_PRIO_EXPERIMENT
+        if (VGQ_PRIO_EXPERIMENT == 3 && M > 1) {                      // the wavefront that is BEHIND within a group has the higher priority
+            const int j = ti % M;
+            if (j == 0) __builtin_amdgcn_s_setprio(3); else if (j == 1) __builtin_amdgcn_s_setprio(2); else if (j == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
         // one ring trip per K-part of the tile (KS = 1: the whole row): the accumulators run on across the parts
@@ -616,7 +753,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][kp * NTB + t], b, acc0, 0, 0, 0);
             if constexpr (QS > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[QS - 1][kp * NTB + t], b, acc1, 0, 0, 0);
             if constexpr (t + BP < NTB) vgq_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
-            if constexpr (t == 0 && VGQ_ABLATE < 3) {
+            if constexpr (t == 0 && VGQ_ABLATE < 3 && !ATEND) {
                 if (kp == 0 && stat_turn) dma_stat_group(tile_first + 2 * sj, sj & (VGQ_STAT_SLOTS - 1));
                 dma_share(u_next, fill_buf);
             }
@@ -626,11 +763,33 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
             __builtin_amdgcn_sched_barrier(0);
         });
         VGQ_TICK(tk1);
-        if constexpr (kp == KS - 1) boundary(ti, acc0, acc1);
+        if constexpr (kp == KS - 1) {
+            if constexpr (PRE) {
+                const float kv = pre_boundary(ti, acc0, acc1);
+                const int j = KS > 1 ? 0 : ti % M;                         // (K-parts: a group is one tile)
+#pragma unroll
+                for (int jj = 0; jj < M; ++jj) if (jj == j) pre_keep[jj] = kv;
+            } else boundary(ti, acc0, acc1);
+        }
         VGQ_TICK(tk2);
         // group end: the next group's pieces have landed (an issuing wavefront leaves the pieces of the (LOOK - 1) M youngest trips in
         // flight: loads return in order), barrier: every wavefront has read this group's buffers, the next group's are readable
         if (M == 1 || (ti * KS + kp) % M == M - 1) {
+        if constexpr (ATEND && VGQ_ABLATE < 3) {
+            // group g = ti / M is done (by this wavefront): the statistics and the pieces of group g + LOOK into the buffers of group g - 1
+            const int g_next = ti / M + LOOK;
+            while (2 * next_stat < min((g_next + 1) * M, T + 1)) {
+                if (wave == (next_stat & (NISSUE - 1))) dma_stat_group(tile_first + 2 * next_stat, next_stat & (VGQ_STAT_SLOTS - 1));
+                ++next_stat;
+            }
+            if (wave < NISSUE) {
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    const int v = g_next * M + j;
+                    dma_share(min(v, U - 1), v % NB);
+                }
+            }
+        }
         if (counted_wait) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LOOK - 1) * M * NPIECE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" ::: "memory");
@@ -639,6 +798,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
 #endif
         if (VGQ_ABLATE < 4) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (PRE) { if (KS > 1) pre_store(ti, 1); else pre_store(ti - (M - 1), M); }
         }
         cur_buf = cur_buf + 1 == NB ? 0 : cur_buf + 1;
 #if VGQ_TIMING
@@ -658,6 +818,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
     if (lane == 0) { atomicAdd(&vgq_stats[0], (unsigned long long)T); atomicAdd(&vgq_stats[1], (unsigned long long)st_slow);
                      atomicAdd(&vgq_stats[2], (unsigned long long)st_cand); atomicAdd(&vgq_stats[3], (unsigned long long)st_pairs); }
 #endif
+    if constexpr (PRE) {
+        if (KS == 1 && M > 1 && T % M != 0) pre_store(T - T % M, T % M);
+        return;
+    }
     if (n_q && VGQ_ABLATE != 7 && VGQ_ABLATE != 8) process_queue();
     flush(pbuf0, n_buf0, pairs0, n_pairs0);
     if (QS > 1) flush(pbuf1, n_buf1, pairs1, n_pairs1);
@@ -668,52 +832,37 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
 }
 
 // ---- host side
-template <int NTB, int MODE>
-static int launch_q8(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(vg_batch_q8_kernel<NTB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+template <int NTB, int MODE, int WAVES, int QS, int KS>
+static int launch_q8_form(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream, bool pre) {
+    auto kern = pre ? vg_batch_q8_kernel<NTB, MODE, WAVES, QS, KS, true> : vg_batch_q8_kernel<NTB, MODE, WAVES, QS, KS, false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((vg_batch_q8_kernel<NTB, MODE>), dim3((unsigned)blocks), dim3(64 * VGQ_WAVES), smem, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * WAVES), smem, stream, a);
     return (int)hipGetLastError();
 }
+template <int NTB, int WAVES, int QS, int KS>
+static int launch_q8_form_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream, bool pre) {
+    if (a.mode == VGH_COS) return launch_q8_form<NTB, VGH_COS, WAVES, QS, KS>(a, blocks, smem, stream, pre);
+    if (a.mode == VGH_L2) return launch_q8_form<NTB, VGH_L2, WAVES, QS, KS>(a, blocks, smem, stream, pre);
+    return launch_q8_form<NTB, VGH_DOT, WAVES, QS, KS>(a, blocks, smem, stream, pre);
+}
 template <int NTB>
-static int launch_q8_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
-    if (a.mode == VGH_COS) return launch_q8<NTB, VGH_COS>(a, blocks, smem, stream);
-    if (a.mode == VGH_L2) return launch_q8<NTB, VGH_L2>(a, blocks, smem, stream);
-    return launch_q8<NTB, VGH_DOT>(a, blocks, smem, stream);
+static int launch_q8_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream, bool pre) {
+    return launch_q8_form_mode<NTB, VGQ_WAVES, VGQ_QS, 1>(a, blocks, smem, stream, pre);
 }
 // the WIDE form of the short-row kernel: eight wavefronts x two query sets = 512 queries per workgroup, one workgroup per CU - a tile is
 // brought in once for 512 queries instead of once per 256 (half the LDS-DMA issues and half the L2 traffic per pair), six ring buffers
-template <int NTB, int MODE>
-static int launch_q8w(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
-    auto kern = vg_batch_q8_kernel<NTB, MODE, 8, 2, 1>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * 8), smem, stream, a);
-    return (int)hipGetLastError();
-}
 template <int NTB>
-static int launch_q8w_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
-    if (a.mode == VGH_COS) return launch_q8w<NTB, VGH_COS>(a, blocks, smem, stream);
-    if (a.mode == VGH_L2) return launch_q8w<NTB, VGH_L2>(a, blocks, smem, stream);
-    return launch_q8w<NTB, VGH_DOT>(a, blocks, smem, stream);
+static int launch_q8w_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream, bool pre) {
+    return launch_q8_form_mode<NTB, 8, 2, 1>(a, blocks, smem, stream, pre);
 }
 static size_t vgqw_lds_bytes(int NTB) {
-    return (size_t)VGQL_RING * NTB * 1024 + (size_t)VGQ_STAT_SLOTS * 1024 + (size_t)8 * 64 * 16 + (size_t)8 * 128 * 8 + (size_t)8 * VGQ_QCAP * 160;
+    return (size_t)VGQW_RING_OF(NTB) * NTB * 1024 + (size_t)VGQ_STAT_SLOTS * 1024 + (size_t)8 * 64 * 16 + (size_t)8 * 128 * 8 + (size_t)8 * VGQ_QCAP * 160;
 }
 // long rows: KS K-parts of NTB k-steps, one query set per wavefront, eight wavefronts
-template <int NTB, int KS, int MODE>
-static int launch_q8l(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
-    auto kern = vg_batch_q8_kernel<NTB, MODE, VGQL_WAVES, VGQL_QS, KS>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * VGQL_WAVES), smem, stream, a);
-    return (int)hipGetLastError();
-}
 template <int NTB, int KS>
-static int launch_q8l_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream) {
-    if (a.mode == VGH_COS) return launch_q8l<NTB, KS, VGH_COS>(a, blocks, smem, stream);
-    if (a.mode == VGH_L2) return launch_q8l<NTB, KS, VGH_L2>(a, blocks, smem, stream);
-    return launch_q8l<NTB, KS, VGH_DOT>(a, blocks, smem, stream);
+static int launch_q8l_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream, bool pre) {
+    return launch_q8_form_mode<NTB, VGQL_WAVES, VGQL_QS, KS>(a, blocks, smem, stream, pre);
 }
 // rows of 513 .. 1536 int8 elements: (k-steps per K-part) * 8 + (K-parts), 0 if not served
 static int vgql_cfg(long long stride_bytes) {
@@ -762,7 +911,8 @@ extern "C" int vg_batch_q8_regions(int nq_pad, int npart) { return (nq_pad / 32)
 // scratch behind the nq_pad query rows the caller uploads: the sorted query rows, their int8 images, statistics, sort keys + own scales +
 // the permutation + the common scale
 extern "C" size_t vg_batch_q8_work_bytes(int nq_pad, long long q8stride_bytes, long long xstride_bytes) {
-    return (size_t)nq_pad * xstride_bytes + (size_t)nq_pad * q8stride_bytes + (size_t)nq_pad * 2 * sizeof(float4) + (size_t)nq_pad * 12 + 16;
+    return (size_t)nq_pad * xstride_bytes + (size_t)nq_pad * q8stride_bytes + (size_t)nq_pad * 2 * sizeof(float4) + (size_t)nq_pad * 12 + 16 +
+           (size_t)VGQ_PRE_TILES * nq_pad * sizeof(float);              // (+ the pre-pass' tile minima)
 }
 // where the statistics (nq_pad x 32 bytes) and the permutation (nq_pad ints: slot -> query) sit in that scratch
 extern "C" size_t vg_batch_q8_work_stat_offset(int nq_pad, long long q8stride_bytes, long long xstride_bytes) {
@@ -770,6 +920,30 @@ extern "C" size_t vg_batch_q8_work_stat_offset(int nq_pad, long long q8stride_by
 }
 extern "C" size_t vg_batch_q8_work_perm_offset(int nq_pad, long long q8stride_bytes, long long xstride_bytes) {
     return vg_batch_q8_work_stat_offset(nq_pad, q8stride_bytes, xstride_bytes) + (size_t)nq_pad * 2 * sizeof(float4) + (size_t)nq_pad * 8;
+}
+
+// ---- what the host needs of a finished batch, in ONE buffer and one copy: [0] the overflow flag, [1] exact evaluations so far (64 bit: words
+// 2, 3), then per slot p: perm[p], judged[p], then the k keys of every slot.  (Five separate copies - three of them into pageable memory -
+// cost ~0.2 ms of host latency per batch: profiles/r10_q8_stage_timeline_*.txt.)
+__global__ __launch_bounds__(256) void vg_q8_pack_kernel(const uint64_t *keys, const int *perm, const float4 *qstat, const uint32_t *overflow_flag,
+                                                         const unsigned long long *evals, int nq_pad, int k, uint32_t *out) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p == 0) { out[0] = *overflow_flag; out[1] = 0u; const unsigned long long e = evals ? *evals : 0ull; out[2] = (uint32_t)e; out[3] = (uint32_t)(e >> 32); }
+    if (p >= nq_pad) return;
+    out[4 + p] = (uint32_t)perm[p];
+    out[4 + nq_pad + p] = qstat[2 * p + 1].y != 0.0f ? 1u : 0u;
+    uint64_t *ko = reinterpret_cast<uint64_t *>(out + 4 + 2 * nq_pad) + (long long)p * k;
+    for (int j = 0; j < k; ++j) ko[j] = keys[(long long)p * 64 + j];
+}
+extern "C" size_t vg_batch_q8_pack_bytes(int nq_pad, int k) { return 16 + (size_t)nq_pad * 8 + (size_t)nq_pad * k * 8; }
+extern "C" int vg_batch_q8_pack_launch(const uint64_t *dev_keys, const void *dev_qwork, int nq_pad, long long q8stride, long long xstride, int k,
+                                       const uint32_t *dev_overflow_flag, const unsigned long long *dev_evals, void *dev_out, hipStream_t stream) {
+    const uint8_t *w = reinterpret_cast<const uint8_t *>(dev_qwork);
+    const float4 *qstat = reinterpret_cast<const float4 *>(w + vg_batch_q8_work_stat_offset(nq_pad, q8stride, xstride));
+    const int *perm = reinterpret_cast<const int *>(w + vg_batch_q8_work_perm_offset(nq_pad, q8stride, xstride));
+    hipLaunchKernelGGL(vg_q8_pack_kernel, dim3((unsigned)((nq_pad + 255) / 256)), dim3(256), 0, stream, dev_keys, perm, qstat, dev_overflow_flag, dev_evals,
+                       nq_pad, k, reinterpret_cast<uint32_t *>(dev_out));
+    return (int)hipGetLastError();
 }
 
 extern "C" int vg_q8_rstat_launch(const void *dev_q8stat, const float *dev_xnorm, long long row0, long long n, void *dev_out, int nn_squared, hipStream_t stream) {
@@ -810,10 +984,10 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     float *common = reinterpret_cast<float *>(perm + nq_pad);
     const dim3 pg((unsigned)((nq_pad + 3) / 4));
     hipLaunchKernelGGL(vg_q8_query_prep_kernel, pg, dim3(256), 0, stream, dev_xqueries, xstride, dim, nq_real, nq_pad, mode, (const int *)nullptr,
-                       (const float *)nullptr, qkeys, qscales, (uint8_t *)nullptr, (uint8_t *)nullptr, q8stride, (float4 *)nullptr, type_code);
-    hipLaunchKernelGGL(vg_q8_rank_kernel, dim3(1), dim3(1024), (size_t)nq_pad * 4, stream, (const float *)qkeys, (const float *)qscales, nq_pad, perm, common);
+                       (const float *)nullptr, (const float *)nullptr, qkeys, qscales, (uint8_t *)nullptr, (uint8_t *)nullptr, q8stride, (float4 *)nullptr, type_code);
+    hipLaunchKernelGGL(vg_q8_rank_kernel, dim3((unsigned)(nq_pad / 256)), dim3(256), (size_t)nq_pad * 4, stream, (const float *)qkeys, (const float *)qscales, nq_pad, perm, common);
     hipLaunchKernelGGL(vg_q8_query_prep_kernel, pg, dim3(256), 0, stream, dev_xqueries, xstride, dim, nq_real, nq_pad, mode, (const int *)perm,
-                       (const float *)common, (float *)nullptr, (float *)nullptr, xq_sorted, qcodes, q8stride, qstat, type_code);
+                       (const float *)common, (const float *)qscales, (float *)nullptr, (float *)nullptr, xq_sorted, qcodes, q8stride, qstat, type_code);
     int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
     const int flag_index = vg_batch_q8_regions(nq_pad, npart);
@@ -826,7 +1000,7 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     hx.rows = nullptr; hx.tiled = 1; hx.queries = xq_sorted; hx.xrows = dev_xrows; hx.xqueries = xq_sorted; hx.xstride = xstride;
     hx.cerr = 0.0f; hx.row_nn = dev_xnorm; hx.cand = dev_cand; hx.n_rows = n_rows; hx.stride = q8stride;
     hx.nq_pad = nq_pad; hx.nq_real = nq_pad; hx.k = k; hx.mode = mode; hx.root = root; hx.dim = dim;      // (sorted slots: padding and unjudged queries sit at the end - the filter passes none of their pairs)
-    hx.pairs = dev_pairs; hx.pair_counts = dev_pair_counts; hx.pair_cap = pair_cap; hx.qnn = nullptr; hx.evals = dev_evals; hx.lds_pairs = 1;
+    hx.pairs = dev_pairs; hx.pair_counts = dev_pair_counts; hx.pair_cap = pair_cap; hx.qnn = nullptr; hx.evals = dev_evals; hx.lds_pairs = 1; hx.part_group = 0;
     hx.tiles_per_part = 0; hx.tile_begin = 0; hx.tile_end = 0; hx.part_base = 0;
 
     BatchArgsQ8 a;
@@ -841,10 +1015,14 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     const bool long_exact = xstride > (type_code == 2 ? 4096 : 2048);       // rows beyond what the short exact kernel's chunks per lane cover
     const int G = nq_pad / (wide ? 512 : VGQ_QPB);
     const int hx_waves = wide ? 16 : VGQ_WAVES * VGQ_QS;                    // 32-query regions per query group and partition
-    // Stages over growing row ranges: the lists are merged after every stage and the next one starts from every query's k-th best over
-    // all rows so far.  Stage 0: two tiles, every gate open (1024 pairs per region and tile), exact lists behind it - no pre-pass kernel of
-    // another kind.  Then x8 while a stage is small (its launches are what it costs), x2 from 1/32 of the corpus on (fewer pairs for the
-    // exact evaluation: ~k ln(growth) rows per query truly enter, several times that pass the int8 bound).
+    // The batch in launches: (1) the bound-only PRE-PASS over the first `pre` tiles + the selection of every query's start threshold
+    // (round 6; round 5 warmed the lists up with five tiny stages - two tiles with every gate open, then x8 x8 x8 x8 - that cost a fifth of
+    // the batch); (2) STAGES over growing row ranges, the first one [0, VGQ_FIRST_MULT x pre) from the pre-pass' thresholds with empty
+    // lists, every later one from every query's exact k-th best over all rows so far (lists merged after every stage): x4 while a stage is
+    // small (its launches are what it costs), x2 from 1/16 of the corpus on (fewer pairs for the exact evaluation: ~k ln(growth) rows per
+    // query truly enter, several times that pass the int8 bound).
+    float *premin = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(common) + 16);
+    const long long pre = std::min<long long>(VGQ_PRE_TILES, std::max<long long>(64, ntiles / 8)) / 8 * 8;
     long long bounds[24];
     int nstages = 0;
     {
@@ -852,50 +1030,67 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
         // (long rows: an exact evaluation reads up to 6 KB - tighter thresholds pay for a few more launches: x1.5; 20.8 -> 20.0 ms at 10M x 1536)
         const int late_growth = sw_growth > 100 ? sw_growth : (lcfg ? 150 : 200);
         bounds[0] = 0;
-        long long b = VGQ_STAGE0_TILES;
+        long long b = pre * (lcfg ? 1 : VGQ_FIRST_MULT);
         while (b < ntiles && nstages + 2 < 24 && ntiles - b > b / 4) {      // (no sliver at the end)
             bounds[++nstages] = b;
-            b = (b < ntiles / 256) ? b * 8 : ((b < ntiles / 16) ? b * 4 : b * late_growth / 100);
+            b = (b < ntiles / 16) ? b * 4 : b * late_growth / 100;
         }
         bounds[++nstages] = ntiles;
     }
+    auto launch_filter = [&](int blocks, bool is_pre) -> int {
+        if (lcfg) {
+            if (ntb == 12) return launch_q8l_mode<12, 2>(a, blocks, smem, stream, is_pre);
+            if (ks == 2) return launch_q8l_mode<16, 2>(a, blocks, smem, stream, is_pre);
+            return launch_q8l_mode<16, 3>(a, blocks, smem, stream, is_pre);
+        }
+        if (wide) {
+            if (ntb == 4) return launch_q8w_mode<4>(a, blocks, smem, stream, is_pre);
+            if (ntb == 8) return launch_q8w_mode<8>(a, blocks, smem, stream, is_pre);
+            if (ntb == 12) return launch_q8w_mode<12>(a, blocks, smem, stream, is_pre);
+            return launch_q8w_mode<16>(a, blocks, smem, stream, is_pre);
+        }
+        if (ntb == 4) return launch_q8_mode<4>(a, blocks, smem, stream, is_pre);
+        if (ntb == 8) return launch_q8_mode<8>(a, blocks, smem, stream, is_pre);
+        if (ntb == 12) return launch_q8_mode<12>(a, blocks, smem, stream, is_pre);
+        return launch_q8_mode<16>(a, blocks, smem, stream, is_pre);
+    };
+    {   // (1) the pre-pass
+        a.tile_begin = 0; a.tile_end = pre;
+        const int np = (int)std::min<long long>(npart, std::max<long long>(8, (pre / 4) / 8 * 8));
+        a.npart = np; a.npart_total = np;
+        a.tiles_per_part = (int)((pre + np - 1) / np);
+        a.init_keys = nullptr; a.premin = premin;
+        if ((rc = launch_filter(G * np, true)) != 0) return rc;
+        hipLaunchKernelGGL(vg_q8_pre_select_kernel, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, stream, (const float *)premin, (int)pre, nq_pad, k, dev_out_keys);
+        if ((rc = (int)hipGetLastError()) != 0) return rc;
+    }
+    a.premin = nullptr;
     for (int s = 0; s < nstages; ++s) {
         a.tile_begin = bounds[s]; a.tile_end = bounds[s + 1];
         const long long tiles_s = a.tile_end - a.tile_begin;
         // a stage of few tiles runs over fewer partitions: fewer regions for the exact-evaluation kernel, fewer lists for the merge
-        const int np = s == 0 ? 8 : (int)std::min<long long>(npart, std::max<long long>(8, (tiles_s / 4) / 8 * 8));
+        const int np = (int)std::min<long long>(npart, std::max<long long>(8, (tiles_s / 4) / 8 * 8));
         a.npart = np; a.npart_total = np;
         a.tiles_per_part = (int)((tiles_s + np - 1) / np);
-        a.init_keys = s == 0 ? nullptr : dev_out_keys;
+        a.init_keys = dev_out_keys;                                         // stage 0: the pre-pass' thresholds (k-th key only), then the merged lists
         hx.npart = np; hx.npart_total = np; hx.n_regions = vg_batch_q8_regions(nq_pad, np);
-        hx.init_keys = a.init_keys; hx.seed = (s > 0) ? 1 : 0;
-        const int blocks = G * np;
-        if (lcfg) {
-            if (ntb == 12) rc = launch_q8l_mode<12, 2>(a, blocks, smem, stream);
-            else if (ks == 2) rc = launch_q8l_mode<16, 2>(a, blocks, smem, stream);
-            else rc = launch_q8l_mode<16, 3>(a, blocks, smem, stream);
-        }
-        else if (wide) {
-            if (ntb == 4) rc = launch_q8w_mode<4>(a, blocks, smem, stream);
-            else if (ntb == 8) rc = launch_q8w_mode<8>(a, blocks, smem, stream);
-            else if (ntb == 12) rc = launch_q8w_mode<12>(a, blocks, smem, stream);
-            else rc = launch_q8w_mode<16>(a, blocks, smem, stream);
-        }
-        else if (ntb == 4) rc = launch_q8_mode<4>(a, blocks, smem, stream);
-        else if (ntb == 8) rc = launch_q8_mode<8>(a, blocks, smem, stream);
-        else if (ntb == 12) rc = launch_q8_mode<12>(a, blocks, smem, stream);
-        else rc = launch_q8_mode<16>(a, blocks, smem, stream);
-        if (rc != 0) return rc;
+        hx.init_keys = a.init_keys; hx.seed = (s > 0) ? 1 : 0;             // (stage 0 starts with empty lists: the thresholds stand for no list entries)
+        // one exact-evaluation block per 32 queries and pg consecutive partitions: 16 .. 31 lists per query reach the merge instead of up to 128
+        int pg = (np % 8 == 0 && np / 8 >= 16) ? 8 : ((np % 4 == 0 && np / 4 >= 16) ? 4 : ((np % 2 == 0 && np / 2 >= 16) ? 2 : 1));
+        if (pg > VGQ_HX_GROUP) pg = VGQ_HX_GROUP;
+        hx.part_group = pg;
+        const int hx_blocks = hx.n_regions / pg, lists = np / pg;
+        if ((rc = launch_filter(G * np, false)) != 0) return rc;
         if (long_exact)
-            rc = type_code == 2 ? vghl_exact_regions_f32(&hx, hx_waves, hx.n_regions, smem_exact, stream)
-                                : (type_code == 1 ? vghl_exact_regions_bf16(&hx, hx_waves, hx.n_regions, smem_exact, stream)
-                                                  : vghl_exact_regions_f16(&hx, hx_waves, hx.n_regions, smem_exact, stream));
+            rc = type_code == 2 ? vghl_exact_regions_f32(&hx, hx_waves, hx_blocks, smem_exact, stream)
+                                : (type_code == 1 ? vghl_exact_regions_bf16(&hx, hx_waves, hx_blocks, smem_exact, stream)
+                                                  : vghl_exact_regions_f16(&hx, hx_waves, hx_blocks, smem_exact, stream));
         else
-        rc = type_code == 2 ? vgh_launch_exact_f32(&hx, xntb, hx_waves, hx.n_regions, smem_exact, stream)
-                            : (type_code == 1 ? vgh_launch_exact_bf16(&hx, xntb, hx_waves, hx.n_regions, smem_exact, stream)
-                                              : vgh_launch_exact_f16(&hx, xntb, hx_waves, hx.n_regions, smem_exact, stream));
+        rc = type_code == 2 ? vgh_launch_exact_f32(&hx, xntb, hx_waves, hx_blocks, smem_exact, stream)
+                            : (type_code == 1 ? vgh_launch_exact_bf16(&hx, xntb, hx_waves, hx_blocks, smem_exact, stream)
+                                              : vgh_launch_exact_f16(&hx, xntb, hx_waves, hx_blocks, smem_exact, stream));
         if (rc != 0) return rc;
-        if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, np, np, k, dev_out_keys, stream)) != 0) return rc;
+        if ((rc = vg_batch_merge_launch(dev_cand, nq_pad, lists, lists, k, dev_out_keys, stream)) != 0) return rc;
     }
     return 0;
 }
