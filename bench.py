@@ -95,7 +95,7 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--batch", type=int, default=1024, help="queries per batch (workload c5)")
     ap.add_argument("--no-also", action="store_true", help="default workload: skip the filter_scan / c3 / c5 sub-results")
-    ap.add_argument("--also", default="filter,c3,c5,matrix,c4,long,c1", help="default workload: which sub-results to append (filter,c3,c5,matrix,c4,long,c1)")
+    ap.add_argument("--also", default="filter,c3,c5,matrix,c4,long,clustered,c1", help="default workload: which sub-results to append (filter,c3,c5,matrix,c4,long,clustered,c1)")
     ap.add_argument("--inprocess", action="store_true",
                     help="--gpus N in ONE process: the product's own multi-device form (vg_shards: block-cyclic deal over the N devices, "
                          "candidate gather by host copies and by one grouped RCCL all-gather), timed per query, same JSON contract")
@@ -1207,7 +1207,7 @@ def main():
     if n_gpus == 1 and args.workload == "c2" and "filter" in also_set:
         # ---- the same queries through the filter scan (the product's default path for this corpus)
         out["filter_scan"] = filter_scan_object(args, pkg, corpus, runner, metric, vt, dim, n_rows, plain_last)
-    if n_gpus == 1 and args.workload == "c2" and (also_set & {"c3", "c5", "matrix", "c4", "long", "c1"}):
+    if n_gpus == 1 and args.workload == "c2" and (also_set & {"c3", "c5", "matrix", "c4", "long", "clustered", "c1"}):
         # ---- configs[2] over its own corpus, then configs[4] over the f32 corpus (the MFMA-bound batch after the HBM-bound
         # lines: they are not timed on a package it has just heated), then the plain-kernel matrix and 100M x 384 on this device
         also = {}
@@ -1228,6 +1228,8 @@ def main():
             also["kernel_matrix"] = also_kernel_matrix(args, pkg, torch, shard, n_rows, k, device_index)
         if "long" in also_set:
             also["long_rows"] = also_long_rows(args, pkg, torch, k, device_index)
+        if "clustered" in also_set:
+            also["clustered"] = also_clustered(args, pkg, torch, k, device_index)
         if "c1" in also_set:
             also["c1"] = also_c1(args, pkg, torch)
         out["also"] = also
@@ -1399,6 +1401,157 @@ def also_c3(args, pkg, torch, shard, also_set, n_rows, k, nq, device_index):
         return line
     except Exception as e:
         return {"error": repr(e)}
+
+
+def _time_scans(corpus, metric, qs, k, n):
+    """(ms per scan as a caller sees it, scan kernel ms, pre-pass ms, kernel name) over n single scans (profiling events on: kernel time by HIP events)"""
+    for i in range(3):
+        corpus.scan_topk(metric, qs[i % len(qs)], k)
+    corpus.set_profiling(True)
+    t0 = time.perf_counter()
+    for i in range(n):
+        corpus.scan_topk(metric, qs[(3 + i) % len(qs)], k)
+    ms = (time.perf_counter() - t0) / n * 1e3
+    _, scan_ms, _, pre_ms = corpus.profile_mean_ms_ex()
+    return ms, scan_ms, pre_ms, corpus.kernel_name(metric)
+
+
+def also_clustered(args, pkg, torch, k, device_index):
+    """`also.clustered`: the DEFAULT paths on data that is not iid - 10M x 384 f32 drawn from 4 096 Gaussian clusters and
+    L2-normalised (tests/datagen.py: what a table of sentence embeddings looks like), cosine and dot, queries near cluster centres; the same
+    corpus quantized to uint8 (the reference's formula over the corpus' own min / max: ~46 of the 256 levels are used); and an ADVERSARIAL
+    corpus (every row within 1e-3 of every query: no bound separates anything - the selectivity guard must hand the query to the plain
+    kernel).  Per leg: the plain kernel, the default single-query path (filter scan) with its exact evaluations per query, the default
+    1024-query batch.  The cost of the filter paths is a property of the data: these figures stand next to the N(0,1) ones, not under them."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import datagen as dgen
+    out = {"what": "default paths on clustered unit-norm data (4096 clusters, within-cluster noise norm %.1f, queries at noise %.1f) and on an adversarial corpus; "
+                   "generator: tests/datagen.py clustered_block / adversarial_block" % (dgen.CLUSTER_NOISE, dgen.QUERY_NOISE), "legs": {}}
+    n_rows, dim, blk, nq_batch = (args.rows or 10_000_000), 384, 500_000, args.batch
+    dev = "cuda:%d" % device_index
+    try:
+        centres = dgen.clustered_centres(torch, 42, dim, device=dev)
+        qs = dgen.clustered_queries(torch, centres, 42, max(nq_batch, 32))
+        c = pkg.Corpus(pkg.F32, dim, capacity=n_rows, device=device_index)
+        lo, hi = float("inf"), float("-inf")
+        for b in range(n_rows // blk):
+            t = dgen.clustered_block(torch, centres, 42, b, blk)
+            lo, hi = min(lo, float(t.min())), max(hi, float(t.max()))
+            torch.cuda.synchronize()
+            c.append_device(t.data_ptr(), blk, dim * 4)
+            del t
+        for mname, metric in (("cosine", pkg.COSINE), ("dot", pkg.DOT)):
+            leg = {}
+            c.set_scan_filter(0)
+            ms, scan_ms, _, kn = _time_scans(c, metric, qs, k, 20)
+            leg["plain"] = {"ms_per_step": ms, "kernel": kn, "kernel_ms": scan_ms, "frac_of_hbm_peak": n_rows * dim * 4 / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if scan_ms > 0 else None}
+            plain_ans = c.scan_topk(metric, qs[0], k)
+            c.set_scan_filter(-1)
+            c.scan_topk(metric, qs[0], k)
+            c.filter_exact_evals()
+            ms, scan_ms, pre_ms, kn = _time_scans(c, metric, qs, k, 20)
+            ev = c.filter_exact_evals() / 23.0
+            dflt_ans = c.scan_topk(metric, qs[0], k)
+            leg["default_single"] = {"ms_per_step": ms, "kernel": kn, "kernel_ms": scan_ms, "prepass_ms": pre_ms, "exact_evaluations_per_query": ev,
+                                     "same_answer_as_plain_scan": bool(np.array_equal(plain_ans[0], dflt_ans[0]) and np.array_equal(plain_ans[1], dflt_ans[1]))}
+            for i in range(2):
+                c.scan_topk_batch(metric, qs[:nq_batch], k)
+            c.batch_filter_exact_evals()
+            t0 = time.perf_counter()
+            for i in range(5):
+                c.scan_topk_batch(metric, qs[:nq_batch], k)
+            bms = (time.perf_counter() - t0) / 5 * 1e3
+            leg["default_batch_%d" % nq_batch] = {"ms_per_step": bms, "batch_path": c.last_batch_path(), "exact_evaluations_per_query": c.batch_filter_exact_evals() / float(5 * nq_batch),
+                                                  "frac_of_int8_peak": 2.0 * nq_batch * n_rows * dim / (bms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS if c.last_batch_path() == 7 else None}
+            out["legs"]["f32_%s" % mname] = leg
+        c.close()
+        del c
+        torch.cuda.empty_cache()
+        # ---- the same clusters at 768 elements, quantized to uint8 with the reference's formula (sqlite-vector.c:1258-1268: scale = 255 / (max - min), offset = min)
+        dim8 = 768
+        centres8 = dgen.clustered_centres(torch, 43, dim8, device=dev)
+        lo8, hi8 = float("inf"), float("-inf")
+        for b in range(0, n_rows // blk, 5):                               # (min / max over a fifth of the blocks: the quantizer's parameters)
+            t = dgen.clustered_block(torch, centres8, 43, b, blk)
+            lo8, hi8 = min(lo8, float(t.min())), max(hi8, float(t.max()))
+            del t
+        scale8 = 255.0 / (hi8 - lo8)
+
+        def q8(t):
+            return torch.clamp(torch.floor((t - lo8) * scale8 + 0.5), 0, 255).to(torch.uint8)
+        c8 = pkg.Corpus(pkg.U8, dim8, capacity=n_rows, device=device_index)
+        levels = 0
+        for b in range(n_rows // blk):
+            t = q8(dgen.clustered_block(torch, centres8, 43, b, blk))
+            if b == 0:
+                levels = int(torch.unique(t).numel())
+            torch.cuda.synchronize()
+            c8.append_device(t.data_ptr(), blk, dim8)
+            del t
+        qs8 = q8(dgen.clustered_block(torch, centres8, 43 + 977, 0, max(nq_batch, 32), noise=dgen.QUERY_NOISE)).cpu().numpy()
+        leg = {"uint8_levels_in_use": levels}
+        c8.set_scan_filter(0)
+        ms, scan_ms, _, kn = _time_scans(c8, pkg.COSINE, qs8, k, 20)
+        leg["plain"] = {"ms_per_step": ms, "kernel": kn, "kernel_ms": scan_ms, "frac_of_hbm_peak": n_rows * dim8 / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if scan_ms > 0 else None}
+        c8.set_scan_filter(-1)
+        c8.scan_topk(pkg.COSINE, qs8[0], k)
+        c8.filter_exact_evals()
+        ms, scan_ms, pre_ms, kn = _time_scans(c8, pkg.COSINE, qs8, k, 20)
+        leg["default_single"] = {"ms_per_step": ms, "kernel": kn, "kernel_ms": scan_ms, "prepass_ms": pre_ms, "exact_evaluations_per_query": c8.filter_exact_evals() / 23.0,
+                                 "nibble_filter_in_use": "_n4_" in kn and c8.filter_guard_cooldown() == 0,
+                                 "guard_sent_the_queries_to_the_plain_kernel": c8.filter_guard_cooldown() > 0}
+        for i in range(2):
+            c8.scan_topk_batch(pkg.COSINE, qs8[:nq_batch], k)
+        t0 = time.perf_counter()
+        for i in range(3):
+            c8.scan_topk_batch(pkg.COSINE, qs8[:nq_batch], k)
+        bms = (time.perf_counter() - t0) / 3 * 1e3
+        leg["default_batch_%d" % nq_batch] = {"ms_per_step": bms, "batch_path": c8.last_batch_path(),
+                                              "frac_of_int8_peak": 2.0 * nq_batch * n_rows * dim8 / (bms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS}
+        out["legs"]["u8_768_cosine"] = leg
+        c8.close()
+        del c8
+        torch.cuda.empty_cache()
+        # ---- adversarial: 2M rows all within ~1e-3 of each other and of the queries
+        na = min(n_rows, 2_000_000)
+        ca = pkg.Corpus(pkg.F32, dim, capacity=na, device=device_index)
+        for b in range(na // blk):
+            t = dgen.adversarial_block(torch, 7, b, blk, dim, device=dev)
+            torch.cuda.synchronize()
+            ca.append_device(t.data_ptr(), blk, dim * 4)
+            del t
+        qa = dgen.adversarial_block(torch, 7, 9999, 32, dim, device=dev).cpu().numpy()
+        leg = {"rows": na}
+        ca.set_scan_filter(0)
+        pms, pscan, _, pkn = _time_scans(ca, pkg.COSINE, qa, k, 20)
+        plain_ans = ca.scan_topk(pkg.COSINE, qa[0], k)
+        ca.set_scan_filter(-1)
+        for i in range(4):                                                 # (the guard needs a few queries to see that the bound does not separate)
+            ca.scan_topk(pkg.COSINE, qa[i], k)
+        dms, dscan, _, dkn = _time_scans(ca, pkg.COSINE, qa, k, 20)
+        dflt_ans = ca.scan_topk(pkg.COSINE, qa[0], k)
+        leg.update({"plain_ms_per_step": pms, "plain_kernel": pkn, "default_ms_per_step": dms,
+                    "default_over_plain": dms / pms if pms > 0 else None, "guard_handed_the_queries_to_the_plain_kernel": ca.filter_guard_cooldown() > 0,
+                    "same_answer_as_plain_scan": bool(np.array_equal(plain_ans[0], dflt_ans[0]) and np.array_equal(plain_ans[1], dflt_ans[1]))})
+        out["legs"]["adversarial_f32_cosine"] = leg
+        ca.close()
+        torch.cuda.empty_cache()
+        L = out["legs"]
+        out["summary"] = {
+            "f32_cosine": {"plain_ms": round(L["f32_cosine"]["plain"]["ms_per_step"], 4), "default_single_ms": round(L["f32_cosine"]["default_single"]["ms_per_step"], 4),
+                           "single_evals_per_query": round(L["f32_cosine"]["default_single"]["exact_evaluations_per_query"], 1),
+                           "batch_ms": round(L["f32_cosine"]["default_batch_%d" % nq_batch]["ms_per_step"], 3),
+                           "batch_evals_per_query": round(L["f32_cosine"]["default_batch_%d" % nq_batch]["exact_evaluations_per_query"], 1)},
+            "f32_dot": {"plain_ms": round(L["f32_dot"]["plain"]["ms_per_step"], 4), "default_single_ms": round(L["f32_dot"]["default_single"]["ms_per_step"], 4),
+                        "batch_ms": round(L["f32_dot"]["default_batch_%d" % nq_batch]["ms_per_step"], 3)},
+            "u8_768_cosine": {"plain_ms": round(L["u8_768_cosine"]["plain"]["ms_per_step"], 4), "default_single_ms": round(L["u8_768_cosine"]["default_single"]["ms_per_step"], 4),
+                              "nibble_filter_in_use": L["u8_768_cosine"]["default_single"]["nibble_filter_in_use"],
+                              "batch_ms": round(L["u8_768_cosine"]["default_batch_%d" % nq_batch]["ms_per_step"], 3)},
+            "adversarial_default_over_plain": round(L["adversarial_f32_cosine"]["default_over_plain"], 3),
+        }
+    except Exception as e:
+        out["error"] = repr(e)
+    return out
 
 
 def also_long_rows(args, pkg, torch, k, device_index):

@@ -35,6 +35,9 @@ const char *vg_scan_kernel_name(vg_corpus *c, int metric);
 /* filter scan: f32 rows evaluated exactly by the filter-scan launches since the last call (then reset) - how selective the
  * bf16 bound is on the data at hand */
 int vg_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals);
+/* the filter scan's selectivity guard: > 0 = the next that many single scans of this corpus take the PLAIN kernel (the last filter
+ * launches evaluated more than 1/8 of the rows exactly: data the bound does not separate), 0 = the filter scan is in use */
+int vg_filter_guard_cooldown(vg_corpus *c);
 /* the same for f32 batches through the bf16 filter (vg_scan_topk_batch): (query, row) pairs evaluated exactly since the last call */
 int vg_batch_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals);
 /* which path answered this corpus' last vg_scan_topk_batch[_keys] call: 0 none yet, 1 the f32 matrix-core kernel, 2 the int8 one,

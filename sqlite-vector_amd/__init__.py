@@ -132,6 +132,7 @@ def _load():
         "vg_shards_patch_rows": (i32, [vp, vp, i64, vp, i64]),
         "vg_shards_delete_rows": (i32, [vp, vp, i64]),
         "vg_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
+        "vg_filter_guard_cooldown": (i32, [vp]),
         "vg_batch_filter_exact_evals": (i32, [vp, C.POINTER(C.c_ulonglong)]),
         "vg_reload_switches": (None, []),
         "vg_batch_last_path": (i32, [vp]),
@@ -323,6 +324,10 @@ class Corpus:
         v = C.c_ulonglong(0)
         _check(lib().vg_filter_exact_evals(self.h, C.byref(v)))
         return v.value
+
+    def filter_guard_cooldown(self):
+        """> 0: the selectivity guard has sent this corpus' next that many single scans to the plain kernel"""
+        return int(lib().vg_filter_guard_cooldown(self.h))
 
     def find_rowid(self, rowid):
         return int(lib().vg_corpus_find_rowid(self.h, rowid))

@@ -737,6 +737,8 @@ extern "C" int vg_filter_exact_evals(vg_corpus *c, unsigned long long *out_evals
     return VG_OK;
 }
 
+extern "C" int vg_filter_guard_cooldown(vg_corpus *c) { return c ? c->filter_cooldown : 0; }
+
 // Per-corpus switch of the filter scan (the extension's scan_filter= option): 0 = plain f32 scans, 1 = filter scan where it
 // serves, -1 = default (the VG_SCAN_FILTER environment switch, else on).  Turning it off releases nothing by itself.
 extern "C" int vg_corpus_set_scan_filter(vg_corpus *c, int mode) {

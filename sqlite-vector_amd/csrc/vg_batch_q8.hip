@@ -715,10 +715,6 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
     vgq_i32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
-#ifdef VGQ_PRIO_EXPERIMENT
-    if (VGQ_PRIO_EXPERIMENT == 1 && WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(2);
-    if (VGQ_PRIO_EXPERIMENT == 2 && WAVES == 8 && (wave & 1)) __builtin_amdgcn_s_setprio(2);
-#endif
 #if VGQ_TIMING
     unsigned long long tk_k = 0, tk_b = 0, tk_w = 0, tk_v = 0;
     const unsigned long long tk_loop0 = __builtin_readcyclecounter();
@@ -726,12 +722,6 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_
     for (int ti = 0; ti < T; ++ti) {
         const int sj = (ti + LEAD) >> 1;                                      // the statistics group this tile's first trip may issue
         const bool stat_turn = ((ti + LEAD) & 1) == 0 && 2 * sj < T + 1 && wave == (sj & (WAVES - 1));
-#ifdef VGQ_PRIO_EXPERIMENT
-        if (VGQ_PRIO_EXPERIMENT == 3 && M > 1) {                      // the wavefront that is BEHIND within a group has the higher priority
-            const int j = ti % M;
-            if (j == 0) __builtin_amdgcn_s_setprio(3); else if (j == 1) __builtin_amdgcn_s_setprio(2); else if (j == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-        }
-#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
         // one ring trip per K-part of the tile (KS = 1: the whole row): the accumulators run on across the parts

@@ -133,3 +133,44 @@ def same_float_bits(a, b):
     a = np.ascontiguousarray(a, dtype=np.float32)
     b = np.ascontiguousarray(b, dtype=np.float32)
     return np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b)))
+
+
+# ---- clustered, unit-norm data (round 6): what sentence-embedding tables look like, instead of iid N(0,1) - the shape the reference's own
+# example feeds it (examples/semantic_search/semantic_search.py:125-165: L2-normalised embeddings, cosine).  Pure functions of (seed, block):
+# bench.py's `also.clustered` leg and tests/test_gpu_clustered.py regenerate the same rows.  `torch` is passed in (this module stays importable
+# without it).
+CLUSTERS = 4096
+CLUSTER_NOISE = 0.5            # norm of the within-cluster noise against the unit centre: cos(row, its centre) ~ 0.89
+QUERY_NOISE = 0.3
+
+
+def clustered_centres(torch, seed, dim, n_clusters=CLUSTERS, device="cuda"):
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed * 7919 + 11)
+    c = torch.randn((n_clusters, dim), generator=gen, device=device, dtype=torch.float32)
+    return c / c.norm(dim=1, keepdim=True)
+
+
+def clustered_block(torch, centres, seed, b, n, noise=CLUSTER_NOISE):
+    """rows [b n, (b + 1) n) of the seeded stream: a random centre + N(0, noise^2 / dim) per element, L2-normalised; float32 on the centres' device"""
+    dev = centres.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed * 100_003 + b)
+    idx = torch.randint(0, centres.shape[0], (n,), generator=gen, device=dev)
+    x = centres[idx] + torch.randn((n, centres.shape[1]), generator=gen, device=dev, dtype=torch.float32) * (noise / centres.shape[1] ** 0.5)
+    return x / x.norm(dim=1, keepdim=True)
+
+
+def clustered_queries(torch, centres, seed, nq, noise=QUERY_NOISE):
+    """nq unit-norm queries near randomly chosen cluster centres (host float32 array)"""
+    return clustered_block(torch, centres, seed + 977, 0, nq, noise=noise).cpu().numpy()
+
+
+def adversarial_block(torch, seed, b, n, dim, device="cuda", spread=1.0e-4):
+    """every row within ~1e-3 of ONE unit vector (and so of every query made the same way): no lower bound can separate them"""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed * 7919 + 13)
+    base = torch.randn((1, dim), generator=gen, device=device, dtype=torch.float32)
+    base = base / base.norm()
+    gen.manual_seed(seed * 100_003 + b)
+    return base + torch.randn((n, dim), generator=gen, device=device, dtype=torch.float32) * spread
