@@ -102,7 +102,7 @@ static const VgSwitchName vg_switch_names[VGSW_COUNT] = {
     {"VG_SHAPE_PREF_ROUND1", 0},
     {"VG_U", 0},
 };
-int vg_switch_values[VGSW_COUNT];
+std::atomic<int> vg_switch_values[VGSW_COUNT];
 void vg_switches_read(void) {
     for (int i = 0; i < VGSW_COUNT; ++i) {
         int v = VGSW_UNSET;
@@ -117,7 +117,7 @@ void vg_switches_read(void) {
                 else v = atoi(e);
             }
         }
-        vg_switch_values[i] = v;
+        vg_switch_values[i].store(v, std::memory_order_relaxed);
     }
 }
 __attribute__((constructor)) static void vg_switches_at_load(void) { vg_switches_read(); }     // (before the first corpus: the table is never all zeros)

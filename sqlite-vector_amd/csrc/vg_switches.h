@@ -3,6 +3,7 @@
 // read ~60 getenv sites, some of them per enqueue).  Switches marked LAB exist in -DVG_LAB builds only (tools/build_*_variants.sh): they
 // are A/B switches whose losing side docs/EXPERIMENTS.md records; a product build compiles them to "unset".
 #pragma once
+#include <atomic>
 #include <climits>
 
 enum VgSwitch {
@@ -53,8 +54,10 @@ enum VgSwitch {
     VGSW_COUNT
 };
 #define VGSW_UNSET INT_MIN
-extern int vg_switch_values[VGSW_COUNT];          // VGSW_UNSET: not in the environment (vg_corpus.hip)
+// (atomics, relaxed: a corpus created on one thread re-reads the environment while scans of other connections read the table - the same
+//  values nearly always, but a plain int array made that a data race)
+extern std::atomic<int> vg_switch_values[VGSW_COUNT];          // VGSW_UNSET: not in the environment (vg_corpus.hip)
 void vg_switches_read(void);                      // (re)reads the environment
 // the switch's integer value, dflt when it is unset (VG_SCAN_FILTER_SHADOW: its first letter; VECTORGPU_SHARD_GATHER: 1 = "rccl")
-static inline int vg_sw(VgSwitch id, int dflt) { const int v = vg_switch_values[id]; return v == VGSW_UNSET ? dflt : v; }
-static inline bool vg_sw_set(VgSwitch id) { return vg_switch_values[id] != VGSW_UNSET; }
+static inline int vg_sw(VgSwitch id, int dflt) { const int v = vg_switch_values[id].load(std::memory_order_relaxed); return v == VGSW_UNSET ? dflt : v; }
+static inline bool vg_sw_set(VgSwitch id) { return vg_switch_values[id].load(std::memory_order_relaxed) != VGSW_UNSET; }

@@ -164,6 +164,57 @@ assert json.loads(b.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])[
 a.execute("DELETE FROM t WHERE id = ?", (int(ids[-1]) + 600,))
 a.close(); b.close()
 print("copy-on-write: one row re-sent for a commit among two holders")
+# a write to a TEMP table moves sqlite3_total_changes, not the file - the connection must KEEP its shared reference
+# (round 5 cloned the whole corpus on the device and never shared it again)
+a, b = connect(), connect()
+ra = a.execute(sql, (qq.tobytes(),)).fetchall()
+assert b.execute(sql, (qq.tobytes(),)).fetchall() == ra
+passes0 = json.loads(a.execute("SELECT vector_gpu_stats()").fetchone()[0])["stage_passes"]
+a.execute("CREATE TEMP TABLE scratch (x)")
+a.execute("INSERT INTO scratch VALUES (1), (2), (3)")
+assert a.execute(sql, (qq.tobytes(),)).fetchall() == ra
+ma = json.loads(a.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])["column"]
+sa = json.loads(a.execute("SELECT vector_gpu_stats()").fetchone()[0])
+assert ma["sharers"] == 2 and sa["shared_copies"] == 1 and sa["stage_passes"] == passes0, (ma, sa, passes0)
+a.close(); b.close()
+print("a TEMP-table write keeps the shared copy (sharers 2, no staging pass)")
+# the staging pass of one table must not hold up first scans of ANOTHER table (round 5: one process-wide mutex across
+# the whole pass).  Eight threads, two tables, every thread its own connection: all answers right, each table staged once per file state.
+d = connect()
+d.execute("CREATE TABLE u (id INTEGER PRIMARY KEY, v BLOB)")
+d.execute("BEGIN")
+d.executemany("INSERT INTO u VALUES (?, ?)", [(i + 1, rows[i].tobytes()) for i in range(50_000)])
+d.execute("COMMIT")
+d.close()
+keep = connect()                                         # (the library - and its statistics - live as long as one connection has it loaded)
+base2 = json.loads(keep.execute("SELECT vector_gpu_stats()").fetchone()[0])
+errors2, bar2 = [], threading.Barrier(8)
+def worker2(i):
+    try:
+        c = sqlite3.connect(path, isolation_level=None, check_same_thread=False, timeout=60)
+        c.enable_load_extension(True)
+        c.load_extension(ext)
+        tbl = "t" if i % 2 == 0 else "u"
+        c.execute("SELECT vector_init('%s', 'v', 'type=FLOAT32,dimension=%d,distance=L2')" % (tbl, dim))
+        bar2.wait()
+        got = c.execute("SELECT rowid, distance FROM vector_full_scan('%s', 'v', ?, 1)" % tbl, (rows[9].tobytes(),)).fetchall()
+        assert got == [((int(ids[9]) if tbl == "t" else 10), 0.0)], (tbl, got)
+        bar2.wait()
+        c.close()
+    except Exception as e:                                # noqa
+        errors2.append((i, repr(e)))
+        try: bar2.abort()
+        except Exception: pass
+th = [threading.Thread(target=worker2, args=(i,)) for i in range(8)]
+[t.start() for t in th]; [t.join() for t in th]
+assert not errors2, errors2
+st2 = json.loads(keep.execute("SELECT vector_gpu_stats()").fetchone()[0])
+keep.close()
+assert 2 <= st2["stage_passes"] + st2["parallel_reader_passes"] - base2["stage_passes"] - base2["parallel_reader_passes"] <= 3 and st2["shared_published"] - base2["shared_published"] == 2, (base2, st2)   # one pass and one published copy per table
+print("two tables staged side by side: passes", st2["stage_passes"] - base2["stage_passes"], "parallel", st2["parallel_reader_passes"] - base2["parallel_reader_passes"], "rows", st2["rows_staged"] - base2["rows_staged"])
+d = connect()
+d.execute("DROP TABLE u")
+d.close()
 d = connect()
 assert json.loads(d.execute("SELECT vector_gpu_stats()").fetchone()[0])["shared_copies"] == 0      # the last reference freed it
 d.execute("DELETE FROM t WHERE id = ?", (int(ids[-1]) + 500,))
