@@ -283,14 +283,18 @@ def cpu_baseline(vt, np_dtype, dim, metric, k, sample_rows, seconds=10.0, all_co
         budget = min(48 << 30, int(host.get("mem_available_bytes") or (8 << 30)) // 3)        # private copies: at most a third of what is free
         repeat = max(1, min(repeat, budget // max(1, nthreads * per * row_bytes)))
         big = rows[:per * nthreads]
-        rate, per, ids, d, cnt, pinned = ref.scan_topk_all_cores(metric, vt, queries[:8], big, k, nthreads, 4.0, cpus=cpus[:nthreads], repeat=repeat)
+        # fewer threads than CPUs in the mask (a quota): spread them evenly over the mask - over the sockets and core complexes, each with its
+        # own memory channels and caches - instead of packing them onto the first few (16 threads on CPUs 0-15 of a 2 x 64-core host: 3.6 x one core)
+        pick = [cpus[(i * len(cpus)) // nthreads] for i in range(nthreads)]
+        rate, per, ids, d, cnt, pinned = ref.scan_topk_all_cores(metric, vt, queries[:8], big, k, nthreads, 4.0, cpus=pick, repeat=repeat)
         cand = sorted((float(dd), int(i) - 1 + t * per) for t in range(nthreads) for i, dd in zip(ids[t][:cnt[t]], d[t][:cnt[t]]))[:k]
         whole = work(big, q)
         merged_ok = [c[1] + 1 for c in cand] == np.asarray(whole[0]).tolist()[:k] or sorted(c[0] for c in cand) == sorted(np.asarray(whole[1]).tolist()[:k])
         out["all_cores"] = {"value": rate, "unit": "vectors/s", "cores": nthreads, "threads_pinned": int(pinned),
                             "GB_per_s": rate * row_bytes / 1e9, "x_one_core": rate / out["value"] if out["value"] else None,
                             "rows_per_thread_per_timed_scan": int(per * repeat), "private_copy_MB_per_thread": per * repeat * row_bytes / 1e6,
-                            "rows": int(per * nthreads), "merged_lists_equal_the_unsplit_scan": bool(merged_ok),
+                            "rows": int(per * nthreads), "cpus_used": pick if nthreads <= 32 else "%d CPUs, every %dth of the mask" % (nthreads, max(1, len(cpus) // nthreads)),
+                            "merged_lists_equal_the_unsplit_scan": bool(merged_ok),
                             "limited_by": ("cgroup cpu.max quota of %.1f cores (affinity mask: %d CPUs)" % (quota, len(cpus))) if (quota and quota < len(cpus))
                                           else "the affinity mask (%d of the host's %d logical CPUs)" % (len(cpus), os.cpu_count() or 0),
                             "note": "a row split of ONE %d x %d matrix (%s) over %d pinned pthreads (oracle/oracle.c orc_scan_topk_threads_pinned): thread i "
