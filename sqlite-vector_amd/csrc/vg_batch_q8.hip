@@ -47,11 +47,15 @@ typedef int vgq_i32x16 __attribute__((ext_vector_type(16)));
 // 384 VGPRs at 1536) - ONE set per wavefront (192), EIGHT wavefronts per workgroup (still 256 queries per pass over the copy), one workgroup
 // per CU, and the ring moves SUB-tiles: 32 rows x NTB k-steps = one K-part of a tile (contiguous in the tile-major copy); the accumulators
 // are carried over a tile's KS parts and the tile boundary runs behind the last one.
+#ifndef VGQL_WAVES
 #define VGQL_WAVES 8
+#endif
+#ifndef VGQL_QS
 #define VGQL_QS 1
+#endif
 #define VGQL_RING 6
 #define VGQ_TILE 32
-#define VGQ_MAX_K 32
+#define VGQ_MAX_K 64                    // (round 6: one list slot per lane of the exact-evaluation wavefront - the single scans' own limit)
 #define VGQ_BPIPE 4
 #define VGQ_RING_OF(NTB) ((NTB) <= 8 ? 6 : (NTB) <= 12 ? 4 : 3)      // tile buffers: two workgroups' rings + statistics + queues fit 160 KB
 #ifndef VGQW_RING
@@ -294,9 +298,9 @@ __device__ __forceinline__ void vgq_wait_lds(vgh_i32x4 &v) {
 // WAVES x QS x 32 = 256 queries per workgroup; KS = K-parts per tile (1: the whole row is one ring buffer)
 // PRE = the bound-only pre-pass (round 6): no gate, no pairs - per (query, tile) the smallest UPPER bound of the distance (see pre_boundary)
 template <int NTB, int MODE, int WAVES = VGQ_WAVES, int QS = VGQ_QS, int KS = 1, bool PRE = false>
-__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? 2 : 1)) void vg_batch_q8_kernel(BatchArgsQ8 a) {
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void vg_batch_q8_kernel(BatchArgsQ8 a) {
     constexpr int THREADS = 64 * WAVES, QPW = 32 * QS, QENT = 16 * QS + 8, QPB = WAVES * QPW;
-    constexpr int NB = WAVES == 4 ? VGQ_RING_OF(NTB) : (KS == 1 && QS == 2 ? VGQW_RING_OF(NTB) : VGQL_RING);   // ring buffers in LDS; one workgroup per CU: six
+    constexpr int NB = (WAVES == 4 && KS == 1) ? VGQ_RING_OF(NTB) : (KS == 1 && QS == 2 ? VGQW_RING_OF(NTB) : VGQL_RING);   // ring buffers in LDS; one workgroup per CU: six
     constexpr bool COS = (MODE == VGH_COS), L2M = (MODE == VGH_L2);
     constexpr int TILE_BYTES = NTB * 2 * 512;
     // TRIPS PER BARRIER (round 6).  Measured with a cycle counter per wavefront (profiles/r10_q8_cycles_per_wave_tile.txt): the SIMD's arbiter

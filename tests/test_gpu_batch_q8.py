@@ -250,3 +250,64 @@ def test_int8_filter_batch_over_long_rows(pkg, orc, vt, dim, monkeypatch):
                 assert np.allclose(dist[i][:cnt[i]], one_d, rtol=1e-5, atol=1e-30)
     monkeypatch.delenv("VG_BATCH_Q8")
     c.close()
+
+
+@pytest.mark.parametrize("k", (33, 64))
+def test_int8_filter_lists_of_up_to_64(pkg, orc, k, monkeypatch):
+    """lists of 33 .. 64 entries on the matrix cores (round 6: the int8 filter's exact-evaluation lists are as long as the single scans' -
+    vector_full_scan_batch(..., 64)): every query against the ORACLE's distances over all rows (adversarial rows included), and against a
+    single scan of the same query up to ties"""
+    dim, n, nq = 384, 70_001, 513
+    rng = np.random.default_rng(9100 + k)
+    rows = rng.standard_normal((n, dim), dtype=np.float32)
+    qs = rng.standard_normal((nq, dim), dtype=np.float32)
+    rows = _adversarial(rows, qs, rng)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    monkeypatch.setenv("VG_BATCH_Q8", "1")
+    for metric in (dg.DOT, dg.COSINE, dg.L2):
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        assert c.last_batch_path() == 7, (metric, k, c.last_batch_path(), c.batch_q8_status())
+        assert np.all(cnt == k)
+        for i in range(0, nq, 8):
+            want = orc.scan_distances(orc.AVX2, metric, dg.F32, qs[i], rows)
+            _check_float_distances(dist[i].astype(np.float32), want[ids[i] - 1], dg.F32, metric, qs[i], rows[ids[i] - 1])
+            rest = np.delete(want, ids[i] - 1)
+            rest = rest[np.isfinite(rest)]
+            tol = 1e-5 * (abs(float(dist[i][k - 1])) + (float(np.abs(qs[i]).sum()) * 4.0 if metric == dg.DOT else (1.0 if metric == dg.COSINE else 0.0)))
+            assert rest.min() >= dist[i][k - 1] - tol, (metric, k, i)          # nothing better was left behind
+        for i in (0, 1, 2, 3, 4, 100):
+            one_ids, one_dist = c.scan_topk(metric, qs[i], k)
+            _same_topk_up_to_ties(ids[i], dist[i], one_ids, one_dist, rtol=1e-5)
+    monkeypatch.delenv("VG_BATCH_Q8")
+    c.close()
+
+
+def test_int8_filter_adversarial_rows_against_the_oracle(pkg, orc, monkeypatch):
+    """oracle-anchored, not GPU-vs-GPU: duplicates of queries, one huge element, constant / zero rows, Inf / NaN rows, 1e+-12
+    norms, a cluster of near-duplicates - every 8th query's list of the int8-filter batch against orc.scan_distances over all 70 001 rows"""
+    dim, n, nq, k = 384, 70_001, 513, 20
+    rng = np.random.default_rng(9200)
+    rows = rng.standard_normal((n, dim), dtype=np.float32)
+    qs = rng.standard_normal((nq, dim), dtype=np.float32)
+    qs[9, 0] = np.float32(50.0)
+    rows = _adversarial(rows, qs, rng)
+    c = pkg.Corpus(pkg.F32, dim)
+    c.append(rows)
+    monkeypatch.setenv("VG_BATCH_Q8", "1")
+    for metric in (dg.DOT, dg.COSINE, dg.L2, dg.SQUARED_L2):
+        ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+        assert c.last_batch_path() == 7
+        for i in list(range(0, nq, 8)) + [1, 2, 3, 4, 9]:
+            m = cnt[i]
+            assert m == k, (metric, i, m)
+            want = orc.scan_distances(orc.AVX2, metric, dg.F32, qs[i], rows)
+            _check_float_distances(dist[i][:m].astype(np.float32), want[ids[i][:m] - 1], dg.F32, metric, qs[i], rows[ids[i][:m] - 1])
+            rest = np.delete(want, ids[i][:m] - 1)
+            rest = rest[np.isfinite(rest)]
+            tol = 1e-5 * (abs(float(dist[i][m - 1])) + (float(np.abs(qs[i]).sum()) * 4.0 if metric == dg.DOT else (1.0 if metric == dg.COSINE else 0.0)))
+            assert len(rest) == 0 or rest.min() >= dist[i][m - 1] - tol, (metric, i)
+        if metric != dg.DOT:
+            assert ids[0][0] == 12 and ids[1][0] == n, (ids[0][:3], ids[1][:3])    # the planted duplicates are every such query's best row
+    monkeypatch.delenv("VG_BATCH_Q8")
+    c.close()
