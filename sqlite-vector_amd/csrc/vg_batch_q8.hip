@@ -72,13 +72,16 @@ typedef int vgq_i32x16 __attribute__((ext_vector_type(16)));
 #define VGQ_TPB 3                       // short rows: ring trips (tiles) per workgroup barrier where the ring has six buffers (see the tile loop)
 #endif
 #ifndef VGQ_PRE_TILES
-#define VGQ_PRE_TILES 1024              // the bound-only pre-pass: tiles it covers (at most 1/8 of the corpus; <= 2048: vg_q8_pre_select_kernel keeps 32 tile minima per lane)
+#define VGQ_PRE_TILES 512              // the bound-only pre-pass: tiles it covers (at most 1/8 of the corpus; <= 2048: vg_q8_pre_select_kernel keeps 32 tile minima per lane)
 #endif
 #ifndef VGQ_HX_GROUP
 #define VGQ_HX_GROUP 4                  // partitions one exact-evaluation block walks at most (BatchArgsH.part_group)
 #endif
+#ifndef VGQ_HX_GROUP_FIRST
+#define VGQ_HX_GROUP_FIRST 0
+#endif
 #ifndef VGQ_FIRST_MULT
-#define VGQ_FIRST_MULT 4                // the first real stage ends at VGQ_FIRST_MULT x the pre-pass' tiles (long rows: 1 x - their bound is twice as wide
+#define VGQ_FIRST_MULT 2                // the first real stage ends at VGQ_FIRST_MULT x the pre-pass' tiles (long rows: 1 x - their bound is twice as wide
 #endif                                  // against the spread of the scores, and an exact evaluation reads up to 6 KB); measured: profiles/r10_q8_schedule_sweep.txt
 #ifndef VGQ_ABLATE
 #define VGQ_ABLATE 0                    // measurement builds (wrong results): 1 = candidates dropped; 2 = no gate; 3 = + no LDS-DMA; 4 = + no barrier
@@ -208,32 +211,27 @@ __global__ __launch_bounds__(256) void vg_q8_query_prep_kernel(const uint8_t *xq
 }
 // perm[rank of query i by (key, i)] = i, and the scale of the batch's MEDIAN query (by key) - what an L2 batch's shared scale is taken
 // from (vg_q8_query_prep_kernel, phase 2: one query with a single huge element must not take the int8 grid away from all the others; it is
-// answered by a single scan instead).  nq_pad / 256 workgroups, every thread ranks ONE query against all of them (nq_pad <= 4096: 16 KB of
-// keys in LDS per workgroup); round 5 ran this in one workgroup: 46 us of a 5 ms batch.
+// answered by a single scan instead).  Round 5 ran this in ONE workgroup: 46 us of a 5 ms batch.
 __global__ __launch_bounds__(256) void vg_q8_rank_kernel(const float *keys, const float *scales, int nq_pad, int *perm, float *median_scale) {
-    extern __shared__ __attribute__((aligned(16))) float vgq_keys_lds[];
-    __shared__ int sjudged[4];
-    int judged = 0;
-    for (int i = threadIdx.x; i < nq_pad; i += 256) { const float kv = keys[i]; vgq_keys_lds[i] = kv; judged += (kv < INFINITY) ? 1 : 0; }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) judged += __shfl_xor(judged, s);
-    if ((threadIdx.x & 63) == 0) sjudged[threadIdx.x >> 6] = judged;
-    __syncthreads();
-    judged = sjudged[0] + sjudged[1] + sjudged[2] + sjudged[3];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && judged == 0) *median_scale = 0.0f;
-    const float4 *k4 = reinterpret_cast<const float4 *>(vgq_keys_lds);
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // one WAVEFRONT per query: lane l compares keys l, l + 64, ... (the 4 .. 16 KB of keys stay in the L2) - 1 024 wavefronts of 16 loads each
+    // instead of 1 024 threads of 1 024 LDS reads each (8 us against 32)
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (i >= nq_pad) return;
-    const float ki = vgq_keys_lds[i];
-    int rank = 0;
-    for (int j4 = 0; j4 < nq_pad / 4; ++j4) {                           // (nq_pad is a multiple of 256)
-        const float4 kj = k4[j4];
-        const int j = 4 * j4;
-        rank += (kj.x < ki || (kj.x == ki && j < i)) + (kj.y < ki || (kj.y == ki && j + 1 < i)) + (kj.z < ki || (kj.z == ki && j + 2 < i)) +
-                (kj.w < ki || (kj.w == ki && j + 3 < i));
+    const float ki = keys[i];
+    int rank = 0, judged = 0;
+    for (int j = lane; j < nq_pad; j += 64) {
+        const float kj = keys[j];
+        rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+        judged += (kj < INFINITY) ? 1 : 0;
     }
-    perm[rank] = i;
-    if (judged > 0 && rank == judged / 2) *median_scale = scales[i];     // (the judged queries hold the first `judged` ranks; one writer)
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { rank += __shfl_xor(rank, s); judged += __shfl_xor(judged, s); }
+    if (lane == 0) {
+        perm[rank] = i;
+        if (judged > 0 && rank == judged / 2) *median_scale = scales[i];     // (the judged queries hold the first `judged` ranks; one writer)
+        if (judged == 0 && i == 0) *median_scale = 0.0f;
+    }
 }
 
 // ---- per-row statistics in the layout the filter's LDS-DMA moves (16 bytes per row)
@@ -979,7 +977,7 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     const dim3 pg((unsigned)((nq_pad + 3) / 4));
     hipLaunchKernelGGL(vg_q8_query_prep_kernel, pg, dim3(256), 0, stream, dev_xqueries, xstride, dim, nq_real, nq_pad, mode, (const int *)nullptr,
                        (const float *)nullptr, (const float *)nullptr, qkeys, qscales, (uint8_t *)nullptr, (uint8_t *)nullptr, q8stride, (float4 *)nullptr, type_code);
-    hipLaunchKernelGGL(vg_q8_rank_kernel, dim3((unsigned)(nq_pad / 256)), dim3(256), (size_t)nq_pad * 4, stream, (const float *)qkeys, (const float *)qscales, nq_pad, perm, common);
+    hipLaunchKernelGGL(vg_q8_rank_kernel, dim3((unsigned)(nq_pad / 4)), dim3(256), 0, stream, (const float *)qkeys, (const float *)qscales, nq_pad, perm, common);
     hipLaunchKernelGGL(vg_q8_query_prep_kernel, pg, dim3(256), 0, stream, dev_xqueries, xstride, dim, nq_real, nq_pad, mode, (const int *)perm,
                        (const float *)common, (const float *)qscales, (float *)nullptr, (float *)nullptr, xq_sorted, qcodes, q8stride, qstat, type_code);
     int rc = (int)hipGetLastError();
@@ -1072,6 +1070,7 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
         // one exact-evaluation block per 32 queries and pg consecutive partitions: 16 .. 31 lists per query reach the merge instead of up to 128
         int pg = (np % 8 == 0 && np / 8 >= 16) ? 8 : ((np % 4 == 0 && np / 4 >= 16) ? 4 : ((np % 2 == 0 && np / 2 >= 16) ? 2 : 1));
         if (pg > VGQ_HX_GROUP) pg = VGQ_HX_GROUP;
+        if (s == 0 && VGQ_HX_GROUP_FIRST) pg = 1;                           // (the first stage has several hundred pairs per query: its walks are long enough)
         hx.part_group = pg;
         const int hx_blocks = hx.n_regions / pg, lists = np / pg;
         if ((rc = launch_filter(G * np, false)) != 0) return rc;
