@@ -96,6 +96,11 @@ if "--update-traffic" in sys.argv and traffic:
     import bench
     h = bench.kernel_source_hash()
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    old_tab = {}
+    try:
+        old_tab = json.load(open(path))
+    except Exception:
+        pass
     tab = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE passes (their own runs, tools/measure.sh pmc): "
                        "FETCH_SIZE[KB] x 1024 x 2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md section HBM), "
                        "full-corpus dispatches only.  bench.py copies the entry matching its kernel and row count into "
@@ -106,5 +111,8 @@ if "--update-traffic" in sys.argv and traffic:
             "bytes_per_launch": int(round(kb * 2048)), "fetch_size_kb": round(kb, 1), "dispatches": n, "kernel_source_hash": h,
             "source": "profiles/%s_default_bench_pmc_fetch_size.csv (rocprofv3 --pmc FETCH_SIZE of `python bench.py`, its own run; "
                       "KB x 1024 x 2 = gfx950 128-B request correction; full-corpus dispatches only)" % tag}
+    for kk, vv in old_tab.items():                       # (the batched workloads' entries - tools/pmc_batch.sh - are not this pass' to drop)
+        if kk.startswith("batch_") and kk not in tab:
+            tab[kk] = vv
     json.dump(tab, open(path, "w"), indent=1)
     print("\n# profiles/pmc_traffic.json rewritten for kernel sources %s: %s" % (h, ", ".join(sorted(traffic))))
