@@ -113,8 +113,17 @@ template <int VT, int ACC> struct AccumHalf {
             if (VT == T_F16) {              // f32 subtract, square in f64 (distance-avx2.c:186-205)
                 const double d0 = (double)(q0 - x0), d1 = (double)(q1 - x1);
                 s0 = fma(d0, d0, s0); s1 = fma(d1, d1, s1);
-            } else {                         // f64 subtract (distance-avx2.c:383-409)
+            } else {
+                // The reference subtracts in f64 (distance-avx2.c:383-409).  The f32 difference of two bf16 values (8 significant bits) is
+                // EXACT unless their exponents lie more than 16 apart - then it is off by <= 2^-24 of itself, 2^-23 of its square, far
+                // inside the bar of finite rows (2 ulp of the float result) - and it saves two of the four f32 -> f64 conversions per
+                // element pair: the bf16 L2 kernel was the slowest plain scan (0.75-0.79 of the HBM peak against 0.82 for f16, whose
+                // reference arithmetic is exactly this).  VG_BF16_F64_DIFF=1 keeps the f64 subtraction (A/B).
+#if defined(VG_BF16_F64_DIFF) && VG_BF16_F64_DIFF
                 const double d0 = (double)q0 - (double)x0, d1 = (double)q1 - (double)x1;
+#else
+                const double d0 = (double)(q0 - x0), d1 = (double)(q1 - x1);
+#endif
                 s0 = fma(d0, d0, s0); s1 = fma(d1, d1, s1);
             }
         } else if (ACC == A_L1) {

@@ -168,6 +168,45 @@ __global__ __launch_bounds__(256) void vg_quantize_kernel(const uint8_t *rows, l
         for (int c0 = 0; c0 < nch; c0 += 16 * G) {
             uint4 buf[G];
             vgq_load_part<G>(buf, p, c0, l16, nch);
+            if constexpr (N == 4 && G >= 4) {
+                // f32 rows: a chunk becomes ONE output dword, and 64 lanes x 4 bytes per store instruction left the pass store-issue bound
+                // (0.75-0.80 of the HBM peak).  Four chunk groups at a time, the four lanes of a quad transpose their 4 x 4 dwords (two
+                // DPP exchange stages) so that lane i holds the 16 CONTIGUOUS bytes of group i: one dwordx4 store per lane and four groups.
+                if (packed_ok && (dim & 15) == 0 && c0 + 64 <= full) {
+                    uint32_t a[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float e[N];
+                        VgqChunk<VT>::widen(buf[g], e);
+                        a[g] = vgq_one<VT>(e[0], scale, offset, qtype_u8) | (vgq_one<VT>(e[1], scale, offset, qtype_u8) << 8) |
+                               (vgq_one<VT>(e[2], scale, offset, qtype_u8) << 16) | (vgq_one<VT>(e[3], scale, offset, qtype_u8) << 24);
+                    }
+                    const bool odd = (l16 & 1) != 0, hi = (l16 & 2) != 0;
+                    {   // lanes i, i ^ 1 swap what the other one needs of (a0, a1) and of (a2, a3)
+                        const uint32_t r01 = vg_dpp_u32<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(odd ? a[0] : a[1]);
+                        const uint32_t r23 = vg_dpp_u32<VG_DPP_QUAD_PERM(1, 0, 3, 2)>(odd ? a[2] : a[3]);
+                        if (odd) { a[0] = r01; a[2] = r23; } else { a[1] = r01; a[3] = r23; }
+                    }
+                    {   // lanes i, i ^ 2 swap (a0, a1) against (a2, a3)
+                        const uint32_t r0 = vg_dpp_u32<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(hi ? a[0] : a[2]);
+                        const uint32_t r1 = vg_dpp_u32<VG_DPP_QUAD_PERM(2, 3, 0, 1)>(hi ? a[1] : a[3]);
+                        if (hi) { a[0] = r0; a[1] = r1; } else { a[2] = r0; a[3] = r1; }
+                    }
+                    // lane i of the quad now holds the dwords of its quad's four lanes for group i (in lane order: a0 from lane 0 ...)
+                    const int cq = c0 + (l16 & 3) * 16 + (l16 & ~3);
+                    *reinterpret_cast<uint4 *>(o + cq * 4) = make_uint4(a[0], a[1], a[2], a[3]);
+#pragma unroll
+                    for (int g = 4; g < G; ++g) {
+                        const int c = c0 + g * 16 + l16;
+                        float e[N];
+                        VgqChunk<VT>::widen(buf[g], e);
+                        if (c < full)
+                            *reinterpret_cast<uint32_t *>(o + c * 4) = vgq_one<VT>(e[0], scale, offset, qtype_u8) | (vgq_one<VT>(e[1], scale, offset, qtype_u8) << 8) |
+                                                                       (vgq_one<VT>(e[2], scale, offset, qtype_u8) << 16) | (vgq_one<VT>(e[3], scale, offset, qtype_u8) << 24);
+                    }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int c = c0 + g * 16 + l16;
