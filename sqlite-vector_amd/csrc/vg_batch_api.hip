@@ -311,8 +311,8 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
 }
 
 // ---- f32 corpora, large batches: the INTEGER matrix cores as the filter over the int8 shadow copy (vg_batch_q8.hip) - 64 queries per
-// wavefront, a quarter of the corpus' bytes streamed, the single scan's f32 arithmetic for the pairs that pass.  Default for batches of more
-// than 256 queries (a workgroup holds 512) over corpora the filter scans' policy covers; VG_BATCH_Q8=0 / 1 forces it off / on.
+// wavefront, a quarter of the corpus' bytes streamed, the single scan's f32 arithmetic for the pairs that pass.  Default for every batch
+// (round 5: from 257 queries on) over corpora the filter scans' policy covers; VG_BATCH_Q8=0 / 1 forces it off / on.
 extern "C" int vg_batch_q8_serves(long long q8stride_bytes, long long xstride_bytes, int k);
 extern "C" int vg_batch_q8_queries_per_block(void);
 extern "C" int vg_batch_q8_regions(int nq_pad, int npart);
@@ -335,8 +335,11 @@ static bool batch_q8_eligible(const vg_corpus *c, int metric, int k, int nq) {
     const bool served_type = c->vtype == VG_TYPE_F32 || c->vtype == VG_TYPE_F16 || c->vtype == VG_TYPE_BF16;   // (the int8 image of the row, whatever it is stored as)
     if (vg_sw(SW_VG_BATCH_MFMA, 1) == 0 || !served_type || metric == VG_DIST_L1 || c->q8tm_disabled || c->filter_disabled) return false;
     const int sw = vg_sw(SW_VG_BATCH_Q8, -1);
+    if (sw != 1 && c->vtype == VG_TYPE_F32 && vg_sw(SW_VG_F32_FILTER, -1) == 0) return false;    // VG_F32_FILTER=0: f32 batches unfiltered (the f32 matrix-core kernel)
     if (sw == 0 || c->n_rows < (sw == 1 ? (1ll << 16) : (1ll << 20))) return false;     // (forced: from 2048 tiles on - the tests' sizes)
-    if (sw < 0 && (nq <= 256 || !vg_scan_filter_policy(c))) return false;             // (its own overflow guard: bq8_cooldown; the bf16 filter's does not apply)
+    // (round 6: every batch size - with the all-padding-set fix a 4-query batch takes 1.3 ms here against 2.2 through the bf16 filter, 128
+    //  queries 1.6 against 2.4, 256 queries 2.0 against 3.0; profiles/r10_small_batches_int8_vs_bf16_filter.txt)
+    if (sw < 0 && !vg_scan_filter_policy(c)) return false;             // (its own overflow guard: bq8_cooldown; the bf16 filter's does not apply)
     return vg_batch_q8_serves(q8_shadow_stride_of(c), c->stride, k) != 0;
 }
 // the tile-major int8 copy + its per-row statistics, built from the row-major shadow copy (vg_filter.hip) and the cached norms, extended

@@ -605,7 +605,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
             if constexpr (L2M) rest = fmaf(-mx2, uumin[s], rest);
             if (COS && nx == 0.0f) rest = -uumin[s];                   // a zero row's cosine distance is 1.0 whatever the query (distance-cpu.c:74-110)
             const float tf = -rest * inv_sx;
-            const float tf2 = fmaf(fabsf(tf), -1.0e-6f, tf);
+            // (a set of padding / unjudged queries only: rest = -Inf, tf = +Inf - and Inf - Inf below was NaN, which the conversion turns into
+            //  0: every lane of every tile became a candidate of such a set, and a 300-query batch - 212 padding slots - took 7.1 ms where 512
+            //  queries take 2.5; found in round 6 with ragged batch sizes, tools/r6_small_batch.py)
+            const float tf2 = fabsf(tf) < 3.0e38f ? fmaf(fabsf(tf), -1.0e-6f, tf) : tf;
             int it;
             asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(it) : "v"(tf2));
             ithr[s] = it;

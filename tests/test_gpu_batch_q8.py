@@ -95,9 +95,10 @@ def test_int8_filter_batch_equals_the_bf16_filter_batch(pkg, orc, dim, monkeypat
 
 
 def test_int8_filter_default_policy_appends_and_unselective_rows(pkg, monkeypatch):
-    """default policy: batches of more than 256 queries over a corpus the filter scans' policy covers (>= 2^20 rows) take the int8
-    filter, smaller ones the bf16 filter; rows appended afterwards extend the tile-major copy; a corpus the bound cannot separate
-    (copies of one row) overflows the pair regions, is answered by the other paths, and cools the int8 path down"""
+    """default policy: EVERY batch (round 6; round 5: more than 256 queries) over a corpus the filter scans' policy covers (>= 2^20 rows)
+    takes the int8 filter - a ragged 300-query batch (212 padding slots), 200 queries, 5 queries; VG_BATCH_Q8=0 keeps the bf16 filter;
+    rows appended afterwards extend the tile-major copy; a corpus the bound cannot separate (copies of one row) overflows the pair
+    regions, is answered by the other paths, and cools the int8 path down"""
     monkeypatch.delenv("VG_F32_FILTER", raising=False)
     monkeypatch.delenv("VG_BATCH_Q8", raising=False)
     monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
@@ -113,9 +114,16 @@ def test_int8_filter_default_policy_appends_and_unselective_rows(pkg, monkeypatc
         assert c.last_batch_path() == 7, (metric, c.last_batch_path(), c.batch_q8_status())
         evals = c.batch_filter_exact_evals()
         assert 0 < evals < 300 * n // 256, (metric, evals)          # the int8 bound is selective on this data
-        ids2, dist2, cnt2 = c.scan_topk_batch(metric, qs[:200], k)
-        # <= 256 queries: the bf16 filter (same exact-evaluation arithmetic: the same bits) - or, once ITS selectivity guard has seen this
+        # smaller batches take the same path (another padding, another sort order of the slots): the same bits for the same queries
+        for sub in (200, 5):
+            ids2, dist2, cnt2 = c.scan_topk_batch(metric, qs[:sub], k)
+            assert c.last_batch_path() == 7, (metric, sub, c.last_batch_path())
+            assert np.array_equal(ids[:sub], ids2) and dg.same_float_bits(dist[:sub], dist2), (metric, sub)
+        # VG_BATCH_Q8=0: the bf16 filter (same exact-evaluation arithmetic: the same bits) - or, once ITS selectivity guard has seen this
         # small corpus' warm-up (lists starting at +Inf: one evaluation per 256 pairs is exceeded), the f32 matrix-core kernel
+        monkeypatch.setenv("VG_BATCH_Q8", "0")
+        ids2, dist2, cnt2 = c.scan_topk_batch(metric, qs[:200], k)
+        monkeypatch.delenv("VG_BATCH_Q8")
         assert c.last_batch_path() in (1, 3)
         if c.last_batch_path() == 3:
             assert np.array_equal(ids[:200], ids2) and dg.same_float_bits(dist[:200], dist2)

@@ -489,7 +489,8 @@ def test_batch_f32_long_rows_through_the_bf16_filter(pkg, orc, metric, monkeypat
 @pytest.mark.gpu
 def test_batch_f32_filter_default_policy_and_selectivity_guard(pkg, monkeypatch):
     """f32 batches of a corpus the filter scan serves (switched on, large enough - here VG_SCAN_FILTER_MIN_MB=0) go through
-    the bf16-filter kernel by default: same lists as the f32 matrix-core kernel; scan_filter=0 / VG_F32_FILTER=0 keep the f32
+    a matrix-core FILTER by default (round 6: the int8 filter at every batch size; below 2^20 rows - the copies-of-one-row corpus
+    at the end - the bf16 filter): same lists as the f32 matrix-core kernel; scan_filter=0 / VG_F32_FILTER=0 keep the f32
     kernel; on rows the bound cannot separate (copies of one row) the guard sends the next batches back to the f32 kernel."""
     monkeypatch.delenv("VG_F32_FILTER", raising=False)
     monkeypatch.setenv("VG_SCAN_FILTER_MIN_MB", "0")
