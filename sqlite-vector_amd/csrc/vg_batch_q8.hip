@@ -65,7 +65,7 @@ typedef int vgq_i32x16 __attribute__((ext_vector_type(16)));
 #ifndef VGQ_DMA_AT_END
 #define VGQ_DMA_AT_END 1                // wide form: waves 0-3 issue a group's LDS-DMA behind their last boundary of the group, where they would wait for waves 4-7 (see the tile loop)
 #endif
-#define VGQ_QCAP 16                     // candidate lanes a wavefront collects before it looks at their accumulators (160 bytes each)
+#define VGQ_QCAP 16                     // candidate lanes a wavefront collects before it looks at their accumulators (160 bytes each)   (= 64 lanes / 4 lanes per entry: a queue run looks at exactly that many)
 #define VGQ_STAT_SLOTS 8                // ring of row-statistics groups (two tiles = 1 KiB each)
 #define VGQ_STAGE0_TILES 2              // the first stage: every pair passes (32 queries x 32 rows per region and tile <= the pair capacity)
 #ifndef VGQ_TPB
@@ -103,6 +103,18 @@ extern "C" int vg_batch_q8_timing(unsigned long long *out16, int reset) {
 #define VGQ_TICK(var) const unsigned long long var = __builtin_readcyclecounter()
 #else
 #define VGQ_TICK(var)
+#endif
+#ifndef VGQ_TRACE
+#define VGQ_TRACE 0                     // measurement builds: per-tile timestamps of ONE workgroup's eight wavefronts (tools/r6_q8_tile_trace.py)
+#endif
+#if VGQ_TRACE
+#define VGQ_TRACE_TILES 96
+__device__ unsigned long long vgq_trace[8 * VGQ_TRACE_TILES * 4];     // [wave][tile][k loop begins | k loop ends | boundary ends | past the wait / barrier]
+extern "C" int vg_batch_q8_trace(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(vgq_trace), sizeof(vgq_trace)) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[8 * VGQ_TRACE_TILES * 4]; if (hipMemcpyToSymbol(HIP_SYMBOL(vgq_trace), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
 #endif
 #if VGQ_STATS
 __device__ unsigned long long vgq_stats[8];
@@ -550,11 +562,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
         const float mx2_e = L2M ? mfac * nx_e * nx_e : 0.0f;
         const int acc8[8] = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
         const unsigned long long set0_lanes = QS > 1 ? 0x3333333333333333ull : ~0ull;
+        // the eight queries' coefficients first, in one burst of LDS reads: read one by one inside the loop below, each iteration waited for
+        // its own round trip - a queue run took ~3 700 cycles (profiles/r10_q8_tile_trace_one_workgroup.txt), and seven wavefronts wait for it
+        float4 kqv[RPL];
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int r = (QS > 1 ? (o & 1) * 8 : o * 4) + i;
+            kqv[i] = kq_w[32 * set + (r & 3) + 8 * (r >> 2) + 4 * h_e];
+        }
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             const int r = (QS > 1 ? (o & 1) * 8 : o * 4) + i;         // register within the set
             const int qi = (r & 3) + 8 * (r >> 2) + 4 * h_e;
-            const float4 kq = kq_w[32 * set + qi];
+            const float4 kq = kqv[i];
             const int I = acc8[i];
             bool pass = live && I >= ithr_e;
             if (nx_e < 0.0f) pass = pass && kq.z > -1.0e38f;                                       // a row that is never judged: every judged query
@@ -733,6 +753,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
         vgb_static_for<0, KS>([&](auto kc) {
         constexpr int kp = decltype(kc)::value;
         VGQ_TICK(tk0);
+#if VGQ_TRACE
+        const unsigned long long tr_k0 = __builtin_readcyclecounter();
+#endif
         const int fill_buf = cur_buf + NB - M >= NB ? cur_buf - M : cur_buf + NB - M;   // (a buffer of the previous group)
         const int u_next = min(ti * KS + kp + NB - M, U - 1);                 // the trip whose DMA this trip issues
         const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
@@ -758,6 +781,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
             __builtin_amdgcn_sched_barrier(0);
         });
         VGQ_TICK(tk1);
+#if VGQ_TRACE
+        const unsigned long long tr_k1 = __builtin_readcyclecounter();
+#endif
         if constexpr (kp == KS - 1) {
             if constexpr (PRE) {
                 const float kv = pre_boundary(ti, acc0, acc1);
@@ -767,6 +793,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
             } else boundary(ti, acc0, acc1);
         }
         VGQ_TICK(tk2);
+#if VGQ_TRACE
+        const unsigned long long tr_b1 = __builtin_readcyclecounter();
+#endif
         // group end: the next group's pieces have landed (an issuing wavefront leaves the pieces of the (LOOK - 1) M youngest trips in
         // flight: loads return in order), barrier: every wavefront has read this group's buffers, the next group's are readable
         if (M == 1 || (ti * KS + kp) % M == M - 1) {
@@ -796,6 +825,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
         if constexpr (PRE) { if (KS > 1) pre_store(ti, 1); else pre_store(ti - (M - 1), M); }
         }
         cur_buf = cur_buf + 1 == NB ? 0 : cur_buf + 1;
+#if VGQ_TRACE
+        if (!PRE && KS == 1 && WAVES == 8 && T > 1000 && blockIdx.x == 37 && ti >= 200 && ti < 200 + VGQ_TRACE_TILES && lane == 0) {
+            unsigned long long *tr = vgq_trace + ((size_t)wave * VGQ_TRACE_TILES + (ti - 200)) * 4;
+            tr[0] = tr_k0; tr[1] = tr_k1; tr[2] = tr_b1; tr[3] = __builtin_readcyclecounter();
+        }
+#endif
 #if VGQ_TIMING
         { const unsigned long long tk3 = __builtin_readcyclecounter(); tk_k += tk1 - tk0; tk_b += tk2 - tk1; tk_w += tk3 - tk2; }
 #endif
