@@ -244,6 +244,13 @@ int vg_scan_topk_reference(vg_corpus *c, int metric, const void *query, int k, i
  * (the *_stream functions), fetched with vg_slab_scan_all.  rowid_base: implicit rowid of scan position p = rowid_base + p where the
  * caller passes rowids = NULL.  The handle serves one query; the extension makes one per scan of a table it cannot keep resident
  * (VECTORGPU_HBM_LIMIT or the device's free memory: INTEGRATION.md). */
+/* Pinned host memory for a HOST-RESIDENT copy of a table that does not fit the device (round 6): the tier between "staged in HBM" and the
+ * reference's own cost model of reading the table for every query (sqlite-vector.c:2077-2107).  Rows handed to vg_slab_scan_rows /
+ * vg_corpus_append from such a block are read by the DMA engine where they lie (no bounce copy): a scan of the copy runs at the host
+ * link's rate.  VG_ERR_NOMEM when the runtime refuses to pin that much. */
+int  vg_host_alloc(size_t bytes, void **out);
+void vg_host_free(void *p);
+
 typedef struct vg_slab_scan vg_slab_scan;
 int  vg_slab_scan_begin(int device, int vtype, int dim, int metric, const void *query, int k, int tie_order, int64_t slab_rows,
                         int64_t rowid_base, vg_slab_scan **out);

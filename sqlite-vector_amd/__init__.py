@@ -155,6 +155,8 @@ def _load():
         "vg_slab_scan_all": (i32, [vp, vp, vp, vp]),
         "vg_slab_scan_destroy": (None, [vp]),
         "vg_device_memory": (i32, [i32, vp, vp]),
+        "vg_host_alloc": (i32, [C.c_size_t, C.POINTER(C.c_void_p)]),
+        "vg_host_free": (None, [vp]),
         "vg_corpus_device_bytes": (i32, [vp, vp]),
         "vg_shards_device_bytes": (i32, [vp, vp]),
         "vg_shards_rowids": (i32, [vp, i64, i64, vp]),

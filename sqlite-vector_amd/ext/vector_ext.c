@@ -104,9 +104,10 @@ static void fn_gpu_memory(sqlite3_context *ctx, int argc, sqlite3_value **argv) 
     pthread_mutex_unlock(&g_shared_mu);
     /* out_of_core: the table (its quantized records) did not fit the device at its last scan - nothing is resident, every scan reads the
      * rows again through two slabs of slab_rows rows (vext_staging.inc: ooc_plan) */
-    char *js = sqlite3_mprintf("{\"column\":{\"staged\":%d,\"rows_bytes\":%lld,\"derived_bytes\":%lld,\"working_bytes\":%lld,\"out_of_core\":%d,\"slab_rows\":%lld,\"sharers\":%d},"
+    char *js = sqlite3_mprintf("{\"column\":{\"staged\":%d,\"rows_bytes\":%lld,\"derived_bytes\":%lld,\"working_bytes\":%lld,\"out_of_core\":%d,\"slab_rows\":%lld,\"host_resident_bytes\":%lld,\"sharers\":%d},"
                                "\"quantized\":{\"staged\":%d,\"rows_bytes\":%lld,\"derived_bytes\":%lld,\"working_bytes\":%lld,\"out_of_core\":%d,\"slab_rows\":%lld,\"sharers\":%d},\"total_bytes\":%lld}",
-                               t->full ? 1 : 0, f[0], f[1], f[2], t->full_ooc, (long long)(t->full_ooc ? t->full_slab_rows : 0), fsh,
+                               t->full ? 1 : 0, f[0], f[1], f[2], t->full_ooc, (long long)(t->full_ooc ? t->full_slab_rows : 0),
+                               (long long)(t->host_rows ? t->host_n * ((long long)elem_size(t->opt.v_type) * t->opt.v_dim + 8) : 0), fsh,
                                t->quant ? 1 : 0, q[0], q[1], q[2], t->quant_ooc, (long long)(t->quant_ooc ? t->quant_slab_rows : 0), qsh,
                                f[0] + f[1] + f[2] + q[0] + q[1] + q[2]);
     if (!js) { sqlite3_result_error_nomem(ctx); return; }
@@ -117,7 +118,7 @@ static void fn_gpu_memory(sqlite3_context *ctx, int argc, sqlite3_value **argv) 
 static void fn_gpu_stats(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
     const stage_stats g = stage_stats_read();
     pthread_mutex_lock(&g_stage_mu);
-    const long long os = ooc_stat_scans, orows = ooc_stat_rows;
+    const long long os = ooc_stat_scans, orows = ooc_stat_rows, hts = g_host_tier_scans, htf = g_host_tier_fills;
     pthread_mutex_unlock(&g_stage_mu);
     long long sh_n = 0, sh_refs = 0, sh_att, sh_pub;
     pthread_mutex_lock(&g_shared_mu);
@@ -125,9 +126,10 @@ static void fn_gpu_stats(sqlite3_context *ctx, int argc, sqlite3_value **argv) {
     sh_att = g_shared_attached; sh_pub = g_shared_published;
     pthread_mutex_unlock(&g_shared_mu);
     char *js = sqlite3_mprintf("{\"stage_passes\":%lld,\"parallel_reader_passes\":%lld,\"rows_staged\":%lld,\"seconds_staging\":%.6f,\"seconds_in_engine_append\":%.6f,\"seconds_count_star\":%.6f,\"seconds_hbm_reserve\":%.6f,\"out_of_core_scans\":%lld,\"out_of_core_rows\":%lld,"
+                               "\"host_tier_scans\":%lld,\"host_tier_fills\":%lld,"
                                "\"shared_copies\":%lld,\"shared_references\":%lld,\"shared_attachments\":%lld,\"shared_published\":%lld}",
                                g.passes, g.parallel_passes, g.rows, g.seconds, g.append_seconds, g.count_seconds, g.reserve_seconds, os, orows,
-                               sh_n, sh_refs, sh_att, sh_pub);
+                               hts, htf, sh_n, sh_refs, sh_att, sh_pub);
     if (!js) { sqlite3_result_error_nomem(ctx); return; }
     sqlite3_result_text(ctx, js, -1, sqlite3_free);
 }

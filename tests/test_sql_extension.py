@@ -1306,6 +1306,53 @@ def test_out_of_core_tables_report_it_and_come_back_when_they_fit(ext_path, orc,
     assert mem["column"]["staged"] == 1 and mem["column"]["out_of_core"] == 0
 
 
+@pytest.mark.gpu
+def test_out_of_core_host_resident_tier(ext_path, monkeypatch):
+    """round 6: a table beyond the device is read ONCE into pinned host memory (vg_host_alloc) and every later scan streams that copy over
+    the host link (vector_gpu_stats: host_tier_fills / host_tier_scans; vector_gpu_memory: host_resident_bytes); a write drops the copy;
+    VECTORGPU_HOST_LIMIT below the table (or 0) keeps round 5's statement-per-scan path; the answers are the resident table's either way,
+    in both tie orders, for rows whose length is not a multiple of 16 bytes too (the repack path of the pinned append)"""
+    import json
+    for dim in (48, 50):
+        n, k = 30_000, 25
+        rows = dg.corpus(dg.F32, n, dim, 9300 + dim)
+        rows[20_000:20_030] = rows[7]
+        q = rows[7].copy()
+        db = connect(ext_path)
+        load_table(db, rows, dg.F32, dg.L2)
+        want = db.execute("SELECT rowid, distance FROM vector_full_scan('t','v',?,?)", (q.tobytes(), k)).fetchall()
+        db.close()
+        monkeypatch.setenv("VECTORGPU_HBM_LIMIT", "1")
+        for host_limit, tier in ((None, True), ("2", False), ("0", False)):          # 2 MiB < the table's 5.8 MB
+            if host_limit is None:
+                monkeypatch.delenv("VECTORGPU_HOST_LIMIT", raising=False)
+            else:
+                monkeypatch.setenv("VECTORGPU_HOST_LIMIT", host_limit)
+            db2 = connect(ext_path)
+            load_table(db2, rows, dg.F32, dg.L2)
+            s0 = json.loads(db2.execute("SELECT vector_gpu_stats()").fetchone()[0])
+            for _ in range(3):
+                assert db2.execute("SELECT rowid, distance FROM vector_full_scan('t','v',?,?)", (q.tobytes(), k)).fetchall() == want
+            s1 = json.loads(db2.execute("SELECT vector_gpu_stats()").fetchone()[0])
+            mem = json.loads(db2.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])["column"]
+            assert mem["out_of_core"] == 1 and mem["staged"] == 0
+            if tier:
+                assert s1["host_tier_fills"] - s0["host_tier_fills"] == 1 and s1["host_tier_scans"] - s0["host_tier_scans"] == 3, (s0, s1)
+                assert mem["host_resident_bytes"] == n * (dim * 4 + 8)
+                assert s1["rows_staged"] - s0["rows_staged"] == n                       # the table was read once for three scans
+                db2.execute("UPDATE t SET v = ? WHERE id = ?", (rows[1].tobytes(), want[0][0]))   # a write: the copy is dropped, the next scan sees it
+                got = db2.execute("SELECT rowid, distance FROM vector_full_scan('t','v',?,?)", (q.tobytes(), k)).fetchall()
+                assert want[0][0] not in [g[0] for g in got] and got[0][1] == 0.0
+                s2 = json.loads(db2.execute("SELECT vector_gpu_stats()").fetchone()[0])
+                assert s2["host_tier_fills"] - s1["host_tier_fills"] == 1
+            else:
+                assert s1["host_tier_scans"] == s0["host_tier_scans"] and mem["host_resident_bytes"] == 0
+                assert s1["rows_staged"] - s0["rows_staged"] == 3 * n
+            db2.close()
+        monkeypatch.delenv("VECTORGPU_HBM_LIMIT")
+        monkeypatch.delenv("VECTORGPU_HOST_LIMIT", raising=False)
+
+
 # ------------------------------------------------------------------------------------------------ one staged copy per process
 @pytest.mark.gpu
 def test_connections_of_one_process_share_one_staged_copy(ext_path, orc, tmp_path):

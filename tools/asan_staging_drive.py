@@ -99,6 +99,33 @@ assert mem["column"]["out_of_core"] == 1 and mem["column"]["staged"] == 0, mem
 stream = d.execute("SELECT count(*), min(distance) FROM vector_full_scan_stream('t', 'v', ?)", (q.tobytes(),)).fetchone()
 batch = d.execute("SELECT query, id FROM vector_full_scan_batch('t', 'v', ?, 3)", (np.stack([q, rows[5]]).tobytes(),)).fetchall()
 print("out of core:", got_ooc[:2], "stream rows", stream, "batch", batch[:3], "quantize", d.execute("SELECT vector_quantize('t', 'v', 'max_memory=1MB')").fetchone())
+# the host-resident tier of an out-of-core table (round 6): the rows are read ONCE into (here: plain) host memory, later scans stream that
+# copy; a write drops it; VECTORGPU_HOST_LIMIT=0 keeps the statement-per-scan path
+assert d.execute(sql, (q.tobytes(),)).fetchall() == got_ooc          # (vector_quantize's own writes moved the stamps: this scan reads the table again)
+st_a = json.loads(d.execute("SELECT vector_gpu_stats()").fetchone()[0])
+assert st_a["host_tier_fills"] >= 1 and st_a["host_tier_scans"] >= 1, st_a
+assert json.loads(d.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])["column"]["host_resident_bytes"] > 8_000_000
+for _ in range(3):
+    assert d.execute(sql, (q.tobytes(),)).fetchall() == got_ooc
+st_b = json.loads(d.execute("SELECT vector_gpu_stats()").fetchone()[0])
+assert st_b["host_tier_fills"] == st_a["host_tier_fills"] and st_b["host_tier_scans"] == st_a["host_tier_scans"] + 3 and st_b["rows_staged"] == st_a["rows_staged"], (st_a, st_b)
+d.execute("INSERT INTO t(id, v) VALUES (?, ?)", (int(ids[-1]) + 77, q.tobytes()))            # a write: the copy is dropped and read again
+g2 = d.execute(sql, (q.tobytes(),)).fetchall()
+assert (int(ids[-1]) + 77, 0.0) in g2, g2
+st_c = json.loads(d.execute("SELECT vector_gpu_stats()").fetchone()[0])
+assert st_c["host_tier_fills"] == st_b["host_tier_fills"] + 1, (st_b, st_c)
+d.execute("DELETE FROM t WHERE id = ?", (int(ids[-1]) + 77,))
+assert d.execute(sql, (q.tobytes(),)).fetchall() == got_ooc
+os.environ["VECTORGPU_HOST_LIMIT"] = "0"
+d3 = connect()
+st_d = json.loads(d3.execute("SELECT vector_gpu_stats()").fetchone()[0])
+assert d3.execute(sql, (q.tobytes(),)).fetchall() == got_ooc
+st_e = json.loads(d3.execute("SELECT vector_gpu_stats()").fetchone()[0])
+assert st_e["host_tier_scans"] == st_d["host_tier_scans"] and st_e["out_of_core_scans"] == st_d["out_of_core_scans"] + 1, (st_d, st_e)
+assert json.loads(d3.execute("SELECT vector_gpu_memory('t','v')").fetchone()[0])["column"]["host_resident_bytes"] == 0
+d3.close()
+del os.environ["VECTORGPU_HOST_LIMIT"]
+print("host-resident tier: fills", st_c["host_tier_fills"], "scans from it", st_c["host_tier_scans"])
 del os.environ["VECTORGPU_HBM_LIMIT"]
 d.close()
 d = connect()

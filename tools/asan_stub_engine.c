@@ -202,6 +202,9 @@ int vg_slab_scan_all(vg_slab_scan *s, int64_t *n, const float **d, const int64_t
 int vg_device_memory(int device, long long *free_bytes, long long *total_bytes) { (void)device; *free_bytes = 1ll << 40; *total_bytes = 1ll << 40; return 0; }
 
 int vg_shards_trim(vg_shards *s) { (void)s; return 0; }
+/* pinned host memory of the host-resident tier: plain memory here */
+int vg_host_alloc(size_t bytes, void **out) { *out = malloc(bytes ? bytes : 1); return *out ? 0 : 3; }
+void vg_host_free(void *p) { free(p); }
 
 int vg_shards_clone(const vg_shards *src, vg_shards **out) {
     vg_shards *s = (vg_shards *)calloc(1, sizeof(*s));
