@@ -128,7 +128,7 @@ extern "C" int vg_batch_q8_stats(unsigned long long *out8, int reset) {
 struct BatchArgsQ8 {
     const uint8_t *rows;      // the TILE-MAJOR int8 shadow copy: tile t = rows 32t .. 32t+31 = 32 * stride contiguous bytes, chunk column c
                               // of the 32 rows at c * 512 + row * 16 (vg_tile_major_kernel over the row-major shadow copy)
-    const float4 *rstat;      // per row: (sx, ||ex|| rounded up, ||x||, 0); a row that is never judged: (1e-30, 3e38, -1, 0); readable for two tiles past the last one
+    const float4 *rstat;      // per row: (sx, ||ex|| rounded up, ||x||, 1 / sx); a row that is never judged: (1e-30, 3e38, -1, 1e30); readable for two tiles past the last one
     const uint8_t *qcodes;    // nq_pad x stride int8 query images (vg_q8_query_prep_kernel), zero padded, in SORTED order (see there)
     const float4 *qstat;      // per query two float4: (sq, sq ||qi|| up, ||eq|| up, |q|), (|q|^2, judged ? 1 : 0, 0, 0)
     long long n_rows, stride; // stride: bytes per int8 row (multiple of 16)
@@ -256,7 +256,10 @@ __global__ __launch_bounds__(256) void vg_q8_rstat_kernel(const float2 *q8stat, 
         const bool judged = zero || ((nrm >= VGQ_JUDGE_LO && nrm <= VGQ_JUDGE_HI) && (s.x > 0.0f && s.x <= 3.0e38f));   // (sx = NaN: Inf / NaN elements)
         // a row that is never judged reads as "every gate open" without a test of its own: a huge residual norm drives the integer
         // threshold to -2^31 (the conversion saturates); ||x|| = -1 marks it for the per-pair test
-        out[row0 + i] = judged ? (zero ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(s.x, s.y, nrm, 0.0f)) : make_float4(1.0e-30f, 3.0e38f, -1.0f, 0.0f);
+        // (.w = 1 / sx, correctly rounded, made HERE once per row: the filter's tile boundary divided by sx per wave-tile - a ten-instruction
+        //  sequence out of ~85; round 6)
+        out[row0 + i] = judged ? (zero ? make_float4(0.0f, 0.0f, 0.0f, __frcp_rn(0.0f)) : make_float4(s.x, s.y, nrm, __frcp_rn(s.x)))
+                               : make_float4(1.0e-30f, 3.0e38f, -1.0f, __frcp_rn(1.0e-30f));
     }
 }
 
@@ -614,7 +617,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
         const float4 rs = rstat_lds[((ti >> 1) & (VGQ_STAT_SLOTS - 1)) * 64 + (ti & 1) * 32 + x];
         if (VGQ_ABLATE >= 2) asm volatile("" :: "v"(acc0[0]), "v"(acc0[15]), "v"(acc1[0]), "v"(acc1[15]));
         const float sx = rs.x, rx = rs.y, nx = rs.z;
-        const float inv_sx = __frcp_rn(sx);                            // (a zero row: +Inf - its accumulators are all 0 and the sign of `rest` decides)
+        // 1 / sx from the statistics (a zero row, and the zero-filled statistics behind the corpus' last row: +Inf - the accumulators are all 0
+        // and the sign of `rest` decides)
+        const float inv_sx = sx != 0.0f ? rs.w : INFINITY;
         const float mx2 = L2M ? mfac * nx * nx : 0.0f;
         int ithr[2] = {0x7FFFFFFF, 0x7FFFFFFF};
 #pragma unroll
