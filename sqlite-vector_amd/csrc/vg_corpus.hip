@@ -82,7 +82,7 @@ static const VgSwitchName vg_switch_names[VGSW_COUNT] = {
     {"VG_HALF_COSN", 1},
     {"VG_HOST_DIRECT", 1},
     {"VG_KEYS_DIRECT", 1},
-    {"VG_LPR_LOG2", 0},
+    {"VG_LPR_LOG2", 1},
     {"VG_MULTI_SCAN", 0},
     {"VG_NT", 1},
     {"VG_Q8_TWO_READS", 1},
@@ -99,11 +99,11 @@ static const VgSwitchName vg_switch_names[VGSW_COUNT] = {
     {"VG_SCAN_FILTER_PREPASS_DIV", 1},
     {"VG_SCAN_FILTER_SHADOW", 0},
     {"VG_SCAN_ORDER", 1},
-    {"VG_SHAPE_BF16_L2_U3", 0},
-    {"VG_SHAPE_F16_ROUND3", 0},
-    {"VG_SHAPE_INT_SHORT_ROUND3", 0},
-    {"VG_SHAPE_PREF_ROUND1", 0},
-    {"VG_U", 0},
+    {"VG_SHAPE_BF16_L2_U3", 1},
+    {"VG_SHAPE_F16_ROUND3", 1},
+    {"VG_SHAPE_INT_SHORT_ROUND3", 1},
+    {"VG_SHAPE_PREF_ROUND1", 1},
+    {"VG_U", 1},
 };
 std::atomic<int> vg_switch_values[VGSW_COUNT];
 void vg_switches_read(void) {

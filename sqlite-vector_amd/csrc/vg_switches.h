@@ -29,7 +29,7 @@ enum VgSwitch {
     SW_VG_HALF_COSN,                       // LAB
     SW_VG_HOST_DIRECT,                       // LAB
     SW_VG_KEYS_DIRECT,                       // LAB
-    SW_VG_LPR_LOG2,
+    SW_VG_LPR_LOG2,                       // LAB
     SW_VG_MULTI_SCAN,
     SW_VG_NT,                       // LAB
     SW_VG_Q8_TWO_READS,                       // LAB
@@ -46,11 +46,11 @@ enum VgSwitch {
     SW_VG_SCAN_FILTER_PREPASS_DIV,                       // LAB
     SW_VG_SCAN_FILTER_SHADOW,
     SW_VG_SCAN_ORDER,                       // LAB
-    SW_VG_SHAPE_BF16_L2_U3,
-    SW_VG_SHAPE_F16_ROUND3,
-    SW_VG_SHAPE_INT_SHORT_ROUND3,
-    SW_VG_SHAPE_PREF_ROUND1,
-    SW_VG_U,
+    SW_VG_SHAPE_BF16_L2_U3,                       // LAB
+    SW_VG_SHAPE_F16_ROUND3,                       // LAB
+    SW_VG_SHAPE_INT_SHORT_ROUND3,                       // LAB
+    SW_VG_SHAPE_PREF_ROUND1,                       // LAB
+    SW_VG_U,                       // LAB
     VGSW_COUNT
 };
 #define VGSW_UNSET INT_MIN

@@ -132,9 +132,15 @@ def test_launch_shape_rules(pkg, monkeypatch):
     assert pkg.plan_scan_shape(F32, 4096, L2)[2] and pkg.plan_scan_shape(F16, 4096, L2)[2]
     with pytest.raises(pkg.VectorGpuError):
         pkg.plan_scan_shape(9, 384, L2)
-    # the experiment override reaches the same function
+    # the experiment overrides (VG_LPR_LOG2 / VG_U, the four VG_SHAPE_* rules of earlier rounds) are -DVG_LAB switches since round 6:
+    # a product build does not read them
     monkeypatch.setenv("VG_LPR_LOG2", "4"); monkeypatch.setenv("VG_U", "6")
-    assert pkg.plan_scan_shape(F32, 384, L2)[:2] == (16, 6)
+    pkg.reload_switches()
+    try:
+        assert pkg.plan_scan_shape(F32, 384, L2)[:2] == (32, 3)
+    finally:
+        monkeypatch.delenv("VG_LPR_LOG2"); monkeypatch.delenv("VG_U")
+        pkg.reload_switches()
 
 
 def test_half_batch_workgroup_form_plan(pkg, monkeypatch):
