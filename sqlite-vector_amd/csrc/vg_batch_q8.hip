@@ -66,6 +66,12 @@ typedef int vgq_i32x16 __attribute__((ext_vector_type(16)));
 #define VGQ_DMA_AT_END 1                // wide form: waves 0-3 issue a group's LDS-DMA behind their last boundary of the group, where they would wait for waves 4-7 (see the tile loop)
 #endif
 #define VGQ_QCAP 16                     // candidate lanes a wavefront collects before it looks at their accumulators (160 bytes each)   (= 64 lanes / 4 lanes per entry: a queue run looks at exactly that many)
+#ifndef VGQ_SWP_DRAIN
+#define VGQ_SWP_DRAIN 1                 // the pipelined form retires two parked candidate lanes per tile beside its MFMAs (see the kernel)
+#endif
+#ifndef VGQ_SWP
+#define VGQ_SWP 1                       // 1: the tile boundary's first test software-pipelined under the next tile's MFMAs (see the kernel)
+#endif
 #define VGQ_STAT_SLOTS 8                // ring of row-statistics groups (two tiles = 1 KiB each)
 #define VGQ_STAGE0_TILES 2              // the first stage: every pair passes (32 queries x 32 rows per region and tile <= the pair capacity)
 #ifndef VGQ_TPB
@@ -550,11 +556,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
     unsigned st_slow = 0, st_cand = 0, st_pairs = 0;
 #endif
     uint32_t *queue_w = queue_lds + wave * (VGQ_QCAP * QENT);
-    unsigned n_q = 0;                                                 // (wave-uniform)
+    unsigned n_q = 0, q_head = 0;                                     // (wave-uniform) entries in the queue; the oldest one's slot (a ring)
     auto process_queue = [&]() __attribute__((always_inline)) {
         constexpr int RPL = 4 * QS;                                   // accumulator registers of an entry per lane (four lanes per entry)
         const int e = lane >> 2, o = lane & 3, set = QS > 1 ? o >> 1 : 0;
-        const uint32_t *ent = queue_w + e * QENT;
+        const uint32_t *ent = queue_w + ((q_head + (unsigned)e) & (unsigned)(VGQ_QCAP - 1)) * QENT;
         const uint4 m0 = *reinterpret_cast<const uint4 *>(ent + 16 * QS), m1 = *reinterpret_cast<const uint4 *>(ent + 16 * QS + 4);
         const uint4 a0 = *reinterpret_cast<const uint4 *>(ent + RPL * o), a1 = *reinterpret_cast<const uint4 *>(ent + RPL * o + (QS > 1 ? 4 : 0));
         const uint32_t row_e = m0.x;
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
             if (pass) (set ? pbuf1 : pbuf0)[at] = ((uint64_t)(uint32_t)qi << 32) | row_e;
             n_buf0 += c0; n_buf1 += c1;
         }
-        n_q = 0;
+        n_q = 0; q_head = 0;
     };
     constexpr int BP = VGQ_BPIPE < NTB ? VGQ_BPIPE : NTB;
     vgh_i32x4 bq[BP];
@@ -612,16 +618,16 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
     // against the set's loosest gate, as an integer: I >= ithr = (-(amax ||ex|| + bbmax ||x|| + ccmax - m uumin)) / sx, rounded down.  Only a
     // set with a lane that passes looks at single accumulators (the same integer comparison, eight registers at a time), and only those
     // pairs get the query's own four coefficients.
-    auto boundary = [&](int ti, const vgq_i32x16 &acc0, const vgq_i32x16 &acc1) __attribute__((always_inline)) {
-        const long long row_cur = (tile_first + ti) * VGQ_TILE + x;
-        const float4 rs = rstat_lds[((ti >> 1) & (VGQ_STAT_SLOTS - 1)) * 64 + (ti & 1) * 32 + x];
+    auto stat_of = [&](int ti) __attribute__((always_inline)) -> float4 { return rstat_lds[((ti >> 1) & (VGQ_STAT_SLOTS - 1)) * 64 + (ti & 1) * 32 + x]; };
+    // (first test: the lanes with a candidate, and the two sets' integer thresholds; candidate path: those lanes park their accumulators)
+    auto boundary_first = [&](const float4 rs, const vgq_i32x16 &acc0, const vgq_i32x16 &acc1, int (&ithr)[2]) __attribute__((always_inline)) -> unsigned long long {
         if (VGQ_ABLATE >= 2) asm volatile("" :: "v"(acc0[0]), "v"(acc0[15]), "v"(acc1[0]), "v"(acc1[15]));
         const float sx = rs.x, rx = rs.y, nx = rs.z;
         // 1 / sx from the statistics (a zero row, and the zero-filled statistics behind the corpus' last row: +Inf - the accumulators are all 0
         // and the sign of `rest` decides)
         const float inv_sx = sx != 0.0f ? rs.w : INFINITY;
         const float mx2 = L2M ? mfac * nx * nx : 0.0f;
-        int ithr[2] = {0x7FFFFFFF, 0x7FFFFFFF};
+        ithr[0] = 0x7FFFFFFF; ithr[1] = 0x7FFFFFFF;
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
             // I >= ithr  <=  I sx + rest >= 0;  ithr = floor(-(rest + sx) / sx) less a relative 1e-6: the "- 1" of the rounding rides in `rest`,
@@ -651,6 +657,14 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
             }
             unsigned long long m = __ballot(cand_lane);
             if (VGQ_ABLATE == 1) { asm volatile("" :: "s"(m)); m = 0ull; }
+            return m;
+        }
+        return 0ull;
+    };
+    auto boundary_cands = [&](int ti, unsigned long long m, const float4 rs, const int (&ithr)[2], const vgq_i32x16 &acc0, const vgq_i32x16 &acc1) __attribute__((always_inline)) {
+        const long long row_cur = (tile_first + ti) * VGQ_TILE + x;
+        const float sx = rs.x, rx = rs.y, nx = rs.z;
+        {
 #if VGQ_STATS
             if (m) ++st_slow;
 #endif
@@ -658,7 +672,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 const bool take = ((m >> lane) & 1ull) != 0ull && n_q + rank < (unsigned)VGQ_QCAP;
                 if (take && VGQ_ABLATE != 7) {
-                    uint32_t *ent = queue_w + (n_q + rank) * QENT;
+                    uint32_t *ent = queue_w + ((q_head + n_q + rank) & (unsigned)(VGQ_QCAP - 1)) * QENT;
                     vgb_static_for<0, 4>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
                         *reinterpret_cast<uint4 *>(ent + 4 * j) = make_uint4((uint32_t)acc0[4 * j], (uint32_t)acc0[4 * j + 1], (uint32_t)acc0[4 * j + 2], (uint32_t)acc0[4 * j + 3]);
@@ -671,9 +685,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
                 const unsigned long long taken = __ballot(take);
                 n_q += (unsigned)__popcll(taken);
                 m &= ~taken;
-                if (n_q == (unsigned)VGQ_QCAP) { if (VGQ_ABLATE == 7 || VGQ_ABLATE == 8) n_q = 0; else process_queue(); }
+                if (n_q == (unsigned)VGQ_QCAP) { if (VGQ_ABLATE == 7 || VGQ_ABLATE == 8) { n_q = 0; q_head = 0; } else process_queue(); }
             }
         }
+    };
+    auto boundary = [&](int ti, const vgq_i32x16 &acc0, const vgq_i32x16 &acc1) __attribute__((always_inline)) {
+        const float4 rs = stat_of(ti);
+        int ithr[2];
+        const unsigned long long m = boundary_first(rs, acc0, acc1, ithr);
+        boundary_cands(ti, m, rs, ithr, acc0, acc1);
     };
     // ---- PRE: what a tile says about every query's k-th best WITHOUT an exact evaluation.  The bound that lets the filter reject a pair
     // also bounds a pair's distance from ABOVE: q.x >= sq sx I - sq ||qi|| ||ex|| - ||eq|| ||x|| =: s_lo, so the distance the exact
@@ -742,18 +762,35 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
                 if (j < count) a.premin[(tile_first + ti_first + j - a.tile_begin) * (long long)a.nq_pad + q0 + qw] = pre_keep[j];
         }
     };
-    vgq_i32x16 acc0, acc1;
+    // SOFTWARE-PIPELINED BOUNDARY (VGQ_SWP, the wide form): a wavefront owns TWO pairs of accumulator sets; tile t's MFMAs run into one pair
+    // while the first test of tile t - 1 (thresholds from the row statistics, the maxima, the ballot: ~55 VALU instructions, no memory access)
+    // reads the other, in the SAME instruction stream - the matrix pipe takes 32 cycles per MFMA and the issue port 4, so up to ~5 other
+    // instructions fit beside every MFMA (MI355X_MICROARCH.md) instead of a block of VALU work during which this wavefront offers the pipe nothing.
+    constexpr bool SWP = VGQ_SWP != 0 && !PRE && KS == 1 && QS == 2 && WAVES == 8 && NTB <= 12;     // (16 k-steps: the second pair spills)
+    vgq_i32x16 acc0, acc1, accb0, accb1;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; accb0[r] = 0; accb1[r] = 0; }
+    float4 rs_prev = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                 // (SWP) the previous tile's row statistics
 #if VGQ_TIMING
     unsigned long long tk_k = 0, tk_b = 0, tk_w = 0, tk_v = 0;
     const unsigned long long tk_loop0 = __builtin_readcyclecounter();
 #endif
-    for (int ti = 0; ti < T; ++ti) {
+    // one tile: its MFMAs into (acc0, acc1); SWP: the previous tile's accumulators are (old0, old1)
+    // DRAIN (SWP, VGQ_SWP_DRAIN): a queue run - 16 parked candidate lanes looked at in one go, ~3 700 cycles - holds up ONE wavefront, and the other
+    // seven then wait for it at the group's barrier: with a run every ~6 tiles somewhere in the workgroup that was most of the ~0.6 ms the
+    // candidates cost inside this kernel.  Instead a tile whose wavefront has parked lanes retires the two OLDEST of them beside its MFMAs,
+    // branch-free: lane (e, set, r) takes accumulator r of set `set` of entry e - five LDS reads issued behind k-step 0 (counted waits: they
+    // ride the B operands' in-order queue), the pair's own test and the compaction into the pair buffers in the last two k-steps.  Runs
+    // remain for a queue that fills faster than that (the first stages) and for the partition's end.
+    constexpr bool CAN_DRAIN = SWP && VGQ_SWP_DRAIN != 0 && NTB >= 8 && VGQ_BPIPE + 3 <= NTB;
+    auto tile_step = [&](int ti, vgq_i32x16 &acc0, vgq_i32x16 &acc1, const vgq_i32x16 &old0, const vgq_i32x16 &old1, auto drain_c) __attribute__((always_inline)) {
+        constexpr bool DRAIN = decltype(drain_c)::value;
         const int sj = (ti + LEAD) >> 1;                                      // the statistics group this tile's first trip may issue
         const bool stat_turn = ((ti + LEAD) & 1) == 0 && 2 * sj < T + 1 && wave == (sj & (WAVES - 1));
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
+        int ithr_prev[2] = {0x7FFFFFFF, 0x7FFFFFFF};
+        unsigned long long m_prev = 0ull;
         // one ring trip per K-part of the tile (KS = 1: the whole row): the accumulators run on across the parts
         vgb_static_for<0, KS>([&](auto kc) {
         constexpr int kp = decltype(kc)::value;
@@ -764,25 +801,109 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
         const int fill_buf = cur_buf + NB - M >= NB ? cur_buf - M : cur_buf + NB - M;   // (a buffer of the previous group)
         const int u_next = min(ti * KS + kp + NB - M, U - 1);                 // the trip whose DMA this trip issues
         const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
+        if constexpr (SWP && VGQ_ABLATE < 3 && !ATEND) {
+            // (the DMA issue has branches: in front of the k loop, so that the MFMAs and the previous tile's first test share ONE basic block)
+            if (stat_turn) dma_stat_group(tile_first + 2 * sj, sj & (VGQ_STAT_SLOTS - 1));
+            dma_share(u_next, fill_buf);
+        }
+        // (SWP) the previous tile's first test in pieces of <= 5 VALU instructions, one piece per k-step (the same arithmetic as boundary_first)
+        float sw_tf[2] = {0.0f, 0.0f};
+        int sw_gm[4] = {0, 0, 0, 0};
+        auto first_piece = [&](auto pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(pc)::value;
+            const float sx = rs_prev.x, rx = rs_prev.y, nx = rs_prev.z;
+            if constexpr (p == 0 || p == 1) {
+                const float inv_sx = sx != 0.0f ? rs_prev.w : INFINITY;
+                float rest = fmaf(amax[p], rx, fmaf(bbmax[p], nx, COS ? sx : ccmax[p] + sx));
+                if constexpr (L2M) rest = fmaf(-(mfac * nx * nx), uumin[p], rest);
+                if (COS && nx == 0.0f) rest = -uumin[p];
+                sw_tf[p] = -rest * inv_sx;
+            } else if constexpr (p == 2 || p == 3) {
+                const float tf = sw_tf[p - 2];
+                const float tf2 = fabsf(tf) < 3.0e38f ? fmaf(fabsf(tf), -1.0e-6f, tf) : tf;
+                int it;
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(it) : "v"(tf2));
+                ithr_prev[p - 2] = it;
+            } else if constexpr (p >= 4 && p <= 7) {
+                const vgq_i32x16 &o = p < 6 ? old0 : old1;
+                constexpr int b = (p & 1) * 8;
+                sw_gm[p - 4] = max(max(max(o[b], o[b + 1]), max(o[b + 2], o[b + 3])), max(max(o[b + 4], o[b + 5]), max(o[b + 6], o[b + 7])));
+            } else if constexpr (p == 8) {
+                // (no "||": the compiler turns it into a branch and sinks the second set's maxima under it)
+                const int c0 = max(sw_gm[0], sw_gm[1]) >= ithr_prev[0] ? 1 : 0, c1 = max(sw_gm[2], sw_gm[3]) >= ithr_prev[1] ? 1 : 0;
+                m_prev = __ballot((c0 | c1) != 0);
+                if (VGQ_ABLATE == 1) { asm volatile("" :: "s"(m_prev)); m_prev = 0ull; }
+                if (ti == 0) m_prev = 0ull;
+            }
+        };
+        // (DRAIN) lane = (entry e = lane >> 5, set = (lane >> 4) & 1, register r = lane & 15)
+        const unsigned n_take = DRAIN ? (n_q < 2u ? n_q : 2u) : 0u;
+        const int d_e = lane >> 5, d_set = (lane >> 4) & 1, d_r = lane & 15;
+        const uint32_t d_ent = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)queue_w +
+                               ((q_head + (unsigned)d_e) & (unsigned)(VGQ_QCAP - 1)) * (unsigned)(QENT * 4);
+        const uint32_t d_kqa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4 *)const_cast<float4 *>(kq_w) +
+                               (uint32_t)((32 * d_set + (d_r & 3) + 8 * (d_r >> 2)) * 16);
+        int d_I = 0;
+        vgh_i32x4 d_m0 = {0, 0, 0, 0}, d_m1 = {0, 0, 0, 0}, d_kq0 = {0, 0, 0, 0}, d_kq1 = {0, 0, 0, 0};
         vgb_static_for<0, BP>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             vgq_lds_read128<1024 * t>(bq[t], baddr);
         });
         vgb_static_for<0, NTB>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            constexpr int in_flight_after = (NTB - 1 - t) < (BP - 1) ? (NTB - 1 - t) : (BP - 1);
+            // (DRAIN: the five entry reads sit between operand BP and operand BP + 1 in the queue - younger than operands 1 .. BP)
+            constexpr int in_flight_after = ((NTB - 1 - t) < (BP - 1) ? (NTB - 1 - t) : (BP - 1)) + (DRAIN && t >= 1 && t <= BP ? 5 : 0);
+            if constexpr (DRAIN && t == BP + 1)
+                asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(bq[t % BP]), "+v"(d_I), "+v"(d_m0), "+v"(d_m1), "+v"(d_kq0), "+v"(d_kq1) : "n"(in_flight_after));
+            else
             vgq_wait_lds<in_flight_after>(bq[t % BP]);
             const vgh_i32x4 b = bq[t % BP];
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[0][kp * NTB + t], b, acc0, 0, 0, 0);
             if constexpr (QS > 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(areg[QS - 1][kp * NTB + t], b, acc1, 0, 0, 0);
             if constexpr (t + BP < NTB) vgq_lds_read128<1024 * (t + BP)>(bq[t % BP], baddr);
-            if constexpr (t == 0 && VGQ_ABLATE < 3 && !ATEND) {
+            if constexpr (DRAIN && t == 0) {
+                asm volatile("ds_read_b32 %0, %1" : "=v"(d_I) : "v"(d_ent + (uint32_t)((16 * d_set + d_r) * 4)) : "memory");
+                vgq_lds_read128<16 * QS * 4>(d_m0, d_ent);
+                vgq_lds_read128<16 * QS * 4 + 16>(d_m1, d_ent);
+                vgq_lds_read128<0>(d_kq0, d_kqa);
+                vgq_lds_read128<64>(d_kq1, d_kqa);
+            }
+            if constexpr (DRAIN && t == NTB - 2) {
+                // the pair's own test (process_queue's arithmetic) and its slot in the set's pair buffer
+                const uint32_t row_e = (uint32_t)d_m0[0];
+                const int ithr_e = d_set ? d_m0[2] : d_m0[1];
+                const float sx_e = __int_as_float(d_m0[3]), rx_e = __int_as_float(d_m1[0]), nx_e = __int_as_float(d_m1[1]);
+                const int h_e = d_m1[2];
+                const vgh_i32x4 kqi = h_e ? d_kq1 : d_kq0;
+                const float kqx = __int_as_float(kqi[0]), kqy = __int_as_float(kqi[1]), kqz = __int_as_float(kqi[2]), kqw = __int_as_float(kqi[3]);
+                float lhs = fmaf((float)d_I, sx_e, fmaf(kqx, rx_e, fmaf(kqy, nx_e, kqz)));
+                if constexpr (L2M) lhs = fmaf(-(mfac * nx_e * nx_e), kqw, lhs);
+                const bool judged = kqz > -1.0e38f;
+                const bool by_row = nx_e < 0.0f ? judged : ((COS && nx_e == 0.0f) ? (judged && kqw <= 0.0f) : lhs >= 0.0f);
+                const bool pass = (unsigned)d_e < n_take && (long long)row_e < a.n_rows && d_I >= ithr_e && by_row;
+                const unsigned long long pm = __ballot(pass);
+                const unsigned long long set0_lanes = 0x0000FFFF0000FFFFull;
+                const unsigned long long mine = d_set ? (pm & ~set0_lanes) : (pm & set0_lanes);
+                const unsigned at = (d_set ? n_buf1 : n_buf0) + __builtin_amdgcn_mbcnt_hi((unsigned)(mine >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mine, 0u));
+                const int qi = (d_r & 3) + 8 * (d_r >> 2) + 4 * h_e;
+                if (pass) (d_set ? pbuf1 : pbuf0)[at] = ((uint64_t)(uint32_t)qi << 32) | row_e;
+                n_buf0 += (unsigned)__popcll(pm & set0_lanes); n_buf1 += (unsigned)__popcll(pm & ~set0_lanes);
+#if VGQ_STATS
+                st_cand += (unsigned)__popcll(__ballot((unsigned)d_e < n_take && d_I >= ithr_e)); st_pairs += (unsigned)__popcll(pm);
+#endif
+            }
+            if constexpr (t == 0 && VGQ_ABLATE < 3 && !ATEND && !SWP) {
                 if (kp == 0 && stat_turn) dma_stat_group(tile_first + 2 * sj, sj & (VGQ_STAT_SLOTS - 1));
                 dma_share(u_next, fill_buf);
             }
             // nothing else moves into the k loop: left alone, the compiler sinks the tile boundary's float work (thresholds from the row
             // statistics) between the MFMAs - and every extra issue slot between two MFMAs on one accumulator stalls the chain
             // (MI355X_MICROARCH.md: + 43 cycles for the first one): last stage of 1024 x 10M x 384 2.65 ms against 1.88
+            if constexpr (SWP) {
+                // pieces 0 .. 8 over the k-steps (NTB < 9: the rest behind the last one)
+                if constexpr (t < NTB - 1) first_piece(tc);
+                else { constexpr int PEND = NTB > 9 ? NTB : 9; vgb_static_for<NTB - 1, PEND>([&](auto pc) { first_piece(pc); }); }
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
         VGQ_TICK(tk1);
@@ -795,6 +916,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
                 const int j = KS > 1 ? 0 : ti % M;                         // (K-parts: a group is one tile)
 #pragma unroll
                 for (int jj = 0; jj < M; ++jj) if (jj == j) pre_keep[jj] = kv;
+            } else if constexpr (SWP) {
+                if constexpr (DRAIN) { q_head = (q_head + n_take) & (unsigned)(VGQ_QCAP - 1); n_q -= n_take; }
+                if (ti > 0) boundary_cands(ti - 1, m_prev, rs_prev, ithr_prev, old0, old1);
+                if constexpr (CAN_DRAIN) {
+                    // a drained tile adds up to 32 pairs per set: every tile starts with room for them (a queue run above may have left 64)
+                    if (n_buf0 > 32u) flush(pbuf0, n_buf0, pairs0, n_pairs0);
+                    if (n_buf1 > 32u) flush(pbuf1, n_buf1, pairs1, n_pairs1);
+                }
+                rs_prev = stat_of(ti);                                       // (read before the group's barrier, as the boundary itself would)
             } else boundary(ti, acc0, acc1);
         }
         VGQ_TICK(tk2);
@@ -840,7 +970,20 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
         { const unsigned long long tk3 = __builtin_readcyclecounter(); tk_k += tk1 - tk0; tk_b += tk2 - tk1; tk_w += tk3 - tk2; }
 #endif
         });
-    }
+    };
+    auto step = [&](int ti, vgq_i32x16 &n0, vgq_i32x16 &n1, const vgq_i32x16 &o0, const vgq_i32x16 &o1) __attribute__((always_inline)) {
+        if constexpr (CAN_DRAIN) {
+            if (n_q) tile_step(ti, n0, n1, o0, o1, std::true_type{});
+            else tile_step(ti, n0, n1, o0, o1, std::false_type{});
+        } else tile_step(ti, n0, n1, o0, o1, std::false_type{});
+    };
+    if constexpr (SWP) {
+        int ti = 0;
+        for (; ti + 1 < T; ti += 2) { step(ti, acc0, acc1, accb0, accb1); step(ti + 1, accb0, accb1, acc0, acc1); }
+        if (ti < T) { step(ti, acc0, acc1, accb0, accb1); boundary(T - 1, acc0, acc1); }
+        else if (T > 0) boundary(T - 1, accb0, accb1);
+    } else
+        for (int ti = 0; ti < T; ++ti) step(ti, acc0, acc1, acc0, acc1);
 #if VGQ_TIMING
     if (lane == 0 && T > 64) {
         const int o = (WAVES == 8 && wave >= 4) ? 8 : 0;
