@@ -62,10 +62,10 @@ typedef int vgq_i32x16 __attribute__((ext_vector_type(16)));
 #define VGQW_RING 6                     // tile buffers of the wide form (eight wavefronts x two query sets, one workgroup per CU)
 #endif
 #define VGQW_RING_OF(NTB) ((VGQW_RING) * (NTB) <= 112 ? (VGQW_RING) : 6)
-#ifndef VGQ_DMA_AT_END
-#define VGQ_DMA_AT_END 1                // wide form: waves 0-3 issue a group's LDS-DMA behind their last boundary of the group, where they would wait for waves 4-7 (see the tile loop)
-#endif
 #define VGQ_QCAP 16                     // candidate lanes a wavefront collects before it looks at their accumulators (160 bytes each)   (= 64 lanes / 4 lanes per entry: a queue run looks at exactly that many)
+#ifndef VGQ_DRAIN_MIN
+#define VGQ_DRAIN_MIN 4                 // parked lanes a wavefront waits for before a tile retires two of them
+#endif
 #ifndef VGQ_SWP_DRAIN
 #define VGQ_SWP_DRAIN 1                 // the pipelined form retires two parked candidate lanes per tile beside its MFMAs (see the kernel)
 #endif
@@ -123,10 +123,10 @@ extern "C" int vg_batch_q8_trace(unsigned long long *out, int reset) {
 }
 #endif
 #if VGQ_STATS
-__device__ unsigned long long vgq_stats[8];
-extern "C" int vg_batch_q8_stats(unsigned long long *out8, int reset) {
+__device__ unsigned long long vgq_stats[32];        // [6 stage classes by tiles per partition][wave-tiles, tiles with a candidate lane, candidate lanes, registers past the integer test, pairs]
+extern "C" int vg_batch_q8_stats(unsigned long long *out8, int reset) {        // (out8: 32 values)
     if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(vgq_stats), sizeof(vgq_stats)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vgq_stats), z, sizeof(z)) != hipSuccess) return -1; }
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vgq_stats), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif
@@ -334,13 +334,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
                              : (NB % VGQ_TPB == 0 && NB >= 2 * VGQ_TPB ? VGQ_TPB : (NB % 2 == 0 && NB >= 4 ? 2 : 1));
     constexpr int LOOK = NB / M - 1;                                 // groups beyond the current one that are resident or on their way
     static_assert(LOOK >= 1 && NB % M == 0, "ring of whole groups");
-    // WHO ISSUES THE LDS-DMA, AND WHEN.  Inside the k loop an LDS-DMA instruction holds its wavefront's issue for ~100-200 cycles: with every
-    // wavefront issuing its share at the head of every k loop that was ~290 of a tile's ~2 600 cycles (profiles/r10_*).  Waves 0-3 - the older
-    // wavefront of every SIMD, which the arbiter serves first - reach a group's barrier ~2 000 cycles before waves 4-7: in the wide form they
-    // issue the WHOLE group behind their last boundary of a group (time they would spend waiting), two groups ahead (LOOK >= 2: the group
-    // issued one barrier ago is the one the counted wait confirms).
-    constexpr bool ATEND = VGQ_DMA_AT_END != 0 && WAVES == 8 && KS == 1 && M > 1 && LOOK >= 2;
-    constexpr int NISSUE = ATEND ? 4 : WAVES;                        // wavefronts that issue tile pieces
+    // (WHO ISSUES THE LDS-DMA: every wavefront its share, in front of its k loop.  Measured and removed in round 6: the four favoured wavefronts
+    //  issuing a whole group behind their last boundary of a group - two groups ahead, nine ring buffers - 5.20 against 5.16 ms, and again beside
+    //  the pipelined first test 4.47 against 4.37; the four favoured wavefronts issuing three pieces each at the usual place: 4.48-4.50 both ways)
+    constexpr int NISSUE = WAVES;                                    // wavefronts that issue tile pieces
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *tile0 = smem;
     float4 *rstat_lds = reinterpret_cast<float4 *>(smem + NB * TILE_BYTES);              // [VGQ_STAT_SLOTS][2 tiles][32 rows]
@@ -432,6 +429,14 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
             ccmax[s] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m3), 32 * s));
             uumin[s] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m4), 32 * s));
         }
+#if VGQ_STATS
+        if (!PRE && part == 0 && a.tiles_per_part >= 1000 && ok) {       // how far a query's own threshold term lies from its set's loosest, relative
+            const float mine = ccmax[QS > 1 ? (lane >> 5) : 0];
+            const float rel1 = (mine - cc) / fabsf(cc);
+            atomicAdd(&vgq_stats[30], (unsigned long long)(rel1 * 1.0e6f));
+            atomicAdd(&vgq_stats[31], 1ull);
+        }
+#endif
     }
     const float4 *kq_w = kq_lds + wave * QPW;
     for (int s = tid; s < NB * TILE_BYTES / 4; s += THREADS) reinterpret_cast<uint32_t *>(tile0)[s] = 0u;   // pad columns
@@ -526,7 +531,6 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const bool counted_wait = all_parts_full;
-    int next_stat = SPRE;                                             // (ATEND) the next statistics group to issue
     const long long region0 = ((long long)(g * a.npart_total + a.part_base + part) * WAVES + wave) * QS;
     uint64_t *pairs0 = a.pairs + region0 * a.pair_cap, *pairs1 = pairs0 + (QS > 1 ? a.pair_cap : 0);
     unsigned n_pairs0 = 0, n_pairs1 = 0;                              // pairs in the regions so far (wave-uniform)
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
     // entry e, all 64 lanes busy, eight steps - and the pairs that pass go to the pair buffers, entries ascending: a query's rows stay
     // in scan order.
 #if VGQ_STATS
-    unsigned st_slow = 0, st_cand = 0, st_pairs = 0;
+    unsigned st_slow = 0, st_cand = 0, st_pairs = 0, st_lanes = 0;
 #endif
     uint32_t *queue_w = queue_lds + wave * (VGQ_QCAP * QENT);
     unsigned n_q = 0, q_head = 0;                                     // (wave-uniform) entries in the queue; the oldest one's slot (a ring)
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
         const float sx = rs.x, rx = rs.y, nx = rs.z;
         {
 #if VGQ_STATS
-            if (m) ++st_slow;
+            if (m) { ++st_slow; st_lanes += (unsigned)__popcll(m); }
 #endif
             while (m) {                                                  // (one trip unless the queue runs full)
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -801,7 +805,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
         const int fill_buf = cur_buf + NB - M >= NB ? cur_buf - M : cur_buf + NB - M;   // (a buffer of the previous group)
         const int u_next = min(ti * KS + kp + NB - M, U - 1);                 // the trip whose DMA this trip issues
         const uint32_t baddr = lds_tile0 + (uint32_t)(cur_buf * TILE_BYTES + h * 512 + x * 16);
-        if constexpr (SWP && VGQ_ABLATE < 3 && !ATEND) {
+        if constexpr (SWP && VGQ_ABLATE < 3) {
             // (the DMA issue has branches: in front of the k loop, so that the MFMAs and the previous tile's first test share ONE basic block)
             if (stat_turn) dma_stat_group(tile_first + 2 * sj, sj & (VGQ_STAT_SLOTS - 1));
             dma_share(u_next, fill_buf);
@@ -892,7 +896,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
                 st_cand += (unsigned)__popcll(__ballot((unsigned)d_e < n_take && d_I >= ithr_e)); st_pairs += (unsigned)__popcll(pm);
 #endif
             }
-            if constexpr (t == 0 && VGQ_ABLATE < 3 && !ATEND && !SWP) {
+            if constexpr (t == 0 && VGQ_ABLATE < 3 && !SWP) {
                 if (kp == 0 && stat_turn) dma_stat_group(tile_first + 2 * sj, sj & (VGQ_STAT_SLOTS - 1));
                 dma_share(u_next, fill_buf);
             }
@@ -934,21 +938,6 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
         // group end: the next group's pieces have landed (an issuing wavefront leaves the pieces of the (LOOK - 1) M youngest trips in
         // flight: loads return in order), barrier: every wavefront has read this group's buffers, the next group's are readable
         if (M == 1 || (ti * KS + kp) % M == M - 1) {
-        if constexpr (ATEND && VGQ_ABLATE < 3) {
-            // group g = ti / M is done (by this wavefront): the statistics and the pieces of group g + LOOK into the buffers of group g - 1
-            const int g_next = ti / M + LOOK;
-            while (2 * next_stat < min((g_next + 1) * M, T + 1)) {
-                if (wave == (next_stat & (NISSUE - 1))) dma_stat_group(tile_first + 2 * next_stat, next_stat & (VGQ_STAT_SLOTS - 1));
-                ++next_stat;
-            }
-            if (wave < NISSUE) {
-#pragma unroll
-                for (int j = 0; j < M; ++j) {
-                    const int v = g_next * M + j;
-                    dma_share(min(v, U - 1), v % NB);
-                }
-            }
-        }
         if (counted_wait) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LOOK - 1) * M * NPIECE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" ::: "memory");
@@ -973,7 +962,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
     };
     auto step = [&](int ti, vgq_i32x16 &n0, vgq_i32x16 &n1, const vgq_i32x16 &o0, const vgq_i32x16 &o1) __attribute__((always_inline)) {
         if constexpr (CAN_DRAIN) {
-            if (n_q) tile_step(ti, n0, n1, o0, o1, std::true_type{});
+            if (n_q >= (unsigned)VGQ_DRAIN_MIN) tile_step(ti, n0, n1, o0, o1, std::true_type{});
             else tile_step(ti, n0, n1, o0, o1, std::false_type{});
         } else tile_step(ti, n0, n1, o0, o1, std::false_type{});
     };
@@ -993,8 +982,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (no LDS-DMA of the ring may land after this workgroup's LDS is gone)
 #if VGQ_STATS
-    if (lane == 0) { atomicAdd(&vgq_stats[0], (unsigned long long)T); atomicAdd(&vgq_stats[1], (unsigned long long)st_slow);
-                     atomicAdd(&vgq_stats[2], (unsigned long long)st_cand); atomicAdd(&vgq_stats[3], (unsigned long long)st_pairs); }
+    if (lane == 0 && !PRE) {
+        const int b = 5 * (T < 16 ? 0 : (T < 64 ? 1 : (T < 256 ? 2 : (T < 448 ? 3 : (T < 1000 ? 4 : 5)))));
+        atomicAdd(&vgq_stats[b + 0], (unsigned long long)T); atomicAdd(&vgq_stats[b + 1], (unsigned long long)st_slow);
+        atomicAdd(&vgq_stats[b + 2], (unsigned long long)st_lanes); atomicAdd(&vgq_stats[b + 3], (unsigned long long)st_cand);
+        atomicAdd(&vgq_stats[b + 4], (unsigned long long)st_pairs);
+    }
 #endif
     if constexpr (PRE) {
         if (KS == 1 && M > 1 && T % M != 0) pre_store(T - T % M, T % M);
