@@ -766,11 +766,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && KS == 1 ? 2 : 1)) void v
                 if (j < count) a.premin[(tile_first + ti_first + j - a.tile_begin) * (long long)a.nq_pad + q0 + qw] = pre_keep[j];
         }
     };
-    // SOFTWARE-PIPELINED BOUNDARY (VGQ_SWP, the wide form): a wavefront owns TWO pairs of accumulator sets; tile t's MFMAs run into one pair
+    // SOFTWARE-PIPELINED BOUNDARY (VGQ_SWP, the short-row forms - 256 queries per workgroup too: 1.60 -> 1.575 / 2.07 -> 1.98 ms per 256-query batch): a wavefront owns TWO pairs of accumulator sets; tile t's MFMAs run into one pair
     // while the first test of tile t - 1 (thresholds from the row statistics, the maxima, the ballot: ~55 VALU instructions, no memory access)
     // reads the other, in the SAME instruction stream - the matrix pipe takes 32 cycles per MFMA and the issue port 4, so up to ~5 other
     // instructions fit beside every MFMA (MI355X_MICROARCH.md) instead of a block of VALU work during which this wavefront offers the pipe nothing.
-    constexpr bool SWP = VGQ_SWP != 0 && !PRE && KS == 1 && QS == 2 && WAVES == 8 && NTB <= 12;     // (16 k-steps: the second pair spills)
+    constexpr bool SWP = VGQ_SWP != 0 && !PRE && KS == 1 && QS == 2 && NTB <= 12;    // (both short-row forms: eight wavefronts x 512 queries, four x 256)     // (16 k-steps: the second pair spills)
     vgq_i32x16 acc0, acc1, accb0, accb1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; accb0[r] = 0; accb1[r] = 0; }
