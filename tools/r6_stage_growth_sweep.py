@@ -6,7 +6,7 @@ os.environ["VG_BATCH_Q8"] = "1"
 import torch
 import __graft_entry__ as g
 pkg = g.load_package()
-n, dim, nq, k = int(os.environ.get("ROWS", "10000000")), int(os.environ.get("DIM", "1536")), 1024, 20
+n, dim, nq, k = int(os.environ.get("ROWS", "10000000")), int(os.environ.get("DIM", "1536")), int(os.environ.get("NQ", "1024")), 20
 c = pkg.Corpus(pkg.F32, dim, capacity=n)
 gen = torch.Generator(device="cuda")
 blk = 500000 if dim <= 512 else 125000
