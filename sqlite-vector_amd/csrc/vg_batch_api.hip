@@ -315,6 +315,7 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
 // (round 5: from 257 queries on) over corpora the filter scans' policy covers; VG_BATCH_Q8=0 / 1 forces it off / on.
 extern "C" int vg_batch_q8_serves(long long q8stride_bytes, long long xstride_bytes, int k);
 extern "C" int vg_batch_q8_queries_per_block(void);
+extern "C" int vg_batch_q8_padded_queries(int nq, long long q8stride_bytes);
 extern "C" int vg_batch_q8_regions(int nq_pad, int npart);
 extern "C" size_t vg_batch_q8_work_bytes(int nq_pad, long long q8stride_bytes, long long xstride_bytes);
 extern "C" size_t vg_batch_q8_work_stat_offset(int nq_pad, long long q8stride_bytes, long long xstride_bytes);
@@ -381,8 +382,8 @@ static int ensure_q8_tile_major(vg_corpus *c) {
 static int scan_topk_batch_q8(vg_corpus *c, int metric, const void *queries, int nq, int k, uint64_t *out_keys, int *out_counts) {
     const long long qs = q8_shadow_stride_of(c);
     const int QPB = vg_batch_q8_queries_per_block();
-    const int nq_pad = ((nq + QPB - 1) / QPB) * QPB;
-    const int G = nq_pad / QPB;
+    const int nq_pad = vg_batch_q8_padded_queries(nq, qs);                  // (128 slots for up to 128 queries over short rows, whole 256-query workgroups otherwise)
+    const int G = std::max(1, nq_pad / QPB);
     const int npart = std::min(256, std::max(8, (vg_batch_q8_workgroups_per_cu(qs) * c->cu_count / G) / 8 * 8));       // two 4-wavefront workgroups per CU (long rows: one of 8)
     int rcn = ensure_q8_tile_major(c);
     if (rcn == -1) { c->bq8_status = 1; return -1; }

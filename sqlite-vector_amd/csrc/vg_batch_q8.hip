@@ -63,6 +63,9 @@ typedef int vgq_i32x16 __attribute__((ext_vector_type(16)));
 #endif
 #define VGQW_RING_OF(NTB) ((VGQW_RING) * (NTB) <= 112 ? (VGQW_RING) : 6)
 #define VGQ_QCAP 16                     // candidate lanes a wavefront collects before it looks at their accumulators (160 bytes each)   (= 64 lanes / 4 lanes per entry: a queue run looks at exactly that many)
+#ifndef VGQ_NARROW
+#define VGQ_NARROW 1                    // batches of up to 128 queries over short rows: the 128-slot form (0: the 256-slot form, as before)
+#endif
 #ifndef VGQ_DRAIN_MIN
 #define VGQ_DRAIN_MIN 4                 // parked lanes a wavefront waits for before a tile retires two of them
 #endif
@@ -1021,6 +1024,16 @@ template <int NTB>
 static int launch_q8_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream, bool pre) {
     return launch_q8_form_mode<NTB, VGQ_WAVES, VGQ_QS, 1>(a, blocks, smem, stream, pre);
 }
+// the NARROW form (round 6): four wavefronts x ONE query set = 128 queries per workgroup, two workgroups per CU - for batches of up to 128
+// queries.  The 256-query form multiplies 256 query slots whatever the batch holds, and with few real queries (no candidates to speak of) it
+// runs at 96 % of the matrix pipe: a 16-query batch paid for 240 padding slots (1.4-1.5 ms).  Half the slots, half the MFMAs.
+template <int NTB>
+static int launch_q8n_mode(const BatchArgsQ8 &a, int blocks, size_t smem, hipStream_t stream, bool pre) {
+    return launch_q8_form_mode<NTB, 4, 1, 1>(a, blocks, smem, stream, pre);
+}
+static size_t vgqn_lds_bytes(int NTB) {
+    return (size_t)VGQ_RING_OF(NTB) * NTB * 1024 + (size_t)VGQ_STAT_SLOTS * 1024 + (size_t)4 * 32 * 16 + (size_t)4 * 64 * 8 + (size_t)4 * VGQ_QCAP * (16 + 8) * 4;
+}
 // the WIDE form of the short-row kernel: eight wavefronts x two query sets = 512 queries per workgroup, one workgroup per CU - a tile is
 // brought in once for 512 queries instead of once per 256 (half the LDS-DMA issues and half the L2 traffic per pair), six ring buffers
 template <int NTB>
@@ -1077,6 +1090,11 @@ extern "C" int vg_batch_q8_serves(long long q8stride_bytes, long long xstride_by
 // workgroups of the filter kernel a CU holds at once (what the caller sizes the partition count by)
 extern "C" int vg_batch_q8_workgroups_per_cu(long long q8stride_bytes) { return vgq_ntb(q8stride_bytes) != 0 ? 2 : 1; }
 extern "C" int vg_batch_q8_queries_per_block(void) { return VGQ_QPB; }
+// what a batch of nq queries is padded to: short rows in the narrow form (128 query slots) up to 128 queries, whole 256-query workgroups otherwise
+extern "C" int vg_batch_q8_padded_queries(int nq, long long q8stride_bytes) {
+    if (VGQ_NARROW != 0 && nq <= 128 && vgq_ntb(q8stride_bytes) != 0) return 128;
+    return ((nq + VGQ_QPB - 1) / VGQ_QPB) * VGQ_QPB;
+}
 extern "C" int vg_batch_q8_max_queries(void) { return 4096; }         // (the rank kernel's LDS)
 extern "C" int vg_batch_q8_regions(int nq_pad, int npart) { return (nq_pad / 32) * npart; }
 // scratch behind the nq_pad query rows the caller uploads: the sorted query rows, their int8 images, statistics, sort keys + own scales +
@@ -1141,7 +1159,7 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     const int lcfg = vgql_cfg(q8stride);
     const int ntb = lcfg ? lcfg / 8 : vgq_ntb(q8stride), ks = lcfg ? lcfg % 8 : 1;
     if (type_code < 0 || type_code > 2) return -1;
-    if (!ntb || !vg_batch_q8_serves(q8stride, xstride, k) || nq_pad % VGQ_QPB != 0 || nq_pad > vg_batch_q8_max_queries() || npart < 8 || npart % 8 != 0 ||
+    if (!ntb || !vg_batch_q8_serves(q8stride, xstride, k) || (nq_pad % VGQ_QPB != 0 && !(nq_pad == 128 && !lcfg)) || nq_pad > vg_batch_q8_max_queries() || npart < 8 || npart % 8 != 0 ||
         npart > VG_SEL_MAX_HEADS) return -1;
     if (mode < VGH_DOT || mode > VGH_L2 || !dev_xnorm || !dev_pairs || !dev_pair_counts || pair_cap < 32 * 32) return -1;
     const long long ntiles = (n_rows + VGQ_TILE - 1) / VGQ_TILE;
@@ -1182,10 +1200,11 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     a.pairs = dev_pairs; a.pair_counts = dev_pair_counts; a.pair_cap = pair_cap; a.flag_index = flag_index;
     // short rows: the wide form (512 queries per workgroup) whenever the padded batch is a multiple of 512 (VG_BATCH_H_WAVES=4: the 256-query form)
     const bool wide = !lcfg && nq_pad % 512 == 0 && vg_sw(SW_VG_BATCH_H_WAVES, 8) != 4;
-    const size_t smem = lcfg ? vgql_lds_bytes(ntb) : (wide ? vgqw_lds_bytes(ntb) : vgq_lds_bytes(ntb));
+    const bool narrow = !lcfg && nq_pad == 128;
+    const size_t smem = lcfg ? vgql_lds_bytes(ntb) : (wide ? vgqw_lds_bytes(ntb) : (narrow ? vgqn_lds_bytes(ntb) : vgq_lds_bytes(ntb)));
     const bool long_exact = xstride > (type_code == 2 ? 4096 : 2048);       // rows beyond what the short exact kernel's chunks per lane cover
-    const int G = nq_pad / (wide ? 512 : VGQ_QPB);
-    const int hx_waves = wide ? 16 : VGQ_WAVES * VGQ_QS;                    // 32-query regions per query group and partition
+    const int G = narrow ? 1 : nq_pad / (wide ? 512 : VGQ_QPB);
+    const int hx_waves = wide ? 16 : (narrow ? 4 : VGQ_WAVES * VGQ_QS);                    // 32-query regions per query group and partition
     // The batch in launches: (1) the bound-only PRE-PASS over the first `pre` tiles + the selection of every query's start threshold
     // (round 6; round 5 warmed the lists up with five tiny stages - two tiles with every gate open, then x8 x8 x8 x8 - that cost a fifth of
     // the batch); (2) STAGES over growing row ranges, the first one [0, VGQ_FIRST_MULT x pre) from the pre-pass' thresholds with empty
@@ -1219,6 +1238,12 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
             if (ntb == 8) return launch_q8w_mode<8>(a, blocks, smem, stream, is_pre);
             if (ntb == 12) return launch_q8w_mode<12>(a, blocks, smem, stream, is_pre);
             return launch_q8w_mode<16>(a, blocks, smem, stream, is_pre);
+        }
+        if (narrow) {
+            if (ntb == 4) return launch_q8n_mode<4>(a, blocks, smem, stream, is_pre);
+            if (ntb == 8) return launch_q8n_mode<8>(a, blocks, smem, stream, is_pre);
+            if (ntb == 12) return launch_q8n_mode<12>(a, blocks, smem, stream, is_pre);
+            return launch_q8n_mode<16>(a, blocks, smem, stream, is_pre);
         }
         if (ntb == 4) return launch_q8_mode<4>(a, blocks, smem, stream, is_pre);
         if (ntb == 8) return launch_q8_mode<8>(a, blocks, smem, stream, is_pre);
