@@ -319,3 +319,36 @@ def test_int8_filter_adversarial_rows_against_the_oracle(pkg, orc, monkeypatch):
             assert ids[0][0] == 12 and ids[1][0] == n, (ids[0][:3], ids[1][:3])    # the planted duplicates are every such query's best row
     monkeypatch.delenv("VG_BATCH_Q8")
     c.close()
+
+@pytest.mark.parametrize("nq", (3, 64, 128))
+def test_int8_filter_128_slot_form(pkg, nq, monkeypatch):
+    """batches of up to 128 queries over short rows take the 128-slot form (four wavefronts x one query set, vg_batch_q8.hip): rowids, distance
+    bits and counts of the bf16 filter batch, three metrics, two row lengths; 129 queries are back on the 256-slot form with the same answers"""
+    k = 20
+    for dim in (100, 384):
+        rng = np.random.default_rng(9100 + dim + nq)
+        n = 90_001
+        rows = rng.standard_normal((n, dim), dtype=np.float32)
+        rows[77] = rows[5]                                          # a duplicate: ties by position
+        c = pkg.Corpus(pkg.F32, dim)
+        c.append(rows)
+        for nqq in (nq, nq + 1 if nq == 128 else nq):
+            qs = rng.standard_normal((nqq, dim), dtype=np.float32)
+            qs[0] = rows[5]
+            for metric in (dg.DOT, dg.COSINE, dg.L2):
+                monkeypatch.setenv("VG_BATCH_Q8", "1")
+                ids, dist, cnt = c.scan_topk_batch(metric, qs, k)
+                assert c.last_batch_path() == 7, (dim, nqq, metric, c.last_batch_path(), c.batch_q8_status())
+                monkeypatch.setenv("VG_BATCH_Q8", "0")
+                monkeypatch.setenv("VG_F32_FILTER", "1")
+                ids0, dist0, cnt0 = c.scan_topk_batch(metric, qs, k)
+                assert c.last_batch_path() == 3
+                monkeypatch.delenv("VG_F32_FILTER")
+                assert np.array_equal(cnt, cnt0), (dim, nqq, metric)
+                for i in range(nqq):
+                    m = cnt[i]
+                    assert m == k and ids[i][:m].tolist() == ids0[i][:m].tolist() and dg.same_float_bits(dist[i][:m], dist0[i][:m]), (dim, nqq, metric, i)
+                if metric != dg.DOT:
+                    assert ids[0][:2].tolist() == [6, 78], ids[0][:3]       # the row itself, then its duplicate (the later position loses the tie)
+        monkeypatch.delenv("VG_BATCH_Q8")
+        c.close()
