@@ -394,7 +394,8 @@ def make_summary(out):
         "c5_default_int8_filter": {"ms_per_step": g(c5, "int8_filter_batch", "ms_per_step"), "frac_of_int8_peak": g(c5, "int8_filter_batch", "frac_of_int8_peak"),
                                    "batch_path": g(c5, "int8_filter_batch", "batch_path"), "hbm_traffic_bytes_per_batch": g(c5, "int8_filter_batch", "traffic"),
                                    "bit_identical_to_bf16_filter": g(c5, "int8_filter_batch", "last_batch_bit_identical_to_the_bf16_filter"),
-                                   "max_rel_vs_reference_kernel": g(c5, "int8_filter_batch", "last_batch_max_rel_difference_from_the_reference_kernel")},
+                                   "max_rel_vs_reference_kernel": g(c5, "int8_filter_batch", "last_batch_max_rel_difference_from_the_reference_kernel"),
+                                   "small_batches_ms_per_batch": g(c5, "int8_filter_batch", "small_batches_ms_per_batch")},
         "long_rows_1536": {"ms_per_step": g(a, "long_rows", "ms_per_step"), "frac": g(a, "long_rows", "roofline", "frac"),
                            "of": "int8 peak" if g(a, "long_rows", "roofline", "batch_path") == 7 else "bf16 peak",
                            "batch_path": g(a, "long_rows", "roofline", "batch_path"), "hbm_traffic_bytes_per_batch": g(a, "long_rows", "roofline", "traffic"),

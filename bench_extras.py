@@ -656,6 +656,21 @@ def also_c5(args, pkg, torch, corpus, n_rows, k):
                     ib["reference_check"] = "%d queries x %d returned rows, reference distance-avx2.c dot on the same rows (oracle/_ref/libref_avx2.so)" % (len(pick), k)
             except Exception as e:
                 ib["reference_check"] = "unavailable: %r" % (e,)
+            # serving-size batches through the same default path (wall clock per batch, 4 timed batches each): up to 128 queries take the
+            # 128-slot form of the filter kernel, 256 the 256-slot form
+            try:
+                small = {}
+                for nq_s in (4, 16, 128, 256):
+                    qsm = batch_queries(v5, nq_s, d5, which=0)
+                    for _ in range(2):
+                        corpus.scan_topk_batch(m5, qsm, k)
+                    t0 = time.perf_counter()
+                    for _ in range(4):
+                        corpus.scan_topk_batch(m5, qsm, k)
+                    small[str(nq_s)] = round((time.perf_counter() - t0) / 4 * 1e3, 4)
+                ib["small_batches_ms_per_batch"] = small
+            except Exception as e:
+                ib["small_batches_ms_per_batch"] = {"error": repr(e)}
             line["int8_filter_batch"] = ib
         except Exception as e:
             line["int8_filter_batch"] = {"error": repr(e)}
