@@ -316,6 +316,7 @@ static int scan_topk_batch_long(vg_corpus *c, int metric, const void *queries, i
 extern "C" int vg_batch_q8_serves(long long q8stride_bytes, long long xstride_bytes, int k);
 extern "C" int vg_batch_q8_queries_per_block(void);
 extern "C" int vg_batch_q8_padded_queries(int nq, long long q8stride_bytes);
+extern "C" int vg_batch_q8_max_partitions(void);
 extern "C" int vg_batch_q8_regions(int nq_pad, int npart);
 extern "C" size_t vg_batch_q8_work_bytes(int nq_pad, long long q8stride_bytes, long long xstride_bytes);
 extern "C" size_t vg_batch_q8_work_stat_offset(int nq_pad, long long q8stride_bytes, long long xstride_bytes);
@@ -384,7 +385,9 @@ static int scan_topk_batch_q8(vg_corpus *c, int metric, const void *queries, int
     const int QPB = vg_batch_q8_queries_per_block();
     const int nq_pad = vg_batch_q8_padded_queries(nq, qs);                  // (128 slots for up to 128 queries over short rows, whole 256-query workgroups otherwise)
     const int G = std::max(1, nq_pad / QPB);
-    const int npart = std::min(256, std::max(8, (vg_batch_q8_workgroups_per_cu(qs) * c->cu_count / G) / 8 * 8));       // two 4-wavefront workgroups per CU (long rows: one of 8)
+    // two 4-wavefront workgroups per CU (long rows: one of 8); the 128-slot form has ONE query group: 512 partitions fill both workgroup slots of
+    // every CU (the stages' merges see np / 4 lists per query)
+    const int npart = std::min(nq_pad == 128 ? vg_batch_q8_max_partitions() : 256, std::max(8, (vg_batch_q8_workgroups_per_cu(qs) * c->cu_count / G) / 8 * 8));
     int rcn = ensure_q8_tile_major(c);
     if (rcn == -1) { c->bq8_status = 1; return -1; }
     if (rcn != VG_OK) return rcn;

@@ -63,6 +63,9 @@ typedef int vgq_i32x16 __attribute__((ext_vector_type(16)));
 #endif
 #define VGQW_RING_OF(NTB) ((VGQW_RING) * (NTB) <= 112 ? (VGQW_RING) : 6)
 #define VGQ_QCAP 16                     // candidate lanes a wavefront collects before it looks at their accumulators (160 bytes each)   (= 64 lanes / 4 lanes per entry: a queue run looks at exactly that many)
+#ifndef VGQ_NARROW_PARTS
+#define VGQ_NARROW_PARTS 512            // partitions of the 128-slot form (one query group: 512 workgroups = two per CU)
+#endif
 #ifndef VGQ_NARROW
 #define VGQ_NARROW 1                    // batches of up to 128 queries over short rows: the 128-slot form (0: the 256-slot form, as before)
 #endif
@@ -1091,6 +1094,7 @@ extern "C" int vg_batch_q8_serves(long long q8stride_bytes, long long xstride_by
 extern "C" int vg_batch_q8_workgroups_per_cu(long long q8stride_bytes) { return vgq_ntb(q8stride_bytes) != 0 ? 2 : 1; }
 extern "C" int vg_batch_q8_queries_per_block(void) { return VGQ_QPB; }
 // what a batch of nq queries is padded to: short rows in the narrow form (128 query slots) up to 128 queries, whole 256-query workgroups otherwise
+extern "C" int vg_batch_q8_max_partitions(void) { return VGQ_NARROW_PARTS; }        // (the 128-slot form; every other form: VG_SEL_MAX_HEADS)
 extern "C" int vg_batch_q8_padded_queries(int nq, long long q8stride_bytes) {
     if (VGQ_NARROW != 0 && nq <= 128 && vgq_ntb(q8stride_bytes) != 0) return 128;
     return ((nq + VGQ_QPB - 1) / VGQ_QPB) * VGQ_QPB;
@@ -1160,7 +1164,7 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     const int ntb = lcfg ? lcfg / 8 : vgq_ntb(q8stride), ks = lcfg ? lcfg % 8 : 1;
     if (type_code < 0 || type_code > 2) return -1;
     if (!ntb || !vg_batch_q8_serves(q8stride, xstride, k) || (nq_pad % VGQ_QPB != 0 && !(nq_pad == 128 && !lcfg)) || nq_pad > vg_batch_q8_max_queries() || npart < 8 || npart % 8 != 0 ||
-        npart > VG_SEL_MAX_HEADS) return -1;
+        npart > ((nq_pad == 128 && !lcfg) ? VGQ_NARROW_PARTS : VG_SEL_MAX_HEADS)) return -1;
     if (mode < VGH_DOT || mode > VGH_L2 || !dev_xnorm || !dev_pairs || !dev_pair_counts || pair_cap < 32 * 32) return -1;
     const long long ntiles = (n_rows + VGQ_TILE - 1) / VGQ_TILE;
     if (ntiles < 2048) return -1;                                     // small corpora: the lists warm up inside a fused kernel instead
@@ -1218,7 +1222,8 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     {
         const int sw_growth = vg_sw(SW_VG_BATCH_STAGES, 0);
         // (long rows: an exact evaluation reads up to 6 KB - tighter thresholds pay for a few more launches: x1.5; 20.8 -> 20.0 ms at 10M x 1536)
-        const int late_growth = sw_growth > 100 ? sw_growth : (lcfg ? 150 : 200);
+        // (the 128-slot form: x4 to the end - a stage's launches weigh more than the pairs of so few queries: 1.17 -> 1.14 ms at 16 queries)
+        const int late_growth = sw_growth > 100 ? sw_growth : (lcfg ? 150 : ((!lcfg && nq_pad == 128) ? 400 : 200));
         bounds[0] = 0;
         long long b = pre * (lcfg ? 1 : VGQ_FIRST_MULT);
         while (b < ntiles && nstages + 2 < 24 && ntiles - b > b / 4) {      // (no sliver at the end)
@@ -1273,7 +1278,7 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
         hx.init_keys = a.init_keys; hx.seed = (s > 0) ? 1 : 0;             // (stage 0 starts with empty lists: the thresholds stand for no list entries)
         // one exact-evaluation block per 32 queries and pg consecutive partitions: 16 .. 31 lists per query reach the merge instead of up to 128
         int pg = (np % 8 == 0 && np / 8 >= 16) ? 8 : ((np % 4 == 0 && np / 4 >= 16) ? 4 : ((np % 2 == 0 && np / 2 >= 16) ? 2 : 1));
-        if (pg > VGQ_HX_GROUP) pg = VGQ_HX_GROUP;
+        if (pg > (narrow ? 8 : VGQ_HX_GROUP)) pg = narrow ? 8 : VGQ_HX_GROUP;   // (the 128-slot form's 512 partitions: 64 lists per query; its walks are short)
         if (s == 0 && VGQ_HX_GROUP_FIRST) pg = 1;                           // (the first stage has several hundred pairs per query: its walks are long enough)
         hx.part_group = pg;
         const int hx_blocks = hx.n_regions / pg, lists = np / pg;
