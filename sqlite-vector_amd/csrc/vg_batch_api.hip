@@ -387,7 +387,7 @@ static int scan_topk_batch_q8(vg_corpus *c, int metric, const void *queries, int
     const int G = std::max(1, nq_pad / QPB);
     // two 4-wavefront workgroups per CU (long rows: one of 8); the 128-slot form has ONE query group: 512 partitions fill both workgroup slots of
     // every CU (the stages' merges see np / 4 lists per query)
-    const int npart = std::min(nq_pad == 128 ? vg_batch_q8_max_partitions() : 256, std::max(8, (vg_batch_q8_workgroups_per_cu(qs) * c->cu_count / G) / 8 * 8));
+    const int npart = std::min((nq_pad <= 256 && vg_batch_q8_workgroups_per_cu(qs) == 2) ? vg_batch_q8_max_partitions() : 256, std::max(8, (vg_batch_q8_workgroups_per_cu(qs) * c->cu_count / G) / 8 * 8));
     int rcn = ensure_q8_tile_major(c);
     if (rcn == -1) { c->bq8_status = 1; return -1; }
     if (rcn != VG_OK) return rcn;

@@ -1164,7 +1164,7 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
     const int ntb = lcfg ? lcfg / 8 : vgq_ntb(q8stride), ks = lcfg ? lcfg % 8 : 1;
     if (type_code < 0 || type_code > 2) return -1;
     if (!ntb || !vg_batch_q8_serves(q8stride, xstride, k) || (nq_pad % VGQ_QPB != 0 && !(nq_pad == 128 && !lcfg)) || nq_pad > vg_batch_q8_max_queries() || npart < 8 || npart % 8 != 0 ||
-        npart > ((nq_pad == 128 && !lcfg) ? VGQ_NARROW_PARTS : VG_SEL_MAX_HEADS)) return -1;
+        npart > ((nq_pad <= 256 && !lcfg) ? VGQ_NARROW_PARTS : VG_SEL_MAX_HEADS)) return -1;
     if (mode < VGH_DOT || mode > VGH_L2 || !dev_xnorm || !dev_pairs || !dev_pair_counts || pair_cap < 32 * 32) return -1;
     const long long ntiles = (n_rows + VGQ_TILE - 1) / VGQ_TILE;
     if (ntiles < 2048) return -1;                                     // small corpora: the lists warm up inside a fused kernel instead
@@ -1278,7 +1278,7 @@ extern "C" int vg_batch_q8_launch(const uint8_t *dev_rows_tm, const void *dev_rs
         hx.init_keys = a.init_keys; hx.seed = (s > 0) ? 1 : 0;             // (stage 0 starts with empty lists: the thresholds stand for no list entries)
         // one exact-evaluation block per 32 queries and pg consecutive partitions: 16 .. 31 lists per query reach the merge instead of up to 128
         int pg = (np % 8 == 0 && np / 8 >= 16) ? 8 : ((np % 4 == 0 && np / 4 >= 16) ? 4 : ((np % 2 == 0 && np / 2 >= 16) ? 2 : 1));
-        if (pg > (narrow ? 8 : VGQ_HX_GROUP)) pg = narrow ? 8 : VGQ_HX_GROUP;   // (the 128-slot form's 512 partitions: 64 lists per query; its walks are short)
+        if (pg > ((narrow || np > 256) ? 8 : VGQ_HX_GROUP)) pg = (narrow || np > 256) ? 8 : VGQ_HX_GROUP;   // (the 128-slot form's 512 partitions: 64 lists per query; its walks are short)
         if (s == 0 && VGQ_HX_GROUP_FIRST) pg = 1;                           // (the first stage has several hundred pairs per query: its walks are long enough)
         hx.part_group = pg;
         const int hx_blocks = hx.n_regions / pg, lists = np / pg;
